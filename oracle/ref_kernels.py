@@ -1,0 +1,79 @@
+"""TEST INFRASTRUCTURE ONLY.  ctypes front-end for the compiled-reference objects of oracle/build_ref.py.
+
+Call conventions mirror the reference's kernel factories
+(reference kernels/custom_kernels.py:125-146, 280-296, 348, 392, 452 and custom_semantic_kernels.py).
+All arrays are C-contiguous numpy arrays of the dtype the reference uses (float32 unless noted);
+execution is sequential in element order -- one legal interleaving of the racy GPU kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from . import build_ref
+
+_F = np.float32
+
+
+def _ptr(a):
+    assert a.flags["C_CONTIGUOUS"], "ref kernels need C-contiguous arrays"
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class RefKernels:
+    """One compiled parameter set of the reference kernels."""
+
+    def __init__(self, params, build=True):
+        self.params = dict(params)
+        path = build_ref.build(self.params) if build else build_ref.so_path(self.params)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = ctypes.CDLL(path)
+        self.C = int(params["cell_n"])
+
+    def _call(self, name, arrays, size):
+        fn = getattr(self.lib, "ref_" + name)
+        fn.restype = None
+        fn(*[_ptr(a) for a in arrays], ctypes.c_long(int(size)))
+
+    # --- core kernels -------------------------------------------------------------------------
+    def error_counting(self, emap, p, R, t, newmap, error, error_cnt, center=(0.0, 0.0)):
+        cx, cy = np.array([center[0]], _F), np.array([center[1]], _F)
+        self._call("error_counting", [emap, p, cx, cy, R, t, newmap, error, error_cnt], p.shape[0])
+
+    def add_points(self, R, t, norm_map, p, emap, newmap, center=(0.0, 0.0)):
+        cx, cy = np.array([center[0]], _F), np.array([center[1]], _F)
+        self._call("add_points", [cx, cy, R, t, norm_map, p, emap, newmap], p.shape[0])
+
+    def average_map(self, newmap, emap):
+        self._call("average_map", [newmap, emap], self.C * self.C)
+
+    def dilation_filter(self, plane, mask, out, out_mask, size=None):
+        name = "dilation_filter" if size is None else "dilation_filter_%d" % size
+        self._call(name, [plane, mask, out, out_mask], self.C * self.C)
+
+    def normal_filter(self, plane, mask, out):
+        self._call("normal_filter", [plane, mask, out], self.C * self.C)
+
+    # --- semantic kernels (reference custom_semantic_kernels.py) ---------------------------------
+    def sem_sum(self, p, R, t, pcl_chan, map_lay, pcl_channels, smap, newmap, size):
+        self._call("sem_sum", [p, R, t, pcl_chan, map_lay, pcl_channels, smap, newmap], size)
+
+    def sem_average(self, newmap, pcl_chan, map_lay, pcl_channels, new_elmap, smap, size):
+        self._call("sem_average", [newmap, pcl_chan, map_lay, pcl_channels, new_elmap, smap], size)
+
+    def sem_class_average(self, newmap, pcl_chan, map_lay, pcl_channels, new_elmap, smap, size):
+        self._call("sem_class_average", [newmap, pcl_chan, map_lay, pcl_channels, new_elmap, smap], size)
+
+    def sem_add_color(self, p, R, t, pcl_chan, map_lay, pcl_channels, color_map, size):
+        self._call("sem_add_color", [p, R, t, pcl_chan, map_lay, pcl_channels, color_map], size)
+
+    def sem_color_average(self, color_map, pcl_chan, map_lay, pcl_channels, smap, size):
+        self._call("sem_color_average", [color_map, pcl_chan, map_lay, pcl_channels, smap], size)
+
+
+def available(params):
+    """True when the object for ``params`` is prebuilt or can be built here."""
+    return os.path.exists(build_ref.so_path(params)) or os.path.isdir(build_ref.REF_ROOT)
