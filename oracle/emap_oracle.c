@@ -1,0 +1,427 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU oracle; never linked into or called from the product path.
+ *
+ * Plain-C restatement of the per-frame hot path of leggedrobotics/elevation_mapping_cupy
+ * (ElevationMap.update_map_with_kernel, reference elevation_mapping.py:316-391) with the DETERMINISTIC
+ * TWO-PHASE CONTRACT documented in DESIGN.md ("Determinism contract"): the reference kernels race with
+ * themselves (custom_kernels.py:170-192, 213-256); this file defines the one outcome the HIP kernels
+ * must reproduce:
+ *   A  count    (error_counting_kernel, custom_kernels.py:280-345)  reads the map of the previous frame
+ *   A' gate     (elevation_mapping.py:346-357)                       host scalar logic
+ *   B  fuse     (add_points_kernel fusion part, :160-197)            reads snapshot S0, writes accumulators only
+ *   B' commit   (effects of :174, :189-192)                          per cell -> snapshot S1
+ *   C  rays     (add_points_kernel visibility part, :198-259)        reads S1, writes accumulators only
+ *   D  average  (average_map_kernel :348-389 + ray commit)           per cell
+ *   then overlap clearance (elevation_mapping.py:393-410), dilation (:392-449), traversability
+ *   (traversability_filter.py:8-47), normals (:452-506), update_variance / update_time (:420-426).
+ * Arithmetic follows the reference expression by expression, including the CuPy `float16` helper-parameter
+ * rounding (mode 0 = reference_fp16); mode 1 = fp32 is the same source with float16 := float.
+ * Pinned by: oracle/ref_kernels (the reference source compiled for the host) on race-free fixtures and
+ * order-independent outputs, see tests/test_oracle_vs_reference_source.py, and tests/golden/.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC  (see oracle/emap_oracle.py).
+ * Map layout here is the reference's planar (7, C, C) float32; plane order
+ * elevation, variance, is_valid, traversability, time, upper_bound, is_upper_bound (elevation_mapping.py:68-77).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+  int32_t cell_n, mode;
+  int32_t enable_edge_sharpen, enable_visibility_cleanup, enable_drift_compensation, enable_overlap_clearance;
+  int32_t dilation_size, pad_;
+  double resolution, sensor_noise_factor, mahalanobis_thresh, outlier_variance;
+  double drift_compensation_variance_inlier, traversability_inlier, wall_num_thresh, max_ray_length;
+  double cleanup_step, cleanup_cos_thresh, min_valid_distance, max_height_range;
+  double ramped_height_range_a, ramped_height_range_b, ramped_height_range_c, max_variance;
+  double initial_variance, time_variance, time_interval, min_height_drift_cnt;
+  double max_drift, drift_compensation_alpha, position_noise_thresh, orientation_noise_thresh;
+  double overlap_clear_range_xy, overlap_clear_range_z, ray_step, reserved_;
+  float w1[36], w2[36], w3[36], w_out[12];
+} eo_params;
+
+/* ---- IEEE binary16 <-> binary32, round-to-nearest-even (what CuPy's float16(float) ctor does) ---- */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+uint16_t eo_f32_to_f16(float f) {
+  uint32_t x = f2u(f), sign = (x >> 16) & 0x8000u, ax = x & 0x7fffffffu;
+  if (ax >= 0x7f800000u) return (uint16_t)(sign | (ax > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);            /* >= 65520 rounds to inf */
+  if (ax < 0x33000001u) return (uint16_t)sign;                           /* <= 2^-25 rounds to 0 */
+  int e = (int)(ax >> 23) - 127;
+  uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+  int shift = (e < -14) ? (13 + (-14 - e)) : 13;                         /* subnormal: extra shift */
+  uint32_t r = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (r & 1))) r++;
+  uint32_t h = (e < -14) ? r : ((uint32_t)(e + 15) << 10) + (r - 0x400u); /* carry propagates into exponent */
+  return (uint16_t)(sign | h);
+}
+float eo_f16_to_f32(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ffu;
+  if (e == 0) { if (!m) return u2f(sign); float v = (float)m * 5.9604644775390625e-08f; return sign ? -v : v; }
+  if (e == 31) return u2f(sign | 0x7f800000u | (m << 13));
+  return u2f(sign | ((e + 112) << 23) | (m << 13));
+}
+#define Q(x) (P->mode == 0 ? eo_f16_to_f32(eo_f32_to_f16(x)) : (x))
+
+static inline int sat_int(double v) {           /* CUDA float->int conversion saturates, NaN -> 0 */
+  if (!(v == v)) return 0;
+  if (v >= 2147483647.0) return 2147483647;
+  if (v <= -2147483648.0) return (int)0x80000000;
+  return (int)v;
+}
+/* map_utils.transform_p (custom_kernels.py:54-57): all seven arguments are float16 parameters */
+static inline float transform_p(const eo_params* P, float x, float y, float z, float r0, float r1, float r2, float t) {
+  return Q(r0) * Q(x) + Q(r1) * Q(y) + Q(r2) * Q(z) + Q(t);
+}
+/* get_x_idx / get_y_idx + clamp (custom_kernels.py:22-33, 45-49) */
+static inline int axis_idx(const eo_params* P, float x, float c) {
+  const int W = P->cell_n;
+  float d = Q(x) - Q(c);
+  int i = sat_int((double)d / P->resolution + 0.5 * W);
+  float fi = Q((float)i), lo = Q(0.0f), hi = Q((float)(W - 1));
+  float r = fmaxf(fminf(fi, hi), lo);
+  return (int)r;
+}
+static inline int get_idx(const eo_params* P, float x, float y, float cx, float cy) {
+  return P->cell_n * axis_idx(P, x, cx) + axis_idx(P, y, cy);
+}
+static inline int is_inside(const eo_params* P, int idx) { /* custom_kernels.py:34-44 */
+  const int W = P->cell_n;
+  int ix = idx / W, iy = idx % W;
+  return !(ix == 0 || ix == W - 1 || iy == 0 || iy == W - 1);
+}
+static inline float z_noise(const eo_params* P, float z) { /* :58-60 */
+  double zz = (double)Q(z);
+  return (float)(P->sensor_noise_factor * zz * zz);
+}
+static inline int is_valid(const eo_params* P, float x_, float y_, float z_, float sx_, float sy_, float sz_) { /* :62-81 */
+  float x = Q(x_), y = Q(y_), z = Q(z_), sx = Q(sx_), sy = Q(sy_), sz = Q(sz_);
+  float d = (x - sx) * (x - sx) + (y - sy) * (y - sy) + (z - sz) * (z - sz);
+  float dxy = (float)fmax((double)sqrtf(x * x + y * y) - P->ramped_height_range_b, 0.0);
+  if ((double)d < P->min_valid_distance * P->min_valid_distance) return 0;
+  if ((double)(z - sz) > (double)dxy * P->ramped_height_range_a + P->ramped_height_range_c ||
+      (double)(z - sz) > P->max_height_range) return 0;
+  return 1;
+}
+
+typedef struct { float x, y, z, v; int idx, valid, inside, finite; } pt_t;
+
+static inline pt_t point_geometry(const eo_params* P, const float* p, const float* R, const float* t) {
+  pt_t o; memset(&o, 0, sizeof o);
+  float rx = p[0], ry = p[1], rz = p[2];
+  o.finite = !(isnan(rx) || isnan(ry) || isnan(rz)); /* rows with NaN are dropped: elevation_mapping.py:458 */
+  if (!o.finite) { o.idx = -1; return o; }
+  o.x = transform_p(P, rx, ry, rz, R[0], R[1], R[2], t[0]);
+  o.y = transform_p(P, rx, ry, rz, R[3], R[4], R[5], t[1]);
+  o.z = transform_p(P, rx, ry, rz, R[6], R[7], R[8], t[2]);
+  o.v = z_noise(P, rz);
+  o.idx = get_idx(P, o.x, o.y, 0.0f, 0.0f);  /* kernels always receive center 0 (elevation_mapping.py:337-338) */
+  o.valid = is_valid(P, o.x, o.y, o.z, t[0], t[1], t[2]);
+  o.inside = is_inside(P, o.idx);
+  return o;
+}
+
+/* tail of add_points_kernel (custom_kernels.py:260-262), exported for the bit-exact index tests */
+void eo_point_index(const eo_params* P, const float* pts, long n, long stride, const float* R, const float* t,
+                    int32_t* idx, uint8_t* valid, uint8_t* inside) {
+  for (long i = 0; i < n; ++i) {
+    pt_t g = point_geometry(P, pts + i * stride, R, t);
+    idx[i] = g.idx; valid[i] = (uint8_t)g.valid; inside[i] = (uint8_t)g.inside;
+  }
+}
+
+/* Phase A: error_counting_kernel (custom_kernels.py:280-345). err_sum is accumulated exactly (double). */
+void eo_count(const eo_params* P, const float* map, const float* pts, long n, long stride, const float* R,
+              const float* t, uint32_t* n_pts, uint32_t* n_inl, double* err_sum, uint32_t* err_cnt) {
+  const long L = (long)P->cell_n * P->cell_n;
+  for (long i = 0; i < n; ++i) {
+    pt_t g = point_geometry(P, pts + i * stride, R, t);
+    if (!g.finite || !g.valid || !g.inside) continue;
+    float h = map[g.idx], v = map[L + g.idx], valid = map[2 * L + g.idx], trav = map[3 * L + g.idx];
+    if (valid > 0.5f && (double)fabsf(h - g.z) < (double)v * P->mahalanobis_thresh &&
+        (double)v < P->drift_compensation_variance_inlier / 2.0 && (double)trav > P->traversability_inlier) {
+      *err_sum += (double)(g.z - h);
+      *err_cnt += 1;
+      n_inl[g.idx] += 1;
+    }
+    n_pts[g.idx] += 1;
+  }
+}
+
+/* Phase A': drift gate (elevation_mapping.py:346-357). Returns the shift to add to plane 0 (0 if none);
+ * *mean_out receives mean_error when the gate fired (else unchanged), *fired says whether it did. */
+float eo_gate(const eo_params* P, double err_sum, uint32_t err_cnt, double position_noise, double orientation_noise,
+              float* mean_out, int* fired) {
+  *fired = 0;
+  float cnt = (float)err_cnt;
+  if (P->enable_drift_compensation && (double)cnt > P->min_height_drift_cnt &&
+      (position_noise > P->position_noise_thresh || orientation_noise > P->orientation_noise_thresh)) {
+    float mean = (float)err_sum / cnt;
+    *mean_out = mean; *fired = 1;
+    if ((double)fabsf(mean) < P->max_drift) return mean * (float)P->drift_compensation_alpha;
+  }
+  return 0.0f;
+}
+
+/* Phase B: fusion part of add_points_kernel (custom_kernels.py:160-197) against snapshot S0 = `map`
+ * (drift shift already applied). Accumulators only; `latest_h` = new_h of the accepted point with the
+ * largest input index (sequential last-writer of :191). */
+void eo_fuse(const eo_params* P, const float* map, const float* pts, long n, long stride, const float* R,
+             const float* t, const uint32_t* n_pts, double* sum_h, double* sum_v, uint32_t* cnt, uint32_t* n_out,
+             float* latest_h) {
+  const long L = (long)P->cell_n * P->cell_n;
+  for (long i = 0; i < n; ++i) {
+    pt_t g = point_geometry(P, pts + i * stride, R, t);
+    if (!g.finite || !g.valid || !g.inside) continue;
+    float map_h = map[g.idx], map_v = map[L + g.idx], num_points = (float)n_pts[g.idx];
+    if ((double)fabsf(map_h - g.z) > (double)map_v * P->mahalanobis_thresh) { n_out[g.idx] += 1; continue; }
+    if (P->enable_edge_sharpen && (double)num_points > P->wall_num_thresh &&
+        (double)g.z < (double)map_h - (double)map_v * P->mahalanobis_thresh / (double)num_points) continue;
+    float new_h = (map_h * g.v + g.z * map_v) / (map_v + g.v);
+    float new_v = (map_v * g.v) / (map_v + g.v);
+    sum_h[g.idx] += (double)new_h; sum_v[g.idx] += (double)new_v; cnt[g.idx] += 1;
+    latest_h[g.idx] = new_h;
+  }
+}
+
+/* Phase B': per-cell commit of the fuse side effects -> snapshot S1 */
+void eo_commit(const eo_params* P, float* map, const uint32_t* cnt, const uint32_t* n_out, const float* latest_h) {
+  const long L = (long)P->cell_n * P->cell_n;
+  const float ov = (float)P->outlier_variance;
+  for (long c = 0; c < L; ++c) {
+    if (n_out[c]) map[L + c] = map[L + c] + ov * (float)n_out[c];
+    if (cnt[c]) { map[2 * L + c] = 1.0f; map[4 * L + c] = 0.0f; map[5 * L + c] = latest_h[c]; map[6 * L + c] = 0.0f; }
+  }
+}
+
+/* Phase C: visibility-cleanup part of add_points_kernel (custom_kernels.py:198-259) against snapshot S1.
+ * Outputs (accumulators, applied by eo_average): ray_dec = sum of validity decrements (exact, double),
+ * ray_hits = number of penetrations, ray_upper = min qualifying nz (init +INF). */
+void eo_rays(const eo_params* P, const float* map, const float* normal, const uint32_t* n_inl, const float* pts,
+             long n, long stride, const float* R, const float* t, double* ray_dec, uint32_t* ray_hits,
+             float* ray_upper, uint64_t* visits_out) {
+  const long L = (long)P->cell_n * P->cell_n;
+  uint64_t visits = 0;
+  for (long i = 0; i < n; ++i) {
+    pt_t g = point_geometry(P, pts + i * stride, R, t);
+    if (!g.finite || !g.valid) continue; /* invalid points march but never act (:226) */
+    /* ray_vector(t, p) :83-101 -- every quantity below is a float16 variable in the reference */
+    float tx = Q(t[0]), ty = Q(t[1]), tz = Q(t[2]), px = Q(g.x), py = Q(g.y), pz = Q(g.z);
+    float vx = Q(px - tx), vy = Q(py - ty), vz = Q(pz - tz);
+    float norm = Q(sqrtf(vx * vx + vy * vy + vz * vz));
+    float rx = 0, ry = 0, rz = 0;
+    if (norm > 0) { rx = Q(vx / norm); ry = Q(vy / norm); rz = Q(vz / norm); }
+    float ray_length = Q(fminf(norm, Q((float)P->max_ray_length)));
+    int last = -1;
+    for (float s = Q((float)P->ray_step); s < ray_length; s = Q((float)((double)s + P->ray_step))) {
+      float nx = t[0] + rx * s, ny = t[1] + ry * s, nz = t[2] + rz * s;
+      int nidx = get_idx(P, nx, ny, 0.0f, 0.0f);
+      if (nidx == last) continue;
+      last = nidx;
+      if (!is_inside(P, nidx)) continue;
+      visits++;
+      float h = map[nidx], v = map[L + nidx], valid = map[2 * L + nidx], time = map[4 * L + nidx];
+      float upper = map[5 * L + nidx], is_upper = map[6 * L + nidx];
+      float d = Q((g.x - nx) * (g.x - nx) + (g.y - ny) * (g.y - ny) + (g.z - nz) * (g.z - nz));
+      if ((double)d < 0.1) continue;
+      if (valid < 0.5f) {
+        if (nz < upper || is_upper < 0.5f) { if (nz < ray_upper[nidx]) ray_upper[nidx] = nz; }
+        continue;
+      }
+      if (time < 0.5f) continue;
+      if ((double)h > (double)nz + 0.01 - fmin((double)v, 1.0) * 0.05) {
+        float ip = Q(rx) * Q(normal[nidx]) + Q(ry) * Q(normal[L + nidx]) + Q(rz) * Q(normal[2 * L + nidx]);
+        if ((double)fabsf(ip) < P->cleanup_cos_thresh) continue;
+        if ((double)(float)n_inl[nidx] > P->wall_num_thresh && (double)time < 1.0) continue;
+        ray_dec[nidx] += (double)(float)(-P->cleanup_step / ((double)ray_length / P->max_ray_length));
+        ray_hits[nidx] += 1;
+        if (nz < upper || is_upper < 0.5f) { if (nz < ray_upper[nidx]) ray_upper[nidx] = nz; }
+      }
+    }
+  }
+  if (visits_out) *visits_out = visits;
+}
+
+/* Phase D: ray commit + average_map_kernel (custom_kernels.py:348-389) */
+void eo_average(const eo_params* P, float* map, const double* sum_h, const double* sum_v, const uint32_t* cnt,
+                const double* ray_dec, const uint32_t* ray_hits, const float* ray_upper) {
+  const long L = (long)P->cell_n * P->cell_n;
+  const float ov = (float)P->outlier_variance;
+  for (long c = 0; c < L; ++c) {
+    if (ray_hits && ray_hits[c]) {
+      map[2 * L + c] = map[2 * L + c] + (float)ray_dec[c];
+      map[L + c] = map[L + c] + ov * (float)ray_hits[c];
+    }
+    if (ray_upper && ray_upper[c] < INFINITY) { map[5 * L + c] = ray_upper[c]; map[6 * L + c] = 1.0f; }
+    float valid0 = map[2 * L + c];
+    if (cnt[c] > 0) {
+      float fc = (float)cnt[c];
+      float nh = (float)(sum_h[c] / (double)cnt[c]), nv = (float)(sum_v[c] / (double)cnt[c]);
+      (void)fc;
+      if ((double)nv > P->max_variance) { map[c] = 0; map[L + c] = (float)P->initial_variance; map[2 * L + c] = 0; }
+      else { map[c] = nh; map[L + c] = nv; map[2 * L + c] = 1; }
+    }
+    if (valid0 < 0.5f) { map[c] = 0; map[L + c] = (float)P->initial_variance; map[2 * L + c] = 0; }
+  }
+}
+
+/* clear_overlap_map (elevation_mapping.py:393-410; window from :88-91) */
+void eo_overlap_clear(const eo_params* P, float* map, float tz) {
+  const int C = P->cell_n; const long L = (long)C * C;
+  int cell_range = (int)(P->overlap_clear_range_xy / P->resolution);
+  if (cell_range < 0) cell_range = 0; if (cell_range > C) cell_range = C;
+  int cmin = C / 2 - cell_range / 2, cmax = C / 2 + cell_range / 2;
+  /* t is a float32 array, range_z a python float: numpy/cupy keep float32 for array-scalar arithmetic */
+  float hmin = tz - (float)P->overlap_clear_range_z, hmax = tz + (float)P->overlap_clear_range_z;
+  for (int r = cmin; r < cmax; ++r) for (int c = cmin; c < cmax; ++c) {
+    long i = (long)r * C + c;
+    if (map[i] < hmin || map[i] > hmax) { map[i] = 0; map[L + i] = (float)P->initial_variance; map[2 * L + i] = 0; }
+    if (map[5 * L + i] < hmin || map[5 * L + i] > hmax) { map[5 * L + i] = 0; map[6 * L + i] = 0; }
+  }
+}
+
+/* dilation_filter_kernel (custom_kernels.py:392-449) incl. flat-index row wrap and signed dx+dy */
+void eo_dilate(int C, int d, const float* plane, const float* mask, float* out, float* outmask) {
+  const long L = (long)C * C;
+  for (long i = 0; i < L; ++i) {
+    out[i] = plane[i];
+    if (mask[i] < 0.5f) {
+      float distance = 100, near_value = 0;
+      for (int dy = -d; dy <= d; ++dy) for (int dx = -d; dx <= d; ++dx) {
+        long j = i + (long)C * dy + dx;
+        if (j < 0 || j >= L) continue;
+        long jx = j / C, jy = j % C;
+        if (jx <= 0 || jx >= C - 1 || jy <= 0 || jy >= C - 1) continue;
+        if (mask[j] > 0.5f && (float)(dx + dy) < distance) { distance = (float)(dx + dy); near_value = plane[j]; }
+      }
+      if (distance < 100) { out[i] = near_value; if (outmask) outmask[i] = 1.0f; }
+    }
+  }
+}
+
+/* traversability filter (traversability_filter.py:8-47): three dilated 3x3 correlations (4 ch each, no bias,
+ * no padding) -> abs -> 1x1 conv -> exp(-x); written to plane 3 interior [3:-3,3:-3] (elevation_mapping.py:385-388) */
+void eo_traversability(const eo_params* P, const float* in, float* trav_plane) {
+  const int C = P->cell_n;
+  const float* w[3] = {P->w1, P->w2, P->w3};
+  for (int r = 3; r < C - 3; ++r) for (int c = 3; c < C - 3; ++c) {
+    float acc = 0.0f;
+    for (int k = 0; k < 3; ++k) { const int dl = k + 1;
+      for (int ch = 0; ch < 4; ++ch) {
+        float s = 0.0f;
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
+          s += w[k][ch * 9 + a * 3 + b] * in[(long)(r + (a - 1) * dl) * C + (c + (b - 1) * dl)];
+        acc += P->w_out[k * 4 + ch] * fabsf(s);
+      } }
+    trav_plane[(long)r * C + c] = expf(-acc);
+  }
+}
+
+/* normal_filter_kernel (custom_kernels.py:452-506); `out` (3,C,C) is zeroed first (elevation_mapping.py:571) */
+void eo_normals(const eo_params* P, const float* plane, const float* valid, float* out) {
+  const int C = P->cell_n; const long L = (long)C * C;
+  memset(out, 0, sizeof(float) * 3 * L);
+  const float res = (float)P->resolution;
+  for (long i = 0; i < L; ++i) {
+    if (!(valid[i] > 0.5f)) continue;
+    long a = i + 1, b = i + C;
+    if (b >= L) continue;
+    long ax = a / C, ay = a % C, bx = b / C, by = b % C;
+    if (ax <= 0 || ax >= C - 1 || ay <= 0 || ay >= C - 1) continue;
+    if (bx <= 0 || bx >= C - 1 || by <= 0 || by >= C - 1) continue;
+    float h = plane[i], dzdx = plane[a] - h, dzdy = plane[b] - h;
+    float nx = -dzdy / res, ny = -dzdx / res;
+    float nrm = sqrtf((nx * nx) + (ny * ny) + 1);
+    out[i] = nx / nrm; out[L + i] = ny / nrm; out[2 * L + i] = 1.0f / nrm;
+  }
+}
+
+void eo_update_variance(const eo_params* P, float* map) { /* elevation_mapping.py:420-422 */
+  const long L = (long)P->cell_n * P->cell_n; const float tv = (float)P->time_variance;
+  for (long c = 0; c < L; ++c) map[L + c] += tv * map[2 * L + c];
+}
+void eo_update_time(const eo_params* P, float* map) { /* :424-426 */
+  const long L = (long)P->cell_n * P->cell_n; const float ti = (float)P->time_interval;
+  for (long c = 0; c < L; ++c) map[4 * L + c] += ti;
+}
+
+/* ---- semantic point-cloud fusion (reference fusion/pointcloud_average.py, _class_average.py, _color.py and
+ * custom_semantic_kernels.py:9-51,167-194,233-267,270-375). Points flagged valid&inside contribute. ---- */
+void eo_sem_sum(const eo_params* P, const float* pts, long n, long stride, const float* R, const float* t,
+                int n_ch, const int32_t* pcl_chan, const int32_t* layer, double* sums /* (n_layers_total, C, C) */) {
+  const long L = (long)P->cell_n * P->cell_n;
+  for (long i = 0; i < n; ++i) {
+    pt_t g = point_geometry(P, pts + i * stride, R, t);
+    if (!g.finite || !g.valid || !g.inside) continue;
+    for (int k = 0; k < n_ch; ++k) sums[(long)layer[k] * L + g.idx] += (double)pts[i * stride + pcl_chan[k]];
+  }
+}
+void eo_sem_average(const eo_params* P, const double* sums, const uint32_t* cnt, int n_ch, const int32_t* layer,
+                    float* smap) {
+  const long L = (long)P->cell_n * P->cell_n;
+  for (long c = 0; c < L; ++c) if (cnt[c] > 0)
+    for (int k = 0; k < n_ch; ++k) smap[(long)layer[k] * L + c] = (float)(sums[(long)layer[k] * L + c] / (double)cnt[c]);
+}
+void eo_sem_class_average(const eo_params* P, const double* sums, const uint32_t* cnt, int n_ch, const int32_t* layer,
+                          double alpha, float* smap) {
+  const long L = (long)P->cell_n * P->cell_n;
+  for (long c = 0; c < L; ++c) if (cnt[c] > 0)
+    for (int k = 0; k < n_ch; ++k) {
+      long j = (long)layer[k] * L + c;
+      float prev = smap[j], mean = (float)(sums[j] / (double)cnt[c]);
+      smap[j] = (prev == 0.0f) ? mean : (float)(alpha * (double)prev + (1.0 - alpha) * (double)mean);
+    }
+}
+/* colour: one packed 0x00RRGGBB channel; integer mean per component (truncating division) */
+void eo_sem_color(const eo_params* P, const float* pts, long n, long stride, const float* R, const float* t,
+                  int pcl_chan, int layer, float* smap) {
+  const long L = (long)P->cell_n * P->cell_n;
+  uint32_t* acc = (uint32_t*)calloc((size_t)4 * L, 4);
+  for (long i = 0; i < n; ++i) {
+    pt_t g = point_geometry(P, pts + i * stride, R, t);
+    if (!g.finite || !g.valid || !g.inside) continue;
+    uint32_t col = f2u(pts[i * stride + pcl_chan]);
+    acc[g.idx] += (col >> 16) & 0xff; acc[L + g.idx] += (col >> 8) & 0xff; acc[2 * L + g.idx] += col & 0xff;
+    acc[3 * L + g.idx] += 1;
+  }
+  for (long c = 0; c < L; ++c) if (acc[3 * L + c]) {
+    uint32_t k = acc[3 * L + c], r = acc[c] / k, g = acc[L + c] / k, b = acc[2 * L + c] / k;
+    smap[(long)layer * L + c] = u2f((r << 16) + (g << 8) + b);
+  }
+  free(acc);
+}
+
+/* ---- one whole frame (what bench.py's cpu_baseline leg times) ---------------------------------------- */
+typedef struct { double err_sum; uint32_t err_cnt; int32_t gate_fired; float mean_error; float shift; uint64_t ray_visits; } eo_stats;
+
+void eo_frame(const eo_params* P, float* map, float* normal, float* trav_input, const float* pts, long n, long stride,
+              const float* R, const float* t, double position_noise, double orientation_noise, eo_stats* st) {
+  const int C = P->cell_n; const long L = (long)C * C;
+  uint32_t* n_pts = calloc(L, 4); uint32_t* n_inl = calloc(L, 4); uint32_t* cnt = calloc(L, 4); uint32_t* n_out = calloc(L, 4);
+  double* sum_h = calloc(L, 8); double* sum_v = calloc(L, 8); float* latest = calloc(L, 4);
+  memset(st, 0, sizeof *st);
+  eo_count(P, map, pts, n, stride, R, t, n_pts, n_inl, &st->err_sum, &st->err_cnt);
+  st->shift = eo_gate(P, st->err_sum, st->err_cnt, position_noise, orientation_noise, &st->mean_error, &st->gate_fired);
+  if (st->shift != 0.0f) for (long c = 0; c < L; ++c) map[c] += st->shift;
+  eo_fuse(P, map, pts, n, stride, R, t, n_pts, sum_h, sum_v, cnt, n_out, latest);
+  eo_commit(P, map, cnt, n_out, latest);
+  double* ray_dec = NULL; uint32_t* ray_hits = NULL; float* ray_upper = NULL;
+  if (P->enable_visibility_cleanup) {
+    ray_dec = calloc(L, 8); ray_hits = calloc(L, 4); ray_upper = malloc(L * 4);
+    for (long c = 0; c < L; ++c) ray_upper[c] = INFINITY;
+    eo_rays(P, map, normal, n_inl, pts, n, stride, R, t, ray_dec, ray_hits, ray_upper, &st->ray_visits);
+  }
+  eo_average(P, map, sum_h, sum_v, cnt, ray_dec, ray_hits, ray_upper);
+  if (P->enable_overlap_clearance) eo_overlap_clear(P, map, t[2]);
+  float* mask = malloc(L * 4);
+  for (long c = 0; c < L; ++c) mask[c] = map[2 * L + c] + map[6 * L + c];
+  memset(trav_input, 0, L * 4);
+  eo_dilate(C, P->dilation_size, map + 5 * L, mask, trav_input, NULL);
+  eo_traversability(P, trav_input, map + 3 * L);
+  eo_normals(P, trav_input, map + 2 * L, normal);
+  free(n_pts); free(n_inl); free(cnt); free(n_out); free(sum_h); free(sum_v); free(latest); free(mask);
+  free(ray_dec); free(ray_hits); free(ray_upper);
+}
