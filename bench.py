@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpoints/s fused + map-update latency of the point-cloud hot path on MI355X.
+
+A "step" is one frame of ``update_map_with_kernel`` (reference EM/elevation_mapping.py:316-391) over one
+synthetic cloud that is already resident in HBM.  Default workload = BASELINE.json configs[1]:
+1024x1024 map (cell_n incl. border), 1 M uniform-random points per frame, shipped core_param.yaml values,
+visibility clean-up and overlap clearance off ("cfg2"); ``--workload cfg3`` turns both on.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3] [--points N] [--cell-n C]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (row strips, see sharded.py)
+
+Prints ONE JSON line (rank 0): metric/value/unit + roofline + cpu_baseline objects (see DESIGN.md "Measurement").
+"""
+import argparse
+import ctypes as ct
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
+    ap.add_argument("--points", type=int, default=1_000_000)
+    ap.add_argument("--cell-n", type=int, default=1024)
+    ap.add_argument("--mode", default="reference_fp16", choices=["reference_fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def workload_cfg(name):
+    from elevation_mapping_cupy_amd.configs import CORE_PARAM_YAML
+    cfg = dict(CORE_PARAM_YAML)
+    if name == "cfg2":
+        cfg.update(enable_visibility_cleanup=False, enable_overlap_clearance=False)
+    return cfg
+
+
+class Hip:
+    """tiny ctypes view of the HIP runtime for device-resident input clouds (plumbing, not the product)."""
+
+    def __init__(self):
+        self.l = ct.CDLL("libamdhip64.so")
+
+    def ck(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: hip error %d" % (what, rc))
+
+    def set_device(self, d):
+        self.ck(self.l.hipSetDevice(d), "hipSetDevice")
+
+    def malloc(self, nbytes):
+        p = ct.c_void_p()
+        self.ck(self.l.hipMalloc(ct.byref(p), ct.c_size_t(nbytes)), "hipMalloc")
+        return p
+
+    def h2d(self, dst, arr):
+        self.ck(self.l.hipMemcpy(dst, ct.c_void_p(arr.ctypes.data), ct.c_size_t(arr.nbytes), 1), "hipMemcpy")
+
+    def sync(self):
+        self.ck(self.l.hipDeviceSynchronize(), "hipDeviceSynchronize")
+
+
+# algorithmic bytes per unit of each stage (DESIGN.md "Kernels and rooflines"):
+#   point passes: 12 B xyz + the compulsory cell traffic of one point; cell passes: planes read + written once.
+STAGE_BYTES = {
+    "count": lambda N, L: 12 * N + 16 * N + 8 * N,            # xyz + (h,v,valid,trav) gather + 1 counter RMW
+    "fuse": lambda N, L: 12 * N + 8 * N + 4 * N + 12 * N,     # xyz + (h,v) + points-per-cell + (sum_h,sum_v,cnt) RMW
+    "commit": lambda N, L: 56 * L,
+    "rays": lambda N, L: 12 * N,                              # reported as visits/s instead (data dependent)
+    "average": lambda N, L: 36 * L,                           # K4: 3+3 planes read, 3 written
+    "overlap": lambda N, L: 0,
+    "dilate": lambda N, L: 12 * L,                            # K5: 2 planes in, 1 out
+    "trav_normals": lambda N, L: 8 * L + 20 * L,              # a13 8 B/cell + K6 20 B/cell
+}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 or world > 1:
+        from elevation_mapping_cupy_amd import sharded
+        return sharded.bench_main(a, rank, world, local_rank)
+
+    from elevation_mapping_cupy_amd import _lib
+    from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
+    from elevation_mapping_cupy_amd.configs import parameter_from
+    import _fixtures as fx
+
+    cfg = workload_cfg(a.workload)
+    C, N = a.cell_n, a.points
+    w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
+    weights = {k: w[k] for k in ("w1", "w2", "w3", "w_out")}
+    par = parameter_from(cfg, C, a.mode, weights)
+    par.device = local_rank
+    emap = ElevationMap(par)
+    lib, ctx = emap._lib, emap._ctx
+    hip = Hip(); hip.set_device(local_rank)
+
+    # 5 seeded clouds resident in HBM: x,y ~ U(-L/2, L/2), sensor-frame z ~ U(-.5,.5); timed clouds lowered
+    NCLOUD = 5
+    clouds_host = [fx.cloud(C, N, s, dz=(0.0 if s == 0 else -0.02 * s)) for s in range(NCLOUD)]
+    clouds_dev = []
+    for p in clouds_host:
+        d = hip.malloc(p.nbytes); hip.h2d(d, p); clouds_dev.append(d)
+    R = np.eye(3, dtype=np.float32).ravel().copy()
+    t = np.array([0, 0, 1], np.float32)
+    Rp, tp = _lib.f32p(R), _lib.f32p(t)
+
+    def frame(i, stats=None):
+        rc = lib.emap_set_points_device(ctx, clouds_dev[i % NCLOUD], ct.c_int64(N), ct.c_int64(3))
+        rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
+        if rc:
+            raise RuntimeError(lib.emap_last_error(ctx).decode())
+
+    # map warm-up (3 frames + time ticks so that the ray pass has stale cells to act on)
+    for i in range(3):
+        frame(i)
+        for _ in range(4):
+            emap.update_time()
+    emap.update_variance()
+    for i in range(a.warmup):
+        frame(i)
+    emap.sync(); hip.sync()
+
+    # ---- timed region: exactly K frames, sync on both sides -------------------------------------------------
+    ms_dev = ct.c_float(0)
+    t0 = time.perf_counter()
+    lib.emap_timer_begin(ctx)
+    for i in range(a.steps):
+        frame(i)
+    lib.emap_timer_end(ctx, ct.byref(ms_dev))
+    emap.sync(); hip.sync()
+    wall = time.perf_counter() - t0
+    ms_per_step = wall * 1e3 / a.steps
+    mpts = N * a.steps / wall / 1e6
+
+    # ---- per-frame latency distribution (each frame individually synchronised) ---------------------------
+    lat = []
+    for i in range(min(a.steps, 40)):
+        emap.sync()
+        t1 = time.perf_counter(); frame(i); emap.sync(); lat.append((time.perf_counter() - t1) * 1e3)
+    p10, p50, p90 = np.percentile(lat, [10, 50, 90])
+
+    # ---- per-stage device time (hipEvents on the kernel's stream) -> roofline of the dominant kernel ------
+    lib.emap_enable_stage_timing(ctx, 2)
+    acc = np.zeros(8)
+    reps = min(a.steps, 20)
+    st = _lib.EmapStats()
+    visits = 0
+    for i in range(reps):
+        frame(i, ct.byref(st))
+        ms8 = (ct.c_float * 8)()
+        lib.emap_get_stage_times(ctx, ms8)
+        acc += np.array(list(ms8)); visits += st.ray_visits
+    lib.emap_enable_stage_timing(ctx, 0)
+    stage_ms = dict(zip(_lib.STAGES, (acc / reps).tolist()))
+    L = C * C
+    dom = max(stage_ms, key=stage_ms.get)
+    dom_bytes = STAGE_BYTES[dom](N, L)
+    achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+    frame_bytes = 12 * N + 56 * L            # B_frame of BASELINE.md §5 (K = 0 extra channels, L = 0 semantic layers)
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes": dom_bytes, "kernel_ms": round(stage_ms[dom], 5),
+            "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+            "frame_algorithmic_bytes": frame_bytes,
+            "frame_frac": round(frame_bytes / (ms_dev.value / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "ray_visits_per_frame": int(visits / reps)}
+
+    # ---- CPU baseline: the oracle port, same workload, bounded sample ---------------------------------------
+    cpu = None
+    if not a.no_cpu_baseline:
+        from oracle import emap_oracle as eo
+        n_cpu = a.cpu_points or (N if a.workload == "cfg2" else min(N, 60000))
+        P = eo.make_params(cfg, cell_n=C, mode=a.mode, weights=weights)
+        om = eo.OracleMap(P)
+        om.frame_c(clouds_host[0][:n_cpu], R, t, 1.0, 1.0)
+        for _ in range(8):
+            om.update_time()
+        reps_cpu, t_cpu = 0, 0.0
+        while reps_cpu < 5 and t_cpu < 20.0:
+            s = time.perf_counter(); om.frame_c(clouds_host[(reps_cpu + 1) % NCLOUD][:n_cpu], R, t, 1.0, 1.0)
+            t_cpu += time.perf_counter() - s; reps_cpu += 1
+        cpu = {"value": round(n_cpu * reps_cpu / t_cpu / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+               "sample": "%d frames of %d points on the %dx%d map (oracle/emap_oracle.c eo_frame, gcc -O2, 1 thread of %d)"
+                         % (reps_cpu, n_cpu, C, C, os.cpu_count())}
+
+    out = {
+        "metric": "Mpoints/s fused (map-update p50 latency in config)", "value": round(mpts, 2), "unit": "Mpoints/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %dx%d map, %d uniform-random points/frame, core_param.yaml values, %s"
+                               % (a.workload, C, C, N, "rays+overlap on" if a.workload == "cfg3" else "add_points + variance fusion, rays/overlap off"),
+                   "index_mode": a.mode, "latency_ms": {"p10": round(p10, 4), "p50": round(p50, 4), "p90": round(p90, 4)},
+                   "device_ms_per_step": round(ms_dev.value / a.steps, 5), "cloud": "device resident (H2D excluded)"},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,503 @@
+// C ABI of the MI355X elevation-map fusion core (declared in include/emap_hip.h).
+// Host-side orchestration only: owns device memory, turns emap_params into kernargs, enqueues the kernels of
+// emap_kernels.hip on ONE stream in the order of the reference's update_map_with_kernel
+// (EM/elevation_mapping.py:316-391).  No per-frame allocation, no D2H sync inside a frame unless stats are asked for.
+#include "emap_device.h"
+#include "../../include/emap_hip.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+// launchers (emap_kernels.hip)
+void launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, ErrSlot*);
+void launch_gate(hipStream_t, const KP&, ErrSlot*, FrameDev*, int, double, double, float, int, int, double, unsigned int, unsigned int);
+void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, const FrameDev*, int*, unsigned char*);
+void launch_commit(hipStream_t, const KP&, Cell*, const AccF*, const FrameDev*);
+void launch_rays(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, const AccF*, AccR*, const float*, long, FrameDev*, bool);
+void launch_average(hipStream_t, const KP&, Cell*, AccF*, AccR*, const FrameDev*, bool, bool);
+void launch_overlap(hipStream_t, const KP&, Cell*, int, int, float, float);
+void launch_dilate(hipStream_t, const KP&, const Cell*, float*, int, int, int);
+void launch_trav_normal(hipStream_t, const KP&, const float*, const float*, const float*, const float*, const float*, Cell*, float*, long);
+void launch_var_time(hipStream_t, const KP&, Cell*, int, int);
+void launch_get_plane(hipStream_t, const KP&, const Cell*, int, float*);
+void launch_set_plane(hipStream_t, const KP&, Cell*, int, const float*);
+void launch_fill_cells(hipStream_t, Cell*, long, const Cell&);
+void launch_f64_to_f32(hipStream_t, const double*, float*, long);
+void launch_point_index(hipStream_t, const KP&, const Pose&, const float*, long, int, int*, unsigned char*);
+void launch_shift(hipStream_t, const KP&, const Cell*, Cell*, int, int, float);
+
+enum { ST_COUNT = 0, ST_FUSE, ST_COMMIT, ST_RAYS, ST_AVERAGE, ST_OVERLAP, ST_DILATE, ST_TRAVN, ST_N };
+
+struct emap_ctx {
+  emap_params prm;
+  emap_strip strip;
+  KP kp;
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  long ncells_alloc;        // (rows + 2*halo) * C
+  Cell* cells; Cell* cells_alt;
+  AccF* acc; AccR* accr;
+  float* trav_in; float* normal;   // normal: 3 planes of ncells_alloc
+  float* scratch;                  // one plane (get/set staging)
+  ErrSlot* slots; FrameDev* frame;
+  // point cloud
+  float* pts_own; long pts_cap;    // owned buffer (floats)
+  double* pts_f64; long pts_f64_cap;
+  const float* pts; long n_pts; int stride;
+  int* tail_idx; unsigned char* tail_flags; long tail_cap;
+  // frame state
+  double pos_noise, ori_noise; bool use_override; double sum_override; unsigned int cnt_override;
+  bool committed;
+  bool stage_timing; hipEvent_t ev[ST_N + 1]; float stage_ms[ST_N];
+  hipEvent_t t0, t1;
+  bool want_ray_stats;
+  std::string err;
+};
+
+#define CK(call)                                                                                         \
+  do { hipError_t e_ = (call);                                                                           \
+       if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return EMAP_ERR_HIP; } } while (0)
+#define CKARG(cond, msg) do { if (!(cond)) { if (ctx) ctx->err = msg; return EMAP_ERR_INVALID; } } while (0)
+
+static float q16(float x) { return (float)(_Float16)x; }
+
+static void build_kp(emap_ctx* ctx) {
+  const emap_params& p = ctx->prm;
+  KP& k = ctx->kp;
+  memset(&k, 0, sizeof k);
+  k.C = p.cell_n; k.mode = p.mode; k.row0 = ctx->strip.row_begin; k.nrows = ctx->strip.row_count; k.halo = ctx->strip.halo_rows;
+  k.edge = p.enable_edge_sharpen; k.dil = p.dilation_size;
+  k.res = p.resolution; k.half_w = 0.5 * p.cell_n; k.snf = p.sensor_noise_factor; k.mt = p.mahalanobis_thresh;
+  k.ov = p.outlier_variance; k.dcvi_half = p.drift_compensation_variance_inlier / 2.0; k.trav_inlier = p.traversability_inlier;
+  k.wall = p.wall_num_thresh; k.mrl = p.max_ray_length; k.cs = p.cleanup_step; k.cos_thresh = p.cleanup_cos_thresh;
+  k.mvd2 = p.min_valid_distance * p.min_valid_distance; k.mhr = p.max_height_range;
+  k.ra = p.ramped_height_range_a; k.rb = p.ramped_height_range_b; k.rc = p.ramped_height_range_c;
+  k.max_var = p.max_variance; k.ray_step = p.ray_step;
+  k.init_var = (float)p.initial_variance; k.ov_f = (float)p.outlier_variance;
+  const bool h = p.mode == EMAP_MODE_REFERENCE_FP16;
+  k.q_wm1 = h ? q16((float)(p.cell_n - 1)) : (float)(p.cell_n - 1);
+  k.q_mrl = h ? q16((float)p.max_ray_length) : (float)p.max_ray_length;
+  k.q_step = h ? q16((float)p.ray_step) : (float)p.ray_step;
+  k.time_var = (float)p.time_variance; k.time_int = (float)p.time_interval; k.res_f = (float)p.resolution;
+}
+
+static Pose make_pose(const emap_ctx* ctx, const float R[9], const float t[3]) {
+  Pose T;
+  const bool h = ctx->prm.mode == EMAP_MODE_REFERENCE_FP16;
+  for (int i = 0; i < 9; ++i) T.Rq[i] = h ? q16(R[i]) : R[i];
+  for (int i = 0; i < 3; ++i) { T.tq[i] = h ? q16(t[i]) : t[i]; T.t[i] = t[i]; }
+  return T;
+}
+
+static int validate(const emap_params* p, const emap_strip* s, std::string* why) {
+  if (!p) { *why = "params null"; return 0; }
+  if (p->cell_n < 8 || p->cell_n > 46340) { *why = "cell_n out of range"; return 0; }
+  if (p->mode != EMAP_MODE_REFERENCE_FP16 && p->mode != EMAP_MODE_FP32) { *why = "bad mode"; return 0; }
+  if (p->mode == EMAP_MODE_REFERENCE_FP16 && p->cell_n > 2049) {
+    *why = "reference_fp16 index mode is only defined for cell_n <= 2049 (half cannot hold larger indices)"; return 0; }
+  if (!(p->resolution > 0)) { *why = "resolution must be > 0"; return 0; }
+  if (p->dilation_size < 0 || p->dilation_size > 32) { *why = "dilation_size out of range"; return 0; }
+  if (s) {
+    if (s->row_begin < 0 || s->row_count <= 0 || s->row_begin + s->row_count > p->cell_n || s->halo_rows < 0) {
+      *why = "bad strip"; return 0; }
+  }
+  return 1;
+}
+
+extern "C" {
+
+int emap_abi_version(void) { return EMAP_ABI_VERSION; }
+
+const char* emap_last_error(const emap_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int emap_destroy(emap_ctx* ctx) {
+  if (!ctx) return EMAP_OK;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  hipFree(ctx->cells); hipFree(ctx->cells_alt); hipFree(ctx->acc); hipFree(ctx->accr); hipFree(ctx->trav_in);
+  hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->slots); hipFree(ctx->frame); hipFree(ctx->pts_own);
+  hipFree(ctx->pts_f64); hipFree(ctx->tail_idx); hipFree(ctx->tail_flags);
+  for (int i = 0; i <= ST_N; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+  if (ctx->t0) hipEventDestroy(ctx->t0);
+  if (ctx->t1) hipEventDestroy(ctx->t1);
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return EMAP_OK;
+}
+
+int emap_clear(emap_ctx* ctx) {
+  CKARG(ctx, "null ctx");
+  CK(hipSetDevice(ctx->device));
+  // ElevationMap.clear (elevation_mapping.py:119-128): all planes 0, variance = initial_variance
+  Cell z = {0.f, (float)ctx->prm.initial_variance, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  launch_fill_cells(ctx->stream, ctx->cells, ctx->ncells_alloc, z);
+  CK(hipMemsetAsync(ctx->acc, 0, sizeof(AccF) * ctx->ncells_alloc, ctx->stream));
+  CK(hipMemsetAsync(ctx->accr, 0, sizeof(AccR) * ctx->ncells_alloc, ctx->stream));
+  CK(hipMemsetAsync(ctx->slots, 0, sizeof(ErrSlot) * EM_ERR_SLOTS, ctx->stream));
+  CK(hipMemsetAsync(ctx->frame, 0, sizeof(FrameDev), ctx->stream));
+  ctx->committed = false;
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+
+int emap_create(const emap_params* params, const emap_strip* strip, int device, void* stream, emap_ctx** out) {
+  if (!out) return EMAP_ERR_INVALID;
+  *out = nullptr;
+  std::string why;
+  if (!validate(params, strip, &why)) { fprintf(stderr, "emap_create: %s\n", why.c_str()); return EMAP_ERR_INVALID; }
+  emap_ctx* ctx = new (std::nothrow) emap_ctx();
+  if (!ctx) return EMAP_ERR_INVALID;
+  ctx->prm = *params;
+  if (strip) ctx->strip = *strip; else { ctx->strip.row_begin = 0; ctx->strip.row_count = params->cell_n; ctx->strip.halo_rows = 0; ctx->strip.pad_ = 0; }
+  ctx->device = device;
+  build_kp(ctx);
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) { fprintf(stderr, "emap_create: hipSetDevice(%d): %s\n", device, hipGetErrorString(e)); delete ctx; return EMAP_ERR_HIP; }
+  if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+  else { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); ctx->own_stream = true;
+         if (e != hipSuccess) { fprintf(stderr, "emap_create: stream: %s\n", hipGetErrorString(e)); delete ctx; return EMAP_ERR_HIP; } }
+  const long C = params->cell_n;
+  ctx->ncells_alloc = (long)(ctx->strip.row_count + 2 * ctx->strip.halo_rows) * C;
+  const long n = ctx->ncells_alloc;
+  int rc = EMAP_OK;
+  auto alloc = [&](void** p, size_t bytes) { if (rc == EMAP_OK && hipMalloc(p, bytes) != hipSuccess) { rc = EMAP_ERR_HIP; fprintf(stderr, "emap_create: hipMalloc(%zu) failed\n", bytes); } };
+  alloc((void**)&ctx->cells, sizeof(Cell) * n); alloc((void**)&ctx->acc, sizeof(AccF) * n); alloc((void**)&ctx->accr, sizeof(AccR) * n);
+  alloc((void**)&ctx->trav_in, sizeof(float) * n); alloc((void**)&ctx->normal, sizeof(float) * 3 * n);
+  alloc((void**)&ctx->scratch, sizeof(float) * n); alloc((void**)&ctx->slots, sizeof(ErrSlot) * EM_ERR_SLOTS);
+  alloc((void**)&ctx->frame, sizeof(FrameDev));
+  if (rc == EMAP_OK) {
+    hipEventCreate(&ctx->t0); hipEventCreate(&ctx->t1);
+    for (int i = 0; i <= ST_N; ++i) hipEventCreate(&ctx->ev[i]);
+    hipMemsetAsync(ctx->trav_in, 0, sizeof(float) * n, ctx->stream);
+    hipMemsetAsync(ctx->normal, 0, sizeof(float) * 3 * n, ctx->stream);
+    rc = emap_clear(ctx);
+    if (rc == EMAP_OK) {
+      // ElevationMap.__init__: traversability plane starts at 1 (elevation_mapping.py:84)
+      Cell z = {0.f, (float)params->initial_variance, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f};
+      launch_fill_cells(ctx->stream, ctx->cells, n, z);
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = EMAP_ERR_HIP;
+    }
+  }
+  if (rc != EMAP_OK) { emap_destroy(ctx); return rc; }
+  *out = ctx;
+  return EMAP_OK;
+}
+
+int emap_set_params(emap_ctx* ctx, const emap_params* params) {
+  CKARG(ctx && params, "null argument");
+  CKARG(params->cell_n == ctx->prm.cell_n, "cell_n cannot change");
+  std::string why;
+  if (!validate(params, &ctx->strip, &why)) { ctx->err = why; return EMAP_ERR_INVALID; }
+  ctx->prm = *params;
+  build_kp(ctx);
+  return EMAP_OK;
+}
+
+int emap_sync(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); CK(hipStreamSynchronize(ctx->stream)); return EMAP_OK; }
+
+// ---- point cloud --------------------------------------------------------------------------------------
+int emap_upload_points(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype) {
+  CKARG(ctx, "null ctx");
+  CKARG(n >= 0 && stride >= 3 && stride < 4096 && (dtype == 0 || dtype == 1), "bad point buffer description");
+  CKARG(n == 0 || host, "null host buffer");
+  CK(hipSetDevice(ctx->device));
+  const long tot = (long)n * stride;
+  if (tot > ctx->pts_cap) {
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->pts_own) CK(hipFree(ctx->pts_own));
+    ctx->pts_own = nullptr; ctx->pts_cap = 0;
+    CK(hipMalloc((void**)&ctx->pts_own, sizeof(float) * tot));
+    ctx->pts_cap = tot;
+  }
+  if (tot > 0) {
+    if (dtype == 0) CK(hipMemcpyAsync(ctx->pts_own, host, sizeof(float) * tot, hipMemcpyHostToDevice, ctx->stream));
+    else {
+      if (tot > ctx->pts_f64_cap) {
+        CK(hipStreamSynchronize(ctx->stream));
+        if (ctx->pts_f64) CK(hipFree(ctx->pts_f64));
+        ctx->pts_f64 = nullptr; ctx->pts_f64_cap = 0;
+        CK(hipMalloc((void**)&ctx->pts_f64, sizeof(double) * tot));
+        ctx->pts_f64_cap = tot;
+      }
+      CK(hipMemcpyAsync(ctx->pts_f64, host, sizeof(double) * tot, hipMemcpyHostToDevice, ctx->stream));
+      launch_f64_to_f32(ctx->stream, ctx->pts_f64, ctx->pts_own, tot);
+    }
+    CK(hipStreamSynchronize(ctx->stream));   // host buffer is only borrowed for the call
+  }
+  ctx->pts = ctx->pts_own; ctx->n_pts = (long)n; ctx->stride = (int)stride;
+  return EMAP_OK;
+}
+
+int emap_set_points_device(emap_ctx* ctx, const float* dev, int64_t n, int64_t stride) {
+  CKARG(ctx, "null ctx");
+  CKARG(n >= 0 && stride >= 3 && stride < 4096 && (n == 0 || dev), "bad device point buffer");
+  ctx->pts = dev; ctx->n_pts = (long)n; ctx->stride = (int)stride;
+  return EMAP_OK;
+}
+
+static int ensure_tail(emap_ctx* ctx) {
+  if (ctx->n_pts > ctx->tail_cap) {
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->tail_idx) CK(hipFree(ctx->tail_idx));
+    if (ctx->tail_flags) CK(hipFree(ctx->tail_flags));
+    ctx->tail_idx = nullptr; ctx->tail_flags = nullptr; ctx->tail_cap = 0;
+    CK(hipMalloc((void**)&ctx->tail_idx, sizeof(int) * ctx->n_pts));
+    CK(hipMalloc((void**)&ctx->tail_flags, ctx->n_pts));
+    ctx->tail_cap = ctx->n_pts;
+  }
+  return EMAP_OK;
+}
+
+int emap_point_index(emap_ctx* ctx, const float R[9], const float t[3], int32_t* idx, uint8_t* valid, uint8_t* inside) {
+  CKARG(ctx && R && t && idx && valid && inside, "null argument");
+  if (!ctx->pts && ctx->n_pts) { ctx->err = "no point cloud bound"; return EMAP_ERR_NO_POINTS; }
+  CK(hipSetDevice(ctx->device));
+  if (ctx->n_pts == 0) return EMAP_OK;
+  int rc = ensure_tail(ctx); if (rc) return rc;
+  launch_point_index(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->tail_idx, ctx->tail_flags);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(idx, ctx->tail_idx, sizeof(int) * ctx->n_pts, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipMemcpyAsync(valid, ctx->tail_flags, ctx->n_pts, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
+  for (long i = 0; i < ctx->n_pts; ++i) { uint8_t f = valid[i]; valid[i] = f & 1; inside[i] = (f >> 1) & 1; }
+  return EMAP_OK;
+}
+
+// ---- stages -----------------------------------------------------------------------------------------------
+#define NEED_POINTS() do { if (!ctx->pts && ctx->n_pts) { ctx->err = "no point cloud bound"; return EMAP_ERR_NO_POINTS; } } while (0)
+
+int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
+  CKARG(ctx && R && t, "null argument"); NEED_POINTS();
+  CK(hipSetDevice(ctx->device));
+  launch_count(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->slots);
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+
+int emap_set_drift_inputs(emap_ctx* ctx, double position_noise, double orientation_noise, const double* err_sum_override,
+                          const uint32_t* err_cnt_override) {
+  CKARG(ctx, "null ctx");
+  CK(hipSetDevice(ctx->device));
+  ctx->pos_noise = position_noise; ctx->ori_noise = orientation_noise;
+  ctx->use_override = err_sum_override && err_cnt_override;
+  if (ctx->use_override) { ctx->sum_override = *err_sum_override; ctx->cnt_override = *err_cnt_override; }
+  const emap_params& p = ctx->prm;
+  int noise_ok = (position_noise > p.position_noise_thresh) || (orientation_noise > p.orientation_noise_thresh);
+  launch_gate(ctx->stream, ctx->kp, ctx->slots, ctx->frame, p.enable_drift_compensation, p.min_height_drift_cnt, p.max_drift,
+              (float)p.drift_compensation_alpha, noise_ok, ctx->use_override ? 1 : 0, ctx->sum_override, ctx->cnt_override,
+              (unsigned int)ctx->n_pts);
+  CK(hipGetLastError());
+  ctx->committed = false;
+  return EMAP_OK;
+}
+
+static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool tail) {
+  NEED_POINTS();
+  CK(hipSetDevice(ctx->device));
+  if (tail) { int rc = ensure_tail(ctx); if (rc) return rc; }
+  launch_fuse(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->frame,
+              tail ? ctx->tail_idx : nullptr, tail ? ctx->tail_flags : nullptr);
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+int emap_fuse(emap_ctx* ctx, const float R[9], const float t[3]) { CKARG(ctx && R && t, "null argument"); return fuse_impl(ctx, R, t, false); }
+
+int emap_commit(emap_ctx* ctx) {
+  CKARG(ctx, "null ctx");
+  CK(hipSetDevice(ctx->device));
+  if (!ctx->committed) { launch_commit(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->frame); ctx->committed = true; }
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+
+int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
+  CKARG(ctx && R && t, "null argument"); NEED_POINTS();
+  CK(hipSetDevice(ctx->device));
+  CKARG(ctx->committed, "emap_rays needs emap_commit first (rays read snapshot S1)");
+  launch_rays(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->accr,
+              ctx->normal, ctx->ncells_alloc, ctx->frame, ctx->want_ray_stats);
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+
+int emap_average(emap_ctx* ctx) {
+  CKARG(ctx, "null ctx");
+  CK(hipSetDevice(ctx->device));
+  launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, true);
+  ctx->committed = false;
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+
+int emap_overlap_clear(emap_ctx* ctx, float t_z) {
+  CKARG(ctx, "null ctx");
+  CK(hipSetDevice(ctx->device));
+  const emap_params& p = ctx->prm;
+  int cell_range = (int)(p.overlap_clear_range_xy / p.resolution);     // elevation_mapping.py:88-91
+  if (cell_range < 0) cell_range = 0; if (cell_range > p.cell_n) cell_range = p.cell_n;
+  int cmin = p.cell_n / 2 - cell_range / 2, cmax = p.cell_n / 2 + cell_range / 2;
+  float hmin = t_z - (float)p.overlap_clear_range_z, hmax = t_z + (float)p.overlap_clear_range_z;
+  launch_overlap(ctx->stream, ctx->kp, ctx->cells, cmin, cmax, hmin, hmax);
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+
+int emap_dilate(emap_ctx* ctx) {
+  CKARG(ctx, "null ctx");
+  CK(hipSetDevice(ctx->device));
+  const int H = ctx->strip.halo_rows, total = ctx->strip.row_count + 2 * H;
+  int lr0 = H - 3 < 0 ? 0 : H - 3, lr1 = H + ctx->strip.row_count + 3 > total ? total : H + ctx->strip.row_count + 3;
+  launch_dilate(ctx->stream, ctx->kp, ctx->cells, ctx->trav_in, ctx->prm.dilation_size, lr0, lr1);
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+
+int emap_traversability_normals(emap_ctx* ctx) {
+  CKARG(ctx, "null ctx");
+  CK(hipSetDevice(ctx->device));
+  launch_trav_normal(ctx->stream, ctx->kp, ctx->prm.w1, ctx->prm.w2, ctx->prm.w3, ctx->prm.w_out, ctx->trav_in, ctx->cells, ctx->normal,
+                     ctx->ncells_alloc);
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+
+int emap_update_variance(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 1, 0); CK(hipGetLastError()); return EMAP_OK; }
+int emap_update_time(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 0, 1); CK(hipGetLastError()); return EMAP_OK; }
+
+int emap_get_stats(emap_ctx* ctx, emap_stats* out) {
+  CKARG(ctx && out, "null argument");
+  CK(hipSetDevice(ctx->device));
+  FrameDev f;
+  CK(hipMemcpyAsync(&f, ctx->frame, sizeof f, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
+  out->err_sum = (double)f.err_sum_fix / EM_SCALE_E; out->err_cnt = (uint32_t)f.err_cnt; out->gate_fired = f.gate_fired;
+  out->mean_error = f.mean_error; out->additive_mean_error = f.additive_mean_error; out->shift = f.shift;
+  out->n_points = f.n_points; out->ray_visits = f.ray_visits;
+  return EMAP_OK;
+}
+
+int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats) {
+  CKARG(ctx && R && t, "null argument"); NEED_POINTS();
+  CK(hipSetDevice(ctx->device));
+  const emap_params& p = ctx->prm;
+  const bool tm = ctx->stage_timing;
+  int rc;
+#define STAGE(i) do { if (tm) CK(hipEventRecord(ctx->ev[i], ctx->stream)); } while (0)
+  STAGE(0);
+  if ((rc = emap_count(ctx, R, t))) return rc;
+  if ((rc = emap_set_drift_inputs(ctx, position_noise, orientation_noise, nullptr, nullptr))) return rc;
+  STAGE(1);
+  if ((rc = fuse_impl(ctx, R, t, false))) return rc;
+  STAGE(2);
+  if (p.enable_visibility_cleanup) {
+    if ((rc = emap_commit(ctx))) return rc;
+    STAGE(3);
+    if ((rc = emap_rays(ctx, R, t))) return rc;
+  } else STAGE(3);
+  STAGE(4);
+  launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, p.enable_visibility_cleanup != 0);
+  ctx->committed = false;
+  CK(hipGetLastError());
+  STAGE(5);
+  if (p.enable_overlap_clearance && (rc = emap_overlap_clear(ctx, t[2]))) return rc;
+  STAGE(6);
+  if ((rc = emap_dilate(ctx))) return rc;
+  STAGE(7);
+  if ((rc = emap_traversability_normals(ctx))) return rc;
+  STAGE(8);
+#undef STAGE
+  if (tm) {
+    CK(hipEventSynchronize(ctx->ev[ST_N]));
+    for (int i = 0; i < ST_N; ++i) CK(hipEventElapsedTime(&ctx->stage_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+  }
+  if (stats) return emap_get_stats(ctx, stats);
+  return EMAP_OK;
+}
+
+// ---- state access -------------------------------------------------------------------------------------------
+static float* plane_ptr(emap_ctx* ctx, int plane) {   // planar planes, offset to the first owned row
+  const long off = (long)ctx->strip.halo_rows * ctx->prm.cell_n;
+  if (plane >= EMAP_PLANE_NORMAL_X && plane <= EMAP_PLANE_NORMAL_Z) return ctx->normal + (long)(plane - EMAP_PLANE_NORMAL_X) * ctx->ncells_alloc + off;
+  if (plane == EMAP_PLANE_TRAV_INPUT) return ctx->trav_in + off;
+  return nullptr;
+}
+
+int emap_get_layer(emap_ctx* ctx, int plane, float* host_out) {
+  CKARG(ctx && host_out && plane >= 0 && plane < EMAP_PLANE_COUNT, "bad argument");
+  CK(hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n;
+  if (plane < 7) {
+    launch_get_plane(ctx->stream, ctx->kp, ctx->cells, plane, ctx->scratch);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(host_out, ctx->scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  } else CK(hipMemcpyAsync(host_out, plane_ptr(ctx, plane), bytes, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
+  return EMAP_OK;
+}
+
+int emap_set_layer(emap_ctx* ctx, int plane, const float* host_in) {
+  CKARG(ctx && host_in && plane >= 0 && plane < EMAP_PLANE_COUNT, "bad argument");
+  CK(hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n;
+  if (plane < 7) {
+    CK(hipMemcpyAsync(ctx->scratch, host_in, bytes, hipMemcpyHostToDevice, ctx->stream));
+    launch_set_plane(ctx->stream, ctx->kp, ctx->cells, plane, ctx->scratch);
+    CK(hipGetLastError());
+  } else CK(hipMemcpyAsync(plane_ptr(ctx, plane), host_in, bytes, hipMemcpyHostToDevice, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
+  return EMAP_OK;
+}
+
+int emap_shift(emap_ctx* ctx, int32_t shift_rows, int32_t shift_cols, float dz) {
+  CKARG(ctx, "null ctx");
+  CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "emap_shift: single-strip contexts only");
+  CK(hipSetDevice(ctx->device));
+  if (shift_rows == 0 && shift_cols == 0 && dz == 0.f) return EMAP_OK;
+  if (!ctx->cells_alt) CK(hipMalloc((void**)&ctx->cells_alt, sizeof(Cell) * ctx->ncells_alloc));
+  launch_shift(ctx->stream, ctx->kp, ctx->cells, ctx->cells_alt, shift_rows, shift_cols, dz);
+  CK(hipGetLastError());
+  Cell* tmp = ctx->cells; ctx->cells = ctx->cells_alt; ctx->cells_alt = tmp;
+  return EMAP_OK;
+}
+
+// ---- halos ----------------------------------------------------------------------------------------------------
+int emap_halo_bytes(emap_ctx* ctx, int64_t* bytes_per_side) {
+  CKARG(ctx && bytes_per_side, "null argument");
+  *bytes_per_side = (int64_t)ctx->strip.halo_rows * ctx->prm.cell_n * (int64_t)sizeof(Cell);
+  return EMAP_OK;
+}
+int emap_halo_pack(emap_ctx* ctx, int side, float* dev_buf) {
+  CKARG(ctx && dev_buf && (side == 0 || side == 1), "bad argument");
+  CK(hipSetDevice(ctx->device));
+  const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
+  if (H == 0) return EMAP_OK;
+  CKARG(n >= H, "strip thinner than its halo");
+  const Cell* src = ctx->cells + (side == 0 ? H * C : (H + n - H) * C);   // first / last H owned rows
+  CK(hipMemcpyAsync(dev_buf, src, sizeof(Cell) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
+  return EMAP_OK;
+}
+int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf) {
+  CKARG(ctx && dev_buf && (side == 0 || side == 1), "bad argument");
+  CK(hipSetDevice(ctx->device));
+  const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
+  if (H == 0) return EMAP_OK;
+  Cell* dst = ctx->cells + (side == 0 ? 0 : (H + n) * C);
+  CK(hipMemcpyAsync(dst, dev_buf, sizeof(Cell) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
+  return EMAP_OK;
+}
+
+// ---- timing -----------------------------------------------------------------------------------------------------
+int emap_timer_begin(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); CK(hipEventRecord(ctx->t0, ctx->stream)); return EMAP_OK; }
+int emap_timer_end(emap_ctx* ctx, float* ms) {
+  CKARG(ctx && ms, "null argument");
+  CK(hipSetDevice(ctx->device));
+  CK(hipEventRecord(ctx->t1, ctx->stream)); CK(hipEventSynchronize(ctx->t1)); CK(hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+  return EMAP_OK;
+}
+int emap_enable_stage_timing(emap_ctx* ctx, int enable) { CKARG(ctx, "null ctx"); ctx->stage_timing = enable != 0; ctx->want_ray_stats = enable > 1; return EMAP_OK; }
+int emap_get_stage_times(emap_ctx* ctx, float ms_out[8]) { CKARG(ctx && ms_out, "null argument"); for (int i = 0; i < ST_N; ++i) ms_out[i] = ctx->stage_ms[i]; return EMAP_OK; }
+
+}  // extern "C"

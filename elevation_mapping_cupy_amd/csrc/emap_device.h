@@ -1,0 +1,141 @@
+// Device-side data layout and arithmetic helpers of the MI355X elevation-map fusion core (gfx950 only).
+//
+// HBM layout (DESIGN.md "Data layout"):
+//   Cell  cells[(rows+2*halo) * C]   32 B, one per map cell, cell-interleaved: the 7 planes of the reference's
+//                                    planar (7,C,C) elevation_map (elevation_mapping.py:68-77) in one sector so a
+//                                    point / ray step touches ONE 32-byte sector instead of 7 cache lines.
+//   AccF  acc[...]                   40 B per-cell frame accumulators of the count + fuse passes (integer /
+//                                    fixed-point atomics => bit-reproducible sums).
+//   AccR  accr[...]                  16 B per-cell accumulators of the visibility pass.
+//   float trav_in[...], normal[3][...]  planar (stencil inputs/outputs want unit stride).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EM_BLOCK 256
+
+struct __attribute__((aligned(32))) Cell {
+  float h, v, valid, trav, time, upper, is_upper, pad;
+};
+static_assert(sizeof(Cell) == 32, "cell is one 32-byte sector");
+
+struct AccF {                      // zero == "nothing happened this frame"
+  unsigned long long pts_inl;      // lo32: points per cell (newmap[4]); hi32: drift inliers per cell (newmap[3])
+  unsigned long long cnt_out;      // lo32: accepted points (newmap[2]);  hi32: outliers (number of :174 hits)
+  long long sum_h;                 // sum of new_h, Q31.32
+  long long sum_v;                 // sum of new_v, Q23.40
+  unsigned long long latest;       // ((point index + 1) << 32) | bits(new_h): largest index wins (= sequential :191)
+};
+static_assert(sizeof(AccF) == 40, "AccF");
+
+struct AccR {
+  long long dec;                   // sum of validity decrements (:251), Q23.40 (negative)
+  unsigned int hits;               // number of penetrations (variance += outlier_variance each, :252)
+  unsigned int upper_key;          // ~ordered(nz) maximised == min nz of qualifying visits; 0 = none
+};
+static_assert(sizeof(AccR) == 16, "AccR");
+
+#define EM_ERR_SLOTS 256
+struct __attribute__((aligned(128))) ErrSlot { long long sum; unsigned long long cnt; };  // Q27.36
+
+struct FrameDev {                  // per-frame scalars that stay on the device (no D2H sync in the frame)
+  long long err_sum_fix;           // Q27.36
+  unsigned long long err_cnt;
+  float shift, mean_error, additive_mean_error;
+  int gate_fired;
+  unsigned long long ray_visits;
+  unsigned int n_points, pad;
+};
+
+#define EM_SCALE_H 4294967296.0          /* 2^32 */
+#define EM_SCALE_V 1099511627776.0       /* 2^40 */
+#define EM_SCALE_E 68719476736.0         /* 2^36 */
+
+// Kernel parameters: everything the reference bakes into its kernel strings as literals
+// (custom_kernels.py:264-274), passed as kernargs instead (no JIT, parameters can change per launch).
+struct KP {
+  int C, mode, row0, nrows, halo, edge, dil, pad0;
+  double res, half_w, snf, mt, ov, dcvi_half, trav_inlier, wall, mrl, cs, cos_thresh, mvd2, mhr, ra, rb, rc;
+  double max_var, ray_step;
+  float init_var, ov_f, q_wm1, q_mrl, q_step, time_var, time_int, res_f;
+};
+
+struct Pose {        // R, t of one frame; Rq/tq are the values after the float16 parameter rounding
+  float Rq[9], tq[3], t[3];
+};
+
+template <int MODE> __device__ __forceinline__ float Qf(float x) {
+  if constexpr (MODE == 0) return (float)(_Float16)x; else return x;   // v_cvt_f16_f32 (RNE) + v_cvt_f32_f16
+}
+
+__device__ __forceinline__ int sat_int(double v) {   // CUDA-style saturating conversion, NaN -> 0
+  if (!(v == v)) return 0;
+  v = fmin(fmax(v, -2147483648.0), 2147483647.0);
+  return (int)v;
+}
+
+// get_x_idx/get_y_idx + clamp (custom_kernels.py:22-33,45-49) for an already-rounded coordinate; map centre is 0
+// (the reference always passes center 0: elevation_mapping.py:337-338,359-360).
+template <int MODE> __device__ __forceinline__ int axis_idx(const KP& P, float xq) {
+  int i = sat_int((double)xq / P.res + P.half_w);
+  float fi = Qf<MODE>((float)i);
+  float r = fmaxf(fminf(fi, P.q_wm1), 0.0f);
+  return (int)r;
+}
+
+struct Geo { float x, y, z, v; int ix, iy; bool finite, valid, inside; };
+
+// is_valid (custom_kernels.py:62-81); arguments already rounded
+__device__ __forceinline__ bool is_valid_q(const KP& P, float x, float y, float z, float sx, float sy, float sz) {
+  float dx = x - sx, dy = y - sy, dz = z - sz;
+  float d = dx * dx + dy * dy + dz * dz;
+  float dxy = (float)fmax((double)sqrtf(x * x + y * y) - P.rb, 0.0);
+  if ((double)d < P.mvd2) return false;
+  if ((double)dz > (double)dxy * P.ra + P.rc || (double)dz > P.mhr) return false;
+  return true;
+}
+
+template <int MODE> __device__ __forceinline__ Geo geometry(const KP& P, const Pose& T, float rx, float ry, float rz) {
+  Geo g;
+  g.finite = !(isnan(rx) || isnan(ry) || isnan(rz));
+  float qx = Qf<MODE>(rx), qy = Qf<MODE>(ry), qz = Qf<MODE>(rz);
+  g.x = T.Rq[0] * qx + T.Rq[1] * qy + T.Rq[2] * qz + T.tq[0];   // transform_p :54-57 (contraction is off)
+  g.y = T.Rq[3] * qx + T.Rq[4] * qy + T.Rq[5] * qz + T.tq[1];
+  g.z = T.Rq[6] * qx + T.Rq[7] * qy + T.Rq[8] * qz + T.tq[2];
+  double zz = (double)qz;
+  g.v = (float)(P.snf * zz * zz);                                   // z_noise :58-60
+  float xq = Qf<MODE>(g.x), yq = Qf<MODE>(g.y), zq = Qf<MODE>(g.z);
+  g.ix = axis_idx<MODE>(P, xq);
+  g.iy = axis_idx<MODE>(P, yq);
+  g.valid = is_valid_q(P, xq, yq, zq, T.tq[0], T.tq[1], T.tq[2]);
+  g.inside = !(g.ix == 0 || g.ix == P.C - 1 || g.iy == 0 || g.iy == P.C - 1);  // is_inside :34-44
+  return g;
+}
+
+// local cell index of global (ix, iy) inside this strip, or -1 if the row is not owned
+__device__ __forceinline__ long owned_cell(const KP& P, int ix, int iy) {
+  int lr = ix - P.row0;
+  if (lr < 0 || lr >= P.nrows) return -1;
+  return (long)(lr + P.halo) * P.C + iy;
+}
+
+__device__ __forceinline__ unsigned int float_ord(float f) {       // monotone map float -> uint
+  unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_float(unsigned int o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };
+__device__ __forceinline__ void load_point(const float* __restrict__ pts, long i, int stride, float& x, float& y, float& z) {
+  if (stride == 3) { P3 p = reinterpret_cast<const P3*>(pts)[i]; x = p.x; y = p.y; z = p.z; }
+  else { const float* p = pts + i * (long)stride; x = p[0]; y = p[1]; z = p[2]; }
+}
+
+// 64-lane sum (DPP-free portable form; executed once per wave and only when an inlier exists)
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

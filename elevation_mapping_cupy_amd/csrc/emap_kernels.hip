@@ -1,0 +1,519 @@
+// Hand-written CDNA4 (gfx950) kernels of the elevation-map fusion hot path.
+// Reference semantics: leggedrobotics/elevation_mapping_cupy, EM/kernels/custom_kernels.py (cited per kernel);
+// execution model: the deterministic two-phase contract of DESIGN.md (fuse and ray passes only READ the map and
+// write integer/fixed-point accumulators, per-cell passes commit) -- not a translation of the CuPy kernels.
+// Compiled with -ffp-contract=off: decisions (indices, gates) must be bit-identical to the oracle.
+#include "emap_device.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// Phase A: drift statistics + points-per-cell (error_counting_kernel, custom_kernels.py:280-345)
+// One point per lane, coalesced 12-B xyz loads; one 16-B gather of (h, v, valid, trav); ONE 64-bit atomic per
+// point (points and inliers packed); the two global sums are wave-reduced and spread over 256 slots.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(EM_BLOCK) void k_count(KP P, Pose T, const float* __restrict__ pts, long n, int stride,
+                                                     const Cell* __restrict__ cells, AccF* __restrict__ acc,
+                                                     ErrSlot* __restrict__ slots) {
+  long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  long long e_fix = 0;
+  unsigned int inl = 0;
+  if (i < n) {
+    float rx, ry, rz;
+    load_point(pts, i, stride, rx, ry, rz);
+    Geo g = geometry<MODE>(P, T, rx, ry, rz);
+    long c = (g.finite && g.valid && g.inside) ? owned_cell(P, g.ix, g.iy) : -1;
+    if (c >= 0) {
+      float4 m = *reinterpret_cast<const float4*>(&cells[c]);   // h, v, valid, trav
+      bool inlier = m.z > 0.5f && (double)fabsf(m.x - g.z) < (double)m.y * P.mt && (double)m.y < P.dcvi_half &&
+                    (double)m.w > P.trav_inlier;
+      if (inlier) { inl = 1; e_fix = __double2ll_rn((double)(g.z - m.x) * EM_SCALE_E); }
+      atomicAdd(&acc[c].pts_inl, 1ull | ((unsigned long long)inl << 32));
+    }
+  }
+  if (__any(inl)) {
+    long long s = wave_sum_ll(e_fix);
+    unsigned long long k = __popcll(__ballot(inl));
+    if ((threadIdx.x & 63) == 0) {
+      unsigned int slot = (blockIdx.x * (EM_BLOCK / 64) + (threadIdx.x >> 6)) & (EM_ERR_SLOTS - 1);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&slots[slot].sum), (unsigned long long)s);
+      atomicAdd(&slots[slot].cnt, k);
+    }
+  }
+}
+
+// Phase A': drift gate (elevation_mapping.py:346-357) evaluated on the device by one wave: reduces the slots
+// (integer => order independent), decides the shift, keeps additive_mean_error, re-arms the slots.
+__global__ __launch_bounds__(64) void k_gate(KP P, ErrSlot* __restrict__ slots, FrameDev* __restrict__ F, int enable,
+                                             double min_cnt, double max_drift, float alpha, int noise_ok,
+                                             int use_override, double sum_override, unsigned int cnt_override,
+                                             unsigned int n_points) {
+  long long s = 0; unsigned long long k = 0;
+  for (int j = threadIdx.x; j < EM_ERR_SLOTS; j += 64) { s += slots[j].sum; k += slots[j].cnt; slots[j].sum = 0; slots[j].cnt = 0; }
+  s = wave_sum_ll(s); k = (unsigned long long)wave_sum_ll((long long)k);
+  if (threadIdx.x == 0) {
+    F->err_sum_fix = s; F->err_cnt = k; F->n_points = n_points; F->ray_visits = 0;
+    double sum = use_override ? sum_override : (double)s / EM_SCALE_E;
+    float cnt = use_override ? (float)cnt_override : (float)k;
+    float shift = 0.0f; int fired = 0;
+    if (enable && (double)cnt > min_cnt && noise_ok) {
+      float mean = (float)sum / cnt;
+      fired = 1;
+      F->mean_error = mean;
+      F->additive_mean_error = F->additive_mean_error + mean;
+      if ((double)fabsf(mean) < max_drift) shift = mean * alpha;
+    }
+    F->shift = shift; F->gate_fired = fired;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Phase B: Kalman fusion (add_points_kernel fusion part, custom_kernels.py:160-197) against snapshot S0.
+// Reads (h, v) + points-per-cell, writes ONLY accumulators: <= 4 64-bit integer atomics into one 40-B record.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, bool TAIL>
+__global__ __launch_bounds__(EM_BLOCK) void k_fuse(KP P, Pose T, const float* __restrict__ pts, long n, int stride,
+                                                    const Cell* __restrict__ cells, AccF* __restrict__ acc,
+                                                    const FrameDev* __restrict__ F, int* __restrict__ tail_idx,
+                                                    unsigned char* __restrict__ tail_flags) {
+  long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float rx, ry, rz;
+  load_point(pts, i, stride, rx, ry, rz);
+  Geo g = geometry<MODE>(P, T, rx, ry, rz);
+  if (TAIL) {
+    tail_idx[i] = g.finite ? P.C * g.ix + g.iy : -1;
+    tail_flags[i] = g.finite ? (unsigned char)((g.valid ? 1 : 0) | (g.inside ? 2 : 0)) : 0;
+  }
+  long c = (g.finite && g.valid && g.inside) ? owned_cell(P, g.ix, g.iy) : -1;
+  if (c < 0) return;
+  const float shift = F->shift;
+  float2 hv = *reinterpret_cast<const float2*>(&cells[c]);
+  float map_h = hv.x + shift, map_v = hv.y;
+  float num_points = (float)(unsigned int)(acc[c].pts_inl & 0xffffffffull);
+  if ((double)fabsf(map_h - g.z) > (double)map_v * P.mt) {          // outlier :173-175
+    atomicAdd(&acc[c].cnt_out, 1ull << 32);
+    return;
+  }
+  if (P.edge && (double)num_points > P.wall &&
+      (double)g.z < (double)map_h - (double)map_v * P.mt / (double)num_points) return;   // edge sharpening :177-179
+  float new_h = (map_h * g.v + g.z * map_v) / (map_v + g.v);          // :181-182
+  float new_v = (map_v * g.v) / (map_v + g.v);
+  atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c].sum_h),
+            (unsigned long long)__double2ll_rn((double)new_h * EM_SCALE_H));
+  atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c].sum_v),
+            (unsigned long long)__double2ll_rn((double)new_v * EM_SCALE_V));
+  atomicAdd(&acc[c].cnt_out, 1ull);
+  atomicMax(&acc[c].latest, ((unsigned long long)(i + 1) << 32) | (unsigned long long)__float_as_uint(new_h));
+}
+
+// effects of custom_kernels.py:174 and :189-192 on one cell (-> snapshot S1)
+__device__ __forceinline__ void commit_cell(const KP& P, Cell& c, const AccF& a) {
+  unsigned int cnt = (unsigned int)(a.cnt_out & 0xffffffffull), n_out = (unsigned int)(a.cnt_out >> 32);
+  if (n_out) c.v = c.v + P.ov_f * (float)n_out;
+  if (cnt) { c.valid = 1.0f; c.time = 0.0f; c.upper = __uint_as_float((unsigned int)(a.latest & 0xffffffffull)); c.is_upper = 0.0f; }
+}
+
+// Phase B': materialise S1 (only launched when the visibility pass runs; otherwise folded into k_average)
+__global__ __launch_bounds__(EM_BLOCK) void k_commit(KP P, Cell* __restrict__ cells, const AccF* __restrict__ acc,
+                                                      const FrameDev* __restrict__ F) {
+  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (li >= (long)P.nrows * P.C) return;
+  long c = li + (long)P.halo * P.C;
+  Cell m = cells[c];
+  AccF a = acc[c];
+  m.h += F->shift;
+  commit_cell(P, m, a);
+  cells[c] = m;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Phase C: visibility clean-up (add_points_kernel ray part, custom_kernels.py:198-259) against snapshot S1.
+// One ray per lane; each step gathers ONE 32-byte cell; all effects go to the 16-byte AccR record
+// (fixed-point add / integer add / ordered-uint max) so the result is independent of scheduling.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(EM_BLOCK) void k_rays(KP P, Pose T, const float* __restrict__ pts, long n, int stride,
+                                                    const Cell* __restrict__ cells, const AccF* __restrict__ acc,
+                                                    AccR* __restrict__ accr, const float* __restrict__ normal,
+                                                    long plane_stride, FrameDev* __restrict__ F) {
+  long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  unsigned long long visits = 0;
+  if (i < n) {
+    float rx_, ry_, rz_;
+    load_point(pts, i, stride, rx_, ry_, rz_);
+    Geo g = geometry<MODE>(P, T, rx_, ry_, rz_);
+    if (g.finite && g.valid) {   // invalid points march but never act (:226)
+      // ray_vector (:83-101): every intermediate is a float16 variable in the reference
+      float px = Qf<MODE>(g.x), py = Qf<MODE>(g.y), pz = Qf<MODE>(g.z);
+      float vx = Qf<MODE>(px - T.tq[0]), vy = Qf<MODE>(py - T.tq[1]), vz = Qf<MODE>(pz - T.tq[2]);
+      float norm = Qf<MODE>(sqrtf(vx * vx + vy * vy + vz * vz));
+      float rx = 0.f, ry = 0.f, rz = 0.f;
+      if (norm > 0.f) { rx = Qf<MODE>(vx / norm); ry = Qf<MODE>(vy / norm); rz = Qf<MODE>(vz / norm); }
+      float ray_length = fminf(norm, P.q_mrl);
+      const float dec = (float)(-P.cs / ((double)ray_length / P.mrl));
+      int last = -1;
+      for (float s = P.q_step; s < ray_length; s = Qf<MODE>((float)((double)s + P.ray_step))) {
+        float nx = T.t[0] + rx * s, ny = T.t[1] + ry * s, nz = T.t[2] + rz * s;
+        int ix = axis_idx<MODE>(P, Qf<MODE>(nx)), iy = axis_idx<MODE>(P, Qf<MODE>(ny));
+        int nidx = P.C * ix + iy;
+        if (nidx == last) continue;
+        last = nidx;
+        if (ix == 0 || ix == P.C - 1 || iy == 0 || iy == P.C - 1) continue;
+        long c = owned_cell(P, ix, iy);
+        if (c < 0) continue;                       // other strip's cell: its owner handles it
+        if (STATS) visits++;
+        const float4* cp = reinterpret_cast<const float4*>(&cells[c]);
+        float4 m0 = cp[0], m1 = cp[1];             // h v valid trav | time upper is_upper pad
+        float ddx = g.x - nx, ddy = g.y - ny, ddz = g.z - nz;
+        float d = Qf<MODE>(ddx * ddx + ddy * ddy + ddz * ddz);
+        if ((double)d < 0.1) continue;
+        if (m0.z < 0.5f) {                         // unknown cell: upper bound (:228-234)
+          if (nz < m1.y || m1.z < 0.5f) atomicMax(&accr[c].upper_key, ~float_ord(nz));
+          continue;
+        }
+        if (m1.x < 0.5f) continue;                 // updated recently (:236)
+        if ((double)m0.x > (double)nz + 0.01 - fmin((double)m0.y, 1.0) * 0.05) {
+          float ip = rx * Qf<MODE>(normal[c]) + ry * Qf<MODE>(normal[plane_stride + c]) + rz * Qf<MODE>(normal[2 * plane_stride + c]);
+          if ((double)fabsf(ip) < P.cos_thresh) continue;
+          float n_inl = (float)(unsigned int)(acc[c].pts_inl >> 32);
+          if ((double)n_inl > P.wall && (double)m1.x < 1.0) continue;
+          atomicAdd(reinterpret_cast<unsigned long long*>(&accr[c].dec),
+                    (unsigned long long)__double2ll_rn((double)dec * EM_SCALE_V));
+          atomicAdd(&accr[c].hits, 1u);
+          if (nz < m1.y || m1.z < 0.5f) atomicMax(&accr[c].upper_key, ~float_ord(nz));
+        }
+      }
+    }
+  }
+  if (STATS) {
+    visits = (unsigned long long)wave_sum_ll((long long)visits);
+    if ((threadIdx.x & 63) == 0 && visits) atomicAdd(&F->ray_visits, visits);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Phase D: per-cell commit of ray effects + average_map_kernel (custom_kernels.py:348-389) + drift shift
+// materialisation (elevation_mapping.py:357) + accumulator re-arm (replaces `new_map *= 0`, :327).
+// Streaming: reads 32+40(+16) B, writes 32 B (+zeroes) per cell.
+// ---------------------------------------------------------------------------------------------------------
+template <bool COMMITTED, bool RAYS>
+__global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cell* __restrict__ cells, AccF* __restrict__ acc,
+                                                       AccR* __restrict__ accr, const FrameDev* __restrict__ F) {
+  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (li >= (long)P.nrows * P.C) return;
+  long c = li + (long)P.halo * P.C;
+  Cell m = cells[c];
+  AccF a = acc[c];
+  if (!COMMITTED) { m.h += F->shift; commit_cell(P, m, a); }
+  if (RAYS) {
+    AccR r = accr[c];
+    if (r.hits) { m.valid = m.valid + (float)((double)r.dec / EM_SCALE_V); m.v = m.v + P.ov_f * (float)r.hits; }
+    if (r.upper_key) { m.upper = ord_float(~r.upper_key); m.is_upper = 1.0f; }
+    if (r.hits | r.upper_key) { AccR z = {0, 0u, 0u}; accr[c] = z; }
+  }
+  float valid0 = m.valid;
+  unsigned int cnt = (unsigned int)(a.cnt_out & 0xffffffffull);
+  if (cnt > 0) {
+    float nh = (float)(((double)a.sum_h / EM_SCALE_H) / (double)cnt);
+    float nv = (float)(((double)a.sum_v / EM_SCALE_V) / (double)cnt);
+    if ((double)nv > P.max_var) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; }
+    else { m.h = nh; m.v = nv; m.valid = 1.f; }
+  }
+  if (valid0 < 0.5f) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; }
+  cells[c] = m;
+  if (a.pts_inl | a.cnt_out) { AccF z = {0ull, 0ull, 0ll, 0ll, 0ull}; acc[c] = z; }
+}
+
+// clear_overlap_map (elevation_mapping.py:393-410): centred window, one launch instead of ~12
+__global__ __launch_bounds__(EM_BLOCK) void k_overlap(KP P, Cell* __restrict__ cells, int cmin, int cmax, float hmin, float hmax) {
+  int w = cmax - cmin;
+  long k = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (k >= (long)w * w) return;
+  int ix = cmin + (int)(k / w), iy = cmin + (int)(k % w);
+  long c = owned_cell(P, ix, iy);
+  if (c < 0) return;
+  Cell m = cells[c];
+  bool ch = false;
+  if (m.h < hmin || m.h > hmax) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; ch = true; }
+  if (m.upper < hmin || m.upper > hmax) { m.upper = 0.f; m.is_upper = 0.f; ch = true; }
+  if (ch) cells[c] = m;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dilation_filter_kernel (custom_kernels.py:392-449) as an LDS-tiled stencil: input plane = upper_bound,
+// mask = is_valid + is_upper_bound (elevation_mapping.py:377-383).  A 16x64 tile (+halo d) of (value, mask)
+// is staged in LDS from the 32-B cells with coalesced 2x dwordx4 loads.  The reference addresses neighbours
+// by FLAT index (i + W*dy + dx), so columns within d of the left/right edge can wrap into the adjacent row:
+// those few columns take an exact global-memory path.
+// Output rows: local rows [lr0, lr1) (owned rows, widened by 3 at strip seams for the traversability halo).
+// ---------------------------------------------------------------------------------------------------------
+#define DT_R 16
+#define DT_C 64
+__global__ __launch_bounds__(EM_BLOCK) void k_dilate(KP P, const Cell* __restrict__ cells, float* __restrict__ out,
+                                                      int d, int lr0, int lr1) {
+  extern __shared__ float lds[];
+  const int W = DT_C + 2 * d, pitch = W + 1, H = DT_R + 2 * d;
+  float* sval = lds;
+  float* smsk = lds + (size_t)H * pitch;
+  const int C = P.C;
+  const int tile_r = lr0 + blockIdx.y * DT_R, tile_c = blockIdx.x * DT_C;   // local row / col of tile origin
+  const int total_rows = P.nrows + 2 * P.halo;
+  for (int k = threadIdx.x; k < H * W; k += EM_BLOCK) {
+    int r = k / W, cc = k % W;
+    int lr = tile_r - d + r, col = tile_c - d + cc;
+    int gr = lr - P.halo + P.row0;                                 // global row
+    float val = 0.f, msk = 0.f;
+    if (lr >= 0 && lr < total_rows && gr >= 1 && gr <= C - 2 && col >= 1 && col <= C - 2) {   // is_inside(j)
+      const float4* cp = reinterpret_cast<const float4*>(&cells[(long)lr * C + col]);
+      float4 m0 = cp[0], m1 = cp[1];
+      val = m1.y; msk = m0.z + m1.z;
+    }
+    sval[r * pitch + cc] = val; smsk[r * pitch + cc] = msk;
+  }
+  __syncthreads();
+  const int tc = threadIdx.x & 63, col = tile_c + tc;
+  if (col >= C) return;
+  const bool wrap = (col <= d - 2) || (col >= C + 1 - d);
+  for (int tr = threadIdx.x >> 6; tr < DT_R; tr += EM_BLOCK / 64) {
+    int lr = tile_r + tr;
+    if (lr >= lr1) break;
+    long c = (long)lr * C + col;
+    const float4* cp = reinterpret_cast<const float4*>(&cells[c]);
+    float4 m0 = cp[0], m1 = cp[1];
+    float res = m1.y;
+    if (m0.z + m1.z < 0.5f) {
+      float distance = 100.f, near_value = 0.f;
+      if (!wrap) {
+        for (int dy = -d; dy <= d; ++dy)
+          for (int dx = -d; dx <= d; ++dx) {
+            int o = (tr + d + dy) * pitch + (tc + d + dx);
+            if (smsk[o] > 0.5f && (float)(dx + dy) < distance) { distance = (float)(dx + dy); near_value = sval[o]; }
+          }
+      } else {
+        const long gi = (long)(lr - P.halo + P.row0) * C + col, L = (long)C * C;
+        for (int dy = -d; dy <= d; ++dy)
+          for (int dx = -d; dx <= d; ++dx) {
+            long j = gi + (long)C * dy + dx;
+            if (j < 0 || j >= L) continue;
+            int jr = (int)(j / C), jc = (int)(j % C);
+            if (jr <= 0 || jr >= C - 1 || jc <= 0 || jc >= C - 1) continue;
+            int jl = jr - P.row0 + P.halo;
+            if (jl < 0 || jl >= total_rows) continue;
+            const float4* np = reinterpret_cast<const float4*>(&cells[(long)jl * C + jc]);
+            float4 n0 = np[0], n1 = np[1];
+            if (n0.z + n1.z > 0.5f && (float)(dx + dy) < distance) { distance = (float)(dx + dy); near_value = n1.y; }
+          }
+      }
+      if (distance < 100.f) res = near_value;
+    }
+    out[c] = res;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// traversability filter (traversability_filter.py:8-47: three dilated 3x3 correlations x 4 channels, abs,
+// 1x1, exp(-x); elevation_mapping.py:385-388) fused with normal_filter_kernel (custom_kernels.py:452-506):
+// both consume the dilated plane, so one LDS tile (halo 3) feeds both.  Weights live in kernargs (SGPRs).
+// ---------------------------------------------------------------------------------------------------------
+struct TravW { float w[3][36]; float wo[12]; };
+#define TT_R 16
+#define TT_C 64
+__global__ __launch_bounds__(EM_BLOCK) void k_trav_normal(KP P, TravW Wt, const float* __restrict__ in, Cell* __restrict__ cells,
+                                                           float* __restrict__ normal, long plane_stride) {
+  __shared__ float tile[(TT_R + 6) * (TT_C + 6 + 1)];
+  const int pitch = TT_C + 6 + 1, C = P.C;
+  const int tile_r = P.halo + blockIdx.y * TT_R, tile_c = blockIdx.x * TT_C;
+  const int total_rows = P.nrows + 2 * P.halo;
+  for (int k = threadIdx.x; k < (TT_R + 6) * (TT_C + 6); k += EM_BLOCK) {
+    int r = k / (TT_C + 6), cc = k % (TT_C + 6);
+    int lr = tile_r - 3 + r, col = tile_c - 3 + cc;
+    float v = 0.f;
+    if (lr >= 0 && lr < total_rows && col >= 0 && col < C) v = in[(long)lr * C + col];
+    tile[r * pitch + cc] = v;
+  }
+  __syncthreads();
+  const int tc = threadIdx.x & 63, col = tile_c + tc;
+  if (col >= C) return;
+  for (int tr = threadIdx.x >> 6; tr < TT_R; tr += EM_BLOCK / 64) {
+    int lr = tile_r + tr;
+    if (lr >= P.halo + P.nrows) break;
+    int gr = lr - P.halo + P.row0;
+    long c = (long)lr * C + col;
+    const float* t0 = &tile[(tr + 3) * pitch + (tc + 3)];
+    if (gr >= 3 && gr <= C - 4 && col >= 3 && col <= C - 4) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int dl = k + 1;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+          float s = 0.f;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) s += Wt.w[k][ch * 9 + a * 3 + b] * t0[(a - 1) * dl * pitch + (b - 1) * dl];
+          acc += Wt.wo[k * 4 + ch] * fabsf(s);
+        }
+      }
+      cells[c].trav = expf(-acc);
+    }
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (gr >= 1 && gr <= C - 3 && col >= 1 && col <= C - 3 && cells[c].valid > 0.5f) {
+      float h = t0[0], dzdx = t0[1] - h, dzdy = t0[pitch] - h;
+      float ax = -dzdy / P.res_f, ay = -dzdx / P.res_f;
+      float nrm = sqrtf((ax * ax) + (ay * ay) + 1.0f);
+      nx = ax / nrm; ny = ay / nrm; nz = 1.0f / nrm;
+    }
+    normal[c] = nx; normal[plane_stride + c] = ny; normal[2 * plane_stride + c] = nz;
+  }
+}
+
+// update_variance + update_time (elevation_mapping.py:420-426)
+__global__ __launch_bounds__(EM_BLOCK) void k_var_time(KP P, Cell* __restrict__ cells, int do_var, int do_time) {
+  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (li >= (long)P.nrows * P.C) return;
+  Cell* m = &cells[li + (long)P.halo * P.C];
+  if (do_var) m->v = m->v + P.time_var * m->valid;
+  if (do_time) m->time = m->time + P.time_int;
+}
+
+// ---- state access helpers --------------------------------------------------------------------------------
+__global__ __launch_bounds__(EM_BLOCK) void k_get_plane(KP P, const Cell* __restrict__ cells, int word, float* __restrict__ out) {
+  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (li >= (long)P.nrows * P.C) return;
+  out[li] = reinterpret_cast<const float*>(&cells[li + (long)P.halo * P.C])[word];
+}
+__global__ __launch_bounds__(EM_BLOCK) void k_set_plane(KP P, Cell* __restrict__ cells, int word, const float* __restrict__ in) {
+  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (li >= (long)P.nrows * P.C) return;
+  reinterpret_cast<float*>(&cells[li + (long)P.halo * P.C])[word] = in[li];
+}
+__global__ __launch_bounds__(EM_BLOCK) void k_fill_cells(Cell* __restrict__ cells, long n, Cell v) {
+  long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i < n) cells[i] = v;
+}
+__global__ __launch_bounds__(EM_BLOCK) void k_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, long n) {
+  long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+template <int MODE>
+__global__ __launch_bounds__(EM_BLOCK) void k_point_index(KP P, Pose T, const float* __restrict__ pts, long n, int stride,
+                                                           int* __restrict__ idx, unsigned char* __restrict__ flags) {
+  long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float rx, ry, rz;
+  load_point(pts, i, stride, rx, ry, rz);
+  Geo g = geometry<MODE>(P, T, rx, ry, rz);
+  idx[i] = g.finite ? P.C * g.ix + g.iy : -1;
+  flags[i] = g.finite ? (unsigned char)((g.valid ? 1 : 0) | (g.inside ? 2 : 0)) : 0;
+}
+
+// shift_map_xy (elevation_mapping.py:200-214): roll + pad into a second buffer; shift_map_z (:216-226)
+__global__ __launch_bounds__(EM_BLOCK) void k_shift(KP P, const Cell* __restrict__ src, Cell* __restrict__ dst, int sr, int sc, float dz) {
+  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  const int C = P.C;
+  if (li >= (long)C * C) return;
+  int r = (int)(li / C), c = (int)(li % C);
+  int pr = r - sr, pc = c - sc;   // cupy.roll: out[r] = in[(r - shift) mod C]
+  bool pad = (sr > 0 && r < sr) || (sr < 0 && r >= C + sr) || (sc > 0 && c < sc) || (sc < 0 && c >= C + sc);
+  Cell m;
+  if (pad) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; m.trav = 0.f; m.time = 0.f; m.upper = 0.f; m.is_upper = 0.f; m.pad = 0.f; }
+  else { pr = ((pr % C) + C) % C; pc = ((pc % C) + C) % C; m = src[(long)pr * C + pc]; }
+  m.h += dz; m.upper += dz;
+  dst[li] = m;
+}
+
+// halo rows: contiguous 32-B cells, so pack/unpack are plain device copies done by the host API.
+
+// ---- launch wrappers used by emap_api.hip -------------------------------------------------------------
+static inline unsigned int nblk(long n) { return (unsigned int)((n + EM_BLOCK - 1) / EM_BLOCK); }
+
+void launch_count(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, const Cell* cells,
+                  AccF* acc, ErrSlot* slots) {
+  if (n <= 0) return;
+  if (P.mode == 0) hipLaunchKernelGGL(k_count<0>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, slots);
+  else hipLaunchKernelGGL(k_count<1>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, slots);
+}
+void launch_gate(hipStream_t s, const KP& P, ErrSlot* slots, FrameDev* F, int enable, double min_cnt, double max_drift,
+                 float alpha, int noise_ok, int use_override, double sum_override, unsigned int cnt_override, unsigned int n_points) {
+  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, P, slots, F, enable, min_cnt, max_drift, alpha, noise_ok, use_override,
+                     sum_override, cnt_override, n_points);
+}
+void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, const Cell* cells, AccF* acc,
+                 const FrameDev* F, int* tail_idx, unsigned char* tail_flags) {
+  if (n <= 0) return;
+  dim3 g(nblk(n)), b(EM_BLOCK);
+  if (tail_idx) {
+    if (P.mode == 0) hipLaunchKernelGGL((k_fuse<0, true>), g, b, 0, s, P, T, pts, n, stride, cells, acc, F, tail_idx, tail_flags);
+    else hipLaunchKernelGGL((k_fuse<1, true>), g, b, 0, s, P, T, pts, n, stride, cells, acc, F, tail_idx, tail_flags);
+  } else {
+    if (P.mode == 0) hipLaunchKernelGGL((k_fuse<0, false>), g, b, 0, s, P, T, pts, n, stride, cells, acc, F, tail_idx, tail_flags);
+    else hipLaunchKernelGGL((k_fuse<1, false>), g, b, 0, s, P, T, pts, n, stride, cells, acc, F, tail_idx, tail_flags);
+  }
+}
+void launch_commit(hipStream_t s, const KP& P, Cell* cells, const AccF* acc, const FrameDev* F) {
+  hipLaunchKernelGGL(k_commit, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, acc, F);
+}
+void launch_rays(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, const Cell* cells,
+                 const AccF* acc, AccR* accr, const float* normal, long plane_stride, FrameDev* F, bool stats) {
+  if (n <= 0) return;
+  dim3 g(nblk(n)), b(EM_BLOCK);
+  if (P.mode == 0) {
+    if (stats) hipLaunchKernelGGL((k_rays<0, true>), g, b, 0, s, P, T, pts, n, stride, cells, acc, accr, normal, plane_stride, F);
+    else hipLaunchKernelGGL((k_rays<0, false>), g, b, 0, s, P, T, pts, n, stride, cells, acc, accr, normal, plane_stride, F);
+  } else {
+    if (stats) hipLaunchKernelGGL((k_rays<1, true>), g, b, 0, s, P, T, pts, n, stride, cells, acc, accr, normal, plane_stride, F);
+    else hipLaunchKernelGGL((k_rays<1, false>), g, b, 0, s, P, T, pts, n, stride, cells, acc, accr, normal, plane_stride, F);
+  }
+}
+void launch_average(hipStream_t s, const KP& P, Cell* cells, AccF* acc, AccR* accr, const FrameDev* F, bool committed, bool rays) {
+  dim3 g(nblk((long)P.nrows * P.C)), b(EM_BLOCK);
+  if (committed) {
+    if (rays) hipLaunchKernelGGL((k_average<true, true>), g, b, 0, s, P, cells, acc, accr, F);
+    else hipLaunchKernelGGL((k_average<true, false>), g, b, 0, s, P, cells, acc, accr, F);
+  } else {
+    if (rays) hipLaunchKernelGGL((k_average<false, true>), g, b, 0, s, P, cells, acc, accr, F);
+    else hipLaunchKernelGGL((k_average<false, false>), g, b, 0, s, P, cells, acc, accr, F);
+  }
+}
+void launch_overlap(hipStream_t s, const KP& P, Cell* cells, int cmin, int cmax, float hmin, float hmax) {
+  long w = cmax - cmin;
+  if (w <= 0) return;
+  hipLaunchKernelGGL(k_overlap, dim3(nblk(w * w)), dim3(EM_BLOCK), 0, s, P, cells, cmin, cmax, hmin, hmax);
+}
+void launch_dilate(hipStream_t s, const KP& P, const Cell* cells, float* out, int d, int lr0, int lr1) {
+  dim3 g((P.C + DT_C - 1) / DT_C, (lr1 - lr0 + DT_R - 1) / DT_R), b(EM_BLOCK);
+  size_t lds = (size_t)2 * (DT_R + 2 * d) * (DT_C + 2 * d + 1) * sizeof(float);
+  hipLaunchKernelGGL(k_dilate, g, b, lds, s, P, cells, out, d, lr0, lr1);
+}
+void launch_trav_normal(hipStream_t s, const KP& P, const float* w1, const float* w2, const float* w3, const float* wo,
+                        const float* in, Cell* cells, float* normal, long plane_stride) {
+  TravW W;
+  for (int i = 0; i < 36; ++i) { W.w[0][i] = w1[i]; W.w[1][i] = w2[i]; W.w[2][i] = w3[i]; }
+  for (int i = 0; i < 12; ++i) W.wo[i] = wo[i];
+  dim3 g((P.C + TT_C - 1) / TT_C, (P.nrows + TT_R - 1) / TT_R), b(EM_BLOCK);
+  hipLaunchKernelGGL(k_trav_normal, g, b, 0, s, P, W, in, cells, normal, plane_stride);
+}
+void launch_var_time(hipStream_t s, const KP& P, Cell* cells, int do_var, int do_time) {
+  hipLaunchKernelGGL(k_var_time, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, do_var, do_time);
+}
+void launch_get_plane(hipStream_t s, const KP& P, const Cell* cells, int word, float* out) {
+  hipLaunchKernelGGL(k_get_plane, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, word, out);
+}
+void launch_set_plane(hipStream_t s, const KP& P, Cell* cells, int word, const float* in) {
+  hipLaunchKernelGGL(k_set_plane, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, word, in);
+}
+void launch_fill_cells(hipStream_t s, Cell* cells, long n, const Cell& v) {
+  hipLaunchKernelGGL(k_fill_cells, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, cells, n, v);
+}
+void launch_f64_to_f32(hipStream_t s, const double* in, float* out, long n) {
+  if (n > 0) hipLaunchKernelGGL(k_f64_to_f32, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, in, out, n);
+}
+void launch_point_index(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, int* idx, unsigned char* flags) {
+  if (n <= 0) return;
+  if (P.mode == 0) hipLaunchKernelGGL(k_point_index<0>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, idx, flags);
+  else hipLaunchKernelGGL(k_point_index<1>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, idx, flags);
+}
+void launch_shift(hipStream_t s, const KP& P, const Cell* src, Cell* dst, int sr, int sc, float dz) {
+  hipLaunchKernelGGL(k_shift, dim3(nblk((long)P.C * P.C)), dim3(EM_BLOCK), 0, s, P, src, dst, sr, sc, dz);
+}

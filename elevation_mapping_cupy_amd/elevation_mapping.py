@@ -1,0 +1,391 @@
+"""``ElevationMap`` -- host-side mirror of the reference's map object for the point-cloud hot path.
+
+Same method names / argument meaning as the reference class (reference EM/elevation_mapping.py:49-922) so the
+ROS wrapper (src/elevation_mapping_wrapper.cpp:173-252) and the reference's tests drive it unchanged; the map
+itself lives in HBM inside ``libemap_hip.so`` (C ABI ``include/emap_hip.h``).  NumPy is used for host arrays only;
+there is no CuPy, no PyTorch and no CPU compute fallback here.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+import threading
+from typing import List
+
+import numpy as np
+
+from . import _lib
+from ._lib import EmapError, EmapParams, EmapStats, EmapStrip, PLANES, f32p
+from .parameter import Parameter
+
+
+class ElevationMap:
+    """Core elevation mapping class (MI355X backend)."""
+
+    layer_names_core = ["elevation", "variance", "is_valid", "traversability", "time", "upper_bound", "is_upper_bound"]
+
+    def __init__(self, param: Parameter, strip=None, stream=None):
+        """
+        Args:
+            param: ``Parameter`` (``update()`` is called if ``cell_n`` is unset).
+            strip: optional ``(row_begin, row_count, halo_rows)`` for row-strip multi-GPU contexts.
+            stream: optional raw ``hipStream_t`` (int) to enqueue on, e.g. ``torch.cuda.current_stream().cuda_stream``.
+        """
+        if param.cell_n is None:
+            param.update()
+        self.param = param
+        self.data_type = np.float32
+        self.resolution = param.resolution
+        self.center = np.zeros(3, dtype=np.float32)
+        self.base_rotation = np.eye(3, dtype=np.float32)
+        self.map_length = param.map_length
+        self.cell_n = int(param.cell_n)
+        self.map_lock = threading.Lock()
+        self.layer_names = list(self.layer_names_core)
+        self.initial_variance = param.initial_variance
+        self.mean_error = 0.0
+        self.additive_mean_error = 0.0
+        mode = param.index_mode
+        if mode == "auto":
+            mode = "reference_fp16" if self.cell_n <= 2049 else "fp32"
+        self.index_mode = mode
+
+        # traversability weights: same file format as the reference (elevation_mapping.py:103-104)
+        wf = os.path.expandvars(os.path.expanduser(param.weight_file or ""))
+        if wf and os.path.isfile(wf):
+            param.load_weights(wf)
+
+        # overlap clearance window (reference :88-91) -- recomputed inside the library, kept for API parity
+        cell_range = int(np.clip(int(param.overlap_clear_range_xy / self.resolution), 0, self.cell_n))
+        self.cell_min = self.cell_n // 2 - cell_range // 2
+        self.cell_max = self.cell_n // 2 + cell_range // 2
+
+        self._lib = _lib.load()
+        self._strip = None
+        if strip is not None:
+            self._strip = EmapStrip(int(strip[0]), int(strip[1]), int(strip[2]), 0)
+        self.rows = self.cell_n if strip is None else int(strip[1])
+        self.row_begin = 0 if strip is None else int(strip[0])
+        self._ctx = ct.c_void_p()
+        P = _lib.fill_params(param, self.cell_n, mode)
+        rc = self._lib.emap_create(ct.byref(P), ct.byref(self._strip) if self._strip is not None else None,
+                                   int(param.device), ct.c_void_p(stream or 0), ct.byref(self._ctx))
+        if rc != 0:
+            self._ctx = ct.c_void_p()
+            raise EmapError("emap_create failed with status %d (no usable HIP device / invalid parameters); "
+                            "the MI355X backend has no CPU fallback" % rc)
+        self._params_struct = P
+        self.traversability_buffer = np.full((self.rows, self.cell_n), np.nan, np.float32)
+
+        # managers are optional layers on top of the hot path (built lazily; see semantic_map / plugins)
+        self.semantic_map = None
+        self.plugin_manager = None
+        try:
+            from .semantic_map import SemanticMap
+            self.semantic_map = SemanticMap(self.param, self)
+        except ImportError:
+            pass
+
+    # ------------------------------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise EmapError("libemap_hip call failed (%d): %s" % (rc, self._lib.emap_last_error(self._ctx).decode()))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None) and self._ctx.value:
+                self._lib.emap_destroy(self._ctx)
+                self._ctx = ct.c_void_p()
+        except Exception:
+            pass
+
+    def close(self):
+        self.__del__()
+
+    def reload_params(self):
+        """Push changed ``self.param`` scalars to the device (kernargs, no recompilation)."""
+        P = _lib.fill_params(self.param, self.cell_n, self.index_mode)
+        self._chk(self._lib.emap_set_params(self._ctx, ct.byref(P)))
+        self._params_struct = P
+
+    # ---- state access ------------------------------------------------------------------------------
+    def get_layer_raw(self, name_or_id):
+        """Raw device plane as a host ``(rows, cell_n)`` float32 array."""
+        pid = PLANES[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+        out = np.empty((self.rows, self.cell_n), np.float32)
+        self._chk(self._lib.emap_get_layer(self._ctx, pid, f32p(out)))
+        return out
+
+    def set_layer_raw(self, name_or_id, array):
+        pid = PLANES[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+        a = np.ascontiguousarray(array, np.float32)
+        assert a.shape == (self.rows, self.cell_n), a.shape
+        self._chk(self._lib.emap_set_layer(self._ctx, pid, f32p(a)))
+
+    @property
+    def elevation_map(self):
+        """Host copy of the planar ``(7, cell_n, cell_n)`` map (reference attribute, elevation_mapping.py:67)."""
+        return np.stack([self.get_layer_raw(k) for k in range(7)], axis=0)
+
+    @elevation_map.setter
+    def elevation_map(self, value):
+        value = np.asarray(value, np.float32)
+        for k in range(7):
+            self.set_layer_raw(k, value[k])
+
+    @property
+    def normal_map(self):
+        return np.stack([self.get_layer_raw(k) for k in (7, 8, 9)], axis=0)
+
+    @normal_map.setter
+    def normal_map(self, value):
+        value = np.asarray(value, np.float32)
+        for j, k in enumerate((7, 8, 9)):
+            self.set_layer_raw(k, value[j])
+
+    @property
+    def traversability_input(self):
+        return self.get_layer_raw(10)
+
+    # ---- reference API -----------------------------------------------------------------------------
+    def clear(self):
+        """Reset all layers (reference :119-128)."""
+        with self.map_lock:
+            self._chk(self._lib.emap_clear(self._ctx))
+            if self.semantic_map is not None:
+                self.semantic_map.clear()
+        self.mean_error = 0.0
+        self.additive_mean_error = 0.0
+
+    def get_position(self, position):
+        position[0][:] = self.center
+
+    def move(self, delta_position):
+        """Relative shift (reference :139-152 -- note the sign convention differs from move_to)."""
+        delta_position = np.asarray(delta_position, np.float32)
+        delta_pixel = np.round(delta_position[:2] / np.float32(self.resolution))
+        self.center[:2] += (delta_pixel * np.float32(self.resolution)).astype(np.float32)
+        self.center[2] += delta_position[2]
+        self._shift(delta_pixel, -float(delta_position[2]))
+
+    def move_to(self, position, R):
+        """Absolute shift + base rotation update (reference :154-170)."""
+        self.base_rotation = np.asarray(R, dtype=np.float32)
+        position = np.asarray(position, np.float32)
+        delta = position - self.center
+        delta_pixel = np.around(delta[:2] / np.float32(self.resolution))
+        self.center[:2] += (delta_pixel * np.float32(self.resolution)).astype(np.float32)
+        self.center[2] += delta[2]
+        self._shift(-delta_pixel, -float(delta[2]))
+
+    def _shift(self, delta_pixel, dz):
+        sv = np.asarray(delta_pixel).astype(np.int32)
+        with self.map_lock:
+            self._chk(self._lib.emap_shift(self._ctx, int(sv[0]), int(sv[1]), ct.c_float(dz)))
+            if self.semantic_map is not None and np.abs(sv).sum() != 0:
+                self.semantic_map.shift_map_xy(sv)
+
+    def shift_map_xy(self, delta_pixel):
+        self._shift(delta_pixel, 0.0)
+
+    def shift_map_z(self, delta_z):
+        self._shift(np.zeros(2), float(delta_z))
+
+    def shift_translation_to_map_center(self, t):
+        t -= self.center
+
+    def bind_points(self, points_all):
+        """Upload a host cloud ``(N, 3+K)`` (float32 or float64) and bind it for the next stage calls."""
+        pts = np.asarray(points_all)
+        if pts.dtype == np.float64:
+            pts = np.ascontiguousarray(pts)
+            dtype = 1
+        else:
+            pts = np.ascontiguousarray(pts, np.float32)
+            dtype = 0
+        assert pts.ndim == 2 and pts.shape[1] >= 3
+        self._chk(self._lib.emap_upload_points(self._ctx, ct.c_void_p(pts.ctypes.data), ct.c_int64(pts.shape[0]),
+                                               ct.c_int64(pts.shape[1]), dtype))
+        self._n_bound = pts.shape[0]
+        self._bound_host = pts
+
+    def bind_points_device(self, dev_ptr, n, stride):
+        """Bind a device-resident float32 cloud (raw pointer) without copying."""
+        self._chk(self._lib.emap_set_points_device(self._ctx, ct.c_void_p(dev_ptr), ct.c_int64(n), ct.c_int64(stride)))
+        self._n_bound = n
+        self._bound_host = None
+
+    @staticmethod
+    def _rt(R, t):
+        R = np.ascontiguousarray(np.asarray(R, np.float32).reshape(9))
+        t = np.ascontiguousarray(np.asarray(t, np.float32).reshape(3))
+        return R, t
+
+    def update_map_with_kernel(self, points_all, channels, R, t, position_noise, orientation_noise, want_stats=True):
+        """One frame (reference :316-391).  ``points_all``: host ``(N, 3+K)`` array or ``None`` to reuse the bound
+        cloud; ``t`` is shifted to the map centre in place like the reference does (:333)."""
+        if points_all is not None:
+            self.bind_points(points_all)
+        R, t32 = self._rt(R, t)
+        with self.map_lock:
+            t32 = t32 - self.center
+            try:
+                t -= self.center  # reference mutates the caller's array
+            except TypeError:
+                pass
+            st = EmapStats()
+            self._chk(self._lib.emap_update(self._ctx, f32p(R), f32p(t32), ct.c_double(position_noise),
+                                            ct.c_double(orientation_noise), ct.byref(st) if want_stats else None))
+            if want_stats:
+                self._take_stats(st)
+            if self.semantic_map is not None and channels:
+                self.semantic_map.update_layers_pointcloud(self, channels, R, t32)
+        return st if want_stats else None
+
+    def _take_stats(self, st):
+        if st.gate_fired:
+            self.mean_error = float(st.mean_error)
+        self.additive_mean_error = float(st.additive_mean_error)
+        self.last_stats = st
+
+    def clear_overlap_map(self, t):
+        self._chk(self._lib.emap_overlap_clear(self._ctx, ct.c_float(float(np.asarray(t, np.float32).reshape(3)[2]))))
+
+    def get_additive_mean_error(self):
+        st = EmapStats()
+        self._chk(self._lib.emap_get_stats(self._ctx, ct.byref(st)))
+        self.additive_mean_error = float(st.additive_mean_error)
+        return self.additive_mean_error
+
+    def update_variance(self):
+        self._chk(self._lib.emap_update_variance(self._ctx))
+
+    def update_time(self):
+        self._chk(self._lib.emap_update_time(self._ctx))
+
+    def update_upper_bound_with_valid_elevation(self):
+        m = self.elevation_map
+        mask = m[2] > 0.5
+        self.set_layer_raw(5, np.where(mask, m[0], m[5]))
+        self.set_layer_raw(6, np.where(mask, 0.0, m[6]))
+
+    def input_pointcloud(self, raw_points, channels: List[str], R, t, position_noise: float, orientation_noise: float):
+        """Entry point used by the ROS wrapper (reference :434-466).  NaN rows are skipped inside the kernels
+        instead of being compacted on the host (:458)."""
+        additional_channels = list(channels[3:])
+        self.update_map_with_kernel(raw_points, additional_channels, np.asarray(R, np.float32),
+                                    np.asarray(t, np.float32).copy(), position_noise, orientation_noise)
+
+    input = input_pointcloud  # name used by the C++ wrapper (src/elevation_mapping_wrapper.cpp:173-178)
+
+    # ---- stage-level API (parity tests; same order as update_map_with_kernel) ----------------------
+    def stage(self, name, R=None, t=None, **kw):
+        L = self._lib
+        if name in ("count", "fuse", "rays"):
+            R, t = self._rt(R, t)
+            self._chk(getattr(L, "emap_" + name)(self._ctx, f32p(R), f32p(t)))
+        elif name == "gate":
+            s, c = kw.get("err_sum"), kw.get("err_cnt")
+            self._chk(L.emap_set_drift_inputs(self._ctx, ct.c_double(kw.get("position_noise", 0.0)),
+                                              ct.c_double(kw.get("orientation_noise", 0.0)),
+                                              ct.byref(ct.c_double(s)) if s is not None else None,
+                                              ct.byref(ct.c_uint32(c)) if c is not None else None))
+        elif name == "overlap":
+            self._chk(L.emap_overlap_clear(self._ctx, ct.c_float(float(t))))
+        elif name in ("commit", "average", "dilate", "traversability_normals", "update_variance", "update_time"):
+            self._chk(getattr(L, "emap_" + name)(self._ctx))
+        else:
+            raise ValueError(name)
+
+    def stats(self):
+        st = EmapStats()
+        self._chk(self._lib.emap_get_stats(self._ctx, ct.byref(st)))
+        return st
+
+    def point_index(self, R, t):
+        """(idx, valid, inside) per bound point -- tail of add_points_kernel (custom_kernels.py:260-262)."""
+        R, t = self._rt(R, t)
+        n = self._n_bound
+        idx, valid, inside = np.empty(n, np.int32), np.empty(n, np.uint8), np.empty(n, np.uint8)
+        self._chk(self._lib.emap_point_index(self._ctx, f32p(R), f32p(t), idx.ctypes.data_as(ct.c_void_p),
+                                             valid.ctypes.data_as(ct.c_void_p), inside.ctypes.data_as(ct.c_void_p)))
+        return idx, valid, inside
+
+    def sync(self):
+        self._chk(self._lib.emap_sync(self._ctx))
+
+    # ---- read-back (reference :579-775) ----------------------------------------------------------
+    def exists_layer(self, name):
+        if name in self.layer_names:
+            return True
+        if self.semantic_map is not None and name in self.semantic_map.layer_names:
+            return True
+        if self.plugin_manager is not None and name in self.plugin_manager.layer_names:
+            return True
+        return False
+
+    def _publish(self, m, fill_nan=False, add_z=False, valid=None):
+        m = m.copy()
+        if fill_nan:
+            m = np.where(valid > 0.5, m, np.nan)
+        if add_z:
+            m = m + self.center[2]
+        return m[1:-1, 1:-1]
+
+    def get_map_with_name_ref(self, name, data):
+        """Fill ``data`` (float32, ``(cell_n-2, cell_n-2)``) in place: border stripped, both axes flipped
+        (reference :720-775)."""
+        with self.map_lock:
+            if name == "elevation":
+                m = self._publish(self.get_layer_raw(0), True, True, self.get_layer_raw(2))
+            elif name == "variance":
+                m = self._publish(self.get_layer_raw(1))
+            elif name == "traversability":
+                trav = np.where((self.get_layer_raw(2) + self.get_layer_raw(6)) > 0.5, self.get_layer_raw(3), np.nan)
+                self.traversability_buffer[3:-3, 3:-3] = trav[3:-3, 3:-3]
+                m = self.traversability_buffer[1:-1, 1:-1]
+            elif name == "time":
+                m = self._publish(self.get_layer_raw(4))
+            elif name in ("upper_bound", "is_upper_bound"):
+                e = self.elevation_map
+                if self.param.use_only_above_for_upper_bound:
+                    valid = np.logical_or(np.logical_and(e[5] > 0.0, e[6] > 0.5), e[2] > 0.5)
+                else:
+                    valid = np.logical_or(e[2] > 0.5, e[6] > 0.5)
+                if name == "upper_bound":
+                    m = np.where(valid, e[5], np.nan)[1:-1, 1:-1] + self.center[2]
+                else:
+                    m = np.where(valid, e[6], np.nan)[1:-1, 1:-1]
+            elif name in ("normal_x", "normal_y", "normal_z"):
+                m = self.get_layer_raw(name)[1:-1, 1:-1]
+            elif self.semantic_map is not None and name in self.semantic_map.layer_names:
+                m = self.semantic_map.get_map_with_name(name)[1:-1, 1:-1]
+            elif self.plugin_manager is not None and name in self.plugin_manager.layer_names:
+                self.plugin_manager.update_with_name(
+                    name, self.elevation_map, self.layer_names,
+                    self.semantic_map.semantic_map if self.semantic_map is not None else None,
+                    self.semantic_map.layer_names if self.semantic_map is not None else [],
+                    self.base_rotation, self.semantic_map.elements_to_shift if self.semantic_map is not None else {})
+                m = self.plugin_manager.get_map_with_name(name)
+                p = self.plugin_manager.get_param_with_name(name)
+                m = self._publish(np.asarray(m), p.fill_nan, p.is_height_layer, self.get_layer_raw(2))
+            else:
+                print("Layer {} is not in the map".format(name))
+                return
+        m = np.flip(np.flip(m, 0), 1)
+        data[...] = m.astype(np.float32)
+
+    def get_normal_ref(self, normal_x_data, normal_y_data, normal_z_data):
+        n = self.normal_map[:, 1:-1, 1:-1]
+        n = np.flip(np.flip(n, 1), 2)
+        normal_x_data[...] = n[0]
+        normal_y_data[...] = n[1]
+        normal_z_data[...] = n[2]
+
+    def get_layer(self, name):
+        """Raw (unflipped, unstripped) layer by name (reference :777-791)."""
+        if name in self.layer_names:
+            return self.get_layer_raw(self.layer_names.index(name))
+        if self.semantic_map is not None and name in self.semantic_map.layer_names:
+            return self.semantic_map.get_map_with_name(name)
+        return None

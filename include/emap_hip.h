@@ -1,0 +1,141 @@
+/* emap_hip.h -- C ABI of the MI355X (gfx950) elevation-map fusion core.
+ *
+ * The reference (leggedrobotics/elevation_mapping_cupy) has no C FFI: its numeric core is a set of CuPy
+ * ElementwiseKernels JIT-compiled from strings and driven by the Python class ElevationMap.  This header is
+ * the drop-in boundary a maintainer binds instead (ctypes stub in INTEGRATION.md); every entry point cites
+ * the reference interface it replaces.  `EM/` = elevation_mapping_cupy/script/elevation_mapping_cupy/.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * emap_status; nothing throws; no global state; one HIP stream per context; a context is
+ * thread-compatible (callers serialise per context, as the reference does with map_lock).
+ * Host pointers are borrowed for the duration of the call; the context owns all device memory.
+ */
+#ifndef EMAP_HIP_H_
+#define EMAP_HIP_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMAP_ABI_VERSION 1
+
+typedef enum {
+  EMAP_OK = 0,
+  EMAP_ERR_INVALID = -1,   /* bad argument */
+  EMAP_ERR_HIP = -2,       /* HIP runtime error, see emap_last_error */
+  EMAP_ERR_NO_POINTS = -3, /* stage needs a point cloud but none is bound */
+  EMAP_ERR_UNSUPPORTED = -4
+} emap_status;
+
+/* index/rounding mode: 0 reproduces the reference's CuPy float16 helper-parameter rounding
+ * bit for bit (valid for cell_n <= 2049); 1 = the same source with float16 := float (any cell_n). */
+enum { EMAP_MODE_REFERENCE_FP16 = 0, EMAP_MODE_FP32 = 1 };
+
+/* Mirrors the scalar fields of the reference's Parameter dataclass (EM/parameter.py:137-216) that the hot
+ * path bakes into its kernels (EM/elevation_mapping.py:228-282).  Doubles hold the Python floats exactly. */
+typedef struct emap_params {
+  int32_t cell_n;                    /* map side incl. the 1-cell border (parameter.py:287) */
+  int32_t mode;                      /* EMAP_MODE_* */
+  int32_t enable_edge_sharpen, enable_visibility_cleanup, enable_drift_compensation, enable_overlap_clearance;
+  int32_t dilation_size, pad_;
+  double resolution, sensor_noise_factor, mahalanobis_thresh, outlier_variance;
+  double drift_compensation_variance_inlier, traversability_inlier, wall_num_thresh, max_ray_length;
+  double cleanup_step, cleanup_cos_thresh, min_valid_distance, max_height_range;
+  double ramped_height_range_a, ramped_height_range_b, ramped_height_range_c, max_variance;
+  double initial_variance, time_variance, time_interval, min_height_drift_cnt;
+  double max_drift, drift_compensation_alpha, position_noise_thresh, orientation_noise_thresh;
+  double overlap_clear_range_xy, overlap_clear_range_z, ray_step, reserved_;
+  float w1[36], w2[36], w3[36], w_out[12]; /* traversability filter weights (EM/traversability_filter.py:15-24) */
+} emap_params;
+
+/* Row-strip placement of this context inside the global map (single GPU: row_begin 0, row_count cell_n,
+ * halo_rows 0).  Cell index = cell_n * ix + iy (custom_kernels.py:45-49), so a strip is a range of ix. */
+typedef struct emap_strip {
+  int32_t row_begin, row_count, halo_rows, pad_;
+} emap_strip;
+
+typedef struct emap_stats {
+  double err_sum;          /* sum of z - map_h over drift inliers (custom_kernels.py:331-334), local strip */
+  uint32_t err_cnt;        /* number of drift inliers, local strip */
+  int32_t gate_fired;      /* drift gate of elevation_mapping.py:346-354 fired this frame */
+  float mean_error;        /* elevation_mapping.py:355 */
+  float additive_mean_error; /* elevation_mapping.py:356 / get_additive_mean_error :412 */
+  float shift;             /* amount added to the elevation plane (:357), 0 if none */
+  uint32_t n_points;       /* points bound for the frame */
+  uint64_t ray_visits;     /* inside-map cells visited by the visibility pass (0 unless stats requested) */
+} emap_stats;
+
+typedef struct emap_ctx emap_ctx;
+
+/* plane ids for emap_get_layer / emap_set_layer: 0..6 = the reference's elevation_map planes in its order
+ * (elevation, variance, is_valid, traversability, time, upper_bound, is_upper_bound; elevation_mapping.py:68-77),
+ * 7..9 = normal_map x,y,z (:81), 10 = traversability_input (dilated upper bound, :377-383). */
+enum { EMAP_PLANE_ELEVATION = 0, EMAP_PLANE_VARIANCE, EMAP_PLANE_IS_VALID, EMAP_PLANE_TRAVERSABILITY, EMAP_PLANE_TIME,
+       EMAP_PLANE_UPPER_BOUND, EMAP_PLANE_IS_UPPER_BOUND, EMAP_PLANE_NORMAL_X, EMAP_PLANE_NORMAL_Y,
+       EMAP_PLANE_NORMAL_Z, EMAP_PLANE_TRAV_INPUT, EMAP_PLANE_COUNT };
+
+/* ---- lifetime ------------------------------------------------------------------------------------- */
+int emap_abi_version(void);
+/* Replaces ElevationMap.__init__ allocation + compile_kernels (EM/elevation_mapping.py:52-117, 228-282).
+ * `stream` = an existing hipStream_t to enqueue on (e.g. torch's current stream) or NULL for a private one. */
+int emap_create(const emap_params* params, const emap_strip* strip_or_null, int device, void* stream, emap_ctx** out);
+int emap_destroy(emap_ctx* ctx);
+int emap_set_params(emap_ctx* ctx, const emap_params* params); /* same cell_n; parameters are kernargs, no JIT */
+const char* emap_last_error(const emap_ctx* ctx);
+int emap_sync(emap_ctx* ctx);
+/* ElevationMap.clear (EM/elevation_mapping.py:119-128) */
+int emap_clear(emap_ctx* ctx);
+
+/* ---- point cloud ------------------------------------------------------------------------------------ */
+/* ElevationMap.input_pointcloud's H2D + cast (EM/elevation_mapping.py:456): rows of `stride` elements,
+ * xyz first; dtype 0 = float32, 1 = float64.  Rows with NaN in xyz are skipped inside the kernels (:458). */
+int emap_upload_points(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype);
+/* bind a device-resident float32 cloud without copying (update_map_with_kernel takes device arrays, :316) */
+int emap_set_points_device(emap_ctx* ctx, const float* dev, int64_t n, int64_t stride);
+/* tail of add_points_kernel (custom_kernels.py:260-262): per point cell idx, is_valid, is_inside */
+int emap_point_index(emap_ctx* ctx, const float R[9], const float t[3], int32_t* idx, uint8_t* valid, uint8_t* inside);
+
+/* ---- one frame = update_map_with_kernel (EM/elevation_mapping.py:316-391); t already centre-relative -- */
+int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise,
+                emap_stats* stats_or_null);
+/* individually callable stages (same order inside emap_update) */
+int emap_count(emap_ctx* ctx, const float R[9], const float t[3]);          /* error_counting_kernel :334-345 */
+int emap_set_drift_inputs(emap_ctx* ctx, double position_noise, double orientation_noise, const double* err_sum_override,
+                          const uint32_t* err_cnt_override); /* gate inputs (:346-354); overrides = all-reduced totals */
+int emap_fuse(emap_ctx* ctx, const float R[9], const float t[3]);           /* add_points_kernel fusion part */
+int emap_commit(emap_ctx* ctx);                                             /* side effects of :174,:189-192 -> S1 */
+int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]);           /* add_points_kernel visibility part */
+int emap_average(emap_ctx* ctx);                                            /* average_map_kernel :369 */
+int emap_overlap_clear(emap_ctx* ctx, float t_z);                           /* clear_overlap_map :393-410 */
+int emap_dilate(emap_ctx* ctx);                                             /* dilation_filter_kernel :376-383 */
+int emap_traversability_normals(emap_ctx* ctx);                             /* :385-391 (filter + update_normal) */
+int emap_update_variance(emap_ctx* ctx);                                    /* :420-422 */
+int emap_update_time(emap_ctx* ctx);                                        /* :424-426 */
+int emap_get_stats(emap_ctx* ctx, emap_stats* out);                         /* blocking D2H of the frame scalars */
+
+/* ---- state access (elevation_map attribute / get_map_with_name_ref's raw planes; test state injection) */
+int emap_get_layer(emap_ctx* ctx, int plane, float* host_out /* (row_count, cell_n) */);
+int emap_set_layer(emap_ctx* ctx, int plane, const float* host_in);
+/* ElevationMap.shift_map_xy / shift_map_z (EM/elevation_mapping.py:200-226): roll by (dx rows, dy cols) with
+ * padding (0; variance plane initial_variance), planes 0 and 5 += dz. Single-strip contexts only. */
+int emap_shift(emap_ctx* ctx, int32_t shift_rows, int32_t shift_cols, float dz);
+
+/* ---- row-strip halos (multi-GPU; exchange itself is done by the caller, e.g. torch.distributed/RCCL) ---- */
+/* pack `halo_rows` owned boundary rows (32-byte cells) next to the lower (side 0) / upper (side 1) neighbour
+ * into a device buffer; unpack a neighbour's rows into the halo. Buffers: halo_rows*cell_n*8 floats. */
+int emap_halo_bytes(emap_ctx* ctx, int64_t* bytes_per_side);
+int emap_halo_pack(emap_ctx* ctx, int side, float* dev_buf);
+int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf);
+
+/* ---- timing on the context's stream (hipEvents; bench.py's roofline leg) -------------------------- */
+int emap_timer_begin(emap_ctx* ctx);
+int emap_timer_end(emap_ctx* ctx, float* elapsed_ms); /* records, synchronises, returns elapsed */
+/* per-stage device times of the last emap_update when profiling is enabled (order: count, fuse, commit, rays,
+ * average, overlap, dilate, trav_normals); enabling inserts events between stages */
+int emap_enable_stage_timing(emap_ctx* ctx, int enable);
+int emap_get_stage_times(emap_ctx* ctx, float ms_out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

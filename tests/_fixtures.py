@@ -1,0 +1,36 @@
+"""Seed-defined inputs shared by the tests and by tests/golden/make_golden.py."""
+import numpy as np
+
+
+def cloud(C, N, seed, res=0.04, dz=0.0, extra=0):
+    """x, y ~ U(-L/2, L/2) with L = C*res, sensor-frame z ~ U(-0.5, 0.5) + dz; float32 (N, 3+extra)."""
+    rng = np.random.default_rng(seed)
+    L = C * res / 2
+    p = np.empty((N, 3 + extra), np.float32)
+    p[:, 0] = rng.uniform(-L, L, N)
+    p[:, 1] = rng.uniform(-L, L, N)
+    p[:, 2] = rng.uniform(-0.5, 0.5, N) + dz
+    for k in range(extra):
+        p[:, 3 + k] = rng.uniform(0, 1, N)
+    return p
+
+
+def rot(roll, pitch, yaw):
+    cr, sr, cp, sp, cy, sy = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return (Rz @ Ry @ Rx).astype(np.float32)
+
+
+POSES = {
+    "identity": (np.eye(3, dtype=np.float32), np.array([0, 0, 1], np.float32)),
+    "rotated": (rot(np.deg2rad(10), np.deg2rad(20), np.deg2rad(30)), np.array([0.3, -0.2, 1.1], np.float32)),
+}
+
+
+def stencil_inputs(C, seed):
+    rng = np.random.default_rng(seed)
+    plane = rng.uniform(-1, 1, (C, C)).astype(np.float32)
+    mask = (rng.uniform(0, 1, (C, C)) < 0.35).astype(np.float32) + (rng.uniform(0, 1, (C, C)) < 0.1).astype(np.float32)
+    return plane, mask.astype(np.float32)

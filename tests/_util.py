@@ -1,0 +1,32 @@
+"""Test helpers: build matching (HIP ElevationMap, OracleMap) pairs from one config dict."""
+import numpy as np
+
+from oracle import emap_oracle as eo
+
+PLANE_NAMES = ["elevation", "variance", "is_valid", "traversability", "time", "upper_bound", "is_upper_bound"]
+
+
+def make_parameter(cfg, cell_n, mode="reference_fp16", weights=None):
+    from elevation_mapping_cupy_amd.configs import parameter_from
+    full = dict(eo.DEFAULTS)
+    full.update(cfg)
+    return parameter_from(full, cell_n, mode, weights)
+
+
+def make_pair(cfg, cell_n, mode="reference_fp16", weights=None):
+    from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
+    hip = ElevationMap(make_parameter(cfg, cell_n, mode, weights))
+    orc = eo.OracleMap(eo.make_params(cfg, cell_n=cell_n, mode=mode, weights=weights))
+    return hip, orc
+
+
+def assert_planes_close(a, b, atol=1e-5, rtol=1e-5, names=PLANE_NAMES, max_bad=0, what=""):
+    """fused height/variance within 1e-5 (north_star); flags exact."""
+    for k in range(a.shape[0]):
+        x, y = a[k].astype(np.float64), b[k].astype(np.float64)
+        bad = ~(np.abs(x - y) <= atol + rtol * np.abs(y))
+        bad &= ~(np.isnan(x) & np.isnan(y))
+        n = int(bad.sum())
+        name = names[k] if k < len(names) else str(k)
+        assert n <= max_bad, "%s plane %s: %d cells differ, max |d| = %g (first at %s: %r vs %r)" % (
+            what, name, n, np.nanmax(np.abs(x - y)), tuple(np.argwhere(bad)[0]), x[bad][0], y[bad][0])

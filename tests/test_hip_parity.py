@@ -1,0 +1,178 @@
+"""GPU parity tests proper: every call goes through the C ABI (libemap_hip.so) and is compared with the CPU
+oracle (oracle/emap_oracle.c, itself pinned to the reference's own kernel source -- tests/test_oracle_*.py)
+on identical seeded inputs.  Bars (BASELINE.json north_star): cell indices / flags / integer counters bit-exact;
+fused height, variance and every other float plane within 1e-5."""
+import numpy as np
+import pytest
+
+import _fixtures as fx
+from _util import assert_planes_close, make_pair
+from oracle import emap_oracle as eo
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # (name, cfg, C, N)
+    ("yaml202", eo.YAML, 202, 50000),          # BASELINE config 1
+    ("default202", eo.DEFAULTS, 202, 50000),
+    ("yaml1024", eo.YAML, 1024, 300000),       # BASELINE config 2/3 map size (oracle-sized N)
+]
+
+
+@pytest.mark.parametrize("mode", ["reference_fp16", "fp32"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("pose", ["identity", "rotated"])
+def test_point_index_bit_exact(case, mode, pose):
+    _, cfg, C, N = case
+    hip, orc = make_pair(cfg, C, mode)
+    R, t = fx.POSES[pose]
+    p = fx.cloud(C, N, 0)
+    p[::997, 1] = np.nan                                  # NaN rows are skipped (elevation_mapping.py:458)
+    p[5::1009] *= 3.0                                     # points outside the map / clamped
+    hip.bind_points(p)
+    i1, v1, s1 = hip.point_index(R, t)
+    i0, v0, s0 = orc.point_index(p, R, t)
+    assert np.array_equal(i1, i0) and np.array_equal(v1, v0) and np.array_equal(s1, s0)
+
+
+def _run_frame_stages(hip, orc, p, R, t, pn=0.0, on=0.0, check=True, tag=""):
+    """Stage by stage, comparing every intermediate the contract defines."""
+    P = orc.P
+    hip.bind_points(p)
+    hip.stage("count", R, t); orc.count(p, R, t)
+    hip.stage("gate", position_noise=pn, orientation_noise=on); orc.gate(pn, on)
+    st = hip.stats()
+    assert st.err_cnt == orc.last["err_cnt"], tag
+    assert abs(st.err_sum - orc.last["err_sum"]) <= 1e-6 * max(1.0, orc.last["err_cnt"]), tag
+    assert bool(st.gate_fired) == orc.last["gate_fired"], tag
+    assert abs(st.shift - orc.last["shift"]) <= 1e-7, tag
+    hip.stage("fuse", R, t); orc.fuse(p, R, t)
+    hip.stage("commit"); orc.commit()
+    if check:
+        assert_planes_close(hip.elevation_map, orc.elevation_map, what=tag + " S1")
+    if P.enable_visibility_cleanup:
+        hip.stage("rays", R, t); orc.rays(p, R, t)
+    hip.stage("average"); orc.average()
+    if check:
+        assert_planes_close(hip.elevation_map, orc.elevation_map, what=tag + " average")
+    if P.enable_overlap_clearance:
+        tz = float(np.float32(t[2]))
+        hip.stage("overlap", t=tz); orc.overlap_clear(tz)
+    hip.stage("dilate"); orc.dilate()
+    if check:
+        assert np.array_equal(hip.traversability_input, orc.traversability_input), tag + " dilation must be exact"
+    hip.stage("traversability_normals"); orc.traversability(); orc.normals()
+    if check:
+        assert_planes_close(hip.elevation_map, orc.elevation_map, what=tag + " frame end")
+        assert_planes_close(hip.normal_map, orc.normal_map, names=["nx", "ny", "nz"], what=tag + " normals")
+
+
+@pytest.mark.parametrize("mode", ["reference_fp16", "fp32"])
+@pytest.mark.parametrize("cfg_name,C,N", [("yaml", 202, 50000), ("default", 202, 50000), ("yaml", 130, 20000)])
+def test_three_frames_stagewise(cfg_name, C, N, mode, weights):
+    """fresh frame, then two warm frames (time advanced, cloud lowered => outliers, drift gate, ray hits)."""
+    cfg = eo.YAML if cfg_name == "yaml" else eo.DEFAULTS
+    hip, orc = make_pair(cfg, C, mode, weights)
+    R, t = fx.POSES["rotated"]
+    _run_frame_stages(hip, orc, fx.cloud(C, N, 0), R, t, tag="f0")
+    for k in range(12):
+        hip.update_time(); orc.update_time()
+    hip.update_variance(); orc.update_variance()
+    assert_planes_close(hip.elevation_map, orc.elevation_map, what="after time/variance")
+    _run_frame_stages(hip, orc, fx.cloud(C, N, 1, dz=-0.02), R, t, pn=1.0, on=1.0, tag="f1")
+    for k in range(6):
+        hip.update_time(); orc.update_time()
+    _run_frame_stages(hip, orc, fx.cloud(C, N, 2, dz=-0.2), R, t, pn=1.0, on=1.0, tag="f2")
+    assert abs(hip.get_additive_mean_error() - float(orc.additive_mean_error)) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["reference_fp16", "fp32"])
+def test_whole_frame_api_matches_stagewise_oracle(mode, weights):
+    """emap_update (one call) == the oracle's update_map_with_kernel over 3 frames, 1024^2 map."""
+    C, N = 1024, 200000
+    hip, orc = make_pair(eo.YAML, C, mode, weights)
+    R, t = fx.POSES["identity"]
+    for f, dz in enumerate((0.0, -0.02, -0.2)):
+        p = fx.cloud(C, N, f, dz=dz)
+        hip.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0)
+        orc.update_map_with_kernel(p, R, t, 1.0, 1.0)
+        for k in range(7):
+            hip.update_time(); orc.update_time()
+        hip.update_variance(); orc.update_variance()
+    assert_planes_close(hip.elevation_map, orc.elevation_map, what="3 frames")
+    assert_planes_close(hip.normal_map, orc.normal_map, names=["nx", "ny", "nz"])
+
+
+def test_run_to_run_bit_identical(weights):
+    """integer / fixed-point accumulators => the same bytes every run (the reference's float atomics are not)."""
+    C, N = 202, 50000
+    outs = []
+    for rep in range(3):
+        hip, _ = make_pair(eo.YAML, C, "reference_fp16", weights)
+        R, t = fx.POSES["rotated"]
+        for f, dz in enumerate((0.0, -0.05)):
+            hip.update_map_with_kernel(fx.cloud(C, N, f, dz=dz), [], R, t.copy(), 1.0, 1.0)
+            for k in range(6):
+                hip.update_time()
+        outs.append(hip.elevation_map.tobytes() + hip.normal_map.tobytes())
+        hip.close()
+    assert outs[0] == outs[1] == outs[2]
+
+
+def test_golden_frame66_against_reference_source(weights):
+    """HIP vs the committed outputs of the reference's own kernels (tests/golden/frame_yaml66.npz), fresh map."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_yaml66.npz"))
+    C, N = 66, 6000
+    for pose, (R, t) in fx.POSES.items():
+        hip, _ = make_pair(eo.YAML, C, "reference_fp16", weights)
+        hip.param.enable_overlap_clearance = False
+        hip.reload_params()
+        p = fx.cloud(C, N, 0)
+        hip.bind_points(p)
+        idx, valid, inside = hip.point_index(R, t)
+        assert np.array_equal(idx, g[pose + "_idx"])
+        assert np.array_equal(valid | (inside << 1), g[pose + "_flags"])
+        hip.update_map_with_kernel(None, [], R, t.copy(), 0.0, 0.0)
+        m = hip.elevation_map
+        gm = g[pose + "_map"]
+        for k in (0, 1, 2, 4, 5, 6):      # plane 3 is written by the traversability filter (not in the golden run)
+            assert_planes_close(m[k:k + 1], gm[k:k + 1], names=[str(k)], what="golden " + pose)
+        assert np.array_equal(hip.traversability_input, g[pose + "_dil"])
+        assert_planes_close(hip.normal_map, g[pose + "_normal"], names=["nx", "ny", "nz"])
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 10])
+def test_dilation_radii_and_wraparound(d):
+    """LDS-tiled dilation incl. the reference's flat-index row wrap (custom_kernels.py:403-407) at radius 1..10."""
+    C = 130
+    cfg = dict(eo.DEFAULTS, dilation_size=d)
+    hip, orc = make_pair(cfg, C)
+    rng = np.random.default_rng(d)
+    e = np.zeros((7, C, C), np.float32)
+    e[5] = rng.uniform(-1, 1, (C, C)); e[2] = rng.uniform(0, 1, (C, C)) < 0.05; e[6] = rng.uniform(0, 1, (C, C)) < 0.03
+    e[2][:, :4] = rng.uniform(0, 1, (C, 4)) < 0.5; e[2][:, -4:] = rng.uniform(0, 1, (C, 4)) < 0.5   # busy edge columns
+    hip.elevation_map = e; orc.elevation_map[...] = e
+    hip.stage("dilate"); orc.dilate()
+    assert np.array_equal(hip.traversability_input, orc.traversability_input)
+
+
+def test_fails_loudly_without_points():
+    from elevation_mapping_cupy_amd._lib import EmapError
+    hip, _ = make_pair(eo.DEFAULTS, 66)
+    R, t = fx.POSES["identity"]
+    hip.bind_points(np.zeros((0, 3), np.float32))
+    hip.update_map_with_kernel(None, [], R, t.copy(), 0, 0)        # empty cloud is legal
+    with pytest.raises(EmapError):
+        hip.stage("rays", R, t)                                     # rays without commit is a contract violation
+
+
+def test_ragged_and_degenerate_inputs(weights):
+    C = 66
+    hip, orc = make_pair(eo.YAML, C, "reference_fp16", weights)
+    R, t = fx.POSES["identity"]
+    p = fx.cloud(C, 777, 3, extra=2)                 # N not a multiple of 64/256, extra channels (stride 5)
+    p[10] = np.nan; p[11, 0] = np.inf; p[12, :3] = 0  # NaN row, inf coordinate, point at the sensor
+    p[100:400, :2] = p[100, :2]                       # 300 points into one cell (> wall_num_thresh)
+    p[12, :3] = [0.0, 0.0, -1.0]
+    _run_frame_stages(hip, orc, p, R, t, tag="ragged f0")
+    _run_frame_stages(hip, orc, p, R, t, pn=1, on=1, tag="ragged f1")
