@@ -9,13 +9,14 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 // launchers (emap_kernels.hip)
 void launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, ErrSlot*);
 void launch_gate(hipStream_t, const KP&, ErrSlot*, FrameDev*, int, double, double, float, int, int, double, unsigned int, unsigned int);
 void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, const FrameDev*, int*, unsigned char*);
-void launch_commit(hipStream_t, const KP&, Cell*, const AccF*, const FrameDev*);
-void launch_rays(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, const AccF*, AccR*, const float*, long, FrameDev*, bool);
+void launch_commit(hipStream_t, const KP&, Cell*, const AccF*, const FrameDev*, unsigned long long*);
+void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, const Cell*, const AccF*, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*);
 void launch_average(hipStream_t, const KP&, Cell*, AccF*, AccR*, const FrameDev*, bool, bool);
 void launch_overlap(hipStream_t, const KP&, Cell*, int, int, float, float);
 void launch_dilate(hipStream_t, const KP&, const Cell*, float*, int, int, int);
@@ -43,6 +44,8 @@ struct emap_ctx {
   float* trav_in; float* normal;   // normal: 3 planes of ncells_alloc
   float* scratch;                  // one plane (get/set staging)
   ErrSlot* slots; FrameDev* frame;
+  RayTab rt; float* ray_S; unsigned short* ray_lut;
+  unsigned long long* inert;       // 1 bit per owned cell, written by k_commit
   // point cloud
   float* pts_own; long pts_cap;    // owned buffer (floats)
   double* pts_f64; long pts_f64_cap;
@@ -84,6 +87,86 @@ static void build_kp(emap_ctx* ctx) {
   k.time_var = (float)p.time_variance; k.time_int = (float)p.time_interval; k.res_f = (float)p.resolution;
 }
 
+// smallest float >= c (a < c  <=>  a < up(c) for float a) / largest float <= c (a > c <=> a > dn(c))
+static float f_up(double c) { float f = (float)c; if ((double)f < c) f = nextafterf(f, INFINITY); return f; }
+static float f_dn(double c) { float f = (float)c; if ((double)f > c) f = nextafterf(f, -INFINITY); return f; }
+
+static int host_axis_idx(const emap_params& p, float xq, float q_wm1, bool half_mode) {
+  double v = (double)xq / p.resolution + 0.5 * p.cell_n;
+  int i = !(v == v) ? 0 : (v >= 2147483647.0 ? 2147483647 : (v <= -2147483648.0 ? (int)0x80000000 : (int)v));
+  float fi = half_mode ? q16((float)i) : (float)i;
+  float r = fmaxf(fminf(fi, q_wm1), 0.0f);
+  return (int)r;
+}
+
+// Tables of the visibility pass: step sequence (custom_kernels.py:203) and, for reference_fp16, the
+// half-bits -> cell-index table (custom_kernels.py:22-33,45-49 evaluated exactly on the host).
+static int build_ray_tables(emap_ctx* ctx) {
+  const emap_params& p = ctx->prm;
+  const bool h = p.mode == EMAP_MODE_REFERENCE_FP16;
+  RayTab& rt = ctx->rt;
+  if (ctx->ray_S) { CK(hipStreamSynchronize(ctx->stream)); CK(hipFree(ctx->ray_S)); ctx->ray_S = nullptr; }
+  if (ctx->ray_lut) { CK(hipStreamSynchronize(ctx->stream)); CK(hipFree(ctx->ray_lut)); ctx->ray_lut = nullptr; }
+  memset(&rt, 0, sizeof rt);
+  std::vector<float> S;
+  const float q_mrl = ctx->kp.q_mrl;
+  float s = ctx->kp.q_step;
+  while (s < q_mrl && S.size() < (1u << 20)) {
+    S.push_back(s);
+    float nx = (float)((double)s + p.ray_step);
+    if (h) nx = q16(nx);
+    if (!(nx > s)) break;   // half saturated: the reference's loop would never terminate here
+    s = nx;
+  }
+  rt.nS = (int)S.size();
+  if (rt.nS) {
+    CK(hipMalloc((void**)&ctx->ray_S, sizeof(float) * S.size()));
+    CK(hipMemcpyAsync(ctx->ray_S, S.data(), sizeof(float) * S.size(), hipMemcpyHostToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+  }
+  rt.S = ctx->ray_S;
+  rt.f_d_thresh = f_up(0.1); rt.f_cos_thresh = f_up(p.cleanup_cos_thresh); rt.f_wall = f_dn(p.wall_num_thresh);
+  if (h) {
+    std::vector<int> full(65536);
+    for (int b = 0; b < 65536; ++b) {
+      unsigned short us = (unsigned short)b; _Float16 hf; memcpy(&hf, &us, 2);
+      full[b] = host_axis_idx(p, (float)hf, ctx->kp.q_wm1, true);
+    }
+    auto at = [&](int sg, int mag) { return full[(sg << 15) | mag]; };
+    int lo = 0x7c00, hi = 1;
+    for (int sg = 0; sg < 2; ++sg) {
+      for (int m = 1; m < 0x7c00; ++m) if (at(sg, m) != at(sg, 1)) { if (m < lo) lo = m; break; }
+      for (int m = 0x7bff; m >= 1; --m) if (at(sg, m) != at(sg, 0x7c00)) { if (m + 1 > hi) hi = m + 1; break; }
+    }
+    if (hi < lo) { hi = lo; }
+    // verify the compact form against the full table (every pattern), else fall back to in-kernel arithmetic
+    bool ok = at(0, 0) == at(0, 1) && at(1, 0) == at(0, 1);
+    rt.small_pos = at(0, 1); rt.small_neg = at(1, 1); rt.big_pos = at(0, 0x7c00); rt.big_neg = at(1, 0x7c00); rt.nan_val = at(0, 0x7e00);
+    for (int sg = 0; sg < 2 && ok; ++sg)
+      for (int m = 1; m < 0x8000; ++m) {
+        int want = at(sg, m), got;
+        if (m >= lo && m < hi) continue;
+        if (m < lo) got = sg ? rt.small_neg : rt.small_pos; else if (m > 0x7c00) got = rt.nan_val; else got = sg ? rt.big_neg : rt.big_pos;
+        if (got != want) { ok = false; break; }
+      }
+    const size_t entries = (size_t)2 * (hi - lo);
+    if (ok && entries > 0 && lo >= 1 && (entries + 4) * 2 <= 60 * 1024 && p.cell_n <= 65535) {
+      const size_t span = (size_t)(hi - lo) + 2;   // per sign: [small, idx(lo..hi-1), big]
+      std::vector<unsigned short> lut(2 * span + 2);
+      for (int sg = 0; sg < 2; ++sg) {
+        lut[sg * span] = (unsigned short)(sg ? rt.small_neg : rt.small_pos);
+        for (int m = lo; m < hi; ++m) lut[sg * span + 1 + (m - lo)] = (unsigned short)at(sg, m);
+        lut[sg * span + span - 1] = (unsigned short)(sg ? rt.big_neg : rt.big_pos);
+      }
+      CK(hipMalloc((void**)&ctx->ray_lut, sizeof(unsigned short) * lut.size()));
+      CK(hipMemcpyAsync(ctx->ray_lut, lut.data(), sizeof(unsigned short) * lut.size(), hipMemcpyHostToDevice, ctx->stream));
+      CK(hipStreamSynchronize(ctx->stream));
+      rt.lut = ctx->ray_lut; rt.lo = lo; rt.hi = hi;
+    }
+  }
+  return EMAP_OK;
+}
+
 static Pose make_pose(const emap_ctx* ctx, const float R[9], const float t[3]) {
   Pose T;
   const bool h = ctx->prm.mode == EMAP_MODE_REFERENCE_FP16;
@@ -119,7 +202,7 @@ int emap_destroy(emap_ctx* ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   hipFree(ctx->cells); hipFree(ctx->cells_alt); hipFree(ctx->acc); hipFree(ctx->accr); hipFree(ctx->trav_in);
   hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->slots); hipFree(ctx->frame); hipFree(ctx->pts_own);
-  hipFree(ctx->pts_f64); hipFree(ctx->tail_idx); hipFree(ctx->tail_flags);
+  hipFree(ctx->pts_f64); hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert);
   for (int i = 0; i <= ST_N; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   if (ctx->t0) hipEventDestroy(ctx->t0);
   if (ctx->t1) hipEventDestroy(ctx->t1);
@@ -168,12 +251,14 @@ int emap_create(const emap_params* params, const emap_strip* strip, int device, 
   alloc((void**)&ctx->trav_in, sizeof(float) * n); alloc((void**)&ctx->normal, sizeof(float) * 3 * n);
   alloc((void**)&ctx->scratch, sizeof(float) * n); alloc((void**)&ctx->slots, sizeof(ErrSlot) * EM_ERR_SLOTS);
   alloc((void**)&ctx->frame, sizeof(FrameDev));
+  alloc((void**)&ctx->inert, sizeof(unsigned long long) * (((size_t)ctx->strip.row_count * C + 63) / 64 + 1));
   if (rc == EMAP_OK) {
     hipEventCreate(&ctx->t0); hipEventCreate(&ctx->t1);
     for (int i = 0; i <= ST_N; ++i) hipEventCreate(&ctx->ev[i]);
     hipMemsetAsync(ctx->trav_in, 0, sizeof(float) * n, ctx->stream);
     hipMemsetAsync(ctx->normal, 0, sizeof(float) * 3 * n, ctx->stream);
     rc = emap_clear(ctx);
+    if (rc == EMAP_OK) rc = build_ray_tables(ctx);
     if (rc == EMAP_OK) {
       // ElevationMap.__init__: traversability plane starts at 1 (elevation_mapping.py:84)
       Cell z = {0.f, (float)params->initial_variance, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f};
@@ -193,7 +278,8 @@ int emap_set_params(emap_ctx* ctx, const emap_params* params) {
   if (!validate(params, &ctx->strip, &why)) { ctx->err = why; return EMAP_ERR_INVALID; }
   ctx->prm = *params;
   build_kp(ctx);
-  return EMAP_OK;
+  CK(hipSetDevice(ctx->device));
+  return build_ray_tables(ctx);
 }
 
 int emap_sync(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); CK(hipStreamSynchronize(ctx->stream)); return EMAP_OK; }
@@ -308,7 +394,7 @@ int emap_fuse(emap_ctx* ctx, const float R[9], const float t[3]) { CKARG(ctx && 
 int emap_commit(emap_ctx* ctx) {
   CKARG(ctx, "null ctx");
   CK(hipSetDevice(ctx->device));
-  if (!ctx->committed) { launch_commit(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->frame); ctx->committed = true; }
+  if (!ctx->committed) { launch_commit(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->frame, ctx->inert); ctx->committed = true; }
   CK(hipGetLastError());
   return EMAP_OK;
 }
@@ -317,8 +403,8 @@ int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
   CKARG(ctx && R && t, "null argument"); NEED_POINTS();
   CK(hipSetDevice(ctx->device));
   CKARG(ctx->committed, "emap_rays needs emap_commit first (rays read snapshot S1)");
-  launch_rays(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->accr,
-              ctx->normal, ctx->ncells_alloc, ctx->frame, ctx->want_ray_stats);
+  launch_rays(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->rt, ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->accr,
+              ctx->normal, ctx->ncells_alloc, ctx->frame, ctx->want_ray_stats, ctx->inert);
   CK(hipGetLastError());
   return EMAP_OK;
 }

@@ -60,6 +60,14 @@ struct KP {
   float init_var, ov_f, q_wm1, q_mrl, q_step, time_var, time_int, res_f;
 };
 
+// host-built tables of the visibility pass (emap_api.hip: build_ray_tables)
+struct RayTab {
+  const float* S; int nS;                   // s_k = Q(s_{k-1} + ray_step), all k with s_k < Q(max_ray_length)
+  const unsigned short* lut; int lo, hi;    // reference_fp16: cell index by half bit pattern, magnitudes [lo, hi), 2 signs
+  int small_pos, small_neg, big_pos, big_neg, nan_val;
+  float f_d_thresh, f_cos_thresh, f_wall;   // float thresholds equivalent to the reference's double comparisons
+};
+
 struct Pose {        // R, t of one frame; Rq/tq are the values after the float16 parameter rounding
   float Rq[9], tq[3], t[3];
 };

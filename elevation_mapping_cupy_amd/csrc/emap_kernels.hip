@@ -89,21 +89,29 @@ __global__ __launch_bounds__(EM_BLOCK) void k_fuse(KP P, Pose T, const float* __
   const float shift = F->shift;
   float2 hv = *reinterpret_cast<const float2*>(&cells[c]);
   float map_h = hv.x + shift, map_v = hv.y;
-  float num_points = (float)(unsigned int)(acc[c].pts_inl & 0xffffffffull);
+  const unsigned int n_pts = (unsigned int)(acc[c].pts_inl & 0xffffffffull);
+  float num_points = (float)n_pts;
+  // a cell that received exactly one point this frame has a single writer: plain stores, no atomics (an atomic costs
+  // ~44 ns/Mop on MI355X regardless of width or locality -- tools/microbench.hip -- a plain 8-B store a third of that)
+  const bool single = n_pts == 1u;
   if ((double)fabsf(map_h - g.z) > (double)map_v * P.mt) {          // outlier :173-175
-    atomicAdd(&acc[c].cnt_out, 1ull << 32);
+    if (single) acc[c].cnt_out = 1ull << 32; else atomicAdd(&acc[c].cnt_out, 1ull << 32);
     return;
   }
   if (P.edge && (double)num_points > P.wall &&
       (double)g.z < (double)map_h - (double)map_v * P.mt / (double)num_points) return;   // edge sharpening :177-179
   float new_h = (map_h * g.v + g.z * map_v) / (map_v + g.v);          // :181-182
   float new_v = (map_v * g.v) / (map_v + g.v);
-  atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c].sum_h),
-            (unsigned long long)__double2ll_rn((double)new_h * EM_SCALE_H));
-  atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c].sum_v),
-            (unsigned long long)__double2ll_rn((double)new_v * EM_SCALE_V));
+  const long long fh = __double2ll_rn((double)new_h * EM_SCALE_H), fv = __double2ll_rn((double)new_v * EM_SCALE_V);
+  const unsigned long long lt = ((unsigned long long)(i + 1) << 32) | (unsigned long long)__float_as_uint(new_h);
+  if (single) {
+    acc[c].cnt_out = 1ull; acc[c].sum_h = fh; acc[c].sum_v = fv; acc[c].latest = lt;
+    return;
+  }
+  atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c].sum_h), (unsigned long long)fh);
+  atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c].sum_v), (unsigned long long)fv);
   atomicAdd(&acc[c].cnt_out, 1ull);
-  atomicMax(&acc[c].latest, ((unsigned long long)(i + 1) << 32) | (unsigned long long)__float_as_uint(new_h));
+  atomicMax(&acc[c].latest, lt);
 }
 
 // effects of custom_kernels.py:174 and :189-192 on one cell (-> snapshot S1)
@@ -114,16 +122,24 @@ __device__ __forceinline__ void commit_cell(const KP& P, Cell& c, const AccF& a)
 }
 
 // Phase B': materialise S1 (only launched when the visibility pass runs; otherwise folded into k_average)
+// Also emits the "inert" bitmap (1 bit per owned cell: known AND updated recently).  A ray step on such a cell cannot
+// have any effect (custom_kernels.py:228-237), so k_rays tests the bit (128 KB for a 1024^2 map, cache resident)
+// instead of gathering the 32-byte cell.
 __global__ __launch_bounds__(EM_BLOCK) void k_commit(KP P, Cell* __restrict__ cells, const AccF* __restrict__ acc,
-                                                      const FrameDev* __restrict__ F) {
+                                                      const FrameDev* __restrict__ F, unsigned long long* __restrict__ inert) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
-  if (li >= (long)P.nrows * P.C) return;
-  long c = li + (long)P.halo * P.C;
-  Cell m = cells[c];
-  AccF a = acc[c];
-  m.h += F->shift;
-  commit_cell(P, m, a);
-  cells[c] = m;
+  bool quiet = false;
+  if (li < (long)P.nrows * P.C) {
+    long c = li + (long)P.halo * P.C;
+    Cell m = cells[c];
+    AccF a = acc[c];
+    m.h += F->shift;
+    commit_cell(P, m, a);
+    cells[c] = m;
+    quiet = !(m.valid < 0.5f) && m.time < 0.5f;
+  }
+  unsigned long long bits = __ballot(quiet);
+  if ((threadIdx.x & 63) == 0 && li < (long)P.nrows * P.C) inert[li >> 6] = bits;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -131,18 +147,55 @@ __global__ __launch_bounds__(EM_BLOCK) void k_commit(KP P, Cell* __restrict__ ce
 // One ray per lane; each step gathers ONE 32-byte cell; all effects go to the 16-byte AccR record
 // (fixed-point add / integer add / ordered-uint max) so the result is independent of scheduling.
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE, bool STATS>
-__global__ __launch_bounds__(EM_BLOCK) void k_rays(KP P, Pose T, const float* __restrict__ pts, long n, int stride,
-                                                    const Cell* __restrict__ cells, const AccF* __restrict__ acc,
-                                                    AccR* __restrict__ accr, const float* __restrict__ normal,
-                                                    long plane_stride, FrameDev* __restrict__ F) {
-  long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+// ALU diet (the first version of this kernel was VALU-bound on two fp64 divisions per step, profiles/r01_a_*):
+//   * the step sequence s_k = half(s_{k-1} + step) does not depend on the ray: host-built table, scalar loads;
+//   * reference_fp16 mode: a coordinate is rounded to half before the index computation, so the cell index is a
+//     function of 16 bits: host-built lookup table (exact double arithmetic of the reference), compacted to the
+//     exponent range where it varies and staged in LDS (~37 KB for a 1024^2 map) -> no fp64 in the loop;
+//   * float-vs-double-constant comparisons use host-rounded float thresholds (exactly equivalent).
+// min-reduce of nz into the ordered-uint key.  Thousands of rays cross the same unknown cell and an atomic costs
+// ~44 ns/Mop whatever the address pattern, so test first with a plain (possibly stale => conservative) load: the key
+// only grows, a stale smaller value can only cause a redundant atomic, never a missed one.
+__device__ __forceinline__ void ray_upper_min(unsigned int* key_ptr, float nz) {
+  const unsigned int key = ~float_ord(nz);
+  if (__builtin_nontemporal_load(key_ptr) < key) atomicMax(key_ptr, key);
+}
+
+template <int MODE, bool LUT> struct IdxLut {
+  const unsigned short* t; unsigned int lo_m1, hi, span;   // per sign: [small, idx(lo..hi-1), big]
+  __device__ __forceinline__ int operator()(const KP& P, float q) const {
+    if constexpr (!LUT) return axis_idx<MODE>(P, q);
+    else {   // branch-free: clamp the magnitude into the tabulated range (sentinels hold the constant tails)
+      const unsigned int b = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)(q + 0.0f));   // -0 -> +0
+      const unsigned int mag = b & 0x7fffu, sg = b >> 15;
+      const unsigned int m = min(max(mag, lo_m1), hi) - lo_m1;
+      return (int)t[sg * span + m];
+    }
+  }
+};
+
+template <int MODE, bool STATS, bool LUT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const float* __restrict__ pts, long n, int stride,
+                                                 const Cell* __restrict__ cells, const AccF* __restrict__ acc,
+                                                 AccR* __restrict__ accr, const float* __restrict__ normal,
+                                                 long plane_stride, FrameDev* __restrict__ F,
+                                                 const unsigned long long* __restrict__ inert) {
+  extern __shared__ unsigned int slut32[];
+  const unsigned int span = (unsigned int)(Rt.hi - Rt.lo) + 2u;
+  if (LUT) {
+    const unsigned int* src = reinterpret_cast<const unsigned int*>(Rt.lut);   // 2 signs * span u16 = span u32
+    for (unsigned int k = threadIdx.x; k < span; k += BLOCK) slut32[k] = src[k];
+    __syncthreads();
+  }
+  IdxLut<MODE, LUT> lut{reinterpret_cast<const unsigned short*>(slut32), (unsigned int)Rt.lo - 1u, (unsigned int)Rt.hi, span};
+  long i = (long)blockIdx.x * BLOCK + threadIdx.x;
   unsigned long long visits = 0;
   if (i < n) {
     float rx_, ry_, rz_;
     load_point(pts, i, stride, rx_, ry_, rz_);
     Geo g = geometry<MODE>(P, T, rx_, ry_, rz_);
-    if (g.finite && g.valid) {   // invalid points march but never act (:226)
+    // invalid points march but never act (:226); non-finite geometry is undefined in the reference and skipped here
+    if (g.finite && g.valid && fabsf(g.x) < INFINITY && fabsf(g.y) < INFINITY && fabsf(g.z) < INFINITY) {
       // ray_vector (:83-101): every intermediate is a float16 variable in the reference
       float px = Qf<MODE>(g.x), py = Qf<MODE>(g.y), pz = Qf<MODE>(g.z);
       float vx = Qf<MODE>(px - T.tq[0]), vy = Qf<MODE>(py - T.tq[1]), vz = Qf<MODE>(pz - T.tq[2]);
@@ -151,36 +204,43 @@ __global__ __launch_bounds__(EM_BLOCK) void k_rays(KP P, Pose T, const float* __
       if (norm > 0.f) { rx = Qf<MODE>(vx / norm); ry = Qf<MODE>(vy / norm); rz = Qf<MODE>(vz / norm); }
       float ray_length = fminf(norm, P.q_mrl);
       const float dec = (float)(-P.cs / ((double)ray_length / P.mrl));
+      const int C = P.C;
       int last = -1;
-      for (float s = P.q_step; s < ray_length; s = Qf<MODE>((float)((double)s + P.ray_step))) {
+      for (int k = 0; k < Rt.nS; ++k) {
+        const float s = Rt.S[k];                   // wave-uniform: scalar load
+        if (!(s < ray_length)) break;
         float nx = T.t[0] + rx * s, ny = T.t[1] + ry * s, nz = T.t[2] + rz * s;
-        int ix = axis_idx<MODE>(P, Qf<MODE>(nx)), iy = axis_idx<MODE>(P, Qf<MODE>(ny));
-        int nidx = P.C * ix + iy;
-        if (nidx == last) continue;
+        const int ix = lut(P, Qf<MODE>(nx)), iy = lut(P, Qf<MODE>(ny));
+        const int nidx = C * ix + iy;
+        const unsigned int lr = (unsigned int)(ix - P.row0);
+        // one predicate, one branch: new cell (:209-210) & inside (:211) & owned by this strip
+        const bool act = (nidx != last) & ((unsigned int)(ix - 1) < (unsigned int)(C - 2)) &
+                         ((unsigned int)(iy - 1) < (unsigned int)(C - 2)) & (lr < (unsigned int)P.nrows);
         last = nidx;
-        if (ix == 0 || ix == P.C - 1 || iy == 0 || iy == P.C - 1) continue;
-        long c = owned_cell(P, ix, iy);
-        if (c < 0) continue;                       // other strip's cell: its owner handles it
+        if (!act) continue;
+        const long li = (long)lr * C + iy;
+        const long c = li + (long)P.halo * C;
         if (STATS) visits++;
+        if ((inert[li >> 6] >> (li & 63)) & 1ull) continue;   // known + fresh cell: nothing can happen
         const float4* cp = reinterpret_cast<const float4*>(&cells[c]);
         float4 m0 = cp[0], m1 = cp[1];             // h v valid trav | time upper is_upper pad
         float ddx = g.x - nx, ddy = g.y - ny, ddz = g.z - nz;
         float d = Qf<MODE>(ddx * ddx + ddy * ddy + ddz * ddz);
-        if ((double)d < 0.1) continue;
+        if (d < Rt.f_d_thresh) continue;           // (double)d < 0.1  (:225-226)
         if (m0.z < 0.5f) {                         // unknown cell: upper bound (:228-234)
-          if (nz < m1.y || m1.z < 0.5f) atomicMax(&accr[c].upper_key, ~float_ord(nz));
+          if (nz < m1.y || m1.z < 0.5f) ray_upper_min(&accr[c].upper_key, nz);
           continue;
         }
         if (m1.x < 0.5f) continue;                 // updated recently (:236)
         if ((double)m0.x > (double)nz + 0.01 - fmin((double)m0.y, 1.0) * 0.05) {
           float ip = rx * Qf<MODE>(normal[c]) + ry * Qf<MODE>(normal[plane_stride + c]) + rz * Qf<MODE>(normal[2 * plane_stride + c]);
-          if ((double)fabsf(ip) < P.cos_thresh) continue;
+          if (fabsf(ip) < Rt.f_cos_thresh) continue;
           float n_inl = (float)(unsigned int)(acc[c].pts_inl >> 32);
-          if ((double)n_inl > P.wall && (double)m1.x < 1.0) continue;
+          if (n_inl > Rt.f_wall && m1.x < 1.0f) continue;
           atomicAdd(reinterpret_cast<unsigned long long*>(&accr[c].dec),
                     (unsigned long long)__double2ll_rn((double)dec * EM_SCALE_V));
           atomicAdd(&accr[c].hits, 1u);
-          if (nz < m1.y || m1.z < 0.5f) atomicMax(&accr[c].upper_key, ~float_ord(nz));
+          if (nz < m1.y || m1.z < 0.5f) ray_upper_min(&accr[c].upper_key, nz);
         }
       }
     }
@@ -258,55 +318,64 @@ __global__ __launch_bounds__(EM_BLOCK) void k_dilate(KP P, const Cell* __restric
   const int C = P.C;
   const int tile_r = lr0 + blockIdx.y * DT_R, tile_c = blockIdx.x * DT_C;   // local row / col of tile origin
   const int total_rows = P.nrows + 2 * P.halo;
-  for (int k = threadIdx.x; k < H * W; k += EM_BLOCK) {
-    int r = k / W, cc = k % W;
-    int lr = tile_r - d + r, col = tile_c - d + cc;
-    int gr = lr - P.halo + P.row0;                                 // global row
-    float val = 0.f, msk = 0.f;
-    if (lr >= 0 && lr < total_rows && gr >= 1 && gr <= C - 2 && col >= 1 && col <= C - 2) {   // is_inside(j)
+  const int tc = threadIdx.x & 63, col = tile_c + tc, wv = threadIdx.x >> 6;
+  // pass 0: every thread reads its own DT_R/4 cells (coalesced 2x dwordx4); in the steady state every cell is known
+  // (mask >= 0.5) and the tile is a pure copy -- the LDS stencil is only staged for tiles that contain a hole.
+  float own_val[DT_R / 4], own_msk[DT_R / 4];
+  int hole = 0;
+#pragma unroll
+  for (int k = 0; k < DT_R / 4; ++k) {
+    int lr = tile_r + wv + 4 * k;
+    own_val[k] = 0.f; own_msk[k] = 1.f;
+    if (col < C && lr < lr1) {
       const float4* cp = reinterpret_cast<const float4*>(&cells[(long)lr * C + col]);
       float4 m0 = cp[0], m1 = cp[1];
-      val = m1.y; msk = m0.z + m1.z;
+      own_val[k] = m1.y; own_msk[k] = m0.z + m1.z;
+      hole |= (own_msk[k] < 0.5f);
     }
-    sval[r * pitch + cc] = val; smsk[r * pitch + cc] = msk;
+  }
+  if (!__syncthreads_or(hole)) {
+#pragma unroll
+    for (int k = 0; k < DT_R / 4; ++k) {
+      int lr = tile_r + wv + 4 * k;
+      if (col < C && lr < lr1) out[(long)lr * C + col] = own_val[k];
+    }
+    return;
+  }
+  // stage (value, mask & is_inside) of the tile + halo d; rows are distributed over the 4 waves, columns over lanes.
+  // The reference addresses neighbours by FLAT index (i + W*dy + dx, custom_kernels.py:403-407): a column left of 0
+  // is the tail of the previous row, a column right of C-1 the head of the next row -- staged exactly like that.
+  for (int r = wv; r < H; r += EM_BLOCK / 64) {
+    for (int cc = tc; cc < W; cc += 64) {
+      int lr = tile_r - d + r, cl = tile_c - d + cc;
+      if (cl < 0) { cl += C; lr -= 1; } else if (cl >= C) { cl -= C; lr += 1; }
+      const int gr = lr - P.halo + P.row0;
+      float val = 0.f, msk = 0.f;
+      if (lr >= 0 && lr < total_rows && gr >= 1 && gr <= C - 2 && cl >= 1 && cl <= C - 2) {   // is_inside(j)
+        const float4* cp = reinterpret_cast<const float4*>(&cells[(long)lr * C + cl]);
+        float4 m0 = cp[0], m1 = cp[1];
+        val = m1.y; msk = m0.z + m1.z;
+      }
+      sval[r * pitch + cc] = val; smsk[r * pitch + cc] = msk;
+    }
   }
   __syncthreads();
-  const int tc = threadIdx.x & 63, col = tile_c + tc;
   if (col >= C) return;
-  const bool wrap = (col <= d - 2) || (col >= C + 1 - d);
-  for (int tr = threadIdx.x >> 6; tr < DT_R; tr += EM_BLOCK / 64) {
-    int lr = tile_r + tr;
+#pragma unroll
+  for (int k = 0; k < DT_R / 4; ++k) {
+    const int tr = wv + 4 * k, lr = tile_r + tr;
     if (lr >= lr1) break;
-    long c = (long)lr * C + col;
-    const float4* cp = reinterpret_cast<const float4*>(&cells[c]);
-    float4 m0 = cp[0], m1 = cp[1];
-    float res = m1.y;
-    if (m0.z + m1.z < 0.5f) {
+    float res = own_val[k];
+    if (own_msk[k] < 0.5f) {
       float distance = 100.f, near_value = 0.f;
-      if (!wrap) {
-        for (int dy = -d; dy <= d; ++dy)
-          for (int dx = -d; dx <= d; ++dx) {
-            int o = (tr + d + dy) * pitch + (tc + d + dx);
-            if (smsk[o] > 0.5f && (float)(dx + dy) < distance) { distance = (float)(dx + dy); near_value = sval[o]; }
-          }
-      } else {
-        const long gi = (long)(lr - P.halo + P.row0) * C + col, L = (long)C * C;
-        for (int dy = -d; dy <= d; ++dy)
-          for (int dx = -d; dx <= d; ++dx) {
-            long j = gi + (long)C * dy + dx;
-            if (j < 0 || j >= L) continue;
-            int jr = (int)(j / C), jc = (int)(j % C);
-            if (jr <= 0 || jr >= C - 1 || jc <= 0 || jc >= C - 1) continue;
-            int jl = jr - P.row0 + P.halo;
-            if (jl < 0 || jl >= total_rows) continue;
-            const float4* np = reinterpret_cast<const float4*>(&cells[(long)jl * C + jc]);
-            float4 n0 = np[0], n1 = np[1];
-            if (n0.z + n1.z > 0.5f && (float)(dx + dy) < distance) { distance = (float)(dx + dy); near_value = n1.y; }
-          }
-      }
+      for (int dy = -d; dy <= d; ++dy)
+        for (int dx = -d; dx <= d; ++dx) {
+          int o = (tr + d + dy) * pitch + (tc + d + dx);
+          if (smsk[o] > 0.5f && (float)(dx + dy) < distance) { distance = (float)(dx + dy); near_value = sval[o]; }
+        }
       if (distance < 100.f) res = near_value;
     }
-    out[c] = res;
+    out[(long)lr * C + col] = res;
   }
 }
 
@@ -451,19 +520,33 @@ void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, lo
     else hipLaunchKernelGGL((k_fuse<1, false>), g, b, 0, s, P, T, pts, n, stride, cells, acc, F, tail_idx, tail_flags);
   }
 }
-void launch_commit(hipStream_t s, const KP& P, Cell* cells, const AccF* acc, const FrameDev* F) {
-  hipLaunchKernelGGL(k_commit, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, acc, F);
+void launch_commit(hipStream_t s, const KP& P, Cell* cells, const AccF* acc, const FrameDev* F, unsigned long long* inert) {
+  hipLaunchKernelGGL(k_commit, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, acc, F, inert);
 }
-void launch_rays(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, const Cell* cells,
-                 const AccF* acc, AccR* accr, const float* normal, long plane_stride, FrameDev* F, bool stats) {
-  if (n <= 0) return;
-  dim3 g(nblk(n)), b(EM_BLOCK);
-  if (P.mode == 0) {
-    if (stats) hipLaunchKernelGGL((k_rays<0, true>), g, b, 0, s, P, T, pts, n, stride, cells, acc, accr, normal, plane_stride, F);
-    else hipLaunchKernelGGL((k_rays<0, false>), g, b, 0, s, P, T, pts, n, stride, cells, acc, accr, normal, plane_stride, F);
+#define RAY_BLOCK_LUT 1024
+template <int MODE, bool STATS> static void launch_rays_t(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
+                                                          long n, int stride, const Cell* cells, const AccF* acc, AccR* accr,
+                                                          const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert) {
+  const bool use_lut = MODE == 0 && Rt.lut != nullptr;
+  if (use_lut) {
+    size_t lds = ((size_t)(Rt.hi - Rt.lo) + 2) * 4;
+    dim3 g((unsigned int)((n + RAY_BLOCK_LUT - 1) / RAY_BLOCK_LUT)), b(RAY_BLOCK_LUT);
+    hipLaunchKernelGGL((k_rays<MODE, STATS, true, RAY_BLOCK_LUT>), g, b, lds, s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
   } else {
-    if (stats) hipLaunchKernelGGL((k_rays<1, true>), g, b, 0, s, P, T, pts, n, stride, cells, acc, accr, normal, plane_stride, F);
-    else hipLaunchKernelGGL((k_rays<1, false>), g, b, 0, s, P, T, pts, n, stride, cells, acc, accr, normal, plane_stride, F);
+    dim3 g(nblk(n)), b(EM_BLOCK);
+    hipLaunchKernelGGL((k_rays<MODE, STATS, false, EM_BLOCK>), g, b, 0, s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
+  }
+}
+void launch_rays(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts, long n, int stride, const Cell* cells,
+                 const AccF* acc, AccR* accr, const float* normal, long plane_stride, FrameDev* F, bool stats,
+                 const unsigned long long* inert) {
+  if (n <= 0) return;
+  if (P.mode == 0) {
+    if (stats) launch_rays_t<0, true>(s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
+    else launch_rays_t<0, false>(s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
+  } else {
+    if (stats) launch_rays_t<1, true>(s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
+    else launch_rays_t<1, false>(s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
   }
 }
 void launch_average(hipStream_t s, const KP& P, Cell* cells, AccF* acc, AccR* accr, const FrameDev* F, bool committed, bool rays) {
