@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library loads, exports every symbol include/emap_hip.h declares, and fails loudly without a GPU."""
+import ctypes as ct
+import os
+import re
+
+import pytest
+
+from conftest import HAS_GPU, ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "emap_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(emap_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from elevation_mapping_cupy_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libemap_hip.so does not export %s" % n
+    assert sorted(_lib.SYMBOLS) == names, "python binding table and header disagree"
+    assert lib.emap_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from elevation_mapping_cupy_amd import _lib
+    from oracle import emap_oracle as eo
+    assert ct.sizeof(_lib.EmapParams) == 8 * 4 + 28 * 8 + (36 * 3 + 12) * 4
+    assert ct.sizeof(_lib.EmapParams) == ct.sizeof(eo.EoParams)
+    assert ct.sizeof(_lib.EmapStrip) == 16
+    assert ct.sizeof(_lib.EmapStats) == 40
+
+
+def test_invalid_arguments_are_rejected_without_touching_a_device():
+    from elevation_mapping_cupy_amd import _lib
+    lib = _lib.load()
+    ctx = ct.c_void_p()
+    P = _lib.EmapParams()
+    P.cell_n = 4000; P.mode = 0; P.resolution = 0.04           # fp16 index mode cannot address 4000 cells
+    assert lib.emap_create(ct.byref(P), None, 0, None, ct.byref(ctx)) == -1 and not ctx.value
+    assert lib.emap_create(None, None, 0, None, ct.byref(ctx)) == -1
+    assert lib.emap_destroy(None) == 0
+    assert lib.emap_update(None, None, None, ct.c_double(0), ct.c_double(0), None) == -1
+
+
+@pytest.mark.skipif(HAS_GPU, reason="only meaningful on a machine without a HIP device")
+def test_no_cpu_fallback_without_gpu():
+    from elevation_mapping_cupy_amd import ElevationMap, Parameter
+    from elevation_mapping_cupy_amd._lib import EmapError
+    p = Parameter(); p.update()
+    with pytest.raises(EmapError):
+        ElevationMap(p)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "elevation_mapping_cupy_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "emap_oracle" not in txt, f
