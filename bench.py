@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--mode", default="reference_fp16", choices=["reference_fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--force-sharded", action="store_true", help="run the row-strip path even with one rank (self-test)")
     return ap.parse_args()
 
 
@@ -94,7 +95,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 or world > 1:
+    if a.gpus > 1 or world > 1 or a.force_sharded:
         from elevation_mapping_cupy_amd import sharded
         return sharded.bench_main(a, rank, world, local_rank)
 

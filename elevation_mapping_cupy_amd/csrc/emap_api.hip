@@ -13,7 +13,7 @@
 
 // launchers (emap_kernels.hip)
 void launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, ErrSlot*);
-void launch_gate(hipStream_t, const KP&, ErrSlot*, FrameDev*, int, double, double, float, int, int, double, unsigned int, unsigned int);
+void launch_gate(hipStream_t, const KP&, ErrSlot*, FrameDev*, int, double, double, float, int, int, double, unsigned int, unsigned int, int, double*, const double*);
 void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, const FrameDev*, int*, unsigned char*);
 void launch_commit(hipStream_t, const KP&, Cell*, const AccF*, const FrameDev*, unsigned long long*);
 void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, const Cell*, const AccF*, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*);
@@ -363,20 +363,49 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
   return EMAP_OK;
 }
 
-int emap_set_drift_inputs(emap_ctx* ctx, double position_noise, double orientation_noise, const double* err_sum_override,
-                          const uint32_t* err_cnt_override) {
-  CKARG(ctx, "null ctx");
+static int gate_impl(emap_ctx* ctx, double position_noise, double orientation_noise, int reduce_only, double* dev_out,
+                     const double* dev_totals) {
   CK(hipSetDevice(ctx->device));
-  ctx->pos_noise = position_noise; ctx->ori_noise = orientation_noise;
-  ctx->use_override = err_sum_override && err_cnt_override;
-  if (ctx->use_override) { ctx->sum_override = *err_sum_override; ctx->cnt_override = *err_cnt_override; }
   const emap_params& p = ctx->prm;
   int noise_ok = (position_noise > p.position_noise_thresh) || (orientation_noise > p.orientation_noise_thresh);
   launch_gate(ctx->stream, ctx->kp, ctx->slots, ctx->frame, p.enable_drift_compensation, p.min_height_drift_cnt, p.max_drift,
               (float)p.drift_compensation_alpha, noise_ok, ctx->use_override ? 1 : 0, ctx->sum_override, ctx->cnt_override,
-              (unsigned int)ctx->n_pts);
+              (unsigned int)ctx->n_pts, reduce_only, dev_out, dev_totals);
   CK(hipGetLastError());
   ctx->committed = false;
+  return EMAP_OK;
+}
+
+int emap_set_drift_inputs(emap_ctx* ctx, double position_noise, double orientation_noise, const double* err_sum_override,
+                          const uint32_t* err_cnt_override) {
+  CKARG(ctx, "null ctx");
+  ctx->pos_noise = position_noise; ctx->ori_noise = orientation_noise;
+  ctx->use_override = err_sum_override && err_cnt_override;
+  if (ctx->use_override) { ctx->sum_override = *err_sum_override; ctx->cnt_override = *err_cnt_override; }
+  return gate_impl(ctx, position_noise, orientation_noise, 0, nullptr, nullptr);
+}
+
+int emap_drift_sums_to_device(emap_ctx* ctx, double* dev_out2) {
+  CKARG(ctx && dev_out2, "null argument");
+  ctx->use_override = false;
+  return gate_impl(ctx, 0.0, 0.0, 1, dev_out2, nullptr);
+}
+
+int emap_set_drift_inputs_device(emap_ctx* ctx, double position_noise, double orientation_noise, const double* dev_totals2) {
+  CKARG(ctx && dev_totals2, "null argument");
+  ctx->use_override = false;
+  return gate_impl(ctx, position_noise, orientation_noise, 0, nullptr, dev_totals2);
+}
+
+int emap_local_drift_sums(emap_ctx* ctx, double* err_sum, uint32_t* err_cnt) {
+  CKARG(ctx && err_sum && err_cnt, "null argument");
+  ctx->use_override = false;
+  int rc = gate_impl(ctx, 0.0, 0.0, 1, nullptr, nullptr);
+  if (rc) return rc;
+  emap_stats st;
+  rc = emap_get_stats(ctx, &st);
+  if (rc) return rc;
+  *err_sum = st.err_sum; *err_cnt = st.err_cnt;
   return EMAP_OK;
 }
 

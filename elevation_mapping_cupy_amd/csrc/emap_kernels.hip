@@ -43,17 +43,26 @@ __global__ __launch_bounds__(EM_BLOCK) void k_count(KP P, Pose T, const float* _
 
 // Phase A': drift gate (elevation_mapping.py:346-357) evaluated on the device by one wave: reduces the slots
 // (integer => order independent), decides the shift, keeps additive_mean_error, re-arms the slots.
+// Row-strip contexts: `reduce_only` publishes the local sums (2 doubles, device memory) for the all-reduce and stops;
+// `dev_totals` (2 doubles, device memory, e.g. the all-reduced tensor) replaces the local sums in the gate.
 __global__ __launch_bounds__(64) void k_gate(KP P, ErrSlot* __restrict__ slots, FrameDev* __restrict__ F, int enable,
                                              double min_cnt, double max_drift, float alpha, int noise_ok,
                                              int use_override, double sum_override, unsigned int cnt_override,
-                                             unsigned int n_points) {
+                                             unsigned int n_points, int reduce_only, double* __restrict__ dev_out,
+                                             const double* __restrict__ dev_totals) {
   long long s = 0; unsigned long long k = 0;
   for (int j = threadIdx.x; j < EM_ERR_SLOTS; j += 64) { s += slots[j].sum; k += slots[j].cnt; slots[j].sum = 0; slots[j].cnt = 0; }
   s = wave_sum_ll(s); k = (unsigned long long)wave_sum_ll((long long)k);
   if (threadIdx.x == 0) {
-    F->err_sum_fix = s; F->err_cnt = k; F->n_points = n_points; F->ray_visits = 0;
-    double sum = use_override ? sum_override : (double)s / EM_SCALE_E;
-    float cnt = use_override ? (float)cnt_override : (float)k;
+    if (reduce_only) {
+      F->err_sum_fix = s; F->err_cnt = k; F->n_points = n_points; F->ray_visits = 0;
+      if (dev_out) { dev_out[0] = (double)s / EM_SCALE_E; dev_out[1] = (double)k; }
+      return;
+    }
+    if (!use_override && !dev_totals) { F->err_sum_fix = s; F->err_cnt = k; }
+    F->n_points = n_points; F->ray_visits = 0;
+    double sum = dev_totals ? dev_totals[0] : (use_override ? sum_override : (double)s / EM_SCALE_E);
+    float cnt = dev_totals ? (float)dev_totals[1] : (use_override ? (float)cnt_override : (float)k);
     float shift = 0.0f; int fired = 0;
     if (enable && (double)cnt > min_cnt && noise_ok) {
       float mean = (float)sum / cnt;
@@ -504,9 +513,10 @@ void launch_count(hipStream_t s, const KP& P, const Pose& T, const float* pts, l
   else hipLaunchKernelGGL(k_count<1>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, slots);
 }
 void launch_gate(hipStream_t s, const KP& P, ErrSlot* slots, FrameDev* F, int enable, double min_cnt, double max_drift,
-                 float alpha, int noise_ok, int use_override, double sum_override, unsigned int cnt_override, unsigned int n_points) {
+                 float alpha, int noise_ok, int use_override, double sum_override, unsigned int cnt_override, unsigned int n_points,
+                 int reduce_only, double* dev_out, const double* dev_totals) {
   hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, P, slots, F, enable, min_cnt, max_drift, alpha, noise_ok, use_override,
-                     sum_override, cnt_override, n_points);
+                     sum_override, cnt_override, n_points, reduce_only, dev_out, dev_totals);
 }
 void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, const Cell* cells, AccF* acc,
                  const FrameDev* F, int* tail_idx, unsigned char* tail_flags) {

@@ -1,0 +1,283 @@
+"""Row-strip sharding of the elevation map over the GPUs of one node (one process per GPU).
+
+New design -- the reference is single-GPU (SURVEY §2.1 "Parallelism strategies: none").  Cell index = C*ix + iy
+(reference custom_kernels.py:45-49), so rank g owns the contiguous rows ``[g*C//G, (g+1)*C//G)`` of every array.
+
+Per frame (same stage order as reference update_map_with_kernel, EM/elevation_mapping.py:316-391):
+
+    count (local rows) -> ALL-REDUCE(sum) of (err_sum, err_cnt) -> gate on the totals -> fuse -> [commit -> rays]
+    -> average -> overlap clearance -> HALO EXCHANGE of `halo` rows of cells with the strip neighbours
+    -> dilation (owned rows +-3) -> traversability + normals
+
+* the cloud is replicated: every rank reads all points and keeps those whose row it owns (no exchange for fusion);
+* rays need no communication: every rank marches every ray and acts only on its own rows;
+* the two exchange steps go through ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on the GPU box,
+  ``gloo`` in the CPU tests); buffers are plain device pointers on the C-ABI side (``emap_halo_pack/unpack``,
+  ``emap_drift_sums_to_device``), so nothing syncs with the host inside a frame.
+
+The orchestration is engine-agnostic (``StripEngine`` protocol) so that the world_size-2 gloo tests can drive it on
+CPU with a test engine; the product engine is ``HipStripEngine`` (libemap_hip.so).
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as ct
+import json
+import os
+import time
+
+import numpy as np
+
+
+def strip_rows(cell_n: int, world: int, rank: int):
+    """Rows [begin, end) owned by ``rank``."""
+    return (rank * cell_n) // world, ((rank + 1) * cell_n) // world
+
+
+def halo_rows_needed(dilation_size: int, world: int) -> int:
+    """dilation radius d, +3 rows for the traversability stencil computed from the dilated plane, +1 for the
+    reference's flat-index wrap into the adjacent row (custom_kernels.py:403-407)."""
+    return 0 if world == 1 else int(dilation_size) + 4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class TorchComm:
+    """The two collectives of the path on top of torch.distributed (nccl=RCCL on GPU, gloo on CPU)."""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device  # torch.device or None (CPU)
+
+    def all_reduce_sum_(self, tensor):
+        """in-place sum of a small float64 tensor (2 elements: err_sum, err_cnt)."""
+        if self.world > 1:
+            self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
+        return tensor
+
+    def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
+        """neighbour exchange on the strip chain: send_lo -> rank-1 (arrives in its recv_hi), send_hi -> rank+1
+        (arrives in its recv_lo).  Edge ranks have one neighbour."""
+        dist = self.dist
+        ops = []
+        if self.rank > 0:
+            ops.append(dist.P2POp(dist.isend, send_lo, self.rank - 1))
+            ops.append(dist.P2POp(dist.irecv, recv_lo, self.rank - 1))
+        if self.rank < self.world - 1:
+            ops.append(dist.P2POp(dist.isend, send_hi, self.rank + 1))
+            ops.append(dist.P2POp(dist.irecv, recv_hi, self.rank + 1))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_float(self, x):
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class HipStripEngine:
+    """One strip on one MI355X: thin adapter from the sharding protocol to the C ABI."""
+
+    def __init__(self, param, rank, world, device_index, torch_device):
+        import torch
+        from .elevation_mapping import ElevationMap
+        self.torch = torch
+        C = int(param.cell_n)
+        r0, r1 = strip_rows(C, world, rank)
+        self.halo = halo_rows_needed(param.dilation_size, world)
+        if world > 1 and (r1 - r0) < self.halo:
+            raise ValueError("strip of %d rows is thinner than the %d-row halo" % (r1 - r0, self.halo))
+        param.device = device_index
+        # one dedicated torch stream per strip: the HIP kernels (C ABI) and the collectives are ordered on it
+        self.stream = torch.cuda.Stream(device=torch_device)
+        self.map = ElevationMap(param, strip=(r0, r1 - r0, self.halo), stream=self.stream.cuda_stream)
+        self.lib, self.ctx = self.map._lib, self.map._ctx
+        self.C, self.rows = C, r1 - r0
+        n = max(1, self.halo * C * 8)
+        with torch.cuda.stream(self.stream):
+            mk = lambda: torch.zeros(n, dtype=torch.float32, device=torch_device)  # noqa: E731
+            self.send = [mk(), mk()]
+            self.recv = [mk(), mk()]
+            self.sums = torch.zeros(2, dtype=torch.float64, device=torch_device)
+        self.stream.synchronize()
+
+    def stream_ctx(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def _chk(self, rc):
+        self.map._chk(rc)
+
+    def bind_points_device(self, ptr, n, stride):
+        self.map.bind_points_device(ptr, n, stride)
+
+    def bind_points(self, points):
+        self.map.bind_points(points)
+
+    def count(self, R, t):
+        self.map.stage("count", R, t)
+
+    def local_sums(self):
+        self._chk(self.lib.emap_drift_sums_to_device(self.ctx, ct.c_void_p(self.sums.data_ptr())))
+        return self.sums
+
+    def gate(self, pn, on, totals):
+        self._chk(self.lib.emap_set_drift_inputs_device(self.ctx, ct.c_double(pn), ct.c_double(on), ct.c_void_p(totals.data_ptr())))
+
+    def fuse(self, R, t):
+        self.map.stage("fuse", R, t)
+
+    def commit(self):
+        self.map.stage("commit")
+
+    def rays(self, R, t):
+        self.map.stage("rays", R, t)
+
+    def average(self):
+        self.map.stage("average")
+
+    def overlap(self, tz):
+        self.map.stage("overlap", t=tz)
+
+    def halo_pack(self):
+        for side in (0, 1):
+            self._chk(self.lib.emap_halo_pack(self.ctx, side, ct.c_void_p(self.send[side].data_ptr())))
+        return self.send[0], self.send[1], self.recv[0], self.recv[1]
+
+    def halo_unpack(self, have_lo, have_hi):
+        if have_lo:
+            self._chk(self.lib.emap_halo_unpack(self.ctx, 0, ct.c_void_p(self.recv[0].data_ptr())))
+        if have_hi:
+            self._chk(self.lib.emap_halo_unpack(self.ctx, 1, ct.c_void_p(self.recv[1].data_ptr())))
+
+    def dilate(self):
+        self.map.stage("dilate")
+
+    def trav_normals(self):
+        self.map.stage("traversability_normals")
+
+    def update_time(self):
+        self.map.update_time()
+
+    def update_variance(self):
+        self.map.update_variance()
+
+    def owned_planes(self):
+        return self.map.elevation_map
+
+    def sync(self):
+        self.map.sync()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class ShardedElevationMap:
+    """Frame orchestration over row strips; ``engine`` implements the stage protocol for the local strip."""
+
+    def __init__(self, engine, comm, enable_visibility_cleanup, enable_overlap_clearance):
+        self.e, self.comm = engine, comm
+        self.rays_on, self.overlap_on = bool(enable_visibility_cleanup), bool(enable_overlap_clearance)
+
+    def update(self, R, t, position_noise, orientation_noise):
+        """One frame on the bound (replicated) cloud; ``t`` is map-centre relative."""
+        e, c = self.e, self.comm
+        ctx = e.stream_ctx() if hasattr(e, "stream_ctx") else contextlib.nullcontext()
+        with ctx:
+            self._update(R, t, position_noise, orientation_noise)
+
+    def _update(self, R, t, position_noise, orientation_noise):
+        e, c = self.e, self.comm
+        e.count(R, t)
+        totals = c.all_reduce_sum_(e.local_sums())            # exchange step 1: 2 scalars
+        e.gate(position_noise, orientation_noise, totals)
+        e.fuse(R, t)
+        if self.rays_on:
+            e.commit()
+            e.rays(R, t)
+        e.average()
+        if self.overlap_on:
+            e.overlap(float(np.float32(np.asarray(t, np.float32).reshape(3)[2])))
+        if c.world > 1:                                        # exchange step 2: halo rows of cells
+            s_lo, s_hi, r_lo, r_hi = e.halo_pack()
+            c.exchange(s_lo, s_hi, r_lo, r_hi)
+            e.halo_unpack(c.rank > 0, c.rank < c.world - 1)
+        e.dilate()
+        e.trav_normals()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def bench_main(a, rank, world, local_rank):
+    """``bench.py --gpus N`` under torch.distributed.run: row strips of the SAME workload as N=1 (strong scaling)."""
+    import torch
+    import torch.distributed as dist
+    from .configs import CORE_PARAM_YAML, parameter_from
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _fixtures as fx
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    cfg = dict(CORE_PARAM_YAML)
+    if a.workload == "cfg2":
+        cfg.update(enable_visibility_cleanup=False, enable_overlap_clearance=False)
+    C, N = a.cell_n, a.points
+    w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
+    weights = {k: w[k] for k in ("w1", "w2", "w3", "w_out")}
+    par = parameter_from(cfg, C, a.mode, weights, device=local_rank)
+    comm = TorchComm(dev)
+    eng = HipStripEngine(par, rank, world, local_rank, dev)
+    sm = ShardedElevationMap(eng, comm, cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
+
+    NCLOUD = 5
+    clouds = [torch.from_numpy(fx.cloud(C, N, s, dz=(0.0 if s == 0 else -0.02 * s))).to(dev) for s in range(NCLOUD)]
+    R = np.eye(3, dtype=np.float32).ravel().copy()
+    t = np.array([0, 0, 1], np.float32)
+
+    def frame(i):
+        cl = clouds[i % NCLOUD]
+        eng.bind_points_device(cl.data_ptr(), N, 3)
+        sm.update(R, t, 1.0, 1.0)
+
+    for i in range(3):
+        frame(i)
+        for _ in range(4):
+            eng.update_time()
+    eng.update_variance()
+    for i in range(a.warmup):
+        frame(i)
+    torch.cuda.synchronize(); comm.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        frame(i)
+    torch.cuda.synchronize()
+    wall_local = time.perf_counter() - t0
+    comm.barrier(); torch.cuda.synchronize()
+    wall = comm.max_float(max(wall_local, 0.0))
+    if rank == 0:
+        out = {
+            "metric": "Mpoints/s fused (map-update p50 latency in config)", "value": round(N * a.steps / wall / 1e6, 2),
+            "unit": "Mpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(wall * 1e3 / a.steps, 5), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %dx%d map in %d row strips, %d uniform-random points/frame replicated to every rank, "
+                                   "core_param.yaml values" % (a.workload, C, C, world, N),
+                       "index_mode": a.mode, "halo_rows": eng.halo, "parallelism": "row-strips x%d" % world,
+                       "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame (RCCL)"},
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()

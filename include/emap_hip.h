@@ -102,6 +102,12 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
 int emap_count(emap_ctx* ctx, const float R[9], const float t[3]);          /* error_counting_kernel :334-345 */
 int emap_set_drift_inputs(emap_ctx* ctx, double position_noise, double orientation_noise, const double* err_sum_override,
                           const uint32_t* err_cnt_override); /* gate inputs (:346-354); overrides = all-reduced totals */
+/* row strips: publish the strip-local (err_sum, err_cnt) as 2 doubles in DEVICE memory (async, no host sync) so
+ * the caller can all-reduce them (RCCL), then gate on the reduced totals read from device memory. The _local_ form
+ * is the blocking host variant. */
+int emap_drift_sums_to_device(emap_ctx* ctx, double* dev_out2);
+int emap_set_drift_inputs_device(emap_ctx* ctx, double position_noise, double orientation_noise, const double* dev_totals2);
+int emap_local_drift_sums(emap_ctx* ctx, double* err_sum, uint32_t* err_cnt);
 int emap_fuse(emap_ctx* ctx, const float R[9], const float t[3]);           /* add_points_kernel fusion part */
 int emap_commit(emap_ctx* ctx);                                             /* side effects of :174,:189-192 -> S1 */
 int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]);           /* add_points_kernel visibility part */

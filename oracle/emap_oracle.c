@@ -109,6 +109,12 @@ static inline int is_valid(const eo_params* P, float x_, float y_, float z_, flo
 
 typedef struct { float x, y, z, v; int idx, valid, inside, finite; } pt_t;
 
+/* Row-strip view used by the multi-process (gloo) sharding tests: point / ray stages only touch cells whose row
+ * (ix = idx / C) lies in [g_row0, g_row1).  Default = whole map. */
+static int g_row0 = 0, g_row1 = 0x7fffffff;
+void eo_set_strip(int row0, int row1) { g_row0 = row0; g_row1 = row1; }
+static inline int owned(const eo_params* P, int idx) { int ix = idx / P->cell_n; return ix >= g_row0 && ix < g_row1; }
+
 static inline pt_t point_geometry(const eo_params* P, const float* p, const float* R, const float* t) {
   pt_t o; memset(&o, 0, sizeof o);
   float rx = p[0], ry = p[1], rz = p[2];
@@ -139,7 +145,7 @@ void eo_count(const eo_params* P, const float* map, const float* pts, long n, lo
   const long L = (long)P->cell_n * P->cell_n;
   for (long i = 0; i < n; ++i) {
     pt_t g = point_geometry(P, pts + i * stride, R, t);
-    if (!g.finite || !g.valid || !g.inside) continue;
+    if (!g.finite || !g.valid || !g.inside || !owned(P, g.idx)) continue;
     float h = map[g.idx], v = map[L + g.idx], valid = map[2 * L + g.idx], trav = map[3 * L + g.idx];
     if (valid > 0.5f && (double)fabsf(h - g.z) < (double)v * P->mahalanobis_thresh &&
         (double)v < P->drift_compensation_variance_inlier / 2.0 && (double)trav > P->traversability_inlier) {
@@ -175,7 +181,7 @@ void eo_fuse(const eo_params* P, const float* map, const float* pts, long n, lon
   const long L = (long)P->cell_n * P->cell_n;
   for (long i = 0; i < n; ++i) {
     pt_t g = point_geometry(P, pts + i * stride, R, t);
-    if (!g.finite || !g.valid || !g.inside) continue;
+    if (!g.finite || !g.valid || !g.inside || !owned(P, g.idx)) continue;
     float map_h = map[g.idx], map_v = map[L + g.idx], num_points = (float)n_pts[g.idx];
     if ((double)fabsf(map_h - g.z) > (double)map_v * P->mahalanobis_thresh) { n_out[g.idx] += 1; continue; }
     if (P->enable_edge_sharpen && (double)num_points > P->wall_num_thresh &&
@@ -221,7 +227,7 @@ void eo_rays(const eo_params* P, const float* map, const float* normal, const ui
       int nidx = get_idx(P, nx, ny, 0.0f, 0.0f);
       if (nidx == last) continue;
       last = nidx;
-      if (!is_inside(P, nidx)) continue;
+      if (!is_inside(P, nidx) || !owned(P, nidx)) continue;
       visits++;
       float h = map[nidx], v = map[L + nidx], valid = map[2 * L + nidx], time = map[4 * L + nidx];
       float upper = map[5 * L + nidx], is_upper = map[6 * L + nidx];

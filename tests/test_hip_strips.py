@@ -1,0 +1,92 @@
+"""GPU: the strip kernels (row0/nrows/halo addressing, owned-row filter of points and rays, device-side drift sums,
+halo pack/unpack) -- G strip contexts on ONE device driven in lock-step by threads must reproduce the single-context
+map bit for bit.  (The multi-process exchange itself is covered on CPU by tests/test_sharded_gloo.py; the driver's
+multi-GPU run uses the same ShardedElevationMap with TorchComm over RCCL.)"""
+import threading
+
+import numpy as np
+import pytest
+
+import _fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+class ThreadComm:
+    """in-process stand-in for TorchComm: same interface, ranks are threads of one process on one GPU."""
+
+    def __init__(self, rank, world, shared):
+        self.rank, self.world, self.sh = rank, world, shared
+
+    def all_reduce_sum_(self, t):
+        sh = self.sh
+        sh["sums"][self.rank] = t
+        sh["bar"].wait()
+        if self.rank == 0:
+            import torch
+            torch.cuda.synchronize()
+            tot = sum(x.clone() for x in sh["sums"])
+            torch.cuda.synchronize()
+            sh["tot"] = tot
+        sh["bar"].wait()
+        t.copy_(sh["tot"])
+        sh["bar"].wait()
+        return t
+
+    def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
+        import torch
+        sh = self.sh
+        sh["send"][self.rank] = (send_lo, send_hi)
+        torch.cuda.synchronize()
+        sh["bar"].wait()
+        if self.rank > 0:
+            recv_lo.copy_(sh["send"][self.rank - 1][1])
+        if self.rank < self.world - 1:
+            recv_hi.copy_(sh["send"][self.rank + 1][0])
+        torch.cuda.synchronize()
+        sh["bar"].wait()
+
+
+@pytest.mark.parametrize("world,cfg_name,C", [(2, "yaml", 130), (3, "default", 202)])
+def test_strip_contexts_reproduce_single_context(world, cfg_name, C, weights):
+    import torch
+    from elevation_mapping_cupy_amd.configs import parameter_from
+    from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
+    from elevation_mapping_cupy_amd.sharded import HipStripEngine, ShardedElevationMap
+    from oracle import emap_oracle as eo
+    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML if cfg_name == "yaml" else {})
+    N = 30000
+    R, t = fx.POSES["rotated"]
+    clouds = [fx.cloud(C, N, f, dz=dz) for f, dz in enumerate((0.0, -0.02, -0.1))]
+    full = ElevationMap(parameter_from(cfg, C, "reference_fp16", weights))
+    for p in clouds:
+        full.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0)
+        for _ in range(6):
+            full.update_time()
+    want, want_n = full.elevation_map, full.normal_map
+    dev = torch.device("cuda", 0)
+    shared = {"bar": threading.Barrier(world), "sums": [None] * world, "send": [None] * world}
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            eng = HipStripEngine(parameter_from(cfg, C, "reference_fp16", weights), rank, world, 0, dev)
+            sm = ShardedElevationMap(eng, ThreadComm(rank, world, shared), cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
+            for p in clouds:
+                eng.bind_points(p)
+                sm.update(R, t, 1.0, 1.0)
+                for _ in range(6):
+                    eng.update_time()
+            eng.sync()
+            out[rank] = (eng.map.row_begin, eng.map.rows, eng.map.elevation_map, eng.map.normal_map, eng.map.get_additive_mean_error())
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            shared["bar"].abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [x.start() for x in th]; [x.join() for x in th]
+    assert not errs, errs
+    for r0, rows, m, nm, add in out:
+        assert m.tobytes() == want[:, r0:r0 + rows].tobytes(), "strip at row %d differs" % r0
+        assert nm.tobytes() == want_n[:, r0:r0 + rows].tobytes()
+        assert add == full.get_additive_mean_error()

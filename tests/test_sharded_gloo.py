@@ -1,0 +1,131 @@
+"""CPU, multi-process: the row-strip orchestration of elevation_mapping_cupy_amd/sharded.py (strip layout, the
+drift all-reduce, halo width and exchange order) driven over torch.distributed/gloo with world_size 2 and 3.
+The local compute of each rank is the CPU oracle restricted to its strip (tests may use the oracle; on the GPU box
+the same orchestration runs with HipStripEngine).  The union of the owned rows must equal a single-process run."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+class OracleStripEngine:
+    def __init__(self, cfg, C, rank, world, weights):
+        import torch
+        from elevation_mapping_cupy_amd.sharded import halo_rows_needed, strip_rows
+        from oracle import emap_oracle as eo
+        self.torch, self.eo = torch, eo
+        self.om = eo.OracleMap(eo.make_params(cfg, cell_n=C, weights=weights))
+        self.r0, self.r1 = strip_rows(C, world, rank)
+        self.H = halo_rows_needed(self.om.P.dilation_size, world)
+        eo.lib().eo_set_strip(self.r0, self.r1)
+        self.C = C
+        # poison the rows this rank does not own: only the halo exchange may make them usable
+        rng = np.random.default_rng(100 + rank)
+        mask = np.ones(C, bool); mask[self.r0:self.r1] = False
+        self.om.elevation_map[:, mask, :] = rng.uniform(-5, 5, (7, int(mask.sum()), C)).astype(np.float32)
+        self.recv = [torch.zeros((7, max(self.H, 1), C), dtype=torch.float32) for _ in range(2)]
+
+    def bind_points(self, p):
+        self.p = p
+
+    def count(self, R, t):
+        self.om.count(self.p, R, t)
+
+    def local_sums(self):
+        return self.torch.tensor([self.om.last["err_sum"], float(self.om.last["err_cnt"])], dtype=self.torch.float64)
+
+    def gate(self, pn, on, totals):
+        self.om.last["err_sum"], self.om.last["err_cnt"] = float(totals[0]), int(round(float(totals[1])))
+        self.om.gate(pn, on)
+
+    def fuse(self, R, t): self.om.fuse(self.p, R, t)
+    def commit(self): self.om.commit()
+    def rays(self, R, t): self.om.rays(self.p, R, t)
+    def average(self): self.om.average()
+    def overlap(self, tz): self.om.overlap_clear(tz)
+
+    def halo_pack(self):
+        m, H = self.om.elevation_map, self.H
+        lo = self.torch.from_numpy(np.ascontiguousarray(m[:, self.r0:self.r0 + H]))
+        hi = self.torch.from_numpy(np.ascontiguousarray(m[:, self.r1 - H:self.r1]))
+        return lo, hi, self.recv[0], self.recv[1]
+
+    def halo_unpack(self, have_lo, have_hi):
+        m, H = self.om.elevation_map, self.H
+        if have_lo:
+            m[:, self.r0 - H:self.r0] = self.recv[0].numpy()
+        if have_hi:
+            m[:, self.r1:self.r1 + H] = self.recv[1].numpy()
+
+    def dilate(self): self.om.dilate()
+    def trav_normals(self): self.om.traversability(); self.om.normals()
+    def update_time(self): self.om.update_time()
+
+
+def _worker(rank, world, port, outdir, cfg_name, C, N):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    import _fixtures as fx
+    from elevation_mapping_cupy_amd.sharded import ShardedElevationMap, TorchComm
+    from oracle import emap_oracle as eo
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = dict(eo.YAML if cfg_name == "yaml" else eo.DEFAULTS)
+    w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz")); weights = {k: w[k] for k in w.files}
+    eng = OracleStripEngine(cfg, C, rank, world, weights)
+    sm = ShardedElevationMap(eng, TorchComm(None), cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
+    R, t = fx.POSES["rotated"]
+    for f, dz in enumerate((0.0, -0.02, -0.1)):
+        eng.bind_points(fx.cloud(C, N, f, dz=dz))          # replicated cloud
+        sm.update(R, t, 1.0, 1.0)
+        for _ in range(6):
+            eng.update_time()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), r0=eng.r0, r1=eng.r1, emap=eng.om.elevation_map[:, eng.r0:eng.r1],
+             normal=eng.om.normal_map[:, eng.r0:eng.r1], add_err=np.float32(eng.om.additive_mean_error))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cfg_name,C,N", [(2, "yaml", 130, 20000), (3, "default", 98, 12000)])
+def test_strips_equal_single_process(world, cfg_name, C, N, weights):
+    import torch.multiprocessing as mp
+    import _fixtures as fx
+    from oracle import emap_oracle as eo
+    outdir = tempfile.mkdtemp()
+    mp.spawn(_worker, args=(world, _free_port(), outdir, cfg_name, C, N), nprocs=world, join=True)
+    cfg = dict(eo.YAML if cfg_name == "yaml" else eo.DEFAULTS)
+    eo.lib().eo_set_strip(0, 1 << 30)
+    ref = eo.OracleMap(eo.make_params(cfg, cell_n=C, weights=weights))
+    R, t = fx.POSES["rotated"]
+    for f, dz in enumerate((0.0, -0.02, -0.1)):
+        ref.update_map_with_kernel(fx.cloud(C, N, f, dz=dz), R, t, 1.0, 1.0)
+        for _ in range(6):
+            ref.update_time()
+    covered = np.zeros(C, bool)
+    for r in range(world):
+        g = np.load(os.path.join(outdir, "rank%d.npz" % r))
+        r0, r1 = int(g["r0"]), int(g["r1"])
+        covered[r0:r1] = True
+        assert np.allclose(g["emap"], ref.elevation_map[:, r0:r1], atol=1e-6, rtol=1e-6, equal_nan=True), "rank %d planes" % r
+        assert np.allclose(g["normal"], ref.normal_map[:, r0:r1], atol=1e-6), "rank %d normals" % r
+        assert abs(float(g["add_err"]) - float(ref.additive_mean_error)) < 1e-6
+    assert covered.all()
+
+
+def test_strip_layout():
+    from elevation_mapping_cupy_amd.sharded import halo_rows_needed, strip_rows
+    for C in (202, 1024, 8192, 130):
+        for G in (1, 2, 3, 4, 8):
+            rows = [strip_rows(C, G, g) for g in range(G)]
+            assert rows[0][0] == 0 and rows[-1][1] == C
+            assert all(rows[i][1] == rows[i + 1][0] for i in range(G - 1))
+    assert halo_rows_needed(3, 1) == 0 and halo_rows_needed(3, 4) == 7
