@@ -42,6 +42,11 @@ class EmapStats(ct.Structure):
                 ("n_points", ct.c_uint32), ("ray_visits", ct.c_uint64)]
 
 
+class EmapSemSpec(ct.Structure):
+    _fields_ = [("n_sum", ct.c_int32), ("sum_chan", ct.c_int32 * 16), ("sum_layer", ct.c_int32 * 16), ("sum_kind", ct.c_int32 * 16),
+                ("n_col", ct.c_int32), ("col_chan", ct.c_int32 * 4), ("col_layer", ct.c_int32 * 4), ("alpha", ct.c_double)]
+
+
 MODE = {"reference_fp16": 0, "fp32": 1}
 PLANES = {"elevation": 0, "variance": 1, "is_valid": 2, "traversability": 3, "time": 4, "upper_bound": 5,
           "is_upper_bound": 6, "normal_x": 7, "normal_y": 8, "normal_z": 9, "traversability_input": 10}
@@ -54,7 +59,8 @@ SYMBOLS = [
     "emap_set_drift_inputs", "emap_drift_sums_to_device", "emap_set_drift_inputs_device",
     "emap_local_drift_sums", "emap_fuse", "emap_commit", "emap_rays", "emap_average", "emap_overlap_clear",
     "emap_dilate", "emap_traversability_normals", "emap_update_variance", "emap_update_time", "emap_get_stats",
-    "emap_get_layer", "emap_set_layer", "emap_shift", "emap_halo_bytes", "emap_halo_pack", "emap_halo_unpack",
+    "emap_get_layer", "emap_set_layer", "emap_shift", "emap_semantic_configure", "emap_semantic_update",
+    "emap_semantic_get_layer", "emap_semantic_set_layer", "emap_semantic_clear", "emap_halo_bytes", "emap_halo_pack", "emap_halo_unpack",
     "emap_timer_begin", "emap_timer_end", "emap_enable_stage_timing", "emap_get_stage_times",
 ]
 

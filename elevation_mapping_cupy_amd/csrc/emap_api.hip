@@ -17,7 +17,13 @@ void launch_gate(hipStream_t, const KP&, ErrSlot*, FrameDev*, int, double, doubl
 void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, const FrameDev*, int*, unsigned char*);
 void launch_commit(hipStream_t, const KP&, Cell*, const AccF*, const FrameDev*, unsigned long long*);
 void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, const Cell*, const AccF*, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*);
-void launch_average(hipStream_t, const KP&, Cell*, AccF*, AccR*, const FrameDev*, bool, bool);
+void launch_average(hipStream_t, const KP&, Cell*, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*);
+#define SEM_MAX_CH 16
+struct SemSpec { int n_sum; int sum_chan[SEM_MAX_CH]; int sum_layer[SEM_MAX_CH]; int sum_kind[SEM_MAX_CH]; int n_col; int col_chan[4]; int col_layer[4]; double alpha; };
+static_assert(sizeof(SemSpec) == sizeof(emap_sem_spec), "emap_sem_spec layout");
+void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
+void launch_sem_finalize(hipStream_t, const KP&, const SemSpec&, const unsigned int*, double*, unsigned int*, float*, long);
+void launch_sem_shift(hipStream_t, int, int, const float*, float*, int, int);
 void launch_overlap(hipStream_t, const KP&, Cell*, int, int, float, float);
 void launch_dilate(hipStream_t, const KP&, const Cell*, float*, int, int, int);
 void launch_trav_normal(hipStream_t, const KP&, const float*, const float*, const float*, const float*, const float*, Cell*, float*, long);
@@ -46,6 +52,8 @@ struct emap_ctx {
   ErrSlot* slots; FrameDev* frame;
   RayTab rt; float* ray_S; unsigned short* ray_lut;
   unsigned long long* inert;       // 1 bit per owned cell, written by k_commit
+  // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
+  int sem_layers; float* sem; double* sem_sums; unsigned int* sem_col; unsigned int* cnt_plane;
   // point cloud
   float* pts_own; long pts_cap;    // owned buffer (floats)
   double* pts_f64; long pts_f64_cap;
@@ -203,6 +211,7 @@ int emap_destroy(emap_ctx* ctx) {
   hipFree(ctx->cells); hipFree(ctx->cells_alt); hipFree(ctx->acc); hipFree(ctx->accr); hipFree(ctx->trav_in);
   hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->slots); hipFree(ctx->frame); hipFree(ctx->pts_own);
   hipFree(ctx->pts_f64); hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert);
+  hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   for (int i = 0; i <= ST_N; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   if (ctx->t0) hipEventDestroy(ctx->t0);
   if (ctx->t1) hipEventDestroy(ctx->t1);
@@ -441,7 +450,7 @@ int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
 int emap_average(emap_ctx* ctx) {
   CKARG(ctx, "null ctx");
   CK(hipSetDevice(ctx->device));
-  launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, true);
+  launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, true, ctx->cnt_plane);
   ctx->committed = false;
   CK(hipGetLastError());
   return EMAP_OK;
@@ -513,7 +522,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
     if ((rc = emap_rays(ctx, R, t))) return rc;
   } else STAGE(3);
   STAGE(4);
-  launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, p.enable_visibility_cleanup != 0);
+  launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, p.enable_visibility_cleanup != 0, ctx->cnt_plane);
   ctx->committed = false;
   CK(hipGetLastError());
   STAGE(5);
@@ -575,6 +584,79 @@ int emap_shift(emap_ctx* ctx, int32_t shift_rows, int32_t shift_cols, float dz) 
   launch_shift(ctx->stream, ctx->kp, ctx->cells, ctx->cells_alt, shift_rows, shift_cols, dz);
   CK(hipGetLastError());
   Cell* tmp = ctx->cells; ctx->cells = ctx->cells_alt; ctx->cells_alt = tmp;
+  if (ctx->sem_layers > 0 && (shift_rows != 0 || shift_cols != 0)) {   // SemanticMap.shift_map_xy (semantic_map.py:127-136)
+    float* alt = nullptr;
+    CK(hipMalloc((void**)&alt, sizeof(float) * ctx->ncells_alloc * ctx->sem_layers));
+    launch_sem_shift(ctx->stream, ctx->prm.cell_n, ctx->sem_layers, ctx->sem, alt, shift_rows, shift_cols);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipFree(ctx->sem)); ctx->sem = alt;
+  }
+  return EMAP_OK;
+}
+
+// ---- RGB / semantic layers (EM/semantic_map.py, EM/fusion/pointcloud_{average,class_average,color}.py) -------------
+int emap_semantic_configure(emap_ctx* ctx, int32_t n_layers) {
+  CKARG(ctx && n_layers >= 0 && n_layers <= 64, "bad layer count");
+  CK(hipSetDevice(ctx->device));
+  const long n = ctx->ncells_alloc;
+  if (!ctx->cnt_plane) {
+    CK(hipMalloc((void**)&ctx->cnt_plane, sizeof(unsigned int) * n));
+    CK(hipMemsetAsync(ctx->cnt_plane, 0, sizeof(unsigned int) * n, ctx->stream));
+    CK(hipMalloc((void**)&ctx->sem_col, sizeof(unsigned int) * n * 13));
+    CK(hipMemsetAsync(ctx->sem_col, 0, sizeof(unsigned int) * n * 13, ctx->stream));
+  }
+  if (n_layers > ctx->sem_layers) {      // grow, keeping existing layers (SemanticMap.add_layer, semantic_map.py:80-97)
+    float* ns = nullptr; double* nq = nullptr;
+    CK(hipMalloc((void**)&ns, sizeof(float) * n * n_layers));
+    CK(hipMalloc((void**)&nq, sizeof(double) * n * n_layers));
+    CK(hipMemsetAsync(ns, 0, sizeof(float) * n * n_layers, ctx->stream));
+    CK(hipMemsetAsync(nq, 0, sizeof(double) * n * n_layers, ctx->stream));
+    if (ctx->sem_layers > 0) CK(hipMemcpyAsync(ns, ctx->sem, sizeof(float) * n * ctx->sem_layers, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->sem) CK(hipFree(ctx->sem));
+    if (ctx->sem_sums) CK(hipFree(ctx->sem_sums));
+    ctx->sem = ns; ctx->sem_sums = nq; ctx->sem_layers = n_layers;
+  }
+  return EMAP_OK;
+}
+
+int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], const emap_sem_spec* spec) {
+  CKARG(ctx && R && t && spec, "null argument"); NEED_POINTS();
+  CKARG(spec->n_sum >= 0 && spec->n_sum <= SEM_MAX_CH && spec->n_col >= 0 && spec->n_col <= 4, "too many channels");
+  CKARG(ctx->cnt_plane, "emap_semantic_configure must be called before the frame (the average pass records the counts)");
+  for (int k = 0; k < spec->n_sum; ++k)
+    CKARG(spec->sum_layer[k] >= 0 && spec->sum_layer[k] < ctx->sem_layers && spec->sum_chan[k] >= 3 && spec->sum_chan[k] < ctx->stride, "bad channel/layer index");
+  for (int k = 0; k < spec->n_col; ++k)
+    CKARG(spec->col_layer[k] >= 0 && spec->col_layer[k] < ctx->sem_layers && spec->col_chan[k] >= 3 && spec->col_chan[k] < ctx->stride, "bad colour channel/layer index");
+  CK(hipSetDevice(ctx->device));
+  SemSpec S; memcpy(&S, spec, sizeof S);
+  launch_sem_points(ctx->stream, ctx->kp, make_pose(ctx, R, t), S, ctx->pts, ctx->n_pts, ctx->stride, ctx->sem_sums, ctx->sem_col, ctx->ncells_alloc);
+  launch_sem_finalize(ctx->stream, ctx->kp, S, ctx->cnt_plane, ctx->sem_sums, ctx->sem_col, ctx->sem, ctx->ncells_alloc);
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+
+int emap_semantic_get_layer(emap_ctx* ctx, int32_t layer, float* host_out) {
+  CKARG(ctx && host_out && layer >= 0 && layer < ctx->sem_layers, "bad argument");
+  CK(hipSetDevice(ctx->device));
+  const long off = (long)layer * ctx->ncells_alloc + (long)ctx->strip.halo_rows * ctx->prm.cell_n;
+  CK(hipMemcpyAsync(host_out, ctx->sem + off, sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
+  return EMAP_OK;
+}
+int emap_semantic_set_layer(emap_ctx* ctx, int32_t layer, const float* host_in) {
+  CKARG(ctx && host_in && layer >= 0 && layer < ctx->sem_layers, "bad argument");
+  CK(hipSetDevice(ctx->device));
+  const long off = (long)layer * ctx->ncells_alloc + (long)ctx->strip.halo_rows * ctx->prm.cell_n;
+  CK(hipMemcpyAsync(ctx->sem + off, host_in, sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n, hipMemcpyHostToDevice, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
+  return EMAP_OK;
+}
+int emap_semantic_clear(emap_ctx* ctx) {
+  CKARG(ctx, "null ctx");
+  CK(hipSetDevice(ctx->device));
+  if (ctx->sem_layers > 0) CK(hipMemsetAsync(ctx->sem, 0, sizeof(float) * ctx->ncells_alloc * ctx->sem_layers, ctx->stream));
   return EMAP_OK;
 }
 

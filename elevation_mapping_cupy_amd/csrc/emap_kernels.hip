@@ -267,7 +267,8 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
 // ---------------------------------------------------------------------------------------------------------
 template <bool COMMITTED, bool RAYS>
 __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cell* __restrict__ cells, AccF* __restrict__ acc,
-                                                       AccR* __restrict__ accr, const FrameDev* __restrict__ F) {
+                                                       AccR* __restrict__ accr, const FrameDev* __restrict__ F,
+                                                       unsigned int* __restrict__ cnt_out) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
   long c = li + (long)P.halo * P.C;
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cell* __restrict__ c
   }
   float valid0 = m.valid;
   unsigned int cnt = (unsigned int)(a.cnt_out & 0xffffffffull);
+  if (cnt_out) cnt_out[c] = cnt;   // accepted-point count survives for the semantic fusion (new_elmap plane 2)
   if (cnt > 0) {
     float nh = (float)(((double)a.sum_h / EM_SCALE_H) / (double)cnt);
     float nv = (float)(((double)a.sum_v / EM_SCALE_V) / (double)cnt);
@@ -559,14 +561,15 @@ void launch_rays(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, co
     else launch_rays_t<1, false>(s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
   }
 }
-void launch_average(hipStream_t s, const KP& P, Cell* cells, AccF* acc, AccR* accr, const FrameDev* F, bool committed, bool rays) {
+void launch_average(hipStream_t s, const KP& P, Cell* cells, AccF* acc, AccR* accr, const FrameDev* F, bool committed, bool rays,
+                    unsigned int* cnt_out) {
   dim3 g(nblk((long)P.nrows * P.C)), b(EM_BLOCK);
   if (committed) {
-    if (rays) hipLaunchKernelGGL((k_average<true, true>), g, b, 0, s, P, cells, acc, accr, F);
-    else hipLaunchKernelGGL((k_average<true, false>), g, b, 0, s, P, cells, acc, accr, F);
+    if (rays) hipLaunchKernelGGL((k_average<true, true>), g, b, 0, s, P, cells, acc, accr, F, cnt_out);
+    else hipLaunchKernelGGL((k_average<true, false>), g, b, 0, s, P, cells, acc, accr, F, cnt_out);
   } else {
-    if (rays) hipLaunchKernelGGL((k_average<false, true>), g, b, 0, s, P, cells, acc, accr, F);
-    else hipLaunchKernelGGL((k_average<false, false>), g, b, 0, s, P, cells, acc, accr, F);
+    if (rays) hipLaunchKernelGGL((k_average<false, true>), g, b, 0, s, P, cells, acc, accr, F, cnt_out);
+    else hipLaunchKernelGGL((k_average<false, false>), g, b, 0, s, P, cells, acc, accr, F, cnt_out);
   }
 }
 void launch_overlap(hipStream_t s, const KP& P, Cell* cells, int cmin, int cmax, float hmin, float hmax) {

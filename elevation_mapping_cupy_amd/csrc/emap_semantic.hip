@@ -1,0 +1,117 @@
+// RGB / semantic point-cloud fusion (BASELINE config 5: height + RGB + semantic layers).
+// Reference: EM/kernels/custom_semantic_kernels.py -- sum_kernel :9-51, average_kernel :167-194, class_average_kernel
+// :233-267, add_color_kernel :270-317, color_average_kernel :320-375 -- driven by EM/fusion/pointcloud_average.py:93-113,
+// pointcloud_class_average.py:106-126, pointcloud_color.py:131-152 and EM/semantic_map.py:223-259.
+// The reference re-reads a float-encoded cell index from the clobbered xyz columns (custom_kernels.py:260-262, exact
+// only below 2^24); here the geometry is recomputed from xyz (a handful of VALU ops) and indices stay int32.
+// One point pass for ALL float channels (one xyz read, K atomics), one cell pass that finalises and re-arms.
+#include "emap_device.h"
+
+#define SEM_MAX_CH 16
+struct SemSpec {
+  int n_sum; int sum_chan[SEM_MAX_CH]; int sum_layer[SEM_MAX_CH]; int sum_kind[SEM_MAX_CH];   // kind 0 average, 1 class_average
+  int n_col; int col_chan[4]; int col_layer[4];
+  double alpha;                                                                                // Parameter.average_weight
+};
+
+template <int MODE>
+__global__ __launch_bounds__(EM_BLOCK) void k_sem_sum(KP P, Pose T, SemSpec S, const float* __restrict__ pts, long n, int stride,
+                                                       double* __restrict__ sums, long plane) {
+  long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float rx, ry, rz;
+  load_point(pts, i, stride, rx, ry, rz);
+  Geo g = geometry<MODE>(P, T, rx, ry, rz);
+  long c = (g.finite && g.valid && g.inside) ? owned_cell(P, g.ix, g.iy) : -1;   // valid && inside (:41-45)
+  if (c < 0) return;
+  const float* p = pts + i * (long)stride;
+  for (int k = 0; k < S.n_sum; ++k) unsafeAtomicAdd(&sums[(long)S.sum_layer[k] * plane + c], (double)p[S.sum_chan[k]]);
+}
+
+// add_color_kernel (:270-317).  The reference launches it with size = N while decoding id = i / K, layer = i % K
+// (fusion/pointcloud_color.py:143): with K colour channels only the first N/K points contribute
+// and the shared counter is incremented once per (point, layer).  Reproduced literally.
+template <int MODE>
+__global__ __launch_bounds__(EM_BLOCK) void k_sem_color(KP P, Pose T, SemSpec S, const float* __restrict__ pts, long n, int stride,
+                                                         unsigned int* __restrict__ col, long plane) {
+  long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int K = S.n_col;
+  long id = i / K; int layer = (int)(i % K);
+  float rx, ry, rz;
+  load_point(pts, id, stride, rx, ry, rz);
+  Geo g = geometry<MODE>(P, T, rx, ry, rz);
+  long c = (g.finite && g.valid && g.inside) ? owned_cell(P, g.ix, g.iy) : -1;
+  if (c < 0) return;
+  unsigned int color = __float_as_uint(pts[id * (long)stride + S.col_chan[layer]]);
+  atomicAdd(&col[(long)(layer * 3) * plane + c], (color & 0xFF0000u) >> 16);
+  atomicAdd(&col[(long)(layer * 3 + 1) * plane + c], (color & 0xFF00u) >> 8);
+  atomicAdd(&col[(long)(layer * 3 + 2) * plane + c], color & 0xFFu);
+  atomicAdd(&col[(long)(K * 3) * plane + c], 1u);
+}
+
+// average_kernel / class_average_kernel / color_average_kernel in one cell pass; accumulators are re-armed here
+// (the reference zeroes new_map with a boolean-mask assignment and allocates a fresh colour map every frame).
+__global__ __launch_bounds__(EM_BLOCK) void k_sem_finalize(KP P, SemSpec S, const unsigned int* __restrict__ cnt_plane,
+                                                            double* __restrict__ sums, unsigned int* __restrict__ col,
+                                                            float* __restrict__ sem, long plane) {
+  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (li >= (long)P.nrows * P.C) return;
+  long c = li + (long)P.halo * P.C;
+  const unsigned int cnt = cnt_plane[c];          // accepted HEIGHT points of this frame (new_elmap plane 2, :185)
+  for (int k = 0; k < S.n_sum; ++k) {
+    const long j = (long)S.sum_layer[k] * plane + c;
+    const double s = sums[j];
+    if (cnt > 0) {
+      if (S.sum_kind[k] == 0) sem[j] = (float)(s / (double)cnt);
+      else {
+        const float prev = sem[j];
+        sem[j] = (prev == 0.0f) ? (float)(s / (double)cnt)
+                                : (float)(S.alpha * (double)prev + (1.0 - S.alpha) * s / (double)cnt);
+      }
+    }
+    if (s != 0.0) sums[j] = 0.0;
+  }
+  if (S.n_col > 0) {
+    const int K = S.n_col;
+    const unsigned int k = col[(long)(K * 3) * plane + c];
+    if (k > 0) {
+      for (int l = 0; l < K; ++l) {
+        unsigned int r = col[(long)(l * 3) * plane + c] / k, g = col[(long)(l * 3 + 1) * plane + c] / k, b = col[(long)(l * 3 + 2) * plane + c] / k;
+        sem[(long)S.col_layer[l] * plane + c] = __uint_as_float((r << 16) + (g << 8) + b);
+      }
+      for (int q = 0; q <= 3 * K; ++q) col[(long)q * plane + c] = 0u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(EM_BLOCK) void k_sem_shift(int C, int nl, const float* __restrict__ src, float* __restrict__ dst, int sr, int sc) {
+  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (li >= (long)C * C) return;
+  int r = (int)(li / C), c = (int)(li % C);
+  bool pad = (sr > 0 && r < sr) || (sr < 0 && r >= C + sr) || (sc > 0 && c < sc) || (sc < 0 && c >= C + sc);
+  int pr = (((r - sr) % C) + C) % C, pc = (((c - sc) % C) + C) % C;
+  for (int l = 0; l < nl; ++l) dst[(long)l * C * C + li] = pad ? 0.f : src[(long)l * C * C + (long)pr * C + pc];
+}
+
+static inline unsigned int nblk_(long n) { return (unsigned int)((n + EM_BLOCK - 1) / EM_BLOCK); }
+
+void launch_sem_points(hipStream_t s, const KP& P, const Pose& T, const SemSpec& S, const float* pts, long n, int stride,
+                       double* sums, unsigned int* col, long plane) {
+  if (n <= 0) return;
+  if (S.n_sum > 0) {
+    if (P.mode == 0) hipLaunchKernelGGL(k_sem_sum<0>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, sums, plane);
+    else hipLaunchKernelGGL(k_sem_sum<1>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, sums, plane);
+  }
+  if (S.n_col > 0) {
+    if (P.mode == 0) hipLaunchKernelGGL(k_sem_color<0>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, col, plane);
+    else hipLaunchKernelGGL(k_sem_color<1>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, col, plane);
+  }
+}
+void launch_sem_finalize(hipStream_t s, const KP& P, const SemSpec& S, const unsigned int* cnt_plane, double* sums, unsigned int* col,
+                         float* sem, long plane) {
+  hipLaunchKernelGGL(k_sem_finalize, dim3(nblk_((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, S, cnt_plane, sums, col, sem, plane);
+}
+void launch_sem_shift(hipStream_t s, int C, int nl, const float* src, float* dst, int sr, int sc) {
+  hipLaunchKernelGGL(k_sem_shift, dim3(nblk_((long)C * C)), dim3(EM_BLOCK), 0, s, C, nl, src, dst, sr, sc);
+}

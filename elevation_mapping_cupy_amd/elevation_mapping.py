@@ -80,11 +80,8 @@ class ElevationMap:
         # managers are optional layers on top of the hot path (built lazily; see semantic_map / plugins)
         self.semantic_map = None
         self.plugin_manager = None
-        try:
-            from .semantic_map import SemanticMap
-            self.semantic_map = SemanticMap(self.param, self)
-        except ImportError:
-            pass
+        from .semantic_map import SemanticMap
+        self.semantic_map = SemanticMap(self.param, self)
 
     # ------------------------------------------------------------------------------------------------
     def _chk(self, rc):
@@ -227,6 +224,8 @@ class ElevationMap:
         if points_all is not None:
             self.bind_points(points_all)
         R, t32 = self._rt(R, t)
+        if self.semantic_map is not None and channels:
+            self.semantic_map.prepare(list(channels))     # layers + count plane must exist before the average pass
         with self.map_lock:
             t32 = t32 - self.center
             try:
@@ -239,7 +238,7 @@ class ElevationMap:
             if want_stats:
                 self._take_stats(st)
             if self.semantic_map is not None and channels:
-                self.semantic_map.update_layers_pointcloud(self, channels, R, t32)
+                self.semantic_map.update_layers_pointcloud(self, list(channels), R, t32)
         return st if want_stats else None
 
     def _take_stats(self, st):
@@ -359,7 +358,7 @@ class ElevationMap:
             elif name in ("normal_x", "normal_y", "normal_z"):
                 m = self.get_layer_raw(name)[1:-1, 1:-1]
             elif self.semantic_map is not None and name in self.semantic_map.layer_names:
-                m = self.semantic_map.get_map_with_name(name)[1:-1, 1:-1]
+                m = self.semantic_map.get_map_with_name(name)
             elif self.plugin_manager is not None and name in self.plugin_manager.layer_names:
                 self.plugin_manager.update_with_name(
                     name, self.elevation_map, self.layer_names,
@@ -387,5 +386,5 @@ class ElevationMap:
         if name in self.layer_names:
             return self.get_layer_raw(self.layer_names.index(name))
         if self.semantic_map is not None and name in self.semantic_map.layer_names:
-            return self.semantic_map.get_map_with_name(name)
+            return self.semantic_map._layer(self.semantic_map.layer_names.index(name))
         return None

@@ -278,6 +278,11 @@ def bench_main(a, rank, world, local_rank):
                        "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame (RCCL)"},
             "roofline": None, "cpu_baseline": None,
         }
-        print(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()
+    if rank == 0:
+        try:  # RCCL prints its banner through C stdio: flush that first so the JSON line is the last line of stdout
+            ct.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)

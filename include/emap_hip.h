@@ -126,6 +126,20 @@ int emap_set_layer(emap_ctx* ctx, int plane, const float* host_in);
  * padding (0; variance plane initial_variance), planes 0 and 5 += dz. Single-strip contexts only. */
 int emap_shift(emap_ctx* ctx, int32_t shift_rows, int32_t shift_cols, float dz);
 
+/* ---- RGB / semantic point-cloud fusion (EM/semantic_map.py:223-259; kernels EM/kernels/custom_semantic_kernels.py:
+ * sum :9-51 + average :167-194 (kind 0) or class_average :233-267 (kind 1); add_color :270-317 + color_average :320-375).
+ * Channel indices are column indices of the bound cloud (>= 3), layer indices address the semantic layer store. */
+typedef struct emap_sem_spec {
+  int32_t n_sum, sum_chan[16], sum_layer[16], sum_kind[16];
+  int32_t n_col, col_chan[4], col_layer[4];
+  double alpha; /* Parameter.average_weight */
+} emap_sem_spec;
+int emap_semantic_configure(emap_ctx* ctx, int32_t n_layers);                 /* SemanticMap.add_layer */
+int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], const emap_sem_spec* spec); /* after emap_update */
+int emap_semantic_get_layer(emap_ctx* ctx, int32_t layer, float* host_out);
+int emap_semantic_set_layer(emap_ctx* ctx, int32_t layer, const float* host_in);
+int emap_semantic_clear(emap_ctx* ctx);                                        /* SemanticMap.clear */
+
 /* ---- row-strip halos (multi-GPU; exchange itself is done by the caller, e.g. torch.distributed/RCCL) ---- */
 /* pack `halo_rows` owned boundary rows (32-byte cells) next to the lower (side 0) / upper (side 1) neighbour
  * into a device buffer; unpack a neighbour's rows into the halo. Buffers: halo_rows*cell_n*8 floats. */

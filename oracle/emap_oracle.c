@@ -377,8 +377,9 @@ void eo_sem_class_average(const eo_params* P, const double* sums, const uint32_t
   for (long c = 0; c < L; ++c) if (cnt[c] > 0)
     for (int k = 0; k < n_ch; ++k) {
       long j = (long)layer[k] * L + c;
-      float prev = smap[j], mean = (float)(sums[j] / (double)cnt[c]);
-      smap[j] = (prev == 0.0f) ? mean : (float)(alpha * (double)prev + (1.0 - alpha) * (double)mean);
+      float prev = smap[j];
+      smap[j] = (prev == 0.0f) ? (float)(sums[j] / (double)cnt[c])
+                               : (float)(alpha * (double)prev + (1.0 - alpha) * sums[j] / (double)cnt[c]);
     }
 }
 /* colour: one packed 0x00RRGGBB channel; integer mean per component (truncating division) */

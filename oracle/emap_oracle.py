@@ -209,6 +209,33 @@ class OracleMap:
     def normals(self):
         lib().eo_normals(ct.byref(self.P), _p(self.traversability_input), _p(self.elevation_map[2]), _p(self.normal_map))
 
+    # ---- semantic point fusion (reference semantic_map.py:223-259 + fusion/pointcloud_*.py) ----------
+    def semantic_update(self, points, R, t, average=(), class_average=(), color=(), n_layers=None, alpha=0.5):
+        """average / class_average / color: lists of (cloud column, layer index). Uses the accepted-point counts of the
+        frame just fused (self.last["cnt"] == new_elmap plane 2)."""
+        pts, C = _pts(points), self.C
+        R = np.ascontiguousarray(R, np.float32).ravel(); t = np.ascontiguousarray(t, np.float32)
+        need = 1 + max([l for _, l in list(average) + list(class_average) + list(color)] + [-1])
+        n_layers = max(n_layers or 0, need)
+        if not hasattr(self, "semantic_map") or self.semantic_map.shape[0] < n_layers:
+            old = getattr(self, "semantic_map", np.zeros((0, C, C), np.float32))
+            self.semantic_map = np.concatenate([old, np.zeros((n_layers - old.shape[0], C, C), np.float32)], axis=0)
+        sm, cnt = self.semantic_map, self.last["cnt"]
+        n, st = ct.c_long(pts.shape[0]), ct.c_long(pts.shape[1])
+        for group, kind in ((average, 0), (class_average, 1)):
+            if not group:
+                continue
+            ch = np.array([c for c, _ in group], np.int32); ly = np.array([l for _, l in group], np.int32)
+            sums = np.zeros((sm.shape[0], C, C))
+            lib().eo_sem_sum(ct.byref(self.P), _p(pts), n, st, _p(R), _p(t), ct.c_int(len(group)), _p(ch), _p(ly), _p(sums))
+            if kind == 0:
+                lib().eo_sem_average(ct.byref(self.P), _p(sums), _p(cnt), ct.c_int(len(group)), _p(ly), _p(sm))
+            else:
+                lib().eo_sem_class_average(ct.byref(self.P), _p(sums), _p(cnt), ct.c_int(len(group)), _p(ly), ct.c_double(alpha), _p(sm))
+        assert len(color) <= 1, "oracle restates the single-colour-channel case (K>1 is a reference launch-size quirk)"
+        for c_, l_ in color:
+            lib().eo_sem_color(ct.byref(self.P), _p(pts), n, st, _p(R), _p(t), ct.c_int(c_), ct.c_int(l_), _p(sm))
+
     def update_variance(self):
         lib().eo_update_variance(ct.byref(self.P), _p(self.elevation_map))
 

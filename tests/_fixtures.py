@@ -34,3 +34,21 @@ def stencil_inputs(C, seed):
     plane = rng.uniform(-1, 1, (C, C)).astype(np.float32)
     mask = (rng.uniform(0, 1, (C, C)) < 0.35).astype(np.float32) + (rng.uniform(0, 1, (C, C)) < 0.1).astype(np.float32)
     return plane, mask.astype(np.float32)
+
+
+def semantic_cloud(C, N, seed):
+    """(N, 7): x y z | two features U(0,1) | one class probability U(0,1) | packed 0x00RRGGBB bit-cast to float32
+    (wire format of the semantic sensor: reference sensor_processing/.../pointcloud_node.py:159-171)."""
+    p = cloud(C, N, seed, extra=4)
+    rng = np.random.default_rng(1000 + seed)
+    rgb = rng.integers(0, 1 << 24, N, dtype=np.uint32)
+    p[:, 6] = rgb.view(np.float32)
+    p[::3, :2] = p[1::3, :2][: p[::3].shape[0]]      # pile points up so that cells see several points
+    return p
+
+
+def semantic_prev(C):
+    rng = np.random.default_rng(77)
+    prev = rng.uniform(0, 1, (C, C)).astype(np.float32)
+    prev[rng.uniform(0, 1, (C, C)) < 0.5] = 0.0
+    return prev

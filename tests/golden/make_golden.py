@@ -106,3 +106,35 @@ if __name__ == "__main__":
     frame66()
     stencils()
     print(sorted(os.listdir(OUT)))
+
+
+def semantic66():
+    """reference semantic kernels (custom_semantic_kernels.py) fed with the clobbered point buffer of add_points."""
+    params = build_ref.PREBUILD["yaml66"]
+    rk = ref_kernels.RefKernels(params)
+    C, N, K = 66, 6000, 4          # columns: x y z | s0 s1 (average) | c0 (class_average) | rgb (color)
+    R, t = fx.POSES["rotated"]; Rf = R.ravel().copy()
+    p = fx.semantic_cloud(C, N, 5)
+    m = np.zeros((7, C, C), np.float32); m[1] = params["initial_variance"]; m[3] = 1
+    nm = np.zeros((7, C, C), np.float32); nrm = np.zeros((3, C, C), np.float32)
+    err = np.zeros(1, np.float32); cnt = np.zeros(1, np.float32)
+    xyz = np.ascontiguousarray(p[:, :3])
+    rk.error_counting(m, xyz, Rf, t, nm, err, cnt); rk.add_points(Rf, t, nrm, xyz, m, nm)
+    pc = p.copy(); pc[:, :3] = xyz                                   # clobbered: idx, valid, inside (custom_kernels.py:260-262)
+    sem = np.zeros((4, C, C), np.float32); sem[2] = fx.semantic_prev(C)   # layer 2 has previous values (EMA branch)
+    newmap = np.zeros((4, C, C), np.float32)
+    i32 = lambda *a: np.array(a, np.int32)
+    rk.sem_sum(pc, Rf, t, i32(3, 4), i32(0, 1), i32(3 + K, 2), sem, newmap, N * 2)
+    rk.sem_average(newmap, i32(3, 4), i32(0, 1), i32(3 + K, 2), nm, sem, C * C * 2)
+    newmap2 = np.zeros((4, C, C), np.float32)
+    rk.sem_sum(pc, Rf, t, i32(5), i32(2), i32(3 + K, 1), sem, newmap2, N)
+    rk.sem_class_average(newmap2, i32(5), i32(2), i32(3 + K, 1), nm, sem, C * C)
+    color_map = np.zeros((4, C, C), np.uint32)
+    rk.sem_add_color(pc, Rf, t, i32(6), i32(3), i32(3 + K, 1), color_map, N)
+    rk.sem_color_average(color_map, i32(6), i32(3), i32(3 + K, 1), sem, C * C)
+    np.savez_compressed(os.path.join(OUT, "semantic_yaml66.npz"), sem=sem, cnt=nm[2])
+
+
+if __name__ == "__main__":
+    semantic66()
+    print(sorted(os.listdir(OUT)))

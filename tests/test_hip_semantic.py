@@ -1,0 +1,73 @@
+"""GPU: RGB / semantic point-cloud fusion through the reference's API surface (input_pointcloud with extra channels,
+pointcloud_channel_fusions mapping) vs the oracle and vs the reference kernels' golden output."""
+import os
+
+import numpy as np
+import pytest
+
+import _fixtures as fx
+from _util import make_pair
+from oracle import emap_oracle as eo
+
+pytestmark = pytest.mark.gpu
+CH = ["x", "y", "z", "s0", "s1", "c0", "rgb"]
+FUSIONS = {"rgb": "color", "c0": "class_average", "default": "average"}
+
+
+def _hip(C, mode="reference_fp16"):
+    hip, orc = make_pair(eo.YAML, C, mode)
+    hip.param.pointcloud_channel_fusions = dict(FUSIONS)
+    return hip, orc
+
+
+def test_against_reference_golden():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "semantic_yaml66.npz"))
+    C, N = 66, 6000
+    hip, _ = _hip(C)
+    R, t = fx.POSES["rotated"]
+    p = fx.semantic_cloud(C, N, 5)
+    hip.semantic_map.prepare(CH[3:])
+    assert hip.semantic_map.layer_names == ["s0", "s1", "c0", "rgb"]
+    hip.semantic_map.set_layer("c0", fx.semantic_prev(C))
+    hip.input_pointcloud(p.astype(np.float64), CH, R, t.copy(), 0.0, 0.0)       # the ROS wrapper hands over float64
+    sm = hip.semantic_map.semantic_map
+    assert np.allclose(sm[:3], g["sem"][:3], atol=1e-6, rtol=1e-6)
+    assert np.array_equal(sm[3].view(np.uint32), g["sem"][3].view(np.uint32))
+    assert hip.exists_layer("rgb") and hip.exists_layer("elevation") and not hip.exists_layer("nope")
+    out = np.zeros((C - 2, C - 2), np.float32)
+    hip.get_map_with_name_ref("s0", out)
+    assert np.array_equal(out, np.flip(sm[0][1:-1, 1:-1]))
+
+
+@pytest.mark.parametrize("mode", ["reference_fp16", "fp32"])
+def test_three_frames_against_oracle(mode):
+    C, N = 130, 30000
+    hip, orc = _hip(C, mode)
+    R, t = fx.POSES["identity"]
+    for f in range(3):
+        p = fx.semantic_cloud(C, N, f)
+        hip.input_pointcloud(p, CH, R, t.copy(), 0.0, 0.0)
+        orc.update_map_with_kernel(p, R, t, 0.0, 0.0)
+        orc.semantic_update(p, R, t, average=[(3, 0), (4, 1)], class_average=[(5, 2)], color=[(6, 3)], alpha=0.5)
+        hip.update_time(); orc.update_time()
+    sm = hip.semantic_map.semantic_map
+    assert np.allclose(sm[:3], orc.semantic_map[:3], atol=1e-6, rtol=1e-5)
+    assert np.array_equal(sm[3].view(np.uint32), orc.semantic_map[3].view(np.uint32))
+
+
+def test_shift_moves_semantic_layers_with_the_map():
+    C, N = 66, 6000
+    hip, _ = _hip(C)
+    R, t = fx.POSES["identity"]
+    hip.input_pointcloud(fx.semantic_cloud(C, N, 1), CH, R, t.copy(), 0.0, 0.0)
+    before_s, before_e = hip.semantic_map.semantic_map, hip.elevation_map
+    hip.move_to(np.array([3 * 0.04, -2 * 0.04, 0.25], np.float32), np.eye(3))
+    after_s, after_e = hip.semantic_map.semantic_map, hip.elevation_map
+    # reference move_to: shift_map_xy(-delta_pixel) = roll by (-3, +2) with zero padding; planes 0 and 5 -= dz
+    want_s = np.roll(before_s, (-3, 2), axis=(1, 2)); want_s[:, -3:, :] = 0; want_s[:, :, :2] = 0
+    assert np.array_equal(after_s, want_s)
+    want_e = np.roll(before_e, (-3, 2), axis=(1, 2)); want_e[:, -3:, :] = 0; want_e[:, :, :2] = 0
+    want_e[1, -3:, :] = hip.initial_variance; want_e[1, :, :2] = hip.initial_variance
+    want_e[0] -= np.float32(0.25); want_e[5] -= np.float32(0.25)
+    assert np.allclose(after_e, want_e, atol=1e-6)
+    assert np.allclose(hip.center, [0.12, -0.08, 0.25], atol=1e-6)

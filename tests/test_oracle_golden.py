@@ -126,3 +126,18 @@ def test_traversability_filter_against_plain_torch(weights):
     o3 = F.conv2d(xt, torch.from_numpy(weights["w3"]), dilation=3)
     out = torch.exp(-F.conv2d(torch.cat((o1, o2, o3), 1).abs(), torch.from_numpy(weights["w_out"])))[0, 0].numpy()
     assert np.allclose(o.elevation_map[3][3:-3, 3:-3], out, atol=1e-5, rtol=1e-5)
+
+
+def test_semantic_fusion_against_reference_kernels():
+    """sum/average, sum/class_average (EMA branch incl.) and colour kernels of custom_semantic_kernels.py."""
+    g = np.load(os.path.join(G, "semantic_yaml66.npz"))
+    C, N = 66, 6000
+    om = eo.OracleMap(eo.make_params(eo.YAML, cell_n=C))
+    R, t = fx.POSES["rotated"]
+    p = fx.semantic_cloud(C, N, 5)
+    om.count(p, R, t); om.gate(0, 0); om.fuse(p, R, t)
+    assert np.array_equal(om.last["cnt"], g["cnt"].astype(np.uint32))
+    om.semantic_map = np.zeros((4, C, C), np.float32); om.semantic_map[2] = fx.semantic_prev(C)
+    om.semantic_update(p, R, t, average=[(3, 0), (4, 1)], class_average=[(5, 2)], color=[(6, 3)], alpha=0.5)
+    assert np.allclose(om.semantic_map[:3], g["sem"][:3], atol=1e-6, rtol=1e-6)
+    assert np.array_equal(om.semantic_map[3].view(np.uint32), g["sem"][3].view(np.uint32))      # packed RGB: bit exact
