@@ -24,6 +24,7 @@ static_assert(sizeof(SemSpec) == sizeof(emap_sem_spec), "emap_sem_spec layout");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
 void launch_sem_finalize(hipStream_t, const KP&, const SemSpec&, const unsigned int*, double*, unsigned int*, float*, long);
 void launch_sem_shift(hipStream_t, int, int, const float*, float*, int, int);
+void launch_min_sweep(hipStream_t, int, int, const float*, const float*, const float*, float*, float*, const unsigned int*, unsigned int*);
 void launch_overlap(hipStream_t, const KP&, Cell*, int, int, float, float);
 void launch_dilate(hipStream_t, const KP&, const Cell*, float*, int, int, int);
 void launch_trav_normal(hipStream_t, const KP&, const float*, const float*, const float*, const float*, const float*, Cell*, float*, long);
@@ -657,6 +658,43 @@ int emap_semantic_clear(emap_ctx* ctx) {
   CKARG(ctx, "null ctx");
   CK(hipSetDevice(ctx->device));
   if (ctx->sem_layers > 0) CK(hipMemsetAsync(ctx->sem, 0, sizeof(float) * ctx->ncells_alloc * ctx->sem_layers, ctx->stream));
+  return EMAP_OK;
+}
+
+// ---- MinFilter plugin (EM/plugins/min_filter.py:84-118) on caller-provided planes ------------------------------------
+int emap_min_filter(emap_ctx* ctx, const float* host_elevation, const float* host_valid, int32_t dilation_size, int32_t iteration_n,
+                    float* host_out, int32_t* sweeps_run) {
+  CKARG(ctx && host_elevation && host_valid && host_out, "null argument");
+  CKARG(dilation_size >= 0 && dilation_size <= 32 && iteration_n >= 0 && iteration_n <= 4096, "bad filter size / iteration count");
+  CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "emap_min_filter: single-strip contexts only");
+  CK(hipSetDevice(ctx->device));
+  const int C = ctx->prm.cell_n; const size_t L = (size_t)C * C, bytes = L * sizeof(float);
+  float* buf = nullptr; unsigned int* cnt = nullptr;
+  CK(hipMalloc((void**)&buf, bytes * 5));
+  if (hipMalloc((void**)&cnt, sizeof(unsigned int) * (iteration_n + 1)) != hipSuccess) { hipFree(buf); ctx->err = "hipMalloc"; return EMAP_ERR_HIP; }
+  float *orig = buf, *v0 = buf + L, *m0 = buf + 2 * L, *v1 = buf + 3 * L, *m1 = buf + 4 * L;
+  int rc = EMAP_OK;
+  auto ck = [&](hipError_t e) { if (e != hipSuccess && rc == EMAP_OK) { rc = EMAP_ERR_HIP; ctx->err = hipGetErrorString(e); } };
+  ck(hipMemcpyAsync(orig, host_valid, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ck(hipMemcpyAsync(v0, host_elevation, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ck(hipMemcpyAsync(m0, orig, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  ck(hipMemsetAsync(cnt, 0, sizeof(unsigned int) * (iteration_n + 1), ctx->stream));
+  for (int k = 0; k < iteration_n && rc == EMAP_OK; ++k) {
+    launch_min_sweep(ctx->stream, C, dilation_size, orig, (k & 1) ? v1 : v0, (k & 1) ? m1 : m0, (k & 1) ? v0 : v1, (k & 1) ? m0 : m1,
+                     k > 0 ? cnt + (k - 1) : nullptr, cnt + k);
+    ck(hipGetLastError());
+  }
+  const float* fv = (iteration_n & 1) ? v1 : v0; const float* fm = (iteration_n & 1) ? m1 : m0;
+  std::vector<float> mask(L);
+  std::vector<unsigned int> hc(iteration_n + 1);
+  ck(hipMemcpyAsync(host_out, fv, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ck(hipMemcpyAsync(mask.data(), fm, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ck(hipMemcpyAsync(hc.data(), cnt, sizeof(unsigned int) * (iteration_n + 1), hipMemcpyDeviceToHost, ctx->stream));
+  ck(hipStreamSynchronize(ctx->stream));
+  hipFree(buf); hipFree(cnt);
+  if (rc != EMAP_OK) return rc;
+  for (size_t i = 0; i < L; ++i) if (!(mask[i] > 0.5f)) host_out[i] = NAN;     // cp.where(mask > 0.5, filtered, nan), :116
+  if (sweeps_run) { int n = 0; for (int k = 0; k < iteration_n; ++k) { ++n; if (hc[k] == 0) break; } *sweeps_run = n; }
   return EMAP_OK;
 }
 

@@ -115,3 +115,65 @@ void launch_sem_finalize(hipStream_t s, const KP& P, const SemSpec& S, const uns
 void launch_sem_shift(hipStream_t s, int C, int nl, const float* src, float* dst, int sr, int sc) {
   hipLaunchKernelGGL(k_sem_shift, dim3(nblk_((long)C * C)), dim3(EM_BLOCK), 0, s, C, nl, src, dst, sr, sc);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// MinFilter plugin sweep (reference EM/plugins/min_filter.py:29-82): fill originally-invalid cells with the minimum
+// of the already-filled values in a (2d+1)^2 window (flat-index neighbours incl. the row wrap).  The reference reads
+// the buffers it writes (in-place, racy); the defined outcome here is the Jacobi one (every cell reads the previous
+// sweep), which the racy kernel can produce.  One LDS-tiled launch per sweep, double buffered; a sweep that finds the
+// previous sweep left no unfilled cell (host-free early exit of :114-115) degenerates into a copy.
+// ---------------------------------------------------------------------------------------------------------
+#define MF_R 16
+#define MF_C 64
+__global__ __launch_bounds__(EM_BLOCK) void k_min_sweep(int C, int d, const float* __restrict__ orig_mask,
+                                                         const float* __restrict__ val, const float* __restrict__ msk,
+                                                         float* __restrict__ oval, float* __restrict__ omsk,
+                                                         const unsigned int* __restrict__ prev_unfilled, unsigned int* __restrict__ unfilled) {
+  extern __shared__ float lds[];
+  const int W = MF_C + 2 * d, pitch = W + 1, H = MF_R + 2 * d;
+  float* sval = lds;
+  float* smsk = lds + (size_t)H * pitch;
+  const int tile_r = blockIdx.y * MF_R, tile_c = blockIdx.x * MF_C;
+  const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6, col = tile_c + tc;
+  const bool frozen = prev_unfilled && *prev_unfilled == 0u;     // everything was filled: later sweeps must not run
+  if (!frozen) {
+    for (int r = wv; r < H; r += EM_BLOCK / 64)
+      for (int cc = tc; cc < W; cc += 64) {
+        int lr = tile_r - d + r, cl = tile_c - d + cc;
+        if (cl < 0) { cl += C; lr -= 1; } else if (cl >= C) { cl -= C; lr += 1; }
+        float v = 0.f, m = 0.f;
+        if (lr >= 1 && lr <= C - 2 && cl >= 1 && cl <= C - 2) { v = val[(long)lr * C + cl]; m = msk[(long)lr * C + cl]; }
+        sval[r * pitch + cc] = v; smsk[r * pitch + cc] = m;
+      }
+    __syncthreads();
+  }
+  unsigned int open_cells = 0;
+  if (col < C) {
+    for (int k = 0; k < MF_R / 4; ++k) {
+      const int tr = wv + 4 * k, row = tile_r + tr;
+      if (row >= C) break;
+      const long i = (long)row * C + col;
+      float v = val[i], m = msk[i];
+      if (!frozen && orig_mask[i] < 0.5f) {
+        float mn = 1000000.0f;
+        for (int dy = -d; dy <= d; ++dy)
+          for (int dx = -d; dx <= d; ++dx) {
+            const int o = (tr + d + dy) * pitch + (tc + d + dx);
+            if (smsk[o] > 0.5f && sval[o] < mn) mn = sval[o];
+          }
+        if (mn < 1000000.0f - 1.0f) { v = mn; m = 0.6f; }
+      }
+      oval[i] = v; omsk[i] = m;
+      open_cells += !(m > 0.5f);
+    }
+  }
+  open_cells = (unsigned int)wave_sum_ll((long long)open_cells);
+  if ((threadIdx.x & 63) == 0 && open_cells) atomicAdd(unfilled, open_cells);
+}
+
+void launch_min_sweep(hipStream_t s, int C, int d, const float* orig_mask, const float* val, const float* msk, float* oval, float* omsk,
+                      const unsigned int* prev_unfilled, unsigned int* unfilled) {
+  dim3 g((C + MF_C - 1) / MF_C, (C + MF_R - 1) / MF_R), b(EM_BLOCK);
+  size_t lds = (size_t)2 * (MF_R + 2 * d) * (MF_C + 2 * d + 1) * sizeof(float);
+  hipLaunchKernelGGL(k_min_sweep, g, b, lds, s, C, d, orig_mask, val, msk, oval, omsk, prev_unfilled, unfilled);
+}

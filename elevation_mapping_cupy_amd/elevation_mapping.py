@@ -82,6 +82,12 @@ class ElevationMap:
         self.plugin_manager = None
         from .semantic_map import SemanticMap
         self.semantic_map = SemanticMap(self.param, self)
+        # plugins (reference :110-113): same YAML format; a missing file just means "no plugins"
+        from .plugins.plugin_manager import PluginManager
+        self.plugin_manager = PluginManager(cell_n=self.cell_n, emap=self)
+        pf = os.path.expandvars(os.path.expanduser(param.plugin_config_file or ""))
+        if pf and os.path.isfile(pf):
+            self.plugin_manager.load_plugin_settings(pf)
 
     # ------------------------------------------------------------------------------------------------
     def _chk(self, rc):

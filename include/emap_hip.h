@@ -140,6 +140,12 @@ int emap_semantic_get_layer(emap_ctx* ctx, int32_t layer, float* host_out);
 int emap_semantic_set_layer(emap_ctx* ctx, int32_t layer, const float* host_in);
 int emap_semantic_clear(emap_ctx* ctx);                                        /* SemanticMap.clear */
 
+/* MinFilter plugin (EM/plugins/min_filter.py:84-118): fills cells with valid < 0.5 by the window minimum of already
+ * filled values, up to iteration_n sweeps, stops after the sweep that filled everything; NaN where still unfilled.
+ * Planes are (cell_n, cell_n) host buffers handed to the plugin (PluginBase.__call__ convention). */
+int emap_min_filter(emap_ctx* ctx, const float* host_elevation, const float* host_valid, int32_t dilation_size,
+                    int32_t iteration_n, float* host_out, int32_t* sweeps_run_or_null);
+
 /* ---- row-strip halos (multi-GPU; exchange itself is done by the caller, e.g. torch.distributed/RCCL) ---- */
 /* pack `halo_rows` owned boundary rows (32-byte cells) next to the lower (side 0) / upper (side 1) neighbour
  * into a device buffer; unpack a neighbour's rows into the halo. Buffers: halo_rows*cell_n*8 floats. */

@@ -111,7 +111,39 @@ def _instantiate(p):
     }
     for extra in p.get("extra_dilation_sizes", ()):
         ks["dilation_filter_%d" % extra] = (ck.dilation_filter_kernel(C, C, extra), f32)
+    for d in p.get("min_filter_sizes", ()):
+        ks["min_filter_%d" % d] = (_min_filter_kernel(C, d), f32)
     return ks
+
+
+def _min_filter_kernel(C, d):
+    """MinFilter builds its kernel inside the plugin class (reference plugins/min_filter.py:22-82): instantiate the
+    class under fake ``cupy`` / package modules and take the captured kernel."""
+    fake = types.ModuleType("cupy")
+    fake.ElementwiseKernel = _Captured
+    fake.zeros = lambda *a, **k: None
+    fake.ndarray = object
+    pkg = types.ModuleType("_refplug")
+    pkg.__path__ = []
+    pm = types.ModuleType("_refplug.plugin_manager")
+
+    class PluginBase:  # noqa: D401 - stand-in for the reference's ABC
+        def __init__(self, *a, **k):
+            pass
+    pm.PluginBase = PluginBase
+    saved = {k: sys.modules.get(k) for k in ("cupy", "_refplug", "_refplug.plugin_manager")}
+    sys.modules.update({"cupy": fake, "_refplug": pkg, "_refplug.plugin_manager": pm})
+    try:
+        spec = importlib.util.spec_from_file_location("_refplug.min_filter", os.path.join(REF_ROOT, "plugins", "min_filter.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m.MinFilter(cell_n=C, dilation_size=d, iteration_n=1).min_filter_kernel
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
 
 
 def _parse_params(s):
@@ -172,7 +204,7 @@ PREBUILD = {
     "yaml1024": with_(PARAM_YAML, cell_n=1024),
     "yaml202_norays": with_(PARAM_YAML, enable_visibility_cleanup=False),
     "yaml1024_norays": with_(PARAM_YAML, cell_n=1024, enable_visibility_cleanup=False),
-    "default34": with_(PARAM_DEFAULT, cell_n=34, extra_dilation_sizes=(1, 3, 10)),
+    "default34": with_(PARAM_DEFAULT, cell_n=34, extra_dilation_sizes=(1, 3, 10), min_filter_sizes=(1, 2)),
     "yaml66": with_(PARAM_YAML, cell_n=66, extra_dilation_sizes=(1, 2, 10)),
 }
 

@@ -401,6 +401,38 @@ void eo_sem_color(const eo_params* P, const float* pts, long n, long stride, con
   free(acc);
 }
 
+/* MinFilter plugin (reference plugins/min_filter.py:29-118), Jacobi sweeps (every cell reads the previous sweep). */
+int eo_min_filter(int C, int d, int iteration_n, const float* elevation, const float* valid, float* out) {
+  const long L = (long)C * C;
+  float* v0 = malloc(L * 4); float* m0 = malloc(L * 4); float* v1 = malloc(L * 4); float* m1 = malloc(L * 4);
+  memcpy(v0, elevation, L * 4); memcpy(m0, valid, L * 4);
+  int sweeps = 0;
+  for (int k = 0; k < iteration_n; ++k) {
+    long open_cells = 0;
+    for (long i = 0; i < L; ++i) {
+      float v = v0[i], m = m0[i];
+      if (valid[i] < 0.5f) {
+        float mn = 1000000.0f;
+        for (int dy = -d; dy <= d; ++dy) for (int dx = -d; dx <= d; ++dx) {
+          long j = i + (long)C * dy + dx;
+          if (j < 0 || j >= L) continue;
+          long jx = j / C, jy = j % C;
+          if (jx <= 0 || jx >= C - 1 || jy <= 0 || jy >= C - 1) continue;
+          if (m0[j] > 0.5f && v0[j] < mn) mn = v0[j];
+        }
+        if (mn < 1000000.0f - 1.0f) { v = mn; m = 0.6f; }
+      }
+      v1[i] = v; m1[i] = m; open_cells += !(m > 0.5f);
+    }
+    float* t; t = v0; v0 = v1; v1 = t; t = m0; m0 = m1; m1 = t;
+    ++sweeps;
+    if (open_cells == 0) break;
+  }
+  for (long i = 0; i < L; ++i) out[i] = (m0[i] > 0.5f) ? v0[i] : NAN;
+  free(v0); free(m0); free(v1); free(m1);
+  return sweeps;
+}
+
 /* ---- one whole frame (what bench.py's cpu_baseline leg times) ---------------------------------------- */
 typedef struct { double err_sum; uint32_t err_cnt; int32_t gate_fired; float mean_error; float shift; uint64_t ray_visits; } eo_stats;
 

@@ -277,3 +277,10 @@ def dilate_plane(C, d, plane, mask):
     lib().eo_dilate(ct.c_int(C), ct.c_int(d), _p(np.ascontiguousarray(plane, np.float32)),
                     _p(np.ascontiguousarray(mask, np.float32)), _p(out), _p(om))
     return out, om
+
+
+def min_filter(C, d, iteration_n, elevation, valid):
+    out = np.zeros((C, C), np.float32)
+    n = lib().eo_min_filter(ct.c_int(C), ct.c_int(d), ct.c_int(iteration_n), _p(np.ascontiguousarray(elevation, np.float32)),
+                            _p(np.ascontiguousarray(valid, np.float32)), _p(out))
+    return out, n

@@ -57,6 +57,10 @@ class RefKernels:
     def normal_filter(self, plane, mask, out):
         self._call("normal_filter", [plane, mask, out], self.C * self.C)
 
+    def min_filter_sweep(self, elevation, valid, newmap, newmask, size):
+        """one in-place sweep of the MinFilter kernel (reference plugins/min_filter.py:29-82), sequential order"""
+        self._call("min_filter_%d" % size, [elevation, valid, newmap, newmask], self.C * self.C)
+
     # --- semantic kernels (reference custom_semantic_kernels.py) ---------------------------------
     def sem_sum(self, p, R, t, pcl_chan, map_lay, pcl_channels, smap, newmap, size):
         self._call("sem_sum", [p, R, t, pcl_chan, map_lay, pcl_channels, smap, newmap], size)

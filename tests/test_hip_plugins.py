@@ -1,0 +1,70 @@
+"""GPU: plugin surface (YAML loading, arity dispatch, read-back post-processing) and the MinFilter sweeps vs the oracle."""
+import numpy as np
+import pytest
+
+import _fixtures as fx
+from _util import make_pair
+from oracle import emap_oracle as eo
+
+pytestmark = pytest.mark.gpu
+
+
+def _holey_map(C, seed, hole_frac):
+    rng = np.random.default_rng(seed)
+    e = np.zeros((7, C, C), np.float32)
+    e[0] = rng.uniform(-1, 1, (C, C)); e[2] = (rng.uniform(0, 1, (C, C)) > hole_frac)
+    e[2][20:50, 30:70] = 0                       # a big hole: needs several sweeps
+    return e
+
+
+@pytest.mark.parametrize("d,iters", [(1, 30), (2, 3), (5, 5)])
+def test_min_filter_matches_oracle(d, iters):
+    from elevation_mapping_cupy_amd.plugins.min_filter import MinFilter
+    C = 130
+    hip, _ = make_pair(eo.DEFAULTS, C)
+    e = _holey_map(C, d, 0.3)
+    mf = MinFilter(cell_n=C, dilation_size=d, iteration_n=iters, emap=hip)
+    got = mf(e, hip.layer_names, None, [])
+    want, sweeps = eo.min_filter(C, d, iters, e[0], e[2])
+    assert mf.sweeps_run == sweeps
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+
+
+def test_plugin_manager_yaml_and_readback(tmp_path):
+    C = 66
+    cfg = tmp_path / "plugins.yaml"
+    cfg.write_text("""
+min_filter:
+  enable: True
+  fill_nan: False
+  is_height_layer: True
+  layer_name: "min_filter"
+  extra_params:
+    dilation_size: 1
+    iteration_n: 30
+disabled_one:
+  enable: False
+  fill_nan: False
+  is_height_layer: False
+  layer_name: "nope"
+  extra_params: {}
+""")
+    from elevation_mapping_cupy_amd.configs import parameter_from
+    from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
+    p = parameter_from(eo.DEFAULTS, C)
+    p.plugin_config_file = str(cfg)
+    hip = ElevationMap(p)
+    assert hip.plugin_manager.layer_names == ["min_filter"] and hip.exists_layer("min_filter")
+    R, t = fx.POSES["identity"]
+    hip.input_pointcloud(fx.cloud(C, 3000, 0), ["x", "y", "z"], R, t.copy(), 0.0, 0.0)
+    hip.move_to(np.array([0.0, 0.0, 0.5], np.float32), np.eye(3))
+    out = np.zeros((C - 2, C - 2), np.float32)
+    hip.get_map_with_name_ref("min_filter", out)
+    e = hip.elevation_map
+    want, _ = eo.min_filter(C, 1, 30, e[0], e[2])
+    want = np.flip(want[1:-1, 1:-1] + hip.center[2])           # is_height_layer: + center_z; both axes flipped
+    assert np.allclose(out, want, equal_nan=True, atol=1e-6)
+    elev = np.zeros((C - 2, C - 2), np.float32)
+    hip.get_map_with_name_ref("elevation", elev)
+    assert np.isnan(elev).sum() == int((e[2][1:-1, 1:-1] <= 0.5).sum())

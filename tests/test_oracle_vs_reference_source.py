@@ -80,3 +80,21 @@ def test_warm_frame_race_exposed_planes_differ_only_where_the_reference_races(we
     for pl in range(7):
         diff = ~np.isclose(om.elevation_map[pl], m[pl], atol=1e-5, rtol=1e-5)
         assert not (diff & ~racy).any(), "plane %d differs on %d race-free cells" % (pl, int((diff & ~racy).sum()))
+
+
+@pytest.mark.parametrize("d", [1, 2])
+def test_min_filter_single_sweep_on_isolated_holes(d):
+    """The MinFilter kernel reads the buffers it writes; with isolated holes (no other hole inside a hole's window)
+    the sequential reference and the Jacobi contract coincide exactly, incl. the flat-index wrap at the edges."""
+    rk = _ref("default34")
+    C = 34
+    rng = np.random.default_rng(d)
+    e0 = rng.uniform(-1, 1, (C, C)).astype(np.float32)
+    v = np.ones((C, C), np.float32)
+    v[3::7, 2::6] = 0; v[10, 0] = 0; v[20, C - 1] = 0; v[0, 15] = 0
+    newmap, newmask = e0.copy(), v.copy()
+    rk.min_filter_sweep(e0, v, newmap, newmask, d)
+    want = np.where(newmask > 0.5, newmap, np.nan)
+    got, sweeps = eo.min_filter(C, d, 1, e0, v)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
