@@ -177,8 +177,18 @@ def main():
     dom_bytes = STAGE_BYTES[dom](N, L)
     achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
     frame_bytes = 12 * N + 56 * L            # B_frame of BASELINE.md §5 (K = 0 extra channels, L = 0 semantic layers)
+    # HBM traffic of the dominant kernel: from the committed rocprofv3 PMC passes of this same command
+    # (tools/profile_round.sh -> profiles/pmc_<workload>.json; counters cannot be read from inside the process)
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_%s.json" % a.workload)
+    if os.path.exists(pmc_file) and C == 1024 and N == 1_000_000 and a.mode == "reference_fp16":
+        kern = {"count": "k_count", "fuse": "k_fuse", "commit": "k_commit", "rays": "k_rays", "average": "k_average",
+                "dilate": "k_dilate", "trav_normals": "k_trav_normal", "overlap": "k_overlap"}[dom]
+        for name, rec in json.load(open(pmc_file))["kernels"].items():
+            if name.startswith(kern):
+                traffic, traffic_src = rec["hbm_bytes"], "profiles/pmc_%s.json (%s)" % (a.workload, name)
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": dom_bytes, "kernel_ms": round(stage_ms[dom], 5),
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
             "frame_algorithmic_bytes": frame_bytes,

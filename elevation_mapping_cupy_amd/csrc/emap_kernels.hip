@@ -353,11 +353,22 @@ __global__ __launch_bounds__(EM_BLOCK) void k_dilate(KP P, const Cell* __restric
     }
     return;
   }
-  // stage (value, mask & is_inside) of the tile + halo d; rows are distributed over the 4 waves, columns over lanes.
-  // The reference addresses neighbours by FLAT index (i + W*dy + dx, custom_kernels.py:403-407): a column left of 0
-  // is the tail of the previous row, a column right of C-1 the head of the next row -- staged exactly like that.
+  // stage (value, mask & is_inside) of the tile + halo d.  The 16x64 interior is already in registers (pass 0);
+  // only the halo ring is fetched.  The reference addresses neighbours by FLAT index (i + W*dy + dx,
+  // custom_kernels.py:403-407): a column left of 0 is the tail of the previous row, a column right of C-1 the head
+  // of the next row -- staged exactly like that.
+#pragma unroll
+  for (int k = 0; k < DT_R / 4; ++k) {
+    const int tr = wv + 4 * k, lr = tile_r + tr, gr = lr - P.halo + P.row0;
+    const bool in = col < C && lr < lr1 && gr >= 1 && gr <= C - 2 && col >= 1 && col <= C - 2;
+    sval[(tr + d) * pitch + tc + d] = own_val[k];
+    smsk[(tr + d) * pitch + tc + d] = in ? own_msk[k] : 0.f;
+  }
+  const bool full_tile = tile_c + DT_C <= C && tile_r + DT_R <= lr1;   // interior fully covered by pass 0
   for (int r = wv; r < H; r += EM_BLOCK / 64) {
+    const bool mid = full_tile && r >= d && r < d + DT_R;
     for (int cc = tc; cc < W; cc += 64) {
+      if (mid && cc >= d && cc < d + DT_C) continue;
       int lr = tile_r - d + r, cl = tile_c - d + cc;
       if (cl < 0) { cl += C; lr -= 1; } else if (cl >= C) { cl -= C; lr += 1; }
       const int gr = lr - P.halo + P.row0;
@@ -378,13 +389,17 @@ __global__ __launch_bounds__(EM_BLOCK) void k_dilate(KP P, const Cell* __restric
     if (lr >= lr1) break;
     float res = own_val[k];
     if (own_msk[k] < 0.5f) {
-      float distance = 100.f, near_value = 0.f;
-      for (int dy = -d; dy <= d; ++dy)
-        for (int dx = -d; dx <= d; ++dx) {
-          int o = (tr + d + dy) * pitch + (tc + d + dx);
-          if (smsk[o] > 0.5f && (float)(dx + dy) < distance) { distance = (float)(dx + dy); near_value = sval[o]; }
+      // The reference scans dy, dx ascending and keeps the FIRST neighbour with the smallest SIGNED dx+dy
+      // (custom_kernels.py:429-436).  Equivalent order: anti-diagonals s = dx+dy ascending, dy ascending inside one --
+      // the first hit wins, so a hole next to known cells costs 1-3 LDS probes instead of (2d+1)^2.
+      bool found = false;
+      for (int s2 = -2 * d; s2 <= 2 * d && !found; ++s2) {
+        const int dy0 = max(-d, s2 - d), dy1 = min(d, s2 + d);
+        for (int dy = dy0; dy <= dy1; ++dy) {
+          const int o = (tr + d + dy) * pitch + (tc + d + (s2 - dy));
+          if (smsk[o] > 0.5f) { res = sval[o]; found = true; break; }
         }
-      if (distance < 100.f) res = near_value;
+      }
     }
     out[(long)lr * C + col] = res;
   }

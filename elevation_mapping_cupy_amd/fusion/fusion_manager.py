@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import importlib
 import inspect
+import sys
 from abc import ABC, abstractmethod
 from typing import Dict
 
@@ -22,6 +23,7 @@ class FusionManager(object):
         self.fusion_plugins: Dict[str, FusionBase] = {}
         self.params = params
         self.plugins = []
+        self.unavailable = []
 
     def register_plugin(self, plugin):
         """``plugin`` = module name under ``elevation_mapping_cupy_amd.fusion`` (e.g. ``pointcloud_average``).
@@ -29,7 +31,7 @@ class FusionManager(object):
         try:
             m = importlib.import_module("." + plugin, package="elevation_mapping_cupy_amd.fusion")
         except ImportError:
-            print("[WARNING] fusion plugin {} is not available on the MI355X backend; skipped.".format(plugin))
+            self.unavailable.append(plugin)   # reported only if a channel actually asks for it (get_plugin_idx)
             return False
         for name, obj in inspect.getmembers(m):
             if inspect.isclass(obj) and issubclass(obj, FusionBase) and name != "FusionBase":
@@ -41,7 +43,8 @@ class FusionManager(object):
         for idx, plugin in enumerate(self.plugins):
             if plugin.name == name:
                 return idx
-        print("[WARNING] Plugin {} is not in the list: {}".format(name, [p.name for p in self.plugins]))
+        print("[WARNING] Plugin {} is not in the list: {} (not available on the MI355X backend: {})".format(
+            name, [p.name for p in self.plugins], self.unavailable), file=sys.stderr)
         return None
 
     def get_plugin(self, name: str, data_type: str = "pointcloud"):

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as ct
 import re
+import sys
 from typing import Dict, List
 
 import numpy as np
@@ -58,11 +59,11 @@ class SemanticMap:
                 if matched is None:
                     if "default" in channel_fusions:
                         default_fusion = channel_fusions["default"]
-                        print(f"[WARNING] Layer {channel} not found in layer_specs. Using {default_fusion} algorithm as default.")
+                        print(f"[WARNING] Layer {channel} not found in layer_specs. Using {default_fusion} algorithm as default.", file=sys.stderr)
                         layer_specs[channel] = default_fusion
                         self.update_fusion_setting()
                     else:
-                        print(f"[WARNING] Layer {channel} not found in layer_specs ({layer_specs}) and no default fusion is configured. Skipping.")
+                        print(f"[WARNING] Layer {channel} not found in layer_specs ({layer_specs}) and no default fusion is configured. Skipping.", file=sys.stderr)
                         continue
                 else:
                     layer_specs[channel] = matched
@@ -90,7 +91,7 @@ class SemanticMap:
         process_channels, fusions = self.get_fusion(channels, self.param.pointcloud_channel_fusions, self.layer_specs_points)
         for channel in process_channels:
             if channel not in self.layer_names:
-                print(f"Layer {channel} not found, adding it to the semantic map")
+                print(f"Layer {channel} not found, adding it to the semantic map", file=sys.stderr)
                 self.add_layer(channel)
         return process_channels, fusions
 

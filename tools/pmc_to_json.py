@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""rocprofv3 PMC databases (separate FETCH_SIZE / WRITE_SIZE passes, as MI355X_MICROARCH.md prescribes) -> per-kernel
+HBM traffic per launch.  Correction (gfx950, calibrated on k_var_time which reads and writes exactly 32 B/cell of a
+1024^2 map: FETCH_SIZE 16 394 KB vs 32 768 KB read, WRITE_SIZE 32 768 KB vs 32 768 KB written):
+bytes_read = 2 * FETCH_SIZE KB * 1024, bytes_written = WRITE_SIZE KB * 1024.
+usage: pmc_to_json.py <fetch.db> <write.db> > profiles/rNN_pmc_<workload>.json"""
+import json
+import re
+import sqlite3
+import sys
+
+
+def per_kernel(db, counter):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name=? group by kernel_name", (counter,)).fetchall()
+    return {re.sub(r"\(.*", "", r[0]).replace("void ", "").strip(): (r[1], r[2]) for r in rows}
+
+
+def main(fetch_db, write_db):
+    f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(f) | set(w)):
+        fk, wk = f.get(k, (0, 0))[0], w.get(k, (0, 0))[0]
+        out[k] = {"FETCH_SIZE_KB": round(fk, 1), "WRITE_SIZE_KB": round(wk, 1), "hbm_read_bytes": int(2 * fk * 1024),
+                  "hbm_write_bytes": int(wk * 1024), "hbm_bytes": int(2 * fk * 1024 + wk * 1024), "launches": f.get(k, (0, 0))[1]}
+    print(json.dumps({"correction": "read = 2 x FETCH_SIZE (gfx950, calibrated on k_var_time), write = WRITE_SIZE", "kernels": out}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
