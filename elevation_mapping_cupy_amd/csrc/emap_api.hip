@@ -36,6 +36,16 @@ void launch_f64_to_f32(hipStream_t, const double*, float*, long);
 void launch_point_index(hipStream_t, const KP&, const Pose&, const float*, long, int, int*, unsigned char*);
 void launch_shift(hipStream_t, const KP&, const Cell*, Cell*, int, int, float);
 
+// tile-binned scatter (emap_binned.hip)
+struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; };
+struct BinTmp { int tile; unsigned int lc; float z, v; };
+struct BinRec { unsigned int lc_inl; float z, v; unsigned int i; };
+void launch_bin_count(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, BinTmp*, unsigned int*, unsigned int*,
+                      unsigned int*, const Cell*, BinRec*, ErrSlot*);
+void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, const Cell*, AccF*, const FrameDev*);
+#define BIN_MAX_T 4096
+#define BIN_MAX_B 2048
+
 enum { ST_COUNT = 0, ST_FUSE, ST_COMMIT, ST_RAYS, ST_AVERAGE, ST_OVERLAP, ST_DILATE, ST_TRAVN, ST_N };
 
 struct emap_ctx {
@@ -53,6 +63,10 @@ struct emap_ctx {
   ErrSlot* slots; FrameDev* frame;
   RayTab rt; float* ray_S; unsigned short* ray_lut;
   unsigned long long* inert;       // 1 bit per owned cell, written by k_commit
+  // tile-binned scatter buffers (allocated on demand)
+  int scatter_mode;                // 0 auto, 1 atomic, 2 binned
+  bool frame_binned;               // the count stage of the current frame used the binned path
+  BinGeo bg; BinTmp* bin_tmp; BinRec* bin_recs; unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap;
   // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
   int sem_layers; float* sem; double* sem_sums; unsigned int* sem_col; unsigned int* cnt_plane;
   // point cloud
@@ -212,6 +226,7 @@ int emap_destroy(emap_ctx* ctx) {
   hipFree(ctx->cells); hipFree(ctx->cells_alt); hipFree(ctx->acc); hipFree(ctx->accr); hipFree(ctx->trav_in);
   hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->slots); hipFree(ctx->frame); hipFree(ctx->pts_own);
   hipFree(ctx->pts_f64); hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert);
+  hipFree(ctx->bin_tmp); hipFree(ctx->bin_recs); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start);
   hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   for (int i = 0; i <= ST_N; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   if (ctx->t0) hipEventDestroy(ctx->t0);
@@ -365,10 +380,55 @@ int emap_point_index(emap_ctx* ctx, const float R[9], const float t[3], int32_t*
 // ---- stages -----------------------------------------------------------------------------------------------
 #define NEED_POINTS() do { if (!ctx->pts && ctx->n_pts) { ctx->err = "no point cloud bound"; return EMAP_ERR_NO_POINTS; } } while (0)
 
+static bool bins_possible(const emap_ctx* ctx) {
+  const long tx = (ctx->prm.cell_n + 63) / 64, ty = (ctx->strip.row_count + 15) / 16;
+  return tx * ty <= BIN_MAX_T;
+}
+static int ensure_bins(emap_ctx* ctx) {
+  const long n = ctx->n_pts;
+  BinGeo& g = ctx->bg;
+  g.tiles_x = (ctx->prm.cell_n + 63) / 64; g.tiles_y = (ctx->strip.row_count + 15) / 16; g.T = g.tiles_x * g.tiles_y;
+  long B = (n + 2047) / 2048; if (B < 1) B = 1; if (B > BIN_MAX_B) B = BIN_MAX_B;
+  long chunk = (n + B - 1) / B; chunk = ((chunk + EM_BLOCK - 1) / EM_BLOCK) * EM_BLOCK; if (chunk < EM_BLOCK) chunk = EM_BLOCK;
+  g.B = (int)((n + chunk - 1) / chunk); if (g.B < 1) g.B = 1;
+  g.chunk = chunk;
+  if (!ctx->bin_hist) {
+    CK(hipMalloc((void**)&ctx->bin_hist, sizeof(unsigned int) * (size_t)BIN_MAX_T * BIN_MAX_B));
+    CK(hipMalloc((void**)&ctx->bin_tile_total, sizeof(unsigned int) * (BIN_MAX_T + 1)));
+    CK(hipMalloc((void**)&ctx->bin_tile_start, sizeof(unsigned int) * (BIN_MAX_T + 1)));
+  }
+  if (n > ctx->bin_cap) {
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->bin_tmp) CK(hipFree(ctx->bin_tmp));
+    if (ctx->bin_recs) CK(hipFree(ctx->bin_recs));
+    ctx->bin_tmp = nullptr; ctx->bin_recs = nullptr; ctx->bin_cap = 0;
+    CK(hipMalloc((void**)&ctx->bin_tmp, sizeof(BinTmp) * n));
+    CK(hipMalloc((void**)&ctx->bin_recs, sizeof(BinRec) * n));
+    ctx->bin_cap = n;
+  }
+  return EMAP_OK;
+}
+
+int emap_set_scatter_mode(emap_ctx* ctx, int32_t mode) {
+  CKARG(ctx && mode >= 0 && mode <= 2, "scatter mode: 0 auto, 1 atomic, 2 binned");
+  CKARG(mode != 2 || bins_possible(ctx), "binned scatter needs <= 4096 tiles of 16x64 cells");
+  ctx->scatter_mode = mode;
+  return EMAP_OK;
+}
+
 int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
   CKARG(ctx && R && t, "null argument"); NEED_POINTS();
   CK(hipSetDevice(ctx->device));
-  launch_count(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->slots);
+  // small clouds: two launches with global atomics win; large clouds: counting sort by tile + LDS reduction
+  const bool binned = ctx->n_pts > 0 && (ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts >= 32768));
+  ctx->frame_binned = binned;
+  if (binned) {
+    int rc = ensure_bins(ctx); if (rc) return rc;
+    launch_bin_count(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_tmp, ctx->bin_hist,
+                     ctx->bin_tile_total, ctx->bin_tile_start, ctx->cells, ctx->bin_recs, ctx->slots);
+  } else {
+    launch_count(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->slots);
+  }
   CK(hipGetLastError());
   return EMAP_OK;
 }
@@ -423,6 +483,11 @@ static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool tai
   NEED_POINTS();
   CK(hipSetDevice(ctx->device));
   if (tail) { int rc = ensure_tail(ctx); if (rc) return rc; }
+  if (ctx->frame_binned && !tail) {
+    launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame);
+    CK(hipGetLastError());
+    return EMAP_OK;
+  }
   launch_fuse(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->frame,
               tail ? ctx->tail_idx : nullptr, tail ? ctx->tail_flags : nullptr);
   CK(hipGetLastError());

@@ -1,0 +1,202 @@
+// Tile-binned scatter: the count + fuse passes WITHOUT per-point global atomics.
+//
+// Why: on MI355X a device-scope atomic costs ~44 us per 1 M operations whatever its width, scope, record layout or
+// spatial coherence (tools/microbench.hip), and the straightforward count + fuse passes need up to 5 of them per point.
+// An LDS atomic is ~100x cheaper, but LDS is per workgroup -- so the points are first counting-sorted by map TILE
+// (16 rows x 64 columns = 1024 cells, the same tile the stencil kernels use) and each tile is then reduced by ONE
+// workgroup in LDS:
+//   k_bin_hist     per chunk of points: geometry once (fp16-quirk transform, validity, cell), per-block LDS histogram
+//                  over tiles, 16-byte staging record per point (tile, cell-in-tile, z, noise)
+//   k_bin_scan1/2  exclusive scan of the (tile, block) histogram -> every block's write cursor, tile start offsets
+//   k_bin_scatter  per chunk: drift-inlier test against the map (error_counting_kernel, custom_kernels.py:317-335),
+//                  wave-reduced error sums, LDS cursor -> 16-byte record at its sorted position
+//   k_tile_fuse    per tile: pass 1 counts points/inliers per cell in LDS (newmap[4], newmap[3]); pass 2 is the Kalman
+//                  update of custom_kernels.py:160-197 accumulated with LDS atomics (64-bit fixed point, ordered max);
+//                  the epilogue writes the 40-byte AccF records with plain coalesced stores.
+// Everything downstream (commit, rays, average, ...) is unchanged and the AccF contents are BIT-IDENTICAL to the
+// atomic path of emap_kernels.hip (integer / fixed-point accumulators are order independent), which stays as the
+// fallback for maps with more than 4096 tiles and for small clouds.
+#include "emap_device.h"
+
+#define BIN_TR 16
+#define BIN_TC 64
+#define BIN_MAX_T 4096
+
+struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; };
+struct __attribute__((aligned(16))) BinTmp { int tile; unsigned int lc; float z, v; };        // staging, point order
+struct __attribute__((aligned(16))) BinRec { unsigned int lc_inl; float z, v; unsigned int i; };  // sorted by tile
+
+// exclusive scan over the 256 threads of a block; returns the block total in `total`
+__device__ __forceinline__ unsigned int block_excl_scan(unsigned int x, unsigned int* sh /*[4]*/, unsigned int& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned int inc = x;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { unsigned int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+  if (lane == 63) sh[w] = inc;
+  __syncthreads();
+  unsigned int base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < EM_BLOCK / 64; ++k) { unsigned int s = sh[k]; if (k < w) base += s; tot += s; }
+  __syncthreads();
+  total = tot;
+  return base + inc - x;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(EM_BLOCK) void k_bin_hist(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
+                                                        BinTmp* __restrict__ tmp, unsigned int* __restrict__ hist) {
+  __shared__ unsigned int h[BIN_MAX_T];
+  for (int t = threadIdx.x; t < G.T; t += EM_BLOCK) h[t] = 0u;
+  __syncthreads();
+  const long base = (long)blockIdx.x * G.chunk;
+  for (long k = threadIdx.x; k < G.chunk; k += EM_BLOCK) {
+    const long i = base + k;
+    if (i >= n) break;
+    float rx, ry, rz;
+    load_point(pts, i, stride, rx, ry, rz);
+    Geo g = geometry<MODE>(P, T, rx, ry, rz);
+    BinTmp r; r.tile = -1; r.lc = 0u; r.z = g.z; r.v = g.v;
+    const int lrow = g.ix - P.row0;
+    if (g.finite && g.valid && g.inside && lrow >= 0 && lrow < P.nrows) {
+      r.tile = (lrow / BIN_TR) * G.tiles_x + (g.iy / BIN_TC);
+      r.lc = (unsigned int)((lrow % BIN_TR) * BIN_TC + (g.iy % BIN_TC));
+      atomicAdd(&h[r.tile], 1u);
+    }
+    tmp[i] = r;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < G.T; t += EM_BLOCK) hist[(long)t * G.B + blockIdx.x] = h[t];
+}
+
+// block t: exclusive scan of hist[t][0..B) in place, tile_total[t] = sum
+__global__ __launch_bounds__(EM_BLOCK) void k_bin_scan1(BinGeo G, unsigned int* __restrict__ hist, unsigned int* __restrict__ tile_total) {
+  __shared__ unsigned int sh[EM_BLOCK / 64];
+  unsigned int* row = hist + (long)blockIdx.x * G.B;
+  unsigned int running = 0;
+  for (int b0 = 0; b0 < G.B; b0 += EM_BLOCK) {
+    const int b = b0 + threadIdx.x;
+    unsigned int x = b < G.B ? row[b] : 0u, tot;
+    unsigned int ex = block_excl_scan(x, sh, tot);
+    if (b < G.B) row[b] = running + ex;
+    running += tot;
+  }
+  if (threadIdx.x == 0) tile_total[blockIdx.x] = running;
+}
+// one block: tile_start[0..T] = exclusive scan of tile_total
+__global__ __launch_bounds__(EM_BLOCK) void k_bin_scan2(BinGeo G, const unsigned int* __restrict__ tile_total, unsigned int* __restrict__ tile_start) {
+  __shared__ unsigned int sh[EM_BLOCK / 64];
+  unsigned int running = 0;
+  for (int t0 = 0; t0 < G.T; t0 += EM_BLOCK) {
+    const int t = t0 + threadIdx.x;
+    unsigned int x = t < G.T ? tile_total[t] : 0u, tot;
+    unsigned int ex = block_excl_scan(x, sh, tot);
+    if (t < G.T) tile_start[t] = running + ex;
+    running += tot;
+  }
+  if (threadIdx.x == 0) tile_start[G.T] = running;
+}
+
+__global__ __launch_bounds__(EM_BLOCK) void k_bin_scatter(KP P, BinGeo G, const BinTmp* __restrict__ tmp, long n,
+                                                           const unsigned int* __restrict__ hist, const unsigned int* __restrict__ tile_start,
+                                                           const Cell* __restrict__ cells, BinRec* __restrict__ recs,
+                                                           ErrSlot* __restrict__ slots) {
+  __shared__ unsigned int cur[BIN_MAX_T];
+  for (int t = threadIdx.x; t < G.T; t += EM_BLOCK) cur[t] = tile_start[t] + hist[(long)t * G.B + blockIdx.x];
+  __syncthreads();
+  const long base = (long)blockIdx.x * G.chunk;
+  const long iters = (G.chunk + EM_BLOCK - 1) / EM_BLOCK;
+  for (long it = 0; it < iters; ++it) {          // uniform trip count: the wave reductions below need all lanes
+    const long i = base + it * EM_BLOCK + threadIdx.x;
+    long long e_fix = 0; unsigned int inl = 0;
+    if (it * EM_BLOCK + threadIdx.x < G.chunk && i < n) {
+      BinTmp r = tmp[i];
+      if (r.tile >= 0) {
+        const int ty = r.tile / G.tiles_x, tx = r.tile - ty * G.tiles_x;
+        const int lrow = ty * BIN_TR + (int)(r.lc / BIN_TC), col = tx * BIN_TC + (int)(r.lc % BIN_TC);
+        const long c = (long)(lrow + P.halo) * P.C + col;
+        float4 m = *reinterpret_cast<const float4*>(&cells[c]);   // h, v, valid, trav
+        bool inlier = m.z > 0.5f && (double)fabsf(m.x - r.z) < (double)m.y * P.mt && (double)m.y < P.dcvi_half &&
+                      (double)m.w > P.trav_inlier;
+        if (inlier) { inl = 1; e_fix = __double2ll_rn((double)(r.z - m.x) * EM_SCALE_E); }
+        const unsigned int pos = atomicAdd(&cur[r.tile], 1u);
+        BinRec o; o.lc_inl = r.lc | (inl << 31); o.z = r.z; o.v = r.v; o.i = (unsigned int)i;
+        recs[pos] = o;
+      }
+    }
+    if (__any(inl)) {
+      long long s = wave_sum_ll(e_fix);
+      unsigned long long k = __popcll(__ballot(inl));
+      if ((threadIdx.x & 63) == 0) {
+        unsigned int slot = (unsigned int)((blockIdx.x * (EM_BLOCK / 64) + (threadIdx.x >> 6) + it) & (EM_ERR_SLOTS - 1));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&slots[slot].sum), (unsigned long long)s);
+        atomicAdd(&slots[slot].cnt, k);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(EM_BLOCK) void k_tile_fuse(KP P, BinGeo G, const BinRec* __restrict__ recs,
+                                                         const unsigned int* __restrict__ tile_start, const Cell* __restrict__ cells,
+                                                         AccF* __restrict__ acc, const FrameDev* __restrict__ F) {
+  constexpr int NC = BIN_TR * BIN_TC;
+  __shared__ unsigned int s_pts[NC], s_inl[NC], s_cnt[NC], s_out[NC];
+  __shared__ unsigned long long s_h[NC], s_v[NC], s_latest[NC];
+  for (int k = threadIdx.x; k < NC; k += EM_BLOCK) { s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull; }
+  const int t = blockIdx.x, ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
+  const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
+  __syncthreads();
+  for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {          // pass 1: newmap[4] / newmap[3]
+    const unsigned int w = recs[k].lc_inl;
+    atomicAdd(&s_pts[w & 0x7fffffffu], 1u);
+    if (w >> 31) atomicAdd(&s_inl[w & 0x7fffffffu], 1u);
+  }
+  __syncthreads();
+  const float shift = F->shift;
+  for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {          // pass 2: custom_kernels.py:160-197
+    const BinRec r = recs[k];
+    const unsigned int lc = r.lc_inl & 0x7fffffffu;
+    const int lrow = ty * BIN_TR + (int)(lc / BIN_TC), col = tx * BIN_TC + (int)(lc % BIN_TC);
+    const long c = (long)(lrow + P.halo) * P.C + col;
+    const float2 hv = *reinterpret_cast<const float2*>(&cells[c]);
+    const float map_h = hv.x + shift, map_v = hv.y;
+    const float num_points = (float)s_pts[lc];
+    if ((double)fabsf(map_h - r.z) > (double)map_v * P.mt) { atomicAdd(&s_out[lc], 1u); continue; }
+    if (P.edge && (double)num_points > P.wall && (double)r.z < (double)map_h - (double)map_v * P.mt / (double)num_points) continue;
+    const float new_h = (map_h * r.v + r.z * map_v) / (map_v + r.v);
+    const float new_v = (map_v * r.v) / (map_v + r.v);
+    atomicAdd(&s_h[lc], (unsigned long long)__double2ll_rn((double)new_h * EM_SCALE_H));
+    atomicAdd(&s_v[lc], (unsigned long long)__double2ll_rn((double)new_v * EM_SCALE_V));
+    atomicAdd(&s_cnt[lc], 1u);
+    atomicMax(&s_latest[lc], ((unsigned long long)(r.i + 1u) << 32) | (unsigned long long)__float_as_uint(new_h));
+  }
+  __syncthreads();
+  const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6, col = tx * BIN_TC + tc;
+  if (col >= P.C) return;
+#pragma unroll
+  for (int k = 0; k < BIN_TR / 4; ++k) {
+    const int tr = wv + 4 * k, lrow = ty * BIN_TR + tr;
+    if (lrow >= P.nrows) break;
+    const int lc = tr * BIN_TC + tc;
+    AccF a;
+    a.pts_inl = (unsigned long long)s_pts[lc] | ((unsigned long long)s_inl[lc] << 32);
+    a.cnt_out = (unsigned long long)s_cnt[lc] | ((unsigned long long)s_out[lc] << 32);
+    a.sum_h = (long long)s_h[lc]; a.sum_v = (long long)s_v[lc]; a.latest = s_latest[lc];
+    acc[(long)(lrow + P.halo) * P.C + col] = a;
+  }
+}
+
+static inline unsigned int nb(long n) { return (unsigned int)((n + EM_BLOCK - 1) / EM_BLOCK); }
+
+// count stage of the binned path: hist + scans + scatter (error sums land in `slots` exactly as k_count leaves them)
+void launch_bin_count(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride, BinTmp* tmp,
+                      unsigned int* hist, unsigned int* tile_total, unsigned int* tile_start, const Cell* cells, BinRec* recs, ErrSlot* slots) {
+  if (P.mode == 0) hipLaunchKernelGGL(k_bin_hist<0>, dim3(G.B), dim3(EM_BLOCK), 0, s, P, T, G, pts, n, stride, tmp, hist);
+  else hipLaunchKernelGGL(k_bin_hist<1>, dim3(G.B), dim3(EM_BLOCK), 0, s, P, T, G, pts, n, stride, tmp, hist);
+  hipLaunchKernelGGL(k_bin_scan1, dim3(G.T), dim3(EM_BLOCK), 0, s, G, hist, tile_total);
+  hipLaunchKernelGGL(k_bin_scan2, dim3(1), dim3(EM_BLOCK), 0, s, G, tile_total, tile_start);
+  hipLaunchKernelGGL(k_bin_scatter, dim3(G.B), dim3(EM_BLOCK), 0, s, P, G, tmp, n, hist, tile_start, cells, recs, slots);
+}
+void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, const Cell* cells,
+                     AccF* acc, const FrameDev* F) {
+  hipLaunchKernelGGL(k_tile_fuse, dim3(G.T), dim3(EM_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F);
+}

@@ -105,6 +105,10 @@ class ElevationMap:
     def close(self):
         self.__del__()
 
+    def set_scatter_mode(self, mode):
+        """"auto" | "atomic" | "binned": how count/fuse scatter into the map (bit-identical results)."""
+        self._chk(self._lib.emap_set_scatter_mode(self._ctx, {"auto": 0, "atomic": 1, "binned": 2}[mode]))
+
     def reload_params(self):
         """Push changed ``self.param`` scalars to the device (kernargs, no recompilation)."""
         P = _lib.fill_params(self.param, self.cell_n, self.index_mode)

@@ -176,3 +176,25 @@ def test_ragged_and_degenerate_inputs(weights):
     p[12, :3] = [0.0, 0.0, -1.0]
     _run_frame_stages(hip, orc, p, R, t, tag="ragged f0")
     _run_frame_stages(hip, orc, p, R, t, pn=1, on=1, tag="ragged f1")
+
+
+@pytest.mark.parametrize("mode", ["reference_fp16", "fp32"])
+@pytest.mark.parametrize("C,N", [(202, 50000), (1024, 400000), (130, 7000)])
+def test_binned_scatter_is_bit_identical_to_atomic_scatter(C, N, mode, weights):
+    """tile-binned LDS reduction (emap_binned.hip) vs global-atomic scatter: same bytes in every plane, 3 frames with
+    outliers, walls (> wall_num_thresh points in a cell), drift gate and rays."""
+    outs = []
+    for scatter in ("atomic", "binned"):
+        hip, _ = make_pair(eo.YAML, C, mode, weights)
+        hip.set_scatter_mode(scatter)
+        R, t = fx.POSES["rotated"]
+        for f, dz in enumerate((0.0, -0.02, -0.2)):
+            p = fx.cloud(C, N, f, dz=dz)
+            p[100:900, :2] = p[100, :2]                  # 800 points into one cell
+            p[::501, 0] = np.nan
+            hip.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0)
+            for k in range(6):
+                hip.update_time()
+        outs.append((hip.elevation_map.tobytes(), hip.normal_map.tobytes(), hip.get_additive_mean_error()))
+        hip.close()
+    assert outs[0] == outs[1]
