@@ -42,7 +42,7 @@ struct BinTmp { int tile; unsigned int lc; float z, v; };
 struct BinRec { unsigned int lc_inl; float z, v; unsigned int i; };
 void launch_bin_count(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, BinTmp*, unsigned int*, unsigned int*,
                       unsigned int*, const Cell*, BinRec*, ErrSlot*);
-void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, const Cell*, AccF*, const FrameDev*);
+void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cell*, AccF*, const FrameDev*, bool, unsigned int*);
 #define BIN_MAX_T 4096
 #define BIN_MAX_B 2048
 
@@ -479,12 +479,13 @@ int emap_local_drift_sums(emap_ctx* ctx, double* err_sum, uint32_t* err_cnt) {
   return EMAP_OK;
 }
 
-static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool tail) {
+static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool tail, bool fuse_average = false) {
   NEED_POINTS();
   CK(hipSetDevice(ctx->device));
   if (tail) { int rc = ensure_tail(ctx); if (rc) return rc; }
   if (ctx->frame_binned && !tail) {
-    launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame);
+    launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame, fuse_average,
+                    ctx->cnt_plane);
     CK(hipGetLastError());
     return EMAP_OK;
   }
@@ -580,7 +581,9 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   if ((rc = emap_count(ctx, R, t))) return rc;
   if ((rc = emap_set_drift_inputs(ctx, position_noise, orientation_noise, nullptr, nullptr))) return rc;
   STAGE(1);
-  if ((rc = fuse_impl(ctx, R, t, false))) return rc;
+  // no visibility pass + binned scatter: fusion, commit and averaging happen in ONE tile kernel
+  const bool fused_avg = ctx->frame_binned && !p.enable_visibility_cleanup;
+  if ((rc = fuse_impl(ctx, R, t, false, fused_avg))) return rc;
   STAGE(2);
   if (p.enable_visibility_cleanup) {
     if ((rc = emap_commit(ctx))) return rc;
@@ -588,7 +591,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
     if ((rc = emap_rays(ctx, R, t))) return rc;
   } else STAGE(3);
   STAGE(4);
-  launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, p.enable_visibility_cleanup != 0, ctx->cnt_plane);
+  if (!fused_avg) launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, p.enable_visibility_cleanup != 0, ctx->cnt_plane);
   ctx->committed = false;
   CK(hipGetLastError());
   STAGE(5);

@@ -135,9 +135,13 @@ __global__ __launch_bounds__(EM_BLOCK) void k_bin_scatter(KP P, BinGeo G, const 
   }
 }
 
+// AVG = true (no visibility pass this frame): the epilogue commits AND averages the tile in registers and writes the
+// 32-byte cells directly -- the AccF records never leave LDS and the separate k_average pass disappears.
+template <bool AVG>
 __global__ __launch_bounds__(EM_BLOCK) void k_tile_fuse(KP P, BinGeo G, const BinRec* __restrict__ recs,
-                                                         const unsigned int* __restrict__ tile_start, const Cell* __restrict__ cells,
-                                                         AccF* __restrict__ acc, const FrameDev* __restrict__ F) {
+                                                         const unsigned int* __restrict__ tile_start, Cell* __restrict__ cells,
+                                                         AccF* __restrict__ acc, const FrameDev* __restrict__ F,
+                                                         unsigned int* __restrict__ cnt_plane) {
   constexpr int NC = BIN_TR * BIN_TC;
   __shared__ unsigned int s_pts[NC], s_inl[NC], s_cnt[NC], s_out[NC];
   __shared__ unsigned long long s_h[NC], s_v[NC], s_latest[NC];
@@ -181,7 +185,15 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
     a.pts_inl = (unsigned long long)s_pts[lc] | ((unsigned long long)s_inl[lc] << 32);
     a.cnt_out = (unsigned long long)s_cnt[lc] | ((unsigned long long)s_out[lc] << 32);
     a.sum_h = (long long)s_h[lc]; a.sum_v = (long long)s_v[lc]; a.latest = s_latest[lc];
-    acc[(long)(lrow + P.halo) * P.C + col] = a;
+    const long c = (long)(lrow + P.halo) * P.C + col;
+    if (AVG) {
+      Cell m = cells[c];
+      m.h += shift;
+      commit_cell(P, m, a);
+      average_cell(P, m, a);
+      cells[c] = m;
+      if (cnt_plane) cnt_plane[c] = s_cnt[lc];
+    } else acc[c] = a;
   }
 }
 
@@ -196,7 +208,8 @@ void launch_bin_count(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G
   hipLaunchKernelGGL(k_bin_scan2, dim3(1), dim3(EM_BLOCK), 0, s, G, tile_total, tile_start);
   hipLaunchKernelGGL(k_bin_scatter, dim3(G.B), dim3(EM_BLOCK), 0, s, P, G, tmp, n, hist, tile_start, cells, recs, slots);
 }
-void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, const Cell* cells,
-                     AccF* acc, const FrameDev* F) {
-  hipLaunchKernelGGL(k_tile_fuse, dim3(G.T), dim3(EM_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F);
+void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cell* cells,
+                     AccF* acc, const FrameDev* F, bool fuse_average, unsigned int* cnt_plane) {
+  if (fuse_average) hipLaunchKernelGGL(k_tile_fuse<true>, dim3(G.T), dim3(EM_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
+  else hipLaunchKernelGGL(k_tile_fuse<false>, dim3(G.T), dim3(EM_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
 }

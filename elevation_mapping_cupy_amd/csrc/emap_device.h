@@ -135,6 +135,25 @@ __device__ __forceinline__ float ord_float(unsigned int o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
+// effects of custom_kernels.py:174 and :189-192 on one cell (-> snapshot S1)
+__device__ __forceinline__ void commit_cell(const KP& P, Cell& c, const AccF& a) {
+  unsigned int cnt = (unsigned int)(a.cnt_out & 0xffffffffull), n_out = (unsigned int)(a.cnt_out >> 32);
+  if (n_out) c.v = c.v + P.ov_f * (float)n_out;
+  if (cnt) { c.valid = 1.0f; c.time = 0.0f; c.upper = __uint_as_float((unsigned int)(a.latest & 0xffffffffull)); c.is_upper = 0.0f; }
+}
+// average_map_kernel (custom_kernels.py:365-389) on one committed cell
+__device__ __forceinline__ void average_cell(const KP& P, Cell& m, const AccF& a) {
+  const float valid0 = m.valid;
+  const unsigned int cnt = (unsigned int)(a.cnt_out & 0xffffffffull);
+  if (cnt > 0) {
+    float nh = (float)(((double)a.sum_h / EM_SCALE_H) / (double)cnt);
+    float nv = (float)(((double)a.sum_v / EM_SCALE_V) / (double)cnt);
+    if ((double)nv > P.max_var) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; }
+    else { m.h = nh; m.v = nv; m.valid = 1.f; }
+  }
+  if (valid0 < 0.5f) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; }
+}
+
 struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };
 __device__ __forceinline__ void load_point(const float* __restrict__ pts, long i, int stride, float& x, float& y, float& z) {
   if (stride == 3) { P3 p = reinterpret_cast<const P3*>(pts)[i]; x = p.x; y = p.y; z = p.z; }

@@ -123,13 +123,6 @@ __global__ __launch_bounds__(EM_BLOCK) void k_fuse(KP P, Pose T, const float* __
   atomicMax(&acc[c].latest, lt);
 }
 
-// effects of custom_kernels.py:174 and :189-192 on one cell (-> snapshot S1)
-__device__ __forceinline__ void commit_cell(const KP& P, Cell& c, const AccF& a) {
-  unsigned int cnt = (unsigned int)(a.cnt_out & 0xffffffffull), n_out = (unsigned int)(a.cnt_out >> 32);
-  if (n_out) c.v = c.v + P.ov_f * (float)n_out;
-  if (cnt) { c.valid = 1.0f; c.time = 0.0f; c.upper = __uint_as_float((unsigned int)(a.latest & 0xffffffffull)); c.is_upper = 0.0f; }
-}
-
 // Phase B': materialise S1 (only launched when the visibility pass runs; otherwise folded into k_average)
 // Also emits the "inert" bitmap (1 bit per owned cell: known AND updated recently).  A ray step on such a cell cannot
 // have any effect (custom_kernels.py:228-237), so k_rays tests the bit (128 KB for a 1024^2 map, cache resident)
@@ -281,16 +274,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cell* __restrict__ c
     if (r.upper_key) { m.upper = ord_float(~r.upper_key); m.is_upper = 1.0f; }
     if (r.hits | r.upper_key) { AccR z = {0, 0u, 0u}; accr[c] = z; }
   }
-  float valid0 = m.valid;
-  unsigned int cnt = (unsigned int)(a.cnt_out & 0xffffffffull);
-  if (cnt_out) cnt_out[c] = cnt;   // accepted-point count survives for the semantic fusion (new_elmap plane 2)
-  if (cnt > 0) {
-    float nh = (float)(((double)a.sum_h / EM_SCALE_H) / (double)cnt);
-    float nv = (float)(((double)a.sum_v / EM_SCALE_V) / (double)cnt);
-    if ((double)nv > P.max_var) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; }
-    else { m.h = nh; m.v = nv; m.valid = 1.f; }
-  }
-  if (valid0 < 0.5f) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; }
+  if (cnt_out) cnt_out[c] = (unsigned int)(a.cnt_out & 0xffffffffull);   // survives for the semantic fusion (new_elmap plane 2)
+  average_cell(P, m, a);
   cells[c] = m;
   if (a.pts_inl | a.cnt_out) { AccF z = {0ull, 0ull, 0ll, 0ll, 0ull}; acc[c] = z; }
 }

@@ -198,3 +198,30 @@ def test_binned_scatter_is_bit_identical_to_atomic_scatter(C, N, mode, weights):
         outs.append((hip.elevation_map.tobytes(), hip.normal_map.tobytes(), hip.get_additive_mean_error()))
         hip.close()
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("mode", ["reference_fp16", "fp32"])
+def test_fused_tile_kernel_without_rays(mode, weights):
+    """rays off + large cloud: emap_update takes the one-kernel fuse+commit+average tile path; it must equal both the
+    oracle and the atomic scatter path (bytes), incl. semantic counts."""
+    C, N = 202, 60000
+    cfg = dict(eo.YAML, enable_visibility_cleanup=False)
+    res = {}
+    for scatter in ("binned", "atomic"):
+        hip, orc = make_pair(cfg, C, mode, weights)
+        hip.set_scatter_mode(scatter)
+        R, t = fx.POSES["rotated"]
+        for f, dz in enumerate((0.0, -0.02, -0.2)):
+            p = fx.cloud(C, N, f, dz=dz, extra=1)
+            p[200:700, :2] = p[200, :2]
+            hip.param.pointcloud_channel_fusions = {"default": "average"}
+            hip.input_pointcloud(p, ["x", "y", "z", "feat"], R, t.copy() + hip.center, 1.0, 1.0)
+            orc.update_map_with_kernel(p, R, t, 1.0, 1.0)
+            orc.semantic_update(p, R, t, average=[(3, 0)])
+            for k in range(6):
+                hip.update_time(); orc.update_time()
+        assert_planes_close(hip.elevation_map, orc.elevation_map, what=scatter)
+        assert np.allclose(hip.semantic_map.semantic_map[0], orc.semantic_map[0], atol=1e-6, rtol=1e-5)
+        res[scatter] = hip.elevation_map.tobytes() + hip.normal_map.tobytes() + hip.semantic_map.semantic_map.tobytes()
+        hip.close()
+    assert res["binned"] == res["atomic"]
