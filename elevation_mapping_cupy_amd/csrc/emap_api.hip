@@ -29,6 +29,7 @@ void launch_overlap(hipStream_t, const KP&, Cell*, int, int, float, float);
 void launch_dilate(hipStream_t, const KP&, const Cell*, float*, int, int, int);
 void launch_trav_normal(hipStream_t, const KP&, const float*, const float*, const float*, const float*, const float*, Cell*, float*, long);
 void launch_var_time(hipStream_t, const KP&, Cell*, int, int);
+void launch_post(hipStream_t, const KP&, const float*, const float*, const float*, const float*, Cell*, float*, float*, long, int);
 void launch_get_plane(hipStream_t, const KP&, const Cell*, int, float*);
 void launch_set_plane(hipStream_t, const KP&, Cell*, int, const float*);
 void launch_fill_cells(hipStream_t, Cell*, long, const Cell&);
@@ -555,6 +556,15 @@ int emap_traversability_normals(emap_ctx* ctx) {
   return EMAP_OK;
 }
 
+int emap_post(emap_ctx* ctx) {   // dilation + traversability + normals in one launch (same results as the two stages)
+  CKARG(ctx, "null ctx");
+  CK(hipSetDevice(ctx->device));
+  launch_post(ctx->stream, ctx->kp, ctx->prm.w1, ctx->prm.w2, ctx->prm.w3, ctx->prm.w_out, ctx->cells, ctx->trav_in, ctx->normal,
+              ctx->ncells_alloc, ctx->prm.dilation_size);
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+
 int emap_update_variance(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 1, 0); CK(hipGetLastError()); return EMAP_OK; }
 int emap_update_time(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 0, 1); CK(hipGetLastError()); return EMAP_OK; }
 
@@ -597,9 +607,8 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   STAGE(5);
   if (p.enable_overlap_clearance && (rc = emap_overlap_clear(ctx, t[2]))) return rc;
   STAGE(6);
-  if ((rc = emap_dilate(ctx))) return rc;
   STAGE(7);
-  if ((rc = emap_traversability_normals(ctx))) return rc;
+  if ((rc = emap_post(ctx))) return rc;
   STAGE(8);
 #undef STAGE
   if (tm) {

@@ -448,6 +448,102 @@ __global__ __launch_bounds__(EM_BLOCK) void k_trav_normal(KP P, TravW Wt, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_post = dilation -> traversability filter + normals in ONE launch (elevation_mapping.py:376-391).  The dilated
+// plane only ever feeds these two stencils, so the tile (+3 halo) of dilated values is produced in LDS from a raw
+// (value, mask) tile (+3+d halo) and consumed in place; `traversability_input` is still written (interior only)
+// because it is a readable attribute of the reference class.  Semantics identical to k_dilate + k_trav_normal.
+// ---------------------------------------------------------------------------------------------------------
+#define PT_R 16
+#define PT_C 64
+__global__ __launch_bounds__(EM_BLOCK) void k_post(KP P, TravW Wt, Cell* __restrict__ cells, float* __restrict__ trav_in,
+                                                    float* __restrict__ normal, long plane_stride, int d) {
+  extern __shared__ float lds[];
+  const int RW = PT_C + 6 + 2 * d, rp = RW + 1, RH = PT_R + 6 + 2 * d;     // raw (value, mask) region
+  const int DW = PT_C + 6, dp = DW + 1, DH = PT_R + 6;                      // dilated region
+  float* rval = lds;
+  float* rmsk = rval + RH * rp;          // mask >= 0; stored as -(mask)-1 when the cell is NOT is_inside (never a source)
+  float* dil = rmsk + RH * rp;
+  float* sval = dil + DH * dp;           // is_valid of the PT_R x PT_C interior (normal filter)
+  const int C = P.C, total_rows = P.nrows + 2 * P.halo;
+  const int tile_r = P.halo + blockIdx.y * PT_R, tile_c = blockIdx.x * PT_C;
+  const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int r = wv; r < RH; r += EM_BLOCK / 64)
+    for (int cc = tc; cc < RW; cc += 64) {
+      int lr = tile_r - 3 - d + r, cl = tile_c - 3 - d + cc;
+      if (cl < 0) { cl += C; lr -= 1; } else if (cl >= C) { cl -= C; lr += 1; }      // flat-index row wrap (:403-407)
+      const int gr = lr - P.halo + P.row0;
+      float val = 0.f, msk = -1.f;
+      if (lr >= 0 && lr < total_rows && gr >= 0 && gr <= C - 1) {
+        const float4* cp = reinterpret_cast<const float4*>(&cells[(long)lr * C + cl]);
+        float4 m0 = cp[0], m1 = cp[1];
+        val = m1.y;
+        const float m = m0.z + m1.z;
+        const bool inside = gr >= 1 && gr <= C - 2 && cl >= 1 && cl <= C - 2;
+        msk = inside ? m : -m - 1.f;
+        const int ir = r - 3 - d, ic = cc - 3 - d;
+        if (ir >= 0 && ir < PT_R && ic >= 0 && ic < PT_C) sval[ir * PT_C + ic] = m0.z;
+      }
+      rval[r * rp + cc] = val; rmsk[r * rp + cc] = msk;
+    }
+  __syncthreads();
+  for (int r = wv; r < DH; r += EM_BLOCK / 64)
+    for (int cc = tc; cc < DW; cc += 64) {
+      const int o0 = (r + d) * rp + (cc + d);
+      const float mraw = rmsk[o0];
+      const float own = mraw < 0.f ? -mraw - 1.f : mraw;
+      float res = rval[o0];
+      if (own < 0.5f) {                      // first hit on ascending anti-diagonals == reference scan order (:429-436)
+        bool found = false;
+        for (int s2 = -2 * d; s2 <= 2 * d && !found; ++s2) {
+          const int dy0 = max(-d, s2 - d), dy1 = min(d, s2 + d);
+          for (int dy = dy0; dy <= dy1; ++dy) {
+            const int o = o0 + dy * rp + (s2 - dy);
+            if (rmsk[o] > 0.5f) { res = rval[o]; found = true; break; }
+          }
+        }
+      }
+      dil[r * dp + cc] = res;
+    }
+  __syncthreads();
+  const int col = tile_c + tc;
+  if (col >= C) return;
+#pragma unroll
+  for (int k = 0; k < PT_R / 4; ++k) {
+    const int tr = wv + 4 * k, lr = tile_r + tr;
+    if (lr >= P.halo + P.nrows) break;
+    const int gr = lr - P.halo + P.row0;
+    const long c = (long)lr * C + col;
+    const float* t0 = &dil[(tr + 3) * dp + (tc + 3)];
+    trav_in[c] = t0[0];
+    if (gr >= 3 && gr <= C - 4 && col >= 3 && col <= C - 4) {
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int dl = q + 1;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+          float sm = 0.f;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) sm += Wt.w[q][ch * 9 + a * 3 + b] * t0[(a - 1) * dl * dp + (b - 1) * dl];
+          acc += Wt.wo[q * 4 + ch] * fabsf(sm);
+        }
+      }
+      cells[c].trav = expf(-acc);
+    }
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (gr >= 1 && gr <= C - 3 && col >= 1 && col <= C - 3 && sval[tr * PT_C + tc] > 0.5f) {
+      float h = t0[0], dzdx = t0[1] - h, dzdy = t0[dp] - h;
+      float ax = -dzdy / P.res_f, ay = -dzdx / P.res_f;
+      float nrm = sqrtf((ax * ax) + (ay * ay) + 1.0f);
+      nx = ax / nrm; ny = ay / nrm; nz = 1.0f / nrm;
+    }
+    normal[c] = nx; normal[plane_stride + c] = ny; normal[2 * plane_stride + c] = nz;
+  }
+}
+
 // update_variance + update_time (elevation_mapping.py:420-426)
 __global__ __launch_bounds__(EM_BLOCK) void k_var_time(KP P, Cell* __restrict__ cells, int do_var, int do_time) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
@@ -589,6 +685,15 @@ void launch_trav_normal(hipStream_t s, const KP& P, const float* w1, const float
   for (int i = 0; i < 12; ++i) W.wo[i] = wo[i];
   dim3 g((P.C + TT_C - 1) / TT_C, (P.nrows + TT_R - 1) / TT_R), b(EM_BLOCK);
   hipLaunchKernelGGL(k_trav_normal, g, b, 0, s, P, W, in, cells, normal, plane_stride);
+}
+void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, const float* w3, const float* wo, Cell* cells,
+                 float* trav_in, float* normal, long plane_stride, int d) {
+  TravW W;
+  for (int i = 0; i < 36; ++i) { W.w[0][i] = w1[i]; W.w[1][i] = w2[i]; W.w[2][i] = w3[i]; }
+  for (int i = 0; i < 12; ++i) W.wo[i] = wo[i];
+  dim3 g((P.C + PT_C - 1) / PT_C, (P.nrows + PT_R - 1) / PT_R), b(EM_BLOCK);
+  size_t lds = sizeof(float) * ((size_t)2 * (PT_R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)(PT_R + 6) * (PT_C + 6 + 1) + (size_t)PT_R * PT_C);
+  hipLaunchKernelGGL(k_post, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d);
 }
 void launch_var_time(hipStream_t s, const KP& P, Cell* cells, int do_var, int do_time) {
   hipLaunchKernelGGL(k_var_time, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, do_var, do_time);

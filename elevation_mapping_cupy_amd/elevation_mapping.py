@@ -301,7 +301,7 @@ class ElevationMap:
                                               ct.byref(ct.c_uint32(c)) if c is not None else None))
         elif name == "overlap":
             self._chk(L.emap_overlap_clear(self._ctx, ct.c_float(float(t))))
-        elif name in ("commit", "average", "dilate", "traversability_normals", "update_variance", "update_time"):
+        elif name in ("commit", "average", "dilate", "traversability_normals", "post", "update_variance", "update_time"):
             self._chk(getattr(L, "emap_" + name)(self._ctx))
         else:
             raise ValueError(name)

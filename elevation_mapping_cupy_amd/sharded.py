@@ -158,11 +158,8 @@ class HipStripEngine:
         if have_hi:
             self._chk(self.lib.emap_halo_unpack(self.ctx, 1, ct.c_void_p(self.recv[1].data_ptr())))
 
-    def dilate(self):
-        self.map.stage("dilate")
-
-    def trav_normals(self):
-        self.map.stage("traversability_normals")
+    def post(self):
+        self.map.stage("post")      # dilation + traversability + normals (one launch)
 
     def update_time(self):
         self.map.update_time()
@@ -208,8 +205,7 @@ class ShardedElevationMap:
             s_lo, s_hi, r_lo, r_hi = e.halo_pack()
             c.exchange(s_lo, s_hi, r_lo, r_hi)
             e.halo_unpack(c.rank > 0, c.rank < c.world - 1)
-        e.dilate()
-        e.trav_normals()
+        e.post()
 
 
 # ---------------------------------------------------------------------------------------------------------------

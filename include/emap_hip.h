@@ -118,6 +118,7 @@ int emap_average(emap_ctx* ctx);                                            /* a
 int emap_overlap_clear(emap_ctx* ctx, float t_z);                           /* clear_overlap_map :393-410 */
 int emap_dilate(emap_ctx* ctx);                                             /* dilation_filter_kernel :376-383 */
 int emap_traversability_normals(emap_ctx* ctx);                             /* :385-391 (filter + update_normal) */
+int emap_post(emap_ctx* ctx);                                               /* the two stages above fused (used by emap_update) */
 int emap_update_variance(emap_ctx* ctx);                                    /* :420-422 */
 int emap_update_time(emap_ctx* ctx);                                        /* :424-426 */
 int emap_get_stats(emap_ctx* ctx, emap_stats* out);                         /* blocking D2H of the frame scalars */

@@ -225,3 +225,27 @@ def test_fused_tile_kernel_without_rays(mode, weights):
         res[scatter] = hip.elevation_map.tobytes() + hip.normal_map.tobytes() + hip.semantic_map.semantic_map.tobytes()
         hip.close()
     assert res["binned"] == res["atomic"]
+
+
+@pytest.mark.parametrize("d", [1, 3, 10])
+def test_fused_post_kernel_equals_the_two_stencil_stages(d, weights):
+    """k_post (dilation -> traversability + normals in one launch) vs k_dilate + k_trav_normal, holes everywhere."""
+    C = 202
+    cfg = dict(eo.YAML, dilation_size=d)
+    a, _ = make_pair(cfg, C, "reference_fp16", weights)
+    b, orc = make_pair(cfg, C, "reference_fp16", weights)
+    rng = np.random.default_rng(d)
+    e = np.zeros((7, C, C), np.float32)
+    e[5] = rng.uniform(-1, 1, (C, C)); e[2] = rng.uniform(0, 1, (C, C)) < 0.6; e[6] = rng.uniform(0, 1, (C, C)) < 0.1
+    e[2][:, :5] = rng.uniform(0, 1, (C, 5)) < 0.5; e[2][40:80, 50:120] = 0; e[6][40:80, 50:120] = 0
+    e[2][0, :] = 1; e[2][:, C - 1] = 1            # "valid" border cells are never a source, but keep their own value
+    a.elevation_map = e; b.elevation_map = e
+    orc.elevation_map[...] = e
+    a.stage("dilate"); a.stage("traversability_normals")
+    b.stage("post")
+    orc.dilate(); orc.traversability(); orc.normals()
+    assert np.array_equal(a.traversability_input, b.traversability_input)
+    assert a.elevation_map.tobytes() == b.elevation_map.tobytes()
+    assert a.normal_map.tobytes() == b.normal_map.tobytes()
+    assert np.array_equal(b.traversability_input, orc.traversability_input)
+    assert_planes_close(b.elevation_map, orc.elevation_map, what="post")

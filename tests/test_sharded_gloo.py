@@ -66,8 +66,7 @@ class OracleStripEngine:
         if have_hi:
             m[:, self.r1:self.r1 + H] = self.recv[1].numpy()
 
-    def dilate(self): self.om.dilate()
-    def trav_normals(self): self.om.traversability(); self.om.normals()
+    def post(self): self.om.dilate(); self.om.traversability(); self.om.normals()
     def update_time(self): self.om.update_time()
 
 
