@@ -135,7 +135,7 @@ static int build_ray_tables(emap_ctx* ctx) {
   std::vector<float> S;
   const float q_mrl = ctx->kp.q_mrl;
   float s = ctx->kp.q_step;
-  while (s < q_mrl && S.size() < (1u << 20)) {
+  while (s < q_mrl && S.size() < 8192u) {   // the table is staged in LDS (<= 32 KB); longer rays are cut like max_ray_length would
     S.push_back(s);
     float nx = (float)((double)s + p.ray_step);
     if (h) nx = q16(nx);

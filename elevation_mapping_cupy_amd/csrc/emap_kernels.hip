@@ -171,7 +171,7 @@ template <int MODE, bool LUT> struct IdxLut {
       const unsigned int b = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)(q + 0.0f));   // -0 -> +0
       const unsigned int mag = b & 0x7fffu, sg = b >> 15;
       const unsigned int m = min(max(mag, lo_m1), hi) - lo_m1;
-      return (int)t[sg * span + m];
+      return (int)t[(sg ? span : 0u) + m];
     }
   }
 };
@@ -183,12 +183,15 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
                                                  long plane_stride, FrameDev* __restrict__ F,
                                                  const unsigned long long* __restrict__ inert) {
   extern __shared__ unsigned int slut32[];
-  const unsigned int span = (unsigned int)(Rt.hi - Rt.lo) + 2u;
+  const unsigned int span = LUT ? (unsigned int)(Rt.hi - Rt.lo) + 2u : 0u;
+  float* sS = reinterpret_cast<float*>(slut32 + span);          // step table s_k staged in LDS (wave-uniform reads)
+  const int nS = Rt.nS;
   if (LUT) {
     const unsigned int* src = reinterpret_cast<const unsigned int*>(Rt.lut);   // 2 signs * span u16 = span u32
     for (unsigned int k = threadIdx.x; k < span; k += BLOCK) slut32[k] = src[k];
-    __syncthreads();
   }
+  for (int k = threadIdx.x; k < nS; k += BLOCK) sS[k] = Rt.S[k];
+  __syncthreads();
   IdxLut<MODE, LUT> lut{reinterpret_cast<const unsigned short*>(slut32), (unsigned int)Rt.lo - 1u, (unsigned int)Rt.hi, span};
   long i = (long)blockIdx.x * BLOCK + threadIdx.x;
   unsigned long long visits = 0;
@@ -207,11 +210,14 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
       float ray_length = fminf(norm, P.q_mrl);
       const float dec = (float)(-P.cs / ((double)ray_length / P.mrl));
       const int C = P.C;
+      const unsigned int halo_cells = (unsigned int)P.halo * (unsigned int)C;
       int last = -1;
-      for (int k = 0; k < Rt.nS; ++k) {
-        const float s = Rt.S[k];                   // wave-uniform: scalar load
+      float s = nS > 0 ? sS[0] : INFINITY;
+      for (int k = 0; k < nS; ++k) {
+        const float s_next = sS[k + 1 < nS ? k + 1 : k];      // prefetch: no dependent LDS wait at the loop head
         if (!(s < ray_length)) break;
         float nx = T.t[0] + rx * s, ny = T.t[1] + ry * s, nz = T.t[2] + rz * s;
+        s = s_next;
         const int ix = lut(P, Qf<MODE>(nx)), iy = lut(P, Qf<MODE>(ny));
         const int nidx = C * ix + iy;
         const unsigned int lr = (unsigned int)(ix - P.row0);
@@ -220,10 +226,10 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
                          ((unsigned int)(iy - 1) < (unsigned int)(C - 2)) & (lr < (unsigned int)P.nrows);
         last = nidx;
         if (!act) continue;
-        const long li = (long)lr * C + iy;
-        const long c = li + (long)P.halo * C;
+        const unsigned int li = lr * (unsigned int)C + (unsigned int)iy;     // < 2^31 cells (checked at create)
+        const unsigned int c = li + halo_cells;
         if (STATS) visits++;
-        if ((inert[li >> 6] >> (li & 63)) & 1ull) continue;   // known + fresh cell: nothing can happen
+        if ((inert[li >> 6] >> (li & 63u)) & 1ull) continue;   // known + fresh cell: nothing can happen
         const float4* cp = reinterpret_cast<const float4*>(&cells[c]);
         float4 m0 = cp[0], m1 = cp[1];             // h v valid trav | time upper is_upper pad
         float ddx = g.x - nx, ddy = g.y - ny, ddz = g.z - nz;
@@ -637,12 +643,12 @@ template <int MODE, bool STATS> static void launch_rays_t(hipStream_t s, const K
                                                           const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert) {
   const bool use_lut = MODE == 0 && Rt.lut != nullptr;
   if (use_lut) {
-    size_t lds = ((size_t)(Rt.hi - Rt.lo) + 2) * 4;
+    size_t lds = ((size_t)(Rt.hi - Rt.lo) + 2) * 4 + (size_t)Rt.nS * 4;
     dim3 g((unsigned int)((n + RAY_BLOCK_LUT - 1) / RAY_BLOCK_LUT)), b(RAY_BLOCK_LUT);
     hipLaunchKernelGGL((k_rays<MODE, STATS, true, RAY_BLOCK_LUT>), g, b, lds, s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
   } else {
     dim3 g(nblk(n)), b(EM_BLOCK);
-    hipLaunchKernelGGL((k_rays<MODE, STATS, false, EM_BLOCK>), g, b, 0, s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
+    hipLaunchKernelGGL((k_rays<MODE, STATS, false, EM_BLOCK>), g, b, (size_t)Rt.nS * 4, s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
   }
 }
 void launch_rays(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts, long n, int stride, const Cell* cells,
