@@ -76,18 +76,21 @@ class Hip:
         self.ck(self.l.hipDeviceSynchronize(), "hipDeviceSynchronize")
 
 
-# algorithmic bytes per unit of each stage (DESIGN.md "Kernels and rooflines"):
-#   point passes: 12 B xyz + the compulsory cell traffic of one point; cell passes: planes read + written once.
+# Algorithmic bytes of each timed stage = the bytes that stage must move once (N points, L cells):
 STAGE_BYTES = {
-    "count": lambda N, L: 12 * N + 16 * N + 8 * N,            # xyz + (h,v,valid,trav) gather + 1 counter RMW
-    "fuse": lambda N, L: 12 * N + 8 * N + 4 * N + 12 * N,     # xyz + (h,v) + points-per-cell + (sum_h,sum_v,cnt) RMW
-    "commit": lambda N, L: 56 * L,
-    "rays": lambda N, L: 12 * N,                              # reported as visits/s instead (data dependent)
-    "average": lambda N, L: 36 * L,                           # K4: 3+3 planes read, 3 written
+    "hist": lambda N, L: 12 * N + 16 * N,                    # xyz in, 16-B staging record out
+    "scan": lambda N, L: 0,
+    "scatter": lambda N, L: 16 * N + 16 * N + 16 * N,        # staging record in, (h,v,valid,trav) of its cell, sorted record out
+    "gate": lambda N, L: 0,
+    "fuse": lambda N, L: 16 * N + 8 * N + 64 * L,            # sorted record, (h,v) of its cell; cells read + written once (fused average)
+    "commit": lambda N, L: 40 * L + 64 * L,
+    "rays": lambda N, L: 12 * N + 32 * L + 16 * L,           # cloud + map + ray accumulators once (the kernel is issue bound: see visits/s)
+    "average": lambda N, L: 40 * L + 16 * L + 64 * L,
     "overlap": lambda N, L: 0,
-    "dilate": lambda N, L: 12 * L,                            # K5: 2 planes in, 1 out
-    "trav_normals": lambda N, L: 8 * L + 20 * L,              # a13 8 B/cell + K6 20 B/cell
+    "post": lambda N, L: 32 * L + 4 * L + 4 * L + 12 * L,    # cells in; traversability_input, traversability, 3 normal planes out
 }
+STAGE_KERNEL = {"hist": "k_bin_hist", "scan": "k_bin_scan1", "scatter": "k_bin_scatter", "gate": "k_gate", "fuse": "k_tile_fuse",
+                "commit": "k_commit", "rays": "k_rays<0, false", "average": "k_average", "overlap": "k_overlap", "post": "k_post"}
 
 
 def main():
@@ -161,15 +164,15 @@ def main():
 
     # ---- per-stage device time (hipEvents on the kernel's stream) -> roofline of the dominant kernel ------
     lib.emap_enable_stage_timing(ctx, 2)
-    acc = np.zeros(8)
+    acc = np.zeros(10)
     reps = min(a.steps, 20)
     st = _lib.EmapStats()
     visits = 0
     for i in range(reps):
         frame(i, ct.byref(st))
-        ms8 = (ct.c_float * 8)()
-        lib.emap_get_stage_times(ctx, ms8)
-        acc += np.array(list(ms8)); visits += st.ray_visits
+        ms10 = (ct.c_float * 10)()
+        lib.emap_get_stage_times(ctx, ms10)
+        acc += np.array(list(ms10)); visits += st.ray_visits
     lib.emap_enable_stage_timing(ctx, 0)
     stage_ms = dict(zip(_lib.STAGES, (acc / reps).tolist()))
     L = C * C
@@ -182,8 +185,7 @@ def main():
     traffic, traffic_src = None, None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_%s.json" % a.workload)
     if os.path.exists(pmc_file) and C == 1024 and N == 1_000_000 and a.mode == "reference_fp16":
-        kern = {"count": "k_count", "fuse": "k_fuse", "commit": "k_commit", "rays": "k_rays", "average": "k_average",
-                "dilate": "k_dilate", "trav_normals": "k_trav_normal", "overlap": "k_overlap"}[dom]
+        kern = STAGE_KERNEL[dom]
         for name, rec in json.load(open(pmc_file))["kernels"].items():
             if name.startswith(kern):
                 traffic, traffic_src = rec["hbm_bytes"], "profiles/pmc_%s.json (%s)" % (a.workload, name)
@@ -193,7 +195,8 @@ def main():
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
             "frame_algorithmic_bytes": frame_bytes,
             "frame_frac": round(frame_bytes / (ms_dev.value / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "ray_visits_per_frame": int(visits / reps)}
+            "ray_visits_per_frame": int(visits / reps),
+            "ray_visits_per_s": (round(visits / reps / (stage_ms["rays"] * 1e-3) / 1e9, 1) if visits else None), "visits_unit": "G cell visits/s"}
 
     # ---- CPU baseline: the oracle port, same workload, bounded sample ---------------------------------------
     cpu = None

@@ -50,7 +50,7 @@ class EmapSemSpec(ct.Structure):
 MODE = {"reference_fp16": 0, "fp32": 1}
 PLANES = {"elevation": 0, "variance": 1, "is_valid": 2, "traversability": 3, "time": 4, "upper_bound": 5,
           "is_upper_bound": 6, "normal_x": 7, "normal_y": 8, "normal_z": 9, "traversability_input": 10}
-STAGES = ["count", "fuse", "commit", "rays", "average", "overlap", "dilate", "trav_normals"]
+STAGES = ["hist", "scan", "scatter", "gate", "fuse", "commit", "rays", "average", "overlap", "post"]
 
 # every symbol include/emap_hip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [

@@ -41,13 +41,15 @@ void launch_shift(hipStream_t, const KP&, const Cell*, Cell*, int, int, float);
 struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; };
 struct BinTmp { int tile; unsigned int lc; float z, v; };
 struct BinRec { unsigned int lc_inl; float z, v; unsigned int i; };
-void launch_bin_count(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, BinTmp*, unsigned int*, unsigned int*,
-                      unsigned int*, const Cell*, BinRec*, ErrSlot*);
+void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, BinTmp*, unsigned int*);
+void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*);
+void launch_bin_scatter(hipStream_t, const KP&, const BinGeo&, const BinTmp*, long, const unsigned int*, const unsigned int*, const Cell*, BinRec*, ErrSlot*);
 void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cell*, AccF*, const FrameDev*, bool, unsigned int*);
 #define BIN_MAX_T 4096
 #define BIN_MAX_B 2048
 
-enum { ST_COUNT = 0, ST_FUSE, ST_COMMIT, ST_RAYS, ST_AVERAGE, ST_OVERLAP, ST_DILATE, ST_TRAVN, ST_N };
+// timed stages of emap_update (emap_get_stage_times): hist+scan are 0 on the atomic path, where "scatter" is k_count
+enum { ST_HIST = 0, ST_SCAN, ST_SCATTER, ST_GATE, ST_FUSE, ST_COMMIT, ST_RAYS, ST_AVERAGE, ST_OVERLAP, ST_POST, ST_N };
 
 struct emap_ctx {
   emap_params prm;
@@ -80,7 +82,7 @@ struct emap_ctx {
   bool committed;
   bool stage_timing; hipEvent_t ev[ST_N + 1]; float stage_ms[ST_N];
   hipEvent_t t0, t1;
-  bool want_ray_stats;
+  bool want_ray_stats; bool in_update;
   std::string err;
 };
 
@@ -425,9 +427,17 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
   ctx->frame_binned = binned;
   if (binned) {
     int rc = ensure_bins(ctx); if (rc) return rc;
-    launch_bin_count(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_tmp, ctx->bin_hist,
-                     ctx->bin_tile_total, ctx->bin_tile_start, ctx->cells, ctx->bin_recs, ctx->slots);
+    const bool tm = ctx->stage_timing && ctx->in_update;
+    if (tm) CK(hipEventRecord(ctx->ev[ST_HIST], ctx->stream));
+    launch_bin_hist(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_tmp, ctx->bin_hist);
+    if (tm) CK(hipEventRecord(ctx->ev[ST_SCAN], ctx->stream));
+    launch_bin_scan(ctx->stream, ctx->bg, ctx->bin_hist, ctx->bin_tile_total, ctx->bin_tile_start);
+    if (tm) CK(hipEventRecord(ctx->ev[ST_SCATTER], ctx->stream));
+    launch_bin_scatter(ctx->stream, ctx->kp, ctx->bg, ctx->bin_tmp, ctx->n_pts, ctx->bin_hist, ctx->bin_tile_start, ctx->cells, ctx->bin_recs,
+                       ctx->slots);
   } else {
+    if (ctx->stage_timing && ctx->in_update)
+      for (int e = ST_HIST; e <= ST_SCATTER; ++e) CK(hipEventRecord(ctx->ev[e], ctx->stream));
     launch_count(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->slots);
   }
   CK(hipGetLastError());
@@ -587,29 +597,31 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   const bool tm = ctx->stage_timing;
   int rc;
 #define STAGE(i) do { if (tm) CK(hipEventRecord(ctx->ev[i], ctx->stream)); } while (0)
-  STAGE(0);
-  if ((rc = emap_count(ctx, R, t))) return rc;
+  ctx->in_update = true;
+  rc = emap_count(ctx, R, t);                 // records ST_HIST / ST_SCAN / ST_SCATTER itself
+  ctx->in_update = false;
+  if (rc) return rc;
+  STAGE(ST_GATE);
   if ((rc = emap_set_drift_inputs(ctx, position_noise, orientation_noise, nullptr, nullptr))) return rc;
-  STAGE(1);
+  STAGE(ST_FUSE);
   // no visibility pass + binned scatter: fusion, commit and averaging happen in ONE tile kernel
   const bool fused_avg = ctx->frame_binned && !p.enable_visibility_cleanup;
   if ((rc = fuse_impl(ctx, R, t, false, fused_avg))) return rc;
-  STAGE(2);
+  STAGE(ST_COMMIT);
   if (p.enable_visibility_cleanup) {
     if ((rc = emap_commit(ctx))) return rc;
-    STAGE(3);
+    STAGE(ST_RAYS);
     if ((rc = emap_rays(ctx, R, t))) return rc;
-  } else STAGE(3);
-  STAGE(4);
+  } else STAGE(ST_RAYS);
+  STAGE(ST_AVERAGE);
   if (!fused_avg) launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, p.enable_visibility_cleanup != 0, ctx->cnt_plane);
   ctx->committed = false;
   CK(hipGetLastError());
-  STAGE(5);
+  STAGE(ST_OVERLAP);
   if (p.enable_overlap_clearance && (rc = emap_overlap_clear(ctx, t[2]))) return rc;
-  STAGE(6);
-  STAGE(7);
+  STAGE(ST_POST);
   if ((rc = emap_post(ctx))) return rc;
-  STAGE(8);
+  STAGE(ST_N);
 #undef STAGE
   if (tm) {
     CK(hipEventSynchronize(ctx->ev[ST_N]));
@@ -810,6 +822,6 @@ int emap_timer_end(emap_ctx* ctx, float* ms) {
   return EMAP_OK;
 }
 int emap_enable_stage_timing(emap_ctx* ctx, int enable) { CKARG(ctx, "null ctx"); ctx->stage_timing = enable != 0; ctx->want_ray_stats = enable > 1; return EMAP_OK; }
-int emap_get_stage_times(emap_ctx* ctx, float ms_out[8]) { CKARG(ctx && ms_out, "null argument"); for (int i = 0; i < ST_N; ++i) ms_out[i] = ctx->stage_ms[i]; return EMAP_OK; }
+int emap_get_stage_times(emap_ctx* ctx, float ms_out[10]) { CKARG(ctx && ms_out, "null argument"); for (int i = 0; i < ST_N; ++i) ms_out[i] = ctx->stage_ms[i]; return EMAP_OK; }
 
 }  // extern "C"

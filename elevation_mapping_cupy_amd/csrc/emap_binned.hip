@@ -199,13 +199,18 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
 
 static inline unsigned int nb(long n) { return (unsigned int)((n + EM_BLOCK - 1) / EM_BLOCK); }
 
-// count stage of the binned path: hist + scans + scatter (error sums land in `slots` exactly as k_count leaves them)
-void launch_bin_count(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride, BinTmp* tmp,
-                      unsigned int* hist, unsigned int* tile_total, unsigned int* tile_start, const Cell* cells, BinRec* recs, ErrSlot* slots) {
+// count stage of the binned path = hist, scans, scatter (error sums land in `slots` exactly as k_count leaves them)
+void launch_bin_hist(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride, BinTmp* tmp,
+                     unsigned int* hist) {
   if (P.mode == 0) hipLaunchKernelGGL(k_bin_hist<0>, dim3(G.B), dim3(EM_BLOCK), 0, s, P, T, G, pts, n, stride, tmp, hist);
   else hipLaunchKernelGGL(k_bin_hist<1>, dim3(G.B), dim3(EM_BLOCK), 0, s, P, T, G, pts, n, stride, tmp, hist);
+}
+void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigned int* tile_total, unsigned int* tile_start) {
   hipLaunchKernelGGL(k_bin_scan1, dim3(G.T), dim3(EM_BLOCK), 0, s, G, hist, tile_total);
   hipLaunchKernelGGL(k_bin_scan2, dim3(1), dim3(EM_BLOCK), 0, s, G, tile_total, tile_start);
+}
+void launch_bin_scatter(hipStream_t s, const KP& P, const BinGeo& G, const BinTmp* tmp, long n, const unsigned int* hist,
+                        const unsigned int* tile_start, const Cell* cells, BinRec* recs, ErrSlot* slots) {
   hipLaunchKernelGGL(k_bin_scatter, dim3(G.B), dim3(EM_BLOCK), 0, s, P, G, tmp, n, hist, tile_start, cells, recs, slots);
 }
 void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cell* cells,

@@ -160,10 +160,11 @@ int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf);
 /* ---- timing on the context's stream (hipEvents; bench.py's roofline leg) -------------------------- */
 int emap_timer_begin(emap_ctx* ctx);
 int emap_timer_end(emap_ctx* ctx, float* elapsed_ms); /* records, synchronises, returns elapsed */
-/* per-stage device times of the last emap_update when profiling is enabled (order: count, fuse, commit, rays,
- * average, overlap, dilate, trav_normals); enabling inserts events between stages */
+/* per-stage device times of the last emap_update when profiling is enabled (order: hist, scan, scatter, gate, fuse,
+ * commit, rays, average, overlap, post; hist/scan are 0 and "scatter" is the count kernel on the global-atomic path);
+ * enabling inserts hipEvents between the stages (each costs a few microseconds of its own) */
 int emap_enable_stage_timing(emap_ctx* ctx, int enable);
-int emap_get_stage_times(emap_ctx* ctx, float ms_out[8]);
+int emap_get_stage_times(emap_ctx* ctx, float ms_out[10]);
 
 #ifdef __cplusplus
 }
