@@ -282,8 +282,9 @@ class ElevationMap:
         """Entry point used by the ROS wrapper (reference :434-466).  NaN rows are skipped inside the kernels
         instead of being compacted on the host (:458)."""
         additional_channels = list(channels[3:])
+        # asynchronous: nothing is read back per frame (get_additive_mean_error / get_map_with_name_ref synchronise)
         self.update_map_with_kernel(raw_points, additional_channels, np.asarray(R, np.float32),
-                                    np.asarray(t, np.float32).copy(), position_noise, orientation_noise)
+                                    np.asarray(t, np.float32).copy(), position_noise, orientation_noise, want_stats=False)
 
     input = input_pointcloud  # name used by the C++ wrapper (src/elevation_mapping_wrapper.cpp:173-178)
 

@@ -249,3 +249,27 @@ def test_fused_post_kernel_equals_the_two_stencil_stages(d, weights):
     assert a.normal_map.tobytes() == b.normal_map.tobytes()
     assert np.array_equal(b.traversability_input, orc.traversability_input)
     assert_planes_close(b.elevation_map, orc.elevation_map, what="post")
+
+
+def test_fp32_index_mode_on_a_map_beyond_the_half_range(weights):
+    """cell_n > 2049: the reference's half-precision clamp cannot address the map; index_mode fp32 (same source with
+    float16 := float) is the defined behaviour there.  Also exercises the auto mode selection and > 1024 tiles."""
+    from elevation_mapping_cupy_amd.configs import parameter_from
+    from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
+    C, N = 2560, 300000
+    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML); cfg.update(enable_visibility_cleanup=False)
+    hip = ElevationMap(parameter_from(cfg, C, "auto", weights))
+    assert hip.index_mode == "fp32"
+    orc = eo.OracleMap(eo.make_params(cfg, cell_n=C, mode="fp32", weights=weights))
+    R, t = fx.POSES["rotated"]
+    for f, dz in enumerate((0.0, -0.05)):
+        p = fx.cloud(C, N, f, dz=dz)
+        hip.bind_points(p)
+        i1 = hip.point_index(R, t); i0 = orc.point_index(p, R, t)
+        assert all(np.array_equal(a, b) for a, b in zip(i1, i0))
+        hip.update_map_with_kernel(None, [], R, t.copy(), 1.0, 1.0)
+        orc.update_map_with_kernel(p, R, t, 1.0, 1.0)
+        hip.update_time(); orc.update_time()
+    assert_planes_close(hip.elevation_map, orc.elevation_map, what="fp32 2560")
+    with pytest.raises(Exception):
+        ElevationMap(parameter_from(cfg, C, "reference_fp16", weights))
