@@ -33,7 +33,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"],
+                    help="cfg2/cfg3: BASELINE configs[1]/[2] (1024^2, 1 M points); cfg5: 8192^2 multi-modal map "
+                         "(height + RGB + 3 semantic layers), 16 M points, fp32 index mode, rays/overlap off")
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--cell-n", type=int, default=1024)
     ap.add_argument("--mode", default="reference_fp16", choices=["reference_fp16", "fp32"])
@@ -109,6 +111,10 @@ def main():
 
     cfg = workload_cfg(a.workload)
     C, N = a.cell_n, a.points
+    multimodal = a.workload == "cfg5"
+    if multimodal:
+        C, N, a.mode = (8192 if a.cell_n == 1024 else a.cell_n), (16_000_000 if a.points == 1_000_000 else a.points), "fp32"
+        cfg.update(enable_visibility_cleanup=False, enable_overlap_clearance=False)
     w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
     weights = {k: w[k] for k in ("w1", "w2", "w3", "w_out")}
     par = parameter_from(cfg, C, a.mode, weights)
@@ -118,8 +124,24 @@ def main():
     hip = Hip(); hip.set_device(local_rank)
 
     # 5 seeded clouds resident in HBM: x,y ~ U(-L/2, L/2), sensor-frame z ~ U(-.5,.5); timed clouds lowered
-    NCLOUD = 5
-    clouds_host = [fx.cloud(C, N, s, dz=(0.0 if s == 0 else -0.02 * s)) for s in range(NCLOUD)]
+    NCLOUD = 2 if multimodal else 5
+    if multimodal:   # x y z | rgb (packed 0x00RRGGBB) | 3 semantic features  -> colour + average fusions
+        clouds_host = []
+        for s_ in range(NCLOUD):
+            p_ = fx.cloud(C, N, s_, dz=-0.02 * s_, extra=4)
+            p_[:, 3] = np.random.default_rng(50 + s_).integers(0, 1 << 24, N, dtype=np.uint32).view(np.float32)
+            clouds_host.append(p_)
+        spec = _lib.EmapSemSpec()
+        spec.n_col, spec.col_chan[0], spec.col_layer[0] = 1, 3, 0
+        spec.n_sum = 3
+        for k_ in range(3):
+            spec.sum_chan[k_], spec.sum_layer[k_], spec.sum_kind[k_] = 4 + k_, 1 + k_, 0
+        spec.alpha = 0.5
+        if lib.emap_semantic_configure(ctx, 4):
+            raise RuntimeError(lib.emap_last_error(ctx).decode())
+    else:
+        clouds_host = [fx.cloud(C, N, s, dz=(0.0 if s == 0 else -0.02 * s)) for s in range(NCLOUD)]
+    stride = clouds_host[0].shape[1]
     clouds_dev = []
     for p in clouds_host:
         d = hip.malloc(p.nbytes); hip.h2d(d, p); clouds_dev.append(d)
@@ -128,8 +150,10 @@ def main():
     Rp, tp = _lib.f32p(R), _lib.f32p(t)
 
     def frame(i, stats=None):
-        rc = lib.emap_set_points_device(ctx, clouds_dev[i % NCLOUD], ct.c_int64(N), ct.c_int64(3))
+        rc = lib.emap_set_points_device(ctx, clouds_dev[i % NCLOUD], ct.c_int64(N), ct.c_int64(stride))
         rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
+        if multimodal:
+            rc = rc or lib.emap_semantic_update(ctx, Rp, tp, ct.byref(spec))
         if rc:
             raise RuntimeError(lib.emap_last_error(ctx).decode())
 
@@ -179,7 +203,7 @@ def main():
     dom = max(stage_ms, key=stage_ms.get)
     dom_bytes = STAGE_BYTES[dom](N, L)
     achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
-    frame_bytes = 12 * N + 56 * L            # B_frame of BASELINE.md §5 (K = 0 extra channels, L = 0 semantic layers)
+    frame_bytes = 12 * N + 56 * L + (16 * N + 32 * L if a.workload == 'cfg5' else 0)   # B_frame of BASELINE.md §5 (K = 0 extra channels, L = 0 semantic layers)
     # HBM traffic of the dominant kernel: from the committed rocprofv3 PMC passes of this same command
     # (tools/profile_round.sh -> profiles/pmc_<workload>.json; counters cannot be read from inside the process)
     traffic, traffic_src = None, None
@@ -200,7 +224,7 @@ def main():
 
     # ---- CPU baseline: the oracle port, same workload, bounded sample ---------------------------------------
     cpu = None
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and not multimodal:
         from oracle import emap_oracle as eo
         n_cpu = a.cpu_points or (N if a.workload == "cfg2" else min(N, 60000))
         P = eo.make_params(cfg, cell_n=C, mode=a.mode, weights=weights)
@@ -221,7 +245,8 @@ def main():
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %dx%d map, %d uniform-random points/frame, core_param.yaml values, %s"
-                               % (a.workload, C, C, N, "rays+overlap on" if a.workload == "cfg3" else "add_points + variance fusion, rays/overlap off"),
+                               % (a.workload, C, C, N, "rays+overlap on" if a.workload == "cfg3" else
+                                  ("height + RGB + 3 semantic layers, fp32 index mode" if multimodal else "add_points + variance fusion, rays/overlap off")),
                    "index_mode": a.mode, "latency_ms": {"p10": round(p10, 4), "p50": round(p50, 4), "p90": round(p90, 4)},
                    "device_ms_per_step": round(ms_dev.value / a.steps, 5), "cloud": "device resident (H2D excluded)"},
         "roofline": roof, "cpu_baseline": cpu,

@@ -6,6 +6,7 @@
 #include "../../include/emap_hip.h"
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -29,7 +30,7 @@ void launch_overlap(hipStream_t, const KP&, Cell*, int, int, float, float);
 void launch_dilate(hipStream_t, const KP&, const Cell*, float*, int, int, int);
 void launch_trav_normal(hipStream_t, const KP&, const float*, const float*, const float*, const float*, const float*, Cell*, float*, long);
 void launch_var_time(hipStream_t, const KP&, Cell*, int, int);
-void launch_post(hipStream_t, const KP&, const float*, const float*, const float*, const float*, Cell*, float*, float*, long, int);
+void launch_post(hipStream_t, const KP&, const float*, const float*, const float*, const float*, Cell*, float*, float*, long, int, int, int);
 void launch_get_plane(hipStream_t, const KP&, const Cell*, int, float*);
 void launch_set_plane(hipStream_t, const KP&, Cell*, int, const float*);
 void launch_fill_cells(hipStream_t, Cell*, long, const Cell&);
@@ -45,7 +46,7 @@ void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const f
 void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*);
 void launch_bin_scatter(hipStream_t, const KP&, const BinGeo&, const BinTmp*, long, const unsigned int*, const unsigned int*, const Cell*, BinRec*, ErrSlot*);
 void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cell*, AccF*, const FrameDev*, bool, unsigned int*);
-#define BIN_MAX_T 4096
+#define BIN_MAX_T 16384
 #define BIN_MAX_B 2048
 
 // timed stages of emap_update (emap_get_stage_times): hist+scan are 0 on the atomic path, where "scatter" is k_count
@@ -69,7 +70,7 @@ struct emap_ctx {
   // tile-binned scatter buffers (allocated on demand)
   int scatter_mode;                // 0 auto, 1 atomic, 2 binned
   bool frame_binned;               // the count stage of the current frame used the binned path
-  BinGeo bg; BinTmp* bin_tmp; BinRec* bin_recs; unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap;
+  BinGeo bg; BinTmp* bin_tmp; BinRec* bin_recs; unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;
   // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
   int sem_layers; float* sem; double* sem_sums; unsigned int* sem_col; unsigned int* cnt_plane;
   // point cloud
@@ -391,12 +392,21 @@ static int ensure_bins(emap_ctx* ctx) {
   const long n = ctx->n_pts;
   BinGeo& g = ctx->bg;
   g.tiles_x = (ctx->prm.cell_n + 63) / 64; g.tiles_y = (ctx->strip.row_count + 15) / 16; g.T = g.tiles_x * g.tiles_y;
-  long B = (n + 2047) / 2048; if (B < 1) B = 1; if (B > BIN_MAX_B) B = BIN_MAX_B;
+  long target = 2048;
+  if (const char* e = getenv("EMAP_BIN_CHUNK")) { long v = atol(e); if (v >= 256 && v <= 65536) target = v; }   // tuning knob
+  long B = (n + target - 1) / target; if (B < 1) B = 1; if (B > BIN_MAX_B) B = BIN_MAX_B;
   long chunk = (n + B - 1) / B; chunk = ((chunk + EM_BLOCK - 1) / EM_BLOCK) * EM_BLOCK; if (chunk < EM_BLOCK) chunk = EM_BLOCK;
   g.B = (int)((n + chunk - 1) / chunk); if (g.B < 1) g.B = 1;
   g.chunk = chunk;
-  if (!ctx->bin_hist) {
-    CK(hipMalloc((void**)&ctx->bin_hist, sizeof(unsigned int) * (size_t)BIN_MAX_T * BIN_MAX_B));
+  const size_t hist_need = (size_t)g.T * (size_t)g.B;
+  if (hist_need > ctx->bin_hist_cap) {
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->bin_hist) CK(hipFree(ctx->bin_hist));
+    ctx->bin_hist = nullptr; ctx->bin_hist_cap = 0;
+    CK(hipMalloc((void**)&ctx->bin_hist, sizeof(unsigned int) * hist_need));
+    ctx->bin_hist_cap = hist_need;
+  }
+  if (!ctx->bin_tile_total) {
     CK(hipMalloc((void**)&ctx->bin_tile_total, sizeof(unsigned int) * (BIN_MAX_T + 1)));
     CK(hipMalloc((void**)&ctx->bin_tile_start, sizeof(unsigned int) * (BIN_MAX_T + 1)));
   }
@@ -414,7 +424,7 @@ static int ensure_bins(emap_ctx* ctx) {
 
 int emap_set_scatter_mode(emap_ctx* ctx, int32_t mode) {
   CKARG(ctx && mode >= 0 && mode <= 2, "scatter mode: 0 auto, 1 atomic, 2 binned");
-  CKARG(mode != 2 || bins_possible(ctx), "binned scatter needs <= 4096 tiles of 16x64 cells");
+  CKARG(mode != 2 || bins_possible(ctx), "binned scatter needs <= 16384 tiles of 16x64 cells");
   ctx->scatter_mode = mode;
   return EMAP_OK;
 }
@@ -507,6 +517,18 @@ static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool tai
 }
 int emap_fuse(emap_ctx* ctx, const float R[9], const float t[3]) { CKARG(ctx && R && t, "null argument"); return fuse_impl(ctx, R, t, false); }
 
+// fuse + commit + average_map in one call for frames without a visibility pass (one tile kernel on the binned path)
+int emap_fuse_average(emap_ctx* ctx, const float R[9], const float t[3]) {
+  CKARG(ctx && R && t, "null argument");
+  const bool fused = ctx->frame_binned;
+  int rc = fuse_impl(ctx, R, t, false, fused);
+  if (rc) return rc;
+  if (!fused) launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, false, ctx->cnt_plane);
+  ctx->committed = false;
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+
 int emap_commit(emap_ctx* ctx) {
   CKARG(ctx, "null ctx");
   CK(hipSetDevice(ctx->device));
@@ -566,14 +588,30 @@ int emap_traversability_normals(emap_ctx* ctx) {
   return EMAP_OK;
 }
 
-int emap_post(emap_ctx* ctx) {   // dilation + traversability + normals in one launch (same results as the two stages)
-  CKARG(ctx, "null ctx");
+// dilation + traversability + normals in one launch (same results as the two stages).  part: 0 = whole strip,
+// 1 = only the tile rows that do not depend on halo rows (can run while the halo exchange is in flight),
+// 2 = the remaining (boundary) tile rows.
+int emap_post_part(emap_ctx* ctx, int32_t part) {
+  CKARG(ctx && part >= 0 && part <= 2, "bad argument");
   CK(hipSetDevice(ctx->device));
-  launch_post(ctx->stream, ctx->kp, ctx->prm.w1, ctx->prm.w2, ctx->prm.w3, ctx->prm.w_out, ctx->cells, ctx->trav_in, ctx->normal,
-              ctx->ncells_alloc, ctx->prm.dilation_size);
+  const int reach = ctx->prm.dilation_size + 4;                  // rows a tile looks beyond itself (stencils + row wrap)
+  const int all_rows = (ctx->strip.row_count + 15) / 16;
+  int first_in = (reach + 15) / 16, last_in = (ctx->strip.row_count - reach) / 16 - 1;   // interior tile rows [first_in, last_in]
+  if (ctx->strip.halo_rows == 0 || last_in < first_in) { first_in = all_rows; last_in = all_rows - 1; }   // no interior split
+  auto run = [&](int r0, int n) {
+    launch_post(ctx->stream, ctx->kp, ctx->prm.w1, ctx->prm.w2, ctx->prm.w3, ctx->prm.w_out, ctx->cells, ctx->trav_in, ctx->normal,
+                ctx->ncells_alloc, ctx->prm.dilation_size, r0, n);
+  };
+  if (part == 0) run(0, -1);
+  else if (part == 1) { if (last_in >= first_in) run(first_in, last_in - first_in + 1); }
+  else {
+    if (last_in >= first_in) { run(0, first_in); run(last_in + 1, all_rows - last_in - 1); }
+    else run(0, -1);
+  }
   CK(hipGetLastError());
   return EMAP_OK;
 }
+int emap_post(emap_ctx* ctx) { return emap_post_part(ctx, 0); }
 
 int emap_update_variance(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 1, 0); CK(hipGetLastError()); return EMAP_OK; }
 int emap_update_time(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 0, 1); CK(hipGetLastError()); return EMAP_OK; }

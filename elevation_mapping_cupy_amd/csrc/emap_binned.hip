@@ -15,12 +15,12 @@
 //                  the epilogue writes the 40-byte AccF records with plain coalesced stores.
 // Everything downstream (commit, rays, average, ...) is unchanged and the AccF contents are BIT-IDENTICAL to the
 // atomic path of emap_kernels.hip (integer / fixed-point accumulators are order independent), which stays as the
-// fallback for maps with more than 4096 tiles and for small clouds.
+// fallback for maps with more than 16384 tiles (> 4096^2 cells per context) and for small clouds.
 #include "emap_device.h"
 
 #define BIN_TR 16
 #define BIN_TC 64
-#define BIN_MAX_T 4096
+#define BIN_MAX_T 16384   /* LDS histogram / cursor arrays are dynamic: 4 B per tile */
 
 struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; };
 struct __attribute__((aligned(16))) BinTmp { int tile; unsigned int lc; float z, v; };        // staging, point order
@@ -45,7 +45,7 @@ __device__ __forceinline__ unsigned int block_excl_scan(unsigned int x, unsigned
 template <int MODE>
 __global__ __launch_bounds__(EM_BLOCK) void k_bin_hist(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
                                                         BinTmp* __restrict__ tmp, unsigned int* __restrict__ hist) {
-  __shared__ unsigned int h[BIN_MAX_T];
+  extern __shared__ unsigned int h[];
   for (int t = threadIdx.x; t < G.T; t += EM_BLOCK) h[t] = 0u;
   __syncthreads();
   const long base = (long)blockIdx.x * G.chunk;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_bin_scatter(KP P, BinGeo G, const 
                                                            const unsigned int* __restrict__ hist, const unsigned int* __restrict__ tile_start,
                                                            const Cell* __restrict__ cells, BinRec* __restrict__ recs,
                                                            ErrSlot* __restrict__ slots) {
-  __shared__ unsigned int cur[BIN_MAX_T];
+  extern __shared__ unsigned int cur[];
   for (int t = threadIdx.x; t < G.T; t += EM_BLOCK) cur[t] = tile_start[t] + hist[(long)t * G.B + blockIdx.x];
   __syncthreads();
   const long base = (long)blockIdx.x * G.chunk;
@@ -202,8 +202,8 @@ static inline unsigned int nb(long n) { return (unsigned int)((n + EM_BLOCK - 1)
 // count stage of the binned path = hist, scans, scatter (error sums land in `slots` exactly as k_count leaves them)
 void launch_bin_hist(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride, BinTmp* tmp,
                      unsigned int* hist) {
-  if (P.mode == 0) hipLaunchKernelGGL(k_bin_hist<0>, dim3(G.B), dim3(EM_BLOCK), 0, s, P, T, G, pts, n, stride, tmp, hist);
-  else hipLaunchKernelGGL(k_bin_hist<1>, dim3(G.B), dim3(EM_BLOCK), 0, s, P, T, G, pts, n, stride, tmp, hist);
+  if (P.mode == 0) hipLaunchKernelGGL(k_bin_hist<0>, dim3(G.B), dim3(EM_BLOCK), sizeof(unsigned int) * G.T, s, P, T, G, pts, n, stride, tmp, hist);
+  else hipLaunchKernelGGL(k_bin_hist<1>, dim3(G.B), dim3(EM_BLOCK), sizeof(unsigned int) * G.T, s, P, T, G, pts, n, stride, tmp, hist);
 }
 void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigned int* tile_total, unsigned int* tile_start) {
   hipLaunchKernelGGL(k_bin_scan1, dim3(G.T), dim3(EM_BLOCK), 0, s, G, hist, tile_total);
@@ -211,7 +211,7 @@ void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigne
 }
 void launch_bin_scatter(hipStream_t s, const KP& P, const BinGeo& G, const BinTmp* tmp, long n, const unsigned int* hist,
                         const unsigned int* tile_start, const Cell* cells, BinRec* recs, ErrSlot* slots) {
-  hipLaunchKernelGGL(k_bin_scatter, dim3(G.B), dim3(EM_BLOCK), 0, s, P, G, tmp, n, hist, tile_start, cells, recs, slots);
+  hipLaunchKernelGGL(k_bin_scatter, dim3(G.B), dim3(EM_BLOCK), sizeof(unsigned int) * G.T, s, P, G, tmp, n, hist, tile_start, cells, recs, slots);
 }
 void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cell* cells,
                      AccF* acc, const FrameDev* F, bool fuse_average, unsigned int* cnt_plane) {

@@ -462,8 +462,10 @@ __global__ __launch_bounds__(EM_BLOCK) void k_trav_normal(KP P, TravW Wt, const 
 // ---------------------------------------------------------------------------------------------------------
 #define PT_R 16
 #define PT_C 64
-__global__ __launch_bounds__(EM_BLOCK) void k_post(KP P, TravW Wt, Cell* __restrict__ cells, float* __restrict__ trav_in,
-                                                    float* __restrict__ normal, long plane_stride, int d) {
+#define PT_THREADS 512   /* 8 waves per tile: the kernel is latency/issue bound, 32 resident waves per CU hide it */
+#define PT_WAVES (PT_THREADS / 64)
+__global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __restrict__ cells, float* __restrict__ trav_in,
+                                                    float* __restrict__ normal, long plane_stride, int d, int tile_row0) {
   extern __shared__ float lds[];
   const int RW = PT_C + 6 + 2 * d, rp = RW + 1, RH = PT_R + 6 + 2 * d;     // raw (value, mask) region
   const int DW = PT_C + 6, dp = DW + 1, DH = PT_R + 6;                      // dilated region
@@ -472,9 +474,9 @@ __global__ __launch_bounds__(EM_BLOCK) void k_post(KP P, TravW Wt, Cell* __restr
   float* dil = rmsk + RH * rp;
   float* sval = dil + DH * dp;           // is_valid of the PT_R x PT_C interior (normal filter)
   const int C = P.C, total_rows = P.nrows + 2 * P.halo;
-  const int tile_r = P.halo + blockIdx.y * PT_R, tile_c = blockIdx.x * PT_C;
+  const int tile_r = P.halo + (tile_row0 + (int)blockIdx.y) * PT_R, tile_c = blockIdx.x * PT_C;
   const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int r = wv; r < RH; r += EM_BLOCK / 64)
+  for (int r = wv; r < RH; r += PT_WAVES)
     for (int cc = tc; cc < RW; cc += 64) {
       int lr = tile_r - 3 - d + r, cl = tile_c - 3 - d + cc;
       if (cl < 0) { cl += C; lr -= 1; } else if (cl >= C) { cl -= C; lr += 1; }      // flat-index row wrap (:403-407)
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_post(KP P, TravW Wt, Cell* __restr
       rval[r * rp + cc] = val; rmsk[r * rp + cc] = msk;
     }
   __syncthreads();
-  for (int r = wv; r < DH; r += EM_BLOCK / 64)
+  for (int r = wv; r < DH; r += PT_WAVES)
     for (int cc = tc; cc < DW; cc += 64) {
       const int o0 = (r + d) * rp + (cc + d);
       const float mraw = rmsk[o0];
@@ -515,8 +517,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_post(KP P, TravW Wt, Cell* __restr
   const int col = tile_c + tc;
   if (col >= C) return;
 #pragma unroll
-  for (int k = 0; k < PT_R / 4; ++k) {
-    const int tr = wv + 4 * k, lr = tile_r + tr;
+  for (int k = 0; k < PT_R / PT_WAVES; ++k) {
+    const int tr = wv + PT_WAVES * k, lr = tile_r + tr;
     if (lr >= P.halo + P.nrows) break;
     const int gr = lr - P.halo + P.row0;
     const long c = (long)lr * C + col;
@@ -692,14 +694,20 @@ void launch_trav_normal(hipStream_t s, const KP& P, const float* w1, const float
   dim3 g((P.C + TT_C - 1) / TT_C, (P.nrows + TT_R - 1) / TT_R), b(EM_BLOCK);
   hipLaunchKernelGGL(k_trav_normal, g, b, 0, s, P, W, in, cells, normal, plane_stride);
 }
+// tile rows [tile_row0, tile_row0 + n_tile_rows) of the strip (16 map rows each); the whole strip when n_tile_rows < 0
 void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, const float* w3, const float* wo, Cell* cells,
-                 float* trav_in, float* normal, long plane_stride, int d) {
+                 float* trav_in, float* normal, long plane_stride, int d, int tile_row0, int n_tile_rows) {
   TravW W;
   for (int i = 0; i < 36; ++i) { W.w[0][i] = w1[i]; W.w[1][i] = w2[i]; W.w[2][i] = w3[i]; }
   for (int i = 0; i < 12; ++i) W.wo[i] = wo[i];
-  dim3 g((P.C + PT_C - 1) / PT_C, (P.nrows + PT_R - 1) / PT_R), b(EM_BLOCK);
+  const int all_rows = (P.nrows + PT_R - 1) / PT_R;
+  if (n_tile_rows < 0) { tile_row0 = 0; n_tile_rows = all_rows; }
+  if (tile_row0 < 0) tile_row0 = 0;
+  if (tile_row0 + n_tile_rows > all_rows) n_tile_rows = all_rows - tile_row0;
+  if (n_tile_rows <= 0) return;
+  dim3 g((P.C + PT_C - 1) / PT_C, n_tile_rows), b(PT_THREADS);
   size_t lds = sizeof(float) * ((size_t)2 * (PT_R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)(PT_R + 6) * (PT_C + 6 + 1) + (size_t)PT_R * PT_C);
-  hipLaunchKernelGGL(k_post, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d);
+  hipLaunchKernelGGL(k_post, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
 }
 void launch_var_time(hipStream_t s, const KP& P, Cell* cells, int do_var, int do_time) {
   hipLaunchKernelGGL(k_var_time, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, do_var, do_time);

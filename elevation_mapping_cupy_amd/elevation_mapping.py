@@ -291,7 +291,7 @@ class ElevationMap:
     # ---- stage-level API (parity tests; same order as update_map_with_kernel) ----------------------
     def stage(self, name, R=None, t=None, **kw):
         L = self._lib
-        if name in ("count", "fuse", "rays"):
+        if name in ("count", "fuse", "rays", "fuse_average"):
             R, t = self._rt(R, t)
             self._chk(getattr(L, "emap_" + name)(self._ctx, f32p(R), f32p(t)))
         elif name == "gate":

@@ -57,9 +57,9 @@ class TorchComm:
             self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
         return tensor
 
-    def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
+    def exchange_start(self, send_lo, send_hi, recv_lo, recv_hi):
         """neighbour exchange on the strip chain: send_lo -> rank-1 (arrives in its recv_hi), send_hi -> rank+1
-        (arrives in its recv_lo).  Edge ranks have one neighbour."""
+        (arrives in its recv_lo).  Edge ranks have one neighbour.  Returns the in-flight requests."""
         dist = self.dist
         ops = []
         if self.rank > 0:
@@ -68,9 +68,11 @@ class TorchComm:
         if self.rank < self.world - 1:
             ops.append(dist.P2POp(dist.isend, send_hi, self.rank + 1))
             ops.append(dist.P2POp(dist.irecv, recv_hi, self.rank + 1))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def exchange_wait(self, works):
+        for w in works:
+            w.wait()
 
     def barrier(self):
         if self.world > 1:
@@ -135,6 +137,9 @@ class HipStripEngine:
     def fuse(self, R, t):
         self.map.stage("fuse", R, t)
 
+    def fuse_average(self, R, t):
+        self.map.stage("fuse_average", R, t)
+
     def commit(self):
         self.map.stage("commit")
 
@@ -158,8 +163,9 @@ class HipStripEngine:
         if have_hi:
             self._chk(self.lib.emap_halo_unpack(self.ctx, 1, ct.c_void_p(self.recv[1].data_ptr())))
 
-    def post(self):
-        self.map.stage("post")      # dilation + traversability + normals (one launch)
+    def post(self, part=0):
+        """dilation + traversability + normals; part 1 = tiles independent of the halo, 2 = boundary tiles, 0 = all"""
+        self._chk(self.lib.emap_post_part(self.ctx, int(part)))
 
     def update_time(self):
         self.map.update_time()
@@ -194,18 +200,24 @@ class ShardedElevationMap:
         e.count(R, t)
         totals = c.all_reduce_sum_(e.local_sums())            # exchange step 1: 2 scalars
         e.gate(position_noise, orientation_noise, totals)
-        e.fuse(R, t)
         if self.rays_on:
+            e.fuse(R, t)
             e.commit()
             e.rays(R, t)
-        e.average()
+            e.average()
+        else:
+            e.fuse_average(R, t)                               # one tile kernel: fuse + commit + average
         if self.overlap_on:
             e.overlap(float(np.float32(np.asarray(t, np.float32).reshape(3)[2])))
-        if c.world > 1:                                        # exchange step 2: halo rows of cells
+        if c.world > 1:                                        # exchange step 2: halo rows of cells ...
             s_lo, s_hi, r_lo, r_hi = e.halo_pack()
-            c.exchange(s_lo, s_hi, r_lo, r_hi)
+            works = c.exchange_start(s_lo, s_hi, r_lo, r_hi)
+            e.post(1)                                          # ... overlapped with the stencils of the interior tiles
+            c.exchange_wait(works)
             e.halo_unpack(c.rank > 0, c.rank < c.world - 1)
-        e.post()
+            e.post(2)
+        else:
+            e.post(0)
 
 
 # ---------------------------------------------------------------------------------------------------------------

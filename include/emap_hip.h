@@ -109,9 +109,10 @@ int emap_drift_sums_to_device(emap_ctx* ctx, double* dev_out2);
 int emap_set_drift_inputs_device(emap_ctx* ctx, double position_noise, double orientation_noise, const double* dev_totals2);
 int emap_local_drift_sums(emap_ctx* ctx, double* err_sum, uint32_t* err_cnt);
 /* how the count/fuse passes scatter into the map: 0 = auto (tile-binned LDS reduction for clouds >= 32768 points on maps
- * with <= 4096 tiles, else global atomics), 1 = global atomics, 2 = tile-binned. Results are bit-identical. */
+ * with <= 16384 tiles of 16x64 cells, else global atomics), 1 = global atomics, 2 = tile-binned. Results are bit-identical. */
 int emap_set_scatter_mode(emap_ctx* ctx, int32_t mode);
 int emap_fuse(emap_ctx* ctx, const float R[9], const float t[3]);           /* add_points_kernel fusion part */
+int emap_fuse_average(emap_ctx* ctx, const float R[9], const float t[3]);   /* fuse+commit+average when no ray pass follows */
 int emap_commit(emap_ctx* ctx);                                             /* side effects of :174,:189-192 -> S1 */
 int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]);           /* add_points_kernel visibility part */
 int emap_average(emap_ctx* ctx);                                            /* average_map_kernel :369 */
@@ -119,6 +120,8 @@ int emap_overlap_clear(emap_ctx* ctx, float t_z);                           /* c
 int emap_dilate(emap_ctx* ctx);                                             /* dilation_filter_kernel :376-383 */
 int emap_traversability_normals(emap_ctx* ctx);                             /* :385-391 (filter + update_normal) */
 int emap_post(emap_ctx* ctx);                                               /* the two stages above fused (used by emap_update) */
+/* row strips: part 1 = tile rows independent of the halo (overlaps the halo exchange), part 2 = boundary tile rows */
+int emap_post_part(emap_ctx* ctx, int32_t part);
 int emap_update_variance(emap_ctx* ctx);                                    /* :420-422 */
 int emap_update_time(emap_ctx* ctx);                                        /* :424-426 */
 int emap_get_stats(emap_ctx* ctx, emap_stats* out);                         /* blocking D2H of the frame scalars */

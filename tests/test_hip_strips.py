@@ -33,7 +33,10 @@ class ThreadComm:
         sh["bar"].wait()
         return t
 
-    def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
+    def exchange_wait(self, works):
+        pass
+
+    def exchange_start(self, send_lo, send_hi, recv_lo, recv_hi):
         import torch
         sh = self.sh
         sh["send"][self.rank] = (send_lo, send_hi)
@@ -45,17 +48,20 @@ class ThreadComm:
             recv_hi.copy_(sh["send"][self.rank + 1][0])
         torch.cuda.synchronize()
         sh["bar"].wait()
+        return []
 
 
-@pytest.mark.parametrize("world,cfg_name,C", [(2, "yaml", 130), (3, "default", 202)])
+@pytest.mark.parametrize("world,cfg_name,C", [(2, "yaml", 130), (3, "default", 202), (2, "yaml_norays", 202)])
 def test_strip_contexts_reproduce_single_context(world, cfg_name, C, weights):
     import torch
     from elevation_mapping_cupy_amd.configs import parameter_from
     from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
     from elevation_mapping_cupy_amd.sharded import HipStripEngine, ShardedElevationMap
     from oracle import emap_oracle as eo
-    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML if cfg_name == "yaml" else {})
-    N = 30000
+    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML if cfg_name.startswith("yaml") else {})
+    if cfg_name.endswith("norays"):
+        cfg["enable_visibility_cleanup"] = False
+    N = 40000
     R, t = fx.POSES["rotated"]
     clouds = [fx.cloud(C, N, f, dz=dz) for f, dz in enumerate((0.0, -0.02, -0.1))]
     full = ElevationMap(parameter_from(cfg, C, "reference_fp16", weights))

@@ -48,6 +48,7 @@ class OracleStripEngine:
         self.om.gate(pn, on)
 
     def fuse(self, R, t): self.om.fuse(self.p, R, t)
+    def fuse_average(self, R, t): self.om.fuse(self.p, R, t); self.om.commit(); self.om.average()
     def commit(self): self.om.commit()
     def rays(self, R, t): self.om.rays(self.p, R, t)
     def average(self): self.om.average()
@@ -66,7 +67,9 @@ class OracleStripEngine:
         if have_hi:
             m[:, self.r1:self.r1 + H] = self.recv[1].numpy()
 
-    def post(self): self.om.dilate(); self.om.traversability(); self.om.normals()
+    def post(self, part=0):
+        if part != 1:          # the oracle has no tile split: everything happens in the "boundary" call
+            self.om.dilate(); self.om.traversability(); self.om.normals()
     def update_time(self): self.om.update_time()
 
 
@@ -78,7 +81,9 @@ def _worker(rank, world, port, outdir, cfg_name, C, N):
     from oracle import emap_oracle as eo
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cfg = dict(eo.YAML if cfg_name == "yaml" else eo.DEFAULTS)
+    cfg = dict(eo.YAML if cfg_name.startswith("yaml") else eo.DEFAULTS)
+    if cfg_name.endswith("norays"):
+        cfg["enable_visibility_cleanup"] = False
     w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz")); weights = {k: w[k] for k in w.files}
     eng = OracleStripEngine(cfg, C, rank, world, weights)
     sm = ShardedElevationMap(eng, TorchComm(None), cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
@@ -94,14 +99,16 @@ def _worker(rank, world, port, outdir, cfg_name, C, N):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cfg_name,C,N", [(2, "yaml", 130, 20000), (3, "default", 98, 12000)])
+@pytest.mark.parametrize("world,cfg_name,C,N", [(2, "yaml", 130, 20000), (3, "default", 98, 12000), (2, "yaml_norays", 130, 20000)])
 def test_strips_equal_single_process(world, cfg_name, C, N, weights):
     import torch.multiprocessing as mp
     import _fixtures as fx
     from oracle import emap_oracle as eo
     outdir = tempfile.mkdtemp()
     mp.spawn(_worker, args=(world, _free_port(), outdir, cfg_name, C, N), nprocs=world, join=True)
-    cfg = dict(eo.YAML if cfg_name == "yaml" else eo.DEFAULTS)
+    cfg = dict(eo.YAML if cfg_name.startswith("yaml") else eo.DEFAULTS)
+    if cfg_name.endswith("norays"):
+        cfg["enable_visibility_cleanup"] = False
     eo.lib().eo_set_strip(0, 1 << 30)
     ref = eo.OracleMap(eo.make_params(cfg, cell_n=C, weights=weights))
     R, t = fx.POSES["rotated"]
