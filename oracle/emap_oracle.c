@@ -109,6 +109,25 @@ static inline int is_valid(const eo_params* P, float x_, float y_, float z_, flo
 
 typedef struct { float x, y, z, v; int idx, valid, inside, finite; } pt_t;
 
+/* Optional OpenMP parallelism over points / cells for bench.py's cpu_baseline leg ("all cores"): eo_set_threads(n).
+ * With n == 1 (default; what every parity test uses) execution is sequential and bit-reproducible; with n > 1 the
+ * accumulators are updated atomically (double adds in arbitrary order => last-bit differences, same contract). */
+static int g_threads = 1;
+void eo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+static inline void atomic_add_f64(double* p, double v) {
+  uint64_t* u = (uint64_t*)p; uint64_t old = __atomic_load_n(u, __ATOMIC_RELAXED), neu;
+  do { double d; memcpy(&d, &old, 8); d += v; memcpy(&neu, &d, 8); } while (!__atomic_compare_exchange_n(u, &old, neu, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
+static inline void atomic_max_u64(uint64_t* p, uint64_t v) {
+  uint64_t old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+static inline void atomic_min_f32(float* p, float v) {   /* plain float min via CAS on the bit pattern */
+  uint32_t* u = (uint32_t*)p; uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED);
+  for (;;) { float f; memcpy(&f, &old, 4); if (!(v < f)) return; uint32_t nv; memcpy(&nv, &v, 4);
+             if (__atomic_compare_exchange_n(u, &old, nv, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return; }
+}
+
 /* Row-strip view used by the multi-process (gloo) sharding tests: point / ray stages only touch cells whose row
  * (ix = idx / C) lies in [g_row0, g_row1).  Default = whole map. */
 static int g_row0 = 0, g_row1 = 0x7fffffff;
@@ -143,18 +162,21 @@ void eo_point_index(const eo_params* P, const float* pts, long n, long stride, c
 void eo_count(const eo_params* P, const float* map, const float* pts, long n, long stride, const float* R,
               const float* t, uint32_t* n_pts, uint32_t* n_inl, double* err_sum, uint32_t* err_cnt) {
   const long L = (long)P->cell_n * P->cell_n;
+  double es = 0.0; unsigned long ec = 0;
+#pragma omp parallel for num_threads(g_threads) reduction(+ : es, ec) schedule(static) if (g_threads > 1)
   for (long i = 0; i < n; ++i) {
     pt_t g = point_geometry(P, pts + i * stride, R, t);
     if (!g.finite || !g.valid || !g.inside || !owned(P, g.idx)) continue;
     float h = map[g.idx], v = map[L + g.idx], valid = map[2 * L + g.idx], trav = map[3 * L + g.idx];
     if (valid > 0.5f && (double)fabsf(h - g.z) < (double)v * P->mahalanobis_thresh &&
         (double)v < P->drift_compensation_variance_inlier / 2.0 && (double)trav > P->traversability_inlier) {
-      *err_sum += (double)(g.z - h);
-      *err_cnt += 1;
-      n_inl[g.idx] += 1;
+      es += (double)(g.z - h);
+      ec += 1;
+      __atomic_fetch_add(&n_inl[g.idx], 1u, __ATOMIC_RELAXED);
     }
-    n_pts[g.idx] += 1;
+    __atomic_fetch_add(&n_pts[g.idx], 1u, __ATOMIC_RELAXED);
   }
+  *err_sum += es; *err_cnt += (uint32_t)ec;
 }
 
 /* Phase A': drift gate (elevation_mapping.py:346-357). Returns the shift to add to plane 0 (0 if none);
@@ -179,24 +201,46 @@ void eo_fuse(const eo_params* P, const float* map, const float* pts, long n, lon
              const float* t, const uint32_t* n_pts, double* sum_h, double* sum_v, uint32_t* cnt, uint32_t* n_out,
              float* latest_h) {
   const long L = (long)P->cell_n * P->cell_n;
+  if (g_threads <= 1) {
+    for (long i = 0; i < n; ++i) {
+      pt_t g = point_geometry(P, pts + i * stride, R, t);
+      if (!g.finite || !g.valid || !g.inside || !owned(P, g.idx)) continue;
+      float map_h = map[g.idx], map_v = map[L + g.idx], num_points = (float)n_pts[g.idx];
+      if ((double)fabsf(map_h - g.z) > (double)map_v * P->mahalanobis_thresh) { n_out[g.idx] += 1; continue; }
+      if (P->enable_edge_sharpen && (double)num_points > P->wall_num_thresh &&
+          (double)g.z < (double)map_h - (double)map_v * P->mahalanobis_thresh / (double)num_points) continue;
+      float new_h = (map_h * g.v + g.z * map_v) / (map_v + g.v);
+      float new_v = (map_v * g.v) / (map_v + g.v);
+      sum_h[g.idx] += (double)new_h; sum_v[g.idx] += (double)new_v; cnt[g.idx] += 1;
+      latest_h[g.idx] = new_h;
+    }
+    return;
+  }
+  uint64_t* key = calloc(L, 8);     /* ((i + 1) << 32) | bits(new_h): largest point index wins, as in the sequential loop */
+#pragma omp parallel for num_threads(g_threads) schedule(static)
   for (long i = 0; i < n; ++i) {
     pt_t g = point_geometry(P, pts + i * stride, R, t);
     if (!g.finite || !g.valid || !g.inside || !owned(P, g.idx)) continue;
     float map_h = map[g.idx], map_v = map[L + g.idx], num_points = (float)n_pts[g.idx];
-    if ((double)fabsf(map_h - g.z) > (double)map_v * P->mahalanobis_thresh) { n_out[g.idx] += 1; continue; }
+    if ((double)fabsf(map_h - g.z) > (double)map_v * P->mahalanobis_thresh) { __atomic_fetch_add(&n_out[g.idx], 1u, __ATOMIC_RELAXED); continue; }
     if (P->enable_edge_sharpen && (double)num_points > P->wall_num_thresh &&
         (double)g.z < (double)map_h - (double)map_v * P->mahalanobis_thresh / (double)num_points) continue;
     float new_h = (map_h * g.v + g.z * map_v) / (map_v + g.v);
     float new_v = (map_v * g.v) / (map_v + g.v);
-    sum_h[g.idx] += (double)new_h; sum_v[g.idx] += (double)new_v; cnt[g.idx] += 1;
-    latest_h[g.idx] = new_h;
+    atomic_add_f64(&sum_h[g.idx], (double)new_h); atomic_add_f64(&sum_v[g.idx], (double)new_v);
+    __atomic_fetch_add(&cnt[g.idx], 1u, __ATOMIC_RELAXED);
+    atomic_max_u64(&key[g.idx], ((uint64_t)(i + 1) << 32) | f2u(new_h));
   }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long c = 0; c < L; ++c) if (key[c]) latest_h[c] = u2f((uint32_t)key[c]);
+  free(key);
 }
 
 /* Phase B': per-cell commit of the fuse side effects -> snapshot S1 */
 void eo_commit(const eo_params* P, float* map, const uint32_t* cnt, const uint32_t* n_out, const float* latest_h) {
   const long L = (long)P->cell_n * P->cell_n;
   const float ov = (float)P->outlier_variance;
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
   for (long c = 0; c < L; ++c) {
     if (n_out[c]) map[L + c] = map[L + c] + ov * (float)n_out[c];
     if (cnt[c]) { map[2 * L + c] = 1.0f; map[4 * L + c] = 0.0f; map[5 * L + c] = latest_h[c]; map[6 * L + c] = 0.0f; }
@@ -211,6 +255,8 @@ void eo_rays(const eo_params* P, const float* map, const float* normal, const ui
              float* ray_upper, uint64_t* visits_out) {
   const long L = (long)P->cell_n * P->cell_n;
   uint64_t visits = 0;
+  const int mt = g_threads > 1;
+#pragma omp parallel for num_threads(g_threads) reduction(+ : visits) schedule(dynamic, 256) if (g_threads > 1)
   for (long i = 0; i < n; ++i) {
     pt_t g = point_geometry(P, pts + i * stride, R, t);
     if (!g.finite || !g.valid) continue; /* invalid points march but never act (:226) */
@@ -234,7 +280,7 @@ void eo_rays(const eo_params* P, const float* map, const float* normal, const ui
       float d = Q((g.x - nx) * (g.x - nx) + (g.y - ny) * (g.y - ny) + (g.z - nz) * (g.z - nz));
       if ((double)d < 0.1) continue;
       if (valid < 0.5f) {
-        if (nz < upper || is_upper < 0.5f) { if (nz < ray_upper[nidx]) ray_upper[nidx] = nz; }
+        if (nz < upper || is_upper < 0.5f) { if (mt) atomic_min_f32(&ray_upper[nidx], nz); else if (nz < ray_upper[nidx]) ray_upper[nidx] = nz; }
         continue;
       }
       if (time < 0.5f) continue;
@@ -242,9 +288,10 @@ void eo_rays(const eo_params* P, const float* map, const float* normal, const ui
         float ip = Q(rx) * Q(normal[nidx]) + Q(ry) * Q(normal[L + nidx]) + Q(rz) * Q(normal[2 * L + nidx]);
         if ((double)fabsf(ip) < P->cleanup_cos_thresh) continue;
         if ((double)(float)n_inl[nidx] > P->wall_num_thresh && (double)time < 1.0) continue;
-        ray_dec[nidx] += (double)(float)(-P->cleanup_step / ((double)ray_length / P->max_ray_length));
-        ray_hits[nidx] += 1;
-        if (nz < upper || is_upper < 0.5f) { if (nz < ray_upper[nidx]) ray_upper[nidx] = nz; }
+        const double dec = (double)(float)(-P->cleanup_step / ((double)ray_length / P->max_ray_length));
+        if (mt) { atomic_add_f64(&ray_dec[nidx], dec); __atomic_fetch_add(&ray_hits[nidx], 1u, __ATOMIC_RELAXED); }
+        else { ray_dec[nidx] += dec; ray_hits[nidx] += 1; }
+        if (nz < upper || is_upper < 0.5f) { if (mt) atomic_min_f32(&ray_upper[nidx], nz); else if (nz < ray_upper[nidx]) ray_upper[nidx] = nz; }
       }
     }
   }
@@ -256,6 +303,7 @@ void eo_average(const eo_params* P, float* map, const double* sum_h, const doubl
                 const double* ray_dec, const uint32_t* ray_hits, const float* ray_upper) {
   const long L = (long)P->cell_n * P->cell_n;
   const float ov = (float)P->outlier_variance;
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
   for (long c = 0; c < L; ++c) {
     if (ray_hits && ray_hits[c]) {
       map[2 * L + c] = map[2 * L + c] + (float)ray_dec[c];
@@ -292,6 +340,7 @@ void eo_overlap_clear(const eo_params* P, float* map, float tz) {
 /* dilation_filter_kernel (custom_kernels.py:392-449) incl. flat-index row wrap and signed dx+dy */
 void eo_dilate(int C, int d, const float* plane, const float* mask, float* out, float* outmask) {
   const long L = (long)C * C;
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
   for (long i = 0; i < L; ++i) {
     out[i] = plane[i];
     if (mask[i] < 0.5f) {
@@ -313,6 +362,7 @@ void eo_dilate(int C, int d, const float* plane, const float* mask, float* out, 
 void eo_traversability(const eo_params* P, const float* in, float* trav_plane) {
   const int C = P->cell_n;
   const float* w[3] = {P->w1, P->w2, P->w3};
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
   for (int r = 3; r < C - 3; ++r) for (int c = 3; c < C - 3; ++c) {
     float acc = 0.0f;
     for (int k = 0; k < 3; ++k) { const int dl = k + 1;
@@ -331,6 +381,7 @@ void eo_normals(const eo_params* P, const float* plane, const float* valid, floa
   const int C = P->cell_n; const long L = (long)C * C;
   memset(out, 0, sizeof(float) * 3 * L);
   const float res = (float)P->resolution;
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
   for (long i = 0; i < L; ++i) {
     if (!(valid[i] > 0.5f)) continue;
     long a = i + 1, b = i + C;
@@ -444,7 +495,10 @@ void eo_frame(const eo_params* P, float* map, float* normal, float* trav_input, 
   memset(st, 0, sizeof *st);
   eo_count(P, map, pts, n, stride, R, t, n_pts, n_inl, &st->err_sum, &st->err_cnt);
   st->shift = eo_gate(P, st->err_sum, st->err_cnt, position_noise, orientation_noise, &st->mean_error, &st->gate_fired);
-  if (st->shift != 0.0f) for (long c = 0; c < L; ++c) map[c] += st->shift;
+  if (st->shift != 0.0f) {
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
+    for (long c = 0; c < L; ++c) map[c] += st->shift;
+  }
   eo_fuse(P, map, pts, n, stride, R, t, n_pts, sum_h, sum_v, cnt, n_out, latest);
   eo_commit(P, map, cnt, n_out, latest);
   double* ray_dec = NULL; uint32_t* ray_hits = NULL; float* ray_upper = NULL;
@@ -456,6 +510,7 @@ void eo_frame(const eo_params* P, float* map, float* normal, float* trav_input, 
   eo_average(P, map, sum_h, sum_v, cnt, ray_dec, ray_hits, ray_upper);
   if (P->enable_overlap_clearance) eo_overlap_clear(P, map, t[2]);
   float* mask = malloc(L * 4);
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
   for (long c = 0; c < L; ++c) mask[c] = map[2 * L + c] + map[6 * L + c];
   memset(trav_input, 0, L * 4);
   eo_dilate(C, P->dilation_size, map + 5 * L, mask, trav_input, NULL);

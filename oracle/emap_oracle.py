@@ -63,7 +63,7 @@ YAML = dict(
 def build(force=False):
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-std=c11", "-shared", "-fPIC",
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", "-std=c11", "-shared", "-fPIC",
                                _SRC, "-o", _SO, "-lm"])
     return _SO
 
@@ -270,6 +270,11 @@ class OracleMap:
             self.mean_error = np.float32(st.mean_error)
             self.additive_mean_error = np.float32(self.additive_mean_error + np.float32(st.mean_error))
         return st
+
+
+def set_threads(n):
+    """OpenMP threads of the C oracle (1 = sequential, bit-reproducible: the setting every parity test uses)."""
+    lib().eo_set_threads(ct.c_int(int(n)))
 
 
 def dilate_plane(C, d, plane, mask):

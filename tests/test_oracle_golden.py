@@ -141,3 +141,20 @@ def test_semantic_fusion_against_reference_kernels():
     om.semantic_update(p, R, t, average=[(3, 0), (4, 1)], class_average=[(5, 2)], color=[(6, 3)], alpha=0.5)
     assert np.allclose(om.semantic_map[:3], g["sem"][:3], atol=1e-6, rtol=1e-6)
     assert np.array_equal(om.semantic_map[3].view(np.uint32), g["sem"][3].view(np.uint32))      # packed RGB: bit exact
+
+
+def test_openmp_baseline_mode_equals_sequential_oracle(weights):
+    """bench.py's cpu_baseline runs the C oracle with OpenMP threads; same contract, so the maps must agree."""
+    C, N = 130, 20000
+    R, t = fx.POSES["rotated"]
+    maps = {}
+    for nt in (1, 4):
+        eo.set_threads(nt)
+        om = eo.OracleMap(eo.make_params(eo.YAML, cell_n=C, weights=weights))
+        for f, dz in enumerate((0.0, -0.02, -0.2)):
+            om.frame_c(fx.cloud(C, N, f, dz=dz), R, t, 1.0, 1.0)
+            for _ in range(6):
+                om.update_time()
+        maps[nt] = (om.elevation_map.copy(), om.normal_map.copy())
+    eo.set_threads(1)
+    assert np.allclose(maps[1][0], maps[4][0], atol=1e-6, rtol=1e-6) and np.allclose(maps[1][1], maps[4][1], atol=1e-6)
