@@ -235,17 +235,30 @@ def main():
             for _ in range(8):
                 om.update_time()
             reps_cpu, t_cpu = 0, 0.0
-            while reps_cpu < 5 and t_cpu < 12.0:
+            while reps_cpu < 5 and t_cpu < 8.0:
                 s = time.perf_counter(); om.frame_c(clouds_host[(reps_cpu + 1) % NCLOUD][:n_cpu], R, t, 1.0, 1.0)
                 t_cpu += time.perf_counter() - s; reps_cpu += 1
             eo.set_threads(1)
             return n_cpu * reps_cpu / t_cpu / 1e6, reps_cpu
-        cores = os.cpu_count() or 1
-        v1, _ = cpu_rate(1)
-        vall, reps_cpu = cpu_rate(cores)
-        cpu = {"value": round(vall, 4), "unit": "Mpoints/s", "cores": cores, "kind": "port", "single_thread_value": round(v1, 4),
-               "sample": "%d frames of %d points on the %dx%d map (oracle/emap_oracle.c eo_frame, gcc -O2 -fopenmp, %d threads; "
-                         "single_thread_value = same on 1 thread)" % (reps_cpu, n_cpu, C, C, cores)}
+        def usable_cores():
+            n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            try:  # cgroup v2 CPU quota of the container
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+            except (OSError, ValueError):
+                pass
+            return n
+        avail = usable_cores()
+        v1, reps_cpu = cpu_rate(1)
+        best_v, best_n = v1, 1
+        for nthr in sorted({min(avail, 8), min(avail, 32), avail} - {1}):    # oversubscription hurts: keep the best setting
+            v, reps_cpu = cpu_rate(nthr)
+            if v > best_v:
+                best_v, best_n = v, nthr
+        cpu = {"value": round(best_v, 4), "unit": "Mpoints/s", "cores": best_n, "kind": "port", "single_thread_value": round(v1, 4),
+               "sample": "<=5 frames (<=8 s) of %d points on the %dx%d map, oracle/emap_oracle.c eo_frame (gcc -O2 -fopenmp); best of "
+                         "1/8/32/%d threads, %d usable cores (os.cpu_count() = %d)" % (n_cpu, C, C, avail, avail, os.cpu_count() or 1)}
 
     out = {
         "metric": "Mpoints/s fused (map-update p50 latency in config)", "value": round(mpts, 2), "unit": "Mpoints/s",
