@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--mode", default="reference_fp16", choices=["reference_fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--scatter", default="auto", choices=["auto", "atomic", "binned"])
+    ap.add_argument("--sort-clouds", default="none", choices=["none", "tile", "angle"],
+                    help="experiment: spatially coherent input order (real sensors deliver scan-ordered clouds)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-strip path even with one rank (self-test)")
     return ap.parse_args()
 
@@ -120,6 +123,7 @@ def main():
     par = parameter_from(cfg, C, a.mode, weights)
     par.device = local_rank
     emap = ElevationMap(par)
+    emap.set_scatter_mode(a.scatter)
     lib, ctx = emap._lib, emap._ctx
     hip = Hip(); hip.set_device(local_rank)
 
@@ -141,6 +145,14 @@ def main():
             raise RuntimeError(lib.emap_last_error(ctx).decode())
     else:
         clouds_host = [fx.cloud(C, N, s, dz=(0.0 if s == 0 else -0.02 * s)) for s in range(NCLOUD)]
+    if a.sort_clouds != "none":
+        for k_, p_ in enumerate(clouds_host):
+            if a.sort_clouds == "tile":
+                ix = np.clip((p_[:, 0] / 0.04 + C / 2).astype(np.int64), 0, C - 1); iy = np.clip((p_[:, 1] / 0.04 + C / 2).astype(np.int64), 0, C - 1)
+                key = (ix // 16) * (C // 64 + 1) * 4096 + (iy // 64) * 4096 + (ix % 16) * 64 + iy % 64
+            else:
+                key = np.arctan2(p_[:, 1], p_[:, 0])
+            clouds_host[k_] = np.ascontiguousarray(p_[np.argsort(key, kind="stable")])
     stride = clouds_host[0].shape[1]
     clouds_dev = []
     for p in clouds_host:

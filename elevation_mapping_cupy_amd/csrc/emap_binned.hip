@@ -15,7 +15,7 @@
 //                  the epilogue writes the 40-byte AccF records with plain coalesced stores.
 // Everything downstream (commit, rays, average, ...) is unchanged and the AccF contents are BIT-IDENTICAL to the
 // atomic path of emap_kernels.hip (integer / fixed-point accumulators are order independent), which stays as the
-// fallback for maps with more than 16384 tiles (> 4096^2 cells per context) and for small clouds.
+// fallback for maps with more than 16384 tiles (> 4096^2 cells per context) and for clouds below ~200 k points (two launches with atomics have the lower latency there).
 #include "emap_device.h"
 
 #define BIN_TR 16

@@ -460,10 +460,12 @@ __global__ __launch_bounds__(EM_BLOCK) void k_trav_normal(KP P, TravW Wt, const 
 // (value, mask) tile (+3+d halo) and consumed in place; `traversability_input` is still written (interior only)
 // because it is a readable attribute of the reference class.  Semantics identical to k_dilate + k_trav_normal.
 // ---------------------------------------------------------------------------------------------------------
-#define PT_R 16
 #define PT_C 64
 #define PT_THREADS 512   /* 8 waves per tile: the kernel is latency/issue bound, 32 resident waves per CU hide it */
 #define PT_WAVES (PT_THREADS / 64)
+// PT_R = tile height: 16 for large maps (less halo amplification), 4 for small maps (4x more workgroups: a robot-scale
+// 200^2 map has only 52 tiles of 16 rows and the kernel time is then one workgroup's latency chain).
+template <int PT_R>
 __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __restrict__ cells, float* __restrict__ trav_in,
                                                     float* __restrict__ normal, long plane_stride, int d, int tile_row0) {
   extern __shared__ float lds[];
@@ -517,8 +519,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
   const int col = tile_c + tc;
   if (col >= C) return;
 #pragma unroll
-  for (int k = 0; k < PT_R / PT_WAVES; ++k) {
+  for (int k = 0; k < (PT_R + PT_WAVES - 1) / PT_WAVES; ++k) {
     const int tr = wv + PT_WAVES * k, lr = tile_r + tr;
+    if (tr >= PT_R) break;
     if (lr >= P.halo + P.nrows) break;
     const int gr = lr - P.halo + P.row0;
     const long c = (long)lr * C + col;
@@ -700,14 +703,18 @@ void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, c
   TravW W;
   for (int i = 0; i < 36; ++i) { W.w[0][i] = w1[i]; W.w[1][i] = w2[i]; W.w[2][i] = w3[i]; }
   for (int i = 0; i < 12; ++i) W.wo[i] = wo[i];
-  const int all_rows = (P.nrows + PT_R - 1) / PT_R;
-  if (n_tile_rows < 0) { tile_row0 = 0; n_tile_rows = all_rows; }
+  // tile_row0 / n_tile_rows are given in units of 16 map rows (emap_post_part); small maps use 4-row tiles
+  const bool small = (long)P.nrows * P.C <= 512L * 512L;
+  const int R = small ? 4 : 16, per16 = 16 / R;
+  const int all_rows = (P.nrows + R - 1) / R;
+  if (n_tile_rows < 0) { tile_row0 = 0; n_tile_rows = all_rows; } else { tile_row0 *= per16; n_tile_rows *= per16; }
   if (tile_row0 < 0) tile_row0 = 0;
   if (tile_row0 + n_tile_rows > all_rows) n_tile_rows = all_rows - tile_row0;
   if (n_tile_rows <= 0) return;
   dim3 g((P.C + PT_C - 1) / PT_C, n_tile_rows), b(PT_THREADS);
-  size_t lds = sizeof(float) * ((size_t)2 * (PT_R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)(PT_R + 6) * (PT_C + 6 + 1) + (size_t)PT_R * PT_C);
-  hipLaunchKernelGGL(k_post, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
+  size_t lds = sizeof(float) * ((size_t)2 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)(R + 6) * (PT_C + 6 + 1) + (size_t)R * PT_C);
+  if (small) hipLaunchKernelGGL(k_post<4>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
+  else hipLaunchKernelGGL(k_post<16>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
 }
 void launch_var_time(hipStream_t s, const KP& P, Cell* cells, int do_var, int do_time) {
   hipLaunchKernelGGL(k_var_time, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, do_var, do_time);

@@ -108,7 +108,7 @@ int emap_set_drift_inputs(emap_ctx* ctx, double position_noise, double orientati
 int emap_drift_sums_to_device(emap_ctx* ctx, double* dev_out2);
 int emap_set_drift_inputs_device(emap_ctx* ctx, double position_noise, double orientation_noise, const double* dev_totals2);
 int emap_local_drift_sums(emap_ctx* ctx, double* err_sum, uint32_t* err_cnt);
-/* how the count/fuse passes scatter into the map: 0 = auto (tile-binned LDS reduction for clouds >= 32768 points on maps
+/* how the count/fuse passes scatter into the map: 0 = auto (tile-binned LDS reduction for clouds >= 196608 points on maps
  * with <= 16384 tiles of 16x64 cells, else global atomics), 1 = global atomics, 2 = tile-binned. Results are bit-identical. */
 int emap_set_scatter_mode(emap_ctx* ctx, int32_t mode);
 int emap_fuse(emap_ctx* ctx, const float R[9], const float t[3]);           /* add_points_kernel fusion part */
