@@ -32,6 +32,7 @@ void launch_trav_normal(hipStream_t, const KP&, const float*, const float*, cons
 void launch_var_time(hipStream_t, const KP&, Cell*, int, int);
 void launch_post(hipStream_t, const KP&, const float*, const float*, const float*, const float*, Cell*, float*, float*, long, int, int, int);
 void launch_get_plane(hipStream_t, const KP&, const Cell*, int, float*);
+void launch_publish(hipStream_t, const KP&, const Cell*, const float*, long, int, float, int, float*);
 void launch_set_plane(hipStream_t, const KP&, Cell*, int, const float*);
 void launch_fill_cells(hipStream_t, Cell*, long, const Cell&);
 void launch_f64_to_f32(hipStream_t, const double*, float*, long);
@@ -686,6 +687,18 @@ int emap_get_layer(emap_ctx* ctx, int plane, float* host_out) {
     CK(hipGetLastError());
     CK(hipMemcpyAsync(host_out, ctx->scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
   } else CK(hipMemcpyAsync(host_out, plane_ptr(ctx, plane), bytes, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
+  return EMAP_OK;
+}
+
+int emap_publish_layer(emap_ctx* ctx, int32_t kind, float center_z, int32_t use_only_above_for_upper_bound, float* host_out) {
+  CKARG(ctx && host_out && kind >= 0 && kind <= 8, "bad argument");
+  CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "emap_publish_layer: single-strip contexts only");
+  CK(hipSetDevice(ctx->device));
+  const long M = ctx->prm.cell_n - 2;
+  launch_publish(ctx->stream, ctx->kp, ctx->cells, ctx->normal, ctx->ncells_alloc, kind, center_z, use_only_above_for_upper_bound, ctx->scratch);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(host_out, ctx->scratch, sizeof(float) * (size_t)(M * M), hipMemcpyDeviceToHost, ctx->stream));
   CK(hipStreamSynchronize(ctx->stream));
   return EMAP_OK;
 }

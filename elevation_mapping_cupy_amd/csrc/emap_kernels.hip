@@ -564,6 +564,37 @@ __global__ __launch_bounds__(EM_BLOCK) void k_var_time(KP P, Cell* __restrict__ 
   if (do_time) m->time = m->time + P.time_int;
 }
 
+// ---- layer read-back for publishing (get_map_with_name_ref, elevation_mapping.py:579-775): border stripped, both axes
+// flipped, NaN for unknown cells, +center_z for height layers -- one kernel + one D2H instead of several host passes.
+// kind: 0 elevation, 1 variance, 2 traversability, 3 time, 4 upper_bound, 5 is_upper_bound, 6..8 normal x/y/z
+__global__ __launch_bounds__(EM_BLOCK) void k_publish(KP P, const Cell* __restrict__ cells, const float* __restrict__ normal,
+                                                       long plane_stride, int kind, float center_z, int only_above,
+                                                       float* __restrict__ out) {
+  const int C = P.C, M = C - 2;
+  long k = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (k >= (long)M * M) return;
+  const int orow = (int)(k / M), ocol = (int)(k % M);
+  const int r = M - orow, c = M - ocol;                 // flip of the [1:-1, 1:-1] view: source cell (r, c) in [1, C-2]
+  const long ci = (long)(r + P.halo) * C + c;
+  const float nanv = __uint_as_float(0x7fc00000u);
+  float v;
+  if (kind >= 6) v = normal[(long)(kind - 6) * plane_stride + ci];
+  else {
+    const Cell m = cells[ci];
+    switch (kind) {
+      case 0: v = m.valid > 0.5f ? m.h + center_z : nanv; break;
+      case 1: v = m.v; break;
+      case 2: v = (r >= 3 && r <= C - 4 && c >= 3 && c <= C - 4 && (m.valid + m.is_upper) > 0.5f) ? m.trav : nanv; break;
+      case 3: v = m.time; break;
+      default: {
+        const bool ok = only_above ? ((m.upper > 0.0f && m.is_upper > 0.5f) || m.valid > 0.5f) : (m.valid > 0.5f || m.is_upper > 0.5f);
+        v = ok ? (kind == 4 ? m.upper + center_z : m.is_upper) : nanv;
+      }
+    }
+  }
+  out[k] = v;
+}
+
 // ---- state access helpers --------------------------------------------------------------------------------
 __global__ __launch_bounds__(EM_BLOCK) void k_get_plane(KP P, const Cell* __restrict__ cells, int word, float* __restrict__ out) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
@@ -718,6 +749,11 @@ void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, c
 }
 void launch_var_time(hipStream_t s, const KP& P, Cell* cells, int do_var, int do_time) {
   hipLaunchKernelGGL(k_var_time, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, do_var, do_time);
+}
+void launch_publish(hipStream_t s, const KP& P, const Cell* cells, const float* normal, long plane_stride, int kind, float center_z,
+                    int only_above, float* out) {
+  const long M = P.C - 2;
+  hipLaunchKernelGGL(k_publish, dim3(nblk(M * M)), dim3(EM_BLOCK), 0, s, P, cells, normal, plane_stride, kind, center_z, only_above, out);
 }
 void launch_get_plane(hipStream_t s, const KP& P, const Cell* cells, int word, float* out) {
   hipLaunchKernelGGL(k_get_plane, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, word, out);

@@ -345,6 +345,14 @@ class ElevationMap:
     def get_map_with_name_ref(self, name, data):
         """Fill ``data`` (float32, ``(cell_n-2, cell_n-2)``) in place: border stripped, both axes flipped
         (reference :720-775)."""
+        builtin = {"elevation": 0, "variance": 1, "traversability": 2, "time": 3, "upper_bound": 4, "is_upper_bound": 5,
+                   "normal_x": 6, "normal_y": 7, "normal_z": 8}
+        if name in builtin and self._strip is None and isinstance(data, np.ndarray) and data.dtype == np.float32 \
+                and data.flags["C_CONTIGUOUS"] and data.shape == (self.cell_n - 2, self.cell_n - 2):
+            with self.map_lock:   # strip / NaN fill / +center_z / double flip happen in one device kernel
+                self._chk(self._lib.emap_publish_layer(self._ctx, builtin[name], ct.c_float(float(self.center[2])),
+                                                       int(bool(self.param.use_only_above_for_upper_bound)), f32p(data)))
+            return
         with self.map_lock:
             if name == "elevation":
                 m = self._publish(self.get_layer_raw(0), True, True, self.get_layer_raw(2))

@@ -129,6 +129,10 @@ int emap_get_stats(emap_ctx* ctx, emap_stats* out);                         /* b
 /* ---- state access (elevation_map attribute / get_map_with_name_ref's raw planes; test state injection) */
 int emap_get_layer(emap_ctx* ctx, int plane, float* host_out /* (row_count, cell_n) */);
 int emap_set_layer(emap_ctx* ctx, int plane, const float* host_in);
+/* ElevationMap.get_map_with_name_ref for the built-in layers (EM/elevation_mapping.py:579-775): fills a C-order
+ * (cell_n-2, cell_n-2) buffer: border stripped, both axes flipped, NaN for unknown cells, +center_z for heights.
+ * kind: 0 elevation, 1 variance, 2 traversability, 3 time, 4 upper_bound, 5 is_upper_bound, 6..8 normal_x/y/z */
+int emap_publish_layer(emap_ctx* ctx, int32_t kind, float center_z, int32_t use_only_above_for_upper_bound, float* host_out);
 /* ElevationMap.shift_map_xy / shift_map_z (EM/elevation_mapping.py:200-226): roll by (dx rows, dy cols) with
  * padding (0; variance plane initial_variance), planes 0 and 5 += dz. Single-strip contexts only. */
 int emap_shift(emap_ctx* ctx, int32_t shift_rows, int32_t shift_cols, float dz);

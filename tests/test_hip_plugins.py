@@ -68,3 +68,36 @@ disabled_one:
     elev = np.zeros((C - 2, C - 2), np.float32)
     hip.get_map_with_name_ref("elevation", elev)
     assert np.isnan(elev).sum() == int((e[2][1:-1, 1:-1] <= 0.5).sum())
+
+
+@pytest.mark.parametrize("only_above", [True, False])
+def test_device_side_layer_readback_matches_reference_postprocessing(only_above):
+    """emap_publish_layer vs a NumPy restatement of get_map_with_name_ref (elevation_mapping.py:579-775)."""
+    C = 98
+    hip, _ = make_pair(dict(eo.YAML, enable_visibility_cleanup=True), C)
+    hip.param.use_only_above_for_upper_bound = only_above
+    R, t = fx.POSES["rotated"]
+    for f in range(2):
+        hip.input_pointcloud(fx.cloud(C, 4000, f, dz=-0.1 * f), ["x", "y", "z"], R, t.copy(), 0.0, 0.0)
+        for _ in range(6):
+            hip.update_time()
+    hip.move_to(np.array([0.0, 0.0, 0.3], np.float32), np.eye(3))
+    e, n, cz = hip.elevation_map, hip.normal_map, hip.center[2]
+    if only_above:
+        ub_ok = ((e[5] > 0.0) & (e[6] > 0.5)) | (e[2] > 0.5)
+    else:
+        ub_ok = (e[2] > 0.5) | (e[6] > 0.5)
+    trav = np.full((C, C), np.nan, np.float32)
+    trav[3:-3, 3:-3] = np.where((e[2] + e[6]) > 0.5, e[3], np.nan)[3:-3, 3:-3]
+    want = {
+        "elevation": np.where(e[2] > 0.5, e[0], np.nan) + cz, "variance": e[1], "time": e[4], "traversability": trav,
+        "upper_bound": np.where(ub_ok, e[5], np.nan) + cz, "is_upper_bound": np.where(ub_ok, e[6], np.nan),
+        "normal_x": n[0], "normal_y": n[1], "normal_z": n[2],
+    }
+    for name, w in want.items():
+        out = np.zeros((C - 2, C - 2), np.float32)
+        hip.get_map_with_name_ref(name, out)
+        assert np.allclose(out, np.flip(w[1:-1, 1:-1]).astype(np.float32), equal_nan=True, atol=1e-6), name
+        out64 = np.zeros((C - 2, C - 2), np.float64)       # non-float32 buffers take the host path
+        hip.get_map_with_name_ref(name, out64)
+        assert np.allclose(out64, out, equal_nan=True), name
