@@ -25,6 +25,7 @@ static_assert(sizeof(SemSpec) == sizeof(emap_sem_spec), "emap_sem_spec layout");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
 void launch_sem_finalize(hipStream_t, const KP&, const SemSpec&, const unsigned int*, double*, unsigned int*, float*, long);
 void launch_sem_shift(hipStream_t, int, int, const float*, float*, int, int);
+void launch_inpaint_sweep(hipStream_t, int, const float*, const float*, float*, float*, const unsigned int*, unsigned int*);
 void launch_min_sweep(hipStream_t, int, int, const float*, const float*, const float*, float*, float*, const unsigned int*, unsigned int*);
 void launch_overlap(hipStream_t, const KP&, Cell*, int, int, float, float);
 void launch_dilate(hipStream_t, const KP&, const Cell*, float*, int, int, int);
@@ -835,6 +836,36 @@ int emap_min_filter(emap_ctx* ctx, const float* host_elevation, const float* hos
   if (rc != EMAP_OK) return rc;
   for (size_t i = 0; i < L; ++i) if (!(mask[i] > 0.5f)) host_out[i] = NAN;     // cp.where(mask > 0.5, filtered, nan), :116
   if (sweeps_run) { int n = 0; for (int k = 0; k < iteration_n; ++k) { ++n; if (hc[k] == 0) break; } *sweeps_run = n; }
+  return EMAP_OK;
+}
+
+// ---- Inpainting plugin substitute (see emap_semantic.hip): fill the pixels with known == 0 of an 8-bit image ---------
+int emap_inpaint_u8(emap_ctx* ctx, const float* host_image, const float* host_known, int32_t max_sweeps, float* host_out,
+                    int32_t* sweeps_run) {
+  CKARG(ctx && host_image && host_known && host_out && max_sweeps >= 0 && max_sweeps <= 65536, "bad argument");
+  CK(hipSetDevice(ctx->device));
+  const int C = ctx->prm.cell_n; const size_t L = (size_t)C * C, bytes = L * sizeof(float);
+  float* buf = nullptr; unsigned int* cnt = nullptr;
+  CK(hipMalloc((void**)&buf, bytes * 4));
+  if (hipMalloc((void**)&cnt, sizeof(unsigned int) * (max_sweeps + 1)) != hipSuccess) { hipFree(buf); ctx->err = "hipMalloc"; return EMAP_ERR_HIP; }
+  float *v0 = buf, *m0 = buf + L, *v1 = buf + 2 * L, *m1 = buf + 3 * L;
+  int rc = EMAP_OK;
+  auto ck = [&](hipError_t e) { if (e != hipSuccess && rc == EMAP_OK) { rc = EMAP_ERR_HIP; ctx->err = hipGetErrorString(e); } };
+  ck(hipMemcpyAsync(v0, host_image, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ck(hipMemcpyAsync(m0, host_known, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ck(hipMemsetAsync(cnt, 0, sizeof(unsigned int) * (max_sweeps + 1), ctx->stream));
+  for (int k = 0; k < max_sweeps && rc == EMAP_OK; ++k) {
+    launch_inpaint_sweep(ctx->stream, C, (k & 1) ? v1 : v0, (k & 1) ? m1 : m0, (k & 1) ? v0 : v1, (k & 1) ? m0 : m1,
+                         k > 0 ? cnt + (k - 1) : nullptr, cnt + k);
+    ck(hipGetLastError());
+  }
+  std::vector<unsigned int> hc(max_sweeps + 1);
+  ck(hipMemcpyAsync(host_out, (max_sweeps & 1) ? v1 : v0, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ck(hipMemcpyAsync(hc.data(), cnt, sizeof(unsigned int) * (max_sweeps + 1), hipMemcpyDeviceToHost, ctx->stream));
+  ck(hipStreamSynchronize(ctx->stream));
+  hipFree(buf); hipFree(cnt);
+  if (rc != EMAP_OK) return rc;
+  if (sweeps_run) { int n = 0; for (int k = 0; k < max_sweeps; ++k) { ++n; if (hc[k] == 0) break; } *sweeps_run = n; }
   return EMAP_OK;
 }
 

@@ -177,3 +177,43 @@ void launch_min_sweep(hipStream_t s, int C, int d, const float* orig_mask, const
   size_t lds = (size_t)2 * (MF_R + 2 * d) * (MF_C + 2 * d + 1) * sizeof(float);
   hipLaunchKernelGGL(k_min_sweep, g, b, lds, s, C, d, orig_mask, val, msk, oval, omsk, prev_unfilled, unfilled);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Inpainting plugin substitute.  The reference (EM/plugins/inpainting.py:53-61) quantises the elevation to 8 bits and
+// calls OpenCV's cv2.inpaint(h, mask, 1, INPAINT_TELEA) -- a serial fast-marching method from an unpinned third-party
+// library that is not available here and whose values no reference test pins.  DOCUMENTED SUBSTITUTE:
+// the same mask / 8-bit semantics, the hole filled front-by-front from its boundary (the marching order of FMM) with
+// the distance-weighted mean of the already known 8-neighbours (weights 1, 1/sqrt2), rounded to 8 bits like OpenCV's
+// uchar output.  One Jacobi sweep per front layer, double buffered, device-side early exit.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EM_BLOCK) void k_inpaint_sweep(int C, const float* __restrict__ val, const float* __restrict__ msk,
+                                                             float* __restrict__ oval, float* __restrict__ omsk,
+                                                             const unsigned int* __restrict__ prev_unfilled, unsigned int* __restrict__ unfilled) {
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  const bool frozen = prev_unfilled && *prev_unfilled == 0u;
+  unsigned int open_cell = 0;
+  if (i < (long)C * C) {
+    float v = val[i], m = msk[i];
+    if (!frozen && m < 0.5f) {
+      const int r = (int)(i / C), c = (int)(i % C);
+      float s = 0.f, w = 0.f;
+      for (int dr = -1; dr <= 1; ++dr)
+        for (int dc = -1; dc <= 1; ++dc) {
+          if (!dr && !dc) continue;
+          const int rr = r + dr, cc = c + dc;
+          if (rr < 0 || rr >= C || cc < 0 || cc >= C) continue;
+          const long j = (long)rr * C + cc;
+          if (msk[j] > 0.5f) { const float wt = (dr && dc) ? 0.70710678f : 1.0f; s += wt * val[j]; w += wt; }
+        }
+      if (w > 0.f) { v = fminf(fmaxf(rintf(s / w), 0.f), 255.f); m = 1.f; }
+    }
+    oval[i] = v; omsk[i] = m;
+    open_cell = !(m > 0.5f);
+  }
+  open_cell = (unsigned int)wave_sum_ll((long long)open_cell);
+  if ((threadIdx.x & 63) == 0 && open_cell) atomicAdd(unfilled, open_cell);
+}
+void launch_inpaint_sweep(hipStream_t s, int C, const float* val, const float* msk, float* oval, float* omsk,
+                          const unsigned int* prev_unfilled, unsigned int* unfilled) {
+  hipLaunchKernelGGL(k_inpaint_sweep, dim3(nblk_((long)C * C)), dim3(EM_BLOCK), 0, s, C, val, msk, oval, omsk, prev_unfilled, unfilled);
+}

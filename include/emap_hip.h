@@ -157,6 +157,12 @@ int emap_semantic_clear(emap_ctx* ctx);                                        /
 int emap_min_filter(emap_ctx* ctx, const float* host_elevation, const float* host_valid, int32_t dilation_size,
                     int32_t iteration_n, float* host_out, int32_t* sweeps_run_or_null);
 
+/* Inpainting plugin (EM/plugins/inpainting.py:53-61) -- DOCUMENTED SUBSTITUTE for the OpenCV Telea call it makes: fills
+ * the pixels with known == 0 of a (cell_n, cell_n) image holding 8-bit values, front by front, with the distance-weighted
+ * mean of the known 8-neighbours. Values stay in [0, 255], integers. */
+int emap_inpaint_u8(emap_ctx* ctx, const float* host_image, const float* host_known, int32_t max_sweeps, float* host_out,
+                    int32_t* sweeps_run_or_null);
+
 /* ---- row-strip halos (multi-GPU; exchange itself is done by the caller, e.g. torch.distributed/RCCL) ---- */
 /* pack `halo_rows` owned boundary rows (32-byte cells) next to the lower (side 0) / upper (side 1) neighbour
  * into a device buffer; unpack a neighbour's rows into the halo. Buffers: halo_rows*cell_n*8 floats. */

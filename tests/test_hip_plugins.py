@@ -101,3 +101,29 @@ def test_device_side_layer_readback_matches_reference_postprocessing(only_above)
         out64 = np.zeros((C - 2, C - 2), np.float64)       # non-float32 buffers take the host path
         hip.get_map_with_name_ref(name, out64)
         assert np.allclose(out64, out, equal_nan=True), name
+
+
+def test_inpainting_substitute_properties():
+    """OpenCV's Telea arithmetic is unpinned (absent third-party library); the substitute must satisfy what any
+    inpainting of the reference's 8-bit pipeline satisfies."""
+    from elevation_mapping_cupy_amd.plugins.inpainting import Inpainting
+    C = 130
+    hip, _ = make_pair(eo.DEFAULTS, C)
+    rng = np.random.default_rng(0)
+    xx, yy = np.meshgrid(np.arange(C), np.arange(C), indexing="ij")
+    e = np.zeros((7, C, C), np.float32)
+    e[0] = (0.5 * np.sin(xx / 17.0) + 0.3 * np.cos(yy / 11.0)).astype(np.float32)
+    e[2] = rng.uniform(0, 1, (C, C)) > 0.3
+    e[2][40:70, 50:90] = 0
+    e[0][e[2] < 0.5] = 0.0                                  # unknown cells hold garbage
+    ip = Inpainting(cell_n=C, emap=hip)
+    out = np.asarray(ip(e, hip.layer_names, None, []), np.float64)
+    known = e[2] >= 0.5
+    hmin, hmax = e[0][known].min(), e[0][known].max()
+    step = (hmax - hmin) / 255
+    assert np.isfinite(out).all()
+    assert np.abs(out[known] - e[0][known]).max() <= step + 1e-6            # 8-bit round trip on known cells
+    assert out.min() >= hmin - 1e-6 and out.max() <= hmax + 1e-6             # stays inside the range of the known data
+    truth = (0.5 * np.sin(xx / 17.0) + 0.3 * np.cos(yy / 11.0))
+    assert np.abs(out[~known] - truth[~known]).mean() < 0.05                 # and is a sensible reconstruction of the smooth surface
+    assert 1 <= ip.sweeps_run <= 40
