@@ -25,6 +25,9 @@ static_assert(sizeof(SemSpec) == sizeof(emap_sem_spec), "emap_sem_spec layout");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
 void launch_sem_finalize(hipStream_t, const KP&, const SemSpec&, const unsigned int*, double*, unsigned int*, float*, long);
 void launch_sem_shift(hipStream_t, int, int, const float*, float*, int, int);
+struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; };
+void launch_image_corr(hipStream_t, const KP&, const CamArgs&, const Cell*, float*, unsigned char*);
+void launch_image_fuse(hipStream_t, const KP&, int, float*, const float*, const float*, const unsigned char*, float, float, double);
 void launch_inpaint_sweep(hipStream_t, int, const float*, const float*, float*, float*, const unsigned int*, unsigned int*);
 void launch_min_sweep(hipStream_t, int, int, const float*, const float*, const float*, float*, float*, const unsigned int*, unsigned int*);
 void launch_overlap(hipStream_t, const KP&, Cell*, int, int, float, float);
@@ -74,6 +77,7 @@ struct emap_ctx {
   bool frame_binned;               // the count stage of the current frame used the binned path
   BinGeo bg; BinTmp* bin_tmp; BinRec* bin_recs; unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;
   // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
+  float* img_uv; unsigned char* img_valid; float* img_buf; size_t img_cap;   // camera path
   int sem_layers; float* sem; double* sem_sums; unsigned int* sem_col; unsigned int* cnt_plane;
   // point cloud
   float* pts_own; long pts_cap;    // owned buffer (floats)
@@ -233,6 +237,7 @@ int emap_destroy(emap_ctx* ctx) {
   hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->slots); hipFree(ctx->frame); hipFree(ctx->pts_own);
   hipFree(ctx->pts_f64); hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert);
   hipFree(ctx->bin_tmp); hipFree(ctx->bin_recs); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start);
+  hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   for (int i = 0; i <= ST_N; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   if (ctx->t0) hipEventDestroy(ctx->t0);
@@ -866,6 +871,52 @@ int emap_inpaint_u8(emap_ctx* ctx, const float* host_image, const float* host_kn
   hipFree(buf); hipFree(cnt);
   if (rc != EMAP_OK) return rc;
   if (sweeps_run) { int n = 0; for (int k = 0; k < max_sweeps; ++k) { ++n; if (hc[k] == 0) break; } *sweeps_run = n; }
+  return EMAP_OK;
+}
+
+// ---- camera path (EM/elevation_mapping.py:468-562, EM/kernels/custom_image_kernels.py) -------------------------------
+int emap_image_correspondence(emap_ctx* ctx, float x1, float y1, float z1, const float P[12], const float K[9], const float D[5],
+                              float image_height, float image_width, const float center[3]) {
+  CKARG(ctx && P && K && D && center, "null argument");
+  CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "camera path: single-strip contexts only");
+  CK(hipSetDevice(ctx->device));
+  const size_t L = (size_t)ctx->prm.cell_n * ctx->prm.cell_n;
+  if (!ctx->img_uv) { CK(hipMalloc((void**)&ctx->img_uv, sizeof(float) * 2 * L)); CK(hipMalloc((void**)&ctx->img_valid, L)); }
+  CamArgs A;
+  memcpy(A.P, P, sizeof A.P); memcpy(A.K, K, sizeof A.K); memcpy(A.D, D, sizeof A.D); memcpy(A.center, center, sizeof A.center);
+  A.x1 = x1; A.y1 = y1; A.z1 = z1; A.ih = image_height; A.iw = image_width;
+  launch_image_corr(ctx->stream, ctx->kp, A, ctx->cells, ctx->img_uv, ctx->img_valid);
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+int emap_image_get_correspondence(emap_ctx* ctx, float* uv_host, uint8_t* valid_host) {
+  CKARG(ctx && uv_host && valid_host && ctx->img_uv, "no correspondence computed yet");
+  CK(hipSetDevice(ctx->device));
+  const size_t L = (size_t)ctx->prm.cell_n * ctx->prm.cell_n;
+  CK(hipMemcpyAsync(uv_host, ctx->img_uv, sizeof(float) * 2 * L, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipMemcpyAsync(valid_host, ctx->img_valid, L, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
+  return EMAP_OK;
+}
+int emap_image_fuse(emap_ctx* ctx, int32_t kind, int32_t layer, const float* host_image, int32_t n_planes, int32_t height, int32_t width,
+                    double alpha) {
+  CKARG(ctx && host_image && (kind == 0 || kind == 1) && layer >= 0 && layer < ctx->sem_layers, "bad argument");
+  CKARG(ctx->img_uv, "emap_image_correspondence must run first");
+  CKARG(n_planes >= (kind == 1 ? 3 : 1) && height > 0 && width > 0, "bad image shape");
+  CK(hipSetDevice(ctx->device));
+  const size_t need = (size_t)n_planes * height * width;
+  if (need > ctx->img_cap) {
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->img_buf) CK(hipFree(ctx->img_buf));
+    ctx->img_buf = nullptr; ctx->img_cap = 0;
+    CK(hipMalloc((void**)&ctx->img_buf, sizeof(float) * need));
+    ctx->img_cap = need;
+  }
+  CK(hipMemcpyAsync(ctx->img_buf, host_image, sizeof(float) * need, hipMemcpyHostToDevice, ctx->stream));
+  launch_image_fuse(ctx->stream, ctx->kp, kind, ctx->sem + (size_t)layer * ctx->ncells_alloc, ctx->img_buf, ctx->img_uv, ctx->img_valid,
+                    (float)height, (float)width, alpha);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(ctx->stream));   // host image is only borrowed for the call
   return EMAP_OK;
 }
 

@@ -217,3 +217,91 @@ void launch_inpaint_sweep(hipStream_t s, int C, const float* val, const float* m
                           const unsigned int* prev_unfilled, unsigned int* unfilled) {
   hipLaunchKernelGGL(k_inpaint_sweep, dim3(nblk_((long)C * C)), dim3(EM_BLOCK), 0, s, C, val, msk, oval, omsk, prev_unfilled, unfilled);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Camera path.  image_to_map_correspondence_kernel (reference EM/kernels/custom_image_kernels.py:
+// 9-157): every known cell is projected into the image (P = K [R|t], optional radtan distortion) and a Bresenham walk
+// towards the camera cell rejects it when terrain in between rises above the line of sight.  Per cell, race free.
+// exponential_/color_correspondences_to_map_kernel (:195-271) then sample the image per cell.
+// ---------------------------------------------------------------------------------------------------------
+struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; };
+
+__device__ __forceinline__ float l2_dist(int x0, int y0, int x1, int y1) { float dx = (float)(x0 - x1), dy = (float)(y0 - y1); return sqrtf(dx * dx + dy * dy); }
+
+__global__ __launch_bounds__(EM_BLOCK) void k_image_corr(KP P, CamArgs A, const Cell* __restrict__ cells, float* __restrict__ uv,
+                                                          unsigned char* __restrict__ valid) {
+  const int W = P.C; const long L = (long)W * W;
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= L) return;
+  float out_u = 0.f, out_v = 0.f; unsigned char out_ok = 0;
+  do {
+    if (cells[i].valid != 1.0f) break;                                     // only cells with is_valid == 1 (:40-42)
+    int y0 = (int)(i % W), x0 = (int)(i / W);
+    float p1 = (float)((double)(x0 - (W / 2)) * P.res + (double)A.center[0]);
+    float p2 = (float)((double)(y0 - (W / 2)) * P.res + (double)A.center[1]);
+    const float z0 = cells[i].h;
+    float p3 = z0 + A.center[2];
+    float u = p1 * A.P[0] + p2 * A.P[1] + p3 * A.P[2] + A.P[3];
+    float v = p1 * A.P[4] + p2 * A.P[5] + p3 * A.P[6] + A.P[7];
+    float d = p1 * A.P[8] + p2 * A.P[9] + p3 * A.P[10] + A.P[11];
+    if (d <= 0.f) break;
+    u = u / d; v = v / d;
+    if (!(A.D[0] == 0.f && A.D[1] == 0.f && A.D[2] == 0.f && A.D[3] == 0.f && A.D[4] == 0.f)) {     // radtan (:66-86)
+      const float k1 = A.D[0], k2 = A.D[1], q1 = A.D[2], q2 = A.D[3], k3 = A.D[4], fx = A.K[0], fy = A.K[4], cx = A.K[2], cy = A.K[5];
+      float x = (u - cx) / fx, y = (v - cy) / fy;
+      float r2 = x * x + y * y;
+      float radial = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2;
+      float uc = x * radial + 2 * q1 * x * y + q2 * (r2 + 2 * x * x);
+      float vc = y * radial + 2 * q2 * x * y + q1 * (r2 + 2 * y * y);
+      u = fx * uc + cx; v = fy * vc + cy;
+    }
+    if ((u < 0.f) || (v < 0.f) || (u >= A.iw) || (v >= A.ih)) break;
+    const int x0c = x0, y0c = y0;
+    const float x1 = A.x1, y1 = A.y1;
+    const float total_dis = l2_dist(x0c, y0c, (int)x1, (int)y1);
+    const float delta_z = A.z1 - z0;
+    const int dx = (int)fabsf(x1 - (float)x0), sx = (float)x0 < x1 ? 1 : -1, dy = -(int)fabsf(y1 - (float)y0), sy = (float)y0 < y1 ? 1 : -1;
+    int error = dx + dy;
+    bool ok = true;
+    for (;;) {                                                               // Bresenham towards the camera cell (:103-147)
+      if ((float)x0 == x1 && (float)y0 == y1) break;
+      if (x0 >= 0 && y0 >= 0 && x0 < W && y0 < W) {
+        const long idx = y0 + (long)x0 * W;
+        const float2 hv = *reinterpret_cast<const float2*>(&cells[idx]);     // h, (v)
+        if (cells[idx].valid != 0.f) {
+          float dis = l2_dist(x0c, y0c, x0, y0);
+          float rayheight = z0 + (dis / total_dis * delta_z);
+          if ((double)hv.x - 0.10 > (double)rayheight) { ok = false; break; }
+        }
+      }
+      const int e2 = 2 * error;
+      if (e2 >= dy) { if ((float)x0 == x1) break; error += dy; x0 += sx; }
+      if (e2 <= dx) { if ((float)y0 == y1) break; error += dx; y0 += sy; }
+    }
+    out_u = u; out_v = v; out_ok = ok ? 1 : 0;
+  } while (false);
+  uv[i] = out_u; uv[L + i] = out_v; valid[i] = out_ok;
+}
+
+__global__ __launch_bounds__(EM_BLOCK) void k_image_fuse(KP P, int kind, float* __restrict__ sem, const float* __restrict__ image,
+                                                          const float* __restrict__ uv, const unsigned char* __restrict__ valid,
+                                                          float ih, float iw, double alpha) {
+  const long L = (long)P.C * P.C;
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= L || !valid[i]) return;
+  const int idx = (int)((float)(int)uv[i] + (float)(int)uv[L + i] * iw);
+  if (kind == 0) sem[i] = (float)((double)sem[i] * (1 - alpha) + alpha * (double)image[idx]);
+  else {
+    const int ig = (int)(iw * ih + (float)idx), ib = (int)(iw * ih * 2 + (float)idx);
+    const unsigned int r = (unsigned int)image[idx], g = (unsigned int)image[ig], b = (unsigned int)image[ib];
+    sem[i] = __uint_as_float((r << 16) + (g << 8) + b);
+  }
+}
+
+void launch_image_corr(hipStream_t s, const KP& P, const CamArgs& A, const Cell* cells, float* uv, unsigned char* valid) {
+  hipLaunchKernelGGL(k_image_corr, dim3(nblk_((long)P.C * P.C)), dim3(EM_BLOCK), 0, s, P, A, cells, uv, valid);
+}
+void launch_image_fuse(hipStream_t s, const KP& P, int kind, float* sem, const float* image, const float* uv, const unsigned char* valid,
+                       float ih, float iw, double alpha) {
+  hipLaunchKernelGGL(k_image_fuse, dim3(nblk_((long)P.C * P.C)), dim3(EM_BLOCK), 0, s, P, kind, sem, image, uv, valid, ih, iw, alpha);
+}

@@ -286,6 +286,42 @@ class ElevationMap:
         self.update_map_with_kernel(raw_points, additional_channels, np.asarray(R, np.float32),
                                     np.asarray(t, np.float32).copy(), position_noise, orientation_noise, want_stats=False)
 
+    def input_image(self, image, channels: List[str], R, t, K, D, distortion_model: str, image_height: int, image_width: int):
+        """Fuse a (multi-channel) camera image into the semantic layers (reference :468-562): every known cell is
+        projected into the image, occluded cells are rejected by a Bresenham walk towards the camera, the image is
+        sampled per cell."""
+        image = np.stack([np.asarray(c) for c in image], axis=0)
+        if image.ndim == 2:
+            image = image[None]
+        image = image.astype(np.float32)
+        K = np.asarray(K, np.float32); R = np.asarray(R, np.float32); t = np.asarray(t, np.float32)
+        D = np.asarray(D, np.float32).reshape(-1)
+        if len(D) < 4:
+            D = np.zeros(5, np.float32)
+        elif len(D) == 4:
+            D = np.concatenate([D, np.zeros(1, np.float32)])
+        else:
+            D = D[:5].copy()
+        if distortion_model != "radtan":
+            D = D * 0            # equidistant / plumb_bob: "not implemented yet" in the reference -> no distortion
+        P = (K @ np.concatenate([R, t[:, None]], 1)).astype(np.float32)
+        t_cam_map = -R.T @ t - self.center
+        x1 = np.float32(np.uint32((self.cell_n / 2) + (t_cam_map[0] / self.resolution)))
+        y1 = np.float32(np.uint32((self.cell_n / 2) + (t_cam_map[1] / self.resolution)))
+        z1 = np.float32(t_cam_map[2])
+        with self.map_lock:
+            self._chk(self._lib.emap_image_correspondence(
+                self._ctx, ct.c_float(x1), ct.c_float(y1), ct.c_float(z1), f32p(np.ascontiguousarray(P.reshape(-1))),
+                f32p(np.ascontiguousarray(K.reshape(-1))), f32p(np.ascontiguousarray(D)), ct.c_float(float(image_height)),
+                ct.c_float(float(image_width)), f32p(np.ascontiguousarray(self.center, np.float32))))
+            self.semantic_map.update_layers_image(self, image, list(channels), image_height, image_width)
+
+    def get_image_correspondence(self):
+        """(uv (2, C, C) float32, valid (C, C) bool) of the last input_image call"""
+        uv = np.empty((2, self.cell_n, self.cell_n), np.float32); valid = np.empty((self.cell_n, self.cell_n), np.uint8)
+        self._chk(self._lib.emap_image_get_correspondence(self._ctx, f32p(uv), valid.ctypes.data_as(ct.c_void_p)))
+        return uv, valid.astype(bool)
+
     input = input_pointcloud  # name used by the C++ wrapper (src/elevation_mapping_wrapper.cpp:173-178)
 
     # ---- stage-level API (parity tests; same order as update_map_with_kernel) ----------------------

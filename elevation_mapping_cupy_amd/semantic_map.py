@@ -124,6 +124,26 @@ class SemanticMap:
         t = np.ascontiguousarray(np.asarray(t, np.float32).reshape(3))
         emap._chk(emap._lib.emap_semantic_update(emap._ctx, f32p(R), f32p(t), ct.byref(spec)))
 
+    def update_layers_image(self, emap, image, channels, image_height, image_width):
+        """sample the image into the semantic layers through the correspondence computed by
+        ``emap_image_correspondence`` (reference semantic_map.py:261-306)."""
+        process_channels, fusion_methods = self.get_fusion(channels, self.param.image_channel_fusions, self.layer_specs_image)
+        image = np.ascontiguousarray(image, np.float32)
+        for j, (fusion, channel) in enumerate(zip(fusion_methods, process_channels)):
+            if channel not in self.layer_names:
+                print(f"Layer {channel} not found, adding it to the semantic map", file=sys.stderr)
+                self.add_layer(channel)
+            plug = self.fusion_manager.get_plugin(fusion, "image")
+            if plug is None:
+                continue
+            idx = self.layer_names.index(channel)
+            if plug.kind == "color":      # the reference hands the whole stack over and reads planes 0..2 as r, g, b
+                img, kind = image, 1
+            else:
+                img, kind = image[j:j + 1], 0
+            emap._chk(emap._lib.emap_image_fuse(emap._ctx, kind, idx, f32p(np.ascontiguousarray(img)), int(img.shape[0]),
+                                                int(image_height), int(image_width), ct.c_double(getattr(plug, "alpha", 0.7))))
+
     # ---- read-back -----------------------------------------------------------------------------------
     def _layer(self, idx):
         out = np.empty((self._emap.rows, self._emap.cell_n), np.float32)

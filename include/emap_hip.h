@@ -163,6 +163,17 @@ int emap_min_filter(emap_ctx* ctx, const float* host_elevation, const float* hos
 int emap_inpaint_u8(emap_ctx* ctx, const float* host_image, const float* host_known, int32_t max_sweeps, float* host_out,
                     int32_t* sweeps_run_or_null);
 
+/* ---- camera path: ElevationMap.input_image (EM/elevation_mapping.py:468-562).
+ * emap_image_correspondence = image_to_map_correspondence_kernel (EM/kernels/custom_image_kernels.py:9-157): x1, y1 = camera
+ * cell (uint32 valued), z1 = camera height above the map centre, P = K [R|t] row major, D = 5 radtan coefficients (all 0 =
+ * none).  emap_image_fuse = exponential_ (kind 0, alpha 0.7 in the reference) / color_ (kind 1, planes 0..2 = r,g,b)
+ * correspondences_to_map_kernel (:195-271) applied to semantic layer `layer` with a host image (n_planes, H, W) float32. */
+int emap_image_correspondence(emap_ctx* ctx, float x1, float y1, float z1, const float P[12], const float K[9], const float D[5],
+                              float image_height, float image_width, const float center[3]);
+int emap_image_get_correspondence(emap_ctx* ctx, float* uv_host /* (2, cell_n, cell_n) */, uint8_t* valid_host);
+int emap_image_fuse(emap_ctx* ctx, int32_t kind, int32_t layer, const float* host_image, int32_t n_planes, int32_t height,
+                    int32_t width, double alpha);
+
 /* ---- row-strip halos (multi-GPU; exchange itself is done by the caller, e.g. torch.distributed/RCCL) ---- */
 /* pack `halo_rows` owned boundary rows (32-byte cells) next to the lower (side 0) / upper (side 1) neighbour
  * into a device buffer; unpack a neighbour's rows into the halo. Buffers: halo_rows*cell_n*8 floats. */

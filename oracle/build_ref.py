@@ -67,7 +67,7 @@ def _load_reference_factories():
     sys.modules["cupy"] = fake
     mods = {}
     try:
-        for fn in ("custom_kernels", "custom_semantic_kernels"):
+        for fn in ("custom_kernels", "custom_semantic_kernels", "custom_image_kernels"):
             spec = importlib.util.spec_from_file_location("_ref_" + fn, os.path.join(REF_ROOT, "kernels", fn + ".py"))
             m = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(m)
@@ -84,7 +84,7 @@ def _instantiate(p):
     """Call the reference factories the way ElevationMap.compile_kernels does
     (reference elevation_mapping.py:228-282) and the fusion plugins do."""
     m = _load_reference_factories()
-    ck, sk = m["custom_kernels"], m["custom_semantic_kernels"]
+    ck, sk, ik = m["custom_kernels"], m["custom_semantic_kernels"], m["custom_image_kernels"]
     C, res = p["cell_n"], p["resolution"]
     f32 = dict(U="float", T="float", W="int", V="float", B="bool")
     u32 = dict(f32, V="unsigned int")
@@ -109,6 +109,13 @@ def _instantiate(p):
         "sem_add_color": (sk.add_color_kernel(C, C), u32),
         "sem_color_average": (sk.color_average_kernel(C, C), u32),
     }
+    if p.get("image_kernels"):
+        # camera path (reference elevation_mapping.py:295-305, fusion/image_exponential.py:49-52, image_color.py):
+        # x1, y1, z1, image sizes and map_idx are passed BY VALUE in the reference's calls (:540-554)
+        ks["image_correspondence"] = (ik.image_to_map_correspondence_kernel(res, C, C, 0.10), f32,
+                                      {"x1", "y1", "z1", "image_height", "image_width"})
+        ks["image_exponential"] = (ik.exponential_correspondences_to_map_kernel(C, C, 0.7), f32, {"map_idx", "image_height", "image_width"})
+        ks["image_color"] = (ik.color_correspondences_to_map_kernel(C, C), f32, {"map_idx", "image_height", "image_width"})
     for extra in p.get("extra_dilation_sizes", ()):
         ks["dilation_filter_%d" % extra] = (ck.dilation_filter_kernel(C, C, extra), f32)
     for d in p.get("min_filter_sizes", ()):
@@ -159,11 +166,13 @@ def _parse_params(s):
 
 def _emit(ks):
     src = ['#include "ref_shim.h"\n']
-    for sym, (k, types_) in ks.items():
+    for sym, spec in ks.items():
+        k, types_ = spec[0], spec[1]
+        scalars = spec[2] if len(spec) > 2 else set()
         params = _parse_params(k.in_params) + _parse_params(k.out_params)
         op = re.sub(r"\breturn\s*;", "continue;", k.operation)
-        args = ", ".join("%s* %s_" % (types_[t], n) for t, n in params)
-        binds = "".join("  Raw<%s> %s{%s_};\n" % (types_[t], n, n) for t, n in params)
+        args = ", ".join(("%s %s" % (types_[t], n)) if n in scalars else ("%s* %s_" % (types_[t], n)) for t, n in params)
+        binds = "".join("  Raw<%s> %s{%s_};\n" % (types_[t], n, n) for t, n in params if n not in scalars)
         tds = "".join("typedef %s %s;\n" % (v, kk) for kk, v in types_.items())
         src.append(
             "namespace ns_%s {\n%s%s\nextern \"C\" void ref_%s(%s, long size_) {\n%s"
@@ -206,6 +215,7 @@ PREBUILD = {
     "yaml1024_norays": with_(PARAM_YAML, cell_n=1024, enable_visibility_cleanup=False),
     "default34": with_(PARAM_DEFAULT, cell_n=34, extra_dilation_sizes=(1, 3, 10), min_filter_sizes=(1, 2)),
     "yaml66": with_(PARAM_YAML, cell_n=66, extra_dilation_sizes=(1, 2, 10)),
+    "image98": with_(PARAM_YAML, cell_n=98, image_kernels=True),
 }
 
 

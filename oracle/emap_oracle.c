@@ -452,6 +452,75 @@ void eo_sem_color(const eo_params* P, const float* pts, long n, long stride, con
   free(acc);
 }
 
+/* ---- camera path: image_to_map_correspondence_kernel (reference kernels/custom_image_kernels.py:9-157) and the
+ * per-cell samplers exponential_/color_correspondences_to_map_kernel (:195-271).  Per-cell, race free.  The scalars
+ * x1, y1 (camera cell, uint32 valued), z1, image_height, image_width arrive as float32 like in the reference call
+ * (elevation_mapping.py:531-554). ---- */
+static inline float l2_distance(int x0, int y0, int x1, int y1) { float dx = x0 - x1, dy = y0 - y1; return sqrtf(dx * dx + dy * dy); }
+void eo_image_correspondence(const eo_params* P, const float* map, float x1, float y1, float z1, const float* Pm, const float* K,
+                             const float* D, float image_height, float image_width, const float* center, float* uv, uint8_t* valid) {
+  const int W = P->cell_n; const long L = (long)W * W;
+  const double res = P->resolution, tol = 0.10;
+  for (long i = 0; i < L; ++i) {
+    if (map[2 * L + i] != 1) continue;
+    int y0 = (int)(i % W), x0 = (int)(i / W);
+    float p1 = (float)((x0 - (W / 2)) * res + center[0]);
+    float p2 = (float)((y0 - (W / 2)) * res + center[1]);
+    float p3 = map[i] + center[2];
+    float u = p1 * Pm[0] + p2 * Pm[1] + p3 * Pm[2] + Pm[3];
+    float v = p1 * Pm[4] + p2 * Pm[5] + p3 * Pm[6] + Pm[7];
+    float d = p1 * Pm[8] + p2 * Pm[9] + p3 * Pm[10] + Pm[11];
+    if (d <= 0) continue;
+    u = u / d; v = v / d;
+    int d_zero = (D[0] == 0 && D[1] == 0 && D[2] == 0 && D[3] == 0 && D[4] == 0);
+    if (!d_zero) {
+      float k1 = D[0], k2 = D[1], q1 = D[2], q2 = D[3], k3 = D[4], fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+      float x = (u - cx) / fx, y = (v - cy) / fy;
+      float r2 = x * x + y * y;
+      float radial = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2;
+      float uc = x * radial + 2 * q1 * x * y + q2 * (r2 + 2 * x * x);
+      float vc = y * radial + 2 * q2 * x * y + q1 * (r2 + 2 * y * y);
+      u = fx * uc + cx; v = fy * vc + cy;
+    }
+    if ((u < 0) || (v < 0) || (u >= image_width) || (v >= image_height)) continue;
+    const int y0c = y0, x0c = x0;
+    float total_dis = l2_distance(x0c, y0c, (int)x1, (int)y1);
+    float z0 = map[i], delta_z = z1 - z0;
+    int dx = (int)fabsf(x1 - x0), sx = x0 < x1 ? 1 : -1, dy = -(int)fabsf(y1 - y0), sy = y0 < y1 ? 1 : -1, error = dx + dy;
+    int ok = 1;
+    for (;;) {
+      if (x0 == x1 && y0 == y1) break;
+      if (x0 >= 0 && y0 >= 0 && x0 < W && y0 < W) {
+        long idx = y0 + (long)x0 * W;
+        if (map[2 * L + idx]) {
+          float dis = l2_distance(x0c, y0c, x0, y0);
+          float rayheight = z0 + (dis / total_dis * delta_z);
+          if ((double)map[idx] - tol > (double)rayheight) { ok = 0; break; }
+        }
+      }
+      int e2 = 2 * error;
+      if (e2 >= dy) { if (x0 == x1) break; error += dy; x0 += sx; }
+      if (e2 <= dx) { if (y0 == y1) break; error += dx; y0 += sy; }
+    }
+    uv[i] = u; uv[L + i] = v; valid[i] = (uint8_t)ok;
+  }
+}
+/* kind 0: exponential (alpha), image = (H, W) plane; kind 1: colour, image = (3, H, W) planes; updates `sem` in place */
+void eo_image_fuse(const eo_params* P, int kind, float* sem, const float* image, const float* uv, const uint8_t* valid,
+                   float image_height, float image_width, double alpha) {
+  const long L = (long)P->cell_n * P->cell_n;
+  for (long i = 0; i < L; ++i) {
+    if (!valid[i]) continue;
+    int idx = (int)((float)(int)uv[i] + (float)(int)uv[L + i] * image_width);
+    if (kind == 0) sem[i] = (float)((double)sem[i] * (1 - alpha) + alpha * (double)image[idx]);
+    else {
+      int ig = (int)(image_width * image_height + (float)idx), ib = (int)(image_width * image_height * 2 + (float)idx);
+      unsigned int r = (unsigned int)image[idx], g = (unsigned int)image[ig], b = (unsigned int)image[ib];
+      sem[i] = u2f((r << 16) + (g << 8) + b);
+    }
+  }
+}
+
 /* MinFilter plugin (reference plugins/min_filter.py:29-118), Jacobi sweeps (every cell reads the previous sweep). */
 int eo_min_filter(int C, int d, int iteration_n, const float* elevation, const float* valid, float* out) {
   const long L = (long)C * C;

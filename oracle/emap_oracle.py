@@ -272,6 +272,24 @@ class OracleMap:
         return st
 
 
+def image_correspondence(P, emap, x1, y1, z1, Pm, K, D, image_height, image_width, center):
+    """reference image_to_map_correspondence_kernel; returns (uv (2,C,C) float32, valid (C,C) uint8)"""
+    C = P.cell_n
+    uv, valid = np.zeros((2, C, C), np.float32), np.zeros((C, C), np.uint8)
+    f = ct.c_float
+    a = lambda x: _p(np.ascontiguousarray(x, np.float32))  # noqa: E731
+    lib().eo_image_correspondence(ct.byref(P), a(emap), f(x1), f(y1), f(z1), a(Pm), a(K), a(D), f(image_height), f(image_width),
+                                  a(center), _p(uv), _p(valid))
+    return uv, valid
+
+
+def image_fuse(P, kind, sem_plane, image, uv, valid, image_height, image_width, alpha=0.7):
+    """in-place update of one semantic plane; kind 'exponential' (image (H,W)) or 'color' (image (3,H,W))"""
+    img = np.ascontiguousarray(image, np.float32)
+    lib().eo_image_fuse(ct.byref(P), ct.c_int({"exponential": 0, "color": 1}[kind]), _p(sem_plane), _p(img), _p(uv), _p(valid),
+                        ct.c_float(image_height), ct.c_float(image_width), ct.c_double(alpha))
+
+
 def set_threads(n):
     """OpenMP threads of the C oracle (1 = sequential, bit-reproducible: the setting every parity test uses)."""
     lib().eo_set_threads(ct.c_int(int(n)))

@@ -57,6 +57,21 @@ class RefKernels:
     def normal_filter(self, plane, mask, out):
         self._call("normal_filter", [plane, mask, out], self.C * self.C)
 
+    # --- camera path (reference custom_image_kernels.py); scalars are passed by value like the reference does ------
+    def image_correspondence(self, emap, x1, y1, z1, P, K, D, image_height, image_width, center, uv, valid):
+        fn = self.lib.ref_image_correspondence
+        fn.restype = None
+        f = ctypes.c_float
+        fn(_ptr(emap), f(x1), f(y1), f(z1), _ptr(P), _ptr(K), _ptr(D), f(image_height), f(image_width), _ptr(center),
+           _ptr(uv), _ptr(valid), ctypes.c_long(self.C * self.C))
+
+    def image_fuse(self, kind, sem_map, map_idx, image, uv, valid, image_height, image_width, new_sem_map):
+        fn = getattr(self.lib, "ref_image_" + kind)
+        fn.restype = None
+        f = ctypes.c_float
+        fn(_ptr(sem_map), f(map_idx), _ptr(image), _ptr(uv), _ptr(valid), f(image_height), f(image_width), _ptr(new_sem_map),
+           ctypes.c_long(self.C * self.C))
+
     def min_filter_sweep(self, elevation, valid, newmap, newmask, size):
         """one in-place sweep of the MinFilter kernel (reference plugins/min_filter.py:29-82), sequential order"""
         self._call("min_filter_%d" % size, [elevation, valid, newmap, newmask], self.C * self.C)

@@ -52,3 +52,24 @@ def semantic_prev(C):
     prev = rng.uniform(0, 1, (C, C)).astype(np.float32)
     prev[rng.uniform(0, 1, (C, C)) < 0.5] = 0.0
     return prev
+
+
+def camera_case(C, seed, with_distortion):
+    """a camera above the map looking down-forward: K, D, R (world->camera), t, image size"""
+    rng = np.random.default_rng(300 + seed)
+    H, W = 48, 64
+    K = np.array([[40.0, 0, W / 2], [0, 40.0, H / 2], [0, 0, 1]], np.float32)
+    D = (np.array([0.05, -0.01, 0.002, -0.001, 0.0005], np.float32) if with_distortion else np.zeros(5, np.float32))
+    Rwc = rot(np.pi + 0.35 * rng.uniform(-1, 1), 0.3 * rng.uniform(-1, 1), rng.uniform(-3, 3))   # optical axis roughly -z
+    cam_pos = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), 1.6], np.float32)
+    t = (-Rwc @ cam_pos).astype(np.float32)
+    return K, D, Rwc.astype(np.float32), t, H, W
+
+
+def camera_inputs(emap_center, cell_n, resolution, K, R, t):
+    """P, x1, y1, z1 exactly as reference input_image computes them (elevation_mapping.py:527-534)"""
+    P = (K @ np.concatenate([R, t[:, None]], 1)).astype(np.float32)
+    t_cam_map = -R.T @ t - emap_center
+    x1 = np.float32(np.uint32((cell_n / 2) + (t_cam_map[0] / resolution)))
+    y1 = np.float32(np.uint32((cell_n / 2) + (t_cam_map[1] / resolution)))
+    return P, x1, y1, np.float32(t_cam_map[2])

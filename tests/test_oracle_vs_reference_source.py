@@ -98,3 +98,35 @@ def test_min_filter_single_sweep_on_isolated_holes(d):
     got, sweeps = eo.min_filter(C, d, 1, e0, v)
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+
+
+@pytest.mark.parametrize("dist", [False, True])
+def test_image_correspondence_and_fusions(dist, weights):
+    """camera path: projection + radtan distortion + Bresenham occlusion walk and the two samplers are per-cell and race
+    free => exact comparison with the reference kernels on a warm map."""
+    rk = _ref("image98")
+    C = 98
+    cfg = dict(eo.YAML, enable_visibility_cleanup=False)
+    om = eo.OracleMap(eo.make_params(cfg, cell_n=C, weights=weights))
+    R0, t0 = fx.POSES["identity"]
+    p = fx.cloud(C, 20000, 0); p[:, 2] += 0.3 * np.sin(p[:, 0] * 2.0)           # relief => occlusions
+    om.update_map_with_kernel(p, R0, t0)
+    K, D, R, t, H, W = fx.camera_case(C, 1, dist)
+    center = np.array([0.1, -0.2, 0.05], np.float32)
+    Pm, x1, y1, z1 = fx.camera_inputs(center, C, 0.04, K, R, t)
+    uv_r = np.zeros((2, C, C), np.float32); va_r = np.zeros((C, C), np.bool_)
+    rk.image_correspondence(om.elevation_map.copy(), x1, y1, z1, Pm.ravel().copy(), K.ravel().copy(), D.copy(), H, W, center, uv_r, va_r)
+    uv, va = eo.image_correspondence(om.P, om.elevation_map, x1, y1, z1, Pm.ravel(), K.ravel(), D, H, W, center)
+    assert va_r.sum() > 50 and (uv_r[0] != 0).sum() > va_r.sum()                # visible cells exist, occluded ones too
+    assert np.array_equal(va.astype(bool), va_r) and np.array_equal(uv, uv_r)
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0, 1, (3, H, W)).astype(np.float32)
+    rgb = rng.integers(0, 256, (3, H, W)).astype(np.float32)
+    sem = rng.uniform(0, 1, (2, C, C)).astype(np.float32)
+    new_r = np.zeros_like(sem)
+    rk.image_fuse("exponential", sem.copy(), 0, img[1].copy(), uv_r, va_r, H, W, new_r)
+    rk.image_fuse("color", sem.copy(), 1, rgb.copy(), uv_r, va_r, H, W, new_r)
+    mine = sem.copy()
+    eo.image_fuse(om.P, "exponential", mine[0], img[1], uv, va, H, W, 0.7)
+    eo.image_fuse(om.P, "color", mine[1], rgb, uv, va, H, W)
+    assert np.array_equal(mine[0], new_r[0]) and np.array_equal(mine[1].view(np.uint32), new_r[1].view(np.uint32))
