@@ -397,6 +397,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_dilate(KP P, const Cell* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// (The 12 x 9 taps are explicit fmaf chains in a fixed order: the same bytes from k_trav_normal and k_post, half the
+// VALU instructions of separate mul + add; the reference's cuDNN summation order is unspecified, tolerance 1e-5.)
 // traversability filter (traversability_filter.py:8-47: three dilated 3x3 correlations x 4 channels, abs,
 // 1x1, exp(-x); elevation_mapping.py:385-388) fused with normal_filter_kernel (custom_kernels.py:452-506):
 // both consume the dilated plane, so one LDS tile (halo 3) feeds both.  Weights live in kernargs (SGPRs).
@@ -437,8 +439,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_trav_normal(KP P, TravW Wt, const 
 #pragma unroll
           for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) s += Wt.w[k][ch * 9 + a * 3 + b] * t0[(a - 1) * dl * pitch + (b - 1) * dl];
-          acc += Wt.wo[k * 4 + ch] * fabsf(s);
+            for (int b = 0; b < 3; ++b) s = fmaf(Wt.w[k][ch * 9 + a * 3 + b], t0[(a - 1) * dl * pitch + (b - 1) * dl], s);
+          acc = fmaf(Wt.wo[k * 4 + ch], fabsf(s), acc);
         }
       }
       cells[c].trav = expf(-acc);
@@ -538,8 +540,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
 #pragma unroll
           for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) sm += Wt.w[q][ch * 9 + a * 3 + b] * t0[(a - 1) * dl * dp + (b - 1) * dl];
-          acc += Wt.wo[q * 4 + ch] * fabsf(sm);
+            for (int b = 0; b < 3; ++b) sm = fmaf(Wt.w[q][ch * 9 + a * 3 + b], t0[(a - 1) * dl * dp + (b - 1) * dl], sm);
+          acc = fmaf(Wt.wo[q * 4 + ch], fabsf(sm), acc);
         }
       }
       cells[c].trav = expf(-acc);
