@@ -50,10 +50,18 @@ class TorchComm:
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device  # torch.device or None (CPU)
+        # RCCL orders its work after the current HIP stream by itself; gloo with device tensors (test setups with
+        # several ranks on one GPU) copies through the host without looking at our stream: drain it first
+        self.host_sync = device is not None and dist.get_backend() == "gloo"
+
+    def _drain(self):
+        if self.host_sync:
+            self.torch.cuda.current_stream(self.device).synchronize()
 
     def all_reduce_sum_(self, tensor):
         """in-place sum of a small float64 tensor (2 elements: err_sum, err_cnt)."""
         if self.world > 1:
+            self._drain()
             self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
         return tensor
 
@@ -61,6 +69,7 @@ class TorchComm:
         """neighbour exchange on the strip chain: send_lo -> rank-1 (arrives in its recv_hi), send_hi -> rank+1
         (arrives in its recv_lo).  Edge ranks have one neighbour.  Returns the in-flight requests."""
         dist = self.dist
+        self._drain()
         ops = []
         if self.rank > 0:
             ops.append(dist.P2POp(dist.isend, send_lo, self.rank - 1))
@@ -73,6 +82,8 @@ class TorchComm:
     def exchange_wait(self, works):
         for w in works:
             w.wait()
+        if self.host_sync:
+            self.torch.cuda.synchronize(self.device)
 
     def barrier(self):
         if self.world > 1:
