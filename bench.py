@@ -36,8 +36,8 @@ def parse():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"],
                     help="cfg2/cfg3: BASELINE configs[1]/[2] (1024^2, 1 M points); cfg5: 8192^2 multi-modal map "
                          "(height + RGB + 3 semantic layers), 16 M points, fp32 index mode, rays/overlap off")
-    ap.add_argument("--points", type=int, default=1_000_000)
-    ap.add_argument("--cell-n", type=int, default=1024)
+    ap.add_argument("--points", type=int, default=None, help="default 1 M (cfg2/cfg3) or 16 M (cfg5)")
+    ap.add_argument("--cell-n", type=int, default=None, help="default 1024 (cfg2/cfg3) or 8192 (cfg5)")
     ap.add_argument("--mode", default="reference_fp16", choices=["reference_fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
@@ -45,7 +45,11 @@ def parse():
     ap.add_argument("--sort-clouds", default="none", choices=["none", "tile", "angle"],
                     help="experiment: spatially coherent input order (real sensors deliver scan-ordered clouds)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-strip path even with one rank (self-test)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    big = a.workload == "cfg5"
+    a.cell_n = a.cell_n or (8192 if big else 1024)
+    a.points = a.points or (16_000_000 if big else 1_000_000)
+    return a
 
 
 def workload_cfg(name):
@@ -116,7 +120,7 @@ def main():
     C, N = a.cell_n, a.points
     multimodal = a.workload == "cfg5"
     if multimodal:
-        C, N, a.mode = (8192 if a.cell_n == 1024 else a.cell_n), (16_000_000 if a.points == 1_000_000 else a.points), "fp32"
+        a.mode = "fp32" if C > 2049 else a.mode
         cfg.update(enable_visibility_cleanup=False, enable_overlap_clearance=False)
     w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
     weights = {k: w[k] for k in ("w1", "w2", "w3", "w_out")}

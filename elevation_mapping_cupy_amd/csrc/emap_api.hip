@@ -50,6 +50,8 @@ struct BinRec { unsigned int lc_inl; float z, v; unsigned int i; };
 void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, BinTmp*, unsigned int*);
 void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*);
 void launch_bin_scatter(hipStream_t, const KP&, const BinGeo&, const BinTmp*, long, const unsigned int*, const unsigned int*, const Cell*, BinRec*, ErrSlot*);
+void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const void*, const BinRec*, const unsigned int*, const float*, long, int,
+                          const unsigned int*, float*, long);
 void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cell*, AccF*, const FrameDev*, bool, unsigned int*);
 #define BIN_MAX_T 16384
 #define BIN_MAX_B 2048
@@ -777,6 +779,12 @@ int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], cons
   for (int k = 0; k < spec->n_col; ++k)
     CKARG(spec->col_layer[k] >= 0 && spec->col_layer[k] < ctx->sem_layers && spec->col_chan[k] >= 3 && spec->col_chan[k] < ctx->stride, "bad colour channel/layer index");
   CK(hipSetDevice(ctx->device));
+  if (ctx->frame_binned) {   // the frame's tile-sorted records are still valid: reduce in LDS, no global atomics
+    launch_tile_semantic(ctx->stream, ctx->kp, ctx->bg, spec, ctx->bin_recs, ctx->bin_tile_start, ctx->pts, ctx->n_pts, ctx->stride,
+                         ctx->cnt_plane, ctx->sem, ctx->ncells_alloc);
+    CK(hipGetLastError());
+    return EMAP_OK;
+  }
   SemSpec S; memcpy(&S, spec, sizeof S);
   launch_sem_points(ctx->stream, ctx->kp, make_pose(ctx, R, t), S, ctx->pts, ctx->n_pts, ctx->stride, ctx->sem_sums, ctx->sem_col, ctx->ncells_alloc);
   launch_sem_finalize(ctx->stream, ctx->kp, S, ctx->cnt_plane, ctx->sem_sums, ctx->sem_col, ctx->sem, ctx->ncells_alloc);

@@ -17,6 +17,7 @@
 // atomic path of emap_kernels.hip (integer / fixed-point accumulators are order independent), which stays as the
 // fallback for maps with more than 16384 tiles (> 4096^2 cells per context) and for clouds below ~200 k points (two launches with atomics have the lower latency there).
 #include "emap_device.h"
+#include <cstring>
 
 #define BIN_TR 16
 #define BIN_TC 64
@@ -217,4 +218,104 @@ void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* 
                      AccF* acc, const FrameDev* F, bool fuse_average, unsigned int* cnt_plane) {
   if (fuse_average) hipLaunchKernelGGL(k_tile_fuse<true>, dim3(G.T), dim3(EM_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
   else hipLaunchKernelGGL(k_tile_fuse<false>, dim3(G.T), dim3(EM_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Semantic / RGB point fusion on the tile-sorted records (reference custom_semantic_kernels.py:9-51,167-194,233-267,
+// 270-375): the atomic path of emap_semantic.hip needs K + 4 global atomics per point (~44 us per million each); here one
+// workgroup per tile accumulates its points in LDS (fp64 / uint32 LDS atomics), finalises the cells of the tile
+// (average / class_average / packed colour) and writes the semantic planes directly -- no accumulator planes in HBM.
+// Channels are processed in groups of 4 (32 KB of fp64 LDS accumulators per group).
+// ---------------------------------------------------------------------------------------------------------
+#define SEM_MAX_CH 16
+struct SemSpecB {
+  int n_sum; int sum_chan[SEM_MAX_CH]; int sum_layer[SEM_MAX_CH]; int sum_kind[SEM_MAX_CH];
+  int n_col; int col_chan[4]; int col_layer[4];
+  double alpha;
+};
+#define SEM_GROUP 4
+__global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemSpecB S, const BinRec* __restrict__ recs,
+                                                             const unsigned int* __restrict__ tile_start, const float* __restrict__ pts,
+                                                             long n, int stride, const unsigned int* __restrict__ cnt_plane,
+                                                             float* __restrict__ sem, long plane) {
+  constexpr int NC = BIN_TR * BIN_TC;
+  __shared__ double s_sum[SEM_GROUP][NC];
+  __shared__ unsigned int s_col[4][NC];                 // r, g, b, count of ONE colour layer at a time
+  const int t = blockIdx.x, ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
+  const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
+  const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6, col = tx * BIN_TC + tc;
+  for (int g0 = 0; g0 < S.n_sum; g0 += SEM_GROUP) {
+    const int ng = min(SEM_GROUP, S.n_sum - g0);
+    for (int k = threadIdx.x; k < SEM_GROUP * NC; k += EM_BLOCK) (&s_sum[0][0])[k] = 0.0;
+    __syncthreads();
+    for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {
+      const BinRec r = recs[k];
+      const unsigned int lc = r.lc_inl & 0x7fffffffu;
+      const float* p = pts + (long)r.i * stride;
+      for (int q = 0; q < ng; ++q) unsafeAtomicAdd(&s_sum[q][lc], (double)p[S.sum_chan[g0 + q]]);
+    }
+    __syncthreads();
+    if (col < P.C) {
+      for (int k = 0; k < BIN_TR / 4; ++k) {
+        const int tr = wv + 4 * k, lrow = ty * BIN_TR + tr;
+        if (lrow >= P.nrows) break;
+        const long c = (long)(lrow + P.halo) * P.C + col;
+        const unsigned int cnt = cnt_plane[c];               // accepted HEIGHT points (new_elmap plane 2, :185)
+        if (cnt == 0) continue;
+        for (int q = 0; q < ng; ++q) {
+          const long j = (long)S.sum_layer[g0 + q] * plane + c;
+          const double s = s_sum[q][tr * BIN_TC + tc];
+          if (S.sum_kind[g0 + q] == 0) sem[j] = (float)(s / (double)cnt);
+          else {
+            const float prev = sem[j];
+            sem[j] = (prev == 0.0f) ? (float)(s / (double)cnt) : (float)(S.alpha * (double)prev + (1.0 - S.alpha) * s / (double)cnt);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (S.n_col > 0) {
+    const int K = S.n_col;
+    // the reference's launch-size quirk (fusion/pointcloud_color.py:143): element e = id * K + layer only exists for e < N,
+    // and ONE counter plane is shared by all K layers
+    for (int k = threadIdx.x; k < NC; k += EM_BLOCK) s_col[3][k] = 0u;
+    __syncthreads();
+    for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {
+      const BinRec r = recs[k];
+      const unsigned int lc = r.lc_inl & 0x7fffffffu;
+      for (int l = 0; l < K; ++l) if ((long)r.i * K + l < n) atomicAdd(&s_col[3][lc], 1u);
+    }
+    __syncthreads();
+    for (int l = 0; l < K; ++l) {
+      for (int k = threadIdx.x; k < 3 * NC; k += EM_BLOCK) (&s_col[0][0])[k] = 0u;
+      __syncthreads();
+      for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {
+        const BinRec r = recs[k];
+        if ((long)r.i * K + l >= n) continue;
+        const unsigned int lc = r.lc_inl & 0x7fffffffu;
+        const unsigned int color = __float_as_uint(pts[(long)r.i * stride + S.col_chan[l]]);
+        atomicAdd(&s_col[0][lc], (color & 0xFF0000u) >> 16);
+        atomicAdd(&s_col[1][lc], (color & 0xFF00u) >> 8);
+        atomicAdd(&s_col[2][lc], color & 0xFFu);
+      }
+      __syncthreads();
+      if (col < P.C) {
+        for (int k = 0; k < BIN_TR / 4; ++k) {
+          const int tr = wv + 4 * k, lrow = ty * BIN_TR + tr, lc = tr * BIN_TC + tc;
+          if (lrow >= P.nrows) break;
+          const unsigned int cn = s_col[3][lc];
+          if (cn == 0) continue;
+          const unsigned int rr = s_col[0][lc] / cn, gg = s_col[1][lc] / cn, bb = s_col[2][lc] / cn;
+          sem[(long)S.col_layer[l] * plane + (long)(lrow + P.halo) * P.C + col] = __uint_as_float((rr << 16) + (gg << 8) + bb);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+void launch_tile_semantic(hipStream_t s, const KP& P, const BinGeo& G, const void* spec, const BinRec* recs, const unsigned int* tile_start,
+                          const float* pts, long n, int stride, const unsigned int* cnt_plane, float* sem, long plane) {
+  SemSpecB S; memcpy(&S, spec, sizeof S);
+  hipLaunchKernelGGL(k_tile_semantic, dim3(G.T), dim3(EM_BLOCK), 0, s, P, G, S, recs, tile_start, pts, n, stride, cnt_plane, sem, plane);
 }

@@ -20,10 +20,12 @@ def _hip(C, mode="reference_fp16"):
     return hip, orc
 
 
-def test_against_reference_golden():
+@pytest.mark.parametrize("scatter", ["atomic", "binned"])
+def test_against_reference_golden(scatter):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "semantic_yaml66.npz"))
     C, N = 66, 6000
     hip, _ = _hip(C)
+    hip.set_scatter_mode(scatter)
     R, t = fx.POSES["rotated"]
     p = fx.semantic_cloud(C, N, 5)
     hip.semantic_map.prepare(CH[3:])
@@ -39,10 +41,12 @@ def test_against_reference_golden():
     assert np.array_equal(out, np.flip(sm[0][1:-1, 1:-1]))
 
 
+@pytest.mark.parametrize("scatter", ["atomic", "binned"])
 @pytest.mark.parametrize("mode", ["reference_fp16", "fp32"])
-def test_three_frames_against_oracle(mode):
+def test_three_frames_against_oracle(mode, scatter):
     C, N = 130, 30000
     hip, orc = _hip(C, mode)
+    hip.set_scatter_mode(scatter)
     R, t = fx.POSES["identity"]
     for f in range(3):
         p = fx.semantic_cloud(C, N, f)
@@ -71,3 +75,27 @@ def test_shift_moves_semantic_layers_with_the_map():
     want_e[0] -= np.float32(0.25); want_e[5] -= np.float32(0.25)
     assert np.allclose(after_e, want_e, atol=1e-6)
     assert np.allclose(hip.center, [0.12, -0.08, 0.25], atol=1e-6)
+
+
+def test_two_colour_channels_quirk_same_on_both_paths():
+    """K = 2 colour channels: the reference launches add_color_kernel with size = N while decoding id = i / K
+    (SURVEY appendix B.12); both device paths must reproduce that identically, plus 6 averaged channels (> one LDS group)."""
+    C, N = 130, 20000
+    res = []
+    for scatter in ("atomic", "binned"):
+        hip, _ = _hip(C)
+        hip.set_scatter_mode(scatter)
+        hip.param.pointcloud_channel_fusions = {"rgb.*": "color", "default": "average"}
+        R, t = fx.POSES["rotated"]
+        p = fx.cloud(C, N, 3, extra=8)
+        rng = np.random.default_rng(9)
+        p[:, 3] = rng.integers(0, 1 << 24, N, dtype=np.uint32).view(np.float32)
+        p[:, 4] = rng.integers(0, 1 << 24, N, dtype=np.uint32).view(np.float32)
+        p[: N // 4, :2] = p[0, :2]
+        hip.input_pointcloud(p, ["x", "y", "z", "rgb", "rgb2", "a", "b", "c", "d", "e", "f"], R, t.copy(), 0.0, 0.0)
+        sm = hip.semantic_map.semantic_map
+        assert hip.semantic_map.layer_names == ["rgb", "rgb2", "a", "b", "c", "d", "e", "f"]
+        res.append(sm)
+    assert np.array_equal(res[0][:2].view(np.uint32), res[1][:2].view(np.uint32))
+    assert np.allclose(res[0][2:], res[1][2:], atol=1e-6, rtol=1e-6)
+    assert (res[0][0].view(np.uint32) != 0).sum() > 100
