@@ -80,6 +80,7 @@ struct emap_ctx {
   BinGeo bg; BinTmp* bin_tmp; BinRec* bin_recs; unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;
   // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
   float* img_uv; unsigned char* img_valid; float* img_buf; size_t img_cap;   // camera path
+  float* sem_alt; int sem_alt_layers;
   int sem_layers; float* sem; double* sem_sums; unsigned int* sem_col; unsigned int* cnt_plane;
   // point cloud
   float* pts_own; long pts_cap;    // owned buffer (floats)
@@ -240,7 +241,7 @@ int emap_destroy(emap_ctx* ctx) {
   hipFree(ctx->pts_f64); hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert);
   hipFree(ctx->bin_tmp); hipFree(ctx->bin_recs); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start);
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
-  hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
+  hipFree(ctx->sem_alt); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   for (int i = 0; i <= ST_N; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   if (ctx->t0) hipEventDestroy(ctx->t0);
   if (ctx->t1) hipEventDestroy(ctx->t1);
@@ -734,12 +735,14 @@ int emap_shift(emap_ctx* ctx, int32_t shift_rows, int32_t shift_cols, float dz) 
   CK(hipGetLastError());
   Cell* tmp = ctx->cells; ctx->cells = ctx->cells_alt; ctx->cells_alt = tmp;
   if (ctx->sem_layers > 0 && (shift_rows != 0 || shift_cols != 0)) {   // SemanticMap.shift_map_xy (semantic_map.py:127-136)
-    float* alt = nullptr;
-    CK(hipMalloc((void**)&alt, sizeof(float) * ctx->ncells_alloc * ctx->sem_layers));
-    launch_sem_shift(ctx->stream, ctx->prm.cell_n, ctx->sem_layers, ctx->sem, alt, shift_rows, shift_cols);
+    if (ctx->sem_alt_layers < ctx->sem_layers) {                       // persistent ping-pong buffer, grown with the layer store
+      if (ctx->sem_alt) { CK(hipStreamSynchronize(ctx->stream)); CK(hipFree(ctx->sem_alt)); ctx->sem_alt = nullptr; ctx->sem_alt_layers = 0; }
+      CK(hipMalloc((void**)&ctx->sem_alt, sizeof(float) * ctx->ncells_alloc * ctx->sem_layers));
+      ctx->sem_alt_layers = ctx->sem_layers;
+    }
+    launch_sem_shift(ctx->stream, ctx->prm.cell_n, ctx->sem_layers, ctx->sem, ctx->sem_alt, shift_rows, shift_cols);
     CK(hipGetLastError());
-    CK(hipStreamSynchronize(ctx->stream));
-    CK(hipFree(ctx->sem)); ctx->sem = alt;
+    float* tmp_s = ctx->sem; ctx->sem = ctx->sem_alt; ctx->sem_alt = tmp_s;
   }
   return EMAP_OK;
 }
