@@ -499,24 +499,36 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
       rval[r * rp + cc] = val; rmsk[r * rp + cc] = msk;
     }
   __syncthreads();
+  // dilated tile: known positions are a copy; the (usually few, scattered) holes are first COMPACTED into an LDS list
+  // and then searched one hole per lane -- a hole-containing wave would otherwise drag all 64 lanes through the
+  // neighbour search (measured: 11 of 33 us with 1.5 % holes).
+  unsigned short* holes = reinterpret_cast<unsigned short*>(sval + PT_R * PT_C);
+  __shared__ unsigned int n_holes;
+  if (threadIdx.x == 0) n_holes = 0u;
+  __syncthreads();
   for (int r = wv; r < DH; r += PT_WAVES)
     for (int cc = tc; cc < DW; cc += 64) {
       const int o0 = (r + d) * rp + (cc + d);
       const float mraw = rmsk[o0];
       const float own = mraw < 0.f ? -mraw - 1.f : mraw;
-      float res = rval[o0];
-      if (own < 0.5f) {                      // first hit on ascending anti-diagonals == reference scan order (:429-436)
-        bool found = false;
-        for (int s2 = -2 * d; s2 <= 2 * d && !found; ++s2) {
-          const int dy0 = max(-d, s2 - d), dy1 = min(d, s2 + d);
-          for (int dy = dy0; dy <= dy1; ++dy) {
-            const int o = o0 + dy * rp + (s2 - dy);
-            if (rmsk[o] > 0.5f) { res = rval[o]; found = true; break; }
-          }
-        }
-      }
-      dil[r * dp + cc] = res;
+      dil[r * dp + cc] = rval[o0];
+      if (own < 0.5f) holes[atomicAdd(&n_holes, 1u)] = (unsigned short)(r * DW + cc);
     }
+  __syncthreads();
+  const unsigned int nh = n_holes;
+  for (unsigned int hi = threadIdx.x; hi < nh; hi += PT_THREADS) {
+    const int pos = holes[hi], r = pos / DW, cc = pos - r * DW;
+    const int o0 = (r + d) * rp + (cc + d);
+    // first hit on ascending anti-diagonals == the reference's scan order with its signed dx+dy criterion (:429-436)
+    bool found = false;
+    for (int s2 = -2 * d; s2 <= 2 * d && !found; ++s2) {
+      const int dy0 = max(-d, s2 - d), dy1 = min(d, s2 + d);
+      for (int dy = dy0; dy <= dy1; ++dy) {
+        const int o = o0 + dy * rp + (s2 - dy);
+        if (rmsk[o] > 0.5f) { dil[r * dp + cc] = rval[o]; found = true; break; }
+      }
+    }
+  }
   __syncthreads();
   const int col = tile_c + tc;
   if (col >= C) return;
@@ -745,7 +757,8 @@ void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, c
   if (tile_row0 + n_tile_rows > all_rows) n_tile_rows = all_rows - tile_row0;
   if (n_tile_rows <= 0) return;
   dim3 g((P.C + PT_C - 1) / PT_C, n_tile_rows), b(PT_THREADS);
-  size_t lds = sizeof(float) * ((size_t)2 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)(R + 6) * (PT_C + 6 + 1) + (size_t)R * PT_C);
+  size_t lds = sizeof(float) * ((size_t)2 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)(R + 6) * (PT_C + 6 + 1) + (size_t)R * PT_C)
+               + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;     // + hole list
   if (small) hipLaunchKernelGGL(k_post<4>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
   else hipLaunchKernelGGL(k_post<16>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
 }
