@@ -207,7 +207,7 @@ static Pose make_pose(const emap_ctx* ctx, const float R[9], const float t[3]) {
   Pose T;
   const bool h = ctx->prm.mode == EMAP_MODE_REFERENCE_FP16;
   for (int i = 0; i < 9; ++i) T.Rq[i] = h ? q16(R[i]) : R[i];
-  for (int i = 0; i < 3; ++i) { T.tq[i] = h ? q16(t[i]) : t[i]; T.t[i] = t[i]; }
+  for (int i = 0; i < 3; ++i) { T.tq[i] = h ? q16(t[i]) : t[i]; T.t[i] = t[i] + 0.0f; }   // -0.0 -> +0.0 (same arithmetic, see IdxLut)
   return T;
 }
 

@@ -168,7 +168,8 @@ template <int MODE, bool LUT> struct IdxLut {
   __device__ __forceinline__ int operator()(const KP& P, float q) const {
     if constexpr (!LUT) return axis_idx<MODE>(P, q);
     else {   // branch-free: clamp the magnitude into the tabulated range (sentinels hold the constant tails)
-      const unsigned int b = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)(q + 0.0f));   // -0 -> +0
+      // (-0.0 would select the negative tail: the host canonicalises t, the only way a sample coordinate becomes -0.0)
+      const unsigned int b = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)q);
       const unsigned int mag = b & 0x7fffu, sg = b >> 15;
       const unsigned int m = min(max(mag, lo_m1), hi) - lo_m1;
       return (int)t[(sg ? span : 0u) + m];
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
                                                  const Cell* __restrict__ cells, const AccF* __restrict__ acc,
                                                  AccR* __restrict__ accr, const float* __restrict__ normal,
                                                  long plane_stride, FrameDev* __restrict__ F,
-                                                 const unsigned long long* __restrict__ inert) {
+                                                 const unsigned long long* __restrict__ inert64) {
+  const unsigned int* __restrict__ inert = reinterpret_cast<const unsigned int*>(inert64);   // 32-bit words: cheaper shifts
   extern __shared__ unsigned int slut32[];
   const unsigned int span = LUT ? (unsigned int)(Rt.hi - Rt.lo) + 2u : 0u;
   float* sS = reinterpret_cast<float*>(slut32 + span);          // step table s_k staged in LDS (wave-uniform reads)
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
       float ray_length = fminf(norm, P.q_mrl);
       const float dec = (float)(-P.cs / ((double)ray_length / P.mrl));
       const int C = P.C;
-      const unsigned int halo_cells = (unsigned int)P.halo * (unsigned int)C;
+      const unsigned int halo_cells = (unsigned int)P.halo * (unsigned int)C, row0_cells = (unsigned int)P.row0 * (unsigned int)C;
       int last = -1;
       float s = nS > 0 ? sS[0] : INFINITY;
       for (int k = 0; k < nS; ++k) {
@@ -226,10 +228,10 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
                          ((unsigned int)(iy - 1) < (unsigned int)(C - 2)) & (lr < (unsigned int)P.nrows);
         last = nidx;
         if (!act) continue;
-        const unsigned int li = lr * (unsigned int)C + (unsigned int)iy;     // < 2^31 cells (checked at create)
+        const unsigned int li = (unsigned int)nidx - row0_cells;              // < 2^31 cells
         const unsigned int c = li + halo_cells;
         if (STATS) visits++;
-        if ((inert[li >> 6] >> (li & 63u)) & 1ull) continue;   // known + fresh cell: nothing can happen
+        if ((inert[li >> 5] >> (li & 31u)) & 1u) continue;     // known + fresh cell: nothing can happen
         const float4* cp = reinterpret_cast<const float4*>(&cells[c]);
         float4 m0 = cp[0], m1 = cp[1];             // h v valid trav | time upper is_upper pad
         float ddx = g.x - nx, ddy = g.y - ny, ddz = g.z - nz;
