@@ -15,7 +15,7 @@
 // launchers (emap_kernels.hip)
 void launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, ErrSlot*);
 void launch_gate(hipStream_t, const KP&, ErrSlot*, FrameDev*, int, double, double, float, int, int, double, unsigned int, unsigned int, int, double*, const double*);
-void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, const FrameDev*, int*, unsigned char*);
+void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, const FrameDev*);
 void launch_commit(hipStream_t, const KP&, Cell*, const AccF*, const FrameDev*, unsigned long long*);
 void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, const Cell*, const AccF*, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*);
 void launch_average(hipStream_t, const KP&, Cell*, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*);
@@ -510,28 +510,26 @@ int emap_local_drift_sums(emap_ctx* ctx, double* err_sum, uint32_t* err_cnt) {
   return EMAP_OK;
 }
 
-static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool tail, bool fuse_average = false) {
+static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool fuse_average = false) {
   NEED_POINTS();
   CK(hipSetDevice(ctx->device));
-  if (tail) { int rc = ensure_tail(ctx); if (rc) return rc; }
-  if (ctx->frame_binned && !tail) {
+  if (ctx->frame_binned) {
     launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame, fuse_average,
                     ctx->cnt_plane);
     CK(hipGetLastError());
     return EMAP_OK;
   }
-  launch_fuse(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->frame,
-              tail ? ctx->tail_idx : nullptr, tail ? ctx->tail_flags : nullptr);
+  launch_fuse(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->frame);
   CK(hipGetLastError());
   return EMAP_OK;
 }
-int emap_fuse(emap_ctx* ctx, const float R[9], const float t[3]) { CKARG(ctx && R && t, "null argument"); return fuse_impl(ctx, R, t, false); }
+int emap_fuse(emap_ctx* ctx, const float R[9], const float t[3]) { CKARG(ctx && R && t, "null argument"); return fuse_impl(ctx, R, t); }
 
 // fuse + commit + average_map in one call for frames without a visibility pass (one tile kernel on the binned path)
 int emap_fuse_average(emap_ctx* ctx, const float R[9], const float t[3]) {
   CKARG(ctx && R && t, "null argument");
   const bool fused = ctx->frame_binned;
-  int rc = fuse_impl(ctx, R, t, false, fused);
+  int rc = fuse_impl(ctx, R, t, fused);
   if (rc) return rc;
   if (!fused) launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, false, ctx->cnt_plane);
   ctx->committed = false;
@@ -654,7 +652,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   STAGE(ST_FUSE);
   // no visibility pass + binned scatter: fusion, commit and averaging happen in ONE tile kernel
   const bool fused_avg = ctx->frame_binned && !p.enable_visibility_cleanup;
-  if ((rc = fuse_impl(ctx, R, t, false, fused_avg))) return rc;
+  if ((rc = fuse_impl(ctx, R, t, fused_avg))) return rc;
   STAGE(ST_COMMIT);
   if (p.enable_visibility_cleanup) {
     if ((rc = emap_commit(ctx))) return rc;

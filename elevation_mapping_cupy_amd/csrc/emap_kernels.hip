@@ -79,20 +79,15 @@ __global__ __launch_bounds__(64) void k_gate(KP P, ErrSlot* __restrict__ slots, 
 // Phase B: Kalman fusion (add_points_kernel fusion part, custom_kernels.py:160-197) against snapshot S0.
 // Reads (h, v) + points-per-cell, writes ONLY accumulators: <= 4 64-bit integer atomics into one 40-B record.
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE, bool TAIL>
+template <int MODE>
 __global__ __launch_bounds__(EM_BLOCK) void k_fuse(KP P, Pose T, const float* __restrict__ pts, long n, int stride,
                                                     const Cell* __restrict__ cells, AccF* __restrict__ acc,
-                                                    const FrameDev* __restrict__ F, int* __restrict__ tail_idx,
-                                                    unsigned char* __restrict__ tail_flags) {
+                                                    const FrameDev* __restrict__ F) {
   long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (i >= n) return;
   float rx, ry, rz;
   load_point(pts, i, stride, rx, ry, rz);
   Geo g = geometry<MODE>(P, T, rx, ry, rz);
-  if (TAIL) {
-    tail_idx[i] = g.finite ? P.C * g.ix + g.iy : -1;
-    tail_flags[i] = g.finite ? (unsigned char)((g.valid ? 1 : 0) | (g.inside ? 2 : 0)) : 0;
-  }
   long c = (g.finite && g.valid && g.inside) ? owned_cell(P, g.ix, g.iy) : -1;
   if (c < 0) return;
   const float shift = F->shift;
@@ -675,16 +670,11 @@ void launch_gate(hipStream_t s, const KP& P, ErrSlot* slots, FrameDev* F, int en
                      sum_override, cnt_override, n_points, reduce_only, dev_out, dev_totals);
 }
 void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, const Cell* cells, AccF* acc,
-                 const FrameDev* F, int* tail_idx, unsigned char* tail_flags) {
+                 const FrameDev* F) {
   if (n <= 0) return;
   dim3 g(nblk(n)), b(EM_BLOCK);
-  if (tail_idx) {
-    if (P.mode == 0) hipLaunchKernelGGL((k_fuse<0, true>), g, b, 0, s, P, T, pts, n, stride, cells, acc, F, tail_idx, tail_flags);
-    else hipLaunchKernelGGL((k_fuse<1, true>), g, b, 0, s, P, T, pts, n, stride, cells, acc, F, tail_idx, tail_flags);
-  } else {
-    if (P.mode == 0) hipLaunchKernelGGL((k_fuse<0, false>), g, b, 0, s, P, T, pts, n, stride, cells, acc, F, tail_idx, tail_flags);
-    else hipLaunchKernelGGL((k_fuse<1, false>), g, b, 0, s, P, T, pts, n, stride, cells, acc, F, tail_idx, tail_flags);
-  }
+  if (P.mode == 0) hipLaunchKernelGGL(k_fuse<0>, g, b, 0, s, P, T, pts, n, stride, cells, acc, F);
+  else hipLaunchKernelGGL(k_fuse<1>, g, b, 0, s, P, T, pts, n, stride, cells, acc, F);
 }
 void launch_commit(hipStream_t s, const KP& P, Cell* cells, const AccF* acc, const FrameDev* F, unsigned long long* inert) {
   hipLaunchKernelGGL(k_commit, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, acc, F, inert);

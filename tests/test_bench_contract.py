@@ -1,0 +1,29 @@
+"""GPU: bench.py prints exactly one JSON line with the fields the driver reads (small sizes, seconds)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3"])
+def test_bench_json_contract(workload):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--workload", workload,
+                          "--cell-n", "202", "--points", "40000", "--cpu-points", "5000"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must hold ONE JSON line, got: %r" % lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["value"] > 0 and d["unit"] == "Mpoints/s" and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and c["unit"] == "Mpoints/s" and c["sample"]
