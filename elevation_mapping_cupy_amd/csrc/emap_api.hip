@@ -3,6 +3,7 @@
 // emap_kernels.hip on ONE stream in the order of the reference's update_map_with_kernel
 // (EM/elevation_mapping.py:316-391).  No per-frame allocation, no D2H sync inside a frame unless stats are asked for.
 #include "emap_device.h"
+#include <cstddef>
 #include "../../include/emap_hip.h"
 #include <cmath>
 #include <cstdio>
@@ -19,11 +20,9 @@ void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, c
 void launch_commit(hipStream_t, const KP&, Cell*, const AccF*, const FrameDev*, unsigned long long*);
 void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, const Cell*, const AccF*, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*);
 void launch_average(hipStream_t, const KP&, Cell*, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*);
-#define SEM_MAX_CH 16
-struct SemSpec { int n_sum; int sum_chan[SEM_MAX_CH]; int sum_layer[SEM_MAX_CH]; int sum_kind[SEM_MAX_CH]; int n_col; int col_chan[4]; int col_layer[4]; double alpha; };
-static_assert(sizeof(SemSpec) == sizeof(emap_sem_spec), "emap_sem_spec layout");
+static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
-void launch_sem_finalize(hipStream_t, const KP&, const SemSpec&, const unsigned int*, double*, unsigned int*, float*, long);
+void launch_sem_finalize(hipStream_t, const KP&, const SemSpec&, const unsigned int*, double*, unsigned int*, float*, float*, long);
 void launch_sem_shift(hipStream_t, int, int, const float*, float*, int, int);
 struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; };
 void launch_image_corr(hipStream_t, const KP&, const CamArgs&, const Cell*, float*, unsigned char*);
@@ -50,8 +49,8 @@ struct BinRec { unsigned int lc_inl; float z, v; unsigned int i; };
 void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, BinTmp*, unsigned int*);
 void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*);
 void launch_bin_scatter(hipStream_t, const KP&, const BinGeo&, const BinTmp*, long, const unsigned int*, const unsigned int*, const Cell*, BinRec*, ErrSlot*);
-void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const void*, const BinRec*, const unsigned int*, const float*, long, int,
-                          const unsigned int*, float*, long);
+void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const float*, long, int,
+                          const unsigned int*, float*, float*, long);
 void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cell*, AccF*, const FrameDev*, bool, unsigned int*);
 #define BIN_MAX_T 16384
 #define BIN_MAX_B 2048
@@ -81,6 +80,7 @@ struct emap_ctx {
   // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
   float* img_uv; unsigned char* img_valid; float* img_buf; size_t img_cap;   // camera path
   float* sem_alt; int sem_alt_layers;
+  float* sem_alpha;   // class_bayesian pseudo-counts (the reference's persistent new_map layers), sem_layers planes, on demand
   int sem_layers; float* sem; double* sem_sums; unsigned int* sem_col; unsigned int* cnt_plane;
   // point cloud
   float* pts_own; long pts_cap;    // owned buffer (floats)
@@ -241,7 +241,7 @@ int emap_destroy(emap_ctx* ctx) {
   hipFree(ctx->pts_f64); hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert);
   hipFree(ctx->bin_tmp); hipFree(ctx->bin_recs); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start);
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
-  hipFree(ctx->sem_alt); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
+  hipFree(ctx->sem_alt); hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   for (int i = 0; i <= ST_N; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   if (ctx->t0) hipEventDestroy(ctx->t0);
   if (ctx->t1) hipEventDestroy(ctx->t1);
@@ -741,6 +741,11 @@ int emap_shift(emap_ctx* ctx, int32_t shift_rows, int32_t shift_cols, float dz) 
     launch_sem_shift(ctx->stream, ctx->prm.cell_n, ctx->sem_layers, ctx->sem, ctx->sem_alt, shift_rows, shift_cols);
     CK(hipGetLastError());
     float* tmp_s = ctx->sem; ctx->sem = ctx->sem_alt; ctx->sem_alt = tmp_s;
+    if (ctx->sem_alpha) {     // new_map is rolled and zero-padded like the layers (semantic_map.py:135-136)
+      launch_sem_shift(ctx->stream, ctx->prm.cell_n, ctx->sem_layers, ctx->sem_alpha, ctx->sem_alt, shift_rows, shift_cols);
+      CK(hipGetLastError());
+      tmp_s = ctx->sem_alpha; ctx->sem_alpha = ctx->sem_alt; ctx->sem_alt = tmp_s;
+    }
   }
   return EMAP_OK;
 }
@@ -763,11 +768,26 @@ int emap_semantic_configure(emap_ctx* ctx, int32_t n_layers) {
     CK(hipMemsetAsync(ns, 0, sizeof(float) * n * n_layers, ctx->stream));
     CK(hipMemsetAsync(nq, 0, sizeof(double) * n * n_layers, ctx->stream));
     if (ctx->sem_layers > 0) CK(hipMemcpyAsync(ns, ctx->sem, sizeof(float) * n * ctx->sem_layers, hipMemcpyDeviceToDevice, ctx->stream));
+    if (ctx->sem_alpha) {
+      float* na = nullptr;
+      CK(hipMalloc((void**)&na, sizeof(float) * n * n_layers));
+      CK(hipMemsetAsync(na, 0, sizeof(float) * n * n_layers, ctx->stream));
+      CK(hipMemcpyAsync(na, ctx->sem_alpha, sizeof(float) * n * ctx->sem_layers, hipMemcpyDeviceToDevice, ctx->stream));
+      CK(hipStreamSynchronize(ctx->stream));
+      CK(hipFree(ctx->sem_alpha)); ctx->sem_alpha = na;
+    }
     CK(hipStreamSynchronize(ctx->stream));
     if (ctx->sem) CK(hipFree(ctx->sem));
     if (ctx->sem_sums) CK(hipFree(ctx->sem_sums));
     ctx->sem = ns; ctx->sem_sums = nq; ctx->sem_layers = n_layers;
   }
+  return EMAP_OK;
+}
+
+static int ensure_alpha(emap_ctx* ctx) {
+  if (ctx->sem_alpha || ctx->sem_layers == 0) return EMAP_OK;
+  CK(hipMalloc((void**)&ctx->sem_alpha, sizeof(float) * ctx->ncells_alloc * ctx->sem_layers));
+  CK(hipMemsetAsync(ctx->sem_alpha, 0, sizeof(float) * ctx->ncells_alloc * ctx->sem_layers, ctx->stream));
   return EMAP_OK;
 }
 
@@ -780,17 +800,46 @@ int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], cons
   for (int k = 0; k < spec->n_col; ++k)
     CKARG(spec->col_layer[k] >= 0 && spec->col_layer[k] < ctx->sem_layers && spec->col_chan[k] >= 3 && spec->col_chan[k] < ctx->stride, "bad colour channel/layer index");
   CK(hipSetDevice(ctx->device));
+  SemSpec S; memset(&S, 0, sizeof S); memcpy(&S, spec, sizeof *spec);
+  int nk[4] = {0, 0, 0, 0};
+  for (int k = 0; k < S.n_sum; ++k) { CKARG(S.sum_kind[k] >= 0 && S.sum_kind[k] <= 3, "bad fusion kind"); nk[S.sum_kind[k]]++; }
+  int seen[4] = {0, 0, 0, 0};
+  for (int k = 0; k < S.n_sum; ++k) {
+    const int kind = S.sum_kind[k];
+    S.sum_K[k] = kind >= 2 ? nk[kind] : 1;
+    S.sum_q[k] = kind >= 2 ? seen[kind]++ : 0;
+  }
+  S.any_bayes = nk[2] > 0;
+  if (S.any_bayes) { int rc = ensure_alpha(ctx); if (rc) return rc; }
   if (ctx->frame_binned) {   // the frame's tile-sorted records are still valid: reduce in LDS, no global atomics
-    launch_tile_semantic(ctx->stream, ctx->kp, ctx->bg, spec, ctx->bin_recs, ctx->bin_tile_start, ctx->pts, ctx->n_pts, ctx->stride,
-                         ctx->cnt_plane, ctx->sem, ctx->ncells_alloc);
+    launch_tile_semantic(ctx->stream, ctx->kp, ctx->bg, S, ctx->bin_recs, ctx->bin_tile_start, ctx->pts, ctx->n_pts, ctx->stride,
+                         ctx->cnt_plane, ctx->sem, ctx->sem_alpha, ctx->ncells_alloc);
     CK(hipGetLastError());
     return EMAP_OK;
   }
-  SemSpec S; memcpy(&S, spec, sizeof S);
   launch_sem_points(ctx->stream, ctx->kp, make_pose(ctx, R, t), S, ctx->pts, ctx->n_pts, ctx->stride, ctx->sem_sums, ctx->sem_col, ctx->ncells_alloc);
-  launch_sem_finalize(ctx->stream, ctx->kp, S, ctx->cnt_plane, ctx->sem_sums, ctx->sem_col, ctx->sem, ctx->ncells_alloc);
+  launch_sem_finalize(ctx->stream, ctx->kp, S, ctx->cnt_plane, ctx->sem_sums, ctx->sem_col, ctx->sem, ctx->sem_alpha, ctx->ncells_alloc);
   CK(hipGetLastError());
   return EMAP_OK;
+}
+
+static int alpha_copy(emap_ctx* ctx, int32_t layer, float* host_out, const float* host_in) {
+  CK(hipSetDevice(ctx->device));
+  int rc = ensure_alpha(ctx); if (rc) return rc;
+  const long off = (long)layer * ctx->ncells_alloc + (long)ctx->strip.halo_rows * ctx->prm.cell_n;
+  const size_t bytes = sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n;
+  if (host_out) CK(hipMemcpyAsync(host_out, ctx->sem_alpha + off, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  else CK(hipMemcpyAsync(ctx->sem_alpha + off, host_in, bytes, hipMemcpyHostToDevice, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
+  return EMAP_OK;
+}
+int emap_semantic_get_alpha(emap_ctx* ctx, int32_t layer, float* host_out) {
+  CKARG(ctx && host_out && layer >= 0 && layer < ctx->sem_layers, "bad argument");
+  return alpha_copy(ctx, layer, host_out, nullptr);
+}
+int emap_semantic_set_alpha(emap_ctx* ctx, int32_t layer, const float* host_in) {
+  CKARG(ctx && host_in && layer >= 0 && layer < ctx->sem_layers, "bad argument");
+  return alpha_copy(ctx, layer, nullptr, host_in);
 }
 
 int emap_semantic_get_layer(emap_ctx* ctx, int32_t layer, float* host_out) {

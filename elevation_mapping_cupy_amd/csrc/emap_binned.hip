@@ -227,17 +227,12 @@ void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* 
 // (average / class_average / packed colour) and writes the semantic planes directly -- no accumulator planes in HBM.
 // Channels are processed in groups of 4 (32 KB of fp64 LDS accumulators per group).
 // ---------------------------------------------------------------------------------------------------------
-#define SEM_MAX_CH 16
-struct SemSpecB {
-  int n_sum; int sum_chan[SEM_MAX_CH]; int sum_layer[SEM_MAX_CH]; int sum_kind[SEM_MAX_CH];
-  int n_col; int col_chan[4]; int col_layer[4];
-  double alpha;
-};
+typedef SemSpec SemSpecB;
 #define SEM_GROUP 4
 __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemSpecB S, const BinRec* __restrict__ recs,
                                                              const unsigned int* __restrict__ tile_start, const float* __restrict__ pts,
                                                              long n, int stride, const unsigned int* __restrict__ cnt_plane,
-                                                             float* __restrict__ sem, long plane) {
+                                                             float* __restrict__ sem, float* __restrict__ alpha_planes, long plane) {
   constexpr int NC = BIN_TR * BIN_TC;
   __shared__ double s_sum[SEM_GROUP][NC];
   __shared__ unsigned int s_col[4][NC];                 // r, g, b, count of ONE colour layer at a time
@@ -252,7 +247,15 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
       const BinRec r = recs[k];
       const unsigned int lc = r.lc_inl & 0x7fffffffu;
       const float* p = pts + (long)r.i * stride;
-      for (int q = 0; q < ng; ++q) unsafeAtomicAdd(&s_sum[q][lc], (double)p[S.sum_chan[g0 + q]]);
+      for (int q = 0; q < ng; ++q) {
+        const float v = p[S.sum_chan[g0 + q]];
+        const int kind = S.sum_kind[g0 + q];
+        if (kind >= 2) {                                                              // compact kernels: id * K + q < N, theta >= 0
+          if ((long)r.i * S.sum_K[g0 + q] + S.sum_q[g0 + q] >= n) continue;
+          if (kind == 2 && !(v >= 0.0f)) continue;
+        }
+        unsafeAtomicAdd(&s_sum[q][lc], (double)v);
+      }
     }
     __syncthreads();
     if (col < P.C) {
@@ -261,11 +264,19 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
         if (lrow >= P.nrows) break;
         const long c = (long)(lrow + P.halo) * P.C + col;
         const unsigned int cnt = cnt_plane[c];               // accepted HEIGHT points (new_elmap plane 2, :185)
-        if (cnt == 0) continue;
         for (int q = 0; q < ng; ++q) {
           const long j = (long)S.sum_layer[g0 + q] * plane + c;
           const double s = s_sum[q][tr * BIN_TC + tc];
-          if (S.sum_kind[g0 + q] == 0) sem[j] = (float)(s / (double)cnt);
+          const int kind = S.sum_kind[g0 + q];
+          if (kind == 2) alpha_planes[j] = (float)((double)alpha_planes[j] + s);   // every cell; renormalised below
+          else if (kind == 3) {
+            const long gcell = (long)(P.row0 + lrow) * P.C + col;
+            if (cnt > 0 && gcell * S.sum_K[g0 + q] + S.sum_q[g0 + q] < (long)P.C * P.C) {
+              const float cn = (float)cnt, feat_ml = (float)s / cn, sigma_old = 0.0f, sigma = 1.0f;
+              sem[j] = sigma * sem[j] / (cn * sigma_old + sigma) + cn * sigma_old * feat_ml / (cn * sigma_old + sigma);
+            }
+          } else if (cnt == 0) continue;
+          else if (kind == 0) sem[j] = (float)(s / (double)cnt);
           else {
             const float prev = sem[j];
             sem[j] = (prev == 0.0f) ? (float)(s / (double)cnt) : (float)(S.alpha * (double)prev + (1.0 - S.alpha) * s / (double)cnt);
@@ -274,6 +285,17 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
       }
     }
     __syncthreads();
+  }
+  if (S.any_bayes && col < P.C) {     // class_bayesian: theta = alpha / sum(alpha) over its layers, same thread <-> same cells as above
+    for (int k = 0; k < BIN_TR / 4; ++k) {
+      const int tr = wv + 4 * k, lrow = ty * BIN_TR + tr;
+      if (lrow >= P.nrows) break;
+      const long c = (long)(lrow + P.halo) * P.C + col;
+      float tot = 0.0f;
+      for (int q = 0; q < S.n_sum; ++q) if (S.sum_kind[q] == 2) tot += alpha_planes[(long)S.sum_layer[q] * plane + c];
+      if (tot == 0.0f) tot = 1.0f;
+      for (int q = 0; q < S.n_sum; ++q) if (S.sum_kind[q] == 2) { const long j = (long)S.sum_layer[q] * plane + c; sem[j] = alpha_planes[j] / tot; }
+    }
   }
   if (S.n_col > 0) {
     const int K = S.n_col;
@@ -314,8 +336,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
     }
   }
 }
-void launch_tile_semantic(hipStream_t s, const KP& P, const BinGeo& G, const void* spec, const BinRec* recs, const unsigned int* tile_start,
-                          const float* pts, long n, int stride, const unsigned int* cnt_plane, float* sem, long plane) {
-  SemSpecB S; memcpy(&S, spec, sizeof S);
-  hipLaunchKernelGGL(k_tile_semantic, dim3(G.T), dim3(EM_BLOCK), 0, s, P, G, S, recs, tile_start, pts, n, stride, cnt_plane, sem, plane);
+void launch_tile_semantic(hipStream_t s, const KP& P, const BinGeo& G, const SemSpec& S, const BinRec* recs, const unsigned int* tile_start,
+                          const float* pts, long n, int stride, const unsigned int* cnt_plane, float* sem, float* alpha_planes, long plane) {
+  hipLaunchKernelGGL(k_tile_semantic, dim3(G.T), dim3(EM_BLOCK), 0, s, P, G, S, recs, tile_start, pts, n, stride, cnt_plane, sem, alpha_planes, plane);
 }

@@ -166,3 +166,16 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// Per-frame description of the RGB / semantic point fusion.  The leading members mirror emap_sem_spec (include/emap_hip.h);
+// sum_K / sum_q are derived by emap_semantic_update: kinds 2 (class_bayesian) and 3 (bayesian_inference) reproduce the
+// reference launch decode id = i / K, layer = i % K with size N (fusion/pointcloud_class_bayesian.py:28-29,67;
+// fusion/pointcloud_bayesian_inference.py:28-29,111), i.e. element (point id, q-th channel of that fusion) exists only
+// while id * K + q < N.  Kinds 0 / 1 carry K = 1, q = 0.
+#define SEM_MAX_CH 16
+struct SemSpec {
+  int n_sum; int sum_chan[SEM_MAX_CH]; int sum_layer[SEM_MAX_CH]; int sum_kind[SEM_MAX_CH];   // kind 0 average, 1 class_average, 2 class_bayesian, 3 bayesian_inference
+  int n_col; int col_chan[4]; int col_layer[4];
+  double alpha;                                                                                // Parameter.average_weight
+  int sum_K[SEM_MAX_CH]; int sum_q[SEM_MAX_CH]; int any_bayes; int pad0;
+};

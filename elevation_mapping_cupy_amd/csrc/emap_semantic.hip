@@ -7,12 +7,6 @@
 // One point pass for ALL float channels (one xyz read, K atomics), one cell pass that finalises and re-arms.
 #include "emap_device.h"
 
-#define SEM_MAX_CH 16
-struct SemSpec {
-  int n_sum; int sum_chan[SEM_MAX_CH]; int sum_layer[SEM_MAX_CH]; int sum_kind[SEM_MAX_CH];   // kind 0 average, 1 class_average
-  int n_col; int col_chan[4]; int col_layer[4];
-  double alpha;                                                                                // Parameter.average_weight
-};
 
 template <int MODE>
 __global__ __launch_bounds__(EM_BLOCK) void k_sem_sum(KP P, Pose T, SemSpec S, const float* __restrict__ pts, long n, int stride,
@@ -25,7 +19,14 @@ __global__ __launch_bounds__(EM_BLOCK) void k_sem_sum(KP P, Pose T, SemSpec S, c
   long c = (g.finite && g.valid && g.inside) ? owned_cell(P, g.ix, g.iy) : -1;   // valid && inside (:41-45)
   if (c < 0) return;
   const float* p = pts + i * (long)stride;
-  for (int k = 0; k < S.n_sum; ++k) unsafeAtomicAdd(&sums[(long)S.sum_layer[k] * plane + c], (double)p[S.sum_chan[k]]);
+  for (int k = 0; k < S.n_sum; ++k) {
+    const float v = p[S.sum_chan[k]];
+    if (S.sum_kind[k] >= 2) {
+      if (i * S.sum_K[k] + S.sum_q[k] >= n) continue;          // launch-size quirk of the compact kernels
+      if (S.sum_kind[k] == 2 && !(v >= 0.0f)) continue;        // alpha_kernel: theta < 0 (or NaN) adds nothing (:36-41)
+    }
+    unsafeAtomicAdd(&sums[(long)S.sum_layer[k] * plane + c], (double)v);
+  }
 }
 
 // add_color_kernel (:270-317).  The reference launches it with size = N while decoding id = i / K, layer = i % K
@@ -54,15 +55,25 @@ __global__ __launch_bounds__(EM_BLOCK) void k_sem_color(KP P, Pose T, SemSpec S,
 // (the reference zeroes new_map with a boolean-mask assignment and allocates a fresh colour map every frame).
 __global__ __launch_bounds__(EM_BLOCK) void k_sem_finalize(KP P, SemSpec S, const unsigned int* __restrict__ cnt_plane,
                                                             double* __restrict__ sums, unsigned int* __restrict__ col,
-                                                            float* __restrict__ sem, long plane) {
+                                                            float* __restrict__ sem, float* __restrict__ alpha_planes, long plane) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
   long c = li + (long)P.halo * P.C;
   const unsigned int cnt = cnt_plane[c];          // accepted HEIGHT points of this frame (new_elmap plane 2, :185)
+  float tot = 0.0f;
   for (int k = 0; k < S.n_sum; ++k) {
     const long j = (long)S.sum_layer[k] * plane + c;
     const double s = sums[j];
-    if (cnt > 0) {
+    if (S.sum_kind[k] == 2) {                      // class_bayesian: pseudo-counts persist (semantic_map.py:54-56), every cell
+      const float a = (float)((double)alpha_planes[j] + s);
+      alpha_planes[j] = a; tot += a;
+    } else if (S.sum_kind[k] == 3) {               // bayesian_inference, literally (pointcloud_bayesian_inference.py:64-76):
+      const long gcell = li + (long)P.row0 * P.C;  // the prior variance layer is zeroed every frame => sigma_old = 0
+      if (cnt > 0 && gcell * S.sum_K[k] + S.sum_q[k] < (long)P.C * P.C) {
+        const float cn = (float)cnt, feat_ml = (float)s / cn, sigma_old = 0.0f, sigma = 1.0f;
+        sem[j] = sigma * sem[j] / (cn * sigma_old + sigma) + cn * sigma_old * feat_ml / (cn * sigma_old + sigma);
+      }
+    } else if (cnt > 0) {
       if (S.sum_kind[k] == 0) sem[j] = (float)(s / (double)cnt);
       else {
         const float prev = sem[j];
@@ -71,6 +82,10 @@ __global__ __launch_bounds__(EM_BLOCK) void k_sem_finalize(KP P, SemSpec S, cons
       }
     }
     if (s != 0.0) sums[j] = 0.0;
+  }
+  if (S.any_bayes) {                               // theta = alpha / sum(alpha), 1 where the sum is 0 (pointcloud_class_bayesian.py:70-75)
+    if (tot == 0.0f) tot = 1.0f;
+    for (int k = 0; k < S.n_sum; ++k) if (S.sum_kind[k] == 2) { const long j = (long)S.sum_layer[k] * plane + c; sem[j] = alpha_planes[j] / tot; }
   }
   if (S.n_col > 0) {
     const int K = S.n_col;
@@ -109,8 +124,8 @@ void launch_sem_points(hipStream_t s, const KP& P, const Pose& T, const SemSpec&
   }
 }
 void launch_sem_finalize(hipStream_t s, const KP& P, const SemSpec& S, const unsigned int* cnt_plane, double* sums, unsigned int* col,
-                         float* sem, long plane) {
-  hipLaunchKernelGGL(k_sem_finalize, dim3(nblk_((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, S, cnt_plane, sums, col, sem, plane);
+                         float* sem, float* alpha_planes, long plane) {
+  hipLaunchKernelGGL(k_sem_finalize, dim3(nblk_((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, S, cnt_plane, sums, col, sem, alpha_planes, plane);
 }
 void launch_sem_shift(hipStream_t s, int C, int nl, const float* src, float* dst, int sr, int sc) {
   hipLaunchKernelGGL(k_sem_shift, dim3(nblk_((long)C * C)), dim3(EM_BLOCK), 0, s, C, nl, src, dst, sr, sc);

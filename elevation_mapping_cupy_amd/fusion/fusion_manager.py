@@ -15,7 +15,7 @@ class FusionBase(ABC):
     @abstractmethod
     def __init__(self, *args, **kwargs):
         self.name = None
-        self.kind = None  # "average" | "class_average" | "color"
+        self.kind = None  # "average" | "class_average" | "class_bayesian" | "bayesian_inference" | "color"
 
 
 class FusionManager(object):
@@ -27,7 +27,7 @@ class FusionManager(object):
 
     def register_plugin(self, plugin):
         """``plugin`` = module name under ``elevation_mapping_cupy_amd.fusion`` (e.g. ``pointcloud_average``).
-        Unsupported reference fusions (image_*, bayesian, class_max) are reported and skipped."""
+        The one reference fusion without a device implementation (pointcloud_class_max) is reported and skipped."""
         try:
             m = importlib.import_module("." + plugin, package="elevation_mapping_cupy_amd.fusion")
         except ImportError:

@@ -15,7 +15,7 @@ import numpy as np
 from ._lib import EmapSemSpec, f32p
 from .fusion.fusion_manager import FusionManager
 
-_KIND = {"average": 0, "class_average": 1}
+_KIND = {"average": 0, "class_average": 1, "class_bayesian": 2, "bayesian_inference": 3}
 
 
 class SemanticMap:
@@ -40,7 +40,7 @@ class SemanticMap:
             self.fusion_manager.register_plugin(fusion)
 
     def update_fusion_setting(self):
-        pass  # only needed by the class_bayesian / class_max fusions (not on this path)
+        pass  # the reference re-flags persistent new_map layers here (:64-78); the alpha planes of the device store need no flag
 
     def add_layer(self, name):
         if name not in self.layer_names:
@@ -160,6 +160,18 @@ class SemanticMap:
         idx = self.layer_names.index(name_or_idx) if isinstance(name_or_idx, str) else int(name_or_idx)
         a = np.ascontiguousarray(array, np.float32)
         self._emap._chk(self._emap._lib.emap_semantic_set_layer(self._emap._ctx, idx, f32p(a)))
+
+    # the reference's persistent ``new_map`` layers of the class_bayesian fusion (semantic_map.py:54-56): Dirichlet pseudo-counts
+    def get_alpha(self, name_or_idx):
+        idx = self.layer_names.index(name_or_idx) if isinstance(name_or_idx, str) else int(name_or_idx)
+        out = np.empty((self._emap.rows, self._emap.cell_n), np.float32)
+        self._emap._chk(self._emap._lib.emap_semantic_get_alpha(self._emap._ctx, idx, f32p(out)))
+        return out
+
+    def set_alpha(self, name_or_idx, array):
+        idx = self.layer_names.index(name_or_idx) if isinstance(name_or_idx, str) else int(name_or_idx)
+        a = np.ascontiguousarray(array, np.float32)
+        self._emap._chk(self._emap._lib.emap_semantic_set_alpha(self._emap._ctx, idx, f32p(a)))
 
     def get_index(self, name):
         return self.layer_names.index(name) if name in self.layer_names else -1

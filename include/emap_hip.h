@@ -138,7 +138,10 @@ int emap_publish_layer(emap_ctx* ctx, int32_t kind, float center_z, int32_t use_
 int emap_shift(emap_ctx* ctx, int32_t shift_rows, int32_t shift_cols, float dz);
 
 /* ---- RGB / semantic point-cloud fusion (EM/semantic_map.py:223-259; kernels EM/kernels/custom_semantic_kernels.py:
- * sum :9-51 + average :167-194 (kind 0) or class_average :233-267 (kind 1); add_color :270-317 + color_average :320-375).
+ * sum :9-51 + average :167-194 (kind 0) or class_average :233-267 (kind 1); add_color :270-317 + color_average :320-375;
+ * kind 2 = class_bayesian (EM/fusion/pointcloud_class_bayesian.py:12-75: alpha kernel + renormalisation over the kind-2 layers
+ * of the call, pseudo-counts persist in the "alpha" planes = the reference's new_map layers, semantic_map.py:54-56);
+ * kind 3 = bayesian_inference (EM/fusion/pointcloud_bayesian_inference.py:12-122, restated literally).
  * Channel indices are column indices of the bound cloud (>= 3), layer indices address the semantic layer store. */
 typedef struct emap_sem_spec {
   int32_t n_sum, sum_chan[16], sum_layer[16], sum_kind[16];
@@ -149,7 +152,9 @@ int emap_semantic_configure(emap_ctx* ctx, int32_t n_layers);                 /*
 int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], const emap_sem_spec* spec); /* after emap_update */
 int emap_semantic_get_layer(emap_ctx* ctx, int32_t layer, float* host_out);
 int emap_semantic_set_layer(emap_ctx* ctx, int32_t layer, const float* host_in);
-int emap_semantic_clear(emap_ctx* ctx);                                        /* SemanticMap.clear */
+int emap_semantic_clear(emap_ctx* ctx);                                        /* SemanticMap.clear (layers only, :47-49) */
+int emap_semantic_get_alpha(emap_ctx* ctx, int32_t layer, float* host_out);    /* SemanticMap.new_map[layer] of a class_bayesian layer */
+int emap_semantic_set_alpha(emap_ctx* ctx, int32_t layer, const float* host_in);
 
 /* MinFilter plugin (EM/plugins/min_filter.py:84-118): fills cells with valid < 0.5 by the window minimum of already
  * filled values, up to iteration_n sweeps, stops after the sweep that filled everything; NaN where still unfilled.

@@ -116,6 +116,13 @@ def _instantiate(p):
                                       {"x1", "y1", "z1", "image_height", "image_width"})
         ks["image_exponential"] = (ik.exponential_correspondences_to_map_kernel(C, C, 0.7), f32, {"map_idx", "image_height", "image_width"})
         ks["image_color"] = (ik.color_correspondences_to_map_kernel(C, C), f32, {"map_idx", "image_height", "image_width"})
+    if p.get("bayes_kernels"):
+        # point fusions that keep their kernels inside the plugin module (reference fusion/pointcloud_class_bayesian.py:12-53,
+        # fusion/pointcloud_bayesian_inference.py:12-83)
+        cb, bi = _fusion_module("pointcloud_class_bayesian"), _fusion_module("pointcloud_bayesian_inference")
+        ks["alpha"] = (cb.alpha_kernel(res, C, C), f32)
+        ks["sum_compact"] = (bi.sum_compact_kernel(res, C, C), f32)
+        ks["bayesian_inference"] = (bi.bayesian_inference_kernel(C, C), f32)
     for extra in p.get("extra_dilation_sizes", ()):
         ks["dilation_filter_%d" % extra] = (ck.dilation_filter_kernel(C, C, extra), f32)
     for d in p.get("min_filter_sizes", ()):
@@ -145,6 +152,32 @@ def _min_filter_kernel(C, d):
         m = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(m)
         return m.MinFilter(cell_n=C, dilation_size=d, iteration_n=1).min_filter_kernel
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def _fusion_module(name):
+    """import reference fusion/<name>.py with fake ``cupy`` and a stand-in for its relative ``.fusion_manager`` import"""
+    fake = types.ModuleType("cupy")
+    fake.ElementwiseKernel = _Captured
+    pkg = types.ModuleType("_reffus")
+    pkg.__path__ = []
+    fm = types.ModuleType("_reffus.fusion_manager")
+
+    class FusionBase:
+        pass
+    fm.FusionBase = FusionBase
+    saved = {k: sys.modules.get(k) for k in ("cupy", "_reffus", "_reffus.fusion_manager")}
+    sys.modules.update({"cupy": fake, "_reffus": pkg, "_reffus.fusion_manager": fm})
+    try:
+        spec = importlib.util.spec_from_file_location("_reffus." + name, os.path.join(REF_ROOT, "fusion", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
     finally:
         for k, v in saved.items():
             if v is None:
@@ -216,6 +249,7 @@ PREBUILD = {
     "default34": with_(PARAM_DEFAULT, cell_n=34, extra_dilation_sizes=(1, 3, 10), min_filter_sizes=(1, 2)),
     "yaml66": with_(PARAM_YAML, cell_n=66, extra_dilation_sizes=(1, 2, 10)),
     "image98": with_(PARAM_YAML, cell_n=98, image_kernels=True),
+    "bayes66": with_(PARAM_YAML, cell_n=66, bayes_kernels=True),
 }
 
 

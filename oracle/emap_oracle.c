@@ -433,6 +433,55 @@ void eo_sem_class_average(const eo_params* P, const double* sums, const uint32_t
                                : (float)(alpha * (double)prev + (1.0 - alpha) * sums[j] / (double)cnt[c]);
     }
 }
+/* class_bayesian (reference fusion/pointcloud_class_bayesian.py:12-75): Dirichlet pseudo-counts.  The alpha kernel is launched
+ * with size = N while decoding id = i / K, layer = i % K, so element (id, layer) exists only while id*K + layer < N; theta
+ * below zero (or NaN) adds nothing.  `alpha` (the reference's persistent new_map layers) accumulates over frames; afterwards
+ * every cell of the K layers is renormalised: semantic = alpha / (sum over the K layers, 1 where that sum is 0). */
+void eo_sem_class_bayesian(const eo_params* P, const float* pts, long n, long stride, const float* R, const float* t,
+                           int n_ch, const int32_t* pcl_chan, const int32_t* layer, float* alpha, float* smap) {
+  const long L = (long)P->cell_n * P->cell_n;
+  double* sums = (double*)calloc((size_t)n_ch * L, 8);
+  for (long id = 0; id < n; ++id) {
+    pt_t g = point_geometry(P, pts + id * stride, R, t);
+    if (!g.finite || !g.valid || !g.inside) continue;
+    for (int k = 0; k < n_ch; ++k) {
+      if (id * n_ch + k >= n) continue;
+      float theta = pts[id * stride + pcl_chan[k]];
+      if (theta >= 0.0f) sums[(long)k * L + g.idx] += (double)theta;
+    }
+  }
+  for (long c = 0; c < L; ++c) {
+    float tot = 0.0f;
+    for (int k = 0; k < n_ch; ++k) {
+      long j = (long)layer[k] * L + c;
+      alpha[j] = (float)((double)alpha[j] + sums[(long)k * L + c]);
+      tot += alpha[j];
+    }
+    if (tot == 0.0f) tot = 1.0f;
+    for (int k = 0; k < n_ch; ++k) { long j = (long)layer[k] * L + c; smap[j] = alpha[j] / tot; }
+  }
+  free(sums);
+}
+/* bayesian_inference (reference fusion/pointcloud_bayesian_inference.py:12-122), restated literally: the prior variance
+ * lives in new_map layers that semantic_map.py:243 zeroes before every fusion, so sigma_old == 0 and the posterior mean
+ * equals the old value (+ 0 * measurement mean, NaN if that mean is not finite); both kernels decode id = i / K. */
+void eo_sem_bayesian_inference(const eo_params* P, const float* pts, long n, long stride, const float* R, const float* t,
+                               const uint32_t* cnt, int n_ch, const int32_t* pcl_chan, const int32_t* layer, float* smap) {
+  const long L = (long)P->cell_n * P->cell_n;
+  double* sums = (double*)calloc((size_t)n_ch * L, 8);
+  for (long id = 0; id < n; ++id) {
+    pt_t g = point_geometry(P, pts + id * stride, R, t);
+    if (!g.finite || !g.valid || !g.inside) continue;
+    for (int k = 0; k < n_ch; ++k) if (id * n_ch + k < n) sums[(long)k * L + g.idx] += (double)pts[id * stride + pcl_chan[k]];
+  }
+  for (long c = 0; c < L; ++c) for (int k = 0; k < n_ch; ++k) {
+    if (c * n_ch + k >= L || cnt[c] == 0) continue;
+    const float cn = (float)cnt[c], feat_ml = (float)(sums[(long)k * L + c]) / cn, sigma_old = 0.0f, sigma = 1.0f;
+    long j = (long)layer[k] * L + c;
+    smap[j] = sigma * smap[j] / (cn * sigma_old + sigma) + cn * sigma_old * feat_ml / (cn * sigma_old + sigma);
+  }
+  free(sums);
+}
 /* colour: one packed 0x00RRGGBB channel; integer mean per component (truncating division) */
 void eo_sem_color(const eo_params* P, const float* pts, long n, long stride, const float* R, const float* t,
                   int pcl_chan, int layer, float* smap) {

@@ -210,12 +210,13 @@ class OracleMap:
         lib().eo_normals(ct.byref(self.P), _p(self.traversability_input), _p(self.elevation_map[2]), _p(self.normal_map))
 
     # ---- semantic point fusion (reference semantic_map.py:223-259 + fusion/pointcloud_*.py) ----------
-    def semantic_update(self, points, R, t, average=(), class_average=(), color=(), n_layers=None, alpha=0.5):
-        """average / class_average / color: lists of (cloud column, layer index). Uses the accepted-point counts of the
-        frame just fused (self.last["cnt"] == new_elmap plane 2)."""
+    def semantic_update(self, points, R, t, average=(), class_average=(), color=(), n_layers=None, alpha=0.5,
+                        class_bayesian=(), bayesian_inference=()):
+        """average / class_average / color / class_bayesian / bayesian_inference: lists of (cloud column, layer index).
+        Uses the accepted-point counts of the frame just fused (self.last["cnt"] == new_elmap plane 2)."""
         pts, C = _pts(points), self.C
         R = np.ascontiguousarray(R, np.float32).ravel(); t = np.ascontiguousarray(t, np.float32)
-        need = 1 + max([l for _, l in list(average) + list(class_average) + list(color)] + [-1])
+        need = 1 + max([l for _, l in list(average) + list(class_average) + list(color) + list(class_bayesian) + list(bayesian_inference)] + [-1])
         n_layers = max(n_layers or 0, need)
         if not hasattr(self, "semantic_map") or self.semantic_map.shape[0] < n_layers:
             old = getattr(self, "semantic_map", np.zeros((0, C, C), np.float32))
@@ -232,6 +233,16 @@ class OracleMap:
                 lib().eo_sem_average(ct.byref(self.P), _p(sums), _p(cnt), ct.c_int(len(group)), _p(ly), _p(sm))
             else:
                 lib().eo_sem_class_average(ct.byref(self.P), _p(sums), _p(cnt), ct.c_int(len(group)), _p(ly), ct.c_double(alpha), _p(sm))
+        if class_bayesian:
+            if not hasattr(self, "semantic_alpha") or self.semantic_alpha.shape[0] < sm.shape[0]:
+                old = getattr(self, "semantic_alpha", np.zeros((0, C, C), np.float32))
+                self.semantic_alpha = np.concatenate([old, np.zeros((sm.shape[0] - old.shape[0], C, C), np.float32)], axis=0)
+            ch = np.array([c for c, _ in class_bayesian], np.int32); ly = np.array([l for _, l in class_bayesian], np.int32)
+            lib().eo_sem_class_bayesian(ct.byref(self.P), _p(pts), n, st, _p(R), _p(t), ct.c_int(len(ch)), _p(ch), _p(ly),
+                                        _p(self.semantic_alpha), _p(sm))
+        if bayesian_inference:
+            ch = np.array([c for c, _ in bayesian_inference], np.int32); ly = np.array([l for _, l in bayesian_inference], np.int32)
+            lib().eo_sem_bayesian_inference(ct.byref(self.P), _p(pts), n, st, _p(R), _p(t), _p(cnt), ct.c_int(len(ch)), _p(ch), _p(ly), _p(sm))
         assert len(color) <= 1, "oracle restates the single-colour-channel case (K>1 is a reference launch-size quirk)"
         for c_, l_ in color:
             lib().eo_sem_color(ct.byref(self.P), _p(pts), n, st, _p(R), _p(t), ct.c_int(c_), ct.c_int(l_), _p(sm))

@@ -92,6 +92,16 @@ class RefKernels:
     def sem_color_average(self, color_map, pcl_chan, map_lay, pcl_channels, smap, size):
         self._call("sem_color_average", [color_map, pcl_chan, map_lay, pcl_channels, smap], size)
 
+    # point fusions whose kernels live in the plugin modules (parameter sets with ``bayes_kernels``)
+    def alpha(self, p, pcl_chan, map_lay, pcl_channels, newmap, size):
+        self._call("alpha", [p, pcl_chan, map_lay, pcl_channels, newmap], size)
+
+    def sum_compact(self, p, R, t, pcl_chan, map_lay, pcl_channels, sum_mean, size):
+        self._call("sum_compact", [p, R, t, pcl_chan, map_lay, pcl_channels, sum_mean], size)
+
+    def bayesian_inference(self, pcl_chan, map_lay, pcl_channels, new_elmap, newmap, sum_mean, smap, size):
+        self._call("bayesian_inference", [pcl_chan, map_lay, pcl_channels, new_elmap, newmap, sum_mean, smap], size)
+
 
 def available(params):
     """True when the object for ``params`` is prebuilt or can be built here."""

@@ -47,6 +47,21 @@ def semantic_cloud(C, N, seed):
     return p
 
 
+def bayes_cloud(C, N, seed):
+    """semantic_cloud whose feature columns 3..5 also hold negative values (class_bayesian ignores theta < 0)"""
+    p = semantic_cloud(C, N, seed)
+    p[:, 3:6] -= np.float32(0.2)
+    return p
+
+
+def bayes_alpha_prior(C):
+    """pseudo-counts already accumulated in two class_bayesian layers (30 % of the cells still empty)"""
+    rng = np.random.default_rng(78)
+    a = rng.uniform(0, 2, (2, C, C)).astype(np.float32)
+    a[:, rng.uniform(0, 1, (C, C)) < 0.3] = 0.0
+    return a
+
+
 def semantic_prev(C):
     rng = np.random.default_rng(77)
     prev = rng.uniform(0, 1, (C, C)).astype(np.float32)

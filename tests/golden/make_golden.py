@@ -135,6 +135,34 @@ def semantic66():
     np.savez_compressed(os.path.join(OUT, "semantic_yaml66.npz"), sem=sem, cnt=nm[2])
 
 
+def bayes66():
+    """class_bayesian (alpha kernel + renormalisation, K = 2 channels incl. the launch-size quirk) and bayesian_inference
+    (sum_compact + bayesian_inference kernels) as reference fusion/pointcloud_class_bayesian.py:56-75 and
+    fusion/pointcloud_bayesian_inference.py:101-122 run them."""
+    params = build_ref.PREBUILD["bayes66"]
+    rk = ref_kernels.RefKernels(params)
+    C, N, K = 66, 6000, 4
+    R, t = fx.POSES["rotated"]; Rf = R.ravel().copy()
+    p = fx.bayes_cloud(C, N, 5)
+    m = np.zeros((7, C, C), np.float32); m[1] = params["initial_variance"]; m[3] = 1
+    nm = np.zeros((7, C, C), np.float32); nrm = np.zeros((3, C, C), np.float32)
+    err = np.zeros(1, np.float32); cnt = np.zeros(1, np.float32)
+    xyz = np.ascontiguousarray(p[:, :3])
+    rk.error_counting(m, xyz, Rf, t, nm, err, cnt); rk.add_points(Rf, t, nrm, xyz, m, nm)
+    pc = p.copy(); pc[:, :3] = xyz
+    i32 = lambda *a: np.array(a, np.int32)
+    sem = np.zeros((3, C, C), np.float32); sem[2] = fx.semantic_prev(C)
+    newmap = np.zeros((3, C, C), np.float32); newmap[:2] = fx.bayes_alpha_prior(C)       # persistent layers (semantic_map.py:54-56)
+    rk.alpha(pc, i32(3, 4), i32(0, 1), i32(3 + K, 2), newmap, N)
+    sum_alpha = np.sum(newmap[[0, 1]], axis=0); sum_alpha[sum_alpha == 0] = 1
+    sem[[0, 1]] = newmap[[0, 1]] / np.expand_dims(sum_alpha, axis=0)
+    sum_mean = np.zeros((1, C, C), np.float32)
+    rk.sum_compact(pc, Rf, t, i32(5), i32(2), i32(3 + K, 1), sum_mean, N)
+    rk.bayesian_inference(i32(5), i32(2), i32(3 + K, 1), nm, newmap, sum_mean, sem, C * C)
+    np.savez_compressed(os.path.join(OUT, "bayes_yaml66.npz"), sem=sem, alpha=newmap[:2], sum_mean=sum_mean)
+
+
 if __name__ == "__main__":
     semantic66()
+    bayes66()
     print(sorted(os.listdir(OUT)))

@@ -99,3 +99,60 @@ def test_two_colour_channels_quirk_same_on_both_paths():
     assert np.array_equal(res[0][:2].view(np.uint32), res[1][:2].view(np.uint32))
     assert np.allclose(res[0][2:], res[1][2:], atol=1e-6, rtol=1e-6)
     assert (res[0][0].view(np.uint32) != 0).sum() > 100
+
+
+BAYES_CH = ["x", "y", "z", "p0", "p1", "b0", "rgb"]
+BAYES_FUSIONS = {"p[01]": "class_bayesian", "b0": "bayesian_inference", "rgb": "color"}
+
+
+@pytest.mark.parametrize("scatter", ["atomic", "binned"])
+def test_bayesian_fusions_against_reference_golden(scatter):
+    """class_bayesian (K = 2: launch-size quirk, theta < 0 ignored, persistent pseudo-counts, renormalisation) and
+    bayesian_inference against the output of the reference's own kernels (tests/golden/make_golden.py: bayes66)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bayes_yaml66.npz"))
+    C, N = 66, 6000
+    hip, _ = make_pair(eo.YAML, C, "reference_fp16")
+    hip.param.pointcloud_channel_fusions = dict(BAYES_FUSIONS)
+    hip.set_scatter_mode(scatter)
+    R, t = fx.POSES["rotated"]
+    p = fx.bayes_cloud(C, N, 5)
+    hip.semantic_map.prepare(BAYES_CH[3:])
+    assert hip.semantic_map.layer_names == ["p0", "p1", "b0", "rgb"]
+    prior = fx.bayes_alpha_prior(C)
+    hip.semantic_map.set_alpha("p0", prior[0]); hip.semantic_map.set_alpha("p1", prior[1])
+    hip.semantic_map.set_layer("b0", fx.semantic_prev(C))
+    hip.input_pointcloud(p, BAYES_CH, R, t.copy(), 0.0, 0.0)
+    sm = hip.semantic_map.semantic_map
+    alpha = np.stack([hip.semantic_map.get_alpha("p0"), hip.semantic_map.get_alpha("p1")])
+    assert np.allclose(alpha, g["alpha"], atol=1e-5, rtol=1e-5)
+    assert np.allclose(sm[:2], g["sem"][:2], atol=1e-6, rtol=1e-5)
+    assert np.array_equal(sm[2], g["sem"][2])
+    assert (sm[3].view(np.uint32) != 0).sum() > 100          # the colour channel of the same cloud is fused alongside
+
+
+@pytest.mark.parametrize("scatter", ["atomic", "binned"])
+def test_class_bayesian_accumulates_over_frames_and_moves_with_the_map(scatter):
+    C, N = 130, 30000
+    hip, orc = make_pair(eo.YAML, C, "fp32")
+    hip.param.pointcloud_channel_fusions = dict(BAYES_FUSIONS)
+    hip.set_scatter_mode(scatter)
+    R, t = fx.POSES["identity"]
+    for f in range(3):
+        p = fx.bayes_cloud(C, N, f)
+        hip.input_pointcloud(p, BAYES_CH, R, t.copy(), 0.0, 0.0)
+        orc.update_map_with_kernel(p, R, t, 0.0, 0.0)
+        orc.semantic_update(p, R, t, class_bayesian=[(3, 0), (4, 1)], bayesian_inference=[(5, 2)], color=[(6, 3)])
+        hip.update_time(); orc.update_time()
+    sm = hip.semantic_map.semantic_map
+    a0 = hip.semantic_map.get_alpha("p0")
+    assert np.allclose(a0, orc.semantic_alpha[0], atol=1e-5, rtol=1e-5) and a0.max() > 1.0
+    assert np.allclose(sm[:2], orc.semantic_map[:2], atol=1e-6, rtol=1e-5)
+    tot = sm[0] + sm[1]
+    assert np.allclose(tot[tot > 0], 1.0, atol=1e-6)          # a categorical distribution wherever anything was observed
+    assert np.array_equal(sm[2], np.zeros_like(sm[2]))        # bayesian_inference never moves off its initial value (reference behaviour)
+    # the pseudo-counts shift with the map (reference semantic_map.py:135-136) and survive clear() (:47-49 only zeroes the layers)
+    hip.move_to(np.array([2 * 0.04, -3 * 0.04, 0.0], np.float32), np.eye(3))
+    want = np.roll(a0, (-2, 3), axis=(0, 1)); want[-2:, :] = 0; want[:, :3] = 0
+    assert np.array_equal(hip.semantic_map.get_alpha("p0"), want)
+    hip.clear()
+    assert np.array_equal(hip.semantic_map.get_alpha("p0"), want) and not hip.semantic_map.semantic_map.any()

@@ -143,6 +143,32 @@ def test_semantic_fusion_against_reference_kernels():
     assert np.array_equal(om.semantic_map[3].view(np.uint32), g["sem"][3].view(np.uint32))      # packed RGB: bit exact
 
 
+def test_bayesian_point_fusions_against_reference_kernels():
+    """class_bayesian (alpha kernel, K = 2 launch-size quirk, negative theta ignored, persistent pseudo-counts, renormalisation)
+    and bayesian_inference (a no-op in the reference: its prior variance layer is zeroed every frame) -- golden output of
+    the reference's own kernels (fusion/pointcloud_class_bayesian.py, fusion/pointcloud_bayesian_inference.py)."""
+    g = np.load(os.path.join(G, "bayes_yaml66.npz"))
+    C, N = 66, 6000
+    om = eo.OracleMap(eo.make_params(eo.YAML, cell_n=C))
+    R, t = fx.POSES["rotated"]
+    p = fx.bayes_cloud(C, N, 5)
+    om.count(p, R, t); om.gate(0, 0); om.fuse(p, R, t)
+    om.semantic_map = np.zeros((3, C, C), np.float32); om.semantic_map[2] = fx.semantic_prev(C)
+    om.semantic_alpha = np.zeros((3, C, C), np.float32); om.semantic_alpha[:2] = fx.bayes_alpha_prior(C)
+    om.semantic_update(p, R, t, class_bayesian=[(3, 0), (4, 1)], bayesian_inference=[(5, 2)])
+    assert np.allclose(om.semantic_alpha[:2], g["alpha"], atol=1e-5, rtol=1e-5)
+    assert np.allclose(om.semantic_map[:2], g["sem"][:2], atol=1e-6, rtol=1e-5)
+    assert np.array_equal(om.semantic_map[2], g["sem"][2])
+    # the quirk is visible: the second half of the cloud never contributes
+    om2 = eo.OracleMap(eo.make_params(eo.YAML, cell_n=C))
+    q = p.copy(); q[N // 2:, 3:6] = 0.5
+    om2.count(q, R, t); om2.gate(0, 0); om2.fuse(q, R, t)
+    om2.semantic_map = np.zeros((3, C, C), np.float32)
+    om2.semantic_alpha = np.zeros((3, C, C), np.float32); om2.semantic_alpha[:2] = fx.bayes_alpha_prior(C)
+    om2.semantic_update(q, R, t, class_bayesian=[(3, 0), (4, 1)])
+    assert np.array_equal(om2.semantic_alpha[:2], om.semantic_alpha[:2])
+
+
 def test_openmp_baseline_mode_equals_sequential_oracle(weights):
     """bench.py's cpu_baseline runs the C oracle with OpenMP threads; same contract, so the maps must agree."""
     C, N = 130, 20000
