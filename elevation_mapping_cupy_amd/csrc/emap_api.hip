@@ -4,6 +4,8 @@
 // (EM/elevation_mapping.py:316-391).  No per-frame allocation, no D2H sync inside a frame unless stats are asked for.
 #include "emap_device.h"
 #include <cstddef>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is dlopen()ed by emap_comm_init
 #include "../../include/emap_hip.h"
 #include <cmath>
 #include <cstdio>
@@ -58,6 +60,14 @@ void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const
 // timed stages of emap_update (emap_get_stage_times): hist+scan are 0 on the atomic path, where "scatter" is k_count
 enum { ST_HIST = 0, ST_SCAN, ST_SCATTER, ST_GATE, ST_FUSE, ST_COMMIT, ST_RAYS, ST_AVERAGE, ST_OVERLAP, ST_POST, ST_N };
 
+// the eight RCCL entry points of the path, bound with dlsym (no link-time dependency: the .so loads on machines without RCCL)
+struct RcclApi {
+  void* handle;
+  decltype(&ncclGetUniqueId) GetUniqueId; decltype(&ncclCommInitRank) CommInitRank; decltype(&ncclCommDestroy) CommDestroy;
+  decltype(&ncclAllReduce) AllReduce; decltype(&ncclSend) Send; decltype(&ncclRecv) Recv;
+  decltype(&ncclGroupStart) GroupStart; decltype(&ncclGroupEnd) GroupEnd; decltype(&ncclGetErrorString) GetErrorString;
+};
+
 struct emap_ctx {
   emap_params prm;
   emap_strip strip;
@@ -93,6 +103,9 @@ struct emap_ctx {
   bool stage_timing; hipEvent_t ev[ST_N + 1]; float stage_ms[ST_N];
   hipEvent_t t0, t1;
   bool want_ray_stats; bool in_update;
+  // row-strip communicator (emap_comm_init): RCCL resolved at run time, exchange on its own stream so that it overlaps the interior stencils
+  struct RcclApi* rccl; ncclComm_t comm; int comm_rank, comm_world;
+  hipStream_t comm_stream; hipEvent_t ev_ready, ev_done; double* comm_sums;   // [0..1] local err_sum / err_cnt, [2..3] totals
   std::string err;
 };
 
@@ -242,6 +255,7 @@ int emap_destroy(emap_ctx* ctx) {
   hipFree(ctx->bin_tmp); hipFree(ctx->bin_recs); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start);
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem_alt); hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
+  emap_comm_destroy(ctx);
   for (int i = 0; i <= ST_N; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   if (ctx->t0) hipEventDestroy(ctx->t0);
   if (ctx->t1) hipEventDestroy(ctx->t1);
@@ -1001,6 +1015,193 @@ int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf) {
   if (H == 0) return EMAP_OK;
   Cell* dst = ctx->cells + (side == 0 ? 0 : (H + n) * C);
   CK(hipMemcpyAsync(dst, dev_buf, sizeof(Cell) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
+  return EMAP_OK;
+}
+
+// ---- multi-GPU: row strips, one process per GPU, RCCL over xGMI ---------------------------------------------------
+// The two exchange steps of the path: an all-reduce of the drift sums (2 x f64) between the count and fuse
+// stages, and the neighbour exchange of halo rows before the stencils.  Halo rows are contiguous in the 32-byte cell array,
+// so RCCL sends the first / last owned rows and receives into the halo rows IN PLACE (no pack / unpack copies); the
+// exchange runs on its own stream while the stencil tiles that do not depend on halo rows run on the main stream.
+static RcclApi* rccl_open(const char* path, std::string* why) {
+  void* h = dlopen(path && *path ? path : "librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) { *why = std::string("dlopen: ") + dlerror(); return nullptr; }
+  RcclApi* a = new RcclApi(); a->handle = h;
+  bool ok = true;
+#define SYM(field, name) do { a->field = (decltype(a->field))dlsym(h, name); if (!a->field) { ok = false; *why = std::string("missing symbol ") + name; } } while (0)
+  SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+  SYM(AllReduce, "ncclAllReduce"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GroupStart, "ncclGroupStart");
+  SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+  if (!ok) { delete a; return nullptr; }   // the handle stays open: unloading a GPU runtime library is not safe
+  return a;
+}
+#define CKN(call)                                                                                                       \
+  do { ncclResult_t r_ = (call);                                                                                        \
+       if (r_ != ncclSuccess) { ctx->err = std::string(#call) + ": " + ctx->rccl->GetErrorString(r_); return EMAP_ERR_COMM; } } while (0)
+
+int emap_comm_unique_id(const char* rccl_path, uint8_t id_out[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (!id_out) return EMAP_ERR_INVALID;
+  std::string why;
+  RcclApi* a = rccl_open(rccl_path, &why);
+  if (!a) { fprintf(stderr, "emap_comm_unique_id: %s\n", why.c_str()); return EMAP_ERR_COMM; }
+  ncclUniqueId id;
+  ncclResult_t r = a->GetUniqueId(&id);
+  if (r != ncclSuccess) { fprintf(stderr, "emap_comm_unique_id: %s\n", a->GetErrorString(r)); delete a; return EMAP_ERR_COMM; }
+  memcpy(id_out, &id, 128);
+  delete a;
+  return EMAP_OK;
+}
+
+int emap_comm_init(emap_ctx* ctx, const char* rccl_path, const uint8_t id[128], int32_t rank, int32_t world) {
+  CKARG(ctx && id && world >= 1 && rank >= 0 && rank < world, "bad rank / world");
+  CKARG(!ctx->rccl, "communicator already initialised");
+  CKARG(world == 1 || ctx->strip.halo_rows > 0, "a strip of a multi-rank map needs halo rows");
+  CK(hipSetDevice(ctx->device));
+  std::string why;
+  RcclApi* a = rccl_open(rccl_path, &why);
+  if (!a) { ctx->err = why; return EMAP_ERR_COMM; }
+  ctx->rccl = a;
+  ncclUniqueId uid; memcpy(&uid, id, 128);
+  ncclResult_t r = a->CommInitRank(&ctx->comm, world, uid, rank);
+  if (r != ncclSuccess) { ctx->err = std::string("ncclCommInitRank: ") + a->GetErrorString(r); delete a; ctx->rccl = nullptr; ctx->comm = nullptr; return EMAP_ERR_COMM; }
+  ctx->comm_rank = rank; ctx->comm_world = world;
+  CK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  CK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
+  CK(hipMalloc((void**)&ctx->comm_sums, sizeof(double) * 4));
+  CK(hipMemsetAsync(ctx->comm_sums, 0, sizeof(double) * 4, ctx->stream));
+  return EMAP_OK;
+}
+
+int emap_comm_destroy(emap_ctx* ctx) {
+  if (!ctx || !ctx->rccl) return EMAP_OK;
+  hipSetDevice(ctx->device);
+  if (ctx->comm_stream) hipStreamSynchronize(ctx->comm_stream);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  if (ctx->comm) ctx->rccl->CommDestroy(ctx->comm);
+  if (ctx->comm_stream) hipStreamDestroy(ctx->comm_stream);
+  if (ctx->ev_ready) hipEventDestroy(ctx->ev_ready);
+  if (ctx->ev_done) hipEventDestroy(ctx->ev_done);
+  hipFree(ctx->comm_sums);
+  delete ctx->rccl;
+  ctx->rccl = nullptr; ctx->comm = nullptr; ctx->comm_stream = nullptr; ctx->ev_ready = ctx->ev_done = nullptr; ctx->comm_sums = nullptr;
+  return EMAP_OK;
+}
+
+// halo exchange with the strip neighbours, in place, on the communication stream; main-stream work issued after this call and
+// before emap_comm_halo_wait overlaps it.  Rank r sends its first H owned rows to r-1 and its last H owned rows to r+1.
+static int halo_exchange_start(emap_ctx* ctx) {
+  const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
+  const size_t bytes = sizeof(Cell) * (size_t)H * C;
+  const RcclApi* a = ctx->rccl;
+  CK(hipEventRecord(ctx->ev_ready, ctx->stream));
+  CK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_ready, 0));
+  CKN(a->GroupStart());
+  if (ctx->comm_rank > 0) {
+    CKN(a->Send(ctx->cells + H * C, bytes, ncclChar, ctx->comm_rank - 1, ctx->comm, ctx->comm_stream));
+    CKN(a->Recv(ctx->cells, bytes, ncclChar, ctx->comm_rank - 1, ctx->comm, ctx->comm_stream));
+  }
+  if (ctx->comm_rank < ctx->comm_world - 1) {
+    CKN(a->Send(ctx->cells + n * C, bytes, ncclChar, ctx->comm_rank + 1, ctx->comm, ctx->comm_stream));          // rows [n-H, n) of the strip
+    CKN(a->Recv(ctx->cells + (H + n) * C, bytes, ncclChar, ctx->comm_rank + 1, ctx->comm, ctx->comm_stream));
+  }
+  CKN(a->GroupEnd());
+  CK(hipEventRecord(ctx->ev_done, ctx->comm_stream));
+  return EMAP_OK;
+}
+
+// One frame of the strip: the stage order of ShardedElevationMap.update (sharded.py) with both exchange steps issued from
+// here -- no Python, no host synchronisation between the stages.
+int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats) {
+  CKARG(ctx && R && t, "null argument"); NEED_POINTS();
+  CKARG(ctx->rccl && ctx->comm, "emap_comm_init has not been called");
+  CK(hipSetDevice(ctx->device));
+  const emap_params& p = ctx->prm;
+  const RcclApi* a = ctx->rccl;
+  const bool tm = ctx->stage_timing;
+  int rc;
+#define STAGE(i) do { if (tm) CK(hipEventRecord(ctx->ev[i], ctx->stream)); } while (0)
+  ctx->in_update = true;
+  rc = emap_count(ctx, R, t);                 // records ST_HIST / ST_SCAN / ST_SCATTER itself
+  ctx->in_update = false;
+  if (rc) return rc;
+  STAGE(ST_GATE);                             // "gate" = local sums + all-reduce + gate
+  ctx->use_override = false;
+  if ((rc = gate_impl(ctx, 0.0, 0.0, 1, ctx->comm_sums, nullptr))) return rc;                       // local sums -> device
+  CKN(a->AllReduce(ctx->comm_sums, ctx->comm_sums + 2, 2, ncclFloat64, ncclSum, ctx->comm, ctx->stream));   // exchange step 1
+  if ((rc = gate_impl(ctx, position_noise, orientation_noise, 0, nullptr, ctx->comm_sums + 2))) return rc;
+  STAGE(ST_FUSE);
+  const bool fused_avg = ctx->frame_binned && !p.enable_visibility_cleanup;
+  if ((rc = fuse_impl(ctx, R, t, fused_avg))) return rc;
+  STAGE(ST_COMMIT);
+  if (p.enable_visibility_cleanup) {
+    if ((rc = emap_commit(ctx))) return rc;
+    STAGE(ST_RAYS);
+    if ((rc = emap_rays(ctx, R, t))) return rc;
+  } else STAGE(ST_RAYS);
+  STAGE(ST_AVERAGE);
+  if (!fused_avg) launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, p.enable_visibility_cleanup != 0, ctx->cnt_plane);
+  ctx->committed = false;
+  CK(hipGetLastError());
+  STAGE(ST_OVERLAP);
+  if (p.enable_overlap_clearance && (rc = emap_overlap_clear(ctx, t[2]))) return rc;
+  STAGE(ST_POST);                             // "post" = halo exchange + stencils
+  if (ctx->comm_world > 1) {
+    if ((rc = halo_exchange_start(ctx))) return rc;                                                 // exchange step 2 ...
+    if ((rc = emap_post_part(ctx, 1))) return rc;                                                   // ... overlapped with the interior tiles
+    CK(hipStreamWaitEvent(ctx->stream, ctx->ev_done, 0));
+    if ((rc = emap_post_part(ctx, 2))) return rc;
+  } else if ((rc = emap_post_part(ctx, 0))) return rc;
+  STAGE(ST_N);
+#undef STAGE
+  if (tm) {
+    CK(hipEventSynchronize(ctx->ev[ST_N]));
+    for (int i = 0; i < ST_N; ++i) CK(hipEventElapsedTime(&ctx->stage_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+  }
+  if (stats) return emap_get_stats(ctx, stats);
+  return EMAP_OK;
+}
+
+// Hardware self-test of the communicator (any world size): all-reduce of known values and one halo round trip.  With a single
+// rank the halo rows are exchanged with the rank itself (send to / receive from rank 0 inside one group).
+int emap_comm_selftest(emap_ctx* ctx) {
+  CKARG(ctx && ctx->rccl && ctx->comm, "emap_comm_init has not been called");
+  CK(hipSetDevice(ctx->device));
+  const RcclApi* a = ctx->rccl;
+  const double mine[2] = {1.0 + ctx->comm_rank, 0.5};
+  CK(hipMemcpyAsync(ctx->comm_sums, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+  CKN(a->AllReduce(ctx->comm_sums, ctx->comm_sums + 2, 2, ncclFloat64, ncclSum, ctx->comm, ctx->stream));
+  double got[2];
+  CK(hipMemcpyAsync(got, ctx->comm_sums + 2, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
+  const int W = ctx->comm_world;
+  if (got[0] != W * (W + 1) / 2.0 || got[1] != 0.5 * W) { ctx->err = "all-reduce self-test: wrong sum"; return EMAP_ERR_COMM; }
+  if (W == 1) {   // self send / recv of one row of cells through the scratch plane
+    const size_t bytes = sizeof(float) * (size_t)ctx->prm.cell_n;
+    float* src = ctx->scratch; float* dst = ctx->scratch + ctx->prm.cell_n;
+    if ((size_t)ctx->ncells_alloc < 2 * (size_t)ctx->prm.cell_n) return EMAP_OK;
+    std::string pat(bytes, 0); for (size_t i = 0; i < bytes; ++i) pat[i] = (char)(i * 7 + 3);
+    CK(hipMemcpyAsync(src, pat.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemsetAsync(dst, 0, bytes, ctx->stream));
+    CK(hipEventRecord(ctx->ev_ready, ctx->stream));
+    CK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_ready, 0));
+    CKN(a->GroupStart());
+    CKN(a->Send(src, bytes, ncclChar, 0, ctx->comm, ctx->comm_stream));
+    CKN(a->Recv(dst, bytes, ncclChar, 0, ctx->comm, ctx->comm_stream));
+    CKN(a->GroupEnd());
+    CK(hipEventRecord(ctx->ev_done, ctx->comm_stream));
+    CK(hipStreamWaitEvent(ctx->stream, ctx->ev_done, 0));
+    std::string back(bytes, 0);
+    CK(hipMemcpyAsync(&back[0], dst, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (back != pat) { ctx->err = "send/recv self-test: payload mismatch"; return EMAP_ERR_COMM; }
+  } else if (ctx->strip.halo_rows > 0) {
+    int rc = halo_exchange_start(ctx); if (rc) return rc;
+    CK(hipStreamWaitEvent(ctx->stream, ctx->ev_done, 0));
+    CK(hipStreamSynchronize(ctx->stream));
+  }
   return EMAP_OK;
 }
 

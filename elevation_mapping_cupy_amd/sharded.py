@@ -96,6 +96,73 @@ class TorchComm:
         return float(t.item())
 
 
+def rccl_library_path():
+    """RCCL build that matches the HIP runtime of this process: PyTorch wheels bundle their own ROCm libraries and export
+    them globally, so with torch imported its librccl.so is the consistent choice; otherwise the system ROCm's."""
+    env = os.environ.get("EMAP_RCCL_LIB")
+    if env:
+        return env
+    import sys
+    if "torch" in sys.modules:
+        cand = os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib", "librccl.so")
+        if os.path.exists(cand):
+            return cand
+    for cand in ("/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        if os.path.exists(cand):
+            return cand
+    return "librccl.so.1"
+
+
+class NativeComm:
+    """Both exchange steps issued by the C library itself (``emap_comm_init`` / ``emap_update_sharded``): RCCL resolved with
+    dlopen, all-reduce on the strip's stream, in-place halo send/recv on a second stream.  torch.distributed (any backend)
+    is only the bootstrap channel for the 128-byte ncclUniqueId and the out-of-band barrier / timing reductions."""
+
+    def __init__(self, engine, rank=None, world=None, bootstrap=True):
+        from ._lib import EmapError
+        self.e = engine
+        if bootstrap:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        else:
+            self.torch = self.dist = None
+            self.rank, self.world = int(rank or 0), int(world or 1)
+        path = rccl_library_path().encode()
+        uid = (ct.c_uint8 * 128)()
+        ok = 1
+        if self.rank == 0:
+            ok = 1 if engine.lib.emap_comm_unique_id(path, uid) == 0 else 0
+        if self.world > 1:
+            # agree on success before the collective init (a rank that cannot load RCCL must not leave the others waiting)
+            payload = [bytes(uid) if ok else None]
+            self.dist.broadcast_object_list(payload, src=0)
+            if payload[0] is None:
+                raise EmapError("rank 0 could not create the RCCL unique id")
+            uid = (ct.c_uint8 * 128).from_buffer_copy(payload[0])
+        elif not ok:
+            raise EmapError("could not create the RCCL unique id (%s)" % path.decode())
+        engine._chk(engine.lib.emap_comm_init(engine.ctx, path, uid, self.rank, self.world))
+        self.path = path.decode()
+
+    def selftest(self):
+        self.e._chk(self.e.lib.emap_comm_selftest(self.e.ctx))
+
+    def barrier(self):
+        if self.world > 1:      # out-of-band (host) barrier on the bootstrap channel; callers synchronise the device themselves
+            self.dist.all_reduce(self.torch.zeros(1, dtype=self.torch.int32))
+
+    def max_float(self, x):
+        if self.world == 1:
+            return float(x)
+        t = self.torch.tensor([x], dtype=self.torch.float64)
+        if self.dist.get_backend() == "nccl":
+            t = t.to(self.e.torch_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
 # ---------------------------------------------------------------------------------------------------------------
 class HipStripEngine:
     """One strip on one MI355X: thin adapter from the sharding protocol to the C ABI."""
@@ -104,6 +171,7 @@ class HipStripEngine:
         import torch
         from .elevation_mapping import ElevationMap
         self.torch = torch
+        self.torch_device = torch_device
         C = int(param.cell_n)
         r0, r1 = strip_rows(C, world, rank)
         self.halo = halo_rows_needed(param.dilation_size, world)
@@ -178,6 +246,13 @@ class HipStripEngine:
         """dilation + traversability + normals; part 1 = tiles independent of the halo, 2 = boundary tiles, 0 = all"""
         self._chk(self.lib.emap_post_part(self.ctx, int(part)))
 
+    def update_native(self, R, t, position_noise, orientation_noise):
+        """whole frame incl. both exchange steps inside the library (needs NativeComm)"""
+        R = np.ascontiguousarray(np.asarray(R, np.float32).reshape(9))
+        t = np.ascontiguousarray(np.asarray(t, np.float32).reshape(3))
+        self._chk(self.lib.emap_update_sharded(self.ctx, R.ctypes.data_as(ct.POINTER(ct.c_float)), t.ctypes.data_as(ct.POINTER(ct.c_float)),
+                                               ct.c_double(position_noise), ct.c_double(orientation_noise), None))
+
     def update_time(self):
         self.map.update_time()
 
@@ -202,6 +277,9 @@ class ShardedElevationMap:
     def update(self, R, t, position_noise, orientation_noise):
         """One frame on the bound (replicated) cloud; ``t`` is map-centre relative."""
         e, c = self.e, self.comm
+        if isinstance(c, NativeComm):
+            e.update_native(R, t, position_noise, orientation_noise)
+            return
         ctx = e.stream_ctx() if hasattr(e, "stream_ctx") else contextlib.nullcontext()
         with ctx:
             self._update(R, t, position_noise, orientation_noise)
@@ -243,12 +321,18 @@ def bench_main(a, rank, world, local_rank):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _fixtures as fx
 
+    # RCCL prints its version banner on stdout through C stdio: keep fd 1 pointed at stderr until the JSON line is due
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        # CPU tensors (bootstrap, timing reductions) go through gloo; the nccl backend is only instantiated if the
+        # torch-driven fallback below has to move device tensors
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
     cfg = dict(CORE_PARAM_YAML)
     if a.workload == "cfg2":
         cfg.update(enable_visibility_cleanup=False, enable_overlap_clearance=False)
@@ -256,8 +340,38 @@ def bench_main(a, rank, world, local_rank):
     w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
     weights = {k: w[k] for k in ("w1", "w2", "w3", "w_out")}
     par = parameter_from(cfg, C, a.mode, weights, device=local_rank)
-    comm = TorchComm(dev)
     eng = HipStripEngine(par, rank, world, local_rank, dev)
+    comm, comm_kind = None, os.environ.get("EMAP_COMM", "native")
+
+    def all_agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # CPU tensor: gloo
+        return int(flag.item()) == 1
+
+    if comm_kind == "native":
+        # every step that can fail on one rank only is followed by an agreement, so that no rank is left alone in a collective
+        try:
+            comm = NativeComm(eng)
+        except Exception as ex:  # noqa: BLE001
+            print("[rank %d] native RCCL path unavailable (%s)" % (rank, ex), file=sys.stderr)
+            comm = None
+        if all_agree(comm is not None):
+            try:
+                comm.selftest()
+                ok = True
+            except Exception as ex:  # noqa: BLE001
+                print("[rank %d] RCCL self-test failed (%s)" % (rank, ex), file=sys.stderr)
+                ok = False
+            if not all_agree(ok):
+                comm = None
+        else:
+            comm = None
+        if comm is None and rank == 0:
+            print("falling back to torch.distributed collectives", file=sys.stderr)
+    if comm is None:
+        comm_kind = "torch"
+        comm = TorchComm(dev)
     sm = ShardedElevationMap(eng, comm, cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
 
     NCLOUD = 5
@@ -285,6 +399,32 @@ def bench_main(a, rank, world, local_rank):
     wall_local = time.perf_counter() - t0
     comm.barrier(); torch.cuda.synchronize()
     wall = comm.max_float(max(wall_local, 0.0))
+    # per-stage device time of THIS rank's strip (hipEvents on the strip's stream) -> roofline of its dominant kernel.
+    # Algorithmic bytes of a strip: every rank reads the whole replicated cloud, but sorts / fuses only the points of its
+    # rows (N / world for uniform clouds) and streams only its L / world cells.
+    roof = None
+    if isinstance(comm, NativeComm):
+        from ._lib import STAGES
+        eng.lib.emap_enable_stage_timing(eng.ctx, 1)
+        reps, acc = min(a.steps, 20), np.zeros(10)
+        for i in range(reps):
+            frame(i)
+            ms10 = (ct.c_float * 10)()
+            eng.lib.emap_get_stage_times(eng.ctx, ms10)
+            acc += np.array(list(ms10))
+        eng.lib.emap_enable_stage_timing(eng.ctx, 0)
+        torch.cuda.synchronize(); comm.barrier()
+        stage_ms = dict(zip(STAGES, (acc / reps).tolist()))
+        Nw, Lw = N / world, C * C / world
+        strip_bytes = {"hist": 28 * N, "scan": 0, "scatter": 16 * N + 32 * Nw, "gate": 0, "fuse": 24 * Nw + 64 * Lw, "commit": 104 * Lw,
+                       "rays": 12 * N + 48 * Lw, "average": 120 * Lw, "overlap": 0, "post": 52 * Lw}
+        kernels = {k: v for k, v in stage_ms.items() if strip_bytes[k] > 0}
+        dom = max(kernels, key=kernels.get)
+        achieved = strip_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                "traffic": None, "algorithmic_bytes": int(strip_bytes[dom]), "kernel_ms": round(stage_ms[dom], 5), "rank": 0,
+                "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+                "note": "rank 0's strip; 'gate' includes the all-reduce, 'post' the halo exchange overlapped with the interior stencils"}
     if rank == 0:
         out = {
             "metric": "Mpoints/s fused (map-update p50 latency in config)", "value": round(N * a.steps / wall / 1e6, 2),
@@ -294,14 +434,21 @@ def bench_main(a, rank, world, local_rank):
             "config": {"workload": "%s: %dx%d map in %d row strips, %d uniform-random points/frame replicated to every rank, "
                                    "core_param.yaml values" % (a.workload, C, C, world, N),
                        "index_mode": a.mode, "halo_rows": eng.halo, "parallelism": "row-strips x%d" % world,
-                       "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame (RCCL)"},
-            "roofline": None, "cpu_baseline": None,
+                       "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame (RCCL, %s)" %
+                                      ("issued by the C library, halo exchange in place on a second stream" if comm_kind == "native"
+                                       else "driven through torch.distributed")},
+            "roofline": roof, "cpu_baseline": None,
         }
-    dist.barrier()
+    comm.barrier()
+    if isinstance(comm, NativeComm):
+        eng.lib.emap_comm_destroy(eng.ctx)
     dist.destroy_process_group()
+    try:
+        ct.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if rank == 0:
-        try:  # RCCL prints its banner through C stdio: flush that first so the JSON line is the last line of stdout
-            ct.CDLL(None).fflush(None)
-        except OSError:
-            pass
         print(json.dumps(out), flush=True)

@@ -24,7 +24,8 @@ typedef enum {
   EMAP_ERR_INVALID = -1,   /* bad argument */
   EMAP_ERR_HIP = -2,       /* HIP runtime error, see emap_last_error */
   EMAP_ERR_NO_POINTS = -3, /* stage needs a point cloud but none is bound */
-  EMAP_ERR_UNSUPPORTED = -4
+  EMAP_ERR_UNSUPPORTED = -4,
+  EMAP_ERR_COMM = -5       /* RCCL could not be loaded or a collective failed, see emap_last_error */
 } emap_status;
 
 /* index/rounding mode: 0 reproduces the reference's CuPy float16 helper-parameter rounding
@@ -185,6 +186,20 @@ int emap_image_fuse(emap_ctx* ctx, int32_t kind, int32_t layer, const float* hos
 int emap_halo_bytes(emap_ctx* ctx, int64_t* bytes_per_side);
 int emap_halo_pack(emap_ctx* ctx, int side, float* dev_buf);
 int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf);
+
+/* ---- row-strip communicator: one process per GPU, RCCL over xGMI issued from the library itself -------------
+ * Nothing like it exists in the reference (single GPU).  `rccl_path` names the RCCL shared object to dlopen (NULL =
+ * "librccl.so.1" from the loader path); rank 0 creates the 128-byte ncclUniqueId, the caller distributes it (any
+ * bootstrap channel) and every rank calls emap_comm_init -- a collective call.  emap_update_sharded is emap_update for a
+ * strip: count -> all-reduce(2 x f64 drift sums) -> gate -> fuse [-> commit -> rays] -> average -> overlap clearance ->
+ * halo exchange of the boundary rows (in place, on a second stream) overlapped with the interior stencil tiles ->
+ * boundary stencil tiles.  emap_comm_selftest checks an all-reduce and a send/recv round trip on the hardware. */
+int emap_comm_unique_id(const char* rccl_path, uint8_t id_out[128]);
+int emap_comm_init(emap_ctx* ctx, const char* rccl_path, const uint8_t id[128], int32_t rank, int32_t world);
+int emap_comm_destroy(emap_ctx* ctx);
+int emap_comm_selftest(emap_ctx* ctx);
+int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise,
+                        emap_stats* stats /* may be NULL: no host synchronisation */);
 
 /* ---- timing on the context's stream (hipEvents; bench.py's roofline leg) -------------------------- */
 int emap_timer_begin(emap_ctx* ctx);
