@@ -416,10 +416,10 @@ static int ensure_bins(emap_ctx* ctx) {
   const long n = ctx->n_pts;
   BinGeo& g = ctx->bg;
   g.tiles_x = (ctx->prm.cell_n + 63) / 64; g.tiles_y = (ctx->strip.row_count + 15) / 16; g.T = g.tiles_x * g.tiles_y;
-  long target = 2048;
+  long target = n >= 1000000 ? 4096 : 2048;
   if (const char* e = getenv("EMAP_BIN_CHUNK")) { long v = atol(e); if (v >= 256 && v <= 65536) target = v; }   // tuning knob
   long B = (n + target - 1) / target; if (B < 1) B = 1; if (B > BIN_MAX_B) B = BIN_MAX_B;
-  long chunk = (n + B - 1) / B; chunk = ((chunk + EM_BLOCK - 1) / EM_BLOCK) * EM_BLOCK; if (chunk < EM_BLOCK) chunk = EM_BLOCK;
+  long chunk = (n + B - 1) / B; chunk = ((chunk + 1023) / 1024) * 1024;   /* a multiple of every hist / scatter block size */
   g.B = (int)((n + chunk - 1) / chunk); if (g.B < 1) g.B = 1;
   g.chunk = chunk;
   const size_t hist_need = (size_t)g.T * (size_t)g.B;

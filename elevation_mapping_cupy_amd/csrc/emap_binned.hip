@@ -18,6 +18,7 @@
 // fallback for maps with more than 16384 tiles (> 4096^2 cells per context) and for clouds below ~200 k points (two launches with atomics have the lower latency there).
 #include "emap_device.h"
 #include <cstring>
+#include <cstdlib>
 
 #define BIN_TR 16
 #define BIN_TC 64
@@ -43,14 +44,14 @@ __device__ __forceinline__ unsigned int block_excl_scan(unsigned int x, unsigned
   return base + inc - x;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(EM_BLOCK) void k_bin_hist(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
+template <int MODE, int BLK>
+__global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
                                                         BinTmp* __restrict__ tmp, unsigned int* __restrict__ hist) {
   extern __shared__ unsigned int h[];
-  for (int t = threadIdx.x; t < G.T; t += EM_BLOCK) h[t] = 0u;
+  for (int t = threadIdx.x; t < G.T; t += BLK) h[t] = 0u;
   __syncthreads();
   const long base = (long)blockIdx.x * G.chunk;
-  for (long k = threadIdx.x; k < G.chunk; k += EM_BLOCK) {
+  for (long k = threadIdx.x; k < G.chunk; k += BLK) {
     const long i = base + k;
     if (i >= n) break;
     float rx, ry, rz;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_bin_hist(KP P, Pose T, BinGeo G, c
     tmp[i] = r;
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < G.T; t += EM_BLOCK) hist[(long)t * G.B + blockIdx.x] = h[t];
+  for (int t = threadIdx.x; t < G.T; t += BLK) hist[(long)t * G.B + blockIdx.x] = h[t];
 }
 
 // block t: exclusive scan of hist[t][0..B) in place, tile_total[t] = sum
@@ -97,19 +98,20 @@ __global__ __launch_bounds__(EM_BLOCK) void k_bin_scan2(BinGeo G, const unsigned
   if (threadIdx.x == 0) tile_start[G.T] = running;
 }
 
-__global__ __launch_bounds__(EM_BLOCK) void k_bin_scatter(KP P, BinGeo G, const BinTmp* __restrict__ tmp, long n,
+template <int BLK>
+__global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, BinGeo G, const BinTmp* __restrict__ tmp, long n,
                                                            const unsigned int* __restrict__ hist, const unsigned int* __restrict__ tile_start,
                                                            const Cell* __restrict__ cells, BinRec* __restrict__ recs,
                                                            ErrSlot* __restrict__ slots) {
   extern __shared__ unsigned int cur[];
-  for (int t = threadIdx.x; t < G.T; t += EM_BLOCK) cur[t] = tile_start[t] + hist[(long)t * G.B + blockIdx.x];
+  for (int t = threadIdx.x; t < G.T; t += BLK) cur[t] = tile_start[t] + hist[(long)t * G.B + blockIdx.x];
   __syncthreads();
   const long base = (long)blockIdx.x * G.chunk;
-  const long iters = (G.chunk + EM_BLOCK - 1) / EM_BLOCK;
+  const long iters = (G.chunk + BLK - 1) / BLK;
   for (long it = 0; it < iters; ++it) {          // uniform trip count: the wave reductions below need all lanes
-    const long i = base + it * EM_BLOCK + threadIdx.x;
+    const long i = base + it * BLK + threadIdx.x;
     long long e_fix = 0; unsigned int inl = 0;
-    if (it * EM_BLOCK + threadIdx.x < G.chunk && i < n) {
+    if (it * BLK + threadIdx.x < G.chunk && i < n) {
       BinTmp r = tmp[i];
       if (r.tile >= 0) {
         const int ty = r.tile / G.tiles_x, tx = r.tile - ty * G.tiles_x;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_bin_scatter(KP P, BinGeo G, const 
       long long s = wave_sum_ll(e_fix);
       unsigned long long k = __popcll(__ballot(inl));
       if ((threadIdx.x & 63) == 0) {
-        unsigned int slot = (unsigned int)((blockIdx.x * (EM_BLOCK / 64) + (threadIdx.x >> 6) + it) & (EM_ERR_SLOTS - 1));
+        unsigned int slot = (unsigned int)((blockIdx.x * (BLK / 64) + (threadIdx.x >> 6) + it) & (EM_ERR_SLOTS - 1));
         atomicAdd(reinterpret_cast<unsigned long long*>(&slots[slot].sum), (unsigned long long)s);
         atomicAdd(&slots[slot].cnt, k);
       }
@@ -201,10 +203,26 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
 static inline unsigned int nb(long n) { return (unsigned int)((n + EM_BLOCK - 1) / EM_BLOCK); }
 
 // count stage of the binned path = hist, scans, scatter (error sums land in `slots` exactly as k_count leaves them)
+// workgroup sizes of the two point passes (measured on MI355X, 1 M points / 1024 tiles: the histogram pass wants many
+// loads in flight -> 1024 threads; the scatter pass 512; 4096-point chunks).  Tuning knobs only.
+static int env_block(const char* name, int dflt) {
+  if (const char* e = getenv(name)) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) return v; }
+  return dflt;
+}
+template <int BLK>
+static void launch_bin_hist_t(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride, BinTmp* tmp,
+                              unsigned int* hist) {
+  if (P.mode == 0) hipLaunchKernelGGL((k_bin_hist<0, BLK>), dim3(G.B), dim3(BLK), sizeof(unsigned int) * G.T, s, P, T, G, pts, n, stride, tmp, hist);
+  else hipLaunchKernelGGL((k_bin_hist<1, BLK>), dim3(G.B), dim3(BLK), sizeof(unsigned int) * G.T, s, P, T, G, pts, n, stride, tmp, hist);
+}
 void launch_bin_hist(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride, BinTmp* tmp,
                      unsigned int* hist) {
-  if (P.mode == 0) hipLaunchKernelGGL(k_bin_hist<0>, dim3(G.B), dim3(EM_BLOCK), sizeof(unsigned int) * G.T, s, P, T, G, pts, n, stride, tmp, hist);
-  else hipLaunchKernelGGL(k_bin_hist<1>, dim3(G.B), dim3(EM_BLOCK), sizeof(unsigned int) * G.T, s, P, T, G, pts, n, stride, tmp, hist);
+  static const int blk = env_block("EMAP_HIST_BLOCK", 1024);
+  switch (blk) {
+    case 1024: launch_bin_hist_t<1024>(s, P, T, G, pts, n, stride, tmp, hist); break;
+    case 512: launch_bin_hist_t<512>(s, P, T, G, pts, n, stride, tmp, hist); break;
+    default: launch_bin_hist_t<256>(s, P, T, G, pts, n, stride, tmp, hist);
+  }
 }
 void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigned int* tile_total, unsigned int* tile_start) {
   hipLaunchKernelGGL(k_bin_scan1, dim3(G.T), dim3(EM_BLOCK), 0, s, G, hist, tile_total);
@@ -212,7 +230,13 @@ void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigne
 }
 void launch_bin_scatter(hipStream_t s, const KP& P, const BinGeo& G, const BinTmp* tmp, long n, const unsigned int* hist,
                         const unsigned int* tile_start, const Cell* cells, BinRec* recs, ErrSlot* slots) {
-  hipLaunchKernelGGL(k_bin_scatter, dim3(G.B), dim3(EM_BLOCK), sizeof(unsigned int) * G.T, s, P, G, tmp, n, hist, tile_start, cells, recs, slots);
+  static const int blk = env_block("EMAP_SCATTER_BLOCK", 512);
+  const size_t sh = sizeof(unsigned int) * G.T;
+  switch (blk) {
+    case 1024: hipLaunchKernelGGL(k_bin_scatter<1024>, dim3(G.B), dim3(1024), sh, s, P, G, tmp, n, hist, tile_start, cells, recs, slots); break;
+    case 512: hipLaunchKernelGGL(k_bin_scatter<512>, dim3(G.B), dim3(512), sh, s, P, G, tmp, n, hist, tile_start, cells, recs, slots); break;
+    default: hipLaunchKernelGGL(k_bin_scatter<256>, dim3(G.B), dim3(256), sh, s, P, G, tmp, n, hist, tile_start, cells, recs, slots);
+  }
 }
 void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cell* cells,
                      AccF* acc, const FrameDev* F, bool fuse_average, unsigned int* cnt_plane) {
