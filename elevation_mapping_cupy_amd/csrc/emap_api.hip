@@ -45,7 +45,7 @@ void launch_point_index(hipStream_t, const KP&, const Pose&, const float*, long,
 void launch_shift(hipStream_t, const KP&, const Cell*, Cell*, int, int, float);
 
 // tile-binned scatter (emap_binned.hip)
-struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; };
+struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, pad_; };
 struct BinTmp { int tile; unsigned int lc; float z, v; };
 struct BinRec { unsigned int lc_inl; float z, v; unsigned int i; };
 void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, BinTmp*, unsigned int*);
@@ -85,6 +85,7 @@ struct emap_ctx {
   unsigned long long* inert;       // 1 bit per owned cell, written by k_commit
   // tile-binned scatter buffers (allocated on demand)
   int scatter_mode;                // 0 auto, 1 atomic, 2 binned
+  int force_sub;                   // test hook: minimum bin height factor (emap_set_scatter_mode bits 8..15)
   bool frame_binned;               // the count stage of the current frame used the binned path
   BinGeo bg; BinTmp* bin_tmp; BinRec* bin_recs; unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;
   // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
@@ -408,14 +409,21 @@ int emap_point_index(emap_ctx* ctx, const float R[9], const float t[3], int32_t*
 // ---- stages -----------------------------------------------------------------------------------------------
 #define NEED_POINTS() do { if (!ctx->pts && ctx->n_pts) { ctx->err = "no point cloud bound"; return EMAP_ERR_NO_POINTS; } } while (0)
 
-static bool bins_possible(const emap_ctx* ctx) {
-  const long tx = (ctx->prm.cell_n + 63) / 64, ty = (ctx->strip.row_count + 15) / 16;
-  return tx * ty <= BIN_MAX_T;
+// bins of `sub` stacked 16 x 64 tiles: the smallest power of two that keeps the bin count within the LDS histogram
+static int bin_sub(const emap_ctx* ctx) {
+  const long tx = (ctx->prm.cell_n + 63) / 64;
+  for (int sub = ctx->force_sub > 0 ? ctx->force_sub : 1; sub <= 64; sub *= 2) {
+    const long ty = (ctx->strip.row_count + 16 * sub - 1) / (16 * sub);
+    if (tx * ty <= BIN_MAX_T) return sub;
+  }
+  return 0;
 }
+static bool bins_possible(const emap_ctx* ctx) { return bin_sub(ctx) > 0; }
 static int ensure_bins(emap_ctx* ctx) {
   const long n = ctx->n_pts;
   BinGeo& g = ctx->bg;
-  g.tiles_x = (ctx->prm.cell_n + 63) / 64; g.tiles_y = (ctx->strip.row_count + 15) / 16; g.T = g.tiles_x * g.tiles_y;
+  g.sub = bin_sub(ctx); g.pad_ = 0;
+  g.tiles_x = (ctx->prm.cell_n + 63) / 64; g.tiles_y = (ctx->strip.row_count + 16 * g.sub - 1) / (16 * g.sub); g.T = g.tiles_x * g.tiles_y;
   long target = n >= 1000000 ? 4096 : 2048;
   if (const char* e = getenv("EMAP_BIN_CHUNK")) { long v = atol(e); if (v >= 256 && v <= 65536) target = v; }   // tuning knob
   long B = (n + target - 1) / target; if (B < 1) B = 1; if (B > BIN_MAX_B) B = BIN_MAX_B;
@@ -447,9 +455,12 @@ static int ensure_bins(emap_ctx* ctx) {
 }
 
 int emap_set_scatter_mode(emap_ctx* ctx, int32_t mode) {
-  CKARG(ctx && mode >= 0 && mode <= 2, "scatter mode: 0 auto, 1 atomic, 2 binned");
-  CKARG(mode != 2 || bins_possible(ctx), "binned scatter needs <= 16384 tiles of 16x64 cells");
-  ctx->scatter_mode = mode;
+  const int m = mode & 0xff, sub = (mode >> 8) & 0xff;
+  CKARG(ctx && m >= 0 && m <= 2 && (mode >> 16) == 0, "scatter mode: 0 auto, 1 atomic, 2 binned");
+  CKARG(sub == 0 || (sub <= 64 && (sub & (sub - 1)) == 0), "bin height factor must be a power of two <= 64");
+  ctx->force_sub = sub;
+  CKARG(m != 2 || bins_possible(ctx), "binned scatter: too many bins for the LDS histogram");
+  ctx->scatter_mode = m;
   return EMAP_OK;
 }
 

@@ -15,7 +15,9 @@
 //                  the epilogue writes the 40-byte AccF records with plain coalesced stores.
 // Everything downstream (commit, rays, average, ...) is unchanged and the AccF contents are BIT-IDENTICAL to the
 // atomic path of emap_kernels.hip (integer / fixed-point accumulators are order independent), which stays as the
-// fallback for maps with more than 16384 tiles (> 4096^2 cells per context) and for clouds below ~200 k points (two launches with atomics have the lower latency there).
+// path for clouds below ~200 k points (two launches with atomics have the lower latency there).  The LDS histogram holds at
+// most 16384 bins: maps with more tiles (> 4096^2 cells per context) sort into bins of 2, 4, ... vertically stacked tiles and
+// the tile kernels reduce one tile of the bin per workgroup (blockIdx.y), re-reading the bin's records from L2.
 #include "emap_device.h"
 #include <cstring>
 #include <cstdlib>
@@ -24,7 +26,7 @@
 #define BIN_TC 64
 #define BIN_MAX_T 16384   /* LDS histogram / cursor arrays are dynamic: 4 B per tile */
 
-struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; };
+struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, pad_; };   // a bin = `sub` stacked 16x64 tiles (sub > 1 only for maps beyond 16384 tiles)
 struct __attribute__((aligned(16))) BinTmp { int tile; unsigned int lc; float z, v; };        // staging, point order
 struct __attribute__((aligned(16))) BinRec { unsigned int lc_inl; float z, v; unsigned int i; };  // sorted by tile
 
@@ -60,8 +62,9 @@ __global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const 
     BinTmp r; r.tile = -1; r.lc = 0u; r.z = g.z; r.v = g.v;
     const int lrow = g.ix - P.row0;
     if (g.finite && g.valid && g.inside && lrow >= 0 && lrow < P.nrows) {
-      r.tile = (lrow / BIN_TR) * G.tiles_x + (g.iy / BIN_TC);
-      r.lc = (unsigned int)((lrow % BIN_TR) * BIN_TC + (g.iy % BIN_TC));
+      const int BR = BIN_TR * G.sub;
+      r.tile = (lrow / BR) * G.tiles_x + (g.iy / BIN_TC);
+      r.lc = (unsigned int)((lrow % BR) * BIN_TC + (g.iy % BIN_TC));
       atomicAdd(&h[r.tile], 1u);
     }
     tmp[i] = r;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, BinGeo G, const BinTm
       BinTmp r = tmp[i];
       if (r.tile >= 0) {
         const int ty = r.tile / G.tiles_x, tx = r.tile - ty * G.tiles_x;
-        const int lrow = ty * BIN_TR + (int)(r.lc / BIN_TC), col = tx * BIN_TC + (int)(r.lc % BIN_TC);
+        const int lrow = ty * BIN_TR * G.sub + (int)(r.lc / BIN_TC), col = tx * BIN_TC + (int)(r.lc % BIN_TC);
         const long c = (long)(lrow + P.halo) * P.C + col;
         float4 m = *reinterpret_cast<const float4*>(&cells[c]);   // h, v, valid, trav
         bool inlier = m.z > 0.5f && (double)fabsf(m.x - r.z) < (double)m.y * P.mt && (double)m.y < P.dcvi_half &&
@@ -148,55 +151,64 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
   constexpr int NC = BIN_TR * BIN_TC;
   __shared__ unsigned int s_pts[NC], s_inl[NC], s_cnt[NC], s_out[NC];
   __shared__ unsigned long long s_h[NC], s_v[NC], s_latest[NC];
-  for (int k = threadIdx.x; k < NC; k += EM_BLOCK) { s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull; }
   const int t = blockIdx.x, ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
   const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
-  __syncthreads();
-  for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {          // pass 1: newmap[4] / newmap[3]
-    const unsigned int w = recs[k].lc_inl;
-    atomicAdd(&s_pts[w & 0x7fffffffu], 1u);
-    if (w >> 31) atomicAdd(&s_inl[w & 0x7fffffffu], 1u);
-  }
-  __syncthreads();
   const float shift = F->shift;
-  for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {          // pass 2: custom_kernels.py:160-197
-    const BinRec r = recs[k];
-    const unsigned int lc = r.lc_inl & 0x7fffffffu;
-    const int lrow = ty * BIN_TR + (int)(lc / BIN_TC), col = tx * BIN_TC + (int)(lc % BIN_TC);
-    const long c = (long)(lrow + P.halo) * P.C + col;
-    const float2 hv = *reinterpret_cast<const float2*>(&cells[c]);
-    const float map_h = hv.x + shift, map_v = hv.y;
-    const float num_points = (float)s_pts[lc];
-    if ((double)fabsf(map_h - r.z) > (double)map_v * P.mt) { atomicAdd(&s_out[lc], 1u); continue; }
-    if (P.edge && (double)num_points > P.wall && (double)r.z < (double)map_h - (double)map_v * P.mt / (double)num_points) continue;
-    const float new_h = (map_h * r.v + r.z * map_v) / (map_v + r.v);
-    const float new_v = (map_v * r.v) / (map_v + r.v);
-    atomicAdd(&s_h[lc], (unsigned long long)__double2ll_rn((double)new_h * EM_SCALE_H));
-    atomicAdd(&s_v[lc], (unsigned long long)__double2ll_rn((double)new_v * EM_SCALE_V));
-    atomicAdd(&s_cnt[lc], 1u);
-    atomicMax(&s_latest[lc], ((unsigned long long)(r.i + 1u) << 32) | (unsigned long long)__float_as_uint(new_h));
-  }
-  __syncthreads();
   const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6, col = tx * BIN_TC + tc;
-  if (col >= P.C) return;
+  {                                               // blockIdx.y = which 16 x 64 tile of the bin (sub == 1 up to 16384 tiles)
+    const int sb = blockIdx.y, row_base = (ty * G.sub + sb) * BIN_TR;
+    if (row_base >= P.nrows) return;              // uniform, before any barrier
+    const unsigned int sel = (unsigned int)sb;
+    for (int k = threadIdx.x; k < NC; k += EM_BLOCK) { s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull; }
+    __syncthreads();
+    for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {          // pass 1: newmap[4] / newmap[3]
+      const unsigned int w = recs[k].lc_inl, lcb = w & 0x7fffffffu;
+      if ((lcb >> 10) != sel) continue;
+      atomicAdd(&s_pts[lcb & 1023u], 1u);
+      if (w >> 31) atomicAdd(&s_inl[lcb & 1023u], 1u);
+    }
+    __syncthreads();
+    for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {          // pass 2: custom_kernels.py:160-197
+      const BinRec r = recs[k];
+      const unsigned int lcb = r.lc_inl & 0x7fffffffu;
+      if ((lcb >> 10) != sel) continue;
+      const unsigned int lc = lcb & 1023u;
+      const int lrow = row_base + (int)(lc / BIN_TC), colr = tx * BIN_TC + (int)(lc % BIN_TC);
+      const long c = (long)(lrow + P.halo) * P.C + colr;
+      const float2 hv = *reinterpret_cast<const float2*>(&cells[c]);
+      const float map_h = hv.x + shift, map_v = hv.y;
+      const float num_points = (float)s_pts[lc];
+      if ((double)fabsf(map_h - r.z) > (double)map_v * P.mt) { atomicAdd(&s_out[lc], 1u); continue; }
+      if (P.edge && (double)num_points > P.wall && (double)r.z < (double)map_h - (double)map_v * P.mt / (double)num_points) continue;
+      const float new_h = (map_h * r.v + r.z * map_v) / (map_v + r.v);
+      const float new_v = (map_v * r.v) / (map_v + r.v);
+      atomicAdd(&s_h[lc], (unsigned long long)__double2ll_rn((double)new_h * EM_SCALE_H));
+      atomicAdd(&s_v[lc], (unsigned long long)__double2ll_rn((double)new_v * EM_SCALE_V));
+      atomicAdd(&s_cnt[lc], 1u);
+      atomicMax(&s_latest[lc], ((unsigned long long)(r.i + 1u) << 32) | (unsigned long long)__float_as_uint(new_h));
+    }
+    __syncthreads();
+    if (col < P.C) {
 #pragma unroll
-  for (int k = 0; k < BIN_TR / 4; ++k) {
-    const int tr = wv + 4 * k, lrow = ty * BIN_TR + tr;
-    if (lrow >= P.nrows) break;
-    const int lc = tr * BIN_TC + tc;
-    AccF a;
-    a.pts_inl = (unsigned long long)s_pts[lc] | ((unsigned long long)s_inl[lc] << 32);
-    a.cnt_out = (unsigned long long)s_cnt[lc] | ((unsigned long long)s_out[lc] << 32);
-    a.sum_h = (long long)s_h[lc]; a.sum_v = (long long)s_v[lc]; a.latest = s_latest[lc];
-    const long c = (long)(lrow + P.halo) * P.C + col;
-    if (AVG) {
-      Cell m = cells[c];
-      m.h += shift;
-      commit_cell(P, m, a);
-      average_cell(P, m, a);
-      cells[c] = m;
-      if (cnt_plane) cnt_plane[c] = s_cnt[lc];
-    } else acc[c] = a;
+      for (int k = 0; k < BIN_TR / 4; ++k) {
+        const int tr = wv + 4 * k, lrow = row_base + tr;
+        if (lrow >= P.nrows) break;
+        const int lc = tr * BIN_TC + tc;
+        AccF a;
+        a.pts_inl = (unsigned long long)s_pts[lc] | ((unsigned long long)s_inl[lc] << 32);
+        a.cnt_out = (unsigned long long)s_cnt[lc] | ((unsigned long long)s_out[lc] << 32);
+        a.sum_h = (long long)s_h[lc]; a.sum_v = (long long)s_v[lc]; a.latest = s_latest[lc];
+        const long c = (long)(lrow + P.halo) * P.C + col;
+        if (AVG) {
+          Cell m = cells[c];
+          m.h += shift;
+          commit_cell(P, m, a);
+          average_cell(P, m, a);
+          cells[c] = m;
+          if (cnt_plane) cnt_plane[c] = s_cnt[lc];
+        } else acc[c] = a;
+      }
+    }
   }
 }
 
@@ -240,8 +252,8 @@ void launch_bin_scatter(hipStream_t s, const KP& P, const BinGeo& G, const BinTm
 }
 void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cell* cells,
                      AccF* acc, const FrameDev* F, bool fuse_average, unsigned int* cnt_plane) {
-  if (fuse_average) hipLaunchKernelGGL(k_tile_fuse<true>, dim3(G.T), dim3(EM_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
-  else hipLaunchKernelGGL(k_tile_fuse<false>, dim3(G.T), dim3(EM_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
+  if (fuse_average) hipLaunchKernelGGL(k_tile_fuse<true>, dim3(G.T, G.sub), dim3(EM_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
+  else hipLaunchKernelGGL(k_tile_fuse<false>, dim3(G.T, G.sub), dim3(EM_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -263,13 +275,17 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
   const int t = blockIdx.x, ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
   const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
   const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6, col = tx * BIN_TC + tc;
+  const int row_base = (ty * G.sub + (int)blockIdx.y) * BIN_TR;       // blockIdx.y = which 16 x 64 tile of the bin
+  if (row_base >= P.nrows) return;
+  const unsigned int sel = blockIdx.y;
   for (int g0 = 0; g0 < S.n_sum; g0 += SEM_GROUP) {
     const int ng = min(SEM_GROUP, S.n_sum - g0);
     for (int k = threadIdx.x; k < SEM_GROUP * NC; k += EM_BLOCK) (&s_sum[0][0])[k] = 0.0;
     __syncthreads();
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {
       const BinRec r = recs[k];
-      const unsigned int lc = r.lc_inl & 0x7fffffffu;
+      if (((r.lc_inl & 0x7fffffffu) >> 10) != sel) continue;
+      const unsigned int lc = r.lc_inl & 1023u;
       const float* p = pts + (long)r.i * stride;
       for (int q = 0; q < ng; ++q) {
         const float v = p[S.sum_chan[g0 + q]];
@@ -284,7 +300,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
     __syncthreads();
     if (col < P.C) {
       for (int k = 0; k < BIN_TR / 4; ++k) {
-        const int tr = wv + 4 * k, lrow = ty * BIN_TR + tr;
+        const int tr = wv + 4 * k, lrow = row_base + tr;
         if (lrow >= P.nrows) break;
         const long c = (long)(lrow + P.halo) * P.C + col;
         const unsigned int cnt = cnt_plane[c];               // accepted HEIGHT points (new_elmap plane 2, :185)
@@ -312,7 +328,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
   }
   if (S.any_bayes && col < P.C) {     // class_bayesian: theta = alpha / sum(alpha) over its layers, same thread <-> same cells as above
     for (int k = 0; k < BIN_TR / 4; ++k) {
-      const int tr = wv + 4 * k, lrow = ty * BIN_TR + tr;
+      const int tr = wv + 4 * k, lrow = row_base + tr;
       if (lrow >= P.nrows) break;
       const long c = (long)(lrow + P.halo) * P.C + col;
       float tot = 0.0f;
@@ -329,7 +345,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
     __syncthreads();
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {
       const BinRec r = recs[k];
-      const unsigned int lc = r.lc_inl & 0x7fffffffu;
+      if (((r.lc_inl & 0x7fffffffu) >> 10) != sel) continue;
+      const unsigned int lc = r.lc_inl & 1023u;
       for (int l = 0; l < K; ++l) if ((long)r.i * K + l < n) atomicAdd(&s_col[3][lc], 1u);
     }
     __syncthreads();
@@ -338,8 +355,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
       __syncthreads();
       for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {
         const BinRec r = recs[k];
-        if ((long)r.i * K + l >= n) continue;
-        const unsigned int lc = r.lc_inl & 0x7fffffffu;
+        if ((long)r.i * K + l >= n || ((r.lc_inl & 0x7fffffffu) >> 10) != sel) continue;
+        const unsigned int lc = r.lc_inl & 1023u;
         const unsigned int color = __float_as_uint(pts[(long)r.i * stride + S.col_chan[l]]);
         atomicAdd(&s_col[0][lc], (color & 0xFF0000u) >> 16);
         atomicAdd(&s_col[1][lc], (color & 0xFF00u) >> 8);
@@ -348,7 +365,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
       __syncthreads();
       if (col < P.C) {
         for (int k = 0; k < BIN_TR / 4; ++k) {
-          const int tr = wv + 4 * k, lrow = ty * BIN_TR + tr, lc = tr * BIN_TC + tc;
+          const int tr = wv + 4 * k, lrow = row_base + tr, lc = tr * BIN_TC + tc;
           if (lrow >= P.nrows) break;
           const unsigned int cn = s_col[3][lc];
           if (cn == 0) continue;
@@ -362,5 +379,5 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
 }
 void launch_tile_semantic(hipStream_t s, const KP& P, const BinGeo& G, const SemSpec& S, const BinRec* recs, const unsigned int* tile_start,
                           const float* pts, long n, int stride, const unsigned int* cnt_plane, float* sem, float* alpha_planes, long plane) {
-  hipLaunchKernelGGL(k_tile_semantic, dim3(G.T), dim3(EM_BLOCK), 0, s, P, G, S, recs, tile_start, pts, n, stride, cnt_plane, sem, alpha_planes, plane);
+  hipLaunchKernelGGL(k_tile_semantic, dim3(G.T, G.sub), dim3(EM_BLOCK), 0, s, P, G, S, recs, tile_start, pts, n, stride, cnt_plane, sem, alpha_planes, plane);
 }

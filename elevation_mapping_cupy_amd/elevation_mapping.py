@@ -105,9 +105,10 @@ class ElevationMap:
     def close(self):
         self.__del__()
 
-    def set_scatter_mode(self, mode):
-        """"auto" | "atomic" | "binned": how count/fuse scatter into the map (bit-identical results)."""
-        self._chk(self._lib.emap_set_scatter_mode(self._ctx, {"auto": 0, "atomic": 1, "binned": 2}[mode]))
+    def set_scatter_mode(self, mode, bin_stack=0):
+        """"auto" | "atomic" | "binned": how count/fuse scatter into the map (bit-identical results).
+        ``bin_stack`` (test hook) forces bins of that many stacked 16x64 tiles, as maps beyond 16384 tiles use."""
+        self._chk(self._lib.emap_set_scatter_mode(self._ctx, {"auto": 0, "atomic": 1, "binned": 2}[mode] | (int(bin_stack) << 8)))
 
     def reload_params(self):
         """Push changed ``self.param`` scalars to the device (kernargs, no recompilation)."""

@@ -227,6 +227,30 @@ def test_fused_tile_kernel_without_rays(mode, weights):
     assert res["binned"] == res["atomic"]
 
 
+@pytest.mark.parametrize("rays", [True, False])
+@pytest.mark.parametrize("stack", [2, 8])
+def test_stacked_bins_of_large_maps_are_bit_identical(stack, rays, weights):
+    """maps with more than 16384 tiles (e.g. 8192^2 on one GPU) sort into bins of 2, 4, ... stacked tiles and reduce them one
+    tile per workgroup (blockIdx.y); forced here on a small map (202 rows is not a multiple of 16 * stack) incl. semantic + RGB."""
+    C, N = 202, 60000
+    cfg = dict(eo.YAML, enable_visibility_cleanup=rays)
+    res = []
+    for scatter, st in (("atomic", 0), ("binned", 0), ("binned", stack)):
+        hip, _ = make_pair(cfg, C, "reference_fp16", weights)
+        hip.set_scatter_mode(scatter, bin_stack=st)
+        hip.param.pointcloud_channel_fusions = {"rgb": "color", "default": "average"}
+        R, t = fx.POSES["rotated"]
+        for f, dz in enumerate((0.0, -0.02, -0.2)):
+            p = fx.semantic_cloud(C, N, f); p[:, 2] += dz
+            p[300:900, :2] = p[300, :2]
+            hip.input_pointcloud(p, ["x", "y", "z", "s0", "s1", "c0", "rgb"], R, t.copy() + hip.center, 1.0, 1.0)
+            for k in range(6):
+                hip.update_time()
+        res.append(hip.elevation_map.tobytes() + hip.normal_map.tobytes() + hip.semantic_map.semantic_map.tobytes())
+        hip.close()
+    assert res[0] == res[1] == res[2]
+
+
 @pytest.mark.parametrize("d", [1, 3, 10])
 def test_fused_post_kernel_equals_the_two_stencil_stages(d, weights):
     """k_post (dilation -> traversability + normals in one launch) vs k_dilate + k_trav_normal, holes everywhere."""
