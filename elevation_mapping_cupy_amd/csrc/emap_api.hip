@@ -26,6 +26,8 @@ static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec 
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
 void launch_sem_finalize(hipStream_t, const KP&, const SemSpec&, const unsigned int*, double*, unsigned int*, float*, float*, long);
 void launch_sem_shift(hipStream_t, int, int, const float*, float*, int, int);
+void launch_polygon_mask(hipStream_t, int, const int*, const int*, int, const int*, float*);
+void launch_dilate_planes(hipStream_t, int, int, const float*, const float*, float*, float*);
 struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; };
 void launch_image_corr(hipStream_t, const KP&, const CamArgs&, const Cell*, float*, unsigned char*);
 void launch_image_fuse(hipStream_t, const KP&, int, float*, const float*, const float*, const unsigned char*, float, float, double);
@@ -1000,6 +1002,77 @@ int emap_image_fuse(emap_ctx* ctx, int32_t kind, int32_t layer, const float* hos
                     (float)height, (float)width, alpha);
   CK(hipGetLastError());
   CK(hipStreamSynchronize(ctx->stream));   // host image is only borrowed for the call
+  return EMAP_OK;
+}
+
+// ---- safety polygon (reference elevation_mapping.py:837-889, polygon_mask_kernel custom_kernels.py:509-651) -------------
+// get_idx of the polygon kernel (:587-603): float16 helper parameters, FLOAT resolution / width constants (unlike the map
+// kernels), index clamped through float16.
+static int polygon_cell(const emap_params& p, float x, float y, float cx, float cy, int* ix, int* iy) {
+  const bool h = p.mode == EMAP_MODE_REFERENCE_FP16;
+  auto Q = [&](float v) { return h ? q16(v) : v; };
+  auto axis = [&](float v, float c) {
+    const float q = (Q(v) - Q(c)) / (float)p.resolution;
+    const double val = (double)q + 0.5 * (double)(float)p.cell_n;
+    int i = (val != val) ? 0 : (int)fmin(fmax(val, -2147483648.0), 2147483647.0);
+    float fi = Q((float)i);
+    fi = fmaxf(fminf(fi, Q((float)(p.cell_n - 1))), Q(0.0f));
+    return (int)fi;
+  };
+  const int idx = p.cell_n * axis(x, cx) + axis(y, cy);
+  *ix = idx / p.cell_n; *iy = idx % p.cell_n;
+  return idx;
+}
+int emap_polygon_mask(emap_ctx* ctx, const float* polygon_xy, int32_t n_vertices, float center_x, float center_y, float* host_mask) {
+  CKARG(ctx && polygon_xy && host_mask && n_vertices >= 1 && n_vertices <= 4096, "bad polygon");
+  CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "emap_polygon_mask: single-strip contexts only");
+  CK(hipSetDevice(ctx->device));
+  const int C = ctx->prm.cell_n;
+  std::vector<int> v(2 * (size_t)n_vertices);
+  float mn[2] = {polygon_xy[0], polygon_xy[1]}, mx[2] = {polygon_xy[0], polygon_xy[1]};
+  for (int j = 0; j < n_vertices; ++j) {
+    polygon_cell(ctx->prm, polygon_xy[2 * j], polygon_xy[2 * j + 1], center_x, center_y, &v[j], &v[n_vertices + j]);
+    for (int a = 0; a < 2; ++a) { mn[a] = fminf(mn[a], polygon_xy[2 * j + a]); mx[a] = fmaxf(mx[a], polygon_xy[2 * j + a]); }
+  }
+  int bbox[4];
+  polygon_cell(ctx->prm, mn[0], mn[1], center_x, center_y, &bbox[0], &bbox[1]);
+  polygon_cell(ctx->prm, mx[0], mx[1], center_x, center_y, &bbox[2], &bbox[3]);
+  int* dv = nullptr;
+  CK(hipMalloc((void**)&dv, sizeof(int) * v.size()));
+  hipError_t e = hipMemcpyAsync(dv, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    launch_polygon_mask(ctx->stream, C, dv, dv + n_vertices, n_vertices, bbox, ctx->scratch);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(host_mask, ctx->scratch, sizeof(float) * (size_t)C * C, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(dv);
+  if (e != hipSuccess) { ctx->err = std::string("emap_polygon_mask: ") + hipGetErrorString(e); return EMAP_ERR_HIP; }
+  return EMAP_OK;
+}
+
+// ---- dilation of caller planes: ElevationMap.initialize_map (reference elevation_mapping.py:899-923) ---------------------
+int emap_dilate_planes(emap_ctx* ctx, const float* host_plane, const float* host_mask, int32_t dilation_size, int32_t iterations,
+                       float* host_out, float* host_out_mask) {
+  CKARG(ctx && host_plane && host_mask && host_out && host_out_mask, "null argument");
+  CKARG(dilation_size >= 0 && dilation_size <= 64 && iterations >= 1 && iterations <= 64, "bad dilation size / iteration count");
+  CK(hipSetDevice(ctx->device));
+  const int C = ctx->prm.cell_n; const size_t L = (size_t)C * C, bytes = L * sizeof(float);
+  float* buf = nullptr;
+  CK(hipMalloc((void**)&buf, bytes * 4));
+  float *p0 = buf, *m0 = buf + L, *p1 = buf + 2 * L, *m1 = buf + 3 * L;
+  hipError_t e = hipMemcpyAsync(p0, host_plane, bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(m0, host_mask, bytes, hipMemcpyHostToDevice, ctx->stream);
+  for (int it = 0; it < iterations && e == hipSuccess; ++it) {
+    launch_dilate_planes(ctx->stream, C, dilation_size, p0, m0, p1, m1);
+    e = hipGetLastError();
+    float* t = p0; p0 = p1; p1 = t; t = m0; m0 = m1; m1 = t;
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(host_out, p0, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(host_out_mask, m0, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(buf);
+  if (e != hipSuccess) { ctx->err = std::string("emap_dilate_planes: ") + hipGetErrorString(e); return EMAP_ERR_HIP; }
   return EMAP_OK;
 }
 

@@ -320,3 +320,76 @@ void launch_image_fuse(hipStream_t s, const KP& P, int kind, float* sem, const f
                        float ih, float iw, double alpha) {
   hipLaunchKernelGGL(k_image_fuse, dim3(nblk_((long)P.C * P.C)), dim3(EM_BLOCK), 0, s, P, kind, sem, image, uv, valid, ih, iw, alpha);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Safety-polygon service: polygon_mask_kernel (reference EM/kernels/custom_kernels.py:509-651).  The vertex and bounding-box
+// cell indices depend only on the polygon, so the host computes them once with the reference's arithmetic (float16 helper
+// parameters, fp32 division; emap_api.hip: emap_polygon_mask); the per-cell test below is the reference's integer
+// ray-crossing test, literally.
+// ---------------------------------------------------------------------------------------------------------
+struct PtI { int x, y; };
+__device__ __forceinline__ bool pm_on_segment(PtI p, PtI q, PtI r) {
+  return q.x <= max(p.x, r.x) && q.x >= min(p.x, r.x) && q.y <= max(p.y, r.y) && q.y >= min(p.y, r.y);
+}
+__device__ __forceinline__ int pm_orientation(PtI p, PtI q, PtI r) {
+  int val = (q.y - p.y) * (r.x - q.x) - (q.x - p.x) * (r.y - q.y);
+  if (val == 0) return 0;
+  return (val > 0) ? 1 : 2;
+}
+__device__ __forceinline__ bool pm_intersect(PtI p1, PtI q1, PtI p2, PtI q2) {
+  int o1 = pm_orientation(p1, q1, p2), o2 = pm_orientation(p1, q1, q2), o3 = pm_orientation(p2, q2, p1), o4 = pm_orientation(p2, q2, q1);
+  if (o1 != o2 && o3 != o4) return true;
+  if (o1 == 0 && pm_on_segment(p1, p2, q1)) return true;
+  if (o2 == 0 && pm_on_segment(p1, q2, q1)) return true;
+  if (o3 == 0 && pm_on_segment(p2, p1, q2)) return true;
+  if (o4 == 0 && pm_on_segment(p2, q1, q2)) return true;
+  return false;
+}
+__global__ __launch_bounds__(EM_BLOCK) void k_polygon_mask(int C, const int* __restrict__ vx, const int* __restrict__ vy, int n,
+                                                            int bminx, int bminy, int bmaxx, int bmaxy, float* __restrict__ mask) {
+  long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= (long)C * C) return;
+  PtI p = {(int)(i / C), (int)(i % C)}, extreme = {100000, p.y};
+  if (p.x < bminx || p.x > bmaxx || p.y < bminy || p.y > bmaxy) { mask[i] = 0.f; return; }
+  int cnt = 0;
+  for (int j = 0; j < n; ++j) {
+    const int j2 = (j + 1) % n;
+    PtI p1 = {vx[j], vy[j]}, p2 = {vx[j2], vy[j2]};
+    if (pm_intersect(p1, p2, p, extreme)) {
+      if (pm_orientation(p1, p, p2) == 0) {
+        if (pm_on_segment(p1, p, p2)) { mask[i] = 1.f; return; }
+      } else if (((p1.y <= p.y) && (p2.y > p.y)) || ((p1.y > p.y) && (p2.y <= p.y))) cnt++;
+    }
+  }
+  mask[i] = (cnt % 2 == 0) ? 0.f : 1.f;
+}
+void launch_polygon_mask(hipStream_t s, int C, const int* vx, const int* vy, int n, const int bbox[4], float* mask) {
+  hipLaunchKernelGGL(k_polygon_mask, dim3(nblk_((long)C * C)), dim3(EM_BLOCK), 0, s, C, vx, vy, n, bbox[0], bbox[1], bbox[2], bbox[3], mask);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dilation_filter_kernel on caller-provided planes (reference custom_kernels.py:392-449), used by ElevationMap.initialize_map
+// (elevation_mapping.py:914-921, radius dilation_size_initialize).  The reference runs it IN PLACE there (map == newmap,
+// mask == newmask: a race on the GPU); this is the out-of-place (Jacobi) outcome.  Service rate: plain window search.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EM_BLOCK) void k_dilate_planes(int C, int d, const float* __restrict__ plane, const float* __restrict__ mask,
+                                                             float* __restrict__ out, float* __restrict__ outmask) {
+  const long L = (long)C * C, i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= L) return;
+  float o = plane[i], om = mask[i];
+  if (om < 0.5f) {
+    float distance = 100.f, near_value = 0.f;
+    for (int dy = -d; dy <= d; ++dy) for (int dx = -d; dx <= d; ++dx) {
+      const long j = i + (long)C * dy + dx;
+      if (j < 0 || j >= L) continue;
+      const long jx = j / C, jy = j % C;
+      if (jx <= 0 || jx >= C - 1 || jy <= 0 || jy >= C - 1) continue;
+      if (mask[j] > 0.5f && (float)(dx + dy) < distance) { distance = (float)(dx + dy); near_value = plane[j]; }
+    }
+    if (distance < 100.f) { o = near_value; om = 1.0f; }
+  }
+  out[i] = o; outmask[i] = om;
+}
+void launch_dilate_planes(hipStream_t s, int C, int d, const float* plane, const float* mask, float* out, float* outmask) {
+  hipLaunchKernelGGL(k_dilate_planes, dim3(nblk_((long)C * C)), dim3(EM_BLOCK), 0, s, C, d, plane, mask, out, outmask);
+}

@@ -391,48 +391,165 @@ class ElevationMap:
                                                        int(bool(self.param.use_only_above_for_upper_bound)), f32p(data)))
             return
         with self.map_lock:
-            if name == "elevation":
-                m = self._publish(self.get_layer_raw(0), True, True, self.get_layer_raw(2))
-            elif name == "variance":
-                m = self._publish(self.get_layer_raw(1))
-            elif name == "traversability":
-                trav = np.where((self.get_layer_raw(2) + self.get_layer_raw(6)) > 0.5, self.get_layer_raw(3), np.nan)
-                self.traversability_buffer[3:-3, 3:-3] = trav[3:-3, 3:-3]
-                m = self.traversability_buffer[1:-1, 1:-1]
-            elif name == "time":
-                m = self._publish(self.get_layer_raw(4))
-            elif name in ("upper_bound", "is_upper_bound"):
-                e = self.elevation_map
-                if self.param.use_only_above_for_upper_bound:
-                    valid = np.logical_or(np.logical_and(e[5] > 0.0, e[6] > 0.5), e[2] > 0.5)
-                else:
-                    valid = np.logical_or(e[2] > 0.5, e[6] > 0.5)
-                if name == "upper_bound":
-                    m = np.where(valid, e[5], np.nan)[1:-1, 1:-1] + self.center[2]
-                else:
-                    m = np.where(valid, e[6], np.nan)[1:-1, 1:-1]
-            elif name in ("normal_x", "normal_y", "normal_z"):
-                m = self.get_layer_raw(name)[1:-1, 1:-1]
-            elif self.semantic_map is not None and name in self.semantic_map.layer_names:
-                m = self.semantic_map.get_map_with_name(name)
-            elif self.plugin_manager is not None and name in self.plugin_manager.layer_names:
-                self.plugin_manager.update_with_name(
-                    name, self.elevation_map, self.layer_names,
-                    self.semantic_map.semantic_map if self.semantic_map is not None else None,
-                    self.semantic_map.layer_names if self.semantic_map is not None else [],
-                    self.base_rotation, self.semantic_map.elements_to_shift if self.semantic_map is not None else {})
-                m = self.plugin_manager.get_map_with_name(name)
-                p = self.plugin_manager.get_param_with_name(name)
-                m = self._publish(np.asarray(m), p.fill_nan, p.is_height_layer, self.get_layer_raw(2))
-            else:
-                print("Layer {} is not in the map".format(name))
-                return
+            m = self._stripped_layer(name)
+        if m is None:
+            print("Layer {} is not in the map".format(name))
+            return
         m = np.flip(np.flip(m, 0), 1)
         data[...] = m.astype(np.float32)
 
-    def get_normal_ref(self, normal_x_data, normal_y_data, normal_z_data):
+    def _stripped_layer(self, name):
+        """border-stripped, unflipped layer as the reference's get_* accessors return it (:598-680, :740-765)"""
+        if name == "elevation":
+            return self._publish(self.get_layer_raw(0), True, True, self.get_layer_raw(2))
+        if name == "variance":
+            return self._publish(self.get_layer_raw(1))
+        if name == "traversability":
+            trav = np.where((self.get_layer_raw(2) + self.get_layer_raw(6)) > 0.5, self.get_layer_raw(3), np.nan)
+            self.traversability_buffer[3:-3, 3:-3] = trav[3:-3, 3:-3]
+            return self.traversability_buffer[1:-1, 1:-1]
+        if name == "time":
+            return self._publish(self.get_layer_raw(4))
+        if name in ("upper_bound", "is_upper_bound"):
+            e = self.elevation_map
+            if self.param.use_only_above_for_upper_bound:
+                valid = np.logical_or(np.logical_and(e[5] > 0.0, e[6] > 0.5), e[2] > 0.5)
+            else:
+                valid = np.logical_or(e[2] > 0.5, e[6] > 0.5)
+            if name == "upper_bound":
+                return np.where(valid, e[5], np.nan)[1:-1, 1:-1] + self.center[2]
+            return np.where(valid, e[6], np.nan)[1:-1, 1:-1]
+        if name in ("normal_x", "normal_y", "normal_z"):
+            return self.get_layer_raw(name)[1:-1, 1:-1]
+        if self.semantic_map is not None and name in self.semantic_map.layer_names:
+            return self.semantic_map.get_map_with_name(name)
+        if self.plugin_manager is not None and name in self.plugin_manager.layer_names:
+            self.plugin_manager.update_with_name(
+                name, self.elevation_map, self.layer_names,
+                self.semantic_map.semantic_map if self.semantic_map is not None else None,
+                self.semantic_map.layer_names if self.semantic_map is not None else [],
+                self.base_rotation, self.semantic_map.elements_to_shift if self.semantic_map is not None else {})
+            m = self.plugin_manager.get_map_with_name(name)
+            p = self.plugin_manager.get_param_with_name(name)
+            return self._publish(np.asarray(m), p.fill_nan, p.is_height_layer, self.get_layer_raw(2))
+        return None
+
+    # the reference's per-layer accessors (:598-680): host arrays, border stripped, NOT flipped
+    def process_map_for_publish(self, input_map, fill_nan=False, add_z=False, xp=np):
+        return self._publish(np.asarray(input_map), fill_nan, add_z, self.get_layer_raw(2) if fill_nan else None)
+
+    def get_elevation(self):
+        return self._stripped_layer("elevation")
+
+    def get_variance(self):
+        return self._stripped_layer("variance")
+
+    def get_traversability(self):
+        return self._stripped_layer("traversability")
+
+    def get_time(self):
+        return self._stripped_layer("time")
+
+    def get_upper_bound(self):
+        return self._stripped_layer("upper_bound")
+
+    def get_is_upper_bound(self):
+        return self._stripped_layer("is_upper_bound")
+
+    def get_normal_maps(self):
+        """(3, C-2, C-2), flipped on both axes like the reference (:776-790)"""
         n = self.normal_map[:, 1:-1, 1:-1]
-        n = np.flip(np.flip(n, 1), 2)
+        return np.ascontiguousarray(np.flip(np.flip(n, 1), 2))
+
+    def xp_of_array(self, array):
+        return np if isinstance(array, np.ndarray) else None
+
+    def copy_to_cpu(self, array, data, stream=None):
+        data[...] = np.asarray(array).astype(np.float32)
+
+    # ---- safety-polygon service (reference :837-897) ---------------------------------------------------------
+    def polygon_mask(self, polygon):
+        """(cell_n, cell_n) 0/1 mask of the cells inside ``polygon`` ((M, 2) world coordinates, already clipped): the device
+        kernel behind get_polygon_traversability (polygon_mask_kernel, custom_kernels.py:509-651)."""
+        poly = np.ascontiguousarray(polygon, np.float32)
+        mask = np.empty((self.cell_n, self.cell_n), np.float32)
+        self._chk(self._lib.emap_polygon_mask(self._ctx, f32p(poly), int(poly.shape[0]), ct.c_float(float(self.center[0])),
+                                              ct.c_float(float(self.center[1])), f32p(mask)))
+        return mask
+
+    def get_polygon_traversability(self, polygon, result):
+        from .traversability_polygon import (calculate_area, get_masked_traversability, is_traversable,
+                                             transform_to_map_position)
+        polygon = np.asarray(polygon)
+        area = calculate_area(polygon)
+        polygon = polygon.astype(np.float32)
+        pmin = self.center[:2] - self.map_length / 2 + self.resolution
+        pmax = self.center[:2] + self.map_length / 2 - self.resolution
+        polygon[:, 0] = polygon[:, 0].clip(pmin[0], pmax[0])
+        polygon[:, 1] = polygon[:, 1].clip(pmin[1], pmax[1])
+        clipped_area = calculate_area(polygon)
+        with self.map_lock:
+            self.mask = self.polygon_mask(polygon)
+            tmp_map = self.get_layer(self.param.checker_layer)
+            masked, masked_isvalid = get_masked_traversability(self.elevation_map, self.mask, tmp_map)
+        t = masked.sum() / masked_isvalid.sum() if masked_isvalid.sum() > 0 else np.float32(0.0)
+        is_safe, un_polygon = is_traversable(masked, self.param.safe_thresh, self.param.safe_min_thresh, self.param.max_unsafe_n)
+        untraversable_polygon_num = 0
+        if un_polygon is not None:
+            un_polygon = transform_to_map_position(un_polygon, self.center[:2], self.cell_n, self.resolution)
+            untraversable_polygon_num = un_polygon.shape[0]
+        if clipped_area < 0.001:
+            is_safe = False
+            print("requested polygon is outside of the map")
+        result[...] = np.array([is_safe, float(t), float(area)])
+        self.untraversable_polygon = un_polygon
+        return untraversable_polygon_num
+
+    def get_untraversable_polygon(self, untraversable_polygon):
+        untraversable_polygon[...] = np.asarray(self.untraversable_polygon)
+
+    # ---- map initialisation from a few known points (reference :899-923, map_initializer.py:25-62) -----------------
+    def initialize_map(self, points, method="cubic"):
+        """Interpolate the elevation between ``points`` ((M, 3) world x, y, z; e.g. the feet positions) with
+        ``scipy.interpolate.griddata`` -- host code in the reference too -- then two dilation passes of radius
+        ``dilation_size_initialize`` on the device and upper bound := elevation on valid cells."""
+        from scipy.interpolate import griddata
+        from .traversability_polygon import transform_to_map_index
+        self.clear()
+        with self.map_lock:
+            points = np.array(points, dtype=np.float32)
+            indices = transform_to_map_index(points[:, :2], self.center[:2].astype(np.float32), self.cell_n, self.resolution)
+            points[:, :2] = indices.astype(points.dtype)
+            points[:, 2] -= self.center[2]
+            m = self.elevation_map
+            known = np.where(m[2] > 0.5)
+            pts_idx = np.vstack([np.stack(known).T, points[:, :2]])
+            values = np.hstack([m[0][known], points[:, 2]])
+            assert pts_idx.shape[0] > 3, "Initialization points must be more than 3."
+            gx, gy = np.mgrid[0:self.cell_n, 0:self.cell_n]
+            interpolated = griddata(pts_idx, values, (gx, gy), method=method)
+            ok = ~np.isnan(interpolated)
+            m[0] = np.nan_to_num(interpolated)
+            m[1] = np.where(ok, self.param.initialized_variance, self.initial_variance)
+            m[2] = np.where(ok, 1.0, 0.0)
+            if self.param.dilation_size_initialize > 0:
+                e = np.ascontiguousarray(m[0], np.float32); v = np.ascontiguousarray(m[2], np.float32)
+                oe, ov = np.empty_like(e), np.empty_like(v)
+                self._chk(self._lib.emap_dilate_planes(self._ctx, f32p(e), f32p(v), int(self.param.dilation_size_initialize), 2, f32p(oe), f32p(ov)))
+                m[0], m[2] = oe, ov
+            mask = m[2] > 0.5                       # update_upper_bound_with_valid_elevation (:428-432)
+            m[5] = np.where(mask, m[0], m[5])
+            m[6] = np.where(mask, 0.0, m[6])
+            for k in (0, 1, 2, 5, 6):
+                self.set_layer_raw(k, m[k])
+
+    def compile_kernels(self):
+        """nothing to compile: parameters are kernel arguments of the prebuilt gfx950 library (reference :228-282)"""
+
+    compile_image_kernels = compile_kernels
+
+    def get_normal_ref(self, normal_x_data, normal_y_data, normal_z_data):
+        n = self.get_normal_maps()
         normal_x_data[...] = n[0]
         normal_y_data[...] = n[1]
         normal_z_data[...] = n[2]
@@ -443,4 +560,12 @@ class ElevationMap:
             return self.get_layer_raw(self.layer_names.index(name))
         if self.semantic_map is not None and name in self.semantic_map.layer_names:
             return self.semantic_map._layer(self.semantic_map.layer_names.index(name))
+        if self.plugin_manager is not None and name in self.plugin_manager.layer_names:
+            self.plugin_manager.update_with_name(
+                name, self.elevation_map, self.layer_names,
+                self.semantic_map.semantic_map if self.semantic_map is not None else None,
+                self.semantic_map.layer_names if self.semantic_map is not None else [],
+                self.base_rotation, self.semantic_map.elements_to_shift if self.semantic_map is not None else {})
+            return self.plugin_manager.get_map_with_name(name)
+        print("Layer {} is not in the map, returning traversabiltiy!".format(name))
         return None

@@ -181,6 +181,16 @@ int emap_image_get_correspondence(emap_ctx* ctx, float* uv_host /* (2, cell_n, c
 int emap_image_fuse(emap_ctx* ctx, int32_t kind, int32_t layer, const float* host_image, int32_t n_planes, int32_t height,
                     int32_t width, double alpha);
 
+/* ---- safety-polygon service: polygon_mask_kernel (EM/kernels/custom_kernels.py:509-651) as launched by
+ * ElevationMap.get_polygon_traversability (EM/elevation_mapping.py:837-889).  `polygon_xy` = (n, 2) float32 world
+ * coordinates already clipped to the map (:851-855); writes the (cell_n, cell_n) 0/1 mask to host memory. */
+int emap_polygon_mask(emap_ctx* ctx, const float* polygon_xy, int32_t n_vertices, float center_x, float center_y, float* host_mask);
+
+/* dilation_filter_kernel (EM/kernels/custom_kernels.py:392-449) on host planes (cell_n x cell_n), `iterations` out-of-place
+ * passes -- the two passes of ElevationMap.initialize_map (EM/elevation_mapping.py:914-921; in place, i.e. racy, there). */
+int emap_dilate_planes(emap_ctx* ctx, const float* host_plane, const float* host_mask, int32_t dilation_size, int32_t iterations,
+                       float* host_out, float* host_out_mask);
+
 /* ---- row-strip halos (multi-GPU; exchange itself is done by the caller, e.g. torch.distributed/RCCL) ---- */
 /* pack `halo_rows` owned boundary rows (32-byte cells) next to the lower (side 0) / upper (side 1) neighbour
  * into a device buffer; unpack a neighbour's rows into the halo. Buffers: halo_rows*cell_n*8 floats. */

@@ -8,8 +8,8 @@ and ``custom_semantic_kernels.py``).  CuPy and CUDA are absent here, so this scr
 2. imports the two reference kernel files *where they lie* under ``/root/reference`` and calls their
    factories with the requested parameter set (parameters are baked into the source as literals, exactly
    as the reference does, so one parameter set == one shared object),
-3. wraps every captured ``operation`` in a sequential ``for (ptrdiff_t i = 0; i < size; ++i)`` loop
-   (``return;`` -> ``continue;``) behind ``oracle/ref_shim.h`` and
+3. wraps every captured ``operation`` in a sequential ``for (ptrdiff_t i = 0; i < size; ++i)`` loop (the body runs in a
+   per-element lambda so that ``return;`` ends the element, also from inner loops) behind ``oracle/ref_shim.h`` and
 4. builds ``oracle/_ref/ref_<hash>.so`` with ``g++ -O2 -mf16c -ffp-contract=off``.
 
 Nothing from the reference is copied into the repository: the generated translation unit and the .so live
@@ -123,6 +123,9 @@ def _instantiate(p):
         ks["alpha"] = (cb.alpha_kernel(res, C, C), f32)
         ks["sum_compact"] = (bi.sum_compact_kernel(res, C, C), f32)
         ks["bayesian_inference"] = (bi.bayesian_inference_kernel(C, C), f32)
+    if p.get("polygon_kernel"):
+        # safety-polygon service (reference elevation_mapping.py:283, 837-889): `raw int16 polygon_n` is a concrete type
+        ks["polygon_mask"] = (ck.polygon_mask_kernel(C, C, res), dict(f32, int16="short"))
     for extra in p.get("extra_dilation_sizes", ()):
         ks["dilation_filter_%d" % extra] = (ck.dilation_filter_kernel(C, C, extra), f32)
     for d in p.get("min_filter_sizes", ()):
@@ -203,13 +206,13 @@ def _emit(ks):
         k, types_ = spec[0], spec[1]
         scalars = spec[2] if len(spec) > 2 else set()
         params = _parse_params(k.in_params) + _parse_params(k.out_params)
-        op = re.sub(r"\breturn\s*;", "continue;", k.operation)
+        op = k.operation                       # runs inside a per-element lambda, so `return;` keeps its meaning even in inner loops
         args = ", ".join(("%s %s" % (types_[t], n)) if n in scalars else ("%s* %s_" % (types_[t], n)) for t, n in params)
         binds = "".join("  Raw<%s> %s{%s_};\n" % (types_[t], n, n) for t, n in params if n not in scalars)
         tds = "".join("typedef %s %s;\n" % (v, kk) for kk, v in types_.items())
         src.append(
             "namespace ns_%s {\n%s%s\nextern \"C\" void ref_%s(%s, long size_) {\n%s"
-            "  for (ptrdiff_t i = 0; i < size_; ++i) {\n%s\n  }\n}\n}\n" % (sym, tds, k.preamble, sym, args, binds, op))
+            "  for (ptrdiff_t i = 0; i < size_; ++i) {\n  [&]() {\n%s\n  }();\n  }\n}\n}\n" % (sym, tds, k.preamble, sym, args, binds, op))
     return "\n".join(src)
 
 
@@ -250,6 +253,7 @@ PREBUILD = {
     "yaml66": with_(PARAM_YAML, cell_n=66, extra_dilation_sizes=(1, 2, 10)),
     "image98": with_(PARAM_YAML, cell_n=98, image_kernels=True),
     "bayes66": with_(PARAM_YAML, cell_n=66, bayes_kernels=True),
+    "polygon130": with_(PARAM_DEFAULT, cell_n=130, polygon_kernel=True),
 }
 
 

@@ -501,6 +501,55 @@ void eo_sem_color(const eo_params* P, const float* pts, long n, long stride, con
   free(acc);
 }
 
+/* ---- safety polygon: polygon_mask_kernel (reference kernels/custom_kernels.py:509-651).  get_idx of THIS kernel divides in
+ * fp32 (`const float resolution`), rounds coordinates / centre / index through float16 like the other helpers. ---- */
+typedef struct { int x, y; } pt_i;
+static int pm_axis(const eo_params* P, float v, float c) {
+  float a = Q(v), b = Q(c);
+  float q = (a - b) / (float)P->resolution;
+  double val = (double)q + 0.5 * (double)(float)P->cell_n;
+  int i = (int)val;
+  float fi = Q((float)i), hi = Q((float)(P->cell_n - 1));
+  fi = fmaxf(fminf(fi, hi), 0.0f);
+  return (int)fi;
+}
+static int pm_on_segment(pt_i p, pt_i q, pt_i r) {
+  return q.x <= (p.x > r.x ? p.x : r.x) && q.x >= (p.x < r.x ? p.x : r.x) && q.y <= (p.y > r.y ? p.y : r.y) && q.y >= (p.y < r.y ? p.y : r.y);
+}
+static int pm_orientation(pt_i p, pt_i q, pt_i r) {
+  int val = (q.y - p.y) * (r.x - q.x) - (q.x - p.x) * (r.y - q.y);
+  return val == 0 ? 0 : (val > 0 ? 1 : 2);
+}
+static int pm_intersect(pt_i p1, pt_i q1, pt_i p2, pt_i q2) {
+  int o1 = pm_orientation(p1, q1, p2), o2 = pm_orientation(p1, q1, q2), o3 = pm_orientation(p2, q2, p1), o4 = pm_orientation(p2, q2, q1);
+  if (o1 != o2 && o3 != o4) return 1;
+  if (o1 == 0 && pm_on_segment(p1, p2, q1)) return 1;
+  if (o2 == 0 && pm_on_segment(p1, q2, q1)) return 1;
+  if (o3 == 0 && pm_on_segment(p2, p1, q2)) return 1;
+  if (o4 == 0 && pm_on_segment(p2, q1, q2)) return 1;
+  return 0;
+}
+void eo_polygon_mask(const eo_params* P, const float* polygon, int n, float cx, float cy, const float* bbox, float* mask) {
+  const int C = P->cell_n;
+  pt_i* v = (pt_i*)malloc(sizeof(pt_i) * (size_t)n);
+  for (int j = 0; j < n; ++j) { v[j].x = pm_axis(P, polygon[2 * j], cx); v[j].y = pm_axis(P, polygon[2 * j + 1], cy); }
+  pt_i bmin = {pm_axis(P, bbox[0], cx), pm_axis(P, bbox[1], cy)}, bmax = {pm_axis(P, bbox[2], cx), pm_axis(P, bbox[3], cy)};
+  for (long i = 0; i < (long)C * C; ++i) {
+    pt_i p = {(int)(i / C), (int)(i % C)}, extreme = {100000, p.y};
+    if (p.x < bmin.x || p.x > bmax.x || p.y < bmin.y || p.y > bmax.y) { mask[i] = 0; continue; }
+    int cnt = 0, on_edge = 0;
+    for (int j = 0; j < n && !on_edge; ++j) {
+      pt_i p1 = v[j], p2 = v[(j + 1) % n];
+      if (pm_intersect(p1, p2, p, extreme)) {
+        if (pm_orientation(p1, p, p2) == 0) { if (pm_on_segment(p1, p, p2)) on_edge = 1; }
+        else if (((p1.y <= p.y) && (p2.y > p.y)) || ((p1.y > p.y) && (p2.y <= p.y))) cnt++;
+      }
+    }
+    mask[i] = on_edge ? 1.0f : (cnt % 2 == 0 ? 0.0f : 1.0f);
+  }
+  free(v);
+}
+
 /* ---- camera path: image_to_map_correspondence_kernel (reference kernels/custom_image_kernels.py:9-157) and the
  * per-cell samplers exponential_/color_correspondences_to_map_kernel (:195-271).  Per-cell, race free.  The scalars
  * x1, y1 (camera cell, uint32 valued), z1, image_height, image_width arrive as float32 like in the reference call

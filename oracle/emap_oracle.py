@@ -301,6 +301,15 @@ def image_fuse(P, kind, sem_plane, image, uv, valid, image_height, image_width, 
                         ct.c_float(image_height), ct.c_float(image_width), ct.c_double(alpha))
 
 
+def polygon_mask(P, polygon, center_x, center_y):
+    """0/1 mask of polygon_mask_kernel; polygon (M, 2) float32 world coordinates (already clipped to the map)"""
+    poly = np.ascontiguousarray(polygon, np.float32)
+    bbox = np.concatenate([poly.min(axis=0), poly.max(axis=0)]).astype(np.float32)
+    mask = np.zeros((P.cell_n, P.cell_n), np.float32)
+    lib().eo_polygon_mask(ct.byref(P), _p(poly), ct.c_int(poly.shape[0]), ct.c_float(center_x), ct.c_float(center_y), _p(bbox), _p(mask))
+    return mask
+
+
 def set_threads(n):
     """OpenMP threads of the C oracle (1 = sequential, bit-reproducible: the setting every parity test uses)."""
     lib().eo_set_threads(ct.c_int(int(n)))

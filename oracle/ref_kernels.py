@@ -92,6 +92,12 @@ class RefKernels:
     def sem_color_average(self, color_map, pcl_chan, map_lay, pcl_channels, smap, size):
         self._call("sem_color_average", [color_map, pcl_chan, map_lay, pcl_channels, smap], size)
 
+    def polygon_mask(self, polygon, center_x, center_y, polygon_bbox, mask):
+        """polygon (M, 2) float32; centre scalars; bbox (4,) = [min_x, min_y, max_x, max_y]; mask (C, C) float32 out"""
+        cx, cy = np.array([center_x], _F), np.array([center_y], _F)
+        n = np.array([polygon.shape[0]], np.int16)
+        self._call("polygon_mask", [np.ascontiguousarray(polygon, _F), cx, cy, n, np.ascontiguousarray(polygon_bbox, _F), mask], mask.size)
+
     # point fusions whose kernels live in the plugin modules (parameter sets with ``bayes_kernels``)
     def alpha(self, p, pcl_chan, map_lay, pcl_channels, newmap, size):
         self._call("alpha", [p, pcl_chan, map_lay, pcl_channels, newmap], size)

@@ -130,3 +130,26 @@ def test_image_correspondence_and_fusions(dist, weights):
     eo.image_fuse(om.P, "exponential", mine[0], img[1], uv, va, H, W, 0.7)
     eo.image_fuse(om.P, "color", mine[1], rgb, uv, va, H, W)
     assert np.array_equal(mine[0], new_r[0]) and np.array_equal(mine[1].view(np.uint32), new_r[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("center", [(0.0, 0.0), (0.52, -0.28)])
+def test_polygon_mask_restatement_vs_reference_kernel(center):
+    """polygon_mask_kernel (custom_kernels.py:509-651): convex, concave, sub-cell and map-filling polygons, bit exact; vertices
+    and edges lie on the mask (the kernel's early `return` from its edge loop)."""
+    params = build_ref.PREBUILD["polygon130"]
+    if not ref_kernels.available(params):
+        pytest.skip("compiled reference not built")
+    rk = ref_kernels.RefKernels(params, build=False)
+    C = 130
+    P = eo.make_params(eo.DEFAULTS, cell_n=C)
+    polys = [np.array([[-0.8, -0.5], [0.9, -0.7], [1.1, 0.6], [-0.2, 1.2]], np.float32),
+             np.array([[-1.5, -1.5], [1.5, -1.5], [1.5, 1.5], [0.0, 0.2], [-1.5, 1.5]], np.float32),
+             np.array([[0.3, 0.3], [0.31, 0.3], [0.3, 0.31]], np.float32),
+             np.array([[-2.5, -2.5], [2.5, -2.5], [2.5, 2.5], [-2.5, 2.5]], np.float32)]
+    for poly in polys:
+        poly = (poly + np.array(center, np.float32)).astype(np.float32)
+        want = np.full((C, C), -1, np.float32)
+        bbox = np.concatenate([poly.min(axis=0), poly.max(axis=0)]).astype(np.float32)
+        rk.polygon_mask(poly, center[0], center[1], bbox, want)
+        got = eo.polygon_mask(P, poly, center[0], center[1])
+        assert np.array_equal(got, want)
