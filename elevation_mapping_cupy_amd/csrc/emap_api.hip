@@ -32,7 +32,9 @@ struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; }
 void launch_image_corr(hipStream_t, const KP&, const CamArgs&, const Cell*, float*, unsigned char*);
 void launch_image_fuse(hipStream_t, const KP&, int, float*, const float*, const float*, const unsigned char*, float, float, double);
 void launch_inpaint_sweep(hipStream_t, int, const float*, const float*, float*, float*, const unsigned int*, unsigned int*);
-void launch_min_sweep(hipStream_t, int, int, const float*, const float*, const float*, float*, float*, const unsigned int*, unsigned int*);
+void launch_min_sweep(hipStream_t, int, int, const float*, const float*, const float*, float*, float*, const unsigned int*, unsigned int*, bool);
+void launch_box3(hipStream_t, int, const float*, float*);
+void launch_erode(hipStream_t, int, int, const float*, float*);
 void launch_overlap(hipStream_t, const KP&, Cell*, int, int, float, float);
 void launch_dilate(hipStream_t, const KP&, const Cell*, float*, int, int, int);
 void launch_trav_normal(hipStream_t, const KP&, const float*, const float*, const float*, const float*, const float*, Cell*, float*, long);
@@ -893,8 +895,8 @@ int emap_semantic_clear(emap_ctx* ctx) {
 }
 
 // ---- MinFilter plugin (EM/plugins/min_filter.py:84-118) on caller-provided planes ------------------------------------
-int emap_min_filter(emap_ctx* ctx, const float* host_elevation, const float* host_valid, int32_t dilation_size, int32_t iteration_n,
-                    float* host_out, int32_t* sweeps_run) {
+static int minmax_filter(emap_ctx* ctx, const float* host_elevation, const float* host_valid, int32_t dilation_size, int32_t iteration_n,
+                         float* host_out, int32_t* sweeps_run, bool is_max) {
   CKARG(ctx && host_elevation && host_valid && host_out, "null argument");
   CKARG(dilation_size >= 0 && dilation_size <= 32 && iteration_n >= 0 && iteration_n <= 4096, "bad filter size / iteration count");
   CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "emap_min_filter: single-strip contexts only");
@@ -912,7 +914,7 @@ int emap_min_filter(emap_ctx* ctx, const float* host_elevation, const float* hos
   ck(hipMemsetAsync(cnt, 0, sizeof(unsigned int) * (iteration_n + 1), ctx->stream));
   for (int k = 0; k < iteration_n && rc == EMAP_OK; ++k) {
     launch_min_sweep(ctx->stream, C, dilation_size, orig, (k & 1) ? v1 : v0, (k & 1) ? m1 : m0, (k & 1) ? v0 : v1, (k & 1) ? m0 : m1,
-                     k > 0 ? cnt + (k - 1) : nullptr, cnt + k);
+                     k > 0 ? cnt + (k - 1) : nullptr, cnt + k, is_max);
     ck(hipGetLastError());
   }
   const float* fv = (iteration_n & 1) ? v1 : v0; const float* fm = (iteration_n & 1) ? m1 : m0;
@@ -926,6 +928,49 @@ int emap_min_filter(emap_ctx* ctx, const float* host_elevation, const float* hos
   if (rc != EMAP_OK) return rc;
   for (size_t i = 0; i < L; ++i) if (!(mask[i] > 0.5f)) host_out[i] = NAN;     // cp.where(mask > 0.5, filtered, nan), :116
   if (sweeps_run) { int n = 0; for (int k = 0; k < iteration_n; ++k) { ++n; if (hc[k] == 0) break; } *sweeps_run = n; }
+  return EMAP_OK;
+}
+
+int emap_min_filter(emap_ctx* ctx, const float* host_elevation, const float* host_valid, int32_t dilation_size, int32_t iteration_n,
+                    float* host_out, int32_t* sweeps_run) {
+  return minmax_filter(ctx, host_elevation, host_valid, dilation_size, iteration_n, host_out, sweeps_run, false);
+}
+int emap_max_filter(emap_ctx* ctx, const float* host_elevation, const float* host_valid, int32_t dilation_size, int32_t iteration_n,
+                    float* host_out, int32_t* sweeps_run) {
+  return minmax_filter(ctx, host_elevation, host_valid, dilation_size, iteration_n, host_out, sweeps_run, true);
+}
+
+// ---- SmoothFilter plugin (EM/plugins/smooth_filter.py:56-58): `passes` x uniform_filter(size=3) on a host plane ---------------
+int emap_smooth_filter(emap_ctx* ctx, const float* host_in, int32_t passes, float* host_out) {
+  CKARG(ctx && host_in && host_out && passes >= 1 && passes <= 64, "bad argument");
+  CK(hipSetDevice(ctx->device));
+  const int C = ctx->prm.cell_n; const size_t L = (size_t)C * C, bytes = L * sizeof(float);
+  float* buf = nullptr;
+  CK(hipMalloc((void**)&buf, bytes * 2));
+  float *a = buf, *b = buf + L;
+  hipError_t e = hipMemcpyAsync(a, host_in, bytes, hipMemcpyHostToDevice, ctx->stream);
+  for (int k = 0; k < passes && e == hipSuccess; ++k) { launch_box3(ctx->stream, C, a, b); e = hipGetLastError(); float* t = a; a = b; b = t; }
+  if (e == hipSuccess) e = hipMemcpyAsync(host_out, a, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(buf);
+  if (e != hipSuccess) { ctx->err = std::string("emap_smooth_filter: ") + hipGetErrorString(e); return EMAP_ERR_HIP; }
+  return EMAP_OK;
+}
+
+// ---- Erosion plugin (EM/plugins/erosion.py:96-104): cv2.erode with a k x k rectangle, `iterations` times, on a host plane ------
+int emap_erode(emap_ctx* ctx, const float* host_in, int32_t kernel_size, int32_t iterations, float* host_out) {
+  CKARG(ctx && host_in && host_out && kernel_size >= 1 && kernel_size <= 63 && iterations >= 0 && iterations <= 256, "bad argument");
+  CK(hipSetDevice(ctx->device));
+  const int C = ctx->prm.cell_n; const size_t L = (size_t)C * C, bytes = L * sizeof(float);
+  float* buf = nullptr;
+  CK(hipMalloc((void**)&buf, bytes * 2));
+  float *a = buf, *b = buf + L;
+  hipError_t e = hipMemcpyAsync(a, host_in, bytes, hipMemcpyHostToDevice, ctx->stream);
+  for (int k = 0; k < iterations && e == hipSuccess; ++k) { launch_erode(ctx->stream, C, kernel_size, a, b); e = hipGetLastError(); float* t = a; a = b; b = t; }
+  if (e == hipSuccess) e = hipMemcpyAsync(host_out, a, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(buf);
+  if (e != hipSuccess) { ctx->err = std::string("emap_erode: ") + hipGetErrorString(e); return EMAP_ERR_HIP; }
   return EMAP_OK;
 }
 

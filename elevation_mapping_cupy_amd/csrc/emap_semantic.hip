@@ -140,6 +140,9 @@ void launch_sem_shift(hipStream_t s, int C, int nl, const float* src, float* dst
 // ---------------------------------------------------------------------------------------------------------
 #define MF_R 16
 #define MF_C 64
+// MAX = true is the MaxFilter plugin (EM/plugins/max_filter.py:36-112): maximum instead of minimum, the cell's CURRENT mask decides
+// whether it is (re)filled, and the reference itself runs that one out of place (it passes copies as inputs).
+template <bool MAX>
 __global__ __launch_bounds__(EM_BLOCK) void k_min_sweep(int C, int d, const float* __restrict__ orig_mask,
                                                          const float* __restrict__ val, const float* __restrict__ msk,
                                                          float* __restrict__ oval, float* __restrict__ omsk,
@@ -169,14 +172,14 @@ __global__ __launch_bounds__(EM_BLOCK) void k_min_sweep(int C, int d, const floa
       if (row >= C) break;
       const long i = (long)row * C + col;
       float v = val[i], m = msk[i];
-      if (!frozen && orig_mask[i] < 0.5f) {
-        float mn = 1000000.0f;
+      if (!frozen && (MAX ? m : orig_mask[i]) < 0.5f) {
+        float mn = MAX ? -1000000.0f : 1000000.0f;
         for (int dy = -d; dy <= d; ++dy)
           for (int dx = -d; dx <= d; ++dx) {
             const int o = (tr + d + dy) * pitch + (tc + d + dx);
-            if (smsk[o] > 0.5f && sval[o] < mn) mn = sval[o];
+            if (smsk[o] > 0.5f && (MAX ? sval[o] > mn : sval[o] < mn)) mn = sval[o];
           }
-        if (mn < 1000000.0f - 1.0f) { v = mn; m = 0.6f; }
+        if (MAX ? (mn > -1000000.0f + 1.0f) : (mn < 1000000.0f - 1.0f)) { v = mn; m = 0.6f; }
       }
       oval[i] = v; omsk[i] = m;
       open_cells += !(m > 0.5f);
@@ -187,10 +190,31 @@ __global__ __launch_bounds__(EM_BLOCK) void k_min_sweep(int C, int d, const floa
 }
 
 void launch_min_sweep(hipStream_t s, int C, int d, const float* orig_mask, const float* val, const float* msk, float* oval, float* omsk,
-                      const unsigned int* prev_unfilled, unsigned int* unfilled) {
+                      const unsigned int* prev_unfilled, unsigned int* unfilled, bool is_max) {
   dim3 g((C + MF_C - 1) / MF_C, (C + MF_R - 1) / MF_R), b(EM_BLOCK);
   size_t lds = (size_t)2 * (MF_R + 2 * d) * (MF_C + 2 * d + 1) * sizeof(float);
-  hipLaunchKernelGGL(k_min_sweep, g, b, lds, s, C, d, orig_mask, val, msk, oval, omsk, prev_unfilled, unfilled);
+  if (is_max) hipLaunchKernelGGL(k_min_sweep<true>, g, b, lds, s, C, d, orig_mask, val, msk, oval, omsk, prev_unfilled, unfilled);
+  else hipLaunchKernelGGL(k_min_sweep<false>, g, b, lds, s, C, d, orig_mask, val, msk, oval, omsk, prev_unfilled, unfilled);
+}
+
+// SmoothFilter plugin (EM/plugins/smooth_filter.py:56-58): scipy-style uniform_filter(size=3), i.e. a separable 3-tap mean along
+// axis 0 then axis 1 with 'reflect' borders (index -1 -> 0, n -> n-1) and a float32 intermediate; one launch per 2-D pass.
+__global__ __launch_bounds__(EM_BLOCK) void k_box3(int C, const float* __restrict__ in, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= (long)C * C) return;
+  const int r = (int)(i / C), c = (int)(i % C);
+  const int r0 = r > 0 ? r - 1 : 0, r2 = r < C - 1 ? r + 1 : C - 1, c0 = c > 0 ? c - 1 : 0, c2 = c < C - 1 ? c + 1 : C - 1;
+  const int rows[3] = {r0, r, r2}, cols[3] = {c0, c, c2};
+  double acc = 0.0;
+  for (int b = 0; b < 3; ++b) {
+    double col = 0.0;
+    for (int a = 0; a < 3; ++a) col += (double)in[(long)rows[a] * C + cols[b]];
+    acc += (double)(float)(col / 3.0);             // float32 intermediate of the axis-0 pass
+  }
+  out[i] = (float)(acc / 3.0);
+}
+void launch_box3(hipStream_t s, int C, const float* in, float* out) {
+  hipLaunchKernelGGL(k_box3, dim3(nblk_((long)C * C)), dim3(EM_BLOCK), 0, s, C, in, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -392,4 +416,30 @@ __global__ __launch_bounds__(EM_BLOCK) void k_dilate_planes(int C, int d, const 
 }
 void launch_dilate_planes(hipStream_t s, int C, int d, const float* plane, const float* mask, float* out, float* outmask) {
   hipLaunchKernelGGL(k_dilate_planes, dim3(nblk_((long)C * C)), dim3(EM_BLOCK), 0, s, C, d, plane, mask, out, outmask);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Erosion plugin (reference EM/plugins/erosion.py:96-104): the reference quantises the layer to 8 bits on the host and calls
+// cv2.erode(img, ones((k, k)), iterations=n) -- OpenCV, an unpinned third-party dependency that is absent here.  Its published
+// definition for a flat rectangular structuring element is the window minimum with the anchor at (k/2, k/2) and pixels outside
+// the image ignored (morphologyDefaultBorderValue); one launch per iteration.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EM_BLOCK) void k_erode(int C, int k, const float* __restrict__ in, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= (long)C * C) return;
+  const int r = (int)(i / C), c = (int)(i % C), a = k / 2;
+  float mn = INFINITY;
+  for (int dr = -a; dr < k - a; ++dr) {
+    const int rr = r + dr;
+    if (rr < 0 || rr >= C) continue;
+    for (int dc = -a; dc < k - a; ++dc) {
+      const int cc = c + dc;
+      if (cc < 0 || cc >= C) continue;
+      mn = fminf(mn, in[(long)rr * C + cc]);
+    }
+  }
+  out[i] = mn;
+}
+void launch_erode(hipStream_t s, int C, int k, const float* in, float* out) {
+  hipLaunchKernelGGL(k_erode, dim3(nblk_((long)C * C)), dim3(EM_BLOCK), 0, s, C, k, in, out);
 }

@@ -1,0 +1,34 @@
+"""``MaxFilter`` plugin: fill invalid cells with the maximum value around them (reference EM/plugins/max_filter.py:12-112).
+The sweeps run on the MI355X (``emap_max_filter``: the min-filter sweep kernel with the comparison reversed)."""
+from __future__ import annotations
+
+import ctypes as ct
+from typing import List
+
+import numpy as np
+
+from .._lib import f32p
+from .plugin_manager import PluginBase
+
+
+class MaxFilter(PluginBase):
+    def __init__(self, cell_n: int = 100, dilation_size: int = 5, iteration_n: int = 5, emap=None, **kwargs):
+        super().__init__()
+        self.iteration_n = int(iteration_n)
+        self.dilation_size = int(dilation_size)
+        self.width = self.height = cell_n
+        self.emap = emap
+        self.sweeps_run = 0
+
+    def __call__(self, elevation_map: np.ndarray, layer_names: List[str], plugin_layers: np.ndarray,
+                 plugin_layer_names: List[str], *args) -> np.ndarray:
+        if self.emap is None:
+            raise RuntimeError("MaxFilter needs the owning ElevationMap (PluginManager(emap=...)): it runs on the device")
+        h = np.ascontiguousarray(elevation_map[0], np.float32)
+        v = np.ascontiguousarray(elevation_map[2], np.float32)
+        out = np.empty_like(h)
+        n = ct.c_int32(0)
+        e = self.emap
+        e._chk(e._lib.emap_max_filter(e._ctx, f32p(h), f32p(v), self.dilation_size, self.iteration_n, f32p(out), ct.byref(n)))
+        self.sweeps_run = n.value
+        return out

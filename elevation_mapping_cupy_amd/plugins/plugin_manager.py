@@ -6,6 +6,7 @@ extra_params[, type]``, discovery = first ``PluginBase`` subclass of module ``pl
 from __future__ import annotations
 
 import importlib
+import sys
 import inspect
 from abc import ABC
 from dataclasses import dataclass
@@ -58,10 +59,16 @@ class PluginManager(object):
         self.plugin_names: List[str] = []
 
     def init(self, plugin_params: List[PluginParams], extra_params: List[Dict]):
-        self.plugin_params = plugin_params
         self.plugins = []
+        kept = []
         for param, extra_param in zip(plugin_params, extra_params):
-            m = importlib.import_module("." + param.name, package=self.package)
+            try:
+                m = importlib.import_module("." + param.name, package=self.package)
+            except ImportError as ex:     # a configured plugin without an implementation here must not take the others down
+                print("[WARNING] plugin {} is not available on this backend ({}); layer {} skipped".format(param.name, ex, param.layer_name),
+                      file=sys.stderr)
+                continue
+            kept.append(param)
             for name, obj in inspect.getmembers(m):
                 if inspect.isclass(obj) and issubclass(obj, PluginBase) and name != "PluginBase":
                     extra_param = dict(extra_param or {})
@@ -69,6 +76,7 @@ class PluginManager(object):
                     if "emap" in signature(obj.__init__).parameters:
                         extra_param["emap"] = self.emap
                     self.plugins.append(obj(**extra_param))
+        self.plugin_params = kept
         self.layers = np.zeros((len(self.plugins), self.cell_n, self.cell_n), dtype=np.float32)
         self.layer_names = [p.layer_name for p in self.plugin_params]
         self.plugin_names = [p.name for p in self.plugin_params]

@@ -164,6 +164,18 @@ int emap_semantic_set_alpha(emap_ctx* ctx, int32_t layer, const float* host_in);
 int emap_min_filter(emap_ctx* ctx, const float* host_elevation, const float* host_valid, int32_t dilation_size,
                     int32_t iteration_n, float* host_out, int32_t* sweeps_run_or_null);
 
+/* MaxFilter plugin (EM/plugins/max_filter.py:36-112): same sweep structure with the window maximum; a cell is filled while its
+ * running mask is < 0.5 and the reference itself runs this one out of place. */
+int emap_max_filter(emap_ctx* ctx, const float* host_elevation, const float* host_valid, int32_t dilation_size,
+                    int32_t iteration_n, float* host_out, int32_t* sweeps_run_or_null);
+/* SmoothFilter plugin (EM/plugins/smooth_filter.py:56-58): `passes` applications of a 3x3 uniform filter with the semantics of
+ * scipy.ndimage.uniform_filter(size=3) ('reflect' borders, separable, float32 intermediate); the plugin uses passes = 2. */
+int emap_smooth_filter(emap_ctx* ctx, const float* host_in, int32_t passes, float* host_out);
+
+/* Erosion plugin (EM/plugins/erosion.py:96-104): what its cv2.erode(img, ones((k, k)), iterations=n) call computes -- the k x k
+ * window minimum (anchor k/2, pixels outside the image ignored), n times.  OpenCV is third-party and absent: parity unpinned. */
+int emap_erode(emap_ctx* ctx, const float* host_in, int32_t kernel_size, int32_t iterations, float* host_out);
+
 /* Inpainting plugin (EM/plugins/inpainting.py:53-61) -- DOCUMENTED SUBSTITUTE for the OpenCV Telea call it makes: fills
  * the pixels with known == 0 of a (cell_n, cell_n) image holding 8-bit values, front by front, with the distance-weighted
  * mean of the known 8-neighbours. Values stay in [0, 255], integers. */

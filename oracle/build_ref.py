@@ -130,10 +130,12 @@ def _instantiate(p):
         ks["dilation_filter_%d" % extra] = (ck.dilation_filter_kernel(C, C, extra), f32)
     for d in p.get("min_filter_sizes", ()):
         ks["min_filter_%d" % d] = (_min_filter_kernel(C, d), f32)
+    for d in p.get("max_filter_sizes", ()):
+        ks["max_filter_%d" % d] = (_min_filter_kernel(C, d, "max_filter", "MaxFilter", "max_filter_kernel"), f32)
     return ks
 
 
-def _min_filter_kernel(C, d):
+def _min_filter_kernel(C, d, module="min_filter", cls="MinFilter", attr="min_filter_kernel"):
     """MinFilter builds its kernel inside the plugin class (reference plugins/min_filter.py:22-82): instantiate the
     class under fake ``cupy`` / package modules and take the captured kernel."""
     fake = types.ModuleType("cupy")
@@ -151,10 +153,10 @@ def _min_filter_kernel(C, d):
     saved = {k: sys.modules.get(k) for k in ("cupy", "_refplug", "_refplug.plugin_manager")}
     sys.modules.update({"cupy": fake, "_refplug": pkg, "_refplug.plugin_manager": pm})
     try:
-        spec = importlib.util.spec_from_file_location("_refplug.min_filter", os.path.join(REF_ROOT, "plugins", "min_filter.py"))
+        spec = importlib.util.spec_from_file_location("_refplug." + module, os.path.join(REF_ROOT, "plugins", module + ".py"))
         m = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(m)
-        return m.MinFilter(cell_n=C, dilation_size=d, iteration_n=1).min_filter_kernel
+        return getattr(getattr(m, cls)(cell_n=C, dilation_size=d, iteration_n=1), attr)
     finally:
         for k, v in saved.items():
             if v is None:
@@ -254,6 +256,7 @@ PREBUILD = {
     "image98": with_(PARAM_YAML, cell_n=98, image_kernels=True),
     "bayes66": with_(PARAM_YAML, cell_n=66, bayes_kernels=True),
     "polygon130": with_(PARAM_DEFAULT, cell_n=130, polygon_kernel=True),
+    "maxfilter34": with_(PARAM_DEFAULT, cell_n=34, max_filter_sizes=(1, 2)),
 }
 
 

@@ -620,7 +620,16 @@ void eo_image_fuse(const eo_params* P, int kind, float* sem, const float* image,
 }
 
 /* MinFilter plugin (reference plugins/min_filter.py:29-118), Jacobi sweeps (every cell reads the previous sweep). */
+static int eo_minmax_filter(int C, int d, int iteration_n, const float* elevation, const float* valid, float* out, int is_max);
 int eo_min_filter(int C, int d, int iteration_n, const float* elevation, const float* valid, float* out) {
+  return eo_minmax_filter(C, d, iteration_n, elevation, valid, out, 0);
+}
+/* MaxFilter plugin (reference plugins/max_filter.py:36-112): maximum, the RUNNING mask decides which cells are filled, inputs are
+ * copies (out of place) in the reference too. */
+int eo_max_filter(int C, int d, int iteration_n, const float* elevation, const float* valid, float* out) {
+  return eo_minmax_filter(C, d, iteration_n, elevation, valid, out, 1);
+}
+static int eo_minmax_filter(int C, int d, int iteration_n, const float* elevation, const float* valid, float* out, int is_max) {
   const long L = (long)C * C;
   float* v0 = malloc(L * 4); float* m0 = malloc(L * 4); float* v1 = malloc(L * 4); float* m1 = malloc(L * 4);
   memcpy(v0, elevation, L * 4); memcpy(m0, valid, L * 4);
@@ -629,16 +638,16 @@ int eo_min_filter(int C, int d, int iteration_n, const float* elevation, const f
     long open_cells = 0;
     for (long i = 0; i < L; ++i) {
       float v = v0[i], m = m0[i];
-      if (valid[i] < 0.5f) {
-        float mn = 1000000.0f;
+      if ((is_max ? m : valid[i]) < 0.5f) {
+        float mn = is_max ? -1000000.0f : 1000000.0f;
         for (int dy = -d; dy <= d; ++dy) for (int dx = -d; dx <= d; ++dx) {
           long j = i + (long)C * dy + dx;
           if (j < 0 || j >= L) continue;
           long jx = j / C, jy = j % C;
           if (jx <= 0 || jx >= C - 1 || jy <= 0 || jy >= C - 1) continue;
-          if (m0[j] > 0.5f && v0[j] < mn) mn = v0[j];
+          if (m0[j] > 0.5f && (is_max ? v0[j] > mn : v0[j] < mn)) mn = v0[j];
         }
-        if (mn < 1000000.0f - 1.0f) { v = mn; m = 0.6f; }
+        if (is_max ? (mn > -1000000.0f + 1.0f) : (mn < 1000000.0f - 1.0f)) { v = mn; m = 0.6f; }
       }
       v1[i] = v; m1[i] = m; open_cells += !(m > 0.5f);
     }

@@ -322,6 +322,23 @@ def dilate_plane(C, d, plane, mask):
     return out, om
 
 
+def max_filter(C, d, iteration_n, elevation, valid):
+    out = np.zeros((C, C), np.float32)
+    n = lib().eo_max_filter(ct.c_int(C), ct.c_int(d), ct.c_int(iteration_n), _p(np.ascontiguousarray(elevation, np.float32)),
+                            _p(np.ascontiguousarray(valid, np.float32)), _p(out))
+    return out, int(n)
+
+
+def smooth_filter(plane, passes=2):
+    """SmoothFilter plugin (reference plugins/smooth_filter.py:56-58): the reference calls cupyx.scipy.ndimage.uniform_filter, whose
+    published algorithm is scipy.ndimage.uniform_filter (third-party, version unpinned): scipy here is the oracle."""
+    from scipy import ndimage
+    h = np.ascontiguousarray(plane, np.float32)
+    for _ in range(passes):
+        h = ndimage.uniform_filter(h, size=3)
+    return h
+
+
 def min_filter(C, d, iteration_n, elevation, valid):
     out = np.zeros((C, C), np.float32)
     n = lib().eo_min_filter(ct.c_int(C), ct.c_int(d), ct.c_int(iteration_n), _p(np.ascontiguousarray(elevation, np.float32)),

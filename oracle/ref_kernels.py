@@ -77,6 +77,10 @@ class RefKernels:
         self._call("min_filter_%d" % size, [elevation, valid, newmap, newmask], self.C * self.C)
 
     # --- semantic kernels (reference custom_semantic_kernels.py) ---------------------------------
+    def max_filter_sweep(self, elevation, valid, newmap, newmask, size):
+        """one sweep of the MaxFilter kernel (reference plugins/max_filter.py:36-93); inputs are copies there (out of place)"""
+        self._call("max_filter_%d" % size, [elevation, valid, newmap, newmask], self.C * self.C)
+
     def sem_sum(self, p, R, t, pcl_chan, map_lay, pcl_channels, smap, newmap, size):
         self._call("sem_sum", [p, R, t, pcl_chan, map_lay, pcl_channels, smap, newmap], size)
 

@@ -31,6 +31,40 @@ def test_min_filter_matches_oracle(d, iters):
     assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
 
 
+@pytest.mark.parametrize("d,iters", [(1, 30), (2, 3), (3, 1)])
+def test_max_filter_matches_oracle(d, iters):
+    from elevation_mapping_cupy_amd.plugins.max_filter import MaxFilter
+    C = 130
+    hip, _ = make_pair(eo.DEFAULTS, C)
+    e = _holey_map(C, d, 0.3)
+    mf = MaxFilter(cell_n=C, dilation_size=d, iteration_n=iters, emap=hip)
+    got = mf(e, hip.layer_names, None, [])
+    want, sweeps = eo.max_filter(C, d, iters, e[0], e[2])
+    assert mf.sweeps_run == sweeps
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+
+
+def test_smooth_filter_matches_scipy_uniform_filter():
+    """SmoothFilter = uniform_filter(size=3) twice ('reflect' borders); scipy.ndimage is the published algorithm behind the
+    reference's cupyx call.  Tolerance 1e-6 relative (float32 output of a double-accumulated 3-tap mean)."""
+    from elevation_mapping_cupy_amd.plugins.smooth_filter import SmoothFilter
+    C = 130
+    hip, _ = make_pair(eo.DEFAULTS, C)
+    e = _holey_map(C, 1, 0.3)
+    e[0] += np.random.default_rng(5).normal(0, 1, (C, C)).astype(np.float32)
+    sf = SmoothFilter(cell_n=C, input_layer_name="elevation", emap=hip)
+    got = sf(e, hip.layer_names, None, [])
+    want = eo.smooth_filter(e[0])
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-6)
+    # by plugin-layer name, and the fallback to the elevation layer
+    sf2 = SmoothFilter(cell_n=C, input_layer_name="min_filter", emap=hip)
+    plug = np.stack([e[1]])
+    assert np.allclose(sf2(e, hip.layer_names, plug, ["min_filter"]), eo.smooth_filter(e[1]), rtol=1e-6, atol=1e-4)
+    sf3 = SmoothFilter(cell_n=C, input_layer_name="nope", emap=hip)
+    assert np.allclose(sf3(e, hip.layer_names, plug, ["min_filter"]), want, rtol=1e-6, atol=1e-6)
+
+
 def test_plugin_manager_yaml_and_readback(tmp_path):
     C = 66
     cfg = tmp_path / "plugins.yaml"
@@ -68,6 +102,60 @@ disabled_one:
     elev = np.zeros((C - 2, C - 2), np.float32)
     hip.get_map_with_name_ref("elevation", elev)
     assert np.isnan(elev).sum() == int((e[2][1:-1, 1:-1] <= 0.5).sum())
+
+
+@pytest.mark.parametrize("k,iters,reverse", [(3, 1, True), (3, 4, False), (5, 2, True), (4, 1, False)])
+def test_erosion_matches_window_minimum(k, iters, reverse):
+    """Erosion = 8-bit quantisation + cv2.erode(ones((k,k)), iterations) + de-quantisation; scipy.ndimage.minimum_filter with a
+    constant border above the value range is the same published operation (OpenCV itself is absent: parity unpinned)."""
+    from scipy import ndimage
+    from elevation_mapping_cupy_amd.plugins.erosion import Erosion
+    C = 98
+    hip, _ = make_pair(eo.DEFAULTS, C)
+    e = _holey_map(C, 1, 0.3)
+    e[3] = np.random.default_rng(k).uniform(0, 1, (C, C)).astype(np.float32)
+    er = Erosion(input_layer_name="traversability", kernel_size=k, iterations=iters, reverse=reverse, emap=hip)
+    got = er(e, hip.layer_names, None, [], np.zeros((0, C, C), np.float32), [])
+    layer = (1 - e[3]) if reverse else e[3]
+    lo, hi = float(layer.min()), float(layer.max())
+    q = ((layer - lo) * 255 / (hi - lo)).astype("uint8")
+    for _ in range(iters):
+        q = ndimage.minimum_filter(q, size=k, mode="constant", cval=255)    # window offsets -k//2 .. k-k//2-1 = cv2 anchor (k//2, k//2)
+    want = q.astype(np.float32) * (hi - lo) / 255 + lo
+    want = (1 - want) if reverse else want
+    assert np.allclose(got, want, atol=1e-6)
+
+
+def test_shipped_plugin_configuration_loads_and_publishes(tmp_path):
+    """the four plugins the reference enables by default (config/core/plugin_config.yaml: min_filter -> smooth, inpainting,
+    erosion of the traversability) plus an unknown one, which is reported and skipped instead of taking the others down"""
+    C = 66
+    cfg = tmp_path / "plugins.yaml"
+    cfg.write_text("""
+min_filter: {enable: True, fill_nan: False, is_height_layer: True, layer_name: "min_filter", extra_params: {dilation_size: 1, iteration_n: 30}}
+smooth_filter: {enable: True, fill_nan: False, is_height_layer: True, layer_name: "smooth", extra_params: {input_layer_name: "min_filter"}}
+inpainting: {enable: True, fill_nan: False, is_height_layer: True, layer_name: "inpaint", extra_params: {method: "telea"}}
+erosion: {enable: True, fill_nan: False, is_height_layer: False, layer_name: "erosion", extra_params: {input_layer_name: "traversability", dilation_size: 3, iteration_n: 20, reverse: True}}
+no_such_plugin: {enable: True, fill_nan: False, is_height_layer: False, layer_name: "ghost", extra_params: {}}
+""")
+    from elevation_mapping_cupy_amd.configs import parameter_from
+    from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
+    p = parameter_from(eo.DEFAULTS, C)
+    p.plugin_config_file = str(cfg)
+    hip = ElevationMap(p)
+    assert hip.plugin_manager.layer_names == ["min_filter", "smooth", "inpaint", "erosion"] and not hip.exists_layer("ghost")
+    R, t = fx.POSES["identity"]
+    hip.input_pointcloud(fx.cloud(C, 3000, 0), ["x", "y", "z"], R, t.copy(), 0.0, 0.0)
+    out = {}
+    for name in ("min_filter", "smooth", "inpaint", "erosion"):
+        out[name] = np.zeros((C - 2, C - 2), np.float32)
+        hip.get_map_with_name_ref(name, out[name])
+    e = hip.elevation_map
+    mf, _ = eo.min_filter(C, 1, 30, e[0], e[2])
+    assert np.allclose(out["smooth"], np.flip(eo.smooth_filter(mf)[1:-1, 1:-1]), atol=1e-5, equal_nan=True)   # smooth reads the min_filter layer
+    assert np.isfinite(out["inpaint"]).all()
+    assert out["erosion"].min() >= -1e-6 and out["erosion"].max() <= 1 + 1e-6
+    assert (out["erosion"] >= np.flip(e[3][1:-1, 1:-1]) - 1e-2).all()       # reverse erosion can only raise traversability (8-bit step)
 
 
 @pytest.mark.parametrize("only_above", [True, False])

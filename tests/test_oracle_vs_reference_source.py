@@ -153,3 +153,28 @@ def test_polygon_mask_restatement_vs_reference_kernel(center):
         rk.polygon_mask(poly, center[0], center[1], bbox, want)
         got = eo.polygon_mask(P, poly, center[0], center[1])
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("d", [1, 2])
+def test_max_filter_sweeps_vs_reference_kernel(d):
+    """MaxFilter (plugins/max_filter.py): the reference passes COPIES as inputs, so its sweeps are out of place and the compiled
+    kernel driven like MaxFilter.__call__ (:95-112) must equal the restatement exactly -- large holes, several sweeps, early stop."""
+    rk = _ref("maxfilter34")
+    C = 34
+    rng = np.random.default_rng(10 + d)
+    e0 = rng.uniform(-1, 1, (C, C)).astype(np.float32)
+    v = (rng.uniform(0, 1, (C, C)) > 0.55).astype(np.float32)
+    v[5:14, 6:17] = 0                                           # a hole that needs several sweeps
+    for iters in (1, 3, 30):
+        cur, mask = e0.copy(), v.copy()
+        ran = 0
+        for _ in range(iters):
+            rk.max_filter_sweep(cur.copy(), mask.copy(), cur, mask, d)
+            ran += 1
+            if (mask > 0.5).all():
+                break
+        want = np.where(mask > 0.5, cur, np.nan)
+        got, sweeps = eo.max_filter(C, d, iters, e0, v)
+        assert sweeps == ran
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
