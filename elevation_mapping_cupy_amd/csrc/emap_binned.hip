@@ -278,9 +278,13 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
   const int row_base = (ty * G.sub + (int)blockIdx.y) * BIN_TR;       // blockIdx.y = which 16 x 64 tile of the bin
   if (row_base >= P.nrows) return;
   const unsigned int sel = blockIdx.y;
+  // one colour channel next to averaged channels (the usual rgb + features cloud): its accumulation rides along the first
+  // group's record loop, so every point row is gathered once
+  const bool ride = S.n_col == 1 && S.n_sum > 0;
   for (int g0 = 0; g0 < S.n_sum; g0 += SEM_GROUP) {
     const int ng = min(SEM_GROUP, S.n_sum - g0);
     for (int k = threadIdx.x; k < SEM_GROUP * NC; k += EM_BLOCK) (&s_sum[0][0])[k] = 0.0;
+    if (ride && g0 == 0) for (int k = threadIdx.x; k < 4 * NC; k += EM_BLOCK) (&s_col[0][0])[k] = 0u;
     __syncthreads();
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {
       const BinRec r = recs[k];
@@ -296,6 +300,13 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
         }
         unsafeAtomicAdd(&s_sum[q][lc], (double)v);
       }
+      if (ride && g0 == 0) {
+        const unsigned int color = __float_as_uint(p[S.col_chan[0]]);
+        atomicAdd(&s_col[0][lc], (color & 0xFF0000u) >> 16);
+        atomicAdd(&s_col[1][lc], (color & 0xFF00u) >> 8);
+        atomicAdd(&s_col[2][lc], color & 0xFFu);
+        atomicAdd(&s_col[3][lc], 1u);
+      }
     }
     __syncthreads();
     if (col < P.C) {
@@ -304,6 +315,14 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
         if (lrow >= P.nrows) break;
         const long c = (long)(lrow + P.halo) * P.C + col;
         const unsigned int cnt = cnt_plane[c];               // accepted HEIGHT points (new_elmap plane 2, :185)
+        if (ride && g0 == 0) {
+          const int lc = tr * BIN_TC + tc;
+          const unsigned int cn = s_col[3][lc];
+          if (cn) {
+            const unsigned int rr = s_col[0][lc] / cn, gg = s_col[1][lc] / cn, bb = s_col[2][lc] / cn;
+            sem[(long)S.col_layer[0] * plane + c] = __uint_as_float((rr << 16) + (gg << 8) + bb);
+          }
+        }
         for (int q = 0; q < ng; ++q) {
           const long j = (long)S.sum_layer[g0 + q] * plane + c;
           const double s = s_sum[q][tr * BIN_TC + tc];
@@ -337,7 +356,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
       for (int q = 0; q < S.n_sum; ++q) if (S.sum_kind[q] == 2) { const long j = (long)S.sum_layer[q] * plane + c; sem[j] = alpha_planes[j] / tot; }
     }
   }
-  if (S.n_col > 0) {
+  if (S.n_col > 0 && !ride) {
     const int K = S.n_col;
     // the reference's launch-size quirk (fusion/pointcloud_color.py:143): element e = id * K + layer only exists for e < N,
     // and ONE counter plane is shared by all K layers
