@@ -39,6 +39,7 @@ void launch_overlap(hipStream_t, const KP&, Cell*, int, int, float, float);
 void launch_dilate(hipStream_t, const KP&, const Cell*, float*, int, int, int);
 void launch_trav_normal(hipStream_t, const KP&, const float*, const float*, const float*, const float*, const float*, Cell*, float*, long);
 void launch_var_time(hipStream_t, const KP&, Cell*, int, int);
+int post_tile_rows(const KP&);
 void launch_post(hipStream_t, const KP&, const float*, const float*, const float*, const float*, Cell*, float*, float*, long, int, int, int);
 void launch_get_plane(hipStream_t, const KP&, const Cell*, int, float*);
 void launch_publish(hipStream_t, const KP&, const Cell*, const float*, long, int, float, int, float*);
@@ -632,9 +633,9 @@ int emap_post_part(emap_ctx* ctx, int32_t part) {
   CKARG(ctx && part >= 0 && part <= 2, "bad argument");
   CK(hipSetDevice(ctx->device));
   const int reach = ctx->prm.dilation_size + 4;                  // rows a tile looks beyond itself (stencils + row wrap)
-  const int all_rows = (ctx->strip.row_count + 15) / 16;
-  int first_in = (reach + 15) / 16, last_in = (ctx->strip.row_count - reach) / 16 - 1;   // interior tile rows [first_in, last_in]
-  if (ctx->strip.halo_rows == 0 || last_in < first_in) { first_in = all_rows; last_in = all_rows - 1; }   // no interior split
+  const int R = post_tile_rows(ctx->kp);                         // tile height of k_post for this map
+  const int all_rows = (ctx->strip.row_count + R - 1) / R;
+  int first_in = (reach + R - 1) / R, last_in = (ctx->strip.row_count - reach) / R - 1;   // interior tile rows [first_in, last_in]
   auto run = [&](int r0, int n) {
     launch_post(ctx->stream, ctx->kp, ctx->prm.w1, ctx->prm.w2, ctx->prm.w3, ctx->prm.w_out, ctx->cells, ctx->trav_in, ctx->normal,
                 ctx->ncells_alloc, ctx->prm.dilation_size, r0, n);

@@ -4,6 +4,7 @@
 // write integer/fixed-point accumulators, per-cell passes commit) -- not a translation of the CuPy kernels.
 // Compiled with -ffp-contract=off: decisions (indices, gates) must be bit-identical to the oracle.
 #include "emap_device.h"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------------
 // Phase A: drift statistics + points-per-cell (error_counting_kernel, custom_kernels.py:280-345)
@@ -735,23 +736,35 @@ void launch_trav_normal(hipStream_t s, const KP& P, const float* w1, const float
   hipLaunchKernelGGL(k_trav_normal, g, b, 0, s, P, W, in, cells, normal, plane_stride);
 }
 // tile rows [tile_row0, tile_row0 + n_tile_rows) of the strip (16 map rows each); the whole strip when n_tile_rows < 0
+// Tile height of k_post (measured on MI355X): 32 rows when that still yields >= 512 workgroups (1024^2 map:
+// 26 us vs 32 us with 16 rows -- less halo re-staging), 16 rows for mid-size maps, 4 rows for robot-scale maps (4x the workgroups).
+int post_tile_rows(const KP& P) {
+  static const int force_r = []() { const char* e = getenv("EMAP_POST_R"); int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32) ? v : 0; }();
+  if (force_r) return force_r;
+  if ((long)P.nrows * P.C <= 512L * 512L) return 4;
+  const size_t lds32 = sizeof(float) * ((size_t)2 * (32 + 6 + 2 * P.dil) * (PT_C + 6 + 2 * P.dil + 1) + (size_t)38 * (PT_C + 7) + (size_t)32 * PT_C)
+                       + sizeof(unsigned short) * (size_t)38 * (PT_C + 6) + 16;
+  if (lds32 > 60 * 1024) return 16;             // large dilation radii: stay inside the default dynamic-LDS window
+  return (long)((P.C + PT_C - 1) / PT_C) * ((P.nrows + 31) / 32) >= 512 ? 32 : 16;
+}
 void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, const float* w3, const float* wo, Cell* cells,
                  float* trav_in, float* normal, long plane_stride, int d, int tile_row0, int n_tile_rows) {
   TravW W;
   for (int i = 0; i < 36; ++i) { W.w[0][i] = w1[i]; W.w[1][i] = w2[i]; W.w[2][i] = w3[i]; }
   for (int i = 0; i < 12; ++i) W.wo[i] = wo[i];
-  // tile_row0 / n_tile_rows are given in units of 16 map rows (emap_post_part); small maps use 4-row tiles
-  const bool small = (long)P.nrows * P.C <= 512L * 512L;
-  const int R = small ? 4 : 16, per16 = 16 / R;
+  // tile_row0 / n_tile_rows are given in units of post_tile_rows(P) map rows (emap_post_part)
+  const int R = post_tile_rows(P);
   const int all_rows = (P.nrows + R - 1) / R;
-  if (n_tile_rows < 0) { tile_row0 = 0; n_tile_rows = all_rows; } else { tile_row0 *= per16; n_tile_rows *= per16; }
+  if (n_tile_rows < 0) { tile_row0 = 0; n_tile_rows = all_rows; }
   if (tile_row0 < 0) tile_row0 = 0;
   if (tile_row0 + n_tile_rows > all_rows) n_tile_rows = all_rows - tile_row0;
   if (n_tile_rows <= 0) return;
   dim3 g((P.C + PT_C - 1) / PT_C, n_tile_rows), b(PT_THREADS);
   size_t lds = sizeof(float) * ((size_t)2 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)(R + 6) * (PT_C + 6 + 1) + (size_t)R * PT_C)
                + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;     // + hole list
-  if (small) hipLaunchKernelGGL(k_post<4>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
+  if (R == 4) hipLaunchKernelGGL(k_post<4>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
+  else if (R == 8) hipLaunchKernelGGL(k_post<8>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
+  else if (R == 32) hipLaunchKernelGGL(k_post<32>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
   else hipLaunchKernelGGL(k_post<16>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
 }
 void launch_var_time(hipStream_t s, const KP& P, Cell* cells, int do_var, int do_time) {
