@@ -143,8 +143,9 @@ __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, BinGeo G, const BinTm
 
 // AVG = true (no visibility pass this frame): the epilogue commits AND averages the tile in registers and writes the
 // 32-byte cells directly -- the AccF records never leave LDS and the separate k_average pass disappears.
+#define TF_BLOCK 1024   /* threads per tile of k_tile_fuse */
 template <bool AVG>
-__global__ __launch_bounds__(EM_BLOCK) void k_tile_fuse(KP P, BinGeo G, const BinRec* __restrict__ recs,
+__global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const BinRec* __restrict__ recs,
                                                          const unsigned int* __restrict__ tile_start, Cell* __restrict__ cells,
                                                          AccF* __restrict__ acc, const FrameDev* __restrict__ F,
                                                          unsigned int* __restrict__ cnt_plane) {
@@ -159,16 +160,16 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
     const int sb = blockIdx.y, row_base = (ty * G.sub + sb) * BIN_TR;
     if (row_base >= P.nrows) return;              // uniform, before any barrier
     const unsigned int sel = (unsigned int)sb;
-    for (int k = threadIdx.x; k < NC; k += EM_BLOCK) { s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull; }
+    for (int k = threadIdx.x; k < NC; k += TF_BLOCK) { s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull; }
     __syncthreads();
-    for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {          // pass 1: newmap[4] / newmap[3]
+    for (unsigned int k = r0 + threadIdx.x; k < r1; k += TF_BLOCK) {          // pass 1: newmap[4] / newmap[3]
       const unsigned int w = recs[k].lc_inl, lcb = w & 0x7fffffffu;
       if ((lcb >> 10) != sel) continue;
       atomicAdd(&s_pts[lcb & 1023u], 1u);
       if (w >> 31) atomicAdd(&s_inl[lcb & 1023u], 1u);
     }
     __syncthreads();
-    for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {          // pass 2: custom_kernels.py:160-197
+    for (unsigned int k = r0 + threadIdx.x; k < r1; k += TF_BLOCK) {          // pass 2: custom_kernels.py:160-197
       const BinRec r = recs[k];
       const unsigned int lcb = r.lc_inl & 0x7fffffffu;
       if ((lcb >> 10) != sel) continue;
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
     __syncthreads();
     if (col < P.C) {
 #pragma unroll
-      for (int k = 0; k < BIN_TR / 4; ++k) {
-        const int tr = wv + 4 * k, lrow = row_base + tr;
+      for (int k = 0; k < BIN_TR / (TF_BLOCK / 64); ++k) {
+        const int tr = wv + (TF_BLOCK / 64) * k, lrow = row_base + tr;
         if (lrow >= P.nrows) break;
         const int lc = tr * BIN_TC + tc;
         AccF a;
@@ -252,8 +253,8 @@ void launch_bin_scatter(hipStream_t s, const KP& P, const BinGeo& G, const BinTm
 }
 void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cell* cells,
                      AccF* acc, const FrameDev* F, bool fuse_average, unsigned int* cnt_plane) {
-  if (fuse_average) hipLaunchKernelGGL(k_tile_fuse<true>, dim3(G.T, G.sub), dim3(EM_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
-  else hipLaunchKernelGGL(k_tile_fuse<false>, dim3(G.T, G.sub), dim3(EM_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
+  if (fuse_average) hipLaunchKernelGGL(k_tile_fuse<true>, dim3(G.T, G.sub), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
+  else hipLaunchKernelGGL(k_tile_fuse<false>, dim3(G.T, G.sub), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
