@@ -253,6 +253,16 @@ class HipStripEngine:
         self._chk(self.lib.emap_update_sharded(self.ctx, R.ctypes.data_as(ct.POINTER(ct.c_float)), t.ctypes.data_as(ct.POINTER(ct.c_float)),
                                                ct.c_double(position_noise), ct.c_double(orientation_noise), None))
 
+    def semantic_prepare(self, channels):
+        """create the layers / count plane of the extra cloud channels BEFORE the frame (SemanticMap.prepare)"""
+        self.map.semantic_map.prepare(list(channels))
+
+    def semantic_update(self, channels, R, t):
+        """RGB / semantic fusion of the bound cloud's extra channels into this strip's layers: per cell, no exchange step"""
+        R = np.ascontiguousarray(np.asarray(R, np.float32).reshape(9))
+        t = np.ascontiguousarray(np.asarray(t, np.float32).reshape(3))
+        self.map.semantic_map.update_layers_pointcloud(self.map, list(channels), R, t)
+
     def update_time(self):
         self.map.update_time()
 
@@ -274,15 +284,21 @@ class ShardedElevationMap:
         self.e, self.comm = engine, comm
         self.rays_on, self.overlap_on = bool(enable_visibility_cleanup), bool(enable_overlap_clearance)
 
-    def update(self, R, t, position_noise, orientation_noise):
-        """One frame on the bound (replicated) cloud; ``t`` is map-centre relative."""
+    def update(self, R, t, position_noise, orientation_noise, channels=None):
+        """One frame on the bound (replicated) cloud; ``t`` is map-centre relative.  ``channels`` (names of ALL cloud columns,
+        x, y, z first) additionally fuses the extra columns into the strip's RGB / semantic layers (BASELINE config 5)."""
         e, c = self.e, self.comm
+        extra = list(channels[3:]) if channels is not None else None      # x, y, z are not layers (input_pointcloud forwards channels[3:])
+        if extra:
+            e.semantic_prepare(extra)
         if isinstance(c, NativeComm):
             e.update_native(R, t, position_noise, orientation_noise)
-            return
-        ctx = e.stream_ctx() if hasattr(e, "stream_ctx") else contextlib.nullcontext()
-        with ctx:
-            self._update(R, t, position_noise, orientation_noise)
+        else:
+            ctx = e.stream_ctx() if hasattr(e, "stream_ctx") else contextlib.nullcontext()
+            with ctx:
+                self._update(R, t, position_noise, orientation_noise)
+        if extra:
+            e.semantic_update(extra, R, t)
 
     def _update(self, R, t, position_noise, orientation_noise):
         e, c = self.e, self.comm
@@ -334,9 +350,12 @@ def bench_main(a, rank, world, local_rank):
         # torch-driven fallback below has to move device tensors
         dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
     cfg = dict(CORE_PARAM_YAML)
-    if a.workload == "cfg2":
+    multimodal = a.workload == "cfg5"
+    if a.workload in ("cfg2", "cfg5"):
         cfg.update(enable_visibility_cleanup=False, enable_overlap_clearance=False)
     C, N = a.cell_n, a.points
+    if multimodal and C > 2049:
+        a.mode = "fp32"
     w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
     weights = {k: w[k] for k in ("w1", "w2", "w3", "w_out")}
     par = parameter_from(cfg, C, a.mode, weights, device=local_rank)
@@ -374,15 +393,28 @@ def bench_main(a, rank, world, local_rank):
         comm = TorchComm(dev)
     sm = ShardedElevationMap(eng, comm, cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
 
-    NCLOUD = 5
-    clouds = [torch.from_numpy(fx.cloud(C, N, s, dz=(0.0 if s == 0 else -0.02 * s))).to(dev) for s in range(NCLOUD)]
+    NCLOUD = 2 if multimodal else 5
+    channels, stride = None, 3
+    if multimodal:                      # rgb (packed 24 bit) + 3 averaged semantic channels, as bench.py builds them at N = 1
+        channels, stride = ["x", "y", "z", "rgb", "sem0", "sem1", "sem2"], 7
+        par.pointcloud_channel_fusions = {"rgb": "color", "default": "average"}
+        host = []
+        for s_ in range(NCLOUD):
+            p_ = fx.cloud(C, N, s_, dz=-0.02 * s_, extra=4)
+            rng = np.random.default_rng(100 + s_)
+            p_[:, 3] = rng.integers(0, 1 << 24, N, dtype=np.uint32).view(np.float32)
+            p_[:, 4:7] = rng.uniform(0, 1, (N, 3)).astype(np.float32)
+            host.append(p_)
+        clouds = [torch.from_numpy(p_).to(dev) for p_ in host]
+    else:
+        clouds = [torch.from_numpy(fx.cloud(C, N, s, dz=(0.0 if s == 0 else -0.02 * s))).to(dev) for s in range(NCLOUD)]
     R = np.eye(3, dtype=np.float32).ravel().copy()
     t = np.array([0, 0, 1], np.float32)
 
     def frame(i):
         cl = clouds[i % NCLOUD]
-        eng.bind_points_device(cl.data_ptr(), N, 3)
-        sm.update(R, t, 1.0, 1.0)
+        eng.bind_points_device(cl.data_ptr(), N, stride)
+        sm.update(R, t, 1.0, 1.0, channels)
 
     for i in range(3):
         frame(i)

@@ -96,3 +96,55 @@ def test_strip_contexts_reproduce_single_context(world, cfg_name, C, weights):
         assert m.tobytes() == want[:, r0:r0 + rows].tobytes(), "strip at row %d differs" % r0
         assert nm.tobytes() == want_n[:, r0:r0 + rows].tobytes()
         assert add == full.get_additive_mean_error()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_strips_fuse_rgb_and_semantic_channels_like_the_single_context(world, weights):
+    """BASELINE config 5 on strips: the extra cloud channels are fused per cell into the strip's own layers (no exchange step);
+    colour layer bit-exact, averaged layers bit-exact too (same LDS reduction per tile or the same atomics per cell)."""
+    import torch
+    from elevation_mapping_cupy_amd.configs import parameter_from
+    from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
+    from elevation_mapping_cupy_amd.sharded import HipStripEngine, ShardedElevationMap
+    from oracle import emap_oracle as eo
+    C, N = 202, 30000
+    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML, enable_visibility_cleanup=False)
+    CH = ["x", "y", "z", "s0", "s1", "c0", "rgb"]
+    FUS = {"rgb": "color", "c0": "class_average", "default": "average"}
+    R, t = fx.POSES["rotated"]
+    clouds = [fx.semantic_cloud(C, N, f) for f in range(2)]
+
+    def par():
+        p = parameter_from(cfg, C, "reference_fp16", weights)
+        p.pointcloud_channel_fusions = dict(FUS)
+        return p
+    full = ElevationMap(par())
+    for p in clouds:
+        full.input_pointcloud(p, CH, R, t.copy() + full.center, 1.0, 1.0)
+        full.update_time()
+    want_e, want_s = full.elevation_map, full.semantic_map.semantic_map
+    dev = torch.device("cuda", 0)
+    shared = {"bar": threading.Barrier(world), "sums": [None] * world, "send": [None] * world}
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            eng = HipStripEngine(par(), rank, world, 0, dev)
+            sm = ShardedElevationMap(eng, ThreadComm(rank, world, shared), False, cfg["enable_overlap_clearance"])
+            for p in clouds:
+                eng.bind_points(p)
+                sm.update(R, t, 1.0, 1.0, CH)
+                eng.update_time()
+            eng.sync()
+            out[rank] = (eng.map.row_begin, eng.map.rows, eng.map.elevation_map, eng.map.semantic_map.semantic_map)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            shared["bar"].abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [x.start() for x in th]; [x.join() for x in th]
+    assert not errs, errs
+    for r0, rows, m, s in out:
+        assert m.tobytes() == want_e[:, r0:r0 + rows].tobytes()
+        assert s.shape == (4, rows, C) and s.tobytes() == want_s[:, r0:r0 + rows].tobytes()
+    assert (want_s[3].view(np.uint32) != 0).sum() > 1000
