@@ -149,16 +149,18 @@ class NativeComm:
     def selftest(self):
         self.e._chk(self.e.lib.emap_comm_selftest(self.e.ctx))
 
+    def _oob(self, t):
+        """tensor for the out-of-band (bootstrap) channel: CPU when gloo is available, else on the strip's device"""
+        return t if "gloo" in str(self.dist.get_backend()) else t.to(self.e.torch_device)
+
     def barrier(self):
         if self.world > 1:      # out-of-band (host) barrier on the bootstrap channel; callers synchronise the device themselves
-            self.dist.all_reduce(self.torch.zeros(1, dtype=self.torch.int32))
+            self.dist.all_reduce(self._oob(self.torch.zeros(1, dtype=self.torch.int32)))
 
     def max_float(self, x):
         if self.world == 1:
             return float(x)
-        t = self.torch.tensor([x], dtype=self.torch.float64)
-        if self.dist.get_backend() == "nccl":
-            t = t.to(self.e.torch_device)
+        t = self._oob(self.torch.tensor([x], dtype=self.torch.float64))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -347,8 +349,16 @@ def bench_main(a, rank, world, local_rank):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         # CPU tensors (bootstrap, timing reductions) go through gloo; the nccl backend is only instantiated if the
-        # torch-driven fallback below has to move device tensors
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        # torch-driven fallback below has to move device tensors.  Single node: keep gloo on the loopback interface (the
+        # container hostname may not resolve); if gloo cannot come up at all, everything runs over nccl.
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        try:
+            dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        except Exception as ex:  # noqa: BLE001
+            print("[rank %d] gloo bootstrap unavailable (%s); using nccl only" % (rank, ex), file=sys.stderr)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    cpu_ok = "gloo" in str(dist.get_backend())
     cfg = dict(CORE_PARAM_YAML)
     multimodal = a.workload == "cfg5"
     if a.workload in ("cfg2", "cfg5"):
@@ -363,7 +373,7 @@ def bench_main(a, rank, world, local_rank):
     comm, comm_kind = None, os.environ.get("EMAP_COMM", "native")
 
     def all_agree(ok):
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=None if cpu_ok else dev)
         if world > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # CPU tensor: gloo
         return int(flag.item()) == 1
