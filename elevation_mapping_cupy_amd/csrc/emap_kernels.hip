@@ -210,8 +210,28 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
       const int C = P.C;
       const unsigned int halo_cells = (unsigned int)P.halo * (unsigned int)C, row0_cells = (unsigned int)P.row0 * (unsigned int)C;
       int last = -1;
-      float s = nS > 0 ? sS[0] : INFINITY;
-      for (int k = 0; k < nS; ++k) {
+      // Row strips: the rows of a strip are a band in x, and x(s) is monotone along a ray, so the samples that can land in owned
+      // rows form one contiguous range of the step table.  March only that range (band widened by 2 cells: more than the
+      // float16 rounding of the sample position can move a cell, and it lets the same-cell test warm up before the first
+      // owned row exactly as in the full march); the per-sample ownership test stays.
+      int k_begin = 0, k_end = nS;
+      if (P.nrows < C) {
+        const float xlo = (float)(((double)(P.row0 - 2) - P.half_w) * P.res), xhi = (float)(((double)(P.row0 + P.nrows + 2) - P.half_w) * P.res);
+        float s_lo = -INFINITY, s_hi = INFINITY;
+        if (fabsf(rx) > 1e-6f) {
+          const float a = (xlo - T.t[0]) / rx, b = (xhi - T.t[0]) / rx;
+          s_lo = fminf(a, b); s_hi = fmaxf(a, b);
+        } else if (T.t[0] < xlo || T.t[0] > xhi) s_hi = -INFINITY;
+        s_lo -= 2.0f * P.q_step; s_hi += 2.0f * P.q_step;
+        int lo = 0, hi = nS;                                    // first k with S[k] >= s_lo
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sS[mid] < s_lo) lo = mid + 1; else hi = mid; }
+        k_begin = lo;
+        hi = nS;                                                // first k with S[k] > s_hi
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sS[mid] <= s_hi) lo = mid + 1; else hi = mid; }
+        k_end = lo;
+      }
+      float s = k_begin < k_end ? sS[k_begin] : INFINITY;
+      for (int k = k_begin; k < k_end; ++k) {
         const float s_next = sS[k + 1 < nS ? k + 1 : k];      // prefetch: no dependent LDS wait at the loop head
         if (!(s < ray_length)) break;
         float nx = T.t[0] + rx * s, ny = T.t[1] + ry * s, nz = T.t[2] + rz * s;

@@ -51,7 +51,7 @@ class ThreadComm:
         return []
 
 
-@pytest.mark.parametrize("world,cfg_name,C", [(2, "yaml", 130), (3, "default", 202), (2, "yaml_norays", 202)])
+@pytest.mark.parametrize("world,cfg_name,C", [(2, "yaml", 130), (3, "default", 202), (2, "yaml_norays", 202), (4, "yaml", 130), (8, "default", 202)])
 def test_strip_contexts_reproduce_single_context(world, cfg_name, C, weights):
     import torch
     from elevation_mapping_cupy_amd.configs import parameter_from
