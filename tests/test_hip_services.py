@@ -104,3 +104,19 @@ def test_initialize_map(weights):
     e2, v2 = eo.dilate_plane(C, 3, e1, v1); v2 = np.where(v1 > 0.5, v1, v2)
     assert np.array_equal(m[2], v2) and np.allclose(m[0], e2, atol=1e-6)
     assert np.allclose(m[1][v0 > 0.5], 10.0) and np.allclose(m[1][v0 < 0.5], hip.initial_variance)
+
+
+def test_move_relative_shift_sign_convention(weights):
+    """move(delta) rolls by +delta_pixel (reference :139-152) whereas move_to rolls by -delta_pixel (:154-170)"""
+    C = 66
+    hip, _ = make_pair(eo.DEFAULTS, C, "reference_fp16", weights)
+    R, t = fx.POSES["identity"]
+    hip.update_map_with_kernel(fx.cloud(C, 6000, 0), [], R, t.copy(), 0.0, 0.0)
+    before = hip.elevation_map
+    hip.move(np.array([2 * 0.04, -1 * 0.04, 0.1], np.float32))
+    after = hip.elevation_map
+    want = np.roll(before, (2, -1), axis=(1, 2)); want[:, :2, :] = 0; want[:, :, -1:] = 0
+    want[1, :2, :] = hip.initial_variance; want[1, :, -1:] = hip.initial_variance
+    want[0] -= np.float32(0.1); want[5] -= np.float32(0.1)
+    assert np.allclose(after, want, atol=1e-6)
+    assert np.allclose(hip.center, [0.08, -0.04, 0.1], atol=1e-6)
