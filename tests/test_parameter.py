@@ -29,3 +29,27 @@ def test_parameter_tables_agree_with_oracle_tables():
     for k, v in CORE_PARAM_YAML.items():
         assert float(eo.YAML[k]) == float(v), k
     assert parameter_from(CORE_PARAM_YAML, 1024).cell_n == 1024
+
+
+def test_reference_package_name_alias_imports():
+    """compat/elevation_mapping_cupy re-exports the classes under the names the ROS wrapper imports (no GPU needed to import)"""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "compat"))
+    try:
+        em = importlib.import_module("elevation_mapping_cupy.elevation_mapping")
+        pm = importlib.import_module("elevation_mapping_cupy.parameter")
+        pl = importlib.import_module("elevation_mapping_cupy.plugins.plugin_manager")
+        fu = importlib.import_module("elevation_mapping_cupy.fusion.fusion_manager")
+        from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
+        from elevation_mapping_cupy_amd.parameter import Parameter
+        assert em.ElevationMap is ElevationMap and pm.Parameter is Parameter
+        assert hasattr(pl, "PluginBase") and hasattr(fu, "FusionBase")
+        p = pm.Parameter()
+        assert "resolution" in p.get_names() and len(p.get_names()) == len(p.get_types())
+    finally:
+        sys.path.pop(0)
+        for k in [k for k in sys.modules if k == "elevation_mapping_cupy" or k.startswith("elevation_mapping_cupy.")]:
+            del sys.modules[k]
