@@ -460,11 +460,17 @@ def bench_main(a, rank, world, local_rank):
         Nw, Lw = N / world, C * C / world
         strip_bytes = {"hist": 28 * N, "scan": 0, "scatter": 16 * N + 32 * Nw, "gate": 0, "fuse": 24 * Nw + 64 * Lw, "commit": 104 * Lw,
                        "rays": 12 * N + 48 * Lw, "average": 120 * Lw, "overlap": 0, "post": 52 * Lw}
+        empty = []                       # spacing of an event pair with nothing in between (bench.py does the same calibration)
+        for _ in range(50):
+            e_ms = ct.c_float(0)
+            eng.lib.emap_timer_begin(eng.ctx); eng.lib.emap_timer_end(eng.ctx, ct.byref(e_ms)); empty.append(e_ms.value)
+        ev_overhead = float(np.median(empty))
         kernels = {k: v for k, v in stage_ms.items() if strip_bytes[k] > 0}
         dom = max(kernels, key=kernels.get)
-        achieved = strip_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        dom_ms = max(stage_ms[dom] - ev_overhead, 1e-6)
+        achieved = strip_bytes[dom] / (dom_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-                "traffic": None, "algorithmic_bytes": int(strip_bytes[dom]), "kernel_ms": round(stage_ms[dom], 5), "rank": 0,
+                "traffic": None, "algorithmic_bytes": int(strip_bytes[dom]), "kernel_ms": round(dom_ms, 5), "event_pair_overhead_ms": round(ev_overhead, 5), "rank": 0,
                 "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
                 "note": "rank 0's strip; 'gate' includes the all-reduce, 'post' the halo exchange overlapped with the interior stencils"}
     if rank == 0:
