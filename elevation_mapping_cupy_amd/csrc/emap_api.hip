@@ -140,6 +140,7 @@ static void build_kp(emap_ctx* ctx) {
   k.q_mrl = h ? q16((float)p.max_ray_length) : (float)p.max_ray_length;
   k.q_step = h ? q16((float)p.ray_step) : (float)p.ray_step;
   k.time_var = (float)p.time_variance; k.time_int = (float)p.time_interval; k.res_f = (float)p.resolution;
+  k.inv_res_f = (float)(1.0 / p.resolution); k.half_w_f = 0.5f * (float)p.cell_n;
 }
 
 // smallest float >= c (a < c  <=>  a < up(c) for float a) / largest float <= c (a > c <=> a > dn(c))
@@ -147,6 +148,13 @@ static float f_up(double c) { float f = (float)c; if ((double)f < c) f = nextaft
 static float f_dn(double c) { float f = (float)c; if ((double)f > c) f = nextafterf(f, -INFINITY); return f; }
 
 static int host_axis_idx(const emap_params& p, float xq, float q_wm1, bool half_mode) {
+  if (!half_mode) {   // fp32 mode: float multiply + float add, truncation, integer clamp (emap_device.h: axis_idx<1>)
+    volatile float m = xq * (float)(1.0 / p.resolution);
+    volatile float vf = m + 0.5f * (float)p.cell_n;
+    const float f = vf;
+    int i = !(f == f) ? 0 : (f >= 2147483648.0f ? 2147483647 : (f <= -2147483648.0f ? (int)0x80000000 : (int)f));
+    return i < 0 ? 0 : (i > p.cell_n - 1 ? p.cell_n - 1 : i);
+  }
   double v = (double)xq / p.resolution + 0.5 * p.cell_n;
   int i = !(v == v) ? 0 : (v >= 2147483647.0 ? 2147483647 : (v <= -2147483648.0 ? (int)0x80000000 : (int)v));
   float fi = half_mode ? q16((float)i) : (float)i;

@@ -57,7 +57,7 @@ struct KP {
   int C, mode, row0, nrows, halo, edge, dil, pad0;
   double res, half_w, snf, mt, ov, dcvi_half, trav_inlier, wall, mrl, cs, cos_thresh, mvd2, mhr, ra, rb, rc;
   double max_var, ray_step;
-  float init_var, ov_f, q_wm1, q_mrl, q_step, time_var, time_int, res_f;
+  float init_var, ov_f, q_wm1, q_mrl, q_step, time_var, time_int, res_f, inv_res_f, half_w_f;
 };
 
 // host-built tables of the visibility pass (emap_api.hip: build_ray_tables)
@@ -85,10 +85,19 @@ __device__ __forceinline__ int sat_int(double v) {   // CUDA-style saturating co
 // get_x_idx/get_y_idx + clamp (custom_kernels.py:22-33,45-49) for an already-rounded coordinate; map centre is 0
 // (the reference always passes center 0: elevation_mapping.py:337-338,359-360).
 template <int MODE> __device__ __forceinline__ int axis_idx(const KP& P, float xq) {
-  int i = sat_int((double)xq / P.res + P.half_w);
-  float fi = Qf<MODE>((float)i);
-  float r = fmaxf(fminf(fi, P.q_wm1), 0.0f);
-  return (int)r;
+  if constexpr (MODE == 0) {           // reference_fp16: the reference's own arithmetic (bit-exact indices)
+    int i = sat_int((double)xq / P.res + P.half_w);
+    float fi = Qf<MODE>((float)i);
+    float r = fmaxf(fminf(fi, P.q_wm1), 0.0f);
+    return (int)r;
+  } else {
+    // fp32 mode is defined by this project (the reference's float16 parameters break beyond 2049 cells): one float multiply,
+    // one float add (no contraction), truncation, integer clamp -- no fp64 in the ray samples of the large maps; the oracle
+    // evaluates the same two roundings.
+    const float v = __fadd_rn(__fmul_rn(xq, P.inv_res_f), P.half_w_f);
+    const int i = __float2int_rz(v);   // saturating, NaN -> 0
+    return min(max(i, 0), P.C - 1);
+  }
 }
 
 struct Geo { float x, y, z, v; int ix, iy; bool finite, valid, inside; };

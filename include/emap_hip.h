@@ -29,7 +29,8 @@ typedef enum {
 } emap_status;
 
 /* index/rounding mode: 0 reproduces the reference's CuPy float16 helper-parameter rounding
- * bit for bit (valid for cell_n <= 2049); 1 = the same source with float16 := float (any cell_n). */
+ * bit for bit (valid for cell_n <= 2049); 1 = the same source with float16 := float (any cell_n), the cell index evaluated
+ * in float: trunc(x * float(1/resolution) + cell_n/2), two roundings, clamped to [0, cell_n-1]. */
 enum { EMAP_MODE_REFERENCE_FP16 = 0, EMAP_MODE_FP32 = 1 };
 
 /* Mirrors the scalar fields of the reference's Parameter dataclass (EM/parameter.py:137-216) that the hot

@@ -80,6 +80,13 @@ static inline float transform_p(const eo_params* P, float x, float y, float z, f
 static inline int axis_idx(const eo_params* P, float x, float c) {
   const int W = P->cell_n;
   float d = Q(x) - Q(c);
+  if (P->mode != 0) {   /* fp32 mode, defined by this project for maps beyond the float16 range: float multiply, float add
+                           (two roundings), truncation, integer clamp */
+    volatile float m = d * (float)(1.0 / P->resolution);
+    volatile float v = m + 0.5f * (float)W;
+    int i = sat_int((double)v);
+    return i < 0 ? 0 : (i > W - 1 ? W - 1 : i);
+  }
   int i = sat_int((double)d / P->resolution + 0.5 * W);
   float fi = Q((float)i), lo = Q(0.0f), hi = Q((float)(W - 1));
   float r = fmaxf(fminf(fi, hi), lo);
