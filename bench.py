@@ -284,6 +284,35 @@ def main():
                "sample": "<=5 frames (<=8 s) of %d points on the %dx%d map, oracle/emap_oracle.c eo_frame (gcc -O2 -fopenmp); best of "
                          "1/8/32/%d threads, %d usable cores (os.cpu_count() = %d)" % (n_cpu, C, C, avail, avail, os.cpu_count() or 1)}
 
+        # second CPU line: the reference's OWN kernel source compiled for the host (oracle/_ref, sequential, 1 thread) on a smaller
+        # sample of the same clouds -- error_counting + add_points + average_map + dilation + normal kernels (its traversability
+        # network is PyTorch and not part of that build)
+        try:
+            from oracle import build_ref, ref_kernels
+            key = {(1024, "cfg2"): "yaml1024_norays", (1024, "cfg3"): "yaml1024", (202, "cfg2"): "yaml202_norays", (202, "cfg3"): "yaml202"}.get((C, a.workload))
+            if key and a.mode == "reference_fp16" and ref_kernels.available(build_ref.PREBUILD[key]):
+                rk = ref_kernels.RefKernels(build_ref.PREBUILD[key], build=False)
+                n_ref = min(N, 200000 if a.workload == "cfg2" else 20000)
+                m_ref = np.zeros((7, C, C), np.float32); m_ref[1] = cfg["initial_variance"]; m_ref[3] = 1
+                nrm_ref = np.zeros((3, C, C), np.float32)
+                Rf = np.ascontiguousarray(R, np.float32).ravel().copy(); tf = np.ascontiguousarray(t, np.float32)
+
+                def ref_frame(k_):
+                    p_ = np.ascontiguousarray(clouds_host[k_ % NCLOUD][:n_ref, :3])
+                    nm_ = np.zeros((7, C, C), np.float32); e_ = np.zeros(1, np.float32); c_ = np.zeros(1, np.float32)
+                    t0_ = time.perf_counter()
+                    rk.error_counting(m_ref, p_, Rf, tf, nm_, e_, c_); rk.add_points(Rf, tf, nrm_ref, p_, m_ref, nm_); rk.average_map(nm_, m_ref)
+                    dil_ = np.zeros((C, C), np.float32); dm_ = np.zeros((C, C), np.float32)
+                    rk.dilation_filter(m_ref[5].copy(), (m_ref[2] + m_ref[6]).copy(), dil_, dm_)
+                    rk.normal_filter(dil_, m_ref[2].copy(), nrm_ref)
+                    return time.perf_counter() - t0_
+                ref_frame(0); m_ref[4] += 1.0
+                t_ref = [ref_frame(1), ref_frame(2)]
+                cpu["reference_kernels"] = {"value": round(n_ref / float(np.mean(t_ref)) / 1e6, 4), "unit": "Mpoints/s", "cores": 1,
+                                            "sample": "2 frames of %d points, the reference's kernel source compiled with g++ -O2 (oracle/build_ref.py)" % n_ref}
+        except Exception as ex:  # noqa: BLE001 - the second line is optional
+            print("reference-kernel CPU line skipped: %s" % ex, file=sys.stderr)
+
     out = {
         "metric": "Mpoints/s fused (map-update p50 latency in config)", "value": round(mpts, 2), "unit": "Mpoints/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
