@@ -89,16 +89,16 @@ class Hip:
 STAGE_BYTES = {
     "hist": lambda N, L: 12 * N + 16 * N,                    # xyz in, 16-B staging record out
     "scan": lambda N, L: 0,
-    "scatter": lambda N, L: 16 * N + 16 * N + 16 * N,        # staging record in, (h,v,valid,trav) of its cell, sorted record out
-    "gate": lambda N, L: 0,
-    "fuse": lambda N, L: 16 * N + 8 * N + 64 * L,            # sorted record, (h,v) of its cell; cells read + written once (fused average)
+    "scatter": lambda N, L: 16 * N + 16 * N,                 # staging record in, sorted record out (a pure permutation)
+    "gate": lambda N, L: 16 * N + 16 * L,                    # per-tile error sums: sorted records + (h,v,valid,trav) of every cell, once
+    "fuse": lambda N, L: 16 * N + 16 * L + 64 * L,           # sorted records, (h,v,valid,trav) staged per tile; cells read + written once (fused average)
     "commit": lambda N, L: 40 * L + 64 * L,
     "rays": lambda N, L: 12 * N + 32 * L + 16 * L,           # cloud + map + ray accumulators once (the kernel is issue bound: see visits/s)
     "average": lambda N, L: 40 * L + 16 * L + 64 * L,
     "overlap": lambda N, L: 0,
     "post": lambda N, L: 32 * L + 4 * L + 4 * L + 12 * L,    # cells in; traversability_input, traversability, 3 normal planes out
 }
-STAGE_KERNEL = {"hist": "k_bin_hist", "scan": "k_bin_scan1", "scatter": "k_bin_scatter", "gate": "k_gate", "fuse": "k_tile_fuse",
+STAGE_KERNEL = {"hist": "k_bin_hist", "scan": "k_bin_scan1", "scatter": "k_bin_scatter", "gate": "k_tile_count", "fuse": "k_tile_fuse",
                 "commit": "k_commit", "rays": "k_rays<0, false", "average": "k_average", "overlap": "k_overlap", "post": "k_post"}
 
 

@@ -55,7 +55,8 @@ struct BinTmp { int tile; unsigned int lc; float z, v; };
 struct BinRec { unsigned int lc_inl; float z, v; unsigned int i; };
 void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, BinTmp*, unsigned int*);
 void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*);
-void launch_bin_scatter(hipStream_t, const KP&, const BinGeo&, const BinTmp*, long, const unsigned int*, const unsigned int*, const Cell*, BinRec*, ErrSlot*);
+void launch_bin_scatter(hipStream_t, const KP&, const BinGeo&, const BinTmp*, long, const unsigned int*, const unsigned int*, BinRec*);
+void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, const Cell*, ErrSlot*);
 void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const float*, long, int,
                           const unsigned int*, float*, float*, long);
 void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cell*, AccF*, const FrameDev*, bool, unsigned int*);
@@ -491,12 +492,14 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
     if (tm) CK(hipEventRecord(ctx->ev[ST_SCAN], ctx->stream));
     launch_bin_scan(ctx->stream, ctx->bg, ctx->bin_hist, ctx->bin_tile_total, ctx->bin_tile_start);
     if (tm) CK(hipEventRecord(ctx->ev[ST_SCATTER], ctx->stream));
-    launch_bin_scatter(ctx->stream, ctx->kp, ctx->bg, ctx->bin_tmp, ctx->n_pts, ctx->bin_hist, ctx->bin_tile_start, ctx->cells, ctx->bin_recs,
-                       ctx->slots);
+    launch_bin_scatter(ctx->stream, ctx->kp, ctx->bg, ctx->bin_tmp, ctx->n_pts, ctx->bin_hist, ctx->bin_tile_start, ctx->bin_recs);
+    if (tm) CK(hipEventRecord(ctx->ev[ST_GATE], ctx->stream));        // the "gate" stage = per-tile error sums + k_gate
+    launch_tile_count(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->slots);
   } else {
     if (ctx->stage_timing && ctx->in_update)
       for (int e = ST_HIST; e <= ST_SCATTER; ++e) CK(hipEventRecord(ctx->ev[e], ctx->stream));
     launch_count(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->slots);
+    if (ctx->stage_timing && ctx->in_update) CK(hipEventRecord(ctx->ev[ST_GATE], ctx->stream));
   }
   CK(hipGetLastError());
   return EMAP_OK;
@@ -684,8 +687,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   ctx->in_update = true;
   rc = emap_count(ctx, R, t);                 // records ST_HIST / ST_SCAN / ST_SCATTER itself
   ctx->in_update = false;
-  if (rc) return rc;
-  STAGE(ST_GATE);
+  if (rc) return rc;            // (emap_count also recorded ST_GATE: the stage starts with the per-tile error sums)
   if ((rc = emap_set_drift_inputs(ctx, position_noise, orientation_noise, nullptr, nullptr))) return rc;
   STAGE(ST_FUSE);
   // no visibility pass + binned scatter: fusion, commit and averaging happen in ONE tile kernel
@@ -1264,8 +1266,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   ctx->in_update = true;
   rc = emap_count(ctx, R, t);                 // records ST_HIST / ST_SCAN / ST_SCATTER itself
   ctx->in_update = false;
-  if (rc) return rc;
-  STAGE(ST_GATE);                             // "gate" = local sums + all-reduce + gate
+  if (rc) return rc;                          // "gate" (recorded by emap_count) = per-tile error sums + local sums + all-reduce + gate
   ctx->use_override = false;
   if ((rc = gate_impl(ctx, 0.0, 0.0, 1, ctx->comm_sums, nullptr))) return rc;                       // local sums -> device
   CKN(a->AllReduce(ctx->comm_sums, ctx->comm_sums + 2, 2, ncclFloat64, ncclSum, ctx->comm, ctx->stream));   // exchange step 1

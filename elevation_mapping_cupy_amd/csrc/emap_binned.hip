@@ -8,8 +8,9 @@
 //   k_bin_hist     per chunk of points: geometry once (fp16-quirk transform, validity, cell), per-block LDS histogram
 //                  over tiles, 16-byte staging record per point (tile, cell-in-tile, z, noise)
 //   k_bin_scan1/2  exclusive scan of the (tile, block) histogram -> every block's write cursor, tile start offsets
-//   k_bin_scatter  per chunk: drift-inlier test against the map (error_counting_kernel, custom_kernels.py:317-335),
-//                  wave-reduced error sums, LDS cursor -> 16-byte record at its sorted position
+//   k_bin_scatter  per chunk: LDS cursor -> 16-byte record at its sorted position (a pure permutation, no map access)
+//   k_tile_count   per tile: cells staged in LDS, drift-inlier test of every record (error_counting_kernel,
+//                  custom_kernels.py:317-335), wave-reduced error sums
 //   k_tile_fuse    per tile: pass 1 counts points/inliers per cell in LDS (newmap[4], newmap[3]); pass 2 is the Kalman
 //                  update of custom_kernels.py:160-197 accumulated with LDS atomics (64-bit fixed point, ordered max);
 //                  the epilogue writes the 40-byte AccF records with plain coalesced stores.
@@ -104,38 +105,66 @@ __global__ __launch_bounds__(EM_BLOCK) void k_bin_scan2(BinGeo G, const unsigned
 template <int BLK>
 __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, BinGeo G, const BinTmp* __restrict__ tmp, long n,
                                                            const unsigned int* __restrict__ hist, const unsigned int* __restrict__ tile_start,
-                                                           const Cell* __restrict__ cells, BinRec* __restrict__ recs,
-                                                           ErrSlot* __restrict__ slots) {
+                                                           BinRec* __restrict__ recs) {
   extern __shared__ unsigned int cur[];
   for (int t = threadIdx.x; t < G.T; t += BLK) cur[t] = tile_start[t] + hist[(long)t * G.B + blockIdx.x];
   __syncthreads();
   const long base = (long)blockIdx.x * G.chunk;
-  const long iters = (G.chunk + BLK - 1) / BLK;
-  for (long it = 0; it < iters; ++it) {          // uniform trip count: the wave reductions below need all lanes
-    const long i = base + it * BLK + threadIdx.x;
+  for (long k = threadIdx.x; k < G.chunk; k += BLK) {      // a pure permutation: staging record in, sorted record out, no map access
+    const long i = base + k;
+    if (i >= n) break;
+    const BinTmp r = tmp[i];
+    if (r.tile < 0) continue;
+    const unsigned int pos = atomicAdd(&cur[r.tile], 1u);
+    BinRec o; o.lc_inl = r.lc; o.z = r.z; o.v = r.v; o.i = (unsigned int)i;
+    recs[pos] = o;
+  }
+}
+
+// drift-inlier test of error_counting_kernel (custom_kernels.py:317-335) on the (h, v, valid, trav) of a cell
+__device__ __forceinline__ bool drift_inlier(const KP& P, const float4 m, float z) {
+  return m.z > 0.5f && (double)fabsf(m.x - z) < (double)m.y * P.mt && (double)m.y < P.dcvi_half && (double)m.w > P.trav_inlier;
+}
+
+#define TF_BLOCK 1024   /* threads per tile of the tile kernels */
+// Error sums of the drift compensation, per tile: the tile's cells are staged ONCE, coalesced, in LDS and every sorted record of
+// the tile is tested against its cell there -- the per-point gather of a random 32-byte cell (a whole 128-byte line per point,
+// 144 MB fetched for 48 MB needed, profiles/r01f_pmc_cfg2.json) is gone.  Wave-reduced sums go to the 256 padded slots.
+__global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const BinRec* __restrict__ recs,
+                                                          const unsigned int* __restrict__ tile_start, const Cell* __restrict__ cells,
+                                                          ErrSlot* __restrict__ slots) {
+  constexpr int NC = BIN_TR * BIN_TC;
+  __shared__ float4 s_cell[NC];
+  const int t = blockIdx.x, ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
+  const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
+  const int row_base = (ty * G.sub + (int)blockIdx.y) * BIN_TR;
+  if (row_base >= P.nrows || r0 == r1) return;
+  {
+    const int tr = threadIdx.x >> 6, tc = threadIdx.x & 63, lrow = row_base + tr, col = tx * BIN_TC + tc;   // 1024 threads = 16 x 64 cells
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lrow < P.nrows && col < P.C) m = *reinterpret_cast<const float4*>(&cells[(long)(lrow + P.halo) * P.C + col]);
+    s_cell[threadIdx.x] = m;
+  }
+  __syncthreads();
+  const unsigned int sel = blockIdx.y;
+  for (unsigned int kb = r0; kb < r1; kb += TF_BLOCK) {     // uniform trip count: the wave reductions need all lanes
+    const unsigned int k = kb + threadIdx.x;
     long long e_fix = 0; unsigned int inl = 0;
-    if (it * BLK + threadIdx.x < G.chunk && i < n) {
-      BinTmp r = tmp[i];
-      if (r.tile >= 0) {
-        const int ty = r.tile / G.tiles_x, tx = r.tile - ty * G.tiles_x;
-        const int lrow = ty * BIN_TR * G.sub + (int)(r.lc / BIN_TC), col = tx * BIN_TC + (int)(r.lc % BIN_TC);
-        const long c = (long)(lrow + P.halo) * P.C + col;
-        float4 m = *reinterpret_cast<const float4*>(&cells[c]);   // h, v, valid, trav
-        bool inlier = m.z > 0.5f && (double)fabsf(m.x - r.z) < (double)m.y * P.mt && (double)m.y < P.dcvi_half &&
-                      (double)m.w > P.trav_inlier;
-        if (inlier) { inl = 1; e_fix = __double2ll_rn((double)(r.z - m.x) * EM_SCALE_E); }
-        const unsigned int pos = atomicAdd(&cur[r.tile], 1u);
-        BinRec o; o.lc_inl = r.lc | (inl << 31); o.z = r.z; o.v = r.v; o.i = (unsigned int)i;
-        recs[pos] = o;
+    if (k < r1) {
+      const BinRec r = recs[k];
+      const unsigned int lcb = r.lc_inl & 0x7fffffffu;
+      if ((lcb >> 10) == sel) {
+        const float4 m = s_cell[lcb & 1023u];
+        if (drift_inlier(P, m, r.z)) { inl = 1; e_fix = __double2ll_rn((double)(r.z - m.x) * EM_SCALE_E); }
       }
     }
     if (__any(inl)) {
-      long long s = wave_sum_ll(e_fix);
-      unsigned long long k = __popcll(__ballot(inl));
+      const long long s = wave_sum_ll(e_fix);
+      const unsigned long long cnt = __popcll(__ballot(inl));
       if ((threadIdx.x & 63) == 0) {
-        unsigned int slot = (unsigned int)((blockIdx.x * (BLK / 64) + (threadIdx.x >> 6) + it) & (EM_ERR_SLOTS - 1));
+        const unsigned int slot = (unsigned int)(((unsigned int)t * (TF_BLOCK / 64) + (threadIdx.x >> 6) + kb) & (EM_ERR_SLOTS - 1));
         atomicAdd(reinterpret_cast<unsigned long long*>(&slots[slot].sum), (unsigned long long)s);
-        atomicAdd(&slots[slot].cnt, k);
+        atomicAdd(&slots[slot].cnt, cnt);
       }
     }
   }
@@ -143,7 +172,6 @@ __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, BinGeo G, const BinTm
 
 // AVG = true (no visibility pass this frame): the epilogue commits AND averages the tile in registers and writes the
 // 32-byte cells directly -- the AccF records never leave LDS and the separate k_average pass disappears.
-#define TF_BLOCK 1024   /* threads per tile of k_tile_fuse */
 template <bool AVG>
 __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const BinRec* __restrict__ recs,
                                                          const unsigned int* __restrict__ tile_start, Cell* __restrict__ cells,
@@ -152,6 +180,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
   constexpr int NC = BIN_TR * BIN_TC;
   __shared__ unsigned int s_pts[NC], s_inl[NC], s_cnt[NC], s_out[NC];
   __shared__ unsigned long long s_h[NC], s_v[NC], s_latest[NC];
+  __shared__ float4 s_cell[NC];            // (h, v, valid, trav) of the tile's cells, staged once (coalesced): no per-record gather
   const int t = blockIdx.x, ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
   const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
   const float shift = F->shift;
@@ -160,13 +189,20 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
     const int sb = blockIdx.y, row_base = (ty * G.sub + sb) * BIN_TR;
     if (row_base >= P.nrows) return;              // uniform, before any barrier
     const unsigned int sel = (unsigned int)sb;
-    for (int k = threadIdx.x; k < NC; k += TF_BLOCK) { s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull; }
+    for (int k = threadIdx.x; k < NC; k += TF_BLOCK) {
+      s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull;
+      const int lrow = row_base + k / BIN_TC, colk = tx * BIN_TC + k % BIN_TC;
+      float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lrow < P.nrows && colk < P.C) m = *reinterpret_cast<const float4*>(&cells[(long)(lrow + P.halo) * P.C + colk]);
+      s_cell[k] = m;
+    }
     __syncthreads();
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += TF_BLOCK) {          // pass 1: newmap[4] / newmap[3]
-      const unsigned int w = recs[k].lc_inl, lcb = w & 0x7fffffffu;
+      const BinRec r = recs[k];
+      const unsigned int lcb = r.lc_inl & 0x7fffffffu;
       if ((lcb >> 10) != sel) continue;
       atomicAdd(&s_pts[lcb & 1023u], 1u);
-      if (w >> 31) atomicAdd(&s_inl[lcb & 1023u], 1u);
+      if (!AVG && drift_inlier(P, s_cell[lcb & 1023u], r.z)) atomicAdd(&s_inl[lcb & 1023u], 1u);   // newmap[3]: only the ray pass reads it
     }
     __syncthreads();
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += TF_BLOCK) {          // pass 2: custom_kernels.py:160-197
@@ -174,9 +210,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
       const unsigned int lcb = r.lc_inl & 0x7fffffffu;
       if ((lcb >> 10) != sel) continue;
       const unsigned int lc = lcb & 1023u;
-      const int lrow = row_base + (int)(lc / BIN_TC), colr = tx * BIN_TC + (int)(lc % BIN_TC);
-      const long c = (long)(lrow + P.halo) * P.C + colr;
-      const float2 hv = *reinterpret_cast<const float2*>(&cells[c]);
+      const float4 hv = s_cell[lc];
       const float map_h = hv.x + shift, map_v = hv.y;
       const float num_points = (float)s_pts[lc];
       if ((double)fabsf(map_h - r.z) > (double)map_v * P.mt) { atomicAdd(&s_out[lc], 1u); continue; }
@@ -242,14 +276,19 @@ void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigne
   hipLaunchKernelGGL(k_bin_scan2, dim3(1), dim3(EM_BLOCK), 0, s, G, tile_total, tile_start);
 }
 void launch_bin_scatter(hipStream_t s, const KP& P, const BinGeo& G, const BinTmp* tmp, long n, const unsigned int* hist,
-                        const unsigned int* tile_start, const Cell* cells, BinRec* recs, ErrSlot* slots) {
+                        const unsigned int* tile_start, BinRec* recs) {
   static const int blk = env_block("EMAP_SCATTER_BLOCK", 512);
   const size_t sh = sizeof(unsigned int) * G.T;
   switch (blk) {
-    case 1024: hipLaunchKernelGGL(k_bin_scatter<1024>, dim3(G.B), dim3(1024), sh, s, P, G, tmp, n, hist, tile_start, cells, recs, slots); break;
-    case 512: hipLaunchKernelGGL(k_bin_scatter<512>, dim3(G.B), dim3(512), sh, s, P, G, tmp, n, hist, tile_start, cells, recs, slots); break;
-    default: hipLaunchKernelGGL(k_bin_scatter<256>, dim3(G.B), dim3(256), sh, s, P, G, tmp, n, hist, tile_start, cells, recs, slots);
+    case 1024: hipLaunchKernelGGL(k_bin_scatter<1024>, dim3(G.B), dim3(1024), sh, s, P, G, tmp, n, hist, tile_start, recs); break;
+    case 512: hipLaunchKernelGGL(k_bin_scatter<512>, dim3(G.B), dim3(512), sh, s, P, G, tmp, n, hist, tile_start, recs); break;
+    default: hipLaunchKernelGGL(k_bin_scatter<256>, dim3(G.B), dim3(256), sh, s, P, G, tmp, n, hist, tile_start, recs);
   }
+}
+void launch_tile_count(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, const Cell* cells,
+                       ErrSlot* slots) {
+  static_assert(TF_BLOCK == BIN_TR * BIN_TC, "one thread per cell of a tile");
+  hipLaunchKernelGGL(k_tile_count, dim3(G.T, G.sub), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, slots);
 }
 void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cell* cells,
                      AccF* acc, const FrameDev* F, bool fuse_average, unsigned int* cnt_plane) {
