@@ -482,7 +482,7 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
   CKARG(ctx && R && t, "null argument"); NEED_POINTS();
   CK(hipSetDevice(ctx->device));
   // small clouds: two launches with global atomics win; large clouds: counting sort by tile + LDS reduction
-  const bool binned = ctx->n_pts > 0 && (ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts >= 196608));   // measured crossover on MI355X: ~200 k points
+  const bool binned = ctx->n_pts > 0 && (ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts >= 131072));   // measured crossover on MI355X: 60-135 k points for 202^2 .. 1024^2 maps
   ctx->frame_binned = binned;
   if (binned) {
     int rc = ensure_bins(ctx); if (rc) return rc;

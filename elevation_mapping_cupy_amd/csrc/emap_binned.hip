@@ -16,7 +16,7 @@
 //                  the epilogue writes the 40-byte AccF records with plain coalesced stores.
 // Everything downstream (commit, rays, average, ...) is unchanged and the AccF contents are BIT-IDENTICAL to the
 // atomic path of emap_kernels.hip (integer / fixed-point accumulators are order independent), which stays as the
-// path for clouds below ~200 k points (two launches with atomics have the lower latency there).  The LDS histogram holds at
+// path for clouds below ~130 k points (two launches with atomics have the lower latency there).  The LDS histogram holds at
 // most 16384 bins: maps with more tiles (> 4096^2 cells per context) sort into bins of 2, 4, ... vertically stacked tiles and
 // the tile kernels reduce one tile of the bin per workgroup (blockIdx.y), re-reading the bin's records from L2.
 #include "emap_device.h"

@@ -110,7 +110,7 @@ int emap_set_drift_inputs(emap_ctx* ctx, double position_noise, double orientati
 int emap_drift_sums_to_device(emap_ctx* ctx, double* dev_out2);
 int emap_set_drift_inputs_device(emap_ctx* ctx, double position_noise, double orientation_noise, const double* dev_totals2);
 int emap_local_drift_sums(emap_ctx* ctx, double* err_sum, uint32_t* err_cnt);
-/* how the count/fuse passes scatter into the map: 0 = auto (tile-binned LDS reduction for clouds >= 196608 points, else global
+/* how the count/fuse passes scatter into the map: 0 = auto (tile-binned LDS reduction for clouds >= 131072 points, else global
  * atomics), 1 = global atomics, 2 = tile-binned. Results are bit-identical. Bins are 16x64-cell tiles; maps with more than
  * 16384 tiles stack 2, 4, ... tiles per bin. Test hook: bits 8..15 of `mode` force a minimum stacking factor (power of two). */
 int emap_set_scatter_mode(emap_ctx* ctx, int32_t mode);
