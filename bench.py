@@ -91,7 +91,7 @@ STAGE_BYTES = {
     "scan": lambda N, L: 0,
     "scatter": lambda N, L: 16 * N + 16 * N,                 # staging record in, sorted record out (a pure permutation)
     "gate": lambda N, L: 16 * N + 16 * L,                    # per-tile error sums: sorted records + (h,v,valid,trav) of every cell, once
-    "fuse": lambda N, L: 16 * N + 16 * L + 64 * L,           # sorted records, (h,v,valid,trav) staged per tile; cells read + written once (fused average)
+    "fuse": lambda N, L: 16 * N + 64 * L,                    # sorted records; cells read (staged per tile) + written once (fused average)
     "commit": lambda N, L: 40 * L + 64 * L,
     "rays": lambda N, L: 12 * N + 32 * L + 16 * L,           # cloud + map + ray accumulators once (the kernel is issue bound: see visits/s)
     "average": lambda N, L: 40 * L + 16 * L + 64 * L,
