@@ -29,9 +29,34 @@ import time
 import numpy as np
 
 
-def strip_rows(cell_n: int, world: int, rank: int):
-    """Rows [begin, end) owned by ``rank``."""
-    return (rank * cell_n) // world, ((rank + 1) * cell_n) // world
+def strip_rows(cell_n: int, world: int, rank: int, weights=None):
+    """Rows [begin, end) owned by ``rank``.  ``weights`` (one non-negative number per row, see ``ray_balanced_weights``) splits
+    the rows into contiguous strips of equal cumulative weight instead of equal height."""
+    if weights is None:
+        return (rank * cell_n) // world, ((rank + 1) * cell_n) // world
+    w = np.asarray(weights, np.float64)
+    assert w.shape == (cell_n,) and (w >= 0).all() and w.sum() > 0
+    cum = np.concatenate([[0.0], np.cumsum(w)]) / w.sum()
+    cuts = [int(np.searchsorted(cum, g / world, side="left")) for g in range(world + 1)]
+    cuts[0], cuts[-1] = 0, cell_n
+    for g in range(1, world + 1):                     # strictly increasing, so that no strip is empty
+        cuts[g] = max(cuts[g], cuts[g - 1] + 1)
+    for g in range(world - 1, -1, -1):
+        cuts[g] = min(cuts[g], cuts[g + 1] - 1)
+    return cuts[rank], cuts[rank + 1]
+
+
+def ray_balanced_weights(cell_n: int, resolution: float, max_ray_length: float, min_rows: int, world: int, cell_weight: float = 0.08):
+    """Row weights for frames WITH the visibility pass and a sensor near the map centre (robot-centric maps): every ray starts at the
+    sensor, so only the rows within ``max_ray_length`` of the centre carry ray work and -- a wave runs as long as its longest ray --
+    that work is proportional to the height of a strip inside this band (tools/exp_strip_rays.py: 0.79 ms for each of the two centre
+    strips of an 8-way uniform split of the 1024^2 / 1 M workload, 0.02 ms for the outer ones).  ``cell_weight`` is the per-row cost of
+    the per-cell stages relative to a row inside the band.  Strips never get thinner than ``min_rows`` (the halo)."""
+    rows = np.arange(cell_n) + 0.5 - cell_n / 2.0
+    w = np.where(np.abs(rows) * resolution <= max_ray_length, 1.0, 0.0) + cell_weight
+    if (w.sum() / world) / w.max() < max(1, min_rows):     # the thinnest strip would be thinner than its halo: keep equal heights
+        return None
+    return w
 
 
 def halo_rows_needed(dilation_size: int, world: int) -> int:
@@ -169,13 +194,13 @@ class NativeComm:
 class HipStripEngine:
     """One strip on one MI355X: thin adapter from the sharding protocol to the C ABI."""
 
-    def __init__(self, param, rank, world, device_index, torch_device):
+    def __init__(self, param, rank, world, device_index, torch_device, row_weights=None):
         import torch
         from .elevation_mapping import ElevationMap
         self.torch = torch
         self.torch_device = torch_device
         C = int(param.cell_n)
-        r0, r1 = strip_rows(C, world, rank)
+        r0, r1 = strip_rows(C, world, rank, row_weights)
         self.halo = halo_rows_needed(param.dilation_size, world)
         if world > 1 and (r1 - r0) < self.halo:
             raise ValueError("strip of %d rows is thinner than the %d-row halo" % (r1 - r0, self.halo))
@@ -369,7 +394,11 @@ def bench_main(a, rank, world, local_rank):
     w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
     weights = {k: w[k] for k in ("w1", "w2", "w3", "w_out")}
     par = parameter_from(cfg, C, a.mode, weights, device=local_rank)
-    eng = HipStripEngine(par, rank, world, local_rank, dev)
+    # frames with the visibility pass: strips of equal ray work (thin around the sensor) instead of equal height
+    row_w = None
+    if cfg["enable_visibility_cleanup"] and world > 1 and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
+        row_w = ray_balanced_weights(C, float(cfg["resolution"]), float(cfg["max_ray_length"]), halo_rows_needed(cfg["dilation_size"], world), world)
+    eng = HipStripEngine(par, rank, world, local_rank, dev, row_w)
     comm, comm_kind = None, os.environ.get("EMAP_COMM", "native")
 
     def all_agree(ok):
@@ -482,6 +511,7 @@ def bench_main(a, rank, world, local_rank):
             "config": {"workload": "%s: %dx%d map in %d row strips, %d uniform-random points/frame replicated to every rank, "
                                    "core_param.yaml values" % (a.workload, C, C, world, N),
                        "index_mode": a.mode, "halo_rows": eng.halo, "parallelism": "row-strips x%d" % world,
+                       "strip_heights": "equal ray work (thin around the sensor)" if row_w is not None else "equal",
                        "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame (RCCL, %s)" %
                                       ("issued by the C library, halo exchange in place on a second stream" if comm_kind == "native"
                                        else "driven through torch.distributed")},

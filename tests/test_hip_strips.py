@@ -51,16 +51,23 @@ class ThreadComm:
         return []
 
 
-@pytest.mark.parametrize("world,cfg_name,C", [(2, "yaml", 130), (3, "default", 202), (2, "yaml_norays", 202), (4, "yaml", 130), (8, "default", 202)])
+@pytest.mark.parametrize("world,cfg_name,C", [(2, "yaml", 130), (3, "default", 202), (2, "yaml_norays", 202), (4, "yaml", 130), (8, "default", 202),
+                                               (4, "default_balanced", 202)])
 def test_strip_contexts_reproduce_single_context(world, cfg_name, C, weights):
     import torch
     from elevation_mapping_cupy_amd.configs import parameter_from
     from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
     from elevation_mapping_cupy_amd.sharded import HipStripEngine, ShardedElevationMap
     from oracle import emap_oracle as eo
+    from elevation_mapping_cupy_amd.sharded import ray_balanced_weights, strip_rows
     cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML if cfg_name.startswith("yaml") else {})
     if cfg_name.endswith("norays"):
         cfg["enable_visibility_cleanup"] = False
+    row_w = None
+    if cfg_name.endswith("balanced"):      # strips of unequal height (equal ray work for a centred sensor, Parameter default ray length 2 m)
+        row_w = ray_balanced_weights(C, cfg["resolution"], cfg["max_ray_length"], 6, world)
+        heights = [strip_rows(C, world, r, row_w)[1] - strip_rows(C, world, r, row_w)[0] for r in range(world)]
+        assert max(heights) > 2 * min(heights) and sum(heights) == C
     N = 40000
     R, t = fx.POSES["rotated"]
     clouds = [fx.cloud(C, N, f, dz=dz) for f, dz in enumerate((0.0, -0.02, -0.1))]
@@ -76,7 +83,7 @@ def test_strip_contexts_reproduce_single_context(world, cfg_name, C, weights):
 
     def run(rank):
         try:
-            eng = HipStripEngine(parameter_from(cfg, C, "reference_fp16", weights), rank, world, 0, dev)
+            eng = HipStripEngine(parameter_from(cfg, C, "reference_fp16", weights), rank, world, 0, dev, row_w)
             sm = ShardedElevationMap(eng, ThreadComm(rank, world, shared), cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
             for p in clouds:
                 eng.bind_points(p)
