@@ -378,6 +378,7 @@ def bench_main(a, rank, world, local_rank):
         # container hostname may not resolve); if gloo cannot come up at all, everything runs over nccl.
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")       # RCCL's bootstrap sockets too (data moves over xGMI / shared memory)
         try:
             dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
         except Exception as ex:  # noqa: BLE001
