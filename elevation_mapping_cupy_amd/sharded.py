@@ -368,6 +368,7 @@ def bench_main(a, rank, world, local_rank):
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
+    local_rank = local_rank % max(1, torch.cuda.device_count())      # more ranks than GPUs only happens in single-GPU test launches
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if not dist.is_initialized():
