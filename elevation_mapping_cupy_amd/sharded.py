@@ -143,7 +143,7 @@ class NativeComm:
     dlopen, all-reduce on the strip's stream, in-place halo send/recv on a second stream.  torch.distributed (any backend)
     is only the bootstrap channel for the 128-byte ncclUniqueId and the out-of-band barrier / timing reductions."""
 
-    def __init__(self, engine, rank=None, world=None, bootstrap=True):
+    def __init__(self, engine, rank=None, world=None, bootstrap=True, uid=None, rccl_path=None):
         from ._lib import EmapError
         self.e = engine
         if bootstrap:
@@ -154,12 +154,15 @@ class NativeComm:
         else:
             self.torch = self.dist = None
             self.rank, self.world = int(rank or 0), int(world or 1)
-        path = rccl_library_path().encode()
-        uid = (ct.c_uint8 * 128)()
+        path = (rccl_path or rccl_library_path()).encode()
         ok = 1
-        if self.rank == 0:
-            ok = 1 if engine.lib.emap_comm_unique_id(path, uid) == 0 else 0
-        if self.world > 1:
+        if uid is not None:              # the caller distributed the id itself (bootstrap=False with several ranks)
+            uid = (ct.c_uint8 * 128).from_buffer_copy(bytes(uid))
+        else:
+            uid = (ct.c_uint8 * 128)()
+            if self.rank == 0:
+                ok = 1 if engine.lib.emap_comm_unique_id(path, uid) == 0 else 0
+        if self.world > 1 and bootstrap:
             # agree on success before the collective init (a rank that cannot load RCCL must not leave the others waiting)
             payload = [bytes(uid) if ok else None]
             self.dist.broadcast_object_list(payload, src=0)

@@ -62,3 +62,75 @@ def test_update_sharded_without_communicator_fails_loudly(weights):
     bad = (ct.c_uint8 * 128)()
     assert m._lib.emap_comm_init(m._ctx, b"/nonexistent/librccl.so", bad, 0, 1) != 0
     assert b"dlopen" in m._lib.emap_last_error(m._ctx)
+
+
+def _fake_rccl():
+    """build tests/fake_rccl/fake_rccl.cpp (in-process stand-in for RCCL: ranks are threads on one GPU) into a temp dir"""
+    import os
+    import subprocess
+    import tempfile
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "fake_rccl.cpp")
+    out = os.path.join(tempfile.gettempdir(), "libfake_rccl_%d.so" % os.getuid())
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-w", src,
+                               "-o", out, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+@pytest.mark.parametrize("world,cfg_name,C,N", [(2, "yaml", 130, 40000), (3, "yaml_norays", 202, 60000), (4, "default", 202, 40000)])
+def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, C, N, weights):
+    """emap_comm_init + emap_update_sharded with SEVERAL ranks: the library's own orchestration (all-reduce between count and fuse,
+    in-place halo send / recv on the second stream, interior / boundary stencil split) driven through a stand-in for the nine RCCL
+    entry points whose ranks are threads of this process (RCCL refuses two ranks on one GPU).  Every strip must equal the rows of
+    the single-context map bit for bit."""
+    import ctypes as ct
+    import threading
+    import torch
+    from elevation_mapping_cupy_amd.configs import parameter_from
+    from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
+    from elevation_mapping_cupy_amd.sharded import HipStripEngine, NativeComm, ShardedElevationMap
+    from oracle import emap_oracle as eo
+    lib_path = _fake_rccl()
+    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML if cfg_name.startswith("yaml") else {})
+    if cfg_name.endswith("norays"):
+        cfg["enable_visibility_cleanup"] = False
+    R, t = fx.POSES["rotated"]
+    clouds = [fx.cloud(C, N, f, dz=dz) for f, dz in enumerate((0.0, -0.02, -0.1))]
+    full = ElevationMap(parameter_from(cfg, C, "reference_fp16", weights))
+    for p in clouds:
+        full.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0)
+        for _ in range(6):
+            full.update_time()
+    want, want_n, want_add = full.elevation_map, full.normal_map, full.get_additive_mean_error()
+    # one id for all ranks (what the bootstrap channel distributes in a real launch)
+    uid = (ct.c_uint8 * 128)()
+    assert full._lib.emap_comm_unique_id(lib_path.encode(), uid) == 0
+    dev = torch.device("cuda", 0)
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            eng = HipStripEngine(parameter_from(cfg, C, "reference_fp16", weights), rank, world, 0, dev)
+            comm = NativeComm(eng, rank=rank, world=world, bootstrap=False, uid=bytes(uid), rccl_path=lib_path)
+            comm.selftest()
+            sm = ShardedElevationMap(eng, comm, cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
+            for p in clouds:
+                eng.bind_points(p)
+                sm.update(R, t, 1.0, 1.0)
+                for _ in range(6):
+                    eng.update_time()
+            eng.sync()
+            out[rank] = (eng.map.row_begin, eng.map.rows, eng.map.elevation_map, eng.map.normal_map, eng.map.get_additive_mean_error())
+            eng.lib.emap_comm_destroy(eng.ctx)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    [x.start() for x in th]
+    [x.join(timeout=120) for x in th]
+    assert not any(x.is_alive() for x in th), "a rank is stuck in the exchange"
+    assert not errs, errs
+    for r0, rows, m, nm, add in out:
+        assert m.tobytes() == want[:, r0:r0 + rows].tobytes(), "strip at row %d differs" % r0
+        assert nm.tobytes() == want_n[:, r0:r0 + rows].tobytes()
+        assert add == want_add
