@@ -498,24 +498,49 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
   const int C = P.C, total_rows = P.nrows + 2 * P.halo;
   const int tile_r = P.halo + (tile_row0 + (int)blockIdx.y) * PT_R, tile_c = blockIdx.x * PT_C;
   const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int r = wv; r < RH; r += PT_WAVES)
-    for (int cc = tc; cc < RW; cc += 64) {
-      int lr = tile_r - 3 - d + r, cl = tile_c - 3 - d + cc;
-      if (cl < 0) { cl += C; lr -= 1; } else if (cl >= C) { cl -= C; lr += 1; }      // flat-index row wrap (:403-407)
-      const int gr = lr - P.halo + P.row0;
-      float val = 0.f, msk = -1.f;
-      if (lr >= 0 && lr < total_rows && gr >= 0 && gr <= C - 1) {
-        const float4* cp = reinterpret_cast<const float4*>(&cells[(long)lr * C + cl]);
-        float4 m0 = cp[0], m1 = cp[1];
-        val = m1.y;
-        const float m = m0.z + m1.z;
-        const bool inside = gr >= 1 && gr <= C - 2 && cl >= 1 && cl <= C - 2;
-        msk = inside ? m : -m - 1.f;
+  // staging: all 512 threads walk the (RH x RW) region linearly, FOUR cells per thread per round with the loads issued back to back
+  // (valid: 1 dword, upper + is_upper: 2 dwords of the 32-B cell) before any of them is consumed -- the region takes two such
+  // rounds instead of twelve dependent load -> LDS-store round trips with half-empty waves (a 76-wide row does not fill two 64-lane
+  // passes).  e / RW by multiply-high (exact: e < 2^16, RW <= 256).
+  {
+    constexpr int U = 4;
+    const int total = RH * RW;
+    const unsigned int magic = (unsigned int)((0x100000000ull + (unsigned long long)RW - 1ull) / (unsigned long long)RW);
+    for (int base = 0; base < total; base += PT_THREADS * U) {
+      float f_valid[U]; float2 f_up[U]; int o_lds[U], o_sval[U]; bool ok[U], inside[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = base + u * PT_THREADS + (int)threadIdx.x;
+        const int r = (int)__umulhi((unsigned int)e, magic), cc = e - r * RW;
+        int lr = tile_r - 3 - d + r, cl = tile_c - 3 - d + cc;
+        if (cl < 0) { cl += C; lr -= 1; } else if (cl >= C) { cl -= C; lr += 1; }      // flat-index row wrap (:403-407)
+        const int gr = lr - P.halo + P.row0;
+        ok[u] = e < total && lr >= 0 && lr < total_rows && gr >= 0 && gr <= C - 1;
+        inside[u] = gr >= 1 && gr <= C - 2 && cl >= 1 && cl <= C - 2;
+        o_lds[u] = e < total ? r * rp + cc : -1;
         const int ir = r - 3 - d, ic = cc - 3 - d;
-        if (ir >= 0 && ir < PT_R && ic >= 0 && ic < PT_C) sval[ir * PT_C + ic] = m0.z;
+        o_sval[u] = (ir >= 0 && ir < PT_R && ic >= 0 && ic < PT_C) ? ir * PT_C + ic : -1;
+        f_valid[u] = 0.f; f_up[u] = make_float2(0.f, 0.f);
+        if (ok[u]) {
+          const float* cp = reinterpret_cast<const float*>(&cells[(long)lr * C + cl]);
+          f_valid[u] = cp[2];                                                 // Cell: h v valid trav | time upper is_upper pad
+          f_up[u] = *reinterpret_cast<const float2*>(cp + 5);
+        }
       }
-      rval[r * rp + cc] = val; rmsk[r * rp + cc] = msk;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (o_lds[u] < 0) continue;
+        float val = 0.f, msk = -1.f;
+        if (ok[u]) {
+          val = f_up[u].x;
+          const float m = f_valid[u] + f_up[u].y;
+          msk = inside[u] ? m : -m - 1.f;
+          if (o_sval[u] >= 0) sval[o_sval[u]] = f_valid[u];
+        }
+        rval[o_lds[u]] = val; rmsk[o_lds[u]] = msk;
+      }
     }
+  }
   __syncthreads();
   // dilated tile: known positions are a copy; the (usually few, scattered) holes are first COMPACTED into an LDS list
   // and then searched one hole per lane -- a hole-containing wave would otherwise drag all 64 lanes through the
