@@ -257,6 +257,8 @@ PREBUILD = {
     "bayes66": with_(PARAM_YAML, cell_n=66, bayes_kernels=True),
     "polygon130": with_(PARAM_DEFAULT, cell_n=130, polygon_kernel=True),
     "maxfilter34": with_(PARAM_DEFAULT, cell_n=34, max_filter_sizes=(1, 2)),
+    # wall-skip fixture (tests/_warm.py): two drift inliers in a cell already exceed wall_num_thresh
+    "wall202": with_(PARAM_DEFAULT, wall_num_thresh=1),
 }
 
 

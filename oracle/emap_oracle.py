@@ -247,6 +247,64 @@ class OracleMap:
         for c_, l_ in color:
             lib().eo_sem_color(ct.byref(self.P), _p(pts), n, st, _p(R), _p(t), ct.c_int(c_), ct.c_int(l_), _p(sm))
 
+    # ---- map shift (reference elevation_mapping.py:139-226): host array code, restated in NumPy ----------------------------
+    def move_to(self, position):
+        """:154-170 (the base rotation is not map state)"""
+        if not hasattr(self, "center"):
+            self.center = np.zeros(3, np.float32)
+        position = np.asarray(position, np.float64)
+        delta = position - self.center
+        delta_pixel = np.around(delta[:2] / self.P.resolution)
+        self.center[:2] += delta_pixel * self.P.resolution
+        self.center[2] += delta[2]
+        self.shift_map_xy(-delta_pixel)
+        self.shift_map_z(-delta[2])
+
+    def move(self, delta_position):
+        """:139-152 (shifts by +delta_pixel: the sign differs from move_to, as in the reference)"""
+        if not hasattr(self, "center"):
+            self.center = np.zeros(3, np.float32)
+        d = np.asarray(delta_position, np.float64)
+        delta_pixel = np.round(d[:2] / self.P.resolution)
+        self.center[:2] += delta_pixel * self.P.resolution
+        self.center[2] += d[2]
+        self.shift_map_xy(delta_pixel)
+        self.shift_map_z(-d[2])
+
+    def shift_map_xy(self, delta_pixel):
+        """:200-214: roll by the integer shift, entering band = 0 on every plane, initial_variance on plane 1.  The normal map
+        and traversability_input are NOT shifted (Appendix C of SURVEY.md)."""
+        sr, sc = (int(v) for v in np.asarray(delta_pixel).astype(np.int32))
+        if abs(sr) + abs(sc) == 0:
+            return
+        m = np.roll(self.elevation_map, (sr, sc), axis=(1, 2))
+        for plane, value in ((slice(None), 0.0), (1, np.float32(self.P.initial_variance))):
+            if sr > 0:
+                m[plane, :sr, :] = value
+            elif sr < 0:
+                m[plane, sr:, :] = value
+            if sc > 0:
+                m[plane, :, :sc] = value
+            elif sc < 0:
+                m[plane, :, sc:] = value
+        self.elevation_map = np.ascontiguousarray(m)
+        if hasattr(self, "semantic_map"):
+            sm = np.roll(self.semantic_map, (sr, sc), axis=(1, 2))
+            if sr > 0:
+                sm[:, :sr, :] = 0
+            elif sr < 0:
+                sm[:, sr:, :] = 0
+            if sc > 0:
+                sm[:, :, :sc] = 0
+            elif sc < 0:
+                sm[:, :, sc:] = 0
+            self.semantic_map = np.ascontiguousarray(sm)
+
+    def shift_map_z(self, delta_z):
+        """:216-226; delta_z is a float64 scalar array in the reference: the sum is rounded once to float32"""
+        self.elevation_map[0] += np.float64(delta_z)
+        self.elevation_map[5] += np.float64(delta_z)
+
     def update_variance(self):
         lib().eo_update_variance(ct.byref(self.P), _p(self.elevation_map))
 

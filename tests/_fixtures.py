@@ -88,3 +88,30 @@ def camera_inputs(emap_center, cell_n, resolution, K, R, t):
     x1 = np.float32(np.uint32((cell_n / 2) + (t_cam_map[0] / resolution)))
     y1 = np.float32(np.uint32((cell_n / 2) + (t_cam_map[1] / resolution)))
     return P, x1, y1, np.float32(t_cam_map[2])
+
+
+def warm_map(C, seed, init_var):
+    """Injected warm map for the race-free single-point fixtures: random heights around the sensor height, variances over
+    3.5 decades (=> outliers AND accepted points), 70 % known cells, `time` in the classes the visibility pass distinguishes
+    (fresh < 0.5 <= wall window < 1.0 <= stale), random upper bounds, random unit normals.  Returns (map (7,C,C), normals (3,C,C))."""
+    rng = np.random.default_rng(4000 + seed)
+    m = np.zeros((7, C, C), np.float32)
+    m[0] = rng.uniform(0.2, 2.2, (C, C))
+    m[1] = 10.0 ** rng.uniform(-3.0, 0.5, (C, C))
+    m[2] = (rng.uniform(0, 1, (C, C)) < 0.7)
+    m[3] = rng.uniform(0, 1, (C, C))
+    m[4] = rng.choice(np.array([0.0, 0.6, 0.9, 1.5, 3.0], np.float32), (C, C))
+    m[5] = rng.uniform(0.0, 2.5, (C, C))
+    m[6] = (rng.uniform(0, 1, (C, C)) < 0.5)
+    inv = m[2] < 0.5                                   # unknown cells look like the reference leaves them
+    m[0][inv] = 0.0; m[1][inv] = init_var
+    n = rng.normal(0, 1, (3, C, C))
+    n /= np.linalg.norm(n, axis=0, keepdims=True)
+    return m, n.astype(np.float32)
+
+
+def single_points(C, K, seed):
+    """K one-point frames: (point (1,3), pose name).  Points are uniform over the map like `cloud`; poses alternate."""
+    p = cloud(C, K, 7000 + seed)
+    names = ["rotated", "identity"]
+    return [(p[k:k + 1].copy(), names[k % 2]) for k in range(K)]

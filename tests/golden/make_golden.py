@@ -98,14 +98,13 @@ def stencils():
     np.savez_compressed(os.path.join(OUT, "stencil.npz"), **save)
 
 
-if __name__ == "__main__":
+def core():
     weights()
     kat("yaml202", build_ref.PREBUILD["yaml202"], 202, 50000)
     kat("default202", build_ref.PREBUILD["default202"], 202, 50000)
     kat("yaml1024", build_ref.PREBUILD["yaml1024"], 1024, 200000)
     frame66()
     stencils()
-    print(sorted(os.listdir(OUT)))
 
 
 def semantic66():
@@ -162,7 +161,106 @@ def bayes66():
     np.savez_compressed(os.path.join(OUT, "bayes_yaml66.npz"), sem=sem, alpha=newmap[:2], sum_mean=sum_mean)
 
 
-if __name__ == "__main__":
-    semantic66()
-    bayes66()
+
+
+def warm_single():
+    """race-free warm fixtures (tests/_warm.py): K one-point frames through the compiled reference on an injected warm map, for
+    both parameter sets; stored as the sparse difference to the untouched map (+ totals that prove the branches were reached)."""
+    import _warm as W
+    from oracle import emap_oracle as eo
+    save = {}
+    for name, cfgname in W.SETS.items():
+        cfg = getattr(eo, cfgname)
+        rk = ref_kernels.RefKernels(build_ref.PREBUILD[name])
+        C = 202
+        m0, nrm = fx.warm_map(C, 1, cfg["initial_variance"])
+        m = m0.copy()
+        om = eo.OracleMap(eo.make_params(cfg, cell_n=C)); om.elevation_map[...] = m0; om.normal_map[...] = nrm
+        tot = [0, 0]
+
+        def frame(p, R, t):
+            W.ref_frame(rk, m, nrm, p, R, t)
+            h, o = W.oracle_frame(om, p, R, t); tot[0] += h; tot[1] += o
+
+        def tick():
+            m[4] += np.float32(cfg["time_interval"]); om.update_time()
+        W.run_single(cfg, C, 1, frame, None, tick)
+        idx, val = W.sparse_diff(W.base_single(m0, cfg), m)
+        save[name + "_idx"], save[name + "_val"] = idx, val
+        save[name + "_hits_outliers"] = np.array(tot, np.int64)      # counted by the contract oracle on the same frames
+        print(name, "entries", idx.size, "ray hits", tot[0], "outliers", tot[1])
+    # wall-skip fixture
+    cfg = dict(eo.DEFAULTS, **W.WALL_CFG)
+    rk = ref_kernels.RefKernels(build_ref.PREBUILD["wall202"])
+    C = 202
+    R, t = fx.POSES["identity"]
+    m0, nrm = fx.warm_map(C, 2, cfg["initial_variance"])
+    m, nrm = m0.copy(), nrm.copy()
+    valid_after, order_dependent, want_skip = [], 0, []
+    for ix, iy, cell, d3, pts, skipped in W.wall_sequence(C):
+        m[:, ix, iy] = cell; nrm[:, ix, iy] = d3
+        mr = m.copy(); W.ref_frame(rk, mr, nrm, pts[::-1].copy(), R, t)
+        W.ref_frame(rk, m, nrm, pts, R, t)
+        order_dependent += not all(np.allclose(m[q], mr[q], atol=1e-6, rtol=1e-6) for q in range(7))
+        valid_after.append(m[2, ix, iy]); want_skip.append(skipped)
+    assert order_dependent == 0, "wall fixture must be race free (forward == reversed point order)"
+    idx, val = W.sparse_diff(W.base_after_reset(m0, np.float32(cfg["initial_variance"])), m)
+    save["wall202_idx"], save["wall202_val"] = idx, val
+    save["wall202_valid_after"] = np.array(valid_after, np.float32)
+    assert all((v == 1.0) == sk for v, sk in zip(valid_after, want_skip)), "wall fixture: skip / penetration pattern not reached"
+    print("wall202 entries", idx.size, "skipped", int((np.array(valid_after) == 1).sum()), "penetrated", int((np.array(valid_after) < 1).sum()))
+    np.savez_compressed(os.path.join(OUT, "warm_single.npz"), **save)
+
+
+def host_steps():
+    """the reference's HOST code of the path executed with NumPy as cupy (oracle/ref_host.py): drift gate, overlap clearance,
+    variance / time decay and a move_to / move sequence."""
+    import _warm as W
+    from oracle import emap_oracle as eo, ref_host
+    H = ref_host.load()
+    save = {}
+    for cname in ("YAML", "DEFAULTS"):
+        cfg = dict(getattr(eo, cname))
+        # drift gate (elevation_mapping.py:346-357)
+        rows = []
+        for err, cnt, pn, on in GATE_CASES:
+            h = H(cfg, 34); h.elevation_map[0] = fx.stencil_inputs(34, 3)[0]
+            h.additive_mean_error = np.float32(0.25)
+            h.drift_gate(np.array([err], np.float32), np.array([cnt], np.float32), pn, on)
+            rows.append([float(np.asarray(h.mean_error).ravel()[0]), float(np.asarray(h.additive_mean_error).ravel()[0]), float(h.elevation_map[0, 5, 7])])
+        save[cname + "_gate"] = np.array(rows, np.float64)
+        # overlap clearance (:393-410), variance / time decay (:420-426)
+        C = 130
+        h = H(cfg, C); m0, _ = fx.warm_map(C, 3, cfg["initial_variance"]); h.elevation_map[...] = m0
+        tz = np.array([0.1, -0.2, 2.6], np.float32)
+        h.clear_overlap_map(tz)
+        save[cname + "_overlap_idx"], save[cname + "_overlap_val"] = W.sparse_diff(m0, h.elevation_map)
+        h.update_variance(); h.update_time()
+        save[cname + "_decay_var_time"] = h.elevation_map[[1, 4]].copy()
+    # shift sequence (:139-226)
+    cfg = dict(eo.YAML); C = 34
+    h = H(cfg, C); m0, _ = fx.warm_map(C, 4, cfg["initial_variance"]); h.elevation_map[...] = m0
+    centers = []
+    for kind, vec in MOVE_SEQUENCE:
+        if kind == "move_to":
+            h.move_to(np.array(vec, np.float64), np.eye(3))
+        else:
+            h.move(np.array(vec, np.float64))
+        centers.append(np.asarray(h.center, np.float32).copy())
+    save["shift_map"] = h.elevation_map.copy(); save["shift_centers"] = np.array(centers)
+    save["shift_sem_calls"] = np.array(h.semantic_map.shifts, np.int32)
+    np.savez_compressed(os.path.join(OUT, "host_steps.npz"), **save)
+    print("host steps:", sorted(save))
+
+
+GATE_CASES = [(12.5, 200, 1.0, 1.0), (-3.0, 150, 0.0, 1.0), (40.0, 200, 1.0, 0.0), (5.0, 100, 1.0, 1.0), (5.0, 101, 0.0, 0.0),
+              (0.0, 0, 1.0, 1.0), (-19.0, 200, 1.0, 1.0)]
+MOVE_SEQUENCE = [("move_to", (0.13, -0.3, 0.05)), ("move_to", (0.13, -0.3, 0.05)), ("move", (-0.21, 0.09, -0.02)),
+                 ("move_to", (0.5, 0.5, 0.0)), ("move", (0.0, 0.0, 0.3)), ("move_to", (-0.9, 0.46, 0.11)), ("move", (2.0, -0.04, 0.0))]
+
+
+if __name__ == "__main__":      # python tests/golden/make_golden.py [core semantic66 bayes66 warm_single host_steps]
+    todo = sys.argv[1:] or ["core", "semantic66", "bayes66", "warm_single", "host_steps"]
+    for name in todo:
+        globals()[name]()
     print(sorted(os.listdir(OUT)))
