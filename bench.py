@@ -4,10 +4,16 @@
 A "step" is one frame of ``update_map_with_kernel`` (reference EM/elevation_mapping.py:316-391) over one
 synthetic cloud that is already resident in HBM.  Default workload = BASELINE.json configs[1]:
 1024x1024 map (cell_n incl. border), 1 M uniform-random points per frame, shipped core_param.yaml values,
-visibility clean-up and overlap clearance off ("cfg2"); ``--workload cfg3`` turns both on.
+visibility clean-up and overlap clearance off ("cfg2"); ``--workload cfg3`` turns both on.  The default cfg2 line also
+carries ``config.cfg3``: the same process then times the cfg3 frame (rays + overlap) on a second map.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3] [--points N] [--cell-n C]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (row strips, see sharded.py)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg5] [--points N] [--cell-n C]
+
+``--gpus N`` (N > 1) runs N row strips, one process per GPU: started by an external launcher
+(``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or, when WORLD_SIZE is unset, by bench.py itself (elevation_mapping_cupy_amd/launch.py).  The strips talk
+through the library's own RCCL communicator (no torch in the process); with fewer devices than ranks (single-GPU boxes)
+the ranks share devices and the collectives fall back to torch.distributed/gloo.
 
 Prints ONE JSON line (rank 0): metric/value/unit + roofline + cpu_baseline objects (see DESIGN.md "Measurement").
 """
@@ -28,7 +34,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -40,12 +46,14 @@ def parse():
     ap.add_argument("--cell-n", type=int, default=None, help="default 1024 (cfg2/cfg3) or 8192 (cfg5)")
     ap.add_argument("--mode", default="reference_fp16", choices=["reference_fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the config.cfg3 sub-measurement of the default cfg2 line")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
     ap.add_argument("--scatter", default="auto", choices=["auto", "atomic", "binned"])
     ap.add_argument("--sort-clouds", default="none", choices=["none", "tile", "angle"],
                     help="experiment: spatially coherent input order (real sensors deliver scan-ordered clouds)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-strip path even with one rank (self-test)")
-    a = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous plumbing only, no GPU work (CPU test hook)")
+    a = ap.parse_args(argv)
     big = a.workload == "cfg5"
     a.cell_n = a.cell_n or (8192 if big else 1024)
     a.points = a.points or (16_000_000 if big else 1_000_000)
@@ -55,7 +63,7 @@ def parse():
 def workload_cfg(name):
     from elevation_mapping_cupy_amd.configs import CORE_PARAM_YAML
     cfg = dict(CORE_PARAM_YAML)
-    if name == "cfg2":
+    if name in ("cfg2", "cfg5"):
         cfg.update(enable_visibility_cleanup=False, enable_overlap_clearance=False)
     return cfg
 
@@ -85,7 +93,8 @@ class Hip:
         self.ck(self.l.hipDeviceSynchronize(), "hipDeviceSynchronize")
 
 
-# Algorithmic bytes of each timed stage = the bytes that stage must move once (N points, L cells):
+# Algorithmic bytes of each timed stage = the bytes that stage must move once (N points, L cells).  "post" follows
+# dilation 12 B/cell (2 planes in, 1 out) + normal filter 20 B/cell + traversability filter 8 B/cell.
 STAGE_BYTES = {
     "hist": lambda N, L: 12 * N + 16 * N,                    # xyz in, 16-B staging record out
     "scan": lambda N, L: 0,
@@ -96,34 +105,179 @@ STAGE_BYTES = {
     "rays": lambda N, L: 12 * N + 32 * L + 16 * L,           # cloud + map + ray accumulators once (the kernel is issue bound: see visits/s)
     "average": lambda N, L: 40 * L + 16 * L + 64 * L,
     "overlap": lambda N, L: 0,
-    "post": lambda N, L: 32 * L + 4 * L + 4 * L + 12 * L,    # cells in; traversability_input, traversability, 3 normal planes out
+    "post": lambda N, L: 40 * L,
 }
 STAGE_KERNEL = {"hist": "k_bin_hist", "scan": "k_bin_scan1", "scatter": "k_bin_scatter", "gate": "k_tile_count", "fuse": "k_tile_fuse",
                 "commit": "k_commit", "rays": "k_rays<0, false", "average": "k_average", "overlap": "k_overlap", "post": "k_post"}
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 or world > 1 or a.force_sharded:
-        from elevation_mapping_cupy_amd import sharded
-        return sharded.bench_main(a, rank, world, local_rank)
+def load_weights():
+    w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
+    return {k: w[k] for k in ("w1", "w2", "w3", "w_out")}
 
+
+def host_clouds(a, C, N, multimodal):
+    """the seeded clouds of SURVEY §8d: x,y ~ U(-L/2, L/2), sensor-frame z ~ U(-.5,.5); the timed clouds are lowered"""
+    import _fixtures as fx
+    ncloud = 2 if multimodal else 5
+    if multimodal:   # x y z | rgb (packed 0x00RRGGBB) | 3 semantic features  -> colour + average fusions
+        clouds = []
+        for s_ in range(ncloud):
+            p_ = fx.cloud(C, N, s_, dz=-0.02 * s_, extra=4)
+            p_[:, 3] = np.random.default_rng(50 + s_).integers(0, 1 << 24, N, dtype=np.uint32).view(np.float32)
+            clouds.append(p_)
+    else:
+        clouds = [fx.cloud(C, N, s, dz=(0.0 if s == 0 else -0.02 * s)) for s in range(ncloud)]
+    if a.sort_clouds != "none":
+        for k_, p_ in enumerate(clouds):
+            if a.sort_clouds == "tile":
+                ix = np.clip((p_[:, 0] / 0.04 + C / 2).astype(np.int64), 0, C - 1); iy = np.clip((p_[:, 1] / 0.04 + C / 2).astype(np.int64), 0, C - 1)
+                key = (ix // 16) * (C // 64 + 1) * 4096 + (iy // 64) * 4096 + (ix % 16) * 64 + iy % 64
+            else:
+                key = np.arctan2(p_[:, 1], p_[:, 0])
+            clouds[k_] = np.ascontiguousarray(p_[np.argsort(key, kind="stable")])
+    return clouds
+
+
+def event_overhead(lib, ctx):
+    """an event pair with NOTHING between its records is already ~4.5 us apart on this stack (marker processing); a stage interval
+    is that spacing + the kernel, so the spacing is calibrated and removed -- the result agrees with rocprofv3's kernel durations"""
+    empty = []
+    for _ in range(50):
+        e_ms = ct.c_float(0)
+        lib.emap_timer_begin(ctx); lib.emap_timer_end(ctx, ct.byref(e_ms)); empty.append(e_ms.value)
+    return float(np.median(empty))
+
+
+def stage_profile(lib, ctx, frame, reps, with_stats=True):
+    from elevation_mapping_cupy_amd import _lib
+    lib.emap_enable_stage_timing(ctx, 2 if with_stats else 1)
+    acc = np.zeros(10)
+    st = _lib.EmapStats()
+    visits = 0
+    for i in range(reps):
+        frame(i, ct.byref(st) if with_stats else None)
+        ms10 = (ct.c_float * 10)()
+        lib.emap_get_stage_times(ctx, ms10)
+        acc += np.array(list(ms10)); visits += st.ray_visits
+    lib.emap_enable_stage_timing(ctx, 0)
+    return dict(zip(_lib.STAGES, (acc / reps).tolist())), visits / reps
+
+
+def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step, visits, pmc_ok, stage_bytes=None):
+    sb = stage_bytes or {k: f(N, L) for k, f in STAGE_BYTES.items()}
+    cand = {k: v for k, v in stage_ms.items() if sb[k] > 0}
+    dom = max(cand, key=cand.get)
+    dom_bytes = sb[dom]
+    dom_ms = max(stage_ms[dom] - ev_overhead, 1e-6)
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel: from the committed rocprofv3 PMC passes of this same command
+    # (tools/profile_round.sh -> profiles/pmc_<workload>.json; counters cannot be read from inside the process)
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
+    if pmc_ok and os.path.exists(pmc_file):
+        kern = STAGE_KERNEL[dom]
+        for name, rec in json.load(open(pmc_file))["kernels"].items():
+            if name.startswith(kern):
+                traffic, traffic_src = rec["hbm_bytes"], "profiles/pmc_%s.json (%s)" % (workload, name)
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes": int(dom_bytes), "kernel_ms": round(dom_ms, 5), "event_pair_overhead_ms": round(ev_overhead, 5),
+            "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},   # raw event spacings (overhead included)
+            "frame_algorithmic_bytes": int(frame_bytes),
+            "frame_frac": round(frame_bytes / (dev_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "ray_visits_per_frame": int(visits),
+            "ray_visits_per_s": (round(visits / (stage_ms["rays"] * 1e-3) / 1e9, 1) if visits else None), "visits_unit": "G cell visits/s"}
+
+
+def cpu_baseline(a, cfg, C, N, clouds_host, weights, R, t):
+    """the oracle port (and the reference's own compiled kernels) on a bounded sample of the same workload"""
+    from oracle import emap_oracle as eo
+    ncloud = len(clouds_host)
+    n_cpu = a.cpu_points or (N if a.workload == "cfg2" else min(N, 60000))
+    P = eo.make_params(cfg, cell_n=C, mode=a.mode, weights=weights)
+
+    def cpu_rate(threads):
+        eo.set_threads(threads)
+        om = eo.OracleMap(P)
+        om.frame_c(clouds_host[0][:n_cpu, :3], R, t, 1.0, 1.0)
+        for _ in range(8):
+            om.update_time()
+        reps_cpu, t_cpu = 0, 0.0
+        while reps_cpu < 5 and t_cpu < 8.0:
+            s = time.perf_counter(); om.frame_c(clouds_host[(reps_cpu + 1) % ncloud][:n_cpu, :3], R, t, 1.0, 1.0)
+            t_cpu += time.perf_counter() - s; reps_cpu += 1
+        eo.set_threads(1)
+        return n_cpu * reps_cpu / t_cpu / 1e6, reps_cpu
+
+    def usable_cores():
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:  # cgroup v2 CPU quota of the container
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+        except (OSError, ValueError):
+            pass
+        return n
+    avail = usable_cores()
+    v1, reps_cpu = cpu_rate(1)
+    best_v, best_n = v1, 1
+    for nthr in sorted({min(avail, 8), min(avail, 32), avail} - {1}):    # oversubscription hurts: keep the best setting
+        v, reps_cpu = cpu_rate(nthr)
+        if v > best_v:
+            best_v, best_n = v, nthr
+    cpu = {"value": round(best_v, 4), "unit": "Mpoints/s", "cores": best_n, "kind": "port", "single_thread_value": round(v1, 4),
+           "sample": "<=5 frames (<=8 s) of %d points on the %dx%d map, oracle/emap_oracle.c eo_frame (gcc -O2 -fopenmp); best of "
+                     "1/8/32/%d threads, %d usable cores (os.cpu_count() = %d)" % (n_cpu, C, C, avail, avail, os.cpu_count() or 1)}
+    # second CPU line: the reference's OWN kernel source compiled for the host (oracle/_ref, sequential, 1 thread) on a smaller
+    # sample of the same clouds -- error_counting + add_points + average_map + dilation + normal kernels (its traversability
+    # network is PyTorch and not part of that build)
+    try:
+        from oracle import build_ref, ref_kernels
+        key = {(1024, "cfg2"): "yaml1024_norays", (1024, "cfg3"): "yaml1024", (202, "cfg2"): "yaml202_norays", (202, "cfg3"): "yaml202"}.get((C, a.workload))
+        if key and a.mode == "reference_fp16" and ref_kernels.available(build_ref.PREBUILD[key]):
+            rk = ref_kernels.RefKernels(build_ref.PREBUILD[key], build=False)
+            n_ref = min(N, 200000 if a.workload == "cfg2" else 20000)
+            m_ref = np.zeros((7, C, C), np.float32); m_ref[1] = cfg["initial_variance"]; m_ref[3] = 1
+            nrm_ref = np.zeros((3, C, C), np.float32)
+            Rf = np.ascontiguousarray(R, np.float32).ravel().copy(); tf = np.ascontiguousarray(t, np.float32)
+
+            def ref_frame(k_):
+                p_ = np.ascontiguousarray(clouds_host[k_ % ncloud][:n_ref, :3])
+                nm_ = np.zeros((7, C, C), np.float32); e_ = np.zeros(1, np.float32); c_ = np.zeros(1, np.float32)
+                t0_ = time.perf_counter()
+                rk.error_counting(m_ref, p_, Rf, tf, nm_, e_, c_); rk.add_points(Rf, tf, nrm_ref, p_, m_ref, nm_); rk.average_map(nm_, m_ref)
+                dil_ = np.zeros((C, C), np.float32); dm_ = np.zeros((C, C), np.float32)
+                rk.dilation_filter(m_ref[5].copy(), (m_ref[2] + m_ref[6]).copy(), dil_, dm_)
+                rk.normal_filter(dil_, m_ref[2].copy(), nrm_ref)
+                return time.perf_counter() - t0_
+            ref_frame(0); m_ref[4] += 1.0
+            t_ref = [ref_frame(1), ref_frame(2)]
+            cpu["reference_kernels"] = {"value": round(n_ref / float(np.mean(t_ref)) / 1e6, 4), "unit": "Mpoints/s", "cores": 1,
+                                        "sample": "2 frames of %d points, the reference's kernel source compiled with g++ -O2 (oracle/build_ref.py)" % n_ref}
+    except Exception as ex:  # noqa: BLE001 - the second line is optional
+        print("reference-kernel CPU line skipped: %s" % ex, file=sys.stderr)
+    return cpu
+
+
+def workload_text(a, C, N, multimodal):
+    return "%s: %dx%d map, %d uniform-random points/frame, core_param.yaml values, %s" % (
+        a.workload, C, C, N, "rays+overlap on" if a.workload == "cfg3" else
+        ("height + RGB + 3 semantic layers, fp32 index mode" if multimodal else "add_points + variance fusion, rays/overlap off"))
+
+
+# -------------------------------------------------------------------------------------------------------------------------------
+def run_single(a, local_rank=0):
     from elevation_mapping_cupy_amd import _lib
     from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
     from elevation_mapping_cupy_amd.configs import parameter_from
-    import _fixtures as fx
 
     cfg = workload_cfg(a.workload)
     C, N = a.cell_n, a.points
     multimodal = a.workload == "cfg5"
-    if multimodal:
-        a.mode = "fp32" if C > 2049 else a.mode
-        cfg.update(enable_visibility_cleanup=False, enable_overlap_clearance=False)
-    w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
-    weights = {k: w[k] for k in ("w1", "w2", "w3", "w_out")}
+    if multimodal and C > 2049:
+        a.mode = "fp32"
+    weights = load_weights()
     par = parameter_from(cfg, C, a.mode, weights)
     par.device = local_rank
     emap = ElevationMap(par)
@@ -131,14 +285,10 @@ def main():
     lib, ctx = emap._lib, emap._ctx
     hip = Hip(); hip.set_device(local_rank)
 
-    # 5 seeded clouds resident in HBM: x,y ~ U(-L/2, L/2), sensor-frame z ~ U(-.5,.5); timed clouds lowered
-    NCLOUD = 2 if multimodal else 5
-    if multimodal:   # x y z | rgb (packed 0x00RRGGBB) | 3 semantic features  -> colour + average fusions
-        clouds_host = []
-        for s_ in range(NCLOUD):
-            p_ = fx.cloud(C, N, s_, dz=-0.02 * s_, extra=4)
-            p_[:, 3] = np.random.default_rng(50 + s_).integers(0, 1 << 24, N, dtype=np.uint32).view(np.float32)
-            clouds_host.append(p_)
+    clouds_host = host_clouds(a, C, N, multimodal)
+    NCLOUD = len(clouds_host)
+    spec = None
+    if multimodal:
         spec = _lib.EmapSemSpec()
         spec.n_col, spec.col_chan[0], spec.col_layer[0] = 1, 3, 0
         spec.n_sum = 3
@@ -147,17 +297,183 @@ def main():
         spec.alpha = 0.5
         if lib.emap_semantic_configure(ctx, 4):
             raise RuntimeError(lib.emap_last_error(ctx).decode())
-    else:
-        clouds_host = [fx.cloud(C, N, s, dz=(0.0 if s == 0 else -0.02 * s)) for s in range(NCLOUD)]
-    if a.sort_clouds != "none":
-        for k_, p_ in enumerate(clouds_host):
-            if a.sort_clouds == "tile":
-                ix = np.clip((p_[:, 0] / 0.04 + C / 2).astype(np.int64), 0, C - 1); iy = np.clip((p_[:, 1] / 0.04 + C / 2).astype(np.int64), 0, C - 1)
-                key = (ix // 16) * (C // 64 + 1) * 4096 + (iy // 64) * 4096 + (ix % 16) * 64 + iy % 64
-            else:
-                key = np.arctan2(p_[:, 1], p_[:, 0])
-            clouds_host[k_] = np.ascontiguousarray(p_[np.argsort(key, kind="stable")])
     stride = clouds_host[0].shape[1]
+    clouds_dev = []
+    for p in clouds_host:
+        d = hip.malloc(p.nbytes); hip.h2d(d, p); clouds_dev.append(d)
+    R = np.eye(3, dtype=np.float32).ravel().copy()
+    t = np.array([0, 0, 1], np.float32)
+    Rp, tp = _lib.f32p(R), _lib.f32p(t)
+
+    def make_frame(lib, ctx):
+        def frame(i, stats=None):
+            rc = lib.emap_set_points_device(ctx, clouds_dev[i % NCLOUD], ct.c_int64(N), ct.c_int64(stride))
+            rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
+            if multimodal:
+                rc = rc or lib.emap_semantic_update(ctx, Rp, tp, ct.byref(spec))
+            if rc:
+                raise RuntimeError(lib.emap_last_error(ctx).decode())
+        return frame
+    frame = make_frame(lib, ctx)
+
+    def warm(em, fr):
+        # map warm-up (3 frames + time ticks so that the ray pass has stale cells to act on)
+        for i in range(3):
+            fr(i)
+            for _ in range(4):
+                em.update_time()
+        em.update_variance()
+        for i in range(a.warmup):
+            fr(i)
+        em.sync(); hip.sync()
+
+    def timed(em, fr, steps):
+        ms_dev = ct.c_float(0)
+        t0 = time.perf_counter()
+        em._lib.emap_timer_begin(em._ctx)
+        for i in range(steps):
+            fr(i)
+        em._lib.emap_timer_end(em._ctx, ct.byref(ms_dev))
+        em.sync(); hip.sync()
+        return time.perf_counter() - t0, ms_dev.value
+
+    def latencies(em, fr, n):
+        lat = []
+        for i in range(n):
+            em.sync()
+            t1 = time.perf_counter(); fr(i); em.sync(); lat.append((time.perf_counter() - t1) * 1e3)
+        return [float(x) for x in np.percentile(lat, [10, 50, 90])]
+
+    warm(emap, frame)
+    # ---- timed region: exactly K frames, sync on both sides -------------------------------------------------
+    wall, ms_dev = timed(emap, frame, a.steps)
+    ms_per_step = wall * 1e3 / a.steps
+    mpts = N * a.steps / wall / 1e6
+    # ---- per-frame latency distribution (each frame individually synchronised) ---------------------------
+    p10, p50, p90 = latencies(emap, frame, min(a.steps, 40))
+    # ---- per-stage device time (hipEvents on the kernel's stream) -> roofline of the dominant kernel ------
+    stage_ms, visits = stage_profile(lib, ctx, frame, min(a.steps, 20))
+    ev_overhead = event_overhead(lib, ctx)
+    L = C * C
+    frame_bytes = 12 * N + 56 * L + (16 * N + 32 * L if multimodal else 0)   # B_frame of BASELINE.md §5 (K extra channels, L semantic layers)
+    pmc_ok = C == 1024 and N == 1_000_000 and a.mode == "reference_fp16"
+    roof = roofline(stage_ms, ev_overhead, N, L, a.workload, frame_bytes, ms_dev / a.steps, visits, pmc_ok)
+
+    # ---- config.cfg3: the frame WITH the visibility pass + overlap clearance, same process, second map ------------------
+    cfg3 = None
+    if a.workload == "cfg2" and not a.no_cfg3 and not multimodal:
+        cfgr = workload_cfg("cfg3")
+        par3 = parameter_from(cfgr, C, a.mode, weights); par3.device = local_rank
+        em3 = ElevationMap(par3); em3.set_scatter_mode(a.scatter)
+        fr3 = make_frame(em3._lib, em3._ctx)
+        warm(em3, fr3)
+        k3 = max(3, min(a.steps, 20))
+        wall3, ms3 = timed(em3, fr3, k3)
+        lat3 = latencies(em3, fr3, min(k3, 10))
+        st3, vis3 = stage_profile(em3._lib, em3._ctx, fr3, min(k3, 8))
+        r3 = roofline(st3, ev_overhead, N, L, "cfg3", frame_bytes, ms3 / k3, vis3, pmc_ok)
+        cfg3 = {"workload": "cfg3: same map and clouds with enable_visibility_cleanup + enable_overlap_clearance",
+                "value": round(N * k3 / wall3 / 1e6, 2), "unit": "Mpoints/s", "steps": k3, "ms_per_step": round(wall3 * 1e3 / k3, 5),
+                "latency_ms": {"p10": round(lat3[0], 4), "p50": round(lat3[1], 4), "p90": round(lat3[2], 4)},
+                "dominant_kernel": r3["kernel"], "kernel_ms": r3["kernel_ms"], "frac": r3["frac"], "traffic": r3["traffic"],
+                "ray_visits_per_frame": r3["ray_visits_per_frame"], "ray_visits_per_s": r3["ray_visits_per_s"],
+                "stage_ms": r3["stage_ms"]}
+        em3.close()
+
+    cpu = None
+    if not a.no_cpu_baseline and not multimodal:
+        cpu = cpu_baseline(a, cfg, C, N, clouds_host, weights, R, t)
+
+    config = {"workload": workload_text(a, C, N, multimodal), "index_mode": a.mode,
+              "latency_ms": {"p10": round(p10, 4), "p50": round(p50, 4), "p90": round(p90, 4)},
+              "device_ms_per_step": round(ms_dev / a.steps, 5), "cloud": "device resident (H2D excluded)"}
+    if cfg3:
+        config["cfg3"] = cfg3
+    out = {
+        "metric": "Mpoints/s fused (map-update p50 latency in config)", "value": round(mpts, 2), "unit": "Mpoints/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": config, "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+
+
+# -------------------------------------------------------------------------------------------------------------------------------
+def run_strips_native(a, rank, world, local_rank, rdv):
+    """one row strip per rank, both exchange steps issued by the C library over RCCL; no torch in the process.
+    Returns (False, None) -- on every rank alike -- when the native communicator cannot be used, so that the caller can fall
+    back, else (True, the JSON object on rank 0)."""
+    from elevation_mapping_cupy_amd import _lib, launch, sharded
+    from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
+    from elevation_mapping_cupy_amd.configs import parameter_from
+
+    ndev = launch.device_count()
+    if not rdv.agree("devices", ndev >= world or os.environ.get("EMAP_RCCL_LIB")):     # RCCL refuses two ranks on one device
+        return False, None
+    dev = local_rank % max(1, ndev)
+    cfg = workload_cfg(a.workload)
+    C, N = a.cell_n, a.points
+    multimodal = a.workload == "cfg5"
+    if multimodal and C > 2049:
+        a.mode = "fp32"
+    weights = load_weights()
+    par = parameter_from(cfg, C, a.mode, weights, device=dev)
+    halo = sharded.halo_rows_needed(par.dilation_size, world)
+    row_w = None
+    if cfg["enable_visibility_cleanup"] and world > 1 and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
+        row_w = sharded.ray_balanced_weights(C, float(cfg["resolution"]), float(cfg["max_ray_length"]), halo, world)
+    r0, r1 = sharded.strip_rows(C, world, rank, row_w)
+    ok, emap, err = True, None, ""
+    try:
+        if world > 1 and r1 - r0 < halo:
+            raise ValueError("strip of %d rows is thinner than the %d-row halo" % (r1 - r0, halo))
+        emap = ElevationMap(par, strip=(r0, r1 - r0, halo))
+        emap.set_scatter_mode(a.scatter)
+    except Exception as ex:  # noqa: BLE001
+        ok, err = False, str(ex)
+    if not rdv.agree("create", ok):
+        if err:
+            print("[rank %d] strip context failed: %s" % (rank, err), file=sys.stderr)
+        return False, None
+    lib, ctx = emap._lib, emap._ctx
+    path = sharded.rccl_library_path().encode()
+    uid = (ct.c_uint8 * 128)()
+    ok = True
+    if rank == 0:
+        ok = lib.emap_comm_unique_id(path, uid) == 0
+        rdv.publish("uid", bytes(uid) if ok else b"")
+    blob = rdv.fetch("uid", 0)
+    if not rdv.agree("uid", len(blob) == 128):
+        return False, None
+    uid = (ct.c_uint8 * 128).from_buffer_copy(blob)
+    ok = lib.emap_comm_init(ctx, path, uid, rank, world) == 0
+    if not ok:
+        print("[rank %d] emap_comm_init: %s" % (rank, lib.emap_last_error(ctx).decode()), file=sys.stderr)
+    if not rdv.agree("init", ok):
+        return False, None
+    ok = lib.emap_comm_selftest(ctx) == 0
+    if not rdv.agree("selftest", ok):
+        lib.emap_comm_destroy(ctx)
+        return False, None
+
+    def reduce(vals, op):
+        buf = (ct.c_double * len(vals))(*vals)
+        if lib.emap_comm_allreduce_host(ctx, buf, len(vals), op):
+            raise RuntimeError(lib.emap_last_error(ctx).decode())
+        return list(buf)
+
+    def barrier():
+        reduce([0.0], 0)
+
+    hip = Hip(); hip.set_device(dev)
+    clouds_host = host_clouds(a, C, N, multimodal)
+    NCLOUD = len(clouds_host)
+    stride = clouds_host[0].shape[1]
+    channels = None
+    if multimodal:
+        channels = ["rgb", "sem0", "sem1", "sem2"]
+        par.pointcloud_channel_fusions = {"rgb": "color", "default": "average"}
+        emap.semantic_map.prepare(channels)
     clouds_dev = []
     for p in clouds_host:
         d = hip.malloc(p.nbytes); hip.h2d(d, p); clouds_dev.append(d)
@@ -167,13 +483,12 @@ def main():
 
     def frame(i, stats=None):
         rc = lib.emap_set_points_device(ctx, clouds_dev[i % NCLOUD], ct.c_int64(N), ct.c_int64(stride))
-        rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
-        if multimodal:
-            rc = rc or lib.emap_semantic_update(ctx, Rp, tp, ct.byref(spec))
+        rc = rc or lib.emap_update_sharded(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
         if rc:
             raise RuntimeError(lib.emap_last_error(ctx).decode())
+        if multimodal:
+            emap.semantic_map.update_layers_pointcloud(emap, channels, R, t)
 
-    # map warm-up (3 frames + time ticks so that the ray pass has stale cells to act on)
     for i in range(3):
         frame(i)
         for _ in range(4):
@@ -181,150 +496,122 @@ def main():
     emap.update_variance()
     for i in range(a.warmup):
         frame(i)
-    emap.sync(); hip.sync()
-
-    # ---- timed region: exactly K frames, sync on both sides -------------------------------------------------
-    ms_dev = ct.c_float(0)
+    emap.sync(); barrier()
+    # ---- timed region: barrier + device sync on both sides, MAX over ranks ------------------------------------------------
     t0 = time.perf_counter()
-    lib.emap_timer_begin(ctx)
     for i in range(a.steps):
         frame(i)
-    lib.emap_timer_end(ctx, ct.byref(ms_dev))
-    emap.sync(); hip.sync()
-    wall = time.perf_counter() - t0
-    ms_per_step = wall * 1e3 / a.steps
-    mpts = N * a.steps / wall / 1e6
-
-    # ---- per-frame latency distribution (each frame individually synchronised) ---------------------------
+    emap.sync()
+    wall_local = time.perf_counter() - t0
+    barrier()
+    wall = reduce([wall_local], 1)[0]
+    # ---- per-frame latency: every frame synchronised on every rank (the collectives keep the ranks in step); max over ranks --------
     lat = []
     for i in range(min(a.steps, 40)):
         emap.sync()
         t1 = time.perf_counter(); frame(i); emap.sync(); lat.append((time.perf_counter() - t1) * 1e3)
-    p10, p50, p90 = np.percentile(lat, [10, 50, 90])
+    pct = reduce([float(x) for x in np.percentile(lat, [10, 50, 90])], 1)
+    # ---- per-stage device time of every rank's strip ------------------------------------------------------------------------------
+    stage_ms, _ = stage_profile(lib, ctx, frame, min(a.steps, 20), with_stats=False)
+    ev_overhead = event_overhead(lib, ctx)
+    emap.sync(); barrier()
+    all_stage = rdv.gather_json("stage_ms", {k: round(v, 5) for k, v in stage_ms.items()})
+    rows = rdv.gather_json("rows", [int(r0), int(r1)])
+    out = None
+    if rank == 0:
+        # algorithmic bytes of a strip: every rank reads the whole replicated cloud, but sorts / fuses only the points of its
+        # rows (N / world for uniform clouds) and streams only its L / world cells
+        Nw, Lw = N / world, C * C / world
+        sb = {"hist": 28 * N, "scan": 0, "scatter": 16 * N + 32 * Nw, "gate": 0, "fuse": 24 * Nw + 64 * Lw, "commit": 104 * Lw,
+              "rays": 12 * N + 48 * Lw, "average": 120 * Lw, "overlap": 0, "post": 40 * Lw}
+        L = C * C
+        frame_bytes = 12 * N + 56 * L + (16 * N + 32 * L if multimodal else 0)
+        roof = roofline(stage_ms, ev_overhead, N, L, a.workload, frame_bytes, wall * 1e3 / a.steps, 0, False, stage_bytes=sb)
+        roof["rank"] = 0
+        roof["per_rank_stage_ms"] = all_stage
+        roof["note"] = "rank 0's strip; 'gate' includes the all-reduce, 'post' the halo exchange overlapped with the interior stencils"
+        cpu = None
+        if not a.no_cpu_baseline and not multimodal:
+            cpu = cpu_baseline(a, cfg, C, N, clouds_host, weights, R, t)
+        out = {
+            "metric": "Mpoints/s fused (map-update p50 latency in config)", "value": round(N * a.steps / wall / 1e6, 2),
+            "unit": "Mpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(wall * 1e3 / a.steps, 5), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload_text(a, C, N, multimodal) + "; %d row strips, cloud replicated to every rank" % world,
+                       "index_mode": a.mode, "latency_ms": {"p10": round(pct[0], 4), "p50": round(pct[1], 4), "p90": round(pct[2], 4)},
+                       "halo_rows": halo, "parallelism": "row-strips x%d" % world, "ranks": world, "physical_devices": min(ndev, world),
+                       "strip_rows": rows, "strip_heights": "equal ray work (thin around the sensor)" if row_w is not None else "equal",
+                       "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame, RCCL issued by the C library "
+                                      "(halo exchange in place on a second stream); bootstrap: file rendezvous, no torch",
+                       "cloud": "device resident (H2D excluded)"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+    rdv.barrier("done")             # file barrier: the other ranks do not spin on the GPU while rank 0 runs the CPU baseline
+    lib.emap_comm_destroy(ctx)
+    return True, out
 
-    # ---- per-stage device time (hipEvents on the kernel's stream) -> roofline of the dominant kernel ------
-    lib.emap_enable_stage_timing(ctx, 2)
-    acc = np.zeros(10)
-    reps = min(a.steps, 20)
-    st = _lib.EmapStats()
-    visits = 0
-    for i in range(reps):
-        frame(i, ct.byref(st))
-        ms10 = (ct.c_float * 10)()
-        lib.emap_get_stage_times(ctx, ms10)
-        acc += np.array(list(ms10)); visits += st.ray_visits
-    lib.emap_enable_stage_timing(ctx, 0)
-    stage_ms = dict(zip(_lib.STAGES, (acc / reps).tolist()))
-    # an event pair with NOTHING between its records is already ~4.5 us apart on this stack (marker processing); a stage interval
-    # is that spacing + the kernel, so the spacing is calibrated and removed -- the result agrees with rocprofv3's kernel durations
-    empty = []
-    for _ in range(50):
-        e_ms = ct.c_float(0)
-        lib.emap_timer_begin(ctx); lib.emap_timer_end(ctx, ct.byref(e_ms)); empty.append(e_ms.value)
-    ev_overhead = float(np.median(empty))
-    L = C * C
-    dom = max(stage_ms, key=stage_ms.get)
-    dom_bytes = STAGE_BYTES[dom](N, L)
-    dom_ms = max(stage_ms[dom] - ev_overhead, 1e-6)
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    frame_bytes = 12 * N + 56 * L + (16 * N + 32 * L if a.workload == 'cfg5' else 0)   # B_frame of BASELINE.md §5 (K = 0 extra channels, L = 0 semantic layers)
-    # HBM traffic of the dominant kernel: from the committed rocprofv3 PMC passes of this same command
-    # (tools/profile_round.sh -> profiles/pmc_<workload>.json; counters cannot be read from inside the process)
-    traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_%s.json" % a.workload)
-    if os.path.exists(pmc_file) and C == 1024 and N == 1_000_000 and a.mode == "reference_fp16":
-        kern = STAGE_KERNEL[dom]
-        for name, rec in json.load(open(pmc_file))["kernels"].items():
-            if name.startswith(kern):
-                traffic, traffic_src = rec["hbm_bytes"], "profiles/pmc_%s.json (%s)" % (a.workload, name)
-    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes": dom_bytes, "kernel_ms": round(dom_ms, 5), "event_pair_overhead_ms": round(ev_overhead, 5),
-            "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},   # raw event spacings (overhead included)
-            "frame_algorithmic_bytes": frame_bytes,
-            "frame_frac": round(frame_bytes / (ms_dev.value / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "ray_visits_per_frame": int(visits / reps),
-            "ray_visits_per_s": (round(visits / reps / (stage_ms["rays"] * 1e-3) / 1e9, 1) if visits else None), "visits_unit": "G cell visits/s"}
 
-    # ---- CPU baseline: the oracle port, same workload, bounded sample ---------------------------------------
-    cpu = None
-    if not a.no_cpu_baseline and not multimodal:
-        from oracle import emap_oracle as eo
-        n_cpu = a.cpu_points or (N if a.workload == "cfg2" else min(N, 60000))
-        P = eo.make_params(cfg, cell_n=C, mode=a.mode, weights=weights)
-        def cpu_rate(threads):
-            eo.set_threads(threads)
-            om = eo.OracleMap(P)
-            om.frame_c(clouds_host[0][:n_cpu], R, t, 1.0, 1.0)
-            for _ in range(8):
-                om.update_time()
-            reps_cpu, t_cpu = 0, 0.0
-            while reps_cpu < 5 and t_cpu < 8.0:
-                s = time.perf_counter(); om.frame_c(clouds_host[(reps_cpu + 1) % NCLOUD][:n_cpu], R, t, 1.0, 1.0)
-                t_cpu += time.perf_counter() - s; reps_cpu += 1
-            eo.set_threads(1)
-            return n_cpu * reps_cpu / t_cpu / 1e6, reps_cpu
-        def usable_cores():
-            n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            try:  # cgroup v2 CPU quota of the container
-                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-                if q != "max":
-                    n = max(1, min(n, int(float(q) / float(per) + 0.5)))
-            except (OSError, ValueError):
-                pass
-            return n
-        avail = usable_cores()
-        v1, reps_cpu = cpu_rate(1)
-        best_v, best_n = v1, 1
-        for nthr in sorted({min(avail, 8), min(avail, 32), avail} - {1}):    # oversubscription hurts: keep the best setting
-            v, reps_cpu = cpu_rate(nthr)
-            if v > best_v:
-                best_v, best_n = v, nthr
-        cpu = {"value": round(best_v, 4), "unit": "Mpoints/s", "cores": best_n, "kind": "port", "single_thread_value": round(v1, 4),
-               "sample": "<=5 frames (<=8 s) of %d points on the %dx%d map, oracle/emap_oracle.c eo_frame (gcc -O2 -fopenmp); best of "
-                         "1/8/32/%d threads, %d usable cores (os.cpu_count() = %d)" % (n_cpu, C, C, avail, avail, os.cpu_count() or 1)}
-
-        # second CPU line: the reference's OWN kernel source compiled for the host (oracle/_ref, sequential, 1 thread) on a smaller
-        # sample of the same clouds -- error_counting + add_points + average_map + dilation + normal kernels (its traversability
-        # network is PyTorch and not part of that build)
+def run_strips(a, rank, world, local_rank):
+    from elevation_mapping_cupy_amd import launch
+    rdv = launch.FileRendezvous.from_env(rank, world, timeout=900.0)
+    if a.dry_run:                       # launcher / rendezvous plumbing only (CPU test hook)
+        got = rdv.gather_json("dry", {"rank": rank, "pid": os.getpid()})
+        ok = rdv.agree("dry", len(got) == world)
+        rdv.barrier("dry_done")
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": got, "agreed": ok}), flush=True)
+        rdv.finish()
+        return
+    # RCCL prints its version banner on stdout through C stdio: keep fd 1 pointed at stderr until the JSON line is due
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    status, out = False, None
+    try:
+        if os.environ.get("EMAP_COMM", "native") == "native":
+            status, out = run_strips_native(a, rank, world, local_rank, rdv)
+    finally:
         try:
-            from oracle import build_ref, ref_kernels
-            key = {(1024, "cfg2"): "yaml1024_norays", (1024, "cfg3"): "yaml1024", (202, "cfg2"): "yaml202_norays", (202, "cfg3"): "yaml202"}.get((C, a.workload))
-            if key and a.mode == "reference_fp16" and ref_kernels.available(build_ref.PREBUILD[key]):
-                rk = ref_kernels.RefKernels(build_ref.PREBUILD[key], build=False)
-                n_ref = min(N, 200000 if a.workload == "cfg2" else 20000)
-                m_ref = np.zeros((7, C, C), np.float32); m_ref[1] = cfg["initial_variance"]; m_ref[3] = 1
-                nrm_ref = np.zeros((3, C, C), np.float32)
-                Rf = np.ascontiguousarray(R, np.float32).ravel().copy(); tf = np.ascontiguousarray(t, np.float32)
+            ct.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    if status:
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+    else:
+        if rank == 0:
+            print("native RCCL strips unavailable here (fewer devices than ranks, or RCCL failed): torch.distributed fallback", file=sys.stderr)
+        from elevation_mapping_cupy_amd import sharded
+        sharded.bench_main(a, rank, world, local_rank)
+    rdv.finish()
 
-                def ref_frame(k_):
-                    p_ = np.ascontiguousarray(clouds_host[k_ % NCLOUD][:n_ref, :3])
-                    nm_ = np.zeros((7, C, C), np.float32); e_ = np.zeros(1, np.float32); c_ = np.zeros(1, np.float32)
-                    t0_ = time.perf_counter()
-                    rk.error_counting(m_ref, p_, Rf, tf, nm_, e_, c_); rk.add_points(Rf, tf, nrm_ref, p_, m_ref, nm_); rk.average_map(nm_, m_ref)
-                    dil_ = np.zeros((C, C), np.float32); dm_ = np.zeros((C, C), np.float32)
-                    rk.dilation_filter(m_ref[5].copy(), (m_ref[2] + m_ref[6]).copy(), dil_, dm_)
-                    rk.normal_filter(dil_, m_ref[2].copy(), nrm_ref)
-                    return time.perf_counter() - t0_
-                ref_frame(0); m_ref[4] += 1.0
-                t_ref = [ref_frame(1), ref_frame(2)]
-                cpu["reference_kernels"] = {"value": round(n_ref / float(np.mean(t_ref)) / 1e6, 4), "unit": "Mpoints/s", "cores": 1,
-                                            "sample": "2 frames of %d points, the reference's kernel source compiled with g++ -O2 (oracle/build_ref.py)" % n_ref}
-        except Exception as ex:  # noqa: BLE001 - the second line is optional
-            print("reference-kernel CPU line skipped: %s" % ex, file=sys.stderr)
 
-    out = {
-        "metric": "Mpoints/s fused (map-update p50 latency in config)", "value": round(mpts, 2), "unit": "Mpoints/s",
-        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %dx%d map, %d uniform-random points/frame, core_param.yaml values, %s"
-                               % (a.workload, C, C, N, "rays+overlap on" if a.workload == "cfg3" else
-                                  ("height + RGB + 3 semantic layers, fp32 index mode" if multimodal else "add_points + variance fusion, rays/overlap off")),
-                   "index_mode": a.mode, "latency_ms": {"p10": round(p10, 4), "p50": round(p50, 4), "p90": round(p90, 4)},
-                   "device_ms_per_step": round(ms_dev.value / a.steps, 5), "cloud": "device resident (H2D excluded)"},
-        "roofline": roof, "cpu_baseline": cpu,
-    }
-    print(json.dumps(out))
+def launch_ranks(a, argv):
+    """bench.py was started without a launcher: become one (one process per GPU, WORLD_SIZE = --gpus)"""
+    from elevation_mapping_cupy_amd import launch
+    rc, out0 = launch.spawn_ranks(os.path.abspath(__file__), argv, a.gpus, timeout=3000)
+    lines = [l for l in out0.splitlines() if l.strip().startswith("{")]
+    if rc != 0 or not lines:
+        sys.stderr.write(out0)
+        raise SystemExit("bench.py --gpus %d: ranks failed (rc %d)" % (a.gpus, rc))
+    print(lines[-1], flush=True)
+
+
+def main():
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a, argv)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or a.force_sharded or a.dry_run:
+        return run_strips(a, rank, world, local_rank)
+    return run_single(a, local_rank)
 
 
 if __name__ == "__main__":

@@ -112,7 +112,7 @@ struct emap_ctx {
   bool want_ray_stats; bool in_update;
   // row-strip communicator (emap_comm_init): RCCL resolved at run time, exchange on its own stream so that it overlaps the interior stencils
   struct RcclApi* rccl; ncclComm_t comm; int comm_rank, comm_world;
-  hipStream_t comm_stream; hipEvent_t ev_ready, ev_done; double* comm_sums;   // [0..1] local err_sum / err_cnt, [2..3] totals
+  hipStream_t comm_stream; hipEvent_t ev_ready, ev_done; double* comm_sums;   // [0..1] local err_sum / err_cnt, [2..3] totals, [4..36) emap_comm_allreduce_host
   std::string err;
 };
 
@@ -1210,8 +1210,8 @@ int emap_comm_init(emap_ctx* ctx, const char* rccl_path, const uint8_t id[128], 
   CK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
   CK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
-  CK(hipMalloc((void**)&ctx->comm_sums, sizeof(double) * 4));
-  CK(hipMemsetAsync(ctx->comm_sums, 0, sizeof(double) * 4, ctx->stream));
+  CK(hipMalloc((void**)&ctx->comm_sums, sizeof(double) * 36));
+  CK(hipMemsetAsync(ctx->comm_sums, 0, sizeof(double) * 36, ctx->stream));
   return EMAP_OK;
 }
 
@@ -1300,6 +1300,18 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
     for (int i = 0; i < ST_N; ++i) CK(hipEventElapsedTime(&ctx->stage_ms[i], ctx->ev[i], ctx->ev[i + 1]));
   }
   if (stats) return emap_get_stats(ctx, stats);
+  return EMAP_OK;
+}
+
+int emap_comm_allreduce_host(emap_ctx* ctx, double* inout, int32_t n, int32_t op) {
+  CKARG(ctx && ctx->rccl && ctx->comm, "emap_comm_init has not been called");
+  CKARG(inout && n >= 1 && n <= 16 && (op == 0 || op == 1), "bad argument");
+  CK(hipSetDevice(ctx->device));
+  double* buf = ctx->comm_sums + 4;     // [4..20) send, [20..36) receive
+  CK(hipMemcpyAsync(buf, inout, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  CKN(ctx->rccl->AllReduce(buf, buf + 16, (size_t)n, ncclFloat64, op == 0 ? ncclSum : ncclMax, ctx->comm, ctx->stream));
+  CK(hipMemcpyAsync(inout, buf + 16, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
   return EMAP_OK;
 }
 

@@ -169,20 +169,21 @@ class ElevationMap:
         position[0][:] = self.center
 
     def move(self, delta_position):
-        """Relative shift (reference :139-152 -- note the sign convention differs from move_to)."""
-        delta_position = np.asarray(delta_position, np.float32)
-        delta_pixel = np.round(delta_position[:2] / np.float32(self.resolution))
-        self.center[:2] += (delta_pixel * np.float32(self.resolution)).astype(np.float32)
+        """Relative shift (reference :139-152 -- note the sign convention differs from move_to).  The caller's float64 position
+        meets the float32 centre in float64, exactly like the reference's array arithmetic (pinned by tests/golden/host_steps.npz)."""
+        delta_position = np.asarray(delta_position, np.float64)
+        delta_pixel = np.round(delta_position[:2] / self.resolution)
+        self.center[:2] += delta_pixel * self.resolution
         self.center[2] += delta_position[2]
         self._shift(delta_pixel, -float(delta_position[2]))
 
     def move_to(self, position, R):
         """Absolute shift + base rotation update (reference :154-170)."""
         self.base_rotation = np.asarray(R, dtype=np.float32)
-        position = np.asarray(position, np.float32)
+        position = np.asarray(position, np.float64)
         delta = position - self.center
-        delta_pixel = np.around(delta[:2] / np.float32(self.resolution))
-        self.center[:2] += (delta_pixel * np.float32(self.resolution)).astype(np.float32)
+        delta_pixel = np.around(delta[:2] / self.resolution)
+        self.center[:2] += delta_pixel * self.resolution
         self.center[2] += delta[2]
         self._shift(-delta_pixel, -float(delta[2]))
 

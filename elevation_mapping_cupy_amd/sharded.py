@@ -77,7 +77,7 @@ class TorchComm:
         self.device = device  # torch.device or None (CPU)
         # RCCL orders its work after the current HIP stream by itself; gloo with device tensors (test setups with
         # several ranks on one GPU) copies through the host without looking at our stream: drain it first
-        self.host_sync = device is not None and dist.get_backend() == "gloo"
+        self.host_sync = device is not None and "nccl" not in str(dist.get_backend())
 
     def _drain(self):
         if self.host_sync:
@@ -371,7 +371,9 @@ def bench_main(a, rank, world, local_rank):
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
-    local_rank = local_rank % max(1, torch.cuda.device_count())      # more ranks than GPUs only happens in single-GPU test launches
+    n_dev = max(1, torch.cuda.device_count())
+    oversubscribed = world > n_dev          # more ranks than GPUs (single-GPU boxes): ranks share devices, RCCL refuses that => gloo
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if not dist.is_initialized():
@@ -384,7 +386,7 @@ def bench_main(a, rank, world, local_rank):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")       # RCCL's bootstrap sockets too (data moves over xGMI / shared memory)
         try:
-            dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+            dist.init_process_group(backend="gloo" if oversubscribed else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
         except Exception as ex:  # noqa: BLE001
             print("[rank %d] gloo bootstrap unavailable (%s); using nccl only" % (rank, ex), file=sys.stderr)
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
@@ -404,7 +406,7 @@ def bench_main(a, rank, world, local_rank):
     if cfg["enable_visibility_cleanup"] and world > 1 and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
         row_w = ray_balanced_weights(C, float(cfg["resolution"]), float(cfg["max_ray_length"]), halo_rows_needed(cfg["dilation_size"], world), world)
     eng = HipStripEngine(par, rank, world, local_rank, dev, row_w)
-    comm, comm_kind = None, os.environ.get("EMAP_COMM", "native")
+    comm, comm_kind = None, ("torch" if oversubscribed else os.environ.get("EMAP_COMM", "native"))
 
     def all_agree(ok):
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=None if cpu_ok else dev)
@@ -515,7 +517,8 @@ def bench_main(a, rank, world, local_rank):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%d map in %d row strips, %d uniform-random points/frame replicated to every rank, "
                                    "core_param.yaml values" % (a.workload, C, C, world, N),
-                       "index_mode": a.mode, "halo_rows": eng.halo, "parallelism": "row-strips x%d" % world,
+                       "index_mode": a.mode, "halo_rows": eng.halo, "parallelism": "row-strips x%d" % world, "ranks": world,
+                       "physical_devices": min(n_dev, world), "oversubscribed": bool(oversubscribed),
                        "strip_heights": "equal ray work (thin around the sensor)" if row_w is not None else "equal",
                        "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame (RCCL, %s)" %
                                       ("issued by the C library, halo exchange in place on a second stream" if comm_kind == "native"

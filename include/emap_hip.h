@@ -222,6 +222,10 @@ int emap_comm_unique_id(const char* rccl_path, uint8_t id_out[128]);
 int emap_comm_init(emap_ctx* ctx, const char* rccl_path, const uint8_t id[128], int32_t rank, int32_t world);
 int emap_comm_destroy(emap_ctx* ctx);
 int emap_comm_selftest(emap_ctx* ctx);
+/* out-of-band reductions over the ranks through the communicator itself (barriers and timing reductions of a launcher:
+ * no second bootstrap channel needed once RCCL is up): all-reduce of n <= 16 host doubles, op 0 = sum, 1 = max, in place;
+ * blocks until the result is back on the host, i.e. it is also a barrier behind all work enqueued on the strip's stream. */
+int emap_comm_allreduce_host(emap_ctx* ctx, double* inout, int32_t n, int32_t op);
 int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise,
                         emap_stats* stats /* may be NULL: no host synchronisation */);
 

@@ -57,7 +57,7 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) { delete comm; return ncclSuccess;
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "fake rccl error"; }
 
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op, ncclComm_t c, hipStream_t stream) {
-  if (dtype != 8 || op != 0) return ncclInvalidArgument;               // ncclFloat64, ncclSum: all the path uses
+  if (dtype != 8 || (op != 0 && op != 2)) return ncclInvalidArgument;  // ncclFloat64 with ncclSum / ncclMax: all the path uses
   if (hipStreamSynchronize(stream) != hipSuccess) return ncclInternalError;
   Shared* sh = c->sh;
   std::unique_lock<std::mutex> l(sh->m);
@@ -67,7 +67,7 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, int dtype
     std::vector<double> tot(count, 0.0), tmp(count);
     for (int r = 0; r < sh->nranks; ++r) {
       if (hipMemcpy(tmp.data(), sh->ar_src[r], count * 8, hipMemcpyDeviceToHost) != hipSuccess) return ncclInternalError;
-      for (size_t k = 0; k < count; ++k) tot[k] += tmp[k];
+      for (size_t k = 0; k < count; ++k) tot[k] = (op == 0) ? tot[k] + tmp[k] : (r == 0 ? tmp[k] : (tmp[k] > tot[k] ? tmp[k] : tot[k]));
     }
     for (int r = 0; r < sh->nranks; ++r)
       if (hipMemcpy(sh->ar_dst[r], tot.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess) return ncclInternalError;

@@ -27,3 +27,20 @@ def test_bench_json_contract(workload):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and c["unit"] == "Mpoints/s" and c["sample"]
+    if workload == "cfg2":          # the default line also carries the frame WITH the visibility pass, timed in the same process
+        c3 = d["config"]["cfg3"]
+        assert c3["value"] > 0 and c3["ms_per_step"] > 0 and c3["ray_visits_per_frame"] > 0 and c3["dominant_kernel"] in c3["stage_ms"]
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: two rank processes, one JSON line, n_gpus = the ranks that really ran.  With
+    one device the ranks share it (RCCL refuses that: gloo carries the collectives); with two devices the library's RCCL path runs."""
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--cell-n", "202",
+                          "--points", "40000", "--cpu-points", "5000", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["value"] > 0 and d["steps"] == 4
+    assert d["config"]["physical_devices"] in (1, 2)
