@@ -93,6 +93,8 @@ struct emap_ctx {
   int scatter_mode;                // 0 auto, 1 atomic, 2 binned
   int force_sub;                   // test hook: minimum bin height factor (emap_set_scatter_mode bits 8..15)
   bool frame_binned;               // the count stage of the current frame used the binned path
+  bool gate_possible;              // false inside emap_update when the host already knows that the drift gate cannot fire: the per-tile
+                                   // error statistics are then skipped (they could not have any effect; err_sum / err_cnt report 0)
   BinGeo bg; BinTmp* bin_tmp; BinRec* bin_recs; unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;
   // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
   float* img_uv; unsigned char* img_valid; float* img_buf; size_t img_cap;   // camera path
@@ -480,6 +482,7 @@ int emap_set_scatter_mode(emap_ctx* ctx, int32_t mode) {
 
 int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
   CKARG(ctx && R && t, "null argument"); NEED_POINTS();
+  if (!ctx->in_update) ctx->gate_possible = true;          // the staged API always gathers the statistics
   CK(hipSetDevice(ctx->device));
   // small clouds: two launches with global atomics win; large clouds: counting sort by tile + LDS reduction
   const bool binned = ctx->n_pts > 0 && (ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts >= 131072));   // measured crossover on MI355X: 60-135 k points for 202^2 .. 1024^2 maps
@@ -494,7 +497,7 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
     if (tm) CK(hipEventRecord(ctx->ev[ST_SCATTER], ctx->stream));
     launch_bin_scatter(ctx->stream, ctx->kp, ctx->bg, ctx->bin_tmp, ctx->n_pts, ctx->bin_hist, ctx->bin_tile_start, ctx->bin_recs);
     if (tm) CK(hipEventRecord(ctx->ev[ST_GATE], ctx->stream));        // the "gate" stage = per-tile error sums + k_gate
-    launch_tile_count(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->slots);
+    if (ctx->gate_possible) launch_tile_count(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->slots);
   } else {
     if (ctx->stage_timing && ctx->in_update)
       for (int e = ST_HIST; e <= ST_SCATTER; ++e) CK(hipEventRecord(ctx->ev[e], ctx->stream));
@@ -685,6 +688,8 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   int rc;
 #define STAGE(i) do { if (tm) CK(hipEventRecord(ctx->ev[i], ctx->stream)); } while (0)
   ctx->in_update = true;
+  // drift gate of elevation_mapping.py:346-349: with compensation off or both noises below their thresholds it cannot fire
+  ctx->gate_possible = p.enable_drift_compensation && (position_noise > p.position_noise_thresh || orientation_noise > p.orientation_noise_thresh);
   rc = emap_count(ctx, R, t);                 // records ST_HIST / ST_SCAN / ST_SCATTER itself
   ctx->in_update = false;
   if (rc) return rc;            // (emap_count also recorded ST_GATE: the stage starts with the per-tile error sums)
@@ -1264,6 +1269,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   int rc;
 #define STAGE(i) do { if (tm) CK(hipEventRecord(ctx->ev[i], ctx->stream)); } while (0)
   ctx->in_update = true;
+  ctx->gate_possible = p.enable_drift_compensation && (position_noise > p.position_noise_thresh || orientation_noise > p.orientation_noise_thresh);
   rc = emap_count(ctx, R, t);                 // records ST_HIST / ST_SCAN / ST_SCATTER itself
   ctx->in_update = false;
   if (rc) return rc;                          // "gate" (recorded by emap_count) = per-tile error sums + local sums + all-reduce + gate
