@@ -20,7 +20,8 @@ void launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, 
 void launch_gate(hipStream_t, const KP&, ErrSlot*, FrameDev*, int, double, double, float, int, int, double, unsigned int, unsigned int, int, double*, const double*);
 void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, const FrameDev*);
 void launch_commit(hipStream_t, const KP&, Cell*, const AccF*, const FrameDev*, unsigned long long*);
-void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, const Cell*, const AccF*, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*);
+void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, const Cell*, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*, const unsigned int*, int, const float*);
+void launch_ray_apply(hipStream_t, const KP&, Cell*, AccR*);
 void launch_average(hipStream_t, const KP&, Cell*, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*);
 static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
@@ -59,7 +60,7 @@ void launch_bin_scatter(hipStream_t, const KP&, const BinGeo&, const BinTmp*, lo
 void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, const Cell*, ErrSlot*);
 void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const float*, long, int,
                           const unsigned int*, float*, float*, long);
-void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cell*, AccF*, const FrameDev*, bool, unsigned int*);
+void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cell*, AccF*, const FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*);
 #define BIN_MAX_T 16384
 #define BIN_MAX_B 2048
 
@@ -88,7 +89,10 @@ struct emap_ctx {
   float* scratch;                  // one plane (get/set staging)
   ErrSlot* slots; FrameDev* frame;
   RayTab rt; float* ray_S; unsigned short* ray_lut;
-  unsigned long long* inert;       // 1 bit per owned cell, written by k_commit
+  unsigned long long* inert;       // 1 bit per owned cell (rows of ceil(C/64) words), written by k_commit / k_tile_fuse<true, true>
+  unsigned int* inl_plane;         // newmap[3] of frames whose tile kernel commits itself (binned path + visibility pass), on demand
+  float* ray_thr;                  // same frames: per 8 x 8 block height at or above which a ray sample cannot affect any cell of the block
+  bool rays_fused;                 // this frame: the tile kernel committed + averaged, k_ray_apply follows the rays
   // tile-binned scatter buffers (allocated on demand)
   int scatter_mode;                // 0 auto, 1 atomic, 2 binned
   int force_sub;                   // test hook: minimum bin height factor (emap_set_scatter_mode bits 8..15)
@@ -143,7 +147,7 @@ static void build_kp(emap_ctx* ctx) {
   k.q_mrl = h ? q16((float)p.max_ray_length) : (float)p.max_ray_length;
   k.q_step = h ? q16((float)p.ray_step) : (float)p.ray_step;
   k.time_var = (float)p.time_variance; k.time_int = (float)p.time_interval; k.res_f = (float)p.resolution;
-  k.inv_res_f = (float)(1.0 / p.resolution); k.half_w_f = 0.5f * (float)p.cell_n;
+  k.inv_res_f = (float)(1.0 / p.resolution); k.half_w_f = 0.5f * (float)p.cell_n; k.cm1_f = (float)(p.cell_n - 1);
 }
 
 // smallest float >= c (a < c  <=>  a < up(c) for float a) / largest float <= c (a > c <=> a > dn(c))
@@ -177,7 +181,9 @@ static int build_ray_tables(emap_ctx* ctx) {
   std::vector<float> S;
   const float q_mrl = ctx->kp.q_mrl;
   float s = ctx->kp.q_step;
-  while (s < q_mrl && S.size() < 8192u) {   // the table is staged in LDS (<= 32 KB); longer rays are cut like max_ray_length would
+  while (s < q_mrl) {
+    if (S.size() >= 8192u) {                  // the table is staged in LDS (<= 32 KB): refuse instead of silently shortening the rays
+      ctx->err = "max_ray_length / ray_step needs more than 8192 ray samples"; return EMAP_ERR_INVALID; }
     S.push_back(s);
     float nx = (float)((double)s + p.ray_step);
     if (h) nx = q16(nx);
@@ -199,6 +205,19 @@ static int build_ray_tables(emap_ctx* ctx) {
       full[b] = host_axis_idx(p, (float)hf, ctx->kp.q_wm1, true);
     }
     auto at = [&](int sg, int mag) { return full[(sg << 15) | mag]; };
+    {   // AxisIdx<0, 2>: is the float formula exact for every half pattern (NaNs excluded: non-finite samples never march)?
+      bool same = true;
+      const float inv = ctx->kp.inv_res_f, hw = ctx->kp.half_w_f, cm1 = ctx->kp.cm1_f;
+      for (int b = 0; b < 65536 && same; ++b) {
+        if ((b & 0x7fff) > 0x7c00) continue;
+        unsigned short us = (unsigned short)b; _Float16 hf; memcpy(&hf, &us, 2);
+        float v = fmaf((float)hf, inv, hw);
+        v = fminf(fmaxf(v, 0.0f), cm1);
+        if ((int)v != full[b]) same = false;
+      }
+      rt.formula_ok = same ? 1 : 0;
+      if (const char* e = getenv("EMAP_RAY_IDX")) { if (atoi(e) != 2) rt.formula_ok = 0; }     // test / tuning hook: force the table path
+    }
     int lo = 0x7c00, hi = 1;
     for (int sg = 0; sg < 2; ++sg) {
       for (int m = 1; m < 0x7c00; ++m) if (at(sg, m) != at(sg, 1)) { if (m < lo) lo = m; break; }
@@ -268,7 +287,7 @@ int emap_destroy(emap_ctx* ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   hipFree(ctx->cells); hipFree(ctx->cells_alt); hipFree(ctx->acc); hipFree(ctx->accr); hipFree(ctx->trav_in);
   hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->slots); hipFree(ctx->frame); hipFree(ctx->pts_own);
-  hipFree(ctx->pts_f64); hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert);
+  hipFree(ctx->pts_f64); hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert); hipFree(ctx->inl_plane); hipFree(ctx->ray_thr);
   hipFree(ctx->bin_tmp); hipFree(ctx->bin_recs); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start);
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem_alt); hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
@@ -321,7 +340,7 @@ int emap_create(const emap_params* params, const emap_strip* strip, int device, 
   alloc((void**)&ctx->trav_in, sizeof(float) * n); alloc((void**)&ctx->normal, sizeof(float) * 3 * n);
   alloc((void**)&ctx->scratch, sizeof(float) * n); alloc((void**)&ctx->slots, sizeof(ErrSlot) * EM_ERR_SLOTS);
   alloc((void**)&ctx->frame, sizeof(FrameDev));
-  alloc((void**)&ctx->inert, sizeof(unsigned long long) * (((size_t)ctx->strip.row_count * C + 63) / 64 + 1));
+  alloc((void**)&ctx->inert, sizeof(unsigned long long) * ((size_t)ctx->strip.row_count * ((C + 63) / 64) + 1));
   if (rc == EMAP_OK) {
     hipEventCreate(&ctx->t0); hipEventCreate(&ctx->t1);
     for (int i = 0; i <= ST_N; ++i) hipEventCreate(&ctx->ev[i]);
@@ -554,12 +573,17 @@ int emap_local_drift_sums(emap_ctx* ctx, double* err_sum, uint32_t* err_cnt) {
   return EMAP_OK;
 }
 
-static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool fuse_average = false) {
+static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool fuse_average = false, bool rays = false) {
   NEED_POINTS();
   CK(hipSetDevice(ctx->device));
   if (ctx->frame_binned) {
-    launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame, fuse_average,
-                    ctx->cnt_plane);
+    if (fuse_average && rays && !ctx->inl_plane) {
+      CK(hipMalloc((void**)&ctx->inl_plane, sizeof(unsigned int) * ctx->ncells_alloc));
+      CK(hipMemsetAsync(ctx->inl_plane, 0, sizeof(unsigned int) * ctx->ncells_alloc, ctx->stream));
+      CK(hipMalloc((void**)&ctx->ray_thr, sizeof(float) * (size_t)((ctx->strip.row_count + 7) / 8 + 2) * ((ctx->prm.cell_n + 7) / 8)));
+    }
+    launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame, fuse_average, rays,
+                    ctx->cnt_plane, ctx->inert, ctx->inl_plane, ctx->ray_thr);
     CK(hipGetLastError());
     return EMAP_OK;
   }
@@ -592,9 +616,12 @@ int emap_commit(emap_ctx* ctx) {
 int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
   CKARG(ctx && R && t, "null argument"); NEED_POINTS();
   CK(hipSetDevice(ctx->device));
-  CKARG(ctx->committed, "emap_rays needs emap_commit first (rays read snapshot S1)");
-  launch_rays(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->rt, ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->accr,
-              ctx->normal, ctx->ncells_alloc, ctx->frame, ctx->want_ray_stats, ctx->inert);
+  CKARG(ctx->committed || ctx->rays_fused, "emap_rays needs emap_commit first (rays read snapshot S1)");
+  // newmap[3]: the tile kernel's dense plane, or the high halves of AccF::pts_inl (5 x u64 records) on the staged / atomic path
+  const unsigned int* inl = ctx->rays_fused ? ctx->inl_plane : reinterpret_cast<const unsigned int*>(ctx->acc) + 1;
+  launch_rays(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->rt, ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->accr,
+              ctx->normal, ctx->ncells_alloc, ctx->frame, ctx->want_ray_stats, ctx->inert, inl, ctx->rays_fused ? 1 : (int)(sizeof(AccF) / 4),
+              ctx->rays_fused ? ctx->ray_thr : nullptr);
   CK(hipGetLastError());
   return EMAP_OK;
 }
@@ -695,18 +722,23 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   if (rc) return rc;            // (emap_count also recorded ST_GATE: the stage starts with the per-tile error sums)
   if ((rc = emap_set_drift_inputs(ctx, position_noise, orientation_noise, nullptr, nullptr))) return rc;
   STAGE(ST_FUSE);
-  // no visibility pass + binned scatter: fusion, commit and averaging happen in ONE tile kernel
-  const bool fused_avg = ctx->frame_binned && !p.enable_visibility_cleanup;
-  if ((rc = fuse_impl(ctx, R, t, fused_avg))) return rc;
+  // binned scatter: fusion, commit and averaging happen in ONE tile kernel; with the visibility pass it also writes the inert
+  // bitmap and the inlier plane, and the ray effects are applied by k_ray_apply ("average" stage) afterwards
+  const bool fused_avg = ctx->frame_binned;
+  const bool rays_on = p.enable_visibility_cleanup != 0;
+  if ((rc = fuse_impl(ctx, R, t, fused_avg, rays_on))) return rc;
   STAGE(ST_COMMIT);
-  if (p.enable_visibility_cleanup) {
-    if ((rc = emap_commit(ctx))) return rc;
+  ctx->rays_fused = fused_avg && rays_on;
+  if (rays_on) {
+    if (!fused_avg && (rc = emap_commit(ctx))) return rc;
     STAGE(ST_RAYS);
-    if ((rc = emap_rays(ctx, R, t))) return rc;
+    rc = emap_rays(ctx, R, t);
+    if (rc) { ctx->rays_fused = false; return rc; }
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
-  if (!fused_avg) launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, p.enable_visibility_cleanup != 0, ctx->cnt_plane);
-  ctx->committed = false;
+  if (!fused_avg) launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane);
+  else if (rays_on) launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr);
+  ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   STAGE(ST_OVERLAP);
   if (p.enable_overlap_clearance && (rc = emap_overlap_clear(ctx, t[2]))) return rc;
@@ -1278,17 +1310,21 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   CKN(a->AllReduce(ctx->comm_sums, ctx->comm_sums + 2, 2, ncclFloat64, ncclSum, ctx->comm, ctx->stream));   // exchange step 1
   if ((rc = gate_impl(ctx, position_noise, orientation_noise, 0, nullptr, ctx->comm_sums + 2))) return rc;
   STAGE(ST_FUSE);
-  const bool fused_avg = ctx->frame_binned && !p.enable_visibility_cleanup;
-  if ((rc = fuse_impl(ctx, R, t, fused_avg))) return rc;
+  const bool fused_avg = ctx->frame_binned;
+  const bool rays_on = p.enable_visibility_cleanup != 0;
+  if ((rc = fuse_impl(ctx, R, t, fused_avg, rays_on))) return rc;
   STAGE(ST_COMMIT);
-  if (p.enable_visibility_cleanup) {
-    if ((rc = emap_commit(ctx))) return rc;
+  ctx->rays_fused = fused_avg && rays_on;
+  if (rays_on) {
+    if (!fused_avg && (rc = emap_commit(ctx))) return rc;
     STAGE(ST_RAYS);
-    if ((rc = emap_rays(ctx, R, t))) return rc;
+    rc = emap_rays(ctx, R, t);
+    if (rc) { ctx->rays_fused = false; return rc; }
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
-  if (!fused_avg) launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, p.enable_visibility_cleanup != 0, ctx->cnt_plane);
-  ctx->committed = false;
+  if (!fused_avg) launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane);
+  else if (rays_on) launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr);
+  ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   STAGE(ST_OVERLAP);
   if (p.enable_overlap_clearance && (rc = emap_overlap_clear(ctx, t[2]))) return rc;

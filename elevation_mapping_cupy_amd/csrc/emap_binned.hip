@@ -170,13 +170,21 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const B
   }
 }
 
-// AVG = true (no visibility pass this frame): the epilogue commits AND averages the tile in registers and writes the
-// 32-byte cells directly -- the AccF records never leave LDS and the separate k_average pass disappears.
-template <bool AVG>
+// AVG = true (whole frames, emap_update): the epilogue commits AND averages the tile in registers and writes the 32-byte cells
+// directly -- the AccF records never leave LDS and the separate k_commit / k_average passes disappear.  That is also valid in front
+// of the visibility pass (RAYS = true): a cell fused this frame is known and fresh (valid = 1, time = 0), so every ray skips it
+// (custom_kernels.py:236) and its averaged (or reset, :374-377) state is never looked at -- the kernel records it as inert in the
+// bitmap k_rays tests first; a cell that is NOT fused is changed by commit / average only in ways the rays do not read (outlier
+// variance is committed here; the reset of unknown cells touches h, v, valid of cells that already have valid < 0.5).  What the
+// rays additionally need is written here too: the inert bitmap (one wave ballot = one 64-bit word per tile row) and newmap[3],
+// the per-cell drift-inlier counts (`inl_plane`, read only when a ray penetrates a cell).  The ray effects are applied afterwards
+// by k_ray_apply.  AVG = false keeps the staged contract: AccF records for k_commit / k_rays / k_average.
+template <bool AVG, bool RAYS>
 __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const BinRec* __restrict__ recs,
                                                          const unsigned int* __restrict__ tile_start, Cell* __restrict__ cells,
                                                          AccF* __restrict__ acc, const FrameDev* __restrict__ F,
-                                                         unsigned int* __restrict__ cnt_plane) {
+                                                         unsigned int* __restrict__ cnt_plane, unsigned long long* __restrict__ inert,
+                                                         unsigned int* __restrict__ inl_plane, float* __restrict__ thr) {
   constexpr int NC = BIN_TR * BIN_TC;
   __shared__ unsigned int s_pts[NC], s_inl[NC], s_cnt[NC], s_out[NC];
   __shared__ unsigned long long s_h[NC], s_v[NC], s_latest[NC];
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
       const unsigned int lcb = r.lc_inl & 0x7fffffffu;
       if ((lcb >> 10) != sel) continue;
       atomicAdd(&s_pts[lcb & 1023u], 1u);
-      if (!AVG && drift_inlier(P, s_cell[lcb & 1023u], r.z)) atomicAdd(&s_inl[lcb & 1023u], 1u);   // newmap[3]: only the ray pass reads it
+      if ((!AVG || RAYS) && drift_inlier(P, s_cell[lcb & 1023u], r.z)) atomicAdd(&s_inl[lcb & 1023u], 1u);   // newmap[3]: only the ray pass reads it
     }
     __syncthreads();
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += TF_BLOCK) {          // pass 2: custom_kernels.py:160-197
@@ -223,11 +231,13 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
       atomicMax(&s_latest[lc], ((unsigned long long)(r.i + 1u) << 32) | (unsigned long long)__float_as_uint(new_h));
     }
     __syncthreads();
-    if (col < P.C) {
-#pragma unroll
-      for (int k = 0; k < BIN_TR / (TF_BLOCK / 64); ++k) {
-        const int tr = wv + (TF_BLOCK / 64) * k, lrow = row_base + tr;
-        if (lrow >= P.nrows) break;
+    {
+      static_assert(BIN_TR == TF_BLOCK / 64, "one wave per tile row");
+      const int tr = wv, lrow = row_base + tr;
+      const bool live = col < P.C && lrow < P.nrows;
+      bool quiet = false;
+      float visit_thr = -INFINITY;        // a ray sample at or above this height cannot affect the cell (k_rays' block filter)
+      if (live) {
         const int lc = tr * BIN_TC + tc;
         AccF a;
         a.pts_inl = (unsigned long long)s_pts[lc] | ((unsigned long long)s_inl[lc] << 32);
@@ -238,10 +248,35 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
           Cell m = cells[c];
           m.h += shift;
           commit_cell(P, m, a);
+          quiet = (!(m.valid < 0.5f) && m.time < 0.5f) || border_cell(P, lrow + P.row0, col);   // snapshot S1 (what the rays are defined on); border cells: see k_commit
+          // unknown cell: acts only while nz < upper_bound (or no bound yet, :229); known stale cell: the penetration test (:239)
+          // h > nz + 0.01 - min(v, 1) * 0.05 implies nz < h + 0.04
+          if (RAYS && !quiet) visit_thr = m.valid < 0.5f ? ((m.is_upper < 0.5f || !(m.upper <= 3.0e38f)) ? INFINITY : m.upper) : m.h + 0.05f;
+          if (RAYS && !(visit_thr >= -INFINITY)) visit_thr = INFINITY;                          // NaN heights: never filter
           average_cell(P, m, a);
           cells[c] = m;
           if (cnt_plane) cnt_plane[c] = s_cnt[lc];
+          if (RAYS) inl_plane[c] = s_inl[lc];
         } else acc[c] = a;
+      }
+      if (AVG && RAYS) {                                       // every wave of the workgroup gets here (no early exit above)
+        if (lrow < P.nrows) {                                  // wave-uniform condition: the ballot sees the whole row segment
+          const unsigned long long bits = __ballot(quiet);
+          if (tc == 0) inert[(long)lrow * ((P.C + 63) / 64) + tx] = bits;
+        }
+        // block thresholds: max over 8 columns (lanes) and 8 rows (waves) through the ordered-uint image of the float
+        unsigned int* s_thr = s_pts;                           // the counters are dead by now: 2 block rows x 8 block columns
+        __syncthreads();
+        if (threadIdx.x < 16) s_thr[threadIdx.x] = 0u;         // float_ord(x) > 0 for every x
+        __syncthreads();
+        unsigned int o = float_ord(visit_thr);
+        o = max(o, (unsigned int)__shfl_xor((int)o, 1, 64)); o = max(o, (unsigned int)__shfl_xor((int)o, 2, 64)); o = max(o, (unsigned int)__shfl_xor((int)o, 4, 64));
+        if ((tc & 7) == 0) atomicMax(&s_thr[(tr >> 3) * 8 + (tc >> 3)], o);
+        __syncthreads();
+        if (threadIdx.x < 16) {
+          const int br = (row_base >> 3) + (threadIdx.x >> 3), bc = tx * 8 + (threadIdx.x & 7);
+          if (br * 8 < P.nrows && bc * 8 < P.C) thr[(long)br * ((P.C + 7) >> 3) + bc] = ord_float(s_thr[threadIdx.x]);
+        }
       }
     }
   }
@@ -290,10 +325,14 @@ void launch_tile_count(hipStream_t s, const KP& P, const BinGeo& G, const BinRec
   static_assert(TF_BLOCK == BIN_TR * BIN_TC, "one thread per cell of a tile");
   hipLaunchKernelGGL(k_tile_count, dim3(G.T, G.sub), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, slots);
 }
+// fuse_average: commit + average in the tile kernel (whole frames); rays: the visibility pass follows (bitmap + inlier plane wanted)
 void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cell* cells,
-                     AccF* acc, const FrameDev* F, bool fuse_average, unsigned int* cnt_plane) {
-  if (fuse_average) hipLaunchKernelGGL(k_tile_fuse<true>, dim3(G.T, G.sub), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
-  else hipLaunchKernelGGL(k_tile_fuse<false>, dim3(G.T, G.sub), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane);
+                     AccF* acc, const FrameDev* F, bool fuse_average, bool rays, unsigned int* cnt_plane, unsigned long long* inert,
+                     unsigned int* inl_plane, float* thr) {
+  const dim3 g(G.T, G.sub), b(TF_BLOCK);
+  if (fuse_average && rays) hipLaunchKernelGGL((k_tile_fuse<true, true>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr);
+  else if (fuse_average) hipLaunchKernelGGL((k_tile_fuse<true, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr);
+  else hipLaunchKernelGGL((k_tile_fuse<false, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr);
 }
 
 // ---------------------------------------------------------------------------------------------------------

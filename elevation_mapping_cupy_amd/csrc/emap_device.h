@@ -57,7 +57,7 @@ struct KP {
   int C, mode, row0, nrows, halo, edge, dil, pad0;
   double res, half_w, snf, mt, ov, dcvi_half, trav_inlier, wall, mrl, cs, cos_thresh, mvd2, mhr, ra, rb, rc;
   double max_var, ray_step;
-  float init_var, ov_f, q_wm1, q_mrl, q_step, time_var, time_int, res_f, inv_res_f, half_w_f;
+  float init_var, ov_f, q_wm1, q_mrl, q_step, time_var, time_int, res_f, inv_res_f, half_w_f, cm1_f, pad1;
 };
 
 // host-built tables of the visibility pass (emap_api.hip: build_ray_tables)
@@ -65,6 +65,7 @@ struct RayTab {
   const float* S; int nS;                   // s_k = Q(s_{k-1} + ray_step), all k with s_k < Q(max_ray_length)
   const unsigned short* lut; int lo, hi;    // reference_fp16: cell index by half bit pattern, magnitudes [lo, hi), 2 signs
   int small_pos, small_neg, big_pos, big_neg, nan_val;
+  int formula_ok, pad_;                     // reference_fp16: trunc(clamp(fma(q, 1/res, C/2))) proven equal to the table for every half pattern
   float f_d_thresh, f_cos_thresh, f_wall;   // float thresholds equivalent to the reference's double comparisons
 };
 
@@ -128,6 +129,9 @@ template <int MODE> __device__ __forceinline__ Geo geometry(const KP& P, const P
   g.inside = !(g.ix == 0 || g.ix == P.C - 1 || g.iy == 0 || g.iy == P.C - 1);  // is_inside :34-44
   return g;
 }
+
+// !is_inside (custom_kernels.py:34-44): first / last row or column of the map
+__device__ __forceinline__ bool border_cell(const KP& P, int gr, int col) { return gr <= 0 || gr >= P.C - 1 || col <= 0 || col >= P.C - 1; }
 
 // local cell index of global (ix, iy) inside this strip, or -1 if the row is not owned
 __device__ __forceinline__ long owned_cell(const KP& P, int ix, int iy) {

@@ -119,25 +119,27 @@ __global__ __launch_bounds__(EM_BLOCK) void k_fuse(KP P, Pose T, const float* __
   atomicMax(&acc[c].latest, lt);
 }
 
-// Phase B': materialise S1 (only launched when the visibility pass runs; otherwise folded into k_average)
+// Phase B': materialise S1 (only launched on the staged / global-atomic path; the tile kernel k_tile_fuse<true, true> commits itself)
 // Also emits the "inert" bitmap (1 bit per owned cell: known AND updated recently).  A ray step on such a cell cannot
 // have any effect (custom_kernels.py:228-237), so k_rays tests the bit (128 KB for a 1024^2 map, cache resident)
-// instead of gathering the 32-byte cell.
-__global__ __launch_bounds__(EM_BLOCK) void k_commit(KP P, Cell* __restrict__ cells, const AccF* __restrict__ acc,
-                                                      const FrameDev* __restrict__ F, unsigned long long* __restrict__ inert) {
-  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+// instead of gathering the 32-byte cell.  Border cells (is_inside false, :34-44 -- rays never act there) are marked inert too, which
+// is how k_rays implements `if (!is_inside(nidx)) continue` (:211) without a test of its own.  Layout: one row of ceil(C / 64) 64-bit words per map row (a 64-column tile segment of a
+// row is exactly one word, so the tile kernel can store a wave ballot); grid: x = 64-column groups, y = rows, one wave per word.
+__global__ __launch_bounds__(64) void k_commit(KP P, Cell* __restrict__ cells, const AccF* __restrict__ acc,
+                                               const FrameDev* __restrict__ F, unsigned long long* __restrict__ inert) {
+  const int lrow = blockIdx.y, col = blockIdx.x * 64 + threadIdx.x;
   bool quiet = false;
-  if (li < (long)P.nrows * P.C) {
-    long c = li + (long)P.halo * P.C;
+  if (col < P.C) {
+    const long c = (long)(lrow + P.halo) * P.C + col;
     Cell m = cells[c];
     AccF a = acc[c];
     m.h += F->shift;
     commit_cell(P, m, a);
     cells[c] = m;
-    quiet = !(m.valid < 0.5f) && m.time < 0.5f;
+    quiet = (!(m.valid < 0.5f) && m.time < 0.5f) || border_cell(P, lrow + P.row0, col);
   }
-  unsigned long long bits = __ballot(quiet);
-  if ((threadIdx.x & 63) == 0 && li < (long)P.nrows * P.C) inert[li >> 6] = bits;
+  const unsigned long long bits = __ballot(quiet);
+  if (threadIdx.x == 0) inert[(long)lrow * gridDim.x + blockIdx.x] = bits;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -159,63 +161,91 @@ __device__ __forceinline__ void ray_upper_min(unsigned int* key_ptr, float nz) {
   if (__builtin_nontemporal_load(key_ptr) < key) atomicMax(key_ptr, key);
 }
 
-template <int MODE, bool LUT> struct IdxLut {
-  const unsigned short* t; unsigned int lo_m1, hi, span;   // per sign: [small, idx(lo..hi-1), big]
-  __device__ __forceinline__ int operator()(const KP& P, float q) const {
-    if constexpr (!LUT) return axis_idx<MODE>(P, q);
-    else {   // branch-free: clamp the magnitude into the tabulated range (sentinels hold the constant tails)
-      // (-0.0 would select the negative tail: the host canonicalises t, the only way a sample coordinate becomes -0.0)
-      const unsigned int b = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)q);
-      const unsigned int mag = b & 0x7fffu, sg = b >> 15;
+// Cell index of a sample coordinate along one axis.  IDX selects how:
+//   0  the defining arithmetic (axis_idx: the reference's fp64 expression in reference_fp16 mode)
+//   1  reference_fp16 only: host-built table over the half bit pattern, staged in LDS (exact by construction)
+//   2  reference_fp16 only: one float fma + clamp + truncation on the half-rounded coordinate -- the host proves it equal to the
+//      defining arithmetic for EVERY half bit pattern before selecting it (emap_api.hip: build_ray_tables), 5 VALU, no LDS
+template <int MODE, int IDX> struct AxisIdx {
+  const unsigned short* t; unsigned int lo_m1, hi, span;   // IDX 1: per sign [small, idx(lo..hi-1), big]
+  __device__ __forceinline__ int operator()(const KP& P, float x) const {
+    if constexpr (IDX == 1) {   // branch-free: clamp the magnitude into the tabulated range (sentinels hold the constant tails)
+      const unsigned int b = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)x);
+      const unsigned int mag = b & 0x7fffu, sg = b > 0x8000u;          // -0.0 indexes like +0.0 (get_idx(-0.0) == get_idx(0.0))
       const unsigned int m = min(max(mag, lo_m1), hi) - lo_m1;
       return (int)t[(sg ? span : 0u) + m];
-    }
+    } else if constexpr (IDX == 2) {
+      const float q = (float)(_Float16)x;
+      const float v = __builtin_amdgcn_fmed3f(__builtin_fmaf(q, P.inv_res_f, P.half_w_f), 0.0f, P.cm1_f);
+      return (int)v;
+    } else return axis_idx<MODE>(P, Qf<MODE>(x));
   }
 };
 
-template <int MODE, bool STATS, bool LUT, int BLOCK>
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// The march.  All lanes of a wave walk the SAME step index k (the step sequence s_k does not depend on the ray), so s_k is a
+// scalar load and the loop counter lives in SGPRs; a lane takes part while k is inside its own range [kb, ke): ke = number of
+// samples with s_k < ray_length (binary search once per ray instead of a compare + break per step), kb > 0 only on row strips.
+// Per step and lane: 4 VALU for the sample position, the two axis indices, one mad for the flat index, the same-cell / inside /
+// range predicate, one bitmap bit; everything else happens only for the few cells that are neither known-and-fresh nor out.
+template <int MODE, bool STATS, int IDX, bool STRIP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const float* __restrict__ pts, long n, int stride,
-                                                 const Cell* __restrict__ cells, const AccF* __restrict__ acc,
+                                                 const Cell* __restrict__ cells,
                                                  AccR* __restrict__ accr, const float* __restrict__ normal,
                                                  long plane_stride, FrameDev* __restrict__ F,
-                                                 const unsigned long long* __restrict__ inert64) {
+                                                 const unsigned long long* __restrict__ inert64,
+                                                 const unsigned int* __restrict__ inl, int inl_stride, const float* __restrict__ thr) {
   const unsigned int* __restrict__ inert = reinterpret_cast<const unsigned int*>(inert64);   // 32-bit words: cheaper shifts
+  const unsigned int wpr32 = (unsigned int)((P.C + 63) / 64) * 2u;                           // 32-bit words per bitmap row
+  // LDS words: [table (span)] [s_k (nS)] [queues (BLOCK/64 * 384)]
   extern __shared__ unsigned int slut32[];
-  const unsigned int span = LUT ? (unsigned int)(Rt.hi - Rt.lo) + 2u : 0u;
-  float* sS = reinterpret_cast<float*>(slut32 + span);          // step table s_k staged in LDS (wave-uniform reads)
+  const unsigned int span = IDX == 1 ? (unsigned int)(Rt.hi - Rt.lo) + 2u : 0u;
+  float* sS = reinterpret_cast<float*>(slut32 + span);          // step table s_k in LDS for the per-ray binary searches
   const int nS = Rt.nS;
-  if (LUT) {
+  if (IDX == 1) {
     const unsigned int* src = reinterpret_cast<const unsigned int*>(Rt.lut);   // 2 signs * span u16 = span u32
     for (unsigned int k = threadIdx.x; k < span; k += BLOCK) slut32[k] = src[k];
   }
   for (int k = threadIdx.x; k < nS; k += BLOCK) sS[k] = Rt.S[k];
+  unsigned int* qbase = reinterpret_cast<unsigned int*>(sS + nS);                 // per-wave visit queues: 3 x 128 words each
   __syncthreads();
-  IdxLut<MODE, LUT> lut{reinterpret_cast<const unsigned short*>(slut32), (unsigned int)Rt.lo - 1u, (unsigned int)Rt.hi, span};
-  long i = (long)blockIdx.x * BLOCK + threadIdx.x;
-  unsigned long long visits = 0;
+  AxisIdx<MODE, IDX> aidx{reinterpret_cast<const unsigned short*>(slut32), (unsigned int)Rt.lo - 1u, (unsigned int)Rt.hi, span};
+  const long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+  const int C = P.C;
+  float gx = 0.f, gy = 0.f, gz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f, dec = 0.f;
+  int kb = 0x7fffffff, ke = 0;                       // empty range: lanes without a (valid) ray never take part
   if (i < n) {
     float rx_, ry_, rz_;
     load_point(pts, i, stride, rx_, ry_, rz_);
     Geo g = geometry<MODE>(P, T, rx_, ry_, rz_);
     // invalid points march but never act (:226); non-finite geometry is undefined in the reference and skipped here
     if (g.finite && g.valid && fabsf(g.x) < INFINITY && fabsf(g.y) < INFINITY && fabsf(g.z) < INFINITY) {
+      gx = g.x; gy = g.y; gz = g.z;
       // ray_vector (:83-101): every intermediate is a float16 variable in the reference
       float px = Qf<MODE>(g.x), py = Qf<MODE>(g.y), pz = Qf<MODE>(g.z);
       float vx = Qf<MODE>(px - T.tq[0]), vy = Qf<MODE>(py - T.tq[1]), vz = Qf<MODE>(pz - T.tq[2]);
       float norm = Qf<MODE>(sqrtf(vx * vx + vy * vy + vz * vz));
-      float rx = 0.f, ry = 0.f, rz = 0.f;
       if (norm > 0.f) { rx = Qf<MODE>(vx / norm); ry = Qf<MODE>(vy / norm); rz = Qf<MODE>(vz / norm); }
-      float ray_length = fminf(norm, P.q_mrl);
-      const float dec = (float)(-P.cs / ((double)ray_length / P.mrl));
-      const int C = P.C;
-      const unsigned int halo_cells = (unsigned int)P.halo * (unsigned int)C, row0_cells = (unsigned int)P.row0 * (unsigned int)C;
-      int last = -1;
+      const float ray_length = fminf(norm, P.q_mrl);
+      dec = (float)(-P.cs / ((double)ray_length / P.mrl));
+      int lo = 0, hi = nS;                                      // ke = first k with !(s_k < ray_length); s_k is strictly increasing
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (sS[mid] < ray_length) lo = mid + 1; else hi = mid; }
+      kb = 0; ke = lo;
       // Row strips: the rows of a strip are a band in x, and x(s) is monotone along a ray, so the samples that can land in owned
       // rows form one contiguous range of the step table.  March only that range (band widened by 2 cells: more than the
       // float16 rounding of the sample position can move a cell, and it lets the same-cell test warm up before the first
       // owned row exactly as in the full march); the per-sample ownership test stays.
-      int k_begin = 0, k_end = nS;
-      if (P.nrows < C) {
+      if (STRIP) {
         const float xlo = (float)(((double)(P.row0 - 2) - P.half_w) * P.res), xhi = (float)(((double)(P.row0 + P.nrows + 2) - P.half_w) * P.res);
         float s_lo = -INFINITY, s_hi = INFINITY;
         if (fabsf(rx) > 1e-6f) {
@@ -223,54 +253,110 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
           s_lo = fminf(a, b); s_hi = fmaxf(a, b);
         } else if (T.t[0] < xlo || T.t[0] > xhi) s_hi = -INFINITY;
         s_lo -= 2.0f * P.q_step; s_hi += 2.0f * P.q_step;
-        int lo = 0, hi = nS;                                    // first k with S[k] >= s_lo
+        lo = 0; hi = nS;                                        // first k with S[k] >= s_lo
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (sS[mid] < s_lo) lo = mid + 1; else hi = mid; }
-        k_begin = lo;
+        kb = lo;
         hi = nS;                                                // first k with S[k] > s_hi
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (sS[mid] <= s_hi) lo = mid + 1; else hi = mid; }
-        k_end = lo;
-      }
-      float s = k_begin < k_end ? sS[k_begin] : INFINITY;
-      for (int k = k_begin; k < k_end; ++k) {
-        const float s_next = sS[k + 1 < nS ? k + 1 : k];      // prefetch: no dependent LDS wait at the loop head
-        if (!(s < ray_length)) break;
-        float nx = T.t[0] + rx * s, ny = T.t[1] + ry * s, nz = T.t[2] + rz * s;
-        s = s_next;
-        const int ix = lut(P, Qf<MODE>(nx)), iy = lut(P, Qf<MODE>(ny));
-        const int nidx = C * ix + iy;
-        const unsigned int lr = (unsigned int)(ix - P.row0);
-        // one predicate, one branch: new cell (:209-210) & inside (:211) & owned by this strip
-        const bool act = (nidx != last) & ((unsigned int)(ix - 1) < (unsigned int)(C - 2)) &
-                         ((unsigned int)(iy - 1) < (unsigned int)(C - 2)) & (lr < (unsigned int)P.nrows);
-        last = nidx;
-        if (!act) continue;
-        const unsigned int li = (unsigned int)nidx - row0_cells;              // < 2^31 cells
-        const unsigned int c = li + halo_cells;
-        if (STATS) visits++;
-        if ((inert[li >> 5] >> (li & 31u)) & 1u) continue;     // known + fresh cell: nothing can happen
-        const float4* cp = reinterpret_cast<const float4*>(&cells[c]);
-        float4 m0 = cp[0], m1 = cp[1];             // h v valid trav | time upper is_upper pad
-        float ddx = g.x - nx, ddy = g.y - ny, ddz = g.z - nz;
-        float d = Qf<MODE>(ddx * ddx + ddy * ddy + ddz * ddz);
-        if (d < Rt.f_d_thresh) continue;           // (double)d < 0.1  (:225-226)
-        if (m0.z < 0.5f) {                         // unknown cell: upper bound (:228-234)
-          if (nz < m1.y || m1.z < 0.5f) ray_upper_min(&accr[c].upper_key, nz);
-          continue;
-        }
-        if (m1.x < 0.5f) continue;                 // updated recently (:236)
-        if ((double)m0.x > (double)nz + 0.01 - fmin((double)m0.y, 1.0) * 0.05) {
-          float ip = rx * Qf<MODE>(normal[c]) + ry * Qf<MODE>(normal[plane_stride + c]) + rz * Qf<MODE>(normal[2 * plane_stride + c]);
-          if (fabsf(ip) < Rt.f_cos_thresh) continue;
-          float n_inl = (float)(unsigned int)(acc[c].pts_inl >> 32);
-          if (n_inl > Rt.f_wall && m1.x < 1.0f) continue;
-          atomicAdd(reinterpret_cast<unsigned long long*>(&accr[c].dec),
-                    (unsigned long long)__double2ll_rn((double)dec * EM_SCALE_V));
-          atomicAdd(&accr[c].hits, 1u);
-          if (nz < m1.y || m1.z < 0.5f) ray_upper_min(&accr[c].upper_key, nz);
-        }
+        ke = min(ke, lo);
+        if (ke <= kb) { kb = 0x7fffffff; ke = 0; }
       }
     }
   }
+  const int wb = __builtin_amdgcn_readfirstlane(wave_min_i(kb)), we = __builtin_amdgcn_readfirstlane(wave_max_i(ke));   // SGPRs
+  const float* __restrict__ Sg = Rt.S;
+  unsigned long long visits = 0;
+  int last = -1;
+  // Deferred cell work.  Only a few percent of the visits need the cell at all (it is neither known-and-fresh nor next to the
+  // ray's end point), but with 64 unrelated rays per wave almost every step has ONE such lane, and its dependent loads (cell ->
+  // normals -> inlier count) then stall the whole wave for a memory round trip per step.  The march therefore only QUEUES those
+  // visits (cell, step s, lane of the ray) in a per-wave LDS stack; whenever 64 are waiting, the wave works them off with all lanes
+  // busy -- lane j takes visit j and fetches the ray's direction and decrement from the owning lane's registers (ds_bpermute).
+  // Results are unchanged: every effect is an order-independent accumulator update.
+  constexpr int QCAP = 128;
+  unsigned int* qc = qbase + (threadIdx.x >> 6) * (3 * QCAP);
+  float* qz = reinterpret_cast<float*>(qc + QCAP);
+  unsigned int* ql = qc + 2 * QCAP;
+  const int lane = threadIdx.x & 63;
+  int qn = 0;                                   // wave-uniform number of queued visits
+  auto work = [&](int first, int count) {       // visits [first, first + count), count <= 64; executed by the whole wave
+    const bool has = lane < count;
+    const unsigned int xy = has ? qc[first + lane] : 0u;
+    const unsigned int lrow = (xy >> 16) - (unsigned int)P.row0, col = xy & 0xffffu;             // owned row of the strip, column
+    const unsigned int c = (lrow + (unsigned int)P.halo) * (unsigned int)C + col;
+    const float s = has ? qz[first + lane] : 0.f;
+    const int src = has ? (int)ql[first + lane] : lane;
+    const float erx = __shfl(rx, src, 64), ery = __shfl(ry, src, 64), erz = __shfl(rz, src, 64), edec = __shfl(dec, src, 64);
+    const float egx = __shfl(gx, src, 64), egy = __shfl(gy, src, 64), egz = __shfl(gz, src, 64);
+    if (!has) return;
+    const float nx = T.t[0] + erx * s, ny = T.t[1] + ery * s, nz = T.t[2] + erz * s;     // the sample, recomputed bit for bit
+    const float ddx = egx - nx, ddy = egy - ny, ddz = egz - nz;
+    const float d = Qf<MODE>(ddx * ddx + ddy * ddy + ddz * ddz);
+    if (d < Rt.f_d_thresh) return;             // (double)d < 0.1: too close to the point (:225-226)
+    // Block threshold (written by k_tile_fuse<true, true>): no cell of this 8 x 8 block can be affected by a sample at or above it
+    // (unknown cells: their upper bound; known stale cells: height + 0.05 > every nz that passes the penetration test).  A random
+    // 32-byte cell costs a 128-byte line across the fabric -- 1.4 GB per frame before this filter; the table is 64 KB and L2 resident.
+    if (thr && nz >= thr[(lrow >> 3) * (unsigned int)((C + 7) >> 3) + (col >> 3)]) return;
+    const float4* cp = reinterpret_cast<const float4*>(&cells[c]);
+    const float4 m0 = cp[0], m1 = cp[1];       // h v valid trav | time upper is_upper pad
+    if (m0.z < 0.5f) {                         // unknown cell: upper bound (:228-234)
+      if (nz < m1.y || m1.z < 0.5f) ray_upper_min(&accr[c].upper_key, nz);
+      return;
+    }
+    if (m1.x < 0.5f) return;                   // updated recently (:236)
+    if ((double)m0.x > (double)nz + 0.01 - fmin((double)m0.y, 1.0) * 0.05) {
+      const float ip = erx * Qf<MODE>(normal[c]) + ery * Qf<MODE>(normal[plane_stride + c]) + erz * Qf<MODE>(normal[2 * plane_stride + c]);
+      if (fabsf(ip) < Rt.f_cos_thresh) return;
+      const float n_inl = (float)inl[(long)c * inl_stride];      // newmap[3]: drift inliers of this frame in the cell
+      if (n_inl > Rt.f_wall && m1.x < 1.0f) return;
+      atomicAdd(reinterpret_cast<unsigned long long*>(&accr[c].dec), (unsigned long long)__double2ll_rn((double)edec * EM_SCALE_V));
+      atomicAdd(&accr[c].hits, 1u);
+      if (nz < m1.y || m1.z < 0.5f) ray_upper_min(&accr[c].upper_key, nz);
+    }
+  };
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f txy = {T.t[0], T.t[1]}, rxy = {rx, ry};
+  for (int k0 = wb; k0 < we; k0 += 64) {
+   const float vS = Sg[min(k0 + lane, nS - 1)];                // the next 64 steps, one per lane: s_k comes out of a register below
+   const int kn = __builtin_amdgcn_readfirstlane(min(64, we - k0));     // wave-uniform (SGPR)
+   for (int j = 0; j < kn; ++j) {
+    const int k = k0 + j;
+    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vS), j));    // wave-uniform
+    const v2f nxy = txy + rxy * s;                              // x, y of the sample (its height is only needed for queued visits)
+    const int ix = aidx(P, nxy.x), iy = aidx(P, nxy.y);
+    const int nidx = (int)(__umul24((unsigned int)ix, (unsigned int)C) + (unsigned int)iy);     // clamped to [0, cell_n - 1], cell_n <= 46340: 24-bit operands
+    // own sample & new cell (:209-210) [& owned by this strip]; border cells (:211) read as inert in the bitmap
+    // (measured: fetching the bitmap word unconditionally -- branch free -- is 10 % slower than this guarded form)
+    bool act;
+    if (STRIP) {
+      const bool mine = (unsigned int)(k - kb) < (unsigned int)(ke - kb);
+      act = mine & (nidx != last) & ((unsigned int)(ix - P.row0) < (unsigned int)P.nrows);
+      last = mine ? nidx : last;
+    } else {
+      act = (k < ke) & (nidx != last);                          // (a lane beyond its last sample never acts again: `last` may run on)
+      last = nidx;
+    }
+    bool need = false;
+    if (act) {
+      if (STATS) visits += (max((unsigned int)(ix - 1), (unsigned int)(iy - 1)) < (unsigned int)(C - 2)) ? 1u : 0u;
+      const unsigned int off = __umul24((unsigned int)(STRIP ? ix - P.row0 : ix), wpr32 * 4u) + (((unsigned int)iy >> 3) & ~3u);   // byte offset of the word
+      const unsigned int w = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(inert) + off);
+      need = __builtin_amdgcn_ubfe(w, (unsigned int)iy, 1u) == 0u;     // bit iy & 31 clear: not (known + fresh), something may happen
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(need);
+    if (mask) {                                                 // wave-uniform
+      if (need) {
+        const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+        qc[pos] = ((unsigned int)ix << 16) | (unsigned int)iy; qz[pos] = s; ql[pos] = (unsigned int)lane;      // cell_n <= 46340: 16 bits each
+      }
+      qn += __popcll(mask);
+      __builtin_amdgcn_wave_barrier();
+      if (qn >= 64) { qn -= 64; work(qn, 64); __builtin_amdgcn_wave_barrier(); }
+    }
+   }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (qn > 0) work(0, qn);
   if (STATS) {
     visits = (unsigned long long)wave_sum_ll((long long)visits);
     if ((threadIdx.x & 63) == 0 && visits) atomicAdd(&F->ray_visits, visits);
@@ -302,6 +388,25 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cell* __restrict__ c
   average_cell(P, m, a);
   cells[c] = m;
   if (a.pts_inl | a.cnt_out) { AccF z = {0ull, 0ull, 0ll, 0ll, 0ull}; acc[c] = z; }
+}
+
+// Applies the effects of the visibility pass when the tile kernel has already committed AND averaged the frame (binned path):
+// only cells that are not fused this frame can carry ray effects (a fused cell is known and fresh: every ray skips it), so this is
+// a 16-byte stream over the ray accumulators with a read-modify-write of the few touched cells: validity decrement + variance
+// inflation (custom_kernels.py:251-252), upper bound (:230-233, :254-255), then average_map_kernel's reset of cells whose
+// validity fell below 0.5 (:380-384); re-arms the accumulators.
+__global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cell* __restrict__ cells, AccR* __restrict__ accr) {
+  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (li >= (long)P.nrows * P.C) return;
+  long c = li + (long)P.halo * P.C;
+  const AccR r = accr[c];
+  if (!(r.hits | r.upper_key)) return;
+  Cell m = cells[c];
+  if (r.hits) { m.valid = m.valid + (float)((double)r.dec / EM_SCALE_V); m.v = m.v + P.ov_f * (float)r.hits; }
+  if (r.upper_key) { m.upper = ord_float(~r.upper_key); m.is_upper = 1.0f; }
+  if (m.valid < 0.5f) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; }
+  cells[c] = m;
+  AccR z = {0, 0u, 0u}; accr[c] = z;
 }
 
 // clear_overlap_map (elevation_mapping.py:393-410): centred window, one launch instead of ~12
@@ -723,32 +828,53 @@ void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, lo
   else hipLaunchKernelGGL(k_fuse<1>, g, b, 0, s, P, T, pts, n, stride, cells, acc, F);
 }
 void launch_commit(hipStream_t s, const KP& P, Cell* cells, const AccF* acc, const FrameDev* F, unsigned long long* inert) {
-  hipLaunchKernelGGL(k_commit, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, acc, F, inert);
+  hipLaunchKernelGGL(k_commit, dim3((P.C + 63) / 64, P.nrows), dim3(64), 0, s, P, cells, acc, F, inert);
 }
-#define RAY_BLOCK_LUT 1024
+void launch_ray_apply(hipStream_t s, const KP& P, Cell* cells, AccR* accr) {
+  hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr);
+}
+#define RAY_BLOCK 1024
+template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
+                                                                              long n, int stride, const Cell* cells, AccR* accr,
+                                                                              const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert,
+                                                                              const unsigned int* inl, int inl_stride, const float* thr) {
+  const size_t lds = (IDX == 1 ? ((size_t)(Rt.hi - Rt.lo) + 2) * 4 : 0) + (size_t)Rt.nS * 4 + (size_t)(RAY_BLOCK / 64) * 3 * 128 * 4;
+  dim3 g((unsigned int)((n + RAY_BLOCK - 1) / RAY_BLOCK)), b(RAY_BLOCK);
+  auto kern = k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK>;
+  static bool raised = false;                          // per instantiation: the half -> index table + queues can exceed the default 64 KB window
+  if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+  hipLaunchKernelGGL(kern, g, b, lds, s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr);
+}
 template <int MODE, bool STATS> static void launch_rays_t(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
-                                                          long n, int stride, const Cell* cells, const AccF* acc, AccR* accr,
-                                                          const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert) {
-  const bool use_lut = MODE == 0 && Rt.lut != nullptr;
-  if (use_lut) {
-    size_t lds = ((size_t)(Rt.hi - Rt.lo) + 2) * 4 + (size_t)Rt.nS * 4;
-    dim3 g((unsigned int)((n + RAY_BLOCK_LUT - 1) / RAY_BLOCK_LUT)), b(RAY_BLOCK_LUT);
-    hipLaunchKernelGGL((k_rays<MODE, STATS, true, RAY_BLOCK_LUT>), g, b, lds, s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
-  } else {
-    dim3 g(nblk(n)), b(EM_BLOCK);
-    hipLaunchKernelGGL((k_rays<MODE, STATS, false, EM_BLOCK>), g, b, (size_t)Rt.nS * 4, s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
-  }
+                                                          long n, int stride, const Cell* cells, AccR* accr,
+                                                          const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert,
+                                                          const unsigned int* inl, int inl_stride, const float* thr) {
+  const bool strip = P.nrows < P.C;
+  // index method (AxisIdx): the float formula when the host proved it exact (reference_fp16) or when it IS the definition (fp32);
+  // else the half -> index table if it fits the default LDS window next to the step table; else the defining arithmetic
+  int idx = 0;
+  if (MODE == 0 && Rt.formula_ok) idx = 2;
+  else if (MODE == 0 && Rt.lut != nullptr && ((size_t)(Rt.hi - Rt.lo) + 2) * 4 + (size_t)Rt.nS * 4 <= 100 * 1024) idx = 1;
+#define RAYS_GO(I, S) launch_rays_i<MODE, STATS, I, S>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr)
+  if (MODE == 0) {
+    if (idx == 2) { if (strip) RAYS_GO(2, true); else RAYS_GO(2, false); }
+    else if (idx == 1) { if (strip) RAYS_GO(1, true); else RAYS_GO(1, false); }
+    else { if (strip) RAYS_GO(0, true); else RAYS_GO(0, false); }
+  } else { if (strip) RAYS_GO(0, true); else RAYS_GO(0, false); }
+#undef RAYS_GO
 }
+// `thr`: per 8 x 8 block visit threshold of k_tile_fuse<true, true> (nullptr: no filter).  `inl` / `inl_stride`: per-cell drift-inlier counts of the frame (newmap[3]) as 32-bit words with an element stride -- the dense
+// plane of the tile kernel (stride 1) or the high halves of AccF::pts_inl (stride 10, offset 1) on the staged / atomic path
 void launch_rays(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts, long n, int stride, const Cell* cells,
-                 const AccF* acc, AccR* accr, const float* normal, long plane_stride, FrameDev* F, bool stats,
-                 const unsigned long long* inert) {
+                 AccR* accr, const float* normal, long plane_stride, FrameDev* F, bool stats,
+                 const unsigned long long* inert, const unsigned int* inl, int inl_stride, const float* thr) {
   if (n <= 0) return;
   if (P.mode == 0) {
-    if (stats) launch_rays_t<0, true>(s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
-    else launch_rays_t<0, false>(s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
+    if (stats) launch_rays_t<0, true>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr);
+    else launch_rays_t<0, false>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr);
   } else {
-    if (stats) launch_rays_t<1, true>(s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
-    else launch_rays_t<1, false>(s, P, T, Rt, pts, n, stride, cells, acc, accr, normal, plane_stride, F, inert);
+    if (stats) launch_rays_t<1, true>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr);
+    else launch_rays_t<1, false>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr);
   }
 }
 void launch_average(hipStream_t s, const KP& P, Cell* cells, AccF* acc, AccR* accr, const FrameDev* F, bool committed, bool rays,
