@@ -594,72 +594,79 @@ template <int PT_R>
 __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __restrict__ cells, float* __restrict__ trav_in,
                                                     float* __restrict__ normal, long plane_stride, int d, int tile_row0) {
   extern __shared__ float lds[];
-  const int RW = PT_C + 6 + 2 * d, rp = RW + 1, RH = PT_R + 6 + 2 * d;     // raw (value, mask) region
-  const int DW = PT_C + 6, dp = DW + 1, DH = PT_R + 6;                      // dilated region
-  float* rval = lds;
+  const int RW = PT_C + 6 + 2 * d, rp = RW + 1, RH = PT_R + 6 + 2 * d;     // staged (value, mask) region: tile + halo 3 + d
+  const int DW = PT_C + 6, DH = PT_R + 6;                                   // region whose DILATED value is needed (halo 3)
+  float* rval = lds;                     // raw upper_bound; holes inside the DW x DH region are overwritten by their dilated value
   float* rmsk = rval + RH * rp;          // mask >= 0; stored as -(mask)-1 when the cell is NOT is_inside (never a source)
-  float* dil = rmsk + RH * rp;
-  float* sval = dil + DH * dp;           // is_valid of the PT_R x PT_C interior (normal filter)
+  float* sval = rmsk + RH * rp;          // is_valid of the PT_R x PT_C interior (normal filter)
   const int C = P.C, total_rows = P.nrows + 2 * P.halo;
   const int tile_r = P.halo + (tile_row0 + (int)blockIdx.y) * PT_R, tile_c = blockIdx.x * PT_C;
-  const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // staging: all 512 threads walk the (RH x RW) region linearly, FOUR cells per thread per round with the loads issued back to back
-  // (valid: 1 dword, upper + is_upper: 2 dwords of the 32-B cell) before any of them is consumed -- the region takes two such
-  // rounds instead of twelve dependent load -> LDS-store round trips with half-empty waves (a 76-wide row does not fill two 64-lane
-  // passes).  e / RW by multiply-high (exact: e < 2^16, RW <= 256).
+  const int tc = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave index in an SGPR: row terms are scalar
+  // staging.  The first 64 columns of the region go row-wise (one wave per region row, lane = column: the row terms are wave
+  // uniform, a cell costs a handful of vector instructions), the remaining 6 + 2d columns as a linear walk over (row, column)
+  // pairs so that their lanes are full too.  All loads of a round (valid: 1 dword; upper + is_upper: 2 dwords of the 32-B cell) are
+  // issued before any is consumed: a 44 x 76 region (32-row tile, d = 3) is ONE round = one memory round trip.
   {
-    constexpr int U = 4;
-    const int total = RH * RW;
-    const unsigned int magic = (unsigned int)((0x100000000ull + (unsigned long long)RW - 1ull) / (unsigned long long)RW);
-    for (int base = 0; base < total; base += PT_THREADS * U) {
-      float f_valid[U]; float2 f_up[U]; int o_lds[U], o_sval[U]; bool ok[U], inside[U];
+    constexpr int JB = 6, EU = 2;                   // rows per wave and edge cells per thread in one round
+    const int r0 = tile_r - 3 - d, c0 = tile_c - 3 - d, EC = RW - 64;
+    const int etotal = RH * EC;
+    const unsigned int emagic = (unsigned int)((0x100000000ull + (unsigned long long)EC - 1ull) / (unsigned long long)EC);
+    auto locate = [&](int r, int cc, int& lr, int& cl, bool& ok, bool& inside) {     // region (r, cc) -> local row, column, flags
+      lr = r0 + r; cl = c0 + cc;
+      if (cl < 0) { cl += C; lr -= 1; } else if (cl >= C) { cl -= C; lr += 1; }      // flat-index row wrap (:403-407)
+      const int gr = lr - P.halo + P.row0;
+      ok = lr >= 0 && lr < total_rows && gr >= 0 && gr <= C - 1;
+      inside = gr >= 1 && gr <= C - 2 && cl >= 1 && cl <= C - 2;
+    };
+    for (int rb = 0, eb = 0; rb < RH || eb < etotal; rb += PT_WAVES * JB, eb += PT_THREADS * EU) {
+      float fv[JB + EU]; float2 fu[JB + EU]; int ol[JB + EU], os[JB + EU]; bool okk[JB + EU], ins[JB + EU];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = base + u * PT_THREADS + (int)threadIdx.x;
-        const int r = (int)__umulhi((unsigned int)e, magic), cc = e - r * RW;
-        int lr = tile_r - 3 - d + r, cl = tile_c - 3 - d + cc;
-        if (cl < 0) { cl += C; lr -= 1; } else if (cl >= C) { cl -= C; lr += 1; }      // flat-index row wrap (:403-407)
-        const int gr = lr - P.halo + P.row0;
-        ok[u] = e < total && lr >= 0 && lr < total_rows && gr >= 0 && gr <= C - 1;
-        inside[u] = gr >= 1 && gr <= C - 2 && cl >= 1 && cl <= C - 2;
-        o_lds[u] = e < total ? r * rp + cc : -1;
+      for (int u = 0; u < JB + EU; ++u) {
+        int r, cc; bool have;
+        if (u < JB) { r = rb + wv + PT_WAVES * u; cc = tc; have = r < RH; }
+        else {
+          const int e = eb + (u - JB) * PT_THREADS + (int)threadIdx.x;
+          r = (int)__umulhi((unsigned int)e, emagic); cc = 64 + e - r * EC; have = e < etotal;
+        }
+        int lr, cl;
+        locate(r, cc, lr, cl, okk[u], ins[u]);
+        okk[u] = okk[u] && have;
+        ol[u] = have ? r * rp + cc : -1;
         const int ir = r - 3 - d, ic = cc - 3 - d;
-        o_sval[u] = (ir >= 0 && ir < PT_R && ic >= 0 && ic < PT_C) ? ir * PT_C + ic : -1;
-        f_valid[u] = 0.f; f_up[u] = make_float2(0.f, 0.f);
-        if (ok[u]) {
+        os[u] = (ir >= 0 && ir < PT_R && ic >= 0 && ic < PT_C) ? ir * PT_C + ic : -1;
+        fv[u] = 0.f; fu[u] = make_float2(0.f, 0.f);
+        if (okk[u]) {
           const float* cp = reinterpret_cast<const float*>(&cells[(long)lr * C + cl]);
-          f_valid[u] = cp[2];                                                 // Cell: h v valid trav | time upper is_upper pad
-          f_up[u] = *reinterpret_cast<const float2*>(cp + 5);
+          fv[u] = cp[2];                                                       // Cell: h v valid trav | time upper is_upper pad
+          fu[u] = *reinterpret_cast<const float2*>(cp + 5);
         }
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (o_lds[u] < 0) continue;
+      for (int u = 0; u < JB + EU; ++u) {
+        if (ol[u] < 0) continue;
         float val = 0.f, msk = -1.f;
-        if (ok[u]) {
-          val = f_up[u].x;
-          const float m = f_valid[u] + f_up[u].y;
-          msk = inside[u] ? m : -m - 1.f;
-          if (o_sval[u] >= 0) sval[o_sval[u]] = f_valid[u];
+        if (okk[u]) {
+          val = fu[u].x;
+          const float m = fv[u] + fu[u].y;
+          msk = ins[u] ? m : -m - 1.f;
+          if (os[u] >= 0) sval[os[u]] = fv[u];
         }
-        rval[o_lds[u]] = val; rmsk[o_lds[u]] = msk;
+        rval[ol[u]] = val; rmsk[ol[u]] = msk;
       }
     }
   }
-  __syncthreads();
-  // dilated tile: known positions are a copy; the (usually few, scattered) holes are first COMPACTED into an LDS list
-  // and then searched one hole per lane -- a hole-containing wave would otherwise drag all 64 lanes through the
-  // neighbour search (measured: 11 of 33 us with 1.5 % holes).
+  // holes of the DW x DH region are first COMPACTED into an LDS list and then searched one hole per lane -- a hole-containing
+  // wave would otherwise drag all 64 lanes through the neighbour search (measured: 11 of 33 us with 1.5 % holes).  The dilated
+  // value replaces the raw one IN PLACE: only cells with mask > 0.5 are ever sources and the masks are not touched, so a filled
+  // hole cannot feed another hole (Jacobi semantics of the reference kernel), and the stencils below read one array.
   unsigned short* holes = reinterpret_cast<unsigned short*>(sval + PT_R * PT_C);
   __shared__ unsigned int n_holes;
   if (threadIdx.x == 0) n_holes = 0u;
   __syncthreads();
   for (int r = wv; r < DH; r += PT_WAVES)
     for (int cc = tc; cc < DW; cc += 64) {
-      const int o0 = (r + d) * rp + (cc + d);
-      const float mraw = rmsk[o0];
+      const float mraw = rmsk[(r + d) * rp + (cc + d)];
       const float own = mraw < 0.f ? -mraw - 1.f : mraw;
-      dil[r * dp + cc] = rval[o0];
       if (own < 0.5f) holes[atomicAdd(&n_holes, 1u)] = (unsigned short)(r * DW + cc);
     }
   __syncthreads();
@@ -673,39 +680,26 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
       const int dy0 = max(-d, s2 - d), dy1 = min(d, s2 + d);
       for (int dy = dy0; dy <= dy1; ++dy) {
         const int o = o0 + dy * rp + (s2 - dy);
-        if (rmsk[o] > 0.5f) { dil[r * dp + cc] = rval[o]; found = true; break; }
+        if (rmsk[o] > 0.5f) { rval[o0] = rval[o]; found = true; break; }     // a hole's slot is never read by another search (its mask is < 0.5)
       }
     }
   }
   __syncthreads();
   const int col = tile_c + tc;
   if (col >= C) return;
-#pragma unroll
-  for (int k = 0; k < (PT_R + PT_WAVES - 1) / PT_WAVES; ++k) {
-    const int tr = wv + PT_WAVES * k, lr = tile_r + tr;
-    if (tr >= PT_R) break;
-    if (lr >= P.halo + P.nrows) break;
-    const int gr = lr - P.halo + P.row0;
+  const float* dil = rval + d * rp + d;          // dilated plane of the DW x DH region, pitch rp
+  const int dp = rp;
+  // Every wave owns PT_R / 8 consecutive tile rows of its column.  Rows are processed in PAIRS with packed fp32 FMAs
+  // (v_pk_fma_f32: the two rows' taps sit in one 64-bit register pair, the weight is a scalar): the same fmaf chain per row,
+  // half the vector instructions of the 12 x 9-tap filter bank.
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  constexpr int RPW = PT_R >= PT_WAVES ? PT_R / PT_WAVES : 1;
+  auto finish_row = [&](int tr, float acc, bool have_acc) {      // traversability, normal, plane writes of one tile row
+    const int lr = tile_r + tr, gr = lr - P.halo + P.row0;
     const long c = (long)lr * C + col;
     const float* t0 = &dil[(tr + 3) * dp + (tc + 3)];
     trav_in[c] = t0[0];
-    if (gr >= 3 && gr <= C - 4 && col >= 3 && col <= C - 4) {
-      float acc = 0.f;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int dl = q + 1;
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-          float sm = 0.f;
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) sm = fmaf(Wt.w[q][ch * 9 + a * 3 + b], t0[(a - 1) * dl * dp + (b - 1) * dl], sm);
-          acc = fmaf(Wt.wo[q * 4 + ch], fabsf(sm), acc);
-        }
-      }
-      cells[c].trav = expf(-acc);
-    }
+    if (have_acc) cells[c].trav = expf(-acc);
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (gr >= 1 && gr <= C - 3 && col >= 1 && col <= C - 3 && sval[tr * PT_C + tc] > 0.5f) {
       float h = t0[0], dzdx = t0[1] - h, dzdy = t0[dp] - h;
@@ -714,6 +708,68 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
       nx = ax / nrm; ny = ay / nrm; nz = 1.0f / nrm;
     }
     normal[c] = nx; normal[plane_stride + c] = ny; normal[2 * plane_stride + c] = nz;
+  };
+  const bool col_in = col >= 3 && col <= C - 4;
+  if constexpr (RPW % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < RPW / 2; ++k) {
+      const int tr = wv * RPW + 2 * k;
+      if (tile_r + tr >= P.halo + P.nrows) break;
+      const bool row1 = tile_r + tr + 1 < P.halo + P.nrows;
+      const int gr = tile_r + tr - P.halo + P.row0;
+      const bool in0 = col_in && gr >= 3 && gr <= C - 4, in1 = col_in && row1 && gr + 1 >= 3 && gr + 1 <= C - 4;
+      v2f acc = {0.f, 0.f};
+      if (in0 || in1) {
+        const float* t0 = &dil[(tr + 3) * dp + (tc + 3)];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int dl = q + 1;
+#pragma unroll
+          for (int ch = 0; ch < 4; ++ch) {
+            v2f sm = {0.f, 0.f};
+#pragma unroll
+            for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+              for (int b2 = 0; b2 < 3; ++b2) {
+                const float* pp = t0 + (a2 - 1) * dl * dp + (b2 - 1) * dl;
+                const v2f tv = {pp[0], pp[dp]};
+                const float w = Wt.w[q][ch * 9 + a2 * 3 + b2];
+                sm = __builtin_elementwise_fma((v2f){w, w}, tv, sm);
+              }
+            const float wo = Wt.wo[q * 4 + ch];
+            acc = __builtin_elementwise_fma((v2f){wo, wo}, __builtin_elementwise_abs(sm), acc);
+          }
+        }
+      }
+      finish_row(tr, acc.x, in0);
+      if (row1) finish_row(tr + 1, acc.y, in1);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int tr = wv * RPW + k;
+      if (tr >= PT_R || tile_r + tr >= P.halo + P.nrows) break;
+      const int gr = tile_r + tr - P.halo + P.row0;
+      const bool in0 = col_in && gr >= 3 && gr <= C - 4;
+      float acc = 0.f;
+      if (in0) {
+        const float* t0 = &dil[(tr + 3) * dp + (tc + 3)];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int dl = q + 1;
+#pragma unroll
+          for (int ch = 0; ch < 4; ++ch) {
+            float sm = 0.f;
+#pragma unroll
+            for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+              for (int b2 = 0; b2 < 3; ++b2) sm = fmaf(Wt.w[q][ch * 9 + a2 * 3 + b2], t0[(a2 - 1) * dl * dp + (b2 - 1) * dl], sm);
+            acc = fmaf(Wt.wo[q * 4 + ch], fabsf(sm), acc);
+          }
+        }
+      }
+      finish_row(tr, acc, in0);
+    }
   }
 }
 
@@ -842,7 +898,7 @@ template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(h
   dim3 g((unsigned int)((n + RAY_BLOCK - 1) / RAY_BLOCK)), b(RAY_BLOCK);
   auto kern = k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK>;
   static bool raised = false;                          // per instantiation: the half -> index table + queues can exceed the default 64 KB window
-  if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+  if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; }
   hipLaunchKernelGGL(kern, g, b, lds, s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr);
 }
 template <int MODE, bool STATS> static void launch_rays_t(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
@@ -896,6 +952,8 @@ void launch_overlap(hipStream_t s, const KP& P, Cell* cells, int cmin, int cmax,
 void launch_dilate(hipStream_t s, const KP& P, const Cell* cells, float* out, int d, int lr0, int lr1) {
   dim3 g((P.C + DT_C - 1) / DT_C, (lr1 - lr0 + DT_R - 1) / DT_R), b(EM_BLOCK);
   size_t lds = (size_t)2 * (DT_R + 2 * d) * (DT_C + 2 * d + 1) * sizeof(float);
+  static bool raised = false;        // dilation radii up to 32 need more than the default 64 KB of dynamic LDS (gfx950: 160 KB per CU)
+  if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_dilate), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; }
   hipLaunchKernelGGL(k_dilate, g, b, lds, s, P, cells, out, d, lr0, lr1);
 }
 void launch_trav_normal(hipStream_t s, const KP& P, const float* w1, const float* w2, const float* w3, const float* wo,
@@ -909,14 +967,18 @@ void launch_trav_normal(hipStream_t s, const KP& P, const float* w1, const float
 // tile rows [tile_row0, tile_row0 + n_tile_rows) of the strip (16 map rows each); the whole strip when n_tile_rows < 0
 // Tile height of k_post (measured on MI355X): 32 rows when that still yields >= 512 workgroups (1024^2 map:
 // 26 us vs 32 us with 16 rows -- less halo re-staging), 16 rows for mid-size maps, 4 rows for robot-scale maps (4x the workgroups).
+static size_t post_lds_bytes(int R, int d) {      // raw (value, mask) region, validity of the interior, hole list
+  return sizeof(float) * ((size_t)2 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)R * PT_C) + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;
+}
 int post_tile_rows(const KP& P) {
   static const int force_r = []() { const char* e = getenv("EMAP_POST_R"); int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32) ? v : 0; }();
-  if (force_r) return force_r;
-  if ((long)P.nrows * P.C <= 512L * 512L) return 4;
-  const size_t lds32 = sizeof(float) * ((size_t)2 * (32 + 6 + 2 * P.dil) * (PT_C + 6 + 2 * P.dil + 1) + (size_t)38 * (PT_C + 7) + (size_t)32 * PT_C)
-                       + sizeof(unsigned short) * (size_t)38 * (PT_C + 6) + 16;
-  if (lds32 > 60 * 1024) return 16;             // large dilation radii: stay inside the default dynamic-LDS window
-  return (long)((P.C + PT_C - 1) / PT_C) * ((P.nrows + 31) / 32) >= 512 ? 32 : 16;
+  int R;
+  if (force_r) R = force_r;
+  else if ((long)P.nrows * P.C <= 512L * 512L) R = 4;
+  else if (post_lds_bytes(32, P.dil) > 60 * 1024) R = 16;             // large dilation radii: keep two workgroups per CU
+  else R = (long)((P.C + PT_C - 1) / PT_C) * ((P.nrows + 31) / 32) >= 512 ? 32 : 16;
+  while (R > 4 && post_lds_bytes(R, P.dil) > 150 * 1024) R /= 2;      // dilation radii up to 32: the staged region must fit the 160 KB LDS
+  return R;
 }
 void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, const float* w3, const float* wo, Cell* cells,
                  float* trav_in, float* normal, long plane_stride, int d, int tile_row0, int n_tile_rows) {
@@ -931,8 +993,15 @@ void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, c
   if (tile_row0 + n_tile_rows > all_rows) n_tile_rows = all_rows - tile_row0;
   if (n_tile_rows <= 0) return;
   dim3 g((P.C + PT_C - 1) / PT_C, n_tile_rows), b(PT_THREADS);
-  size_t lds = sizeof(float) * ((size_t)2 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)(R + 6) * (PT_C + 6 + 1) + (size_t)R * PT_C)
-               + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;     // + hole list
+  const size_t lds = post_lds_bytes(R, d);
+  static bool raised = false;
+  if (!raised) {        // beyond the default 64 KB dynamic-LDS window (large dilation radii)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_post<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_post<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_post<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_post<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    raised = true;
+  }
   if (R == 4) hipLaunchKernelGGL(k_post<4>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
   else if (R == 8) hipLaunchKernelGGL(k_post<8>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
   else if (R == 32) hipLaunchKernelGGL(k_post<32>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);

@@ -297,3 +297,19 @@ def test_fp32_index_mode_on_a_map_beyond_the_half_range(weights):
     assert_planes_close(hip.elevation_map, orc.elevation_map, what="fp32 2560")
     with pytest.raises(Exception):
         ElevationMap(parameter_from(cfg, C, "reference_fp16", weights))
+
+
+@pytest.mark.parametrize("d", [12, 20, 32])
+def test_large_dilation_radius(d, weights):
+    """dilation radii whose LDS tiles exceed the default 64 KB window (emap_create accepts up to 32): fused and staged stencils"""
+    C, N = 202, 6000                                     # sparse cloud: large unknown regions, long-range fills
+    cfg = dict(eo.YAML, dilation_size=d, enable_visibility_cleanup=False)
+    hip, orc = make_pair(cfg, C, "reference_fp16", weights)
+    R, t = fx.POSES["rotated"]
+    p = fx.cloud(C, N, 3)
+    hip.update_map_with_kernel(p, [], R, t.copy(), 0.0, 0.0)          # k_post
+    orc.update_map_with_kernel(p, R, t, 0.0, 0.0)
+    assert np.array_equal(hip.traversability_input, orc.traversability_input)
+    assert_planes_close(hip.elevation_map, orc.elevation_map, what="d=%d" % d)
+    hip.stage("dilate")                                                 # k_dilate on the same state
+    assert np.array_equal(hip.traversability_input, orc.traversability_input)
