@@ -52,6 +52,8 @@ def parse(argv=None):
     ap.add_argument("--sort-clouds", default="none", choices=["none", "tile", "angle"],
                     help="experiment: spatially coherent input order (real sensors deliver scan-ordered clouds)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-strip path even with one rank (self-test)")
+    ap.add_argument("--pre-shift", type=int, nargs=2, default=None, metavar=("ROWS", "COLS"),
+                    help="experiment: shift the map by this many cells before the frames (circular origin off the tile grid)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous plumbing only, no GPU work (CPU test hook)")
     a = ap.parse_args(argv)
     big = a.workload == "cfg5"
@@ -317,6 +319,8 @@ def run_single(a, local_rank=0):
     frame = make_frame(lib, ctx)
 
     def warm(em, fr):
+        if a.pre_shift:
+            em.shift_map_xy(np.array(a.pre_shift))
         # map warm-up (3 frames + time ticks so that the ray pass has stale cells to act on)
         for i in range(3):
             fr(i)

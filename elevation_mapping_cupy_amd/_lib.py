@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libemap_hip.so")
+LIB_PATH = os.environ.get("EMAP_HIP_LIB") or os.path.join(_PKG, "libemap_hip.so")      # (override: A/B runs of two builds)
 
 _INTS = ["cell_n", "mode", "enable_edge_sharpen", "enable_visibility_cleanup", "enable_drift_compensation",
          "enable_overlap_clearance", "dilation_size", "pad_"]
@@ -59,7 +59,7 @@ SYMBOLS = [
     "emap_set_drift_inputs", "emap_drift_sums_to_device", "emap_set_drift_inputs_device",
     "emap_local_drift_sums", "emap_set_scatter_mode", "emap_fuse", "emap_fuse_average", "emap_commit", "emap_rays", "emap_average", "emap_overlap_clear",
     "emap_dilate", "emap_traversability_normals", "emap_post", "emap_post_part", "emap_update_variance", "emap_update_time", "emap_get_stats",
-    "emap_get_layer", "emap_set_layer", "emap_publish_layer", "emap_shift", "emap_semantic_configure", "emap_semantic_update",
+    "emap_get_layer", "emap_set_layer", "emap_publish_layer", "emap_shift", "emap_strip_logical_begin", "emap_semantic_configure", "emap_semantic_update",
     "emap_semantic_get_layer", "emap_semantic_set_layer", "emap_semantic_clear", "emap_semantic_get_alpha", "emap_semantic_set_alpha", "emap_min_filter", "emap_max_filter", "emap_smooth_filter", "emap_erode", "emap_inpaint_u8", "emap_image_correspondence", "emap_image_get_correspondence",
     "emap_image_fuse", "emap_polygon_mask", "emap_dilate_planes", "emap_halo_bytes", "emap_halo_pack", "emap_halo_unpack",
     "emap_comm_unique_id", "emap_comm_init", "emap_comm_destroy", "emap_comm_selftest", "emap_comm_allreduce_host", "emap_update_sharded",
@@ -90,7 +90,11 @@ def load():
     lib.emap_last_error.argtypes = [ct.c_void_p]
     for s in SYMBOLS:
         if s not in ("emap_last_error",):
-            getattr(lib, s).restype = ct.c_int
+            try:
+                getattr(lib, s).restype = ct.c_int
+            except AttributeError:
+                if not os.environ.get("EMAP_HIP_LIB"):      # an older build handed in for an A/B run may lack newer entry points
+                    raise
     _lib = lib
     return lib
 

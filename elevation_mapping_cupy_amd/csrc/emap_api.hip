@@ -21,12 +21,11 @@ void launch_gate(hipStream_t, const KP&, ErrSlot*, FrameDev*, int, double, doubl
 void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, const FrameDev*);
 void launch_commit(hipStream_t, const KP&, Cell*, const AccF*, const FrameDev*, unsigned long long*);
 void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, const Cell*, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*, const unsigned int*, int, const float*);
-void launch_ray_apply(hipStream_t, const KP&, Cell*, AccR*);
+void launch_ray_apply(hipStream_t, const KP&, Cell*, AccR*, unsigned long long*);
 void launch_average(hipStream_t, const KP&, Cell*, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*);
 static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
 void launch_sem_finalize(hipStream_t, const KP&, const SemSpec&, const unsigned int*, double*, unsigned int*, float*, float*, long);
-void launch_sem_shift(hipStream_t, int, int, const float*, float*, int, int);
 void launch_polygon_mask(hipStream_t, int, const int*, const int*, int, const int*, float*);
 void launch_dilate_planes(hipStream_t, int, int, const float*, const float*, float*, float*);
 struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; };
@@ -37,18 +36,18 @@ void launch_min_sweep(hipStream_t, int, int, const float*, const float*, const f
 void launch_box3(hipStream_t, int, const float*, float*);
 void launch_erode(hipStream_t, int, int, const float*, float*);
 void launch_overlap(hipStream_t, const KP&, Cell*, int, int, float, float);
-void launch_dilate(hipStream_t, const KP&, const Cell*, float*, int, int, int);
-void launch_trav_normal(hipStream_t, const KP&, const float*, const float*, const float*, const float*, const float*, Cell*, float*, long);
 void launch_var_time(hipStream_t, const KP&, Cell*, int, int);
 int post_tile_rows(const KP&);
-void launch_post(hipStream_t, const KP&, const float*, const float*, const float*, const float*, Cell*, float*, float*, long, int, int, int);
+void launch_post(hipStream_t, const KP&, const float*, const float*, const float*, const float*, Cell*, float*, float*, long, int, int, const int*, const int*, int);
 void launch_get_plane(hipStream_t, const KP&, const Cell*, int, float*);
 void launch_publish(hipStream_t, const KP&, const Cell*, const float*, long, int, float, int, float*);
 void launch_set_plane(hipStream_t, const KP&, Cell*, int, const float*);
 void launch_fill_cells(hipStream_t, Cell*, long, const Cell&);
 void launch_f64_to_f32(hipStream_t, const double*, float*, long);
 void launch_point_index(hipStream_t, const KP&, const Pose&, const float*, long, int, int*, unsigned char*);
-void launch_shift(hipStream_t, const KP&, const Cell*, Cell*, int, int, float);
+void launch_plane_view(hipStream_t, const KP&, int, int, float*, float*, int);
+void launch_materialize(hipStream_t, const KP&, Cell*);
+void launch_band_clear(hipStream_t, const KP&, float*, int, long, int, int);
 
 // tile-binned scatter (emap_binned.hip)
 struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, pad_; };
@@ -83,7 +82,8 @@ struct emap_ctx {
   hipStream_t stream;
   bool own_stream;
   long ncells_alloc;        // (rows + 2*halo) * C
-  Cell* cells; Cell* cells_alt;
+  Cell* cells;
+  int torg_r, torg_c;              // origin traversability_input was written with (kp.norg_*: the normal planes)
   AccF* acc; AccR* accr;
   float* trav_in; float* normal;   // normal: 3 planes of ncells_alloc
   float* scratch;                  // one plane (get/set staging)
@@ -92,6 +92,7 @@ struct emap_ctx {
   unsigned long long* inert;       // 1 bit per owned cell (rows of ceil(C/64) words), written by k_commit / k_tile_fuse<true, true>
   unsigned int* inl_plane;         // newmap[3] of frames whose tile kernel commits itself (binned path + visibility pass), on demand
   float* ray_thr;                  // same frames: per 8 x 8 block height at or above which a ray sample cannot affect any cell of the block
+  bool inert_zero;                 // the bitmap is all zero (k_ray_apply leaves it so; k_commit overwrites it)
   bool rays_fused;                 // this frame: the tile kernel committed + averaged, k_ray_apply follows the rays
   // tile-binned scatter buffers (allocated on demand)
   int scatter_mode;                // 0 auto, 1 atomic, 2 binned
@@ -102,7 +103,6 @@ struct emap_ctx {
   BinGeo bg; BinTmp* bin_tmp; BinRec* bin_recs; unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;
   // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
   float* img_uv; unsigned char* img_valid; float* img_buf; size_t img_cap;   // camera path
-  float* sem_alt; int sem_alt_layers;
   float* sem_alpha;   // class_bayesian pseudo-counts (the reference's persistent new_map layers), sem_layers planes, on demand
   int sem_layers; float* sem; double* sem_sums; unsigned int* sem_col; unsigned int* cnt_plane;
   // point cloud
@@ -132,7 +132,9 @@ static float q16(float x) { return (float)(_Float16)x; }
 static void build_kp(emap_ctx* ctx) {
   const emap_params& p = ctx->prm;
   KP& k = ctx->kp;
+  const KP old = k;
   memset(&k, 0, sizeof k);
+  k.org_r = old.org_r; k.org_c = old.org_c; k.norg_r = old.norg_r; k.norg_c = old.norg_c; k.mv = old.mv;   // map-shift state survives a parameter update
   k.C = p.cell_n; k.mode = p.mode; k.row0 = ctx->strip.row_begin; k.nrows = ctx->strip.row_count; k.halo = ctx->strip.halo_rows;
   k.edge = p.enable_edge_sharpen; k.dil = p.dilation_size;
   k.res = p.resolution; k.half_w = 0.5 * p.cell_n; k.snf = p.sensor_noise_factor; k.mt = p.mahalanobis_thresh;
@@ -211,9 +213,9 @@ static int build_ray_tables(emap_ctx* ctx) {
       for (int b = 0; b < 65536 && same; ++b) {
         if ((b & 0x7fff) > 0x7c00) continue;
         unsigned short us = (unsigned short)b; _Float16 hf; memcpy(&hf, &us, 2);
-        float v = fmaf((float)hf, inv, hw);
-        v = fminf(fmaxf(v, 0.0f), cm1);
-        if ((int)v != full[b]) same = false;
+        const float q = (float)hf, v = fmaf(q, inv, hw);
+        const int got = (int)fminf(fmaxf(v, 0.0f), cm1) - ((q < 0.0f && v == hw) ? 1 : 0);
+        if (got != full[b]) same = false;
       }
       rt.formula_ok = same ? 1 : 0;
       if (const char* e = getenv("EMAP_RAY_IDX")) { if (atoi(e) != 2) rt.formula_ok = 0; }     // test / tuning hook: force the table path
@@ -260,6 +262,16 @@ static Pose make_pose(const emap_ctx* ctx, const float R[9], const float t[3]) {
   return T;
 }
 
+// Map shifts are lazy (emap_shift): kernels of the frame replay them, everything else sees them written out first.
+static int flush_moves(emap_ctx* ctx) {
+  if (ctx->kp.mv.n == 0) return EMAP_OK;
+  launch_materialize(ctx->stream, ctx->kp, ctx->cells);
+  ctx->kp.mv.n = 0;
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+#define FLUSH() do { int rc_ = flush_moves(ctx); if (rc_) return rc_; } while (0)
+
 static int validate(const emap_params* p, const emap_strip* s, std::string* why) {
   if (!p) { *why = "params null"; return 0; }
   if (p->cell_n < 8 || p->cell_n > 46340) { *why = "cell_n out of range"; return 0; }
@@ -285,12 +297,12 @@ int emap_destroy(emap_ctx* ctx) {
   if (!ctx) return EMAP_OK;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
-  hipFree(ctx->cells); hipFree(ctx->cells_alt); hipFree(ctx->acc); hipFree(ctx->accr); hipFree(ctx->trav_in);
+  hipFree(ctx->cells); hipFree(ctx->acc); hipFree(ctx->accr); hipFree(ctx->trav_in);
   hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->slots); hipFree(ctx->frame); hipFree(ctx->pts_own);
   hipFree(ctx->pts_f64); hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert); hipFree(ctx->inl_plane); hipFree(ctx->ray_thr);
   hipFree(ctx->bin_tmp); hipFree(ctx->bin_recs); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start);
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
-  hipFree(ctx->sem_alt); hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
+  hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   emap_comm_destroy(ctx);
   for (int i = 0; i <= ST_N; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   if (ctx->t0) hipEventDestroy(ctx->t0);
@@ -306,6 +318,7 @@ int emap_clear(emap_ctx* ctx) {
   // ElevationMap.clear (elevation_mapping.py:119-128): all planes 0, variance = initial_variance
   Cell z = {0.f, (float)ctx->prm.initial_variance, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   launch_fill_cells(ctx->stream, ctx->cells, ctx->ncells_alloc, z);
+  ctx->kp.mv.n = 0;                   // every cell has just been written
   CK(hipMemsetAsync(ctx->acc, 0, sizeof(AccF) * ctx->ncells_alloc, ctx->stream));
   CK(hipMemsetAsync(ctx->accr, 0, sizeof(AccR) * ctx->ncells_alloc, ctx->stream));
   CK(hipMemsetAsync(ctx->slots, 0, sizeof(ErrSlot) * EM_ERR_SLOTS, ctx->stream));
@@ -582,8 +595,12 @@ static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool fus
       CK(hipMemsetAsync(ctx->inl_plane, 0, sizeof(unsigned int) * ctx->ncells_alloc, ctx->stream));
       CK(hipMalloc((void**)&ctx->ray_thr, sizeof(float) * (size_t)((ctx->strip.row_count + 7) / 8 + 2) * ((ctx->prm.cell_n + 7) / 8)));
     }
+    if (fuse_average && rays && ((ctx->kp.org_c | ctx->prm.cell_n) & 63) != 0 && !ctx->inert_zero)     // unaligned columns: the tile kernel ORs its ballots into the logical bitmap
+      CK(hipMemsetAsync(ctx->inert, 0, sizeof(unsigned long long) * ((size_t)ctx->strip.row_count * ((ctx->prm.cell_n + 63) / 64) + 1), ctx->stream));
+    if (fuse_average && rays) ctx->inert_zero = false;
     launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame, fuse_average, rays,
                     ctx->cnt_plane, ctx->inert, ctx->inl_plane, ctx->ray_thr);
+    if (fuse_average) ctx->kp.mv.n = 0;   // every owned cell rewritten: pending map shifts are in memory now
     CK(hipGetLastError());
     return EMAP_OK;
   }
@@ -599,7 +616,7 @@ int emap_fuse_average(emap_ctx* ctx, const float R[9], const float t[3]) {
   const bool fused = ctx->frame_binned;
   int rc = fuse_impl(ctx, R, t, fused);
   if (rc) return rc;
-  if (!fused) launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, false, ctx->cnt_plane);
+  if (!fused) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, false, ctx->cnt_plane); ctx->kp.mv.n = 0; }
   ctx->committed = false;
   CK(hipGetLastError());
   return EMAP_OK;
@@ -608,7 +625,11 @@ int emap_fuse_average(emap_ctx* ctx, const float R[9], const float t[3]) {
 int emap_commit(emap_ctx* ctx) {
   CKARG(ctx, "null ctx");
   CK(hipSetDevice(ctx->device));
-  if (!ctx->committed) { launch_commit(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->frame, ctx->inert); ctx->committed = true; }
+  if (!ctx->committed) {
+    launch_commit(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->frame, ctx->inert);
+    ctx->committed = true; ctx->inert_zero = false;
+    ctx->kp.mv.n = 0;                 // k_commit rewrote every owned cell: pending map shifts are in memory now
+  }
   CK(hipGetLastError());
   return EMAP_OK;
 }
@@ -630,7 +651,7 @@ int emap_average(emap_ctx* ctx) {
   CKARG(ctx, "null ctx");
   CK(hipSetDevice(ctx->device));
   launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, true, ctx->cnt_plane);
-  ctx->committed = false;
+  ctx->committed = false; ctx->kp.mv.n = 0;       // (uncommitted: k_average wrote the pending map shifts out itself)
   CK(hipGetLastError());
   return EMAP_OK;
 }
@@ -638,6 +659,7 @@ int emap_average(emap_ctx* ctx) {
 int emap_overlap_clear(emap_ctx* ctx, float t_z) {
   CKARG(ctx, "null ctx");
   CK(hipSetDevice(ctx->device));
+  FLUSH();
   const emap_params& p = ctx->prm;
   int cell_range = (int)(p.overlap_clear_range_xy / p.resolution);     // elevation_mapping.py:88-91
   if (cell_range < 0) cell_range = 0; if (cell_range > p.cell_n) cell_range = p.cell_n;
@@ -648,52 +670,57 @@ int emap_overlap_clear(emap_ctx* ctx, float t_z) {
   return EMAP_OK;
 }
 
-int emap_dilate(emap_ctx* ctx) {
+// Stencil stages.  The kernels work on LOGICAL rows; a strip owns the physical rows [row_begin, row_begin + row_count), i.e. the
+// logical rows ls + j (mod cell_n), j = 0 .. row_count-1, with ls = (row_begin - org_r) mod cell_n: one or two logical intervals.
+static void post_rows(emap_ctx* ctx, int nj, const int* j0, const int* j1, int stage) {      // outputs for the strip's rows j0[k] <= j < j1[k]
+  const int C = ctx->prm.cell_n;
+  const int ls = ((ctx->strip.row_begin - ctx->kp.org_r) % C + C) % C;
+  int sb[4], se[4], n = 0;
+  for (int k = 0; k < nj; ++k) {
+    if (j1[k] <= j0[k]) continue;
+    const int b = ls + j0[k], e = ls + j1[k];                             // unwrapped logical rows
+    if (e <= C) { sb[n] = b; se[n] = e; n++; }
+    else if (b >= C) { sb[n] = b - C; se[n] = e - C; n++; }
+    else { sb[n] = b; se[n] = C; n++; sb[n] = 0; se[n] = e - C; n++; }    // the circular seam lies inside: never inside one tile
+  }
+  launch_post(ctx->stream, ctx->kp, ctx->prm.w1, ctx->prm.w2, ctx->prm.w3, ctx->prm.w_out, ctx->cells, ctx->trav_in, ctx->normal,
+              ctx->ncells_alloc, ctx->prm.dilation_size, n, sb, se, stage);
+}
+
+int emap_dilate(emap_ctx* ctx) {          // dilation_filter_kernel alone: traversability_input (k_post, stage 1)
   CKARG(ctx, "null ctx");
   CK(hipSetDevice(ctx->device));
-  const int H = ctx->strip.halo_rows, total = ctx->strip.row_count + 2 * H;
-  int lr0 = H - 3 < 0 ? 0 : H - 3, lr1 = H + ctx->strip.row_count + 3 > total ? total : H + ctx->strip.row_count + 3;
-  launch_dilate(ctx->stream, ctx->kp, ctx->cells, ctx->trav_in, ctx->prm.dilation_size, lr0, lr1);
+  FLUSH();
+  { const int j0 = 0, j1 = ctx->strip.row_count; post_rows(ctx, 1, &j0, &j1, 1); }
+  ctx->torg_r = ctx->kp.org_r; ctx->torg_c = ctx->kp.org_c;
   CK(hipGetLastError());
   return EMAP_OK;
 }
 
-int emap_traversability_normals(emap_ctx* ctx) {
-  CKARG(ctx, "null ctx");
-  CK(hipSetDevice(ctx->device));
-  launch_trav_normal(ctx->stream, ctx->kp, ctx->prm.w1, ctx->prm.w2, ctx->prm.w3, ctx->prm.w_out, ctx->trav_in, ctx->cells, ctx->normal,
-                     ctx->ncells_alloc);
-  CK(hipGetLastError());
-  return EMAP_OK;
-}
+int emap_traversability_normals(emap_ctx* ctx) { return emap_post_part(ctx, 0); }     // (recomputes the dilation it consumes: same values)
 
-// dilation + traversability + normals in one launch (same results as the two stages).  part: 0 = whole strip,
-// 1 = only the tile rows that do not depend on halo rows (can run while the halo exchange is in flight),
-// 2 = the remaining (boundary) tile rows.
+// dilation + traversability + normals in one launch.  part: 0 = whole strip,
+// 1 = only the rows that do not depend on halo rows (can run while the halo exchange is in flight),
+// 2 = the remaining (boundary) rows.
 int emap_post_part(emap_ctx* ctx, int32_t part) {
   CKARG(ctx && part >= 0 && part <= 2, "bad argument");
   CK(hipSetDevice(ctx->device));
-  const int reach = ctx->prm.dilation_size + 4;                  // rows a tile looks beyond itself (stencils + row wrap)
-  const int R = post_tile_rows(ctx->kp);                         // tile height of k_post for this map
-  const int all_rows = (ctx->strip.row_count + R - 1) / R;
-  int first_in = (reach + R - 1) / R, last_in = (ctx->strip.row_count - reach) / R - 1;   // interior tile rows [first_in, last_in]
-  auto run = [&](int r0, int n) {
-    launch_post(ctx->stream, ctx->kp, ctx->prm.w1, ctx->prm.w2, ctx->prm.w3, ctx->prm.w_out, ctx->cells, ctx->trav_in, ctx->normal,
-                ctx->ncells_alloc, ctx->prm.dilation_size, r0, n);
-  };
-  if (part == 0) run(0, -1);
-  else if (part == 1) { if (last_in >= first_in) run(first_in, last_in - first_in + 1); }
-  else {
-    if (last_in >= first_in) { run(0, first_in); run(last_in + 1, all_rows - last_in - 1); }
-    else run(0, -1);
-  }
+  FLUSH();
+  const int n = ctx->strip.row_count;
+  const int reach = ctx->prm.dilation_size + 4;                  // rows a stencil looks beyond its own (dilation + filter + row wrap)
+  const int lo = reach < n ? reach : n, hi = n - reach > lo ? n - reach : lo;      // interior rows [lo, hi)
+  const int jb0[2] = {0, hi}, je0[2] = {lo, n}, z = 0;
+  if (part == 0) post_rows(ctx, 1, &z, &n, 0);
+  else if (part == 1) post_rows(ctx, 1, &lo, &hi, 0);
+  else post_rows(ctx, 2, jb0, je0, 0);               // at most 3 logical intervals: the seam lies in one of the two boundary bands
+  if (part != 1) { ctx->kp.norg_r = ctx->torg_r = ctx->kp.org_r; ctx->kp.norg_c = ctx->torg_c = ctx->kp.org_c; }   // outputs carry the current origin
   CK(hipGetLastError());
   return EMAP_OK;
 }
 int emap_post(emap_ctx* ctx) { return emap_post_part(ctx, 0); }
 
-int emap_update_variance(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 1, 0); CK(hipGetLastError()); return EMAP_OK; }
-int emap_update_time(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 0, 1); CK(hipGetLastError()); return EMAP_OK; }
+int emap_update_variance(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 1, 0); ctx->kp.mv.n = 0; CK(hipGetLastError()); return EMAP_OK; }
+int emap_update_time(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 0, 1); ctx->kp.mv.n = 0; CK(hipGetLastError()); return EMAP_OK; }
 
 int emap_get_stats(emap_ctx* ctx, emap_stats* out) {
   CKARG(ctx && out, "null argument");
@@ -736,8 +763,8 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
     if (rc) { ctx->rays_fused = false; return rc; }
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
-  if (!fused_avg) launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane);
-  else if (rays_on) launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr);
+  if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane); ctx->kp.mv.n = 0; }
+  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   STAGE(ST_OVERLAP);
@@ -755,30 +782,35 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
 }
 
 // ---- state access -------------------------------------------------------------------------------------------
-static float* plane_ptr(emap_ctx* ctx, int plane) {   // planar planes, offset to the first owned row
-  const long off = (long)ctx->strip.halo_rows * ctx->prm.cell_n;
-  if (plane >= EMAP_PLANE_NORMAL_X && plane <= EMAP_PLANE_NORMAL_Z) return ctx->normal + (long)(plane - EMAP_PLANE_NORMAL_X) * ctx->ncells_alloc + off;
-  if (plane == EMAP_PLANE_TRAV_INPUT) return ctx->trav_in + off;
-  return nullptr;
+// Views are (row_count, cell_n) host arrays in LOGICAL order (k_plane_view / k_get_plane): row j = logical row j of a full map,
+// or the j-th logical row of a strip (emap_strip_logical_begin), columns logical.
+static int plane_view(emap_ctx* ctx, int plane, float* host, bool to_device) {
+  const size_t bytes = sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n;
+  FLUSH();
+  if (to_device) CK(hipMemcpyAsync(ctx->scratch, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (plane < 7) {
+    if (to_device) launch_set_plane(ctx->stream, ctx->kp, ctx->cells, plane, ctx->scratch);
+    else launch_get_plane(ctx->stream, ctx->kp, ctx->cells, plane, ctx->scratch);
+  } else if (plane == EMAP_PLANE_TRAV_INPUT) launch_plane_view(ctx->stream, ctx->kp, ctx->torg_r, ctx->torg_c, ctx->trav_in, ctx->scratch, to_device);
+  else launch_plane_view(ctx->stream, ctx->kp, ctx->kp.norg_r, ctx->kp.norg_c, ctx->normal + (long)(plane - EMAP_PLANE_NORMAL_X) * ctx->ncells_alloc,
+                         ctx->scratch, to_device);
+  CK(hipGetLastError());
+  if (!to_device) CK(hipMemcpyAsync(host, ctx->scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
+  return EMAP_OK;
 }
 
 int emap_get_layer(emap_ctx* ctx, int plane, float* host_out) {
   CKARG(ctx && host_out && plane >= 0 && plane < EMAP_PLANE_COUNT, "bad argument");
   CK(hipSetDevice(ctx->device));
-  const size_t bytes = sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n;
-  if (plane < 7) {
-    launch_get_plane(ctx->stream, ctx->kp, ctx->cells, plane, ctx->scratch);
-    CK(hipGetLastError());
-    CK(hipMemcpyAsync(host_out, ctx->scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  } else CK(hipMemcpyAsync(host_out, plane_ptr(ctx, plane), bytes, hipMemcpyDeviceToHost, ctx->stream));
-  CK(hipStreamSynchronize(ctx->stream));
-  return EMAP_OK;
+  return plane_view(ctx, plane, host_out, false);
 }
 
 int emap_publish_layer(emap_ctx* ctx, int32_t kind, float center_z, int32_t use_only_above_for_upper_bound, float* host_out) {
   CKARG(ctx && host_out && kind >= 0 && kind <= 8, "bad argument");
   CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "emap_publish_layer: single-strip contexts only");
   CK(hipSetDevice(ctx->device));
+  FLUSH();
   const long M = ctx->prm.cell_n - 2;
   launch_publish(ctx->stream, ctx->kp, ctx->cells, ctx->normal, ctx->ncells_alloc, kind, center_z, use_only_above_for_upper_bound, ctx->scratch);
   CK(hipGetLastError());
@@ -790,39 +822,37 @@ int emap_publish_layer(emap_ctx* ctx, int32_t kind, float center_z, int32_t use_
 int emap_set_layer(emap_ctx* ctx, int plane, const float* host_in) {
   CKARG(ctx && host_in && plane >= 0 && plane < EMAP_PLANE_COUNT, "bad argument");
   CK(hipSetDevice(ctx->device));
-  const size_t bytes = sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n;
-  if (plane < 7) {
-    CK(hipMemcpyAsync(ctx->scratch, host_in, bytes, hipMemcpyHostToDevice, ctx->stream));
-    launch_set_plane(ctx->stream, ctx->kp, ctx->cells, plane, ctx->scratch);
-    CK(hipGetLastError());
-  } else CK(hipMemcpyAsync(plane_ptr(ctx, plane), host_in, bytes, hipMemcpyHostToDevice, ctx->stream));
-  CK(hipStreamSynchronize(ctx->stream));
+  return plane_view(ctx, plane, const_cast<float*>(host_in), true);
+}
+
+int emap_strip_logical_begin(emap_ctx* ctx, int32_t* logical_row) {
+  CKARG(ctx && logical_row, "null argument");
+  const int C = ctx->prm.cell_n;
+  *logical_row = ctx->strip.row_count == C ? 0 : ((ctx->strip.row_begin - ctx->kp.org_r) % C + C) % C;
   return EMAP_OK;
 }
 
+// ElevationMap.shift_map_xy / shift_map_z (EM/elevation_mapping.py:200-226) WITHOUT moving data: the roll becomes a rotation of the
+// circular origin, the reset of the entering band and the z offset become a pending entry that the frame kernels replay (cell_now)
+// and the next full rewrite of the cells writes out; only the semantic layers clear their entering band here (O(border) bytes).
+// The normal planes and traversability_input keep their own origin: the reference does not shift them.
 int emap_shift(emap_ctx* ctx, int32_t shift_rows, int32_t shift_cols, float dz) {
   CKARG(ctx, "null ctx");
-  CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "emap_shift: single-strip contexts only");
   CK(hipSetDevice(ctx->device));
+  const int C = ctx->prm.cell_n;
+  CKARG(shift_rows > -(1 << 20) && shift_rows < (1 << 20) && shift_cols > -(1 << 20) && shift_cols < (1 << 20), "absurd shift");   // (a shift of cell_n or more resets every cell: the replay predicate covers it)
   if (shift_rows == 0 && shift_cols == 0 && dz == 0.f) return EMAP_OK;
-  if (!ctx->cells_alt) CK(hipMalloc((void**)&ctx->cells_alt, sizeof(Cell) * ctx->ncells_alloc));
-  launch_shift(ctx->stream, ctx->kp, ctx->cells, ctx->cells_alt, shift_rows, shift_cols, dz);
-  CK(hipGetLastError());
-  Cell* tmp = ctx->cells; ctx->cells = ctx->cells_alt; ctx->cells_alt = tmp;
-  if (ctx->sem_layers > 0 && (shift_rows != 0 || shift_cols != 0)) {   // SemanticMap.shift_map_xy (semantic_map.py:127-136)
-    if (ctx->sem_alt_layers < ctx->sem_layers) {                       // persistent ping-pong buffer, grown with the layer store
-      if (ctx->sem_alt) { CK(hipStreamSynchronize(ctx->stream)); CK(hipFree(ctx->sem_alt)); ctx->sem_alt = nullptr; ctx->sem_alt_layers = 0; }
-      CK(hipMalloc((void**)&ctx->sem_alt, sizeof(float) * ctx->ncells_alloc * ctx->sem_layers));
-      ctx->sem_alt_layers = ctx->sem_layers;
-    }
-    launch_sem_shift(ctx->stream, ctx->prm.cell_n, ctx->sem_layers, ctx->sem, ctx->sem_alt, shift_rows, shift_cols);
+  if (ctx->kp.mv.n == EM_MAX_MOVES) FLUSH();       // more moves than the replay list holds before the next frame: one full pass
+  KP& k = ctx->kp;
+  k.org_r = ((k.org_r - shift_rows) % C + C) % C;   // roll: new logical r holds old logical r - shift  =>  physical = r - shift + org
+  k.org_c = ((k.org_c - shift_cols) % C + C) % C;
+  Moves& mv = k.mv;
+  mv.org_r[mv.n] = k.org_r; mv.org_c[mv.n] = k.org_c; mv.sr[mv.n] = shift_rows; mv.sc[mv.n] = shift_cols; mv.dz[mv.n] = dz;
+  mv.n++;
+  if (ctx->sem_layers > 0 && (shift_rows != 0 || shift_cols != 0)) {   // SemanticMap.shift_map_xy (semantic_map.py:127-136): roll + zero pad
+    launch_band_clear(ctx->stream, k, ctx->sem, ctx->sem_layers, ctx->ncells_alloc, shift_rows, shift_cols);
+    if (ctx->sem_alpha) launch_band_clear(ctx->stream, k, ctx->sem_alpha, ctx->sem_layers, ctx->ncells_alloc, shift_rows, shift_cols);   // new_map too (:135-136)
     CK(hipGetLastError());
-    float* tmp_s = ctx->sem; ctx->sem = ctx->sem_alt; ctx->sem_alt = tmp_s;
-    if (ctx->sem_alpha) {     // new_map is rolled and zero-padded like the layers (semantic_map.py:135-136)
-      launch_sem_shift(ctx->stream, ctx->prm.cell_n, ctx->sem_layers, ctx->sem_alpha, ctx->sem_alt, shift_rows, shift_cols);
-      CK(hipGetLastError());
-      tmp_s = ctx->sem_alpha; ctx->sem_alpha = ctx->sem_alt; ctx->sem_alt = tmp_s;
-    }
   }
   return EMAP_OK;
 }
@@ -900,40 +930,37 @@ int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], cons
   return EMAP_OK;
 }
 
-static int alpha_copy(emap_ctx* ctx, int32_t layer, float* host_out, const float* host_in) {
-  CK(hipSetDevice(ctx->device));
-  int rc = ensure_alpha(ctx); if (rc) return rc;
-  const long off = (long)layer * ctx->ncells_alloc + (long)ctx->strip.halo_rows * ctx->prm.cell_n;
+static int sem_view(emap_ctx* ctx, float* planes, int32_t layer, float* host, bool to_device) {   // semantic layers share the map's origin
   const size_t bytes = sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n;
-  if (host_out) CK(hipMemcpyAsync(host_out, ctx->sem_alpha + off, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  else CK(hipMemcpyAsync(ctx->sem_alpha + off, host_in, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (to_device) CK(hipMemcpyAsync(ctx->scratch, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  launch_plane_view(ctx->stream, ctx->kp, ctx->kp.org_r, ctx->kp.org_c, planes + (long)layer * ctx->ncells_alloc, ctx->scratch, to_device);
+  CK(hipGetLastError());
+  if (!to_device) CK(hipMemcpyAsync(host, ctx->scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
   CK(hipStreamSynchronize(ctx->stream));
   return EMAP_OK;
 }
 int emap_semantic_get_alpha(emap_ctx* ctx, int32_t layer, float* host_out) {
   CKARG(ctx && host_out && layer >= 0 && layer < ctx->sem_layers, "bad argument");
-  return alpha_copy(ctx, layer, host_out, nullptr);
+  CK(hipSetDevice(ctx->device));
+  int rc = ensure_alpha(ctx); if (rc) return rc;
+  return sem_view(ctx, ctx->sem_alpha, layer, host_out, false);
 }
 int emap_semantic_set_alpha(emap_ctx* ctx, int32_t layer, const float* host_in) {
   CKARG(ctx && host_in && layer >= 0 && layer < ctx->sem_layers, "bad argument");
-  return alpha_copy(ctx, layer, nullptr, host_in);
+  CK(hipSetDevice(ctx->device));
+  int rc = ensure_alpha(ctx); if (rc) return rc;
+  return sem_view(ctx, ctx->sem_alpha, layer, const_cast<float*>(host_in), true);
 }
 
 int emap_semantic_get_layer(emap_ctx* ctx, int32_t layer, float* host_out) {
   CKARG(ctx && host_out && layer >= 0 && layer < ctx->sem_layers, "bad argument");
   CK(hipSetDevice(ctx->device));
-  const long off = (long)layer * ctx->ncells_alloc + (long)ctx->strip.halo_rows * ctx->prm.cell_n;
-  CK(hipMemcpyAsync(host_out, ctx->sem + off, sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n, hipMemcpyDeviceToHost, ctx->stream));
-  CK(hipStreamSynchronize(ctx->stream));
-  return EMAP_OK;
+  return sem_view(ctx, ctx->sem, layer, host_out, false);
 }
 int emap_semantic_set_layer(emap_ctx* ctx, int32_t layer, const float* host_in) {
   CKARG(ctx && host_in && layer >= 0 && layer < ctx->sem_layers, "bad argument");
   CK(hipSetDevice(ctx->device));
-  const long off = (long)layer * ctx->ncells_alloc + (long)ctx->strip.halo_rows * ctx->prm.cell_n;
-  CK(hipMemcpyAsync(ctx->sem + off, host_in, sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n, hipMemcpyHostToDevice, ctx->stream));
-  CK(hipStreamSynchronize(ctx->stream));
-  return EMAP_OK;
+  return sem_view(ctx, ctx->sem, layer, const_cast<float*>(host_in), true);
 }
 int emap_semantic_clear(emap_ctx* ctx) {
   CKARG(ctx, "null ctx");
@@ -1058,6 +1085,7 @@ int emap_image_correspondence(emap_ctx* ctx, float x1, float y1, float z1, const
   CKARG(ctx && P && K && D && center, "null argument");
   CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "camera path: single-strip contexts only");
   CK(hipSetDevice(ctx->device));
+  FLUSH();
   const size_t L = (size_t)ctx->prm.cell_n * ctx->prm.cell_n;
   if (!ctx->img_uv) { CK(hipMalloc((void**)&ctx->img_uv, sizeof(float) * 2 * L)); CK(hipMalloc((void**)&ctx->img_valid, L)); }
   CamArgs A;
@@ -1322,8 +1350,8 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
     if (rc) { ctx->rays_fused = false; return rc; }
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
-  if (!fused_avg) launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane);
-  else if (rays_on) launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr);
+  if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane); ctx->kp.mv.n = 0; }
+  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   STAGE(ST_OVERLAP);

@@ -61,11 +61,11 @@ __global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const 
     load_point(pts, i, stride, rx, ry, rz);
     Geo g = geometry<MODE>(P, T, rx, ry, rz);
     BinTmp r; r.tile = -1; r.lc = 0u; r.z = g.z; r.v = g.v;
-    const int lrow = g.ix - P.row0;
+    const int lrow = phys_row(P, g.ix) - P.row0, pcol = phys_col(P, g.iy);      // tiles are PHYSICAL: 16 owned rows x 64 columns of memory
     if (g.finite && g.valid && g.inside && lrow >= 0 && lrow < P.nrows) {
       const int BR = BIN_TR * G.sub;
-      r.tile = (lrow / BR) * G.tiles_x + (g.iy / BIN_TC);
-      r.lc = (unsigned int)((lrow % BR) * BIN_TC + (g.iy % BIN_TC));
+      r.tile = (lrow / BR) * G.tiles_x + (pcol / BIN_TC);
+      r.lc = (unsigned int)((lrow % BR) * BIN_TC + (pcol % BIN_TC));
       atomicAdd(&h[r.tile], 1u);
     }
     tmp[i] = r;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const B
   {
     const int tr = threadIdx.x >> 6, tc = threadIdx.x & 63, lrow = row_base + tr, col = tx * BIN_TC + tc;   // 1024 threads = 16 x 64 cells
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lrow < P.nrows && col < P.C) m = *reinterpret_cast<const float4*>(&cells[(long)(lrow + P.halo) * P.C + col]);
+    if (lrow < P.nrows && col < P.C) { m = *reinterpret_cast<const float4*>(&cells[(long)(lrow + P.halo) * P.C + col]); cell_now(P, m, P.row0 + lrow, col); }
     s_cell[threadIdx.x] = m;
   }
   __syncthreads();
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
       s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull;
       const int lrow = row_base + k / BIN_TC, colk = tx * BIN_TC + k % BIN_TC;
       float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lrow < P.nrows && colk < P.C) m = *reinterpret_cast<const float4*>(&cells[(long)(lrow + P.halo) * P.C + colk]);
+      if (lrow < P.nrows && colk < P.C) { m = *reinterpret_cast<const float4*>(&cells[(long)(lrow + P.halo) * P.C + colk]); cell_now(P, m, P.row0 + lrow, colk); }
       s_cell[k] = m;
     }
     __syncthreads();
@@ -246,9 +246,10 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
         const long c = (long)(lrow + P.halo) * P.C + col;
         if (AVG) {
           Cell m = cells[c];
+          cell_now(P, m, P.row0 + lrow, col);                  // pending map shifts are written out with this rewrite
           m.h += shift;
           commit_cell(P, m, a);
-          quiet = (!(m.valid < 0.5f) && m.time < 0.5f) || border_cell(P, lrow + P.row0, col);   // snapshot S1 (what the rays are defined on); border cells: see k_commit
+          quiet = (!(m.valid < 0.5f) && m.time < 0.5f) || border_cell(P, logi_row(P, P.row0 + lrow), logi_col(P, col));   // snapshot S1 (what the rays are defined on); border cells: see k_commit
           // unknown cell: acts only while nz < upper_bound (or no bound yet, :229); known stale cell: the penetration test (:239)
           // h > nz + 0.01 - min(v, 1) * 0.05 implies nz < h + 0.04
           if (RAYS && !quiet) visit_thr = m.valid < 0.5f ? ((m.is_upper < 0.5f || !(m.upper <= 3.0e38f)) ? INFINITY : m.upper) : m.h + 0.05f;
@@ -261,8 +262,23 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
       }
       if (AVG && RAYS) {                                       // every wave of the workgroup gets here (no early exit above)
         if (lrow < P.nrows) {                                  // wave-uniform condition: the ballot sees the whole row segment
+          // the bitmap is indexed by LOGICAL column (k_commit): the 64 physical columns of this wave are one or two runs of logical
+          // columns that straddle word boundaries -> OR the shifted pieces into the (pre-zeroed) words
           const unsigned long long bits = __ballot(quiet);
-          if (tc == 0) inert[(long)lrow * ((P.C + 63) / 64) + tx] = bits;
+          if (tc == 0 && ((P.org_c | P.C) & 63) == 0) inert[(long)bitmap_row(P, P.row0 + lrow) * (P.C / 64) + logi_col(P, tx * BIN_TC) / 64] = bits;   // aligned: one whole word
+          else if (tc == 0) {
+            unsigned long long* row = inert + (long)bitmap_row(P, P.row0 + lrow) * ((P.C + 63) / 64);
+            const int ncol = min(64, P.C - tx * BIN_TC);                      // physical columns of this segment
+            int done = 0;
+            while (done < ncol) {                                              // runs of consecutive logical columns (<= 2)
+              const int l0 = logi_col(P, tx * BIN_TC + done), run = min(ncol - done, P.C - l0);
+              const unsigned long long piece = (run == 64 ? bits : ((bits >> done) & ((1ull << run) - 1ull)));
+              const int sh = l0 & 63;
+              if (piece << sh) atomicOr(&row[l0 >> 6], piece << sh);
+              if (sh && (piece >> (64 - sh))) atomicOr(&row[(l0 >> 6) + 1], piece >> (64 - sh));
+              done += run;
+            }
+          }
         }
         // block thresholds: max over 8 columns (lanes) and 8 rows (waves) through the ordered-uint image of the float
         unsigned int* s_thr = s_pts;                           // the counters are dead by now: 2 block rows x 8 block columns
@@ -408,7 +424,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
           const int kind = S.sum_kind[g0 + q];
           if (kind == 2) alpha_planes[j] = (float)((double)alpha_planes[j] + s);   // every cell; renormalised below
           else if (kind == 3) {
-            const long gcell = (long)(P.row0 + lrow) * P.C + col;
+            const long gcell = (long)logi_row(P, P.row0 + lrow) * P.C + logi_col(P, col);      // the reference's flat LOGICAL cell index
             if (cnt > 0 && gcell * S.sum_K[g0 + q] + S.sum_q[g0 + q] < (long)P.C * P.C) {
               const float cn = (float)cnt, feat_ml = (float)s / cn, sigma_old = 0.0f, sigma = 1.0f;
               sem[j] = sigma * sem[j] / (cn * sigma_old + sigma) + cn * sigma_old * feat_ml / (cn * sigma_old + sigma);

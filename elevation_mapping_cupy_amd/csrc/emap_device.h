@@ -53,8 +53,19 @@ struct FrameDev {                  // per-frame scalars that stay on the device 
 
 // Kernel parameters: everything the reference bakes into its kernel strings as literals
 // (custom_kernels.py:264-274), passed as kernargs instead (no JIT, parameters can change per launch).
+// Map shifts that have not been written into the cells yet (DESIGN.md "Map shift"): move_to / move only rotate the circular origin
+// and append an entry here; every kernel that reads cells before the next full rewrite replays the entries on the fly (cell_now),
+// the next pass that rewrites every cell (the frame's tile kernel / commit pass, k_var_time, k_materialize) writes them out.
+#define EM_MAX_MOVES 4
+struct Moves { int n, pad_; int org_r[EM_MAX_MOVES], org_c[EM_MAX_MOVES], sr[EM_MAX_MOVES], sc[EM_MAX_MOVES]; float dz[EM_MAX_MOVES]; };
+
 struct KP {
   int C, mode, row0, nrows, halo, edge, dil, pad0;
+  // circular origin: logical cell (r, c) lives at physical row (r + org_r) mod C, column (c + org_c) mod C; row0 / nrows / halo
+  // describe PHYSICAL rows (a strip keeps its rows when the map shifts).  norg_*: origin the stencil outputs (normal planes,
+  // traversability_input) were written with -- the reference does not shift those (elevation_mapping.py:200-214).
+  int org_r, org_c, norg_r, norg_c;
+  Moves mv;
   double res, half_w, snf, mt, ov, dcvi_half, trav_inlier, wall, mrl, cs, cos_thresh, mvd2, mhr, ra, rb, rc;
   double max_var, ray_step;
   float init_var, ov_f, q_wm1, q_mrl, q_step, time_var, time_int, res_f, inv_res_f, half_w_f, cm1_f, pad1;
@@ -130,14 +141,55 @@ template <int MODE> __device__ __forceinline__ Geo geometry(const KP& P, const P
   return g;
 }
 
-// !is_inside (custom_kernels.py:34-44): first / last row or column of the map
-__device__ __forceinline__ bool border_cell(const KP& P, int gr, int col) { return gr <= 0 || gr >= P.C - 1 || col <= 0 || col >= P.C - 1; }
+// !is_inside (custom_kernels.py:34-44): first / last row or column of the map (LOGICAL coordinates)
+__device__ __forceinline__ bool border_cell(const KP& P, int r, int c) { return r <= 0 || r >= P.C - 1 || c <= 0 || c >= P.C - 1; }
 
-// local cell index of global (ix, iy) inside this strip, or -1 if the row is not owned
+// ---- circular origin: logical <-> physical ------------------------------------------------------------------------------
+__device__ __forceinline__ int wrap_up(int v, int C) { return v >= C ? v - C : v; }       // v in [0, 2C)
+__device__ __forceinline__ int wrap_dn(int v, int C) { return v < 0 ? v + C : v; }        // v in [-C, C)
+__device__ __forceinline__ int phys_row(const KP& P, int r) { return wrap_up(r + P.org_r, P.C); }     // r in [0, C)
+__device__ __forceinline__ int phys_col(const KP& P, int c) { return wrap_up(c + P.org_c, P.C); }
+__device__ __forceinline__ int logi_row(const KP& P, int pr) { return wrap_dn(pr - P.org_r, P.C); }
+__device__ __forceinline__ int logi_col(const KP& P, int pc) { return wrap_dn(pc - P.org_c, P.C); }
+// row of the local arrays (halo + owned rows + halo) that holds physical row pr, or -1 if the strip does not hold it
+__device__ __forceinline__ int local_row(const KP& P, int pr) {
+  int rel = pr - P.row0;                                   // owned: [0, nrows); halos continue circularly on both sides
+  if (rel < 0) rel += P.C;
+  if (rel < P.nrows + P.halo) return P.halo + rel;
+  if (rel >= P.C - P.halo) return P.halo - (P.C - rel);
+  return -1;
+}
+// local cell index of LOGICAL (ix, iy), or -1 if this strip does not own the row
 __device__ __forceinline__ long owned_cell(const KP& P, int ix, int iy) {
-  int lr = ix - P.row0;
-  if (lr < 0 || lr >= P.nrows) return -1;
-  return (long)(lr + P.halo) * P.C + iy;
+  int rel = phys_row(P, ix) - P.row0;
+  if (rel < 0 || rel >= P.nrows) return -1;
+  return (long)(rel + P.halo) * P.C + phys_col(P, iy);
+}
+
+// row of the inert bitmap for physical row prow: the logical row on single-strip contexts, else the local (physical) row
+__device__ __forceinline__ int bitmap_row(const KP& P, int prow) { return P.nrows == P.C ? logi_row(P, prow) : prow - P.row0; }
+
+struct Owned { long c; int prow, pcol; };
+__device__ __forceinline__ Owned owned(const KP& P, int ix, int iy) {
+  Owned o; o.prow = phys_row(P, ix); o.pcol = phys_col(P, iy);
+  const int rel = o.prow - P.row0;
+  o.c = (rel < 0 || rel >= P.nrows) ? -1 : (long)(rel + P.halo) * P.C + o.pcol;
+  return o;
+}
+
+// A cell as it is NOW: the pending map shifts replayed on the stored value (shift_map_xy: cells of the entering band are reset,
+// variance to initial_variance; shift_map_z: planes 0 and 5 += dz -- elevation_mapping.py:172-226), in the order they happened.
+// (prow, pcol): PHYSICAL row / column of the cell.  Free when nothing is pending.
+__device__ __forceinline__ void cell_now(const KP& P, float& h, float& v, float& valid, float& trav, float& time, float& upper,
+                                         float& is_upper, int prow, int pcol) {
+  for (int m = 0; m < P.mv.n; ++m) {
+    const int r = wrap_dn(prow - P.mv.org_r[m], P.C), c = wrap_dn(pcol - P.mv.org_c[m], P.C);     // logical position after move m
+    const int sr = P.mv.sr[m], sc = P.mv.sc[m];
+    if ((sr > 0 && r < sr) || (sr < 0 && r >= P.C + sr) || (sc > 0 && c < sc) || (sc < 0 && c >= P.C + sc)) {
+      h = 0.f; v = P.init_var; valid = 0.f; trav = 0.f; time = 0.f; upper = 0.f; is_upper = 0.f;
+    }
+    h += P.mv.dz[m]; upper += P.mv.dz[m];
+  }
 }
 
 __device__ __forceinline__ unsigned int float_ord(float f) {       // monotone map float -> uint
@@ -146,6 +198,14 @@ __device__ __forceinline__ unsigned int float_ord(float f) {       // monotone m
 }
 __device__ __forceinline__ float ord_float(unsigned int o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+__device__ __forceinline__ void cell_now(const KP& P, Cell& m, int prow, int pcol) {
+  if (P.mv.n) cell_now(P, m.h, m.v, m.valid, m.trav, m.time, m.upper, m.is_upper, prow, pcol);
+}
+// (h, v, valid, trav) part only (drift statistics, fusion)
+__device__ __forceinline__ void cell_now(const KP& P, float4& m, int prow, int pcol) {
+  if (P.mv.n) { float time = 0.f, upper = 0.f, is_upper = 0.f; cell_now(P, m.x, m.y, m.z, m.w, time, upper, is_upper, prow, pcol); }
 }
 
 // effects of custom_kernels.py:174 and :189-192 on one cell (-> snapshot S1)

@@ -5,6 +5,7 @@
 // Compiled with -ffp-contract=off: decisions (indices, gates) must be bit-identical to the oracle.
 #include "emap_device.h"
 #include <cstdlib>
+#include <cstring>
 
 // ---------------------------------------------------------------------------------------------------------
 // Phase A: drift statistics + points-per-cell (error_counting_kernel, custom_kernels.py:280-345)
@@ -22,9 +23,11 @@ __global__ __launch_bounds__(EM_BLOCK) void k_count(KP P, Pose T, const float* _
     float rx, ry, rz;
     load_point(pts, i, stride, rx, ry, rz);
     Geo g = geometry<MODE>(P, T, rx, ry, rz);
-    long c = (g.finite && g.valid && g.inside) ? owned_cell(P, g.ix, g.iy) : -1;
+    Owned oc = owned(P, g.ix, g.iy);
+    long c = (g.finite && g.valid && g.inside) ? oc.c : -1;
     if (c >= 0) {
       float4 m = *reinterpret_cast<const float4*>(&cells[c]);   // h, v, valid, trav
+      cell_now(P, m, oc.prow, oc.pcol);
       bool inlier = m.z > 0.5f && (double)fabsf(m.x - g.z) < (double)m.y * P.mt && (double)m.y < P.dcvi_half &&
                     (double)m.w > P.trav_inlier;
       if (inlier) { inl = 1; e_fix = __double2ll_rn((double)(g.z - m.x) * EM_SCALE_E); }
@@ -89,10 +92,12 @@ __global__ __launch_bounds__(EM_BLOCK) void k_fuse(KP P, Pose T, const float* __
   float rx, ry, rz;
   load_point(pts, i, stride, rx, ry, rz);
   Geo g = geometry<MODE>(P, T, rx, ry, rz);
-  long c = (g.finite && g.valid && g.inside) ? owned_cell(P, g.ix, g.iy) : -1;
+  const Owned oc = owned(P, g.ix, g.iy);
+  long c = (g.finite && g.valid && g.inside) ? oc.c : -1;
   if (c < 0) return;
   const float shift = F->shift;
-  float2 hv = *reinterpret_cast<const float2*>(&cells[c]);
+  float4 hv = *reinterpret_cast<const float4*>(&cells[c]);
+  cell_now(P, hv, oc.prow, oc.pcol);
   float map_h = hv.x + shift, map_v = hv.y;
   const unsigned int n_pts = (unsigned int)(acc[c].pts_inl & 0xffffffffull);
   float num_points = (float)n_pts;
@@ -123,23 +128,27 @@ __global__ __launch_bounds__(EM_BLOCK) void k_fuse(KP P, Pose T, const float* __
 // Also emits the "inert" bitmap (1 bit per owned cell: known AND updated recently).  A ray step on such a cell cannot
 // have any effect (custom_kernels.py:228-237), so k_rays tests the bit (128 KB for a 1024^2 map, cache resident)
 // instead of gathering the 32-byte cell.  Border cells (is_inside false, :34-44 -- rays never act there) are marked inert too, which
-// is how k_rays implements `if (!is_inside(nidx)) continue` (:211) without a test of its own.  Layout: one row of ceil(C / 64) 64-bit words per map row (a 64-column tile segment of a
+// is how k_rays implements `if (!is_inside(nidx)) continue` (:211) without a test of its own.  The bitmap is indexed by LOGICAL
+// column and, on single-strip contexts, logical row (strips: local physical row) -- what the march has at hand (bitmap_row).  Layout: one row of ceil(C / 64) 64-bit words per map row (a 64-column tile segment of a
 // row is exactly one word, so the tile kernel can store a wave ballot); grid: x = 64-column groups, y = rows, one wave per word.
 __global__ __launch_bounds__(64) void k_commit(KP P, Cell* __restrict__ cells, const AccF* __restrict__ acc,
                                                const FrameDev* __restrict__ F, unsigned long long* __restrict__ inert) {
-  const int lrow = blockIdx.y, col = blockIdx.x * 64 + threadIdx.x;
+  // one wave = 64 LOGICAL columns of one owned physical row (so that its ballot is one aligned word of the logical bitmap)
+  const int lrow = blockIdx.y, lcol = blockIdx.x * 64 + threadIdx.x, prow = P.row0 + lrow;
   bool quiet = false;
-  if (col < P.C) {
-    const long c = (long)(lrow + P.halo) * P.C + col;
+  if (lcol < P.C) {
+    const int pcol = phys_col(P, lcol);
+    const long c = (long)(lrow + P.halo) * P.C + pcol;
     Cell m = cells[c];
+    cell_now(P, m, prow, pcol);                   // pending map shifts are written out here
     AccF a = acc[c];
     m.h += F->shift;
     commit_cell(P, m, a);
     cells[c] = m;
-    quiet = (!(m.valid < 0.5f) && m.time < 0.5f) || border_cell(P, lrow + P.row0, col);
+    quiet = (!(m.valid < 0.5f) && m.time < 0.5f) || border_cell(P, logi_row(P, prow), lcol);
   }
   const unsigned long long bits = __ballot(quiet);
-  if (threadIdx.x == 0) inert[(long)lrow * gridDim.x + blockIdx.x] = bits;
+  if (threadIdx.x == 0) inert[(long)bitmap_row(P, prow) * gridDim.x + blockIdx.x] = bits;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -164,7 +173,7 @@ __device__ __forceinline__ void ray_upper_min(unsigned int* key_ptr, float nz) {
 // Cell index of a sample coordinate along one axis.  IDX selects how:
 //   0  the defining arithmetic (axis_idx: the reference's fp64 expression in reference_fp16 mode)
 //   1  reference_fp16 only: host-built table over the half bit pattern, staged in LDS (exact by construction)
-//   2  reference_fp16 only: one float fma + clamp + truncation on the half-rounded coordinate -- the host proves it equal to the
+//   2  reference_fp16 only: one float fma + clamp + truncation (+ one patch) on the half-rounded coordinate -- the host proves it equal to the
 //      defining arithmetic for EVERY half bit pattern before selecting it (emap_api.hip: build_ray_tables), 5 VALU, no LDS
 template <int MODE, int IDX> struct AxisIdx {
   const unsigned short* t; unsigned int lo_m1, hi, span;   // IDX 1: per sign [small, idx(lo..hi-1), big]
@@ -176,8 +185,10 @@ template <int MODE, int IDX> struct AxisIdx {
       return (int)t[(sg ? span : 0u) + m];
     } else if constexpr (IDX == 2) {
       const float q = (float)(_Float16)x;
-      const float v = __builtin_amdgcn_fmed3f(__builtin_fmaf(q, P.inv_res_f, P.half_w_f), 0.0f, P.cm1_f);
-      return (int)v;
+      const float v = __builtin_fmaf(q, P.inv_res_f, P.half_w_f);
+      // the one place where the single fp32 rounding differs from the reference's double: a tiny negative coordinate, whose sum
+      // rounds UP to exactly C/2 (the double stays just below it and truncates to C/2 - 1)
+      return (int)__builtin_amdgcn_fmed3f(v, 0.0f, P.cm1_f) - (((q < 0.0f) & (v == P.half_w_f)) ? 1 : 0);
     } else return axis_idx<MODE>(P, Qf<MODE>(x));
   }
 };
@@ -198,8 +209,10 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // samples with s_k < ray_length (binary search once per ray instead of a compare + break per step), kb > 0 only on row strips.
 // Per step and lane: 4 VALU for the sample position, the two axis indices, one mad for the flat index, the same-cell / inside /
 // range predicate, one bitmap bit; everything else happens only for the few cells that are neither known-and-fresh nor out.
+// (launch bounds: 8 waves per SIMD, i.e. two 1024-thread workgroups per CU -- measured: with 82 instead of 70 SGPRs the kernel
+// silently dropped to one workgroup per CU and ran 13 % slower)
 template <int MODE, bool STATS, int IDX, bool STRIP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const float* __restrict__ pts, long n, int stride,
+__global__ __launch_bounds__(BLOCK, 8) void k_rays(KP P, Pose T, RayTab Rt, const float* __restrict__ pts, long n, int stride,
                                                  const Cell* __restrict__ cells,
                                                  AccR* __restrict__ accr, const float* __restrict__ normal,
                                                  long plane_stride, FrameDev* __restrict__ F,
@@ -246,20 +259,24 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
       // float16 rounding of the sample position can move a cell, and it lets the same-cell test warm up before the first
       // owned row exactly as in the full march); the per-sample ownership test stays.
       if (STRIP) {
-        const float xlo = (float)(((double)(P.row0 - 2) - P.half_w) * P.res), xhi = (float)(((double)(P.row0 + P.nrows + 2) - P.half_w) * P.res);
-        float s_lo = -INFINITY, s_hi = INFINITY;
-        if (fabsf(rx) > 1e-6f) {
-          const float a = (xlo - T.t[0]) / rx, b = (xhi - T.t[0]) / rx;
-          s_lo = fminf(a, b); s_hi = fmaxf(a, b);
-        } else if (T.t[0] < xlo || T.t[0] > xhi) s_hi = -INFINITY;
-        s_lo -= 2.0f * P.q_step; s_hi += 2.0f * P.q_step;
-        lo = 0; hi = nS;                                        // first k with S[k] >= s_lo
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sS[mid] < s_lo) lo = mid + 1; else hi = mid; }
-        kb = lo;
-        hi = nS;                                                // first k with S[k] > s_hi
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sS[mid] <= s_hi) lo = mid + 1; else hi = mid; }
-        ke = min(ke, lo);
-        if (ke <= kb) { kb = 0x7fffffff; ke = 0; }
+        // the owned PHYSICAL rows are the logical rows [ls, ls + nrows) mod C; when that interval wraps the whole ray is marched
+        const int ls = logi_row(P, P.row0);
+        if (ls + P.nrows <= C) {
+          const float xlo = (float)(((double)(ls - 2) - P.half_w) * P.res), xhi = (float)(((double)(ls + P.nrows + 2) - P.half_w) * P.res);
+          float s_lo = -INFINITY, s_hi = INFINITY;
+          if (fabsf(rx) > 1e-6f) {
+            const float a = (xlo - T.t[0]) / rx, b = (xhi - T.t[0]) / rx;
+            s_lo = fminf(a, b); s_hi = fmaxf(a, b);
+          } else if (T.t[0] < xlo || T.t[0] > xhi) s_hi = -INFINITY;
+          s_lo -= 2.0f * P.q_step; s_hi += 2.0f * P.q_step;
+          lo = 0; hi = nS;                                        // first k with S[k] >= s_lo
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (sS[mid] < s_lo) lo = mid + 1; else hi = mid; }
+          kb = lo;
+          hi = nS;                                                // first k with S[k] > s_hi
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (sS[mid] <= s_hi) lo = mid + 1; else hi = mid; }
+          ke = min(ke, lo);
+          if (ke <= kb) { kb = 0x7fffffff; ke = 0; }
+        }
       }
     }
   }
@@ -282,7 +299,8 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
   auto work = [&](int first, int count) {       // visits [first, first + count), count <= 64; executed by the whole wave
     const bool has = lane < count;
     const unsigned int xy = has ? qc[first + lane] : 0u;
-    const unsigned int lrow = (xy >> 16) - (unsigned int)P.row0, col = xy & 0xffffu;             // owned row of the strip, column
+    const int lix = (int)(xy >> 16), liy = (int)(xy & 0xffffu);                                   // logical cell of the visit
+    const unsigned int lrow = (unsigned int)(phys_row(P, lix) - P.row0), col = (unsigned int)phys_col(P, liy);   // owned (physical) row, column
     const unsigned int c = (lrow + (unsigned int)P.halo) * (unsigned int)C + col;
     const float s = has ? qz[first + lane] : 0.f;
     const int src = has ? (int)ql[first + lane] : lane;
@@ -305,7 +323,11 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
     }
     if (m1.x < 0.5f) return;                   // updated recently (:236)
     if ((double)m0.x > (double)nz + 0.01 - fmin((double)m0.y, 1.0) * 0.05) {
-      const float ip = erx * Qf<MODE>(normal[c]) + ery * Qf<MODE>(normal[plane_stride + c]) + erz * Qf<MODE>(normal[2 * plane_stride + c]);
+      // the normal planes keep the origin they were written with (the reference does not shift normal_map): logical -> their rows
+      float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+      const int nlr = local_row(P, wrap_up(lix + P.norg_r, C));
+      if (nlr >= 0) { const long cn = (long)nlr * C + wrap_up(liy + P.norg_c, C); n0 = normal[cn]; n1 = normal[plane_stride + cn]; n2 = normal[2 * plane_stride + cn]; }
+      const float ip = erx * Qf<MODE>(n0) + ery * Qf<MODE>(n1) + erz * Qf<MODE>(n2);
       if (fabsf(ip) < Rt.f_cos_thresh) return;
       const float n_inl = (float)inl[(long)c * inl_stride];      // newmap[3]: drift inliers of this frame in the cell
       if (n_inl > Rt.f_wall && m1.x < 1.0f) return;
@@ -328,9 +350,11 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
     // own sample & new cell (:209-210) [& owned by this strip]; border cells (:211) read as inert in the bitmap
     // (measured: fetching the bitmap word unconditionally -- branch free -- is 10 % slower than this guarded form)
     bool act;
+    unsigned int brow = (unsigned int)ix;                       // bitmap row: the logical row ...
     if (STRIP) {
       const bool mine = (unsigned int)(k - kb) < (unsigned int)(ke - kb);
-      act = mine & (nidx != last) & ((unsigned int)(ix - P.row0) < (unsigned int)P.nrows);
+      brow = (unsigned int)(phys_row(P, ix) - P.row0);          // ... or, on strips, the local physical row (also the ownership test)
+      act = mine & (nidx != last) & (brow < (unsigned int)P.nrows);
       last = mine ? nidx : last;
     } else {
       act = (k < ke) & (nidx != last);                          // (a lane beyond its last sample never acts again: `last` may run on)
@@ -339,7 +363,7 @@ __global__ __launch_bounds__(BLOCK) void k_rays(KP P, Pose T, RayTab Rt, const f
     bool need = false;
     if (act) {
       if (STATS) visits += (max((unsigned int)(ix - 1), (unsigned int)(iy - 1)) < (unsigned int)(C - 2)) ? 1u : 0u;
-      const unsigned int off = __umul24((unsigned int)(STRIP ? ix - P.row0 : ix), wpr32 * 4u) + (((unsigned int)iy >> 3) & ~3u);   // byte offset of the word
+      const unsigned int off = __umul24(brow, wpr32 * 4u) + (((unsigned int)iy >> 3) & ~3u);   // byte offset of the word
       const unsigned int w = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(inert) + off);
       need = __builtin_amdgcn_ubfe(w, (unsigned int)iy, 1u) == 0u;     // bit iy & 31 clear: not (known + fresh), something may happen
     }
@@ -377,7 +401,10 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cell* __restrict__ c
   long c = li + (long)P.halo * P.C;
   Cell m = cells[c];
   AccF a = acc[c];
-  if (!COMMITTED) { m.h += F->shift; commit_cell(P, m, a); }
+  if (!COMMITTED) {
+    if (P.mv.n) { const int lrow = (int)(li / P.C); cell_now(P, m, P.row0 + lrow, (int)(li - (long)lrow * P.C)); }     // pending map shifts
+    m.h += F->shift; commit_cell(P, m, a);
+  }
   if (RAYS) {
     AccR r = accr[c];
     if (r.hits) { m.valid = m.valid + (float)((double)r.dec / EM_SCALE_V); m.v = m.v + P.ov_f * (float)r.hits; }
@@ -395,9 +422,11 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cell* __restrict__ c
 // a 16-byte stream over the ray accumulators with a read-modify-write of the few touched cells: validity decrement + variance
 // inflation (custom_kernels.py:251-252), upper bound (:230-233, :254-255), then average_map_kernel's reset of cells whose
 // validity fell below 0.5 (:380-384); re-arms the accumulators.
-__global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cell* __restrict__ cells, AccR* __restrict__ accr) {
+__global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cell* __restrict__ cells, AccR* __restrict__ accr,
+                                                        unsigned long long* __restrict__ inert) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
+  if (li < (long)P.nrows * ((P.C + 63) / 64)) inert[li] = 0ull;      // the rays are done with the bitmap: leave it zeroed for the tile kernel's ORs
   long c = li + (long)P.halo * P.C;
   const AccR r = accr[c];
   if (!(r.hits | r.upper_key)) return;
@@ -424,183 +453,40 @@ __global__ __launch_bounds__(EM_BLOCK) void k_overlap(KP P, Cell* __restrict__ c
   if (ch) cells[c] = m;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// dilation_filter_kernel (custom_kernels.py:392-449) as an LDS-tiled stencil: input plane = upper_bound,
-// mask = is_valid + is_upper_bound (elevation_mapping.py:377-383).  A 16x64 tile (+halo d) of (value, mask)
-// is staged in LDS from the 32-B cells with coalesced 2x dwordx4 loads.  The reference addresses neighbours
-// by FLAT index (i + W*dy + dx), so columns within d of the left/right edge can wrap into the adjacent row:
-// those few columns take an exact global-memory path.
-// Output rows: local rows [lr0, lr1) (owned rows, widened by 3 at strip seams for the traversability halo).
-// ---------------------------------------------------------------------------------------------------------
-#define DT_R 16
-#define DT_C 64
-__global__ __launch_bounds__(EM_BLOCK) void k_dilate(KP P, const Cell* __restrict__ cells, float* __restrict__ out,
-                                                      int d, int lr0, int lr1) {
-  extern __shared__ float lds[];
-  const int W = DT_C + 2 * d, pitch = W + 1, H = DT_R + 2 * d;
-  float* sval = lds;
-  float* smsk = lds + (size_t)H * pitch;
-  const int C = P.C;
-  const int tile_r = lr0 + blockIdx.y * DT_R, tile_c = blockIdx.x * DT_C;   // local row / col of tile origin
-  const int total_rows = P.nrows + 2 * P.halo;
-  const int tc = threadIdx.x & 63, col = tile_c + tc, wv = threadIdx.x >> 6;
-  // pass 0: every thread reads its own DT_R/4 cells (coalesced 2x dwordx4); in the steady state every cell is known
-  // (mask >= 0.5) and the tile is a pure copy -- the LDS stencil is only staged for tiles that contain a hole.
-  float own_val[DT_R / 4], own_msk[DT_R / 4];
-  int hole = 0;
-#pragma unroll
-  for (int k = 0; k < DT_R / 4; ++k) {
-    int lr = tile_r + wv + 4 * k;
-    own_val[k] = 0.f; own_msk[k] = 1.f;
-    if (col < C && lr < lr1) {
-      const float4* cp = reinterpret_cast<const float4*>(&cells[(long)lr * C + col]);
-      float4 m0 = cp[0], m1 = cp[1];
-      own_val[k] = m1.y; own_msk[k] = m0.z + m1.z;
-      hole |= (own_msk[k] < 0.5f);
-    }
-  }
-  if (!__syncthreads_or(hole)) {
-#pragma unroll
-    for (int k = 0; k < DT_R / 4; ++k) {
-      int lr = tile_r + wv + 4 * k;
-      if (col < C && lr < lr1) out[(long)lr * C + col] = own_val[k];
-    }
-    return;
-  }
-  // stage (value, mask & is_inside) of the tile + halo d.  The 16x64 interior is already in registers (pass 0);
-  // only the halo ring is fetched.  The reference addresses neighbours by FLAT index (i + W*dy + dx,
-  // custom_kernels.py:403-407): a column left of 0 is the tail of the previous row, a column right of C-1 the head
-  // of the next row -- staged exactly like that.
-#pragma unroll
-  for (int k = 0; k < DT_R / 4; ++k) {
-    const int tr = wv + 4 * k, lr = tile_r + tr, gr = lr - P.halo + P.row0;
-    const bool in = col < C && lr < lr1 && gr >= 1 && gr <= C - 2 && col >= 1 && col <= C - 2;
-    sval[(tr + d) * pitch + tc + d] = own_val[k];
-    smsk[(tr + d) * pitch + tc + d] = in ? own_msk[k] : 0.f;
-  }
-  const bool full_tile = tile_c + DT_C <= C && tile_r + DT_R <= lr1;   // interior fully covered by pass 0
-  for (int r = wv; r < H; r += EM_BLOCK / 64) {
-    const bool mid = full_tile && r >= d && r < d + DT_R;
-    for (int cc = tc; cc < W; cc += 64) {
-      if (mid && cc >= d && cc < d + DT_C) continue;
-      int lr = tile_r - d + r, cl = tile_c - d + cc;
-      if (cl < 0) { cl += C; lr -= 1; } else if (cl >= C) { cl -= C; lr += 1; }
-      const int gr = lr - P.halo + P.row0;
-      float val = 0.f, msk = 0.f;
-      if (lr >= 0 && lr < total_rows && gr >= 1 && gr <= C - 2 && cl >= 1 && cl <= C - 2) {   // is_inside(j)
-        const float4* cp = reinterpret_cast<const float4*>(&cells[(long)lr * C + cl]);
-        float4 m0 = cp[0], m1 = cp[1];
-        val = m1.y; msk = m0.z + m1.z;
-      }
-      sval[r * pitch + cc] = val; smsk[r * pitch + cc] = msk;
-    }
-  }
-  __syncthreads();
-  if (col >= C) return;
-#pragma unroll
-  for (int k = 0; k < DT_R / 4; ++k) {
-    const int tr = wv + 4 * k, lr = tile_r + tr;
-    if (lr >= lr1) break;
-    float res = own_val[k];
-    if (own_msk[k] < 0.5f) {
-      // The reference scans dy, dx ascending and keeps the FIRST neighbour with the smallest SIGNED dx+dy
-      // (custom_kernels.py:429-436).  Equivalent order: anti-diagonals s = dx+dy ascending, dy ascending inside one --
-      // the first hit wins, so a hole next to known cells costs 1-3 LDS probes instead of (2d+1)^2.
-      bool found = false;
-      for (int s2 = -2 * d; s2 <= 2 * d && !found; ++s2) {
-        const int dy0 = max(-d, s2 - d), dy1 = min(d, s2 + d);
-        for (int dy = dy0; dy <= dy1; ++dy) {
-          const int o = (tr + d + dy) * pitch + (tc + d + (s2 - dy));
-          if (smsk[o] > 0.5f) { res = sval[o]; found = true; break; }
-        }
-      }
-    }
-    out[(long)lr * C + col] = res;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// (The 12 x 9 taps are explicit fmaf chains in a fixed order: the same bytes from k_trav_normal and k_post, half the
-// VALU instructions of separate mul + add; the reference's cuDNN summation order is unspecified, tolerance 1e-5.)
-// traversability filter (traversability_filter.py:8-47: three dilated 3x3 correlations x 4 channels, abs,
-// 1x1, exp(-x); elevation_mapping.py:385-388) fused with normal_filter_kernel (custom_kernels.py:452-506):
-// both consume the dilated plane, so one LDS tile (halo 3) feeds both.  Weights live in kernargs (SGPRs).
-// ---------------------------------------------------------------------------------------------------------
-struct TravW { float w[3][36]; float wo[12]; };
-#define TT_R 16
-#define TT_C 64
-__global__ __launch_bounds__(EM_BLOCK) void k_trav_normal(KP P, TravW Wt, const float* __restrict__ in, Cell* __restrict__ cells,
-                                                           float* __restrict__ normal, long plane_stride) {
-  __shared__ float tile[(TT_R + 6) * (TT_C + 6 + 1)];
-  const int pitch = TT_C + 6 + 1, C = P.C;
-  const int tile_r = P.halo + blockIdx.y * TT_R, tile_c = blockIdx.x * TT_C;
-  const int total_rows = P.nrows + 2 * P.halo;
-  for (int k = threadIdx.x; k < (TT_R + 6) * (TT_C + 6); k += EM_BLOCK) {
-    int r = k / (TT_C + 6), cc = k % (TT_C + 6);
-    int lr = tile_r - 3 + r, col = tile_c - 3 + cc;
-    float v = 0.f;
-    if (lr >= 0 && lr < total_rows && col >= 0 && col < C) v = in[(long)lr * C + col];
-    tile[r * pitch + cc] = v;
-  }
-  __syncthreads();
-  const int tc = threadIdx.x & 63, col = tile_c + tc;
-  if (col >= C) return;
-  for (int tr = threadIdx.x >> 6; tr < TT_R; tr += EM_BLOCK / 64) {
-    int lr = tile_r + tr;
-    if (lr >= P.halo + P.nrows) break;
-    int gr = lr - P.halo + P.row0;
-    long c = (long)lr * C + col;
-    const float* t0 = &tile[(tr + 3) * pitch + (tc + 3)];
-    if (gr >= 3 && gr <= C - 4 && col >= 3 && col <= C - 4) {
-      float acc = 0.f;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int dl = k + 1;
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-          float s = 0.f;
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) s = fmaf(Wt.w[k][ch * 9 + a * 3 + b], t0[(a - 1) * dl * pitch + (b - 1) * dl], s);
-          acc = fmaf(Wt.wo[k * 4 + ch], fabsf(s), acc);
-        }
-      }
-      cells[c].trav = expf(-acc);
-    }
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (gr >= 1 && gr <= C - 3 && col >= 1 && col <= C - 3 && cells[c].valid > 0.5f) {
-      float h = t0[0], dzdx = t0[1] - h, dzdy = t0[pitch] - h;
-      float ax = -dzdy / P.res_f, ay = -dzdx / P.res_f;
-      float nrm = sqrtf((ax * ax) + (ay * ay) + 1.0f);
-      nx = ax / nrm; ny = ay / nrm; nz = 1.0f / nrm;
-    }
-    normal[c] = nx; normal[plane_stride + c] = ny; normal[2 * plane_stride + c] = nz;
-  }
-}
+// (The 12 x 9 taps are explicit fma chains in a fixed order; the reference's cuDNN summation order is unspecified, tolerance 1e-5.)
+struct TravW { float w[3][36]; float wo[12]; };   // weights of the traversability filter (traversability_filter.py:8-47) as kernargs (SGPRs)
 
 // ---------------------------------------------------------------------------------------------------------
 // k_post = dilation -> traversability filter + normals in ONE launch (elevation_mapping.py:376-391).  The dilated
 // plane only ever feeds these two stencils, so the tile (+3 halo) of dilated values is produced in LDS from a raw
 // (value, mask) tile (+3+d halo) and consumed in place; `traversability_input` is still written (interior only)
-// because it is a readable attribute of the reference class.  Semantics identical to k_dilate + k_trav_normal.
+// because it is a readable attribute of the reference class.
 // ---------------------------------------------------------------------------------------------------------
 #define PT_C 64
 #define PT_THREADS 512   /* 8 waves per tile: the kernel is latency/issue bound, 32 resident waves per CU hide it */
 #define PT_WAVES (PT_THREADS / 64)
 // PT_R = tile height: 16 for large maps (less halo amplification), 4 for small maps (4x more workgroups: a robot-scale
 // 200^2 map has only 52 tiles of 16 rows and the kernel time is then one workgroup's latency chain).
-template <int PT_R>
+// Rows are LOGICAL map rows here (the stencils are defined on the logical map; a tile never straddles the circular seam because
+// the launcher hands over logical row intervals [seg_b, seg_e)): local_row(phys_row(.)) / phys_col(.) place a cell in memory.
+// STAGE 0: everything; 1: dilation only (traversability_input), the separately callable stage of the parity tests.
+// Up to four logical row intervals per launch (a strip's rows around the circular seam, the boundary rows of a strip): a launch of a
+// few tiles alone costs a whole workgroup latency chain (~18 us measured), so the pieces go into ONE grid.
+struct PostSegs { int n, b[4], e[4], t0[4]; };     // interval [b, e) starts at tile row t0 of the grid
+template <int PT_R, int STAGE>
 __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __restrict__ cells, float* __restrict__ trav_in,
-                                                    float* __restrict__ normal, long plane_stride, int d, int tile_row0) {
+                                                    float* __restrict__ normal, long plane_stride, int d, PostSegs S) {
+  int seg_b = S.b[0], seg_e = S.e[0], ty = blockIdx.y;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) if (k < S.n && (int)blockIdx.y >= S.t0[k]) { seg_b = S.b[k]; seg_e = S.e[k]; ty = blockIdx.y - S.t0[k]; }
   extern __shared__ float lds[];
   const int RW = PT_C + 6 + 2 * d, rp = RW + 1, RH = PT_R + 6 + 2 * d;     // staged (value, mask) region: tile + halo 3 + d
   const int DW = PT_C + 6, DH = PT_R + 6;                                   // region whose DILATED value is needed (halo 3)
   float* rval = lds;                     // raw upper_bound; holes inside the DW x DH region are overwritten by their dilated value
   float* rmsk = rval + RH * rp;          // mask >= 0; stored as -(mask)-1 when the cell is NOT is_inside (never a source)
   float* sval = rmsk + RH * rp;          // is_valid of the PT_R x PT_C interior (normal filter)
-  const int C = P.C, total_rows = P.nrows + 2 * P.halo;
-  const int tile_r = P.halo + (tile_row0 + (int)blockIdx.y) * PT_R, tile_c = blockIdx.x * PT_C;
+  const int C = P.C;
+  const int tile_r = seg_b + ty * PT_R, tile_c = blockIdx.x * PT_C;      // logical row / column of the tile origin
   const int tc = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave index in an SGPR: row terms are scalar
   // staging.  The first 64 columns of the region go row-wise (one wave per region row, lane = column: the row terms are wave
   // uniform, a cell costs a handful of vector instructions), the remaining 6 + 2d columns as a linear walk over (row, column)
@@ -611,12 +497,14 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
     const int r0 = tile_r - 3 - d, c0 = tile_c - 3 - d, EC = RW - 64;
     const int etotal = RH * EC;
     const unsigned int emagic = (unsigned int)((0x100000000ull + (unsigned long long)EC - 1ull) / (unsigned long long)EC);
-    auto locate = [&](int r, int cc, int& lr, int& cl, bool& ok, bool& inside) {     // region (r, cc) -> local row, column, flags
-      lr = r0 + r; cl = c0 + cc;
-      if (cl < 0) { cl += C; lr -= 1; } else if (cl >= C) { cl -= C; lr += 1; }      // flat-index row wrap (:403-407)
-      const int gr = lr - P.halo + P.row0;
-      ok = lr >= 0 && lr < total_rows && gr >= 0 && gr <= C - 1;
+    auto locate = [&](int r, int cc, long& ci, bool& ok, bool& inside) {     // region (r, cc) -> cell index, flags
+      int gr = r0 + r, cl = c0 + cc;
+      if (cl < 0) { cl += C; gr -= 1; } else if (cl >= C) { cl -= C; gr += 1; }      // flat-index row wrap (:403-407)
+      const bool in_map = gr >= 0 && gr <= C - 1;
+      const int lrow = in_map ? local_row(P, phys_row(P, gr)) : -1;
+      ok = lrow >= 0;
       inside = gr >= 1 && gr <= C - 2 && cl >= 1 && cl <= C - 2;
+      ci = (long)lrow * C + phys_col(P, in_map ? cl : 0);
     };
     for (int rb = 0, eb = 0; rb < RH || eb < etotal; rb += PT_WAVES * JB, eb += PT_THREADS * EU) {
       float fv[JB + EU]; float2 fu[JB + EU]; int ol[JB + EU], os[JB + EU]; bool okk[JB + EU], ins[JB + EU];
@@ -628,15 +516,15 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
           const int e = eb + (u - JB) * PT_THREADS + (int)threadIdx.x;
           r = (int)__umulhi((unsigned int)e, emagic); cc = 64 + e - r * EC; have = e < etotal;
         }
-        int lr, cl;
-        locate(r, cc, lr, cl, okk[u], ins[u]);
+        long ci;
+        locate(r, cc, ci, okk[u], ins[u]);
         okk[u] = okk[u] && have;
         ol[u] = have ? r * rp + cc : -1;
         const int ir = r - 3 - d, ic = cc - 3 - d;
         os[u] = (ir >= 0 && ir < PT_R && ic >= 0 && ic < PT_C) ? ir * PT_C + ic : -1;
         fv[u] = 0.f; fu[u] = make_float2(0.f, 0.f);
         if (okk[u]) {
-          const float* cp = reinterpret_cast<const float*>(&cells[(long)lr * C + cl]);
+          const float* cp = reinterpret_cast<const float*>(&cells[ci]);
           fv[u] = cp[2];                                                       // Cell: h v valid trav | time upper is_upper pad
           fu[u] = *reinterpret_cast<const float2*>(cp + 5);
         }
@@ -685,8 +573,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
     }
   }
   __syncthreads();
-  const int col = tile_c + tc;
+  const int col = tile_c + tc;                   // logical column
   if (col >= C) return;
+  const int pcol = phys_col(P, col);
   const float* dil = rval + d * rp + d;          // dilated plane of the DW x DH region, pitch rp
   const int dp = rp;
   // Every wave owns PT_R / 8 consecutive tile rows of its column.  Rows are processed in PAIRS with packed fp32 FMAs
@@ -695,10 +584,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
   typedef float v2f __attribute__((ext_vector_type(2)));
   constexpr int RPW = PT_R >= PT_WAVES ? PT_R / PT_WAVES : 1;
   auto finish_row = [&](int tr, float acc, bool have_acc) {      // traversability, normal, plane writes of one tile row
-    const int lr = tile_r + tr, gr = lr - P.halo + P.row0;
-    const long c = (long)lr * C + col;
+    const int gr = tile_r + tr;
+    const long c = (long)local_row(P, phys_row(P, gr)) * C + pcol;
     const float* t0 = &dil[(tr + 3) * dp + (tc + 3)];
     trav_in[c] = t0[0];
+    if (STAGE == 1) return;
     if (have_acc) cells[c].trav = expf(-acc);
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (gr >= 1 && gr <= C - 3 && col >= 1 && col <= C - 3 && sval[tr * PT_C + tc] > 0.5f) {
@@ -709,14 +599,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
     }
     normal[c] = nx; normal[plane_stride + c] = ny; normal[2 * plane_stride + c] = nz;
   };
-  const bool col_in = col >= 3 && col <= C - 4;
+  const bool col_in = STAGE == 0 && col >= 3 && col <= C - 4;
   if constexpr (RPW % 2 == 0) {
 #pragma unroll
     for (int k = 0; k < RPW / 2; ++k) {
-      const int tr = wv * RPW + 2 * k;
-      if (tile_r + tr >= P.halo + P.nrows) break;
-      const bool row1 = tile_r + tr + 1 < P.halo + P.nrows;
-      const int gr = tile_r + tr - P.halo + P.row0;
+      const int tr = wv * RPW + 2 * k, gr = tile_r + tr;
+      if (gr >= seg_e) break;
+      const bool row1 = gr + 1 < seg_e;
       const bool in0 = col_in && gr >= 3 && gr <= C - 4, in1 = col_in && row1 && gr + 1 >= 3 && gr + 1 <= C - 4;
       v2f acc = {0.f, 0.f};
       if (in0 || in1) {
@@ -747,9 +636,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
   } else {
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
-      const int tr = wv * RPW + k;
-      if (tr >= PT_R || tile_r + tr >= P.halo + P.nrows) break;
-      const int gr = tile_r + tr - P.halo + P.row0;
+      const int tr = wv * RPW + k, gr = tile_r + tr;
+      if (tr >= PT_R || gr >= seg_e) break;
       const bool in0 = col_in && gr >= 3 && gr <= C - 4;
       float acc = 0.f;
       if (in0) {
@@ -778,6 +666,15 @@ __global__ __launch_bounds__(EM_BLOCK) void k_var_time(KP P, Cell* __restrict__ 
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
   Cell* m = &cells[li + (long)P.halo * P.C];
+  if (P.mv.n) {                                   // pending map shifts: the whole cell is written out first (uniform branch)
+    const int lrow = (int)(li / P.C);
+    Cell c = *m;
+    cell_now(P, c, P.row0 + lrow, (int)(li - (long)lrow * P.C));
+    if (do_var) c.v = c.v + P.time_var * c.valid;
+    if (do_time) c.time = c.time + P.time_int;
+    *m = c;
+    return;
+  }
   if (do_var) m->v = m->v + P.time_var * m->valid;
   if (do_time) m->time = m->time + P.time_int;
 }
@@ -792,13 +689,12 @@ __global__ __launch_bounds__(EM_BLOCK) void k_publish(KP P, const Cell* __restri
   long k = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (k >= (long)M * M) return;
   const int orow = (int)(k / M), ocol = (int)(k % M);
-  const int r = M - orow, c = M - ocol;                 // flip of the [1:-1, 1:-1] view: source cell (r, c) in [1, C-2]
-  const long ci = (long)(r + P.halo) * C + c;
+  const int r = M - orow, c = M - ocol;                 // flip of the [1:-1, 1:-1] view: source cell (r, c) in [1, C-2], logical
   const float nanv = __uint_as_float(0x7fc00000u);
   float v;
-  if (kind >= 6) v = normal[(long)(kind - 6) * plane_stride + ci];
+  if (kind >= 6) v = normal[(long)(kind - 6) * plane_stride + (long)wrap_up(r + P.norg_r, C) * C + wrap_up(c + P.norg_c, C)];
   else {
-    const Cell m = cells[ci];
+    const Cell m = cells[(long)(phys_row(P, r) + P.halo) * C + phys_col(P, c)];
     switch (kind) {
       case 0: v = m.valid > 0.5f ? m.h + center_z : nanv; break;
       case 1: v = m.v; break;
@@ -814,15 +710,52 @@ __global__ __launch_bounds__(EM_BLOCK) void k_publish(KP P, const Cell* __restri
 }
 
 // ---- state access helpers --------------------------------------------------------------------------------
+// External views are in the order of the strip's LOGICAL rows (row j of the view = logical row logi_row(row0) + j, wrapping) and
+// logical columns; (org_r, org_c) = origin of the array being viewed (cells and semantic layers: the map origin; normal planes and
+// traversability_input: the origin they were written with).
+__device__ __forceinline__ long view_cell(const KP& P, long li, int org_r, int org_c) {
+  const int j = (int)(li / P.C), c = (int)(li - (long)j * P.C);
+  const int r = P.nrows == P.C ? j : wrap_up(logi_row(P, P.row0) + j, P.C);   // logical row (a full map is viewed from logical row 0)
+  const int lr = local_row(P, wrap_up(r + org_r, P.C));
+  return lr < 0 ? -1 : (long)lr * P.C + wrap_up(c + org_c, P.C);
+}
 __global__ __launch_bounds__(EM_BLOCK) void k_get_plane(KP P, const Cell* __restrict__ cells, int word, float* __restrict__ out) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
-  out[li] = reinterpret_cast<const float*>(&cells[li + (long)P.halo * P.C])[word];
+  out[li] = reinterpret_cast<const float*>(&cells[view_cell(P, li, P.org_r, P.org_c)])[word];
 }
 __global__ __launch_bounds__(EM_BLOCK) void k_set_plane(KP P, Cell* __restrict__ cells, int word, const float* __restrict__ in) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
-  reinterpret_cast<float*>(&cells[li + (long)P.halo * P.C])[word] = in[li];
+  reinterpret_cast<float*>(&cells[view_cell(P, li, P.org_r, P.org_c)])[word] = in[li];
+}
+// planar float arrays (semantic layers, normal planes, traversability_input): gather / scatter between the view and the array
+__global__ __launch_bounds__(EM_BLOCK) void k_plane_view(KP P, int org_r, int org_c, float* __restrict__ plane, float* __restrict__ view, int to_plane) {
+  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (li >= (long)P.nrows * P.C) return;
+  const long c = view_cell(P, li, org_r, org_c);
+  if (to_plane) { if (c >= 0) plane[c] = view[li]; }
+  else view[li] = c >= 0 ? plane[c] : 0.0f;        // rows this strip does not hold (normals written before a row shift): 0
+}
+// writes the pending map shifts into every owned cell (one full pass; needed only when something reads the map between a
+// move and the next frame)
+__global__ __launch_bounds__(EM_BLOCK) void k_materialize(KP P, Cell* __restrict__ cells) {
+  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (li >= (long)P.nrows * P.C) return;
+  const int lrow = (int)(li / P.C);
+  Cell* p = &cells[li + (long)P.halo * P.C];
+  Cell m = *p;
+  cell_now(P, m, P.row0 + lrow, (int)(li - (long)lrow * P.C));
+  *p = m;
+}
+// zero-fills the band that a roll by (sr, sc) brought in (SemanticMap.shift_map_xy, semantic_map.py:127-136) in `nl` planes
+__global__ __launch_bounds__(EM_BLOCK) void k_band_clear(KP P, float* __restrict__ planes, int nl, long plane_stride, int sr, int sc) {
+  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (li >= (long)P.nrows * P.C) return;
+  const int lrow = (int)(li / P.C), pcol = (int)(li - (long)lrow * P.C);
+  const int r = logi_row(P, P.row0 + lrow), c = logi_col(P, pcol);
+  if (!((sr > 0 && r < sr) || (sr < 0 && r >= P.C + sr) || (sc > 0 && c < sc) || (sc < 0 && c >= P.C + sc))) return;
+  for (int l = 0; l < nl; ++l) planes[(long)l * plane_stride + li + (long)P.halo * P.C] = 0.0f;
 }
 __global__ __launch_bounds__(EM_BLOCK) void k_fill_cells(Cell* __restrict__ cells, long n, Cell v) {
   long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
@@ -842,21 +775,6 @@ __global__ __launch_bounds__(EM_BLOCK) void k_point_index(KP P, Pose T, const fl
   Geo g = geometry<MODE>(P, T, rx, ry, rz);
   idx[i] = g.finite ? P.C * g.ix + g.iy : -1;
   flags[i] = g.finite ? (unsigned char)((g.valid ? 1 : 0) | (g.inside ? 2 : 0)) : 0;
-}
-
-// shift_map_xy (elevation_mapping.py:200-214): roll + pad into a second buffer; shift_map_z (:216-226)
-__global__ __launch_bounds__(EM_BLOCK) void k_shift(KP P, const Cell* __restrict__ src, Cell* __restrict__ dst, int sr, int sc, float dz) {
-  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
-  const int C = P.C;
-  if (li >= (long)C * C) return;
-  int r = (int)(li / C), c = (int)(li % C);
-  int pr = r - sr, pc = c - sc;   // cupy.roll: out[r] = in[(r - shift) mod C]
-  bool pad = (sr > 0 && r < sr) || (sr < 0 && r >= C + sr) || (sc > 0 && c < sc) || (sc < 0 && c >= C + sc);
-  Cell m;
-  if (pad) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; m.trav = 0.f; m.time = 0.f; m.upper = 0.f; m.is_upper = 0.f; m.pad = 0.f; }
-  else { pr = ((pr % C) + C) % C; pc = ((pc % C) + C) % C; m = src[(long)pr * C + pc]; }
-  m.h += dz; m.upper += dz;
-  dst[li] = m;
 }
 
 // halo rows: contiguous 32-B cells, so pack/unpack are plain device copies done by the host API.
@@ -886,8 +804,8 @@ void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, lo
 void launch_commit(hipStream_t s, const KP& P, Cell* cells, const AccF* acc, const FrameDev* F, unsigned long long* inert) {
   hipLaunchKernelGGL(k_commit, dim3((P.C + 63) / 64, P.nrows), dim3(64), 0, s, P, cells, acc, F, inert);
 }
-void launch_ray_apply(hipStream_t s, const KP& P, Cell* cells, AccR* accr) {
-  hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr);
+void launch_ray_apply(hipStream_t s, const KP& P, Cell* cells, AccR* accr, unsigned long long* inert) {
+  hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr, inert);
 }
 #define RAY_BLOCK 1024
 template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
@@ -949,24 +867,6 @@ void launch_overlap(hipStream_t s, const KP& P, Cell* cells, int cmin, int cmax,
   if (w <= 0) return;
   hipLaunchKernelGGL(k_overlap, dim3(nblk(w * w)), dim3(EM_BLOCK), 0, s, P, cells, cmin, cmax, hmin, hmax);
 }
-void launch_dilate(hipStream_t s, const KP& P, const Cell* cells, float* out, int d, int lr0, int lr1) {
-  dim3 g((P.C + DT_C - 1) / DT_C, (lr1 - lr0 + DT_R - 1) / DT_R), b(EM_BLOCK);
-  size_t lds = (size_t)2 * (DT_R + 2 * d) * (DT_C + 2 * d + 1) * sizeof(float);
-  static bool raised = false;        // dilation radii up to 32 need more than the default 64 KB of dynamic LDS (gfx950: 160 KB per CU)
-  if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_dilate), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; }
-  hipLaunchKernelGGL(k_dilate, g, b, lds, s, P, cells, out, d, lr0, lr1);
-}
-void launch_trav_normal(hipStream_t s, const KP& P, const float* w1, const float* w2, const float* w3, const float* wo,
-                        const float* in, Cell* cells, float* normal, long plane_stride) {
-  TravW W;
-  for (int i = 0; i < 36; ++i) { W.w[0][i] = w1[i]; W.w[1][i] = w2[i]; W.w[2][i] = w3[i]; }
-  for (int i = 0; i < 12; ++i) W.wo[i] = wo[i];
-  dim3 g((P.C + TT_C - 1) / TT_C, (P.nrows + TT_R - 1) / TT_R), b(EM_BLOCK);
-  hipLaunchKernelGGL(k_trav_normal, g, b, 0, s, P, W, in, cells, normal, plane_stride);
-}
-// tile rows [tile_row0, tile_row0 + n_tile_rows) of the strip (16 map rows each); the whole strip when n_tile_rows < 0
-// Tile height of k_post (measured on MI355X): 32 rows when that still yields >= 512 workgroups (1024^2 map:
-// 26 us vs 32 us with 16 rows -- less halo re-staging), 16 rows for mid-size maps, 4 rows for robot-scale maps (4x the workgroups).
 static size_t post_lds_bytes(int R, int d) {      // raw (value, mask) region, validity of the interior, hole list
   return sizeof(float) * ((size_t)2 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)R * PT_C) + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;
 }
@@ -980,32 +880,28 @@ int post_tile_rows(const KP& P) {
   while (R > 4 && post_lds_bytes(R, P.dil) > 150 * 1024) R /= 2;      // dilation radii up to 32: the staged region must fit the 160 KB LDS
   return R;
 }
+// outputs for up to four LOGICAL row intervals [seg_b[k], seg_e[k]) (owned by this strip, no circular seam inside); stage 1 = dilation only
 void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, const float* w3, const float* wo, Cell* cells,
-                 float* trav_in, float* normal, long plane_stride, int d, int tile_row0, int n_tile_rows) {
+                 float* trav_in, float* normal, long plane_stride, int d, int nseg, const int* seg_b, const int* seg_e, int stage) {
   TravW W;
   for (int i = 0; i < 36; ++i) { W.w[0][i] = w1[i]; W.w[1][i] = w2[i]; W.w[2][i] = w3[i]; }
   for (int i = 0; i < 12; ++i) W.wo[i] = wo[i];
-  // tile_row0 / n_tile_rows are given in units of post_tile_rows(P) map rows (emap_post_part)
   const int R = post_tile_rows(P);
-  const int all_rows = (P.nrows + R - 1) / R;
-  if (n_tile_rows < 0) { tile_row0 = 0; n_tile_rows = all_rows; }
-  if (tile_row0 < 0) tile_row0 = 0;
-  if (tile_row0 + n_tile_rows > all_rows) n_tile_rows = all_rows - tile_row0;
-  if (n_tile_rows <= 0) return;
-  dim3 g((P.C + PT_C - 1) / PT_C, n_tile_rows), b(PT_THREADS);
-  const size_t lds = post_lds_bytes(R, d);
-  static bool raised = false;
-  if (!raised) {        // beyond the default 64 KB dynamic-LDS window (large dilation radii)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_post<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_post<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_post<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_post<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    raised = true;
+  PostSegs S; memset(&S, 0, sizeof S);
+  int tiles = 0;
+  for (int k = 0; k < nseg && S.n < 4; ++k) {
+    if (seg_e[k] <= seg_b[k]) continue;
+    S.b[S.n] = seg_b[k]; S.e[S.n] = seg_e[k]; S.t0[S.n] = tiles; tiles += (seg_e[k] - seg_b[k] + R - 1) / R; S.n++;
   }
-  if (R == 4) hipLaunchKernelGGL(k_post<4>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
-  else if (R == 8) hipLaunchKernelGGL(k_post<8>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
-  else if (R == 32) hipLaunchKernelGGL(k_post<32>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
-  else hipLaunchKernelGGL(k_post<16>, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, tile_row0);
+  if (!tiles) return;
+  dim3 g((P.C + PT_C - 1) / PT_C, tiles), b(PT_THREADS);
+  const size_t lds = post_lds_bytes(R, d);
+#define POST_GO(RR, ST) do { auto kern = k_post<RR, ST>; static bool raised = false; \
+    if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; } \
+    hipLaunchKernelGGL(kern, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, S); } while (0)
+  if (stage == 1) { if (R == 4) POST_GO(4, 1); else if (R == 8) POST_GO(8, 1); else if (R == 32) POST_GO(32, 1); else POST_GO(16, 1); }
+  else { if (R == 4) POST_GO(4, 0); else if (R == 8) POST_GO(8, 0); else if (R == 32) POST_GO(32, 0); else POST_GO(16, 0); }
+#undef POST_GO
 }
 void launch_var_time(hipStream_t s, const KP& P, Cell* cells, int do_var, int do_time) {
   hipLaunchKernelGGL(k_var_time, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, do_var, do_time);
@@ -1032,6 +928,12 @@ void launch_point_index(hipStream_t s, const KP& P, const Pose& T, const float* 
   if (P.mode == 0) hipLaunchKernelGGL(k_point_index<0>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, idx, flags);
   else hipLaunchKernelGGL(k_point_index<1>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, idx, flags);
 }
-void launch_shift(hipStream_t s, const KP& P, const Cell* src, Cell* dst, int sr, int sc, float dz) {
-  hipLaunchKernelGGL(k_shift, dim3(nblk((long)P.C * P.C)), dim3(EM_BLOCK), 0, s, P, src, dst, sr, sc, dz);
+void launch_plane_view(hipStream_t s, const KP& P, int org_r, int org_c, float* plane, float* view, int to_plane) {
+  hipLaunchKernelGGL(k_plane_view, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, org_r, org_c, plane, view, to_plane);
+}
+void launch_materialize(hipStream_t s, const KP& P, Cell* cells) {
+  hipLaunchKernelGGL(k_materialize, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells);
+}
+void launch_band_clear(hipStream_t s, const KP& P, float* planes, int nl, long plane_stride, int sr, int sc) {
+  if (nl > 0) hipLaunchKernelGGL(k_band_clear, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, planes, nl, plane_stride, sr, sc);
 }

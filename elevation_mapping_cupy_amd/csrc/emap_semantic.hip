@@ -68,7 +68,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_sem_finalize(KP P, SemSpec S, cons
       const float a = (float)((double)alpha_planes[j] + s);
       alpha_planes[j] = a; tot += a;
     } else if (S.sum_kind[k] == 3) {               // bayesian_inference, literally (pointcloud_bayesian_inference.py:64-76):
-      const long gcell = li + (long)P.row0 * P.C;  // the prior variance layer is zeroed every frame => sigma_old = 0
+      const int lrow_ = (int)(li / P.C);            // the prior variance layer is zeroed every frame => sigma_old = 0
+      const long gcell = (long)logi_row(P, P.row0 + lrow_) * P.C + logi_col(P, (int)(li - (long)lrow_ * P.C));   // the reference's flat LOGICAL cell index
       if (cnt > 0 && gcell * S.sum_K[k] + S.sum_q[k] < (long)P.C * P.C) {
         const float cn = (float)cnt, feat_ml = (float)s / cn, sigma_old = 0.0f, sigma = 1.0f;
         sem[j] = sigma * sem[j] / (cn * sigma_old + sigma) + cn * sigma_old * feat_ml / (cn * sigma_old + sigma);
@@ -100,15 +101,6 @@ __global__ __launch_bounds__(EM_BLOCK) void k_sem_finalize(KP P, SemSpec S, cons
   }
 }
 
-__global__ __launch_bounds__(EM_BLOCK) void k_sem_shift(int C, int nl, const float* __restrict__ src, float* __restrict__ dst, int sr, int sc) {
-  long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
-  if (li >= (long)C * C) return;
-  int r = (int)(li / C), c = (int)(li % C);
-  bool pad = (sr > 0 && r < sr) || (sr < 0 && r >= C + sr) || (sc > 0 && c < sc) || (sc < 0 && c >= C + sc);
-  int pr = (((r - sr) % C) + C) % C, pc = (((c - sc) % C) + C) % C;
-  for (int l = 0; l < nl; ++l) dst[(long)l * C * C + li] = pad ? 0.f : src[(long)l * C * C + (long)pr * C + pc];
-}
-
 static inline unsigned int nblk_(long n) { return (unsigned int)((n + EM_BLOCK - 1) / EM_BLOCK); }
 
 void launch_sem_points(hipStream_t s, const KP& P, const Pose& T, const SemSpec& S, const float* pts, long n, int stride,
@@ -126,9 +118,6 @@ void launch_sem_points(hipStream_t s, const KP& P, const Pose& T, const SemSpec&
 void launch_sem_finalize(hipStream_t s, const KP& P, const SemSpec& S, const unsigned int* cnt_plane, double* sums, unsigned int* col,
                          float* sem, float* alpha_planes, long plane) {
   hipLaunchKernelGGL(k_sem_finalize, dim3(nblk_((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, S, cnt_plane, sums, col, sem, alpha_planes, plane);
-}
-void launch_sem_shift(hipStream_t s, int C, int nl, const float* src, float* dst, int sr, int sc) {
-  hipLaunchKernelGGL(k_sem_shift, dim3(nblk_((long)C * C)), dim3(EM_BLOCK), 0, s, C, nl, src, dst, sr, sc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -280,11 +269,12 @@ __global__ __launch_bounds__(EM_BLOCK) void k_image_corr(KP P, CamArgs A, const 
   if (i >= L) return;
   float out_u = 0.f, out_v = 0.f; unsigned char out_ok = 0;
   do {
-    if (cells[i].valid != 1.0f) break;                                     // only cells with is_valid == 1 (:40-42)
-    int y0 = (int)(i % W), x0 = (int)(i / W);
+    int y0 = (int)(i % W), x0 = (int)(i / W);                              // logical cell; single-strip contexts: physical row = local row
+    const Cell me = cells[(long)phys_row(P, x0) * W + phys_col(P, y0)];
+    if (me.valid != 1.0f) break;                                           // only cells with is_valid == 1 (:40-42)
     float p1 = (float)((double)(x0 - (W / 2)) * P.res + (double)A.center[0]);
     float p2 = (float)((double)(y0 - (W / 2)) * P.res + (double)A.center[1]);
-    const float z0 = cells[i].h;
+    const float z0 = me.h;
     float p3 = z0 + A.center[2];
     float u = p1 * A.P[0] + p2 * A.P[1] + p3 * A.P[2] + A.P[3];
     float v = p1 * A.P[4] + p2 * A.P[5] + p3 * A.P[6] + A.P[7];
@@ -311,7 +301,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_image_corr(KP P, CamArgs A, const 
     for (;;) {                                                               // Bresenham towards the camera cell (:103-147)
       if ((float)x0 == x1 && (float)y0 == y1) break;
       if (x0 >= 0 && y0 >= 0 && x0 < W && y0 < W) {
-        const long idx = y0 + (long)x0 * W;
+        const long idx = phys_col(P, y0) + (long)phys_row(P, x0) * W;
         const float2 hv = *reinterpret_cast<const float2*>(&cells[idx]);     // h, (v)
         if (cells[idx].valid != 0.f) {
           float dis = l2_dist(x0c, y0c, x0, y0);
@@ -335,11 +325,13 @@ __global__ __launch_bounds__(EM_BLOCK) void k_image_fuse(KP P, int kind, float* 
   const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (i >= L || !valid[i]) return;
   const int idx = (int)((float)(int)uv[i] + (float)(int)uv[L + i] * iw);
-  if (kind == 0) sem[i] = (float)((double)sem[i] * (1 - alpha) + alpha * (double)image[idx]);
+  const int x0 = (int)(i / P.C), y0 = (int)(i - (long)x0 * P.C);
+  const long pc = (long)phys_row(P, x0) * P.C + phys_col(P, y0);           // the layer is stored with the map's circular origin
+  if (kind == 0) sem[pc] = (float)((double)sem[pc] * (1 - alpha) + alpha * (double)image[idx]);
   else {
     const int ig = (int)(iw * ih + (float)idx), ib = (int)(iw * ih * 2 + (float)idx);
     const unsigned int r = (unsigned int)image[idx], g = (unsigned int)image[ig], b = (unsigned int)image[ib];
-    sem[i] = __uint_as_float((r << 16) + (g << 8) + b);
+    sem[pc] = __uint_as_float((r << 16) + (g << 8) + b);
   }
 }
 

@@ -137,8 +137,13 @@ int emap_set_layer(emap_ctx* ctx, int plane, const float* host_in);
  * kind: 0 elevation, 1 variance, 2 traversability, 3 time, 4 upper_bound, 5 is_upper_bound, 6..8 normal_x/y/z */
 int emap_publish_layer(emap_ctx* ctx, int32_t kind, float center_z, int32_t use_only_above_for_upper_bound, float* host_out);
 /* ElevationMap.shift_map_xy / shift_map_z (EM/elevation_mapping.py:200-226): roll by (dx rows, dy cols) with
- * padding (0; variance plane initial_variance), planes 0 and 5 += dz. Single-strip contexts only. */
+ * padding (0; variance plane initial_variance), planes 0 and 5 += dz -- as a rotation of the map's circular origin plus a pending
+ * entry that later kernels replay: no cell is moved, only the entering band of the semantic layers is cleared.  Works on strips
+ * (every rank calls it with the same arguments; a strip keeps its PHYSICAL rows, the logical rows it holds change). */
 int emap_shift(emap_ctx* ctx, int32_t shift_rows, int32_t shift_cols, float dz);
+/* first LOGICAL map row of the (row_count, cell_n) views emap_get_layer / emap_set_layer exchange (0 for a full map; a strip holds
+ * the logical rows begin, begin + 1, ... modulo cell_n, which change with every row shift) */
+int emap_strip_logical_begin(emap_ctx* ctx, int32_t* logical_row);
 
 /* ---- RGB / semantic point-cloud fusion (EM/semantic_map.py:223-259; kernels EM/kernels/custom_semantic_kernels.py:
  * sum :9-51 + average :167-194 (kind 0) or class_average :233-267 (kind 1); add_color :270-317 + color_average :320-375;
