@@ -272,6 +272,13 @@ static int flush_moves(emap_ctx* ctx) {
 }
 #define FLUSH() do { int rc_ = flush_moves(ctx); if (rc_) return rc_; } while (0)
 
+// rows between the origin the normal planes were written with and the map's origin (signed, shortest way round)
+static int normal_row_lag(const emap_ctx* ctx) {
+  const int C = ctx->prm.cell_n;
+  int d = ((ctx->kp.norg_r - ctx->kp.org_r) % C + C) % C;
+  return d > C / 2 ? d - C : d;
+}
+
 static int validate(const emap_params* p, const emap_strip* s, std::string* why) {
   if (!p) { *why = "params null"; return 0; }
   if (p->cell_n < 8 || p->cell_n > 46340) { *why = "cell_n out of range"; return 0; }
@@ -1223,6 +1230,30 @@ int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf) {
   return EMAP_OK;
 }
 
+// boundary rows of the three normal planes (3 x halo_rows x cell_n floats per side) for the exchange after a row shift
+// (see normal_exchange); emap_normal_row_lag tells the caller whether it is due
+int emap_normal_row_lag(emap_ctx* ctx, int32_t* lag) { CKARG(ctx && lag, "null argument"); *lag = normal_row_lag(ctx); return EMAP_OK; }
+int emap_normal_halo_pack(emap_ctx* ctx, int side, float* dev_buf) {
+  CKARG(ctx && dev_buf && (side == 0 || side == 1), "bad argument");
+  CK(hipSetDevice(ctx->device));
+  const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
+  if (H == 0) return EMAP_OK;
+  for (int k = 0; k < 3; ++k)
+    CK(hipMemcpyAsync(dev_buf + (size_t)k * H * C, ctx->normal + (size_t)k * ctx->ncells_alloc + (side == 0 ? H * C : n * C), sizeof(float) * H * C,
+                      hipMemcpyDeviceToDevice, ctx->stream));
+  return EMAP_OK;
+}
+int emap_normal_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf) {
+  CKARG(ctx && dev_buf && (side == 0 || side == 1), "bad argument");
+  CK(hipSetDevice(ctx->device));
+  const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
+  if (H == 0) return EMAP_OK;
+  for (int k = 0; k < 3; ++k)
+    CK(hipMemcpyAsync(ctx->normal + (size_t)k * ctx->ncells_alloc + (side == 0 ? 0 : (H + n) * C), dev_buf + (size_t)k * H * C, sizeof(float) * H * C,
+                      hipMemcpyDeviceToDevice, ctx->stream));
+  return EMAP_OK;
+}
+
 // ---- multi-GPU: row strips, one process per GPU, RCCL over xGMI ---------------------------------------------------
 // The two exchange steps of the path: an all-reduce of the drift sums (2 x f64) between the count and fuse
 // stages, and the neighbour exchange of halo rows before the stencils.  Halo rows are contiguous in the 32-byte cell array,
@@ -1296,24 +1327,39 @@ int emap_comm_destroy(emap_ctx* ctx) {
 }
 
 // halo exchange with the strip neighbours, in place, on the communication stream; main-stream work issued after this call and
-// before emap_comm_halo_wait overlaps it.  Rank r sends its first H owned rows to r-1 and its last H owned rows to r+1.
-static int halo_exchange_start(emap_ctx* ctx) {
-  const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
-  const size_t bytes = sizeof(Cell) * (size_t)H * C;
+// before the wait on ev_done overlaps it.  The strips are PHYSICAL row ranges of a circular map, so the neighbours form a ring:
+// rank r sends its first H owned rows to r-1 and its last H owned rows to r+1 (mod world).  The logical seam of the map lies
+// wherever the circular origin put it; rows across it are received like any others and masked by the stencils (is_inside).
+// Posting order (sends: low, high; receives: upper halo, lower halo) keeps the pairs apart when both neighbours are the same rank.
+static int ring_exchange(emap_ctx* ctx, char* base, size_t row_bytes, hipStream_t st) {
+  const long H = ctx->strip.halo_rows, n = ctx->strip.row_count;
+  const size_t bytes = row_bytes * (size_t)H;
   const RcclApi* a = ctx->rccl;
+  const int W = ctx->comm_world, prev = (ctx->comm_rank + W - 1) % W, next = (ctx->comm_rank + 1) % W;
+  CKN(a->GroupStart());
+  CKN(a->Send(base + row_bytes * H, bytes, ncclChar, prev, ctx->comm, st));                  // first H owned rows
+  CKN(a->Send(base + row_bytes * n, bytes, ncclChar, next, ctx->comm, st));                  // rows [n-H, n) of the strip
+  CKN(a->Recv(base + row_bytes * (H + n), bytes, ncclChar, next, ctx->comm, st));            // upper halo
+  CKN(a->Recv(base, bytes, ncclChar, prev, ctx->comm, st));                                  // lower halo
+  CKN(a->GroupEnd());
+  return EMAP_OK;
+}
+static int halo_exchange_start(emap_ctx* ctx) {
   CK(hipEventRecord(ctx->ev_ready, ctx->stream));
   CK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_ready, 0));
-  CKN(a->GroupStart());
-  if (ctx->comm_rank > 0) {
-    CKN(a->Send(ctx->cells + H * C, bytes, ncclChar, ctx->comm_rank - 1, ctx->comm, ctx->comm_stream));
-    CKN(a->Recv(ctx->cells, bytes, ncclChar, ctx->comm_rank - 1, ctx->comm, ctx->comm_stream));
-  }
-  if (ctx->comm_rank < ctx->comm_world - 1) {
-    CKN(a->Send(ctx->cells + n * C, bytes, ncclChar, ctx->comm_rank + 1, ctx->comm, ctx->comm_stream));          // rows [n-H, n) of the strip
-    CKN(a->Recv(ctx->cells + (H + n) * C, bytes, ncclChar, ctx->comm_rank + 1, ctx->comm, ctx->comm_stream));
-  }
-  CKN(a->GroupEnd());
+  int rc = ring_exchange(ctx, reinterpret_cast<char*>(ctx->cells), sizeof(Cell) * (size_t)ctx->prm.cell_n, ctx->comm_stream);
+  if (rc) return rc;
   CK(hipEventRecord(ctx->ev_done, ctx->comm_stream));
+  return EMAP_OK;
+}
+// After a row shift the un-shifted normal planes (the reference does not roll normal_map) sit `lag` rows away from the cells they
+// belong to: up to halo_rows of them are with a neighbour.  One ring exchange of the planes' boundary rows into their halo rows
+// before the visibility pass restores them (k_rays: local_row of the normal's physical row); beyond halo_rows they read as 0.
+static int normal_exchange(emap_ctx* ctx) {
+  for (int k = 0; k < 3; ++k) {
+    int rc = ring_exchange(ctx, reinterpret_cast<char*>(ctx->normal + (size_t)k * ctx->ncells_alloc), sizeof(float) * (size_t)ctx->prm.cell_n, ctx->stream);
+    if (rc) return rc;
+  }
   return EMAP_OK;
 }
 
@@ -1346,6 +1392,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   if (rays_on) {
     if (!fused_avg && (rc = emap_commit(ctx))) return rc;
     STAGE(ST_RAYS);
+    if (ctx->comm_world > 1 && normal_row_lag(ctx) != 0 && (rc = normal_exchange(ctx))) { ctx->rays_fused = false; return rc; }
     rc = emap_rays(ctx, R, t);
     if (rc) { ctx->rays_fused = false; return rc; }
   } else STAGE(ST_RAYS);

@@ -124,6 +124,14 @@ class ElevationMap:
         self._chk(self._lib.emap_get_layer(self._ctx, pid, f32p(out)))
         return out
 
+    @property
+    def logical_row_begin(self):
+        """first LOGICAL map row of this context's (rows, cell_n) views: 0 for a full map; a strip holds the logical rows
+        begin, begin + 1, ... modulo cell_n, and they change with every row shift (the strip keeps its physical rows)"""
+        r = ct.c_int32(0)
+        self._chk(self._lib.emap_strip_logical_begin(self._ctx, ct.byref(r)))
+        return int(r.value)
+
     def set_layer_raw(self, name_or_id, array):
         pid = PLANES[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
         a = np.ascontiguousarray(array, np.float32)

@@ -91,18 +91,17 @@ class TorchComm:
         return tensor
 
     def exchange_start(self, send_lo, send_hi, recv_lo, recv_hi):
-        """neighbour exchange on the strip chain: send_lo -> rank-1 (arrives in its recv_hi), send_hi -> rank+1
-        (arrives in its recv_lo).  Edge ranks have one neighbour.  Returns the in-flight requests."""
+        """neighbour exchange on the strip RING (strips are physical row ranges of a circular map): send_lo -> rank-1 (arrives in
+        its recv_hi), send_hi -> rank+1 (arrives in its recv_lo), modulo world.  The posting order (sends low, high; receives
+        upper, lower) keeps the pairs apart when both neighbours are the same rank.  Returns the in-flight requests."""
         dist = self.dist
+        if self.world == 1:
+            return []
         self._drain()
-        ops = []
-        if self.rank > 0:
-            ops.append(dist.P2POp(dist.isend, send_lo, self.rank - 1))
-            ops.append(dist.P2POp(dist.irecv, recv_lo, self.rank - 1))
-        if self.rank < self.world - 1:
-            ops.append(dist.P2POp(dist.isend, send_hi, self.rank + 1))
-            ops.append(dist.P2POp(dist.irecv, recv_hi, self.rank + 1))
-        return dist.batch_isend_irecv(ops) if ops else []
+        prev, nxt = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        ops = [dist.P2POp(dist.isend, send_lo, prev), dist.P2POp(dist.isend, send_hi, nxt),
+               dist.P2POp(dist.irecv, recv_hi, nxt), dist.P2POp(dist.irecv, recv_lo, prev)]
+        return dist.batch_isend_irecv(ops)
 
     def exchange_wait(self, works):
         for w in works:
@@ -276,6 +275,33 @@ class HipStripEngine:
         """dilation + traversability + normals; part 1 = tiles independent of the halo, 2 = boundary tiles, 0 = all"""
         self._chk(self.lib.emap_post_part(self.ctx, int(part)))
 
+    def normal_row_lag(self):
+        """rows by which the (never shifted) normal planes lag the cells since the last row shift"""
+        lag = ct.c_int32(0)
+        self._chk(self.lib.emap_normal_row_lag(self.ctx, ct.byref(lag)))
+        return lag.value
+
+    def normal_halo_pack(self):
+        if not hasattr(self, "nsend"):
+            n = max(1, 3 * self.halo * self.C)
+            with self.torch.cuda.stream(self.stream):
+                mk = lambda: self.torch.zeros(n, dtype=self.torch.float32, device=self.torch_device)  # noqa: E731
+                self.nsend, self.nrecv = [mk(), mk()], [mk(), mk()]
+        for side in (0, 1):
+            self._chk(self.lib.emap_normal_halo_pack(self.ctx, side, ct.c_void_p(self.nsend[side].data_ptr())))
+        return self.nsend[0], self.nsend[1], self.nrecv[0], self.nrecv[1]
+
+    def normal_halo_unpack(self):
+        for side in (0, 1):
+            self._chk(self.lib.emap_normal_halo_unpack(self.ctx, side, ct.c_void_p(self.nrecv[side].data_ptr())))
+
+    def move_to(self, position, R):
+        """every rank shifts its strip by the same amount: the strip keeps its PHYSICAL rows, the logical rows it holds change"""
+        self.map.move_to(position, R)
+
+    def move(self, delta_position):
+        self.map.move(delta_position)
+
     def update_native(self, R, t, position_noise, orientation_noise):
         """whole frame incl. both exchange steps inside the library (needs NativeComm)"""
         R = np.ascontiguousarray(np.asarray(R, np.float32).reshape(9))
@@ -314,6 +340,12 @@ class ShardedElevationMap:
         self.e, self.comm = engine, comm
         self.rays_on, self.overlap_on = bool(enable_visibility_cleanup), bool(enable_overlap_clearance)
 
+    def move_to(self, position, R):
+        self.e.move_to(position, R)
+
+    def move(self, delta_position):
+        self.e.move(delta_position)
+
     def update(self, R, t, position_noise, orientation_noise, channels=None):
         """One frame on the bound (replicated) cloud; ``t`` is map-centre relative.  ``channels`` (names of ALL cloud columns,
         x, y, z first) additionally fuses the extra columns into the strip's RGB / semantic layers (BASELINE config 5)."""
@@ -338,6 +370,11 @@ class ShardedElevationMap:
         if self.rays_on:
             e.fuse(R, t)
             e.commit()
+            if c.world > 1 and hasattr(e, "normal_row_lag") and e.normal_row_lag() != 0:
+                # a row shift since the last frame: the un-shifted normal planes sit `lag` rows off -- fetch the neighbours' rows
+                n_lo, n_hi, q_lo, q_hi = e.normal_halo_pack()
+                c.exchange_wait(c.exchange_start(n_lo, n_hi, q_lo, q_hi))
+                e.normal_halo_unpack()
             e.rays(R, t)
             e.average()
         else:
@@ -349,7 +386,7 @@ class ShardedElevationMap:
             works = c.exchange_start(s_lo, s_hi, r_lo, r_hi)
             e.post(1)                                          # ... overlapped with the stencils of the interior tiles
             c.exchange_wait(works)
-            e.halo_unpack(c.rank > 0, c.rank < c.world - 1)
+            e.halo_unpack(True, True)                          # ring: every strip has both neighbours
             e.post(2)
         else:
             e.post(0)

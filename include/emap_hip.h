@@ -215,6 +215,13 @@ int emap_dilate_planes(emap_ctx* ctx, const float* host_plane, const float* host
 int emap_halo_bytes(emap_ctx* ctx, int64_t* bytes_per_side);
 int emap_halo_pack(emap_ctx* ctx, int side, float* dev_buf);
 int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf);
+/* The strips are physical row ranges of a circular map: neighbours form a RING (rank 0's lower neighbour is the last rank).
+ * After a row shift the normal planes (not shifted in the reference) lag the cells by emap_normal_row_lag rows; when that is not
+ * 0 and the visibility pass is on, the callers exchange the planes' boundary rows too (3 x halo_rows x cell_n floats per side)
+ * before emap_rays.  emap_update_sharded does both by itself. */
+int emap_normal_row_lag(emap_ctx* ctx, int32_t* lag);
+int emap_normal_halo_pack(emap_ctx* ctx, int side, float* dev_buf);
+int emap_normal_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf);
 
 /* ---- row-strip communicator: one process per GPU, RCCL over xGMI issued from the library itself -------------
  * Nothing like it exists in the reference (single GPU).  `rccl_path` names the RCCL shared object to dlopen (NULL =

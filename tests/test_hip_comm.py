@@ -77,8 +77,9 @@ def _fake_rccl():
     return out
 
 
+@pytest.mark.parametrize("moves", [False, True])
 @pytest.mark.parametrize("world,cfg_name,C,N", [(2, "yaml", 130, 40000), (3, "yaml_norays", 202, 60000), (4, "default", 202, 40000)])
-def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, C, N, weights):
+def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, C, N, moves, weights):
     """emap_comm_init + emap_update_sharded with SEVERAL ranks: the library's own orchestration (all-reduce between count and fuse,
     in-place halo send / recv on the second stream, interior / boundary stencil split) driven through a stand-in for the nine RCCL
     entry points whose ranks are threads of this process (RCCL refuses two ranks on one GPU).  Every strip must equal the rows of
@@ -96,11 +97,14 @@ def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, 
         cfg["enable_visibility_cleanup"] = False
     R, t = fx.POSES["rotated"]
     clouds = [fx.cloud(C, N, f, dz=dz) for f, dz in enumerate((0.0, -0.02, -0.1))]
+    MV = [(0.13, -0.3, 0.05), (-0.10, 0.17, -0.02), None] if moves else [None] * 3      # move_to between the frames: ring halo, normal rows (after a move a strip's view of the un-shifted normals has holes until the next frame)
     full = ElevationMap(parameter_from(cfg, C, "reference_fp16", weights))
-    for p in clouds:
-        full.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0)
+    for p, mv in zip(clouds, MV):
+        full.update_map_with_kernel(p, [], R, (t + full.center).astype(np.float32), 1.0, 1.0)
         for _ in range(6):
             full.update_time()
+        if mv is not None:
+            full.move_to(np.array(mv, np.float64), np.eye(3))
     want, want_n, want_add = full.elevation_map, full.normal_map, full.get_additive_mean_error()
     # one id for all ranks (what the bootstrap channel distributes in a real launch)
     uid = (ct.c_uint8 * 128)()
@@ -114,13 +118,15 @@ def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, 
             comm = NativeComm(eng, rank=rank, world=world, bootstrap=False, uid=bytes(uid), rccl_path=lib_path)
             comm.selftest()
             sm = ShardedElevationMap(eng, comm, cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
-            for p in clouds:
+            for p, mv in zip(clouds, MV):
                 eng.bind_points(p)
-                sm.update(R, t, 1.0, 1.0)
+                sm.update(R, t, 1.0, 1.0)                        # (map-centre relative t: the sensor rides with the centre)
                 for _ in range(6):
                     eng.update_time()
+                if mv is not None:
+                    sm.move_to(np.array(mv, np.float64), np.eye(3))
             eng.sync()
-            out[rank] = (eng.map.row_begin, eng.map.rows, eng.map.elevation_map, eng.map.normal_map, eng.map.get_additive_mean_error())
+            out[rank] = (eng.map.logical_row_begin, eng.map.rows, eng.map.elevation_map, eng.map.normal_map, eng.map.get_additive_mean_error())
             eng.lib.emap_comm_destroy(eng.ctx)
         except Exception as e:  # pragma: no cover
             errs.append(e)
@@ -130,7 +136,8 @@ def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, 
     [x.join(timeout=120) for x in th]
     assert not any(x.is_alive() for x in th), "a rank is stuck in the exchange"
     assert not errs, errs
-    for r0, rows, m, nm, add in out:
-        assert m.tobytes() == want[:, r0:r0 + rows].tobytes(), "strip at row %d differs" % r0
-        assert nm.tobytes() == want_n[:, r0:r0 + rows].tobytes()
+    for b, rows, m, nm, add in out:
+        idx = (b + np.arange(rows)) % C                           # the strip's view: logical rows b, b + 1, ... of the full map
+        assert m.tobytes() == np.take(want, idx, axis=1).tobytes(), "strip whose view starts at logical row %d differs" % b
+        assert nm.tobytes() == np.take(want_n, idx, axis=1).tobytes()
         assert add == want_add

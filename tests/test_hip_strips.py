@@ -42,10 +42,8 @@ class ThreadComm:
         sh["send"][self.rank] = (send_lo, send_hi)
         torch.cuda.synchronize()
         sh["bar"].wait()
-        if self.rank > 0:
-            recv_lo.copy_(sh["send"][self.rank - 1][1])
-        if self.rank < self.world - 1:
-            recv_hi.copy_(sh["send"][self.rank + 1][0])
+        recv_lo.copy_(sh["send"][(self.rank - 1) % self.world][1])          # ring: strips are physical rows of a circular map
+        recv_hi.copy_(sh["send"][(self.rank + 1) % self.world][0])
         torch.cuda.synchronize()
         sh["bar"].wait()
         return []
@@ -155,3 +153,68 @@ def test_strips_fuse_rgb_and_semantic_channels_like_the_single_context(world, we
         assert m.tobytes() == want_e[:, r0:r0 + rows].tobytes()
         assert s.shape == (4, rows, C) and s.tobytes() == want_s[:, r0:r0 + rows].tobytes()
     assert (want_s[3].view(np.uint32) != 0).sum() > 1000
+
+
+def _rows_of(full_planes, begin, rows):
+    """the strip's view: logical rows begin, begin + 1, ... (modulo cell_n) of the full map"""
+    C = full_planes.shape[1]
+    return np.take(full_planes, (begin + np.arange(rows)) % C, axis=1)
+
+
+# row shifts of at most halo_rows (= 7) per move: after a larger one the visibility pass of the next frame finds the un-shifted normals
+# of the seam rows on no rank and reads them as 0 (documented deviation of strips; DESIGN.md "Map shift")
+MOVES = [(0.13, -0.3, 0.05), (-0.10, 0.49, -0.02), (0.17, 0.5, 0.0), (-0.05, -0.9, 0.11)]
+
+
+@pytest.mark.parametrize("world,cfg_name", [(2, "yaml"), (3, "yaml"), (4, "yaml_norays")])
+def test_strips_follow_the_robot_like_the_single_context(world, cfg_name, weights):
+    """move_to between frames on row strips: every rank rotates its circular origin by the same amount (a strip keeps its physical
+    rows, the logical rows it holds change, the halo ring hands the seam rows round); frames, decay and read-back must equal the
+    single context bit for bit -- including the visibility pass, whose un-shifted normal planes are fetched from the neighbour."""
+    import torch
+    from elevation_mapping_cupy_amd.configs import parameter_from
+    from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
+    from elevation_mapping_cupy_amd.sharded import HipStripEngine, ShardedElevationMap
+    from oracle import emap_oracle as eo
+    C, N = 130, 30000
+    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML)
+    if cfg_name.endswith("norays"):
+        cfg["enable_visibility_cleanup"] = False
+    R, t0 = fx.POSES["rotated"]
+    clouds = [fx.cloud(C, N, f, dz=-0.02 * f) for f in range(5)]
+
+    def drive(frame, move, tick, center):
+        for f, p in enumerate(clouds):
+            frame(p, (t0 + center()).astype(np.float32))
+            for _ in range(6):
+                tick()
+            if f < len(MOVES):
+                move(np.array(MOVES[f], np.float64))
+    full = ElevationMap(parameter_from(cfg, C, "reference_fp16", weights))
+    drive(lambda p, tw: full.update_map_with_kernel(p, [], R, tw, 1.0, 1.0), lambda v: full.move_to(v, np.eye(3)), full.update_time, lambda: full.center)
+    want, want_n = full.elevation_map, full.normal_map
+    dev = torch.device("cuda", 0)
+    shared = {"bar": threading.Barrier(world), "sums": [None] * world, "send": [None] * world}
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            eng = HipStripEngine(parameter_from(cfg, C, "reference_fp16", weights), rank, world, 0, dev)
+            sm = ShardedElevationMap(eng, ThreadComm(rank, world, shared), cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
+
+            def frame(p, tw):
+                eng.bind_points(p)
+                sm.update(R, (tw - eng.map.center).astype(np.float32), 1.0, 1.0)       # the strip protocol takes map-centre relative t
+            drive(frame, lambda v: sm.move_to(v, np.eye(3)), eng.update_time, lambda: eng.map.center)
+            eng.sync()
+            out[rank] = (eng.map.logical_row_begin, eng.map.rows, eng.map.elevation_map, eng.map.normal_map)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            shared["bar"].abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [x.start() for x in th]; [x.join() for x in th]
+    assert not errs, errs
+    assert sorted(b for b, *_ in out) != sorted((r * C) // world for r in range(world)), "the moves must have shifted rows"
+    for b, rows, m, nm in out:
+        assert m.tobytes() == _rows_of(want, b, rows).tobytes(), "strip whose view starts at logical row %d differs" % b
+        assert nm.tobytes() == _rows_of(want_n, b, rows).tobytes()
