@@ -62,9 +62,11 @@ class OracleStripEngine:
 
     def halo_unpack(self, have_lo, have_hi):
         m, H = self.om.elevation_map, self.H
-        if have_lo:
+        # the exchange is a ring (strips are physical rows of a circular map); this engine's map is not shifted, so the rows that
+        # arrive across the wrap (rank 0's lower, the last rank's upper halo) lie beyond the logical map border and are dropped
+        if have_lo and self.r0 > 0:
             m[:, self.r0 - H:self.r0] = self.recv[0].numpy()
-        if have_hi:
+        if have_hi and self.r1 < self.C:
             m[:, self.r1:self.r1 + H] = self.recv[1].numpy()
 
     def post(self, part=0):
