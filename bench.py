@@ -94,6 +94,19 @@ class Hip:
     def sync(self):
         self.ck(self.l.hipDeviceSynchronize(), "hipDeviceSynchronize")
 
+    def pinned_h2d_gbs(self, nbytes, reps=5):
+        """bandwidth of a plain hipMemcpy from pinned host memory (the PCIe-bound rate the inclusive figures are compared with)"""
+        h, d = ct.c_void_p(), self.malloc(nbytes)
+        self.ck(self.l.hipHostMalloc(ct.byref(h), ct.c_size_t(nbytes), 0), "hipHostMalloc")
+        ct.memset(h, 1, nbytes)
+        best = 0.0
+        for _ in range(reps):
+            self.sync(); t0 = time.perf_counter()
+            self.ck(self.l.hipMemcpy(d, h, ct.c_size_t(nbytes), 1), "hipMemcpy"); self.sync()
+            best = max(best, nbytes / (time.perf_counter() - t0) / 1e9)
+        self.l.hipHostFree(h); self.l.hipFree(d)
+        return best
+
 
 # Algorithmic bytes of each timed stage = the bytes that stage must move once (DESIGN.md §5; N points, L cells).  "post" follows
 # SURVEY §8(d): dilation 12 B/cell (2 planes in, 1 out) + normal filter 20 B/cell + traversability filter 8 B/cell.
@@ -384,6 +397,30 @@ def run_single(a, local_rank=0):
                 "stage_ms": r3["stage_ms"]}
         em3.close()
 
+    # ---- the reference's real entry point: input_pointcloud with a HOST cloud (float64 as the ROS wrapper passes it, float32) -----
+    # never part of `value`; the upload is asynchronous (host-side cast into pinned memory, DMA overlapping the previous frame)
+    h2d = None
+    if not multimodal:
+        gbs = hip.pinned_h2d_gbs(24 * N)
+        h2d = {"pinned_h2d_GBs": round(gbs, 1)}
+        Rm = R.reshape(3, 3)
+        for name, dt, bpp in (("f64", np.float64, 24), ("f32", np.float32, 12)):
+            hosts = [np.ascontiguousarray(c[:, :3], dt) for c in clouds_host[:2]]
+            for i in range(4):
+                emap.input_pointcloud(hosts[i % 2], ["x", "y", "z"], Rm, t.copy(), 1.0, 1.0)
+            emap.sync()
+            k_in = max(4, min(a.steps, 30))
+            t0 = time.perf_counter()
+            for i in range(k_in):
+                emap.input_pointcloud(hosts[i % 2], ["x", "y", "z"], Rm, t.copy(), 1.0, 1.0)
+            emap.sync()
+            dt_ms = (time.perf_counter() - t0) * 1e3 / k_in
+            bound_ms = bpp * N / (gbs * 1e9) * 1e3
+            h2d[name] = {"ms_per_frame": round(dt_ms, 4), "Mpoints_s": round(N / dt_ms / 1e3, 1), "pcie_bound_ms": round(bound_ms, 4),
+                         "frac_of_pcie_bound_rate": round(bound_ms / dt_ms, 3)}
+        h2d["note"] = ("input_pointcloud(host cloud): frames per second through the reference's entry point; pcie_bound_ms = the time a plain "
+                       "pinned hipMemcpy of the caller's bytes (24 / 12 per point) takes at pinned_h2d_GBs")
+
     cpu = None
     if not a.no_cpu_baseline and not multimodal:
         cpu = cpu_baseline(a, cfg, C, N, clouds_host, weights, R, t)
@@ -393,6 +430,8 @@ def run_single(a, local_rank=0):
               "device_ms_per_step": round(ms_dev / a.steps, 5), "cloud": "device resident (H2D excluded)"}
     if cfg3:
         config["cfg3"] = cfg3
+    if h2d:
+        config["h2d_inclusive"] = h2d
     out = {
         "metric": "Mpoints/s fused (map-update p50 latency in config)", "value": round(mpts, 2), "unit": "Mpoints/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),

@@ -11,8 +11,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 // launchers (emap_kernels.hip)
@@ -43,7 +48,6 @@ void launch_get_plane(hipStream_t, const KP&, const Cell*, int, float*);
 void launch_publish(hipStream_t, const KP&, const Cell*, const float*, long, int, float, int, float*);
 void launch_set_plane(hipStream_t, const KP&, Cell*, int, const float*);
 void launch_fill_cells(hipStream_t, Cell*, long, const Cell&);
-void launch_f64_to_f32(hipStream_t, const double*, float*, long);
 void launch_point_index(hipStream_t, const KP&, const Pose&, const float*, long, int, int*, unsigned char*);
 void launch_plane_view(hipStream_t, const KP&, int, int, float*, float*, int);
 void launch_materialize(hipStream_t, const KP&, Cell*);
@@ -72,6 +76,35 @@ struct RcclApi {
   decltype(&ncclGetUniqueId) GetUniqueId; decltype(&ncclCommInitRank) CommInitRank; decltype(&ncclCommDestroy) CommDestroy;
   decltype(&ncclAllReduce) AllReduce; decltype(&ncclSend) Send; decltype(&ncclRecv) Recv;
   decltype(&ncclGroupStart) GroupStart; decltype(&ncclGroupEnd) GroupEnd; decltype(&ncclGetErrorString) GetErrorString;
+};
+
+// ---- asynchronous cloud upload (a1: ElevationMap.input_pointcloud, EM/elevation_mapping.py:456-458) ------------------------------
+// The ROS wrapper hands over a pageable float64 matrix.  It is converted to float32 on the HOST by a few worker threads straight
+// into a pinned slot (so only 12 of the 24 bytes per point cross PCIe and no device-side cast pass is needed), chunk by chunk, each
+// chunk's DMA on a copy stream overlapping the next chunk's conversion; the device buffer is double buffered so the upload of frame
+// k+1 overlaps the kernels of frame k.  The call returns when the caller's buffer has been consumed (it is only borrowed).
+struct Workers {
+  std::vector<std::thread> th; std::mutex m; std::condition_variable cv, done_cv;
+  std::function<void(int, int)> job; int gen = 0, pending = 0; bool stop = false;
+  explicit Workers(int n) {
+    for (int i = 0; i < n; ++i) th.emplace_back([this, i, n] {
+      int seen = 0;
+      for (;;) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return stop || gen != seen; });
+        if (stop) return;
+        seen = gen; auto f = job; l.unlock();
+        f(i, n);
+        l.lock(); if (--pending == 0) done_cv.notify_all();
+      }
+    });
+  }
+  void run(const std::function<void(int, int)>& f) {       // f(worker, n_workers) on every worker; returns when all are done
+    std::unique_lock<std::mutex> l(m);
+    job = f; pending = (int)th.size(); ++gen; cv.notify_all();
+    done_cv.wait(l, [&] { return pending == 0; });
+  }
+  ~Workers() { { std::lock_guard<std::mutex> l(m); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
 };
 
 struct emap_ctx {
@@ -106,8 +139,10 @@ struct emap_ctx {
   float* sem_alpha;   // class_bayesian pseudo-counts (the reference's persistent new_map layers), sem_layers planes, on demand
   int sem_layers; float* sem; double* sem_sums; unsigned int* sem_col; unsigned int* cnt_plane;
   // point cloud
-  float* pts_own; long pts_cap;    // owned buffer (floats)
-  double* pts_f64; long pts_f64_cap;
+  float* pts_dev[2]; long pts_cap[2];      // owned device buffers (floats), ping-pong between consecutive uploads
+  float* pts_pin[2]; long pin_cap[2];      // pinned host slots the clouds are converted / copied into
+  hipEvent_t ev_copied[2], ev_used[2];     // DMA of slot done (copy stream) / the frame that read the slot's device buffer done (main stream)
+  int up_slot; bool up_used[2]; hipStream_t copy_stream; Workers* workers;
   const float* pts; long n_pts; int stride;
   int* tail_idx; unsigned char* tail_flags; long tail_cap;
   // frame state
@@ -305,8 +340,11 @@ int emap_destroy(emap_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   hipFree(ctx->cells); hipFree(ctx->acc); hipFree(ctx->accr); hipFree(ctx->trav_in);
-  hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->slots); hipFree(ctx->frame); hipFree(ctx->pts_own);
-  hipFree(ctx->pts_f64); hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert); hipFree(ctx->inl_plane); hipFree(ctx->ray_thr);
+  hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->slots); hipFree(ctx->frame);
+  for (int k = 0; k < 2; ++k) { hipFree(ctx->pts_dev[k]); if (ctx->pts_pin[k]) hipHostFree(ctx->pts_pin[k]); if (ctx->ev_copied[k]) hipEventDestroy(ctx->ev_copied[k]); if (ctx->ev_used[k]) hipEventDestroy(ctx->ev_used[k]); }
+  if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+  delete ctx->workers;
+  hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert); hipFree(ctx->inl_plane); hipFree(ctx->ray_thr);
   hipFree(ctx->bin_tmp); hipFree(ctx->bin_recs); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start);
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
@@ -400,29 +438,47 @@ int emap_upload_points(emap_ctx* ctx, const void* host, int64_t n, int64_t strid
   CKARG(n == 0 || host, "null host buffer");
   CK(hipSetDevice(ctx->device));
   const long tot = (long)n * stride;
-  if (tot > ctx->pts_cap) {
-    CK(hipStreamSynchronize(ctx->stream));
-    if (ctx->pts_own) CK(hipFree(ctx->pts_own));
-    ctx->pts_own = nullptr; ctx->pts_cap = 0;
-    CK(hipMalloc((void**)&ctx->pts_own, sizeof(float) * tot));
-    ctx->pts_cap = tot;
+  if (!ctx->copy_stream) {
+    CK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) { CK(hipEventCreateWithFlags(&ctx->ev_copied[k], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ctx->ev_used[k], hipEventDisableTiming)); }
+    int nt = (int)std::thread::hardware_concurrency() / 2; if (nt > 8) nt = 8; if (nt < 1) nt = 1;
+    if (const char* e = getenv("EMAP_UPLOAD_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) nt = v; }
+    ctx->workers = new Workers(nt);
+  }
+  // everything enqueued so far may read the buffer of the previous upload: mark the point after which that buffer is free again
+  if (ctx->up_used[ctx->up_slot]) CK(hipEventRecord(ctx->ev_used[ctx->up_slot], ctx->stream));
+  const int sl = ctx->up_slot ^= 1;
+  // this slot's device buffer was read by the kernels before the previous upload, its pinned memory by the DMA two uploads ago
+  if (ctx->up_used[sl]) { CK(hipEventSynchronize(ctx->ev_used[sl])); CK(hipEventSynchronize(ctx->ev_copied[sl])); }
+  if (tot > ctx->pts_cap[sl]) {
+    if (ctx->pts_dev[sl]) CK(hipFree(ctx->pts_dev[sl]));
+    ctx->pts_dev[sl] = nullptr; ctx->pts_cap[sl] = 0;
+    CK(hipMalloc((void**)&ctx->pts_dev[sl], sizeof(float) * tot));
+    ctx->pts_cap[sl] = tot;
+  }
+  if (tot > ctx->pin_cap[sl]) {
+    if (ctx->pts_pin[sl]) CK(hipHostFree(ctx->pts_pin[sl]));
+    ctx->pts_pin[sl] = nullptr; ctx->pin_cap[sl] = 0;
+    CK(hipHostMalloc((void**)&ctx->pts_pin[sl], sizeof(float) * tot, hipHostMallocDefault));
+    ctx->pin_cap[sl] = tot;
   }
   if (tot > 0) {
-    if (dtype == 0) CK(hipMemcpyAsync(ctx->pts_own, host, sizeof(float) * tot, hipMemcpyHostToDevice, ctx->stream));
-    else {
-      if (tot > ctx->pts_f64_cap) {
-        CK(hipStreamSynchronize(ctx->stream));
-        if (ctx->pts_f64) CK(hipFree(ctx->pts_f64));
-        ctx->pts_f64 = nullptr; ctx->pts_f64_cap = 0;
-        CK(hipMalloc((void**)&ctx->pts_f64, sizeof(double) * tot));
-        ctx->pts_f64_cap = tot;
-      }
-      CK(hipMemcpyAsync(ctx->pts_f64, host, sizeof(double) * tot, hipMemcpyHostToDevice, ctx->stream));
-      launch_f64_to_f32(ctx->stream, ctx->pts_f64, ctx->pts_own, tot);
+    float* pin = ctx->pts_pin[sl];
+    const long chunk = 1L << 19;                                    // 2 MB of float32 per DMA
+    for (long c0 = 0; c0 < tot; c0 += chunk) {
+      const long c1 = c0 + chunk < tot ? c0 + chunk : tot;
+      ctx->workers->run([&](int w, int nw) {
+        const long per = (c1 - c0 + nw - 1) / nw, a = c0 + (long)w * per, b = a + per < c1 ? a + per : c1;
+        if (dtype == 0) { if (b > a) memcpy(pin + a, static_cast<const float*>(host) + a, sizeof(float) * (size_t)(b - a)); }
+        else { const double* src = static_cast<const double*>(host); for (long i = a; i < b; ++i) pin[i] = (float)src[i]; }   // fp32 cast (:456)
+      });
+      CK(hipMemcpyAsync(ctx->pts_dev[sl] + c0, pin + c0, sizeof(float) * (size_t)(c1 - c0), hipMemcpyHostToDevice, ctx->copy_stream));
     }
-    CK(hipStreamSynchronize(ctx->stream));   // host buffer is only borrowed for the call
+    CK(hipEventRecord(ctx->ev_copied[sl], ctx->copy_stream));
+    CK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[sl], 0));     // kernels enqueued from now on see the cloud; nothing waits on the host
+    ctx->up_used[sl] = true;
   }
-  ctx->pts = ctx->pts_own; ctx->n_pts = (long)n; ctx->stride = (int)stride;
+  ctx->pts = ctx->pts_dev[sl]; ctx->n_pts = (long)n; ctx->stride = (int)stride;
   return EMAP_OK;
 }
 

@@ -761,10 +761,6 @@ __global__ __launch_bounds__(EM_BLOCK) void k_fill_cells(Cell* __restrict__ cell
   long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (i < n) cells[i] = v;
 }
-__global__ __launch_bounds__(EM_BLOCK) void k_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, long n) {
-  long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
-  if (i < n) out[i] = (float)in[i];
-}
 template <int MODE>
 __global__ __launch_bounds__(EM_BLOCK) void k_point_index(KP P, Pose T, const float* __restrict__ pts, long n, int stride,
                                                            int* __restrict__ idx, unsigned char* __restrict__ flags) {
@@ -919,9 +915,6 @@ void launch_set_plane(hipStream_t s, const KP& P, Cell* cells, int word, const f
 }
 void launch_fill_cells(hipStream_t s, Cell* cells, long n, const Cell& v) {
   hipLaunchKernelGGL(k_fill_cells, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, cells, n, v);
-}
-void launch_f64_to_f32(hipStream_t s, const double* in, float* out, long n) {
-  if (n > 0) hipLaunchKernelGGL(k_f64_to_f32, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, in, out, n);
 }
 void launch_point_index(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, int* idx, unsigned char* flags) {
   if (n <= 0) return;
