@@ -120,6 +120,7 @@ struct emap_ctx {
   AccF* acc; AccR* accr;
   float* trav_in; float* normal;   // normal: 3 planes of ncells_alloc
   float* scratch;                  // one plane (get/set staging)
+  float* plug_buf; size_t plug_cap; unsigned int* plug_cnt; int plug_cnt_cap;   // plane scratch of the publish-time plugins (kept between calls)
   ErrSlot* slots; FrameDev* frame;
   RayTab rt; float* ray_S; unsigned short* ray_lut;
   unsigned long long* inert;       // 1 bit per owned cell (rows of ceil(C/64) words), written by k_commit / k_tile_fuse<true, true>
@@ -314,6 +315,25 @@ static int normal_row_lag(const emap_ctx* ctx) {
   return d > C / 2 ? d - C : d;
 }
 
+static int plugin_scratch(emap_ctx* ctx, size_t planes, int counters) {
+  const size_t need = planes * (size_t)ctx->prm.cell_n * ctx->prm.cell_n;
+  if (need > ctx->plug_cap) {
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->plug_buf) CK(hipFree(ctx->plug_buf));
+    ctx->plug_buf = nullptr; ctx->plug_cap = 0;
+    CK(hipMalloc((void**)&ctx->plug_buf, sizeof(float) * need));
+    ctx->plug_cap = need;
+  }
+  if (counters > ctx->plug_cnt_cap) {
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->plug_cnt) CK(hipFree(ctx->plug_cnt));
+    ctx->plug_cnt = nullptr; ctx->plug_cnt_cap = 0;
+    CK(hipMalloc((void**)&ctx->plug_cnt, sizeof(unsigned int) * counters));
+    ctx->plug_cnt_cap = counters;
+  }
+  return EMAP_OK;
+}
+
 static int validate(const emap_params* p, const emap_strip* s, std::string* why) {
   if (!p) { *why = "params null"; return 0; }
   if (p->cell_n < 8 || p->cell_n > 46340) { *why = "cell_n out of range"; return 0; }
@@ -340,7 +360,7 @@ int emap_destroy(emap_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   hipFree(ctx->cells); hipFree(ctx->acc); hipFree(ctx->accr); hipFree(ctx->trav_in);
-  hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->slots); hipFree(ctx->frame);
+  hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->plug_buf); hipFree(ctx->plug_cnt); hipFree(ctx->slots); hipFree(ctx->frame);
   for (int k = 0; k < 2; ++k) { hipFree(ctx->pts_dev[k]); if (ctx->pts_pin[k]) hipHostFree(ctx->pts_pin[k]); if (ctx->ev_copied[k]) hipEventDestroy(ctx->ev_copied[k]); if (ctx->ev_used[k]) hipEventDestroy(ctx->ev_used[k]); }
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   delete ctx->workers;
@@ -1035,35 +1055,36 @@ int emap_semantic_clear(emap_ctx* ctx) {
 // ---- MinFilter plugin (EM/plugins/min_filter.py:84-118) on caller-provided planes ------------------------------------
 static int minmax_filter(emap_ctx* ctx, const float* host_elevation, const float* host_valid, int32_t dilation_size, int32_t iteration_n,
                          float* host_out, int32_t* sweeps_run, bool is_max) {
-  CKARG(ctx && host_elevation && host_valid && host_out, "null argument");
+  CKARG(ctx && host_out && ((host_elevation && host_valid) || (!host_elevation && !host_valid)), "null argument");
   CKARG(dilation_size >= 0 && dilation_size <= 32 && iteration_n >= 0 && iteration_n <= 4096, "bad filter size / iteration count");
   CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "emap_min_filter: single-strip contexts only");
   CK(hipSetDevice(ctx->device));
   const int C = ctx->prm.cell_n; const size_t L = (size_t)C * C, bytes = L * sizeof(float);
-  float* buf = nullptr; unsigned int* cnt = nullptr;
-  CK(hipMalloc((void**)&buf, bytes * 5));
-  if (hipMalloc((void**)&cnt, sizeof(unsigned int) * (iteration_n + 1)) != hipSuccess) { hipFree(buf); ctx->err = "hipMalloc"; return EMAP_ERR_HIP; }
+  int rc = plugin_scratch(ctx, 5, iteration_n + 1); if (rc) return rc;
+  float* buf = ctx->plug_buf; unsigned int* cnt = ctx->plug_cnt;
   float *orig = buf, *v0 = buf + L, *m0 = buf + 2 * L, *v1 = buf + 3 * L, *m1 = buf + 4 * L;
-  int rc = EMAP_OK;
-  auto ck = [&](hipError_t e) { if (e != hipSuccess && rc == EMAP_OK) { rc = EMAP_ERR_HIP; ctx->err = hipGetErrorString(e); } };
-  ck(hipMemcpyAsync(orig, host_valid, bytes, hipMemcpyHostToDevice, ctx->stream));
-  ck(hipMemcpyAsync(v0, host_elevation, bytes, hipMemcpyHostToDevice, ctx->stream));
-  ck(hipMemcpyAsync(m0, orig, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-  ck(hipMemsetAsync(cnt, 0, sizeof(unsigned int) * (iteration_n + 1), ctx->stream));
-  for (int k = 0; k < iteration_n && rc == EMAP_OK; ++k) {
+  if (host_elevation) {
+    CK(hipMemcpyAsync(orig, host_valid, bytes, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemcpyAsync(v0, host_elevation, bytes, hipMemcpyHostToDevice, ctx->stream));
+  } else {                         // the map's own planes, de-interleaved on the device (no PCIe round trip of the inputs)
+    FLUSH();
+    launch_get_plane(ctx->stream, ctx->kp, ctx->cells, 2, orig);
+    launch_get_plane(ctx->stream, ctx->kp, ctx->cells, 0, v0);
+  }
+  CK(hipMemcpyAsync(m0, orig, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  CK(hipMemsetAsync(cnt, 0, sizeof(unsigned int) * (iteration_n + 1), ctx->stream));
+  for (int k = 0; k < iteration_n; ++k) {
     launch_min_sweep(ctx->stream, C, dilation_size, orig, (k & 1) ? v1 : v0, (k & 1) ? m1 : m0, (k & 1) ? v0 : v1, (k & 1) ? m0 : m1,
                      k > 0 ? cnt + (k - 1) : nullptr, cnt + k, is_max);
-    ck(hipGetLastError());
+    CK(hipGetLastError());
   }
   const float* fv = (iteration_n & 1) ? v1 : v0; const float* fm = (iteration_n & 1) ? m1 : m0;
   std::vector<float> mask(L);
   std::vector<unsigned int> hc(iteration_n + 1);
-  ck(hipMemcpyAsync(host_out, fv, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  ck(hipMemcpyAsync(mask.data(), fm, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  ck(hipMemcpyAsync(hc.data(), cnt, sizeof(unsigned int) * (iteration_n + 1), hipMemcpyDeviceToHost, ctx->stream));
-  ck(hipStreamSynchronize(ctx->stream));
-  hipFree(buf); hipFree(cnt);
-  if (rc != EMAP_OK) return rc;
+  CK(hipMemcpyAsync(host_out, fv, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipMemcpyAsync(mask.data(), fm, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipMemcpyAsync(hc.data(), cnt, sizeof(unsigned int) * (iteration_n + 1), hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
   for (size_t i = 0; i < L; ++i) if (!(mask[i] > 0.5f)) host_out[i] = NAN;     // cp.where(mask > 0.5, filtered, nan), :116
   if (sweeps_run) { int n = 0; for (int k = 0; k < iteration_n; ++k) { ++n; if (hc[k] == 0) break; } *sweeps_run = n; }
   return EMAP_OK;
@@ -1118,27 +1139,33 @@ int emap_inpaint_u8(emap_ctx* ctx, const float* host_image, const float* host_kn
   CKARG(ctx && host_image && host_known && host_out && max_sweeps >= 0 && max_sweeps <= 65536, "bad argument");
   CK(hipSetDevice(ctx->device));
   const int C = ctx->prm.cell_n; const size_t L = (size_t)C * C, bytes = L * sizeof(float);
-  float* buf = nullptr; unsigned int* cnt = nullptr;
-  CK(hipMalloc((void**)&buf, bytes * 4));
-  if (hipMalloc((void**)&cnt, sizeof(unsigned int) * (max_sweeps + 1)) != hipSuccess) { hipFree(buf); ctx->err = "hipMalloc"; return EMAP_ERR_HIP; }
+  const int BATCH = 16;                      // sweeps between two looks at the unfilled counter
+  int rc = plugin_scratch(ctx, 4, BATCH + 1); if (rc) return rc;
+  float* buf = ctx->plug_buf; unsigned int* cnt = ctx->plug_cnt;
   float *v0 = buf, *m0 = buf + L, *v1 = buf + 2 * L, *m1 = buf + 3 * L;
-  int rc = EMAP_OK;
-  auto ck = [&](hipError_t e) { if (e != hipSuccess && rc == EMAP_OK) { rc = EMAP_ERR_HIP; ctx->err = hipGetErrorString(e); } };
-  ck(hipMemcpyAsync(v0, host_image, bytes, hipMemcpyHostToDevice, ctx->stream));
-  ck(hipMemcpyAsync(m0, host_known, bytes, hipMemcpyHostToDevice, ctx->stream));
-  ck(hipMemsetAsync(cnt, 0, sizeof(unsigned int) * (max_sweeps + 1), ctx->stream));
-  for (int k = 0; k < max_sweeps && rc == EMAP_OK; ++k) {
-    launch_inpaint_sweep(ctx->stream, C, (k & 1) ? v1 : v0, (k & 1) ? m1 : m0, (k & 1) ? v0 : v1, (k & 1) ? m0 : m1,
-                         k > 0 ? cnt + (k - 1) : nullptr, cnt + k);
-    ck(hipGetLastError());
+  CK(hipMemcpyAsync(v0, host_image, bytes, hipMemcpyHostToDevice, ctx->stream));
+  CK(hipMemcpyAsync(m0, host_known, bytes, hipMemcpyHostToDevice, ctx->stream));
+  int done = 0; bool filled = false;
+  std::vector<unsigned int> hc(BATCH + 1);
+  while (done < max_sweeps && !filled) {      // the front usually closes after a few sweeps: stop launching once nothing is left
+    const int nb = max_sweeps - done < BATCH ? max_sweeps - done : BATCH;
+    CK(hipMemsetAsync(cnt, 0, sizeof(unsigned int) * (BATCH + 1), ctx->stream));
+    for (int k = 0; k < nb; ++k) {
+      const int g = done + k;
+      launch_inpaint_sweep(ctx->stream, C, (g & 1) ? v1 : v0, (g & 1) ? m1 : m0, (g & 1) ? v0 : v1, (g & 1) ? m0 : m1,
+                           k > 0 ? cnt + (k - 1) : nullptr, cnt + k);
+      CK(hipGetLastError());
+    }
+    CK(hipMemcpyAsync(hc.data(), cnt, sizeof(unsigned int) * (BATCH + 1), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    int used = nb;
+    for (int k = 0; k < nb; ++k) if (hc[k] == 0) { used = k + 1; filled = true; break; }
+    done += nb;                               // sweeps after the closing one are copies: the result is the latest buffer either way
+    if (sweeps_run) *sweeps_run = done - nb + used;
   }
-  std::vector<unsigned int> hc(max_sweeps + 1);
-  ck(hipMemcpyAsync(host_out, (max_sweeps & 1) ? v1 : v0, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  ck(hipMemcpyAsync(hc.data(), cnt, sizeof(unsigned int) * (max_sweeps + 1), hipMemcpyDeviceToHost, ctx->stream));
-  ck(hipStreamSynchronize(ctx->stream));
-  hipFree(buf); hipFree(cnt);
-  if (rc != EMAP_OK) return rc;
-  if (sweeps_run) { int n = 0; for (int k = 0; k < max_sweeps; ++k) { ++n; if (hc[k] == 0) break; } *sweeps_run = n; }
+  if (sweeps_run && max_sweeps == 0) *sweeps_run = 0;
+  CK(hipMemcpyAsync(host_out, (done & 1) ? v1 : v0, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
   return EMAP_OK;
 }
 

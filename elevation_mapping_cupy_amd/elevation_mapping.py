@@ -19,6 +19,54 @@ from ._lib import EmapError, EmapParams, EmapStats, EmapStrip, PLANES, f32p
 from .parameter import Parameter
 
 
+def _shoelace_area(xy):
+    """area of a simple polygon (n, 2)"""
+    x, y = np.asarray(xy, np.float64).T
+    return 0.5 * abs(float(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))))
+
+
+def _hull_ring(cells):
+    """closed counter-clockwise hull ring (k + 1, 2) around integer cells (n, 2), or None when they do not span an area.  The
+    reference asks shapely for ``MultiPoint(...).convex_hull`` (absent here); scipy's Qhull yields the same vertex set."""
+    if cells.shape[0] < 3:
+        return None
+    from scipy.spatial import ConvexHull, QhullError
+    pts = cells.astype(np.float64)
+    try:
+        v = ConvexHull(pts).vertices
+    except QhullError:              # collinear cells
+        return None
+    return np.vstack([pts[v], pts[v[:1]]])
+
+
+class LazyPlanes:
+    """What a plugin receives as ``elevation_map`` / ``semantic_map``: indexable like the reference's ``(L, C, C)`` array, but a
+    plane only crosses PCIe when the plugin actually touches it (the built-in plugins run on the device and never do)."""
+
+    def __init__(self, n, fetch, device_map=None):
+        self._n, self._fetch, self._cache = int(n), fetch, {}
+        self.shape = (self._n,)
+        self.device_map = device_map          # the ElevationMap whose live core planes these are (built-in plugins read them on the device)
+
+    def __len__(self):
+        return self._n
+
+    def _plane(self, k):
+        k = int(k) % self._n if self._n else int(k)
+        if k not in self._cache:
+            self._cache[k] = self._fetch(k)
+        return self._cache[k]
+
+    def __getitem__(self, key):
+        if isinstance(key, (int, np.integer)):
+            return self._plane(key)
+        return np.asarray(self)[key]
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.stack([self._plane(k) for k in range(self._n)], axis=0) if self._n else np.zeros((0, 0, 0), np.float32)
+        return a.astype(dtype) if dtype is not None else a
+
+
 class ElevationMap:
     """Core elevation mapping class (MI355X backend)."""
 
@@ -407,8 +455,14 @@ class ElevationMap:
         m = np.flip(np.flip(m, 0), 1)
         data[...] = m.astype(np.float32)
 
+    def _require_full_map(self, what):
+        if self._strip is not None:
+            raise EmapError("%s works on a full map; this context holds the row strip [%d, %d) -- gather the strips first "
+                            "(ShardedElevationMap)" % (what, self.row_begin, self.row_begin + self.rows))
+
     def _stripped_layer(self, name):
         """border-stripped, unflipped layer as the reference's get_* accessors return it (:598-680, :740-765)"""
+        self._require_full_map("layer read-back (%s)" % name)
         if name == "elevation":
             return self._publish(self.get_layer_raw(0), True, True, self.get_layer_raw(2))
         if name == "variance":
@@ -433,9 +487,10 @@ class ElevationMap:
         if self.semantic_map is not None and name in self.semantic_map.layer_names:
             return self.semantic_map.get_map_with_name(name)
         if self.plugin_manager is not None and name in self.plugin_manager.layer_names:
+            sem = self.semantic_map
             self.plugin_manager.update_with_name(
-                name, self.elevation_map, self.layer_names,
-                self.semantic_map.semantic_map if self.semantic_map is not None else None,
+                name, LazyPlanes(7, self.get_layer_raw, device_map=self), self.layer_names,
+                LazyPlanes(len(sem.layer_names), sem._layer) if sem is not None else None,
                 self.semantic_map.layer_names if self.semantic_map is not None else [],
                 self.base_rotation, self.semantic_map.elements_to_shift if self.semantic_map is not None else {})
             m = self.plugin_manager.get_map_with_name(name)
@@ -487,32 +542,35 @@ class ElevationMap:
         return mask
 
     def get_polygon_traversability(self, polygon, result):
-        from .traversability_polygon import (calculate_area, get_masked_traversability, is_traversable,
-                                             transform_to_map_position)
-        polygon = np.asarray(polygon)
-        area = calculate_area(polygon)
-        polygon = polygon.astype(np.float32)
-        pmin = self.center[:2] - self.map_length / 2 + self.resolution
-        pmax = self.center[:2] + self.map_length / 2 - self.resolution
-        polygon[:, 0] = polygon[:, 0].clip(pmin[0], pmax[0])
-        polygon[:, 1] = polygon[:, 1].clip(pmin[1], pmax[1])
-        clipped_area = calculate_area(polygon)
+        """Safety check of a footprint polygon (node service; reference :837-889).  The cell mask comes from the device
+        (``emap_polygon_mask`` = the reference's polygon_mask_kernel, bit-exact); the statistics are a few reductions over the
+        masked interior: ``result`` = (is_safe, mean untraversability of the known cells inside, polygon area); the return value is
+        the vertex count of the hull around the cells that are too untraversable (``get_untraversable_polygon`` hands it out)."""
+        self._require_full_map("get_polygon_traversability")
+        poly = np.asarray(polygon, np.float64)
+        area = _shoelace_area(poly)
+        reach = self.map_length / 2 - self.resolution                  # the polygon is clipped to the map interior (:851-855)
+        clipped = np.clip(poly.astype(np.float32), self.center[:2] - reach, self.center[:2] + reach).astype(np.float32)
         with self.map_lock:
-            self.mask = self.polygon_mask(polygon)
-            tmp_map = self.get_layer(self.param.checker_layer)
-            masked, masked_isvalid = get_masked_traversability(self.elevation_map, self.mask, tmp_map)
-        t = masked.sum() / masked_isvalid.sum() if masked_isvalid.sum() > 0 else np.float32(0.0)
-        is_safe, un_polygon = is_traversable(masked, self.param.safe_thresh, self.param.safe_min_thresh, self.param.max_unsafe_n)
-        untraversable_polygon_num = 0
-        if un_polygon is not None:
-            un_polygon = transform_to_map_position(un_polygon, self.center[:2], self.cell_n, self.resolution)
-            untraversable_polygon_num = un_polygon.shape[0]
-        if clipped_area < 0.001:
-            is_safe = False
+            self.mask = self.polygon_mask(clipped)
+            layer = np.asarray(self.get_layer(self.param.checker_layer), np.float32)
+            valid = self.get_layer_raw("is_valid")
+        inner = (slice(1, -1), slice(1, -1))
+        footprint, known = self.mask[inner], valid[inner]
+        risk = np.where(known > 0.5, 1.0 - layer[inner], 0.0) * footprint           # unknown cells count as traversable
+        n_known = float((known * footprint).sum())
+        mean_risk = float(risk.sum()) / n_known if n_known > 0 else 0.0
+        too_risky = risk > 1.0 - self.param.safe_thresh
+        safe = int(too_risky.sum()) <= self.param.max_unsafe_n and float(risk.max()) <= 1.0 - self.param.safe_min_thresh
+        if _shoelace_area(clipped) < 0.001:
             print("requested polygon is outside of the map")
-        result[...] = np.array([is_safe, float(t), float(area)])
-        self.untraversable_polygon = un_polygon
-        return untraversable_polygon_num
+            safe = False
+        ring = _hull_ring(np.argwhere(too_risky))
+        if ring is not None:                                            # cell indices of the border-stripped view -> map frame
+            ring = self.center[:2].reshape(1, 2) + (ring - self.cell_n / 2.0) * self.resolution
+        self.untraversable_polygon = ring
+        result[...] = np.array([safe, mean_risk, area])
+        return 0 if ring is None else int(ring.shape[0])
 
     def get_untraversable_polygon(self, untraversable_polygon):
         untraversable_polygon[...] = np.asarray(self.untraversable_polygon)
@@ -523,11 +581,12 @@ class ElevationMap:
         ``scipy.interpolate.griddata`` -- host code in the reference too -- then two dilation passes of radius
         ``dilation_size_initialize`` on the device and upper bound := elevation on valid cells."""
         from scipy.interpolate import griddata
-        from .traversability_polygon import transform_to_map_index
+        self._require_full_map("initialize_map")
         self.clear()
         with self.map_lock:
             points = np.array(points, dtype=np.float32)
-            indices = transform_to_map_index(points[:, :2], self.center[:2].astype(np.float32), self.cell_n, self.resolution)
+            # world x, y -> (fractional, truncated) cell indices around the map centre
+            indices = ((points[:, :2] - self.center[:2].astype(np.float32).reshape(1, 2)) / self.resolution + self.cell_n / 2).astype(np.int32)
             points[:, :2] = indices.astype(points.dtype)
             points[:, 2] -= self.center[2]
             m = self.elevation_map
@@ -570,9 +629,10 @@ class ElevationMap:
         if self.semantic_map is not None and name in self.semantic_map.layer_names:
             return self.semantic_map._layer(self.semantic_map.layer_names.index(name))
         if self.plugin_manager is not None and name in self.plugin_manager.layer_names:
+            sem = self.semantic_map
             self.plugin_manager.update_with_name(
-                name, self.elevation_map, self.layer_names,
-                self.semantic_map.semantic_map if self.semantic_map is not None else None,
+                name, LazyPlanes(7, self.get_layer_raw, device_map=self), self.layer_names,
+                LazyPlanes(len(sem.layer_names), sem._layer) if sem is not None else None,
                 self.semantic_map.layer_names if self.semantic_map is not None else [],
                 self.base_rotation, self.semantic_map.elements_to_shift if self.semantic_map is not None else {})
             return self.plugin_manager.get_map_with_name(name)

@@ -24,11 +24,16 @@ class MaxFilter(PluginBase):
                  plugin_layer_names: List[str], *args) -> np.ndarray:
         if self.emap is None:
             raise RuntimeError("MaxFilter needs the owning ElevationMap (PluginManager(emap=...)): it runs on the device")
-        h = np.ascontiguousarray(elevation_map[0], np.float32)
-        v = np.ascontiguousarray(elevation_map[2], np.float32)
-        out = np.empty_like(h)
-        n = ct.c_int32(0)
         e = self.emap
-        e._chk(e._lib.emap_max_filter(e._ctx, f32p(h), f32p(v), self.dilation_size, self.iteration_n, f32p(out), ct.byref(n)))
+        out = np.empty((e.cell_n, e.cell_n), np.float32)
+        n = ct.c_int32(0)
+        if getattr(elevation_map, "device_map", None) is e:
+            # the map's own live planes (get_map_with_name_ref): NULL inputs = read elevation / is_valid on the device, only the
+            # result crosses PCIe
+            e._chk(e._lib.emap_max_filter(e._ctx, None, None, self.dilation_size, self.iteration_n, f32p(out), ct.byref(n)))
+        else:
+            h = np.ascontiguousarray(elevation_map[0], np.float32)
+            v = np.ascontiguousarray(elevation_map[2], np.float32)
+            e._chk(e._lib.emap_max_filter(e._ctx, f32p(h), f32p(v), self.dilation_size, self.iteration_n, f32p(out), ct.byref(n)))
         self.sweeps_run = n.value
         return out

@@ -166,7 +166,8 @@ int emap_semantic_set_alpha(emap_ctx* ctx, int32_t layer, const float* host_in);
 
 /* MinFilter plugin (EM/plugins/min_filter.py:84-118): fills cells with valid < 0.5 by the window minimum of already
  * filled values, up to iteration_n sweeps, stops after the sweep that filled everything; NaN where still unfilled.
- * Planes are (cell_n, cell_n) host buffers handed to the plugin (PluginBase.__call__ convention). */
+ * Planes are (cell_n, cell_n) host buffers handed to the plugin (PluginBase.__call__ convention); with both inputs NULL the
+ * map's own elevation / is_valid planes are taken on the device (the built-in plugin: only the result crosses PCIe). */
 int emap_min_filter(emap_ctx* ctx, const float* host_elevation, const float* host_valid, int32_t dilation_size,
                     int32_t iteration_n, float* host_out, int32_t* sweeps_run_or_null);
 

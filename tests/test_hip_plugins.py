@@ -215,3 +215,23 @@ def test_inpainting_substitute_properties():
     truth = (0.5 * np.sin(xx / 17.0) + 0.3 * np.cos(yy / 11.0))
     assert np.abs(out[~known] - truth[~known]).mean() < 0.05                 # and is a sensible reconstruction of the smooth surface
     assert 1 <= ip.sweeps_run <= 40
+
+
+def test_builtin_plugins_read_the_live_map_on_the_device(weights, tmp_path):
+    """get_map_with_name_ref hands the plugins a lazy view of the map: MinFilter takes elevation / is_valid on the device (no plane is
+    fetched to the host), a user plugin that indexes the view gets host planes on demand -- both see the same map"""
+    from elevation_mapping_cupy_amd.elevation_mapping import LazyPlanes
+    from elevation_mapping_cupy_amd.plugins.min_filter import MinFilter
+    C = 130
+    hip, _ = make_pair(eo.DEFAULTS, C, "reference_fp16", weights)
+    R, t = fx.POSES["rotated"]
+    hip.update_map_with_kernel(fx.cloud(C, 9000, 2), [], R, t.copy(), 0.0, 0.0)
+    fetched = []
+    view = LazyPlanes(7, lambda k: (fetched.append(k), hip.get_layer_raw(k))[1], device_map=hip)
+    mf = MinFilter(cell_n=C, dilation_size=1, iteration_n=30, emap=hip)
+    on_device = mf(view, hip.layer_names, None, [])
+    assert fetched == []                                         # nothing crossed PCIe but the result
+    from_host = mf(hip.elevation_map, hip.layer_names, None, [])
+    assert np.array_equal(on_device, from_host, equal_nan=True)
+    assert np.array_equal(view[2], hip.get_layer_raw(2)) and fetched == [2]      # a user plugin indexing the view
+    assert np.asarray(view).shape == (7, C, C)
