@@ -454,7 +454,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_overlap(KP P, Cell* __restrict__ c
 }
 
 // (The 12 x 9 taps are explicit fma chains in a fixed order; the reference's cuDNN summation order is unspecified, tolerance 1e-5.)
-struct TravW { float w[3][36]; float wo[12]; };   // weights of the traversability filter (traversability_filter.py:8-47) as kernargs (SGPRs)
+struct TravW { float w[3][9][4]; float wo[3][4]; };   // weights of the traversability filter (traversability_filter.py:8-47) as kernargs (SGPRs): [filter][tap][channel]
 
 // ---------------------------------------------------------------------------------------------------------
 // k_post = dilation -> traversability filter + normals in ONE launch (elevation_mapping.py:376-391).  The dilated
@@ -463,8 +463,9 @@ struct TravW { float w[3][36]; float wo[12]; };   // weights of the traversabili
 // because it is a readable attribute of the reference class.
 // ---------------------------------------------------------------------------------------------------------
 #define PT_C 64
-#define PT_THREADS 512   /* 8 waves per tile: the kernel is latency/issue bound, 32 resident waves per CU hide it */
-#define PT_WAVES (PT_THREADS / 64)
+#ifndef POST_T32
+#define POST_T32 512
+#endif
 // PT_R = tile height: 16 for large maps (less halo amplification), 4 for small maps (4x more workgroups: a robot-scale
 // 200^2 map has only 52 tiles of 16 rows and the kernel time is then one workgroup's latency chain).
 // Rows are LOGICAL map rows here (the stencils are defined on the logical map; a tile never straddles the circular seam because
@@ -472,74 +473,118 @@ struct TravW { float w[3][36]; float wo[12]; };   // weights of the traversabili
 // STAGE 0: everything; 1: dilation only (traversability_input), the separately callable stage of the parity tests.
 // Up to four logical row intervals per launch (a strip's rows around the circular seam, the boundary rows of a strip): a launch of a
 // few tiles alone costs a whole workgroup latency chain (~18 us measured), so the pieces go into ONE grid.
-struct PostSegs { int n, b[4], e[4], t0[4]; };     // interval [b, e) starts at tile row t0 of the grid
+struct PostSegs { int n, b[4], e[4], t0[4]; unsigned int emagic; };     // interval [b, e) starts at tile row t0 of the grid; emagic = ceil(2^32 / (6 + 2d))
+// cheap correctly-rounded-in-practice float helpers of the stencil epilogue (the IEEE division / sqrt / exp sequences of the
+// compiler cost ~55 vector instructions per cell here and the kernel is issue bound).  Error <= 1 ulp against the reference's
+// IEEE operations; the parity tolerance on traversability / normals is 1e-5 (cuDNN's summation order is unspecified anyway).
+__device__ __forceinline__ float div_by(float a, float b, float rb) {      // a / b with rb ~ 1/b (relative error <= 1 ulp)
+  const float q = a * rb;
+  return fmaf(fmaf(-q, b, a), rb, q);
+}
+__device__ __forceinline__ float exp_neg(float a) {                         // exp(-a), a >= 0
+  const float x = -a, L2E = 1.44269502f, L2E_LO = 1.92596299e-8f;
+  const float t = x * L2E;
+  float lo = fmaf(x, L2E, -t);
+  lo = fmaf(x, L2E_LO, lo);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, lo * 0.693147182f, e);
+}
+
 template <int PT_R, int STAGE>
-__global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __restrict__ cells, float* __restrict__ trav_in,
+__global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, TravW Wt, Cell* __restrict__ cells, float* __restrict__ trav_in,
                                                     float* __restrict__ normal, long plane_stride, int d, PostSegs S) {
   int seg_b = S.b[0], seg_e = S.e[0], ty = blockIdx.y;
 #pragma unroll
   for (int k = 1; k < 4; ++k) if (k < S.n && (int)blockIdx.y >= S.t0[k]) { seg_b = S.b[k]; seg_e = S.e[k]; ty = blockIdx.y - S.t0[k]; }
+  constexpr int PT_THREADS = PT_R >= 32 ? POST_T32 : 512, PT_WAVES = PT_THREADS / 64;     // 32-row tiles: 16 waves, two output rows per thread
   extern __shared__ float lds[];
   const int RW = PT_C + 6 + 2 * d, rp = RW + 1, RH = PT_R + 6 + 2 * d;     // staged (value, mask) region: tile + halo 3 + d
   const int DW = PT_C + 6, DH = PT_R + 6;                                   // region whose DILATED value is needed (halo 3)
   float* rval = lds;                     // raw upper_bound; holes inside the DW x DH region are overwritten by their dilated value
   float* rmsk = rval + RH * rp;          // mask >= 0; stored as -(mask)-1 when the cell is NOT is_inside (never a source)
   float* sval = rmsk + RH * rp;          // is_valid of the PT_R x PT_C interior (normal filter)
+  int* rtab = reinterpret_cast<int*>(sval + PT_R * PT_C);     // RH + 2 row terms
   const int C = P.C;
   const int tile_r = seg_b + ty * PT_R, tile_c = blockIdx.x * PT_C;      // logical row / column of the tile origin
-  const int tc = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave index in an SGPR: row terms are scalar
-  // staging.  The first 64 columns of the region go row-wise (one wave per region row, lane = column: the row terms are wave
-  // uniform, a cell costs a handful of vector instructions), the remaining 6 + 2d columns as a linear walk over (row, column)
-  // pairs so that their lanes are full too.  All loads of a round (valid: 1 dword; upper + is_upper: 2 dwords of the 32-B cell) are
-  // issued before any is consumed: a 44 x 76 region (32-row tile, d = 3) is ONE round = one memory round trip.
+  const int tc = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave index in an SGPR
+  // staging.  The first 64 columns of the region go row-wise: one wave per region row, lane = column.  Everything that depends on
+  // the row (circular origin, strip ownership, border) is computed ONCE per tile into a small LDS table, everything that depends
+  // on the column once per lane; a cell then costs one table read and one add for its address.  Tiles at the left / right map edge
+  // see the reference's flat-index row wrap (:403-407: column -1 of row r is column C-1 of row r-1): such a lane reads the table
+  // one row up or down.  The remaining 6 + 2d columns go as a linear walk over (row, column) pairs so that their lanes are full too.
+  // All loads of a round (valid: 1 dword; upper + is_upper: 2 dwords of the 32-B cell) are issued before any is consumed: a 44 x 76
+  // region (32-row tile, d = 3) is ONE round = one memory round trip.
   {
-    constexpr int JB = 6, EU = 2;                   // rows per wave and edge cells per thread in one round
+    constexpr int JB = PT_R >= 32 ? 48 / PT_WAVES : 6, EU = PT_R >= 32 ? (528 + PT_THREADS - 1) / PT_THREADS : 2;     // rows per wave and edge cells per thread in one round
     const int r0 = tile_r - 3 - d, c0 = tile_c - 3 - d, EC = RW - 64;
     const int etotal = RH * EC;
-    const unsigned int emagic = (unsigned int)((0x100000000ull + (unsigned long long)EC - 1ull) / (unsigned long long)EC);
-    auto locate = [&](int r, int cc, long& ci, bool& ok, bool& inside) {     // region (r, cc) -> cell index, flags
-      int gr = r0 + r, cl = c0 + cc;
-      if (cl < 0) { cl += C; gr -= 1; } else if (cl >= C) { cl -= C; gr += 1; }      // flat-index row wrap (:403-407)
-      const bool in_map = gr >= 0 && gr <= C - 1;
-      const int lrow = in_map ? local_row(P, phys_row(P, gr)) : -1;
-      ok = lrow >= 0;
-      inside = gr >= 1 && gr <= C - 2 && cl >= 1 && cl <= C - 2;
-      ci = (long)lrow * C + phys_col(P, in_map ? cl : 0);
+    // row table: region row j - 1 (one extra row on both sides for the flat-index carry) -> index of its first cell in the local
+    // arrays, -1: not in the map / strip; bit 30: a border row (never a dilation source)
+    for (int j = threadIdx.x; j < RH + 2; j += PT_THREADS) {
+      const int g = r0 - 1 + j;
+      const bool in_map = g >= 0 && g <= C - 1;
+      const int lr = in_map ? local_row(P, phys_row(P, g)) : -1;
+      rtab[j] = lr < 0 ? -1 : (lr * C) | ((g >= 1 && g <= C - 2) ? 0 : 0x40000000);
+    }
+    __syncthreads();
+    auto col_terms = [&](int cc, int& dr, int& pc, bool& cin) {     // region column -> row carry, physical column, inside flag
+      int cl = c0 + cc; dr = 0;
+      if (cl < 0) { cl += C; dr = -1; } else if (cl >= C) { cl -= C; dr = 1; }
+      cin = cl >= 1 && cl <= C - 2;
+      pc = cl < C ? phys_col(P, cl) : -1;                            // (a region wider than the map: columns past the wrap are unused)
     };
+    int ldr, lpc; bool lcin;
+    col_terms(tc, ldr, lpc, lcin);
+    const int icl = tc - 3 - d;                                      // interior column of the lane's region column
+    const int* ltab = rtab + 1 + ldr;                                // the lane's view of the row table
     for (int rb = 0, eb = 0; rb < RH || eb < etotal; rb += PT_WAVES * JB, eb += PT_THREADS * EU) {
+      // per unit: LDS slot (-1: none), interior slot of the validity tile (-1: none), inside flag, the three dwords of the cell
+      // (cells that are not in the map / strip load cell 0 and are masked afterwards: no divergent branch around the loads)
       float fv[JB + EU]; float2 fu[JB + EU]; int ol[JB + EU], os[JB + EU]; bool okk[JB + EU], ins[JB + EU];
 #pragma unroll
-      for (int u = 0; u < JB + EU; ++u) {
-        int r, cc; bool have;
-        if (u < JB) { r = rb + wv + PT_WAVES * u; cc = tc; have = r < RH; }
-        else {
-          const int e = eb + (u - JB) * PT_THREADS + (int)threadIdx.x;
-          r = (int)__umulhi((unsigned int)e, emagic); cc = 64 + e - r * EC; have = e < etotal;
-        }
-        long ci;
-        locate(r, cc, ci, okk[u], ins[u]);
-        okk[u] = okk[u] && have;
-        ol[u] = have ? r * rp + cc : -1;
-        const int ir = r - 3 - d, ic = cc - 3 - d;
-        os[u] = (ir >= 0 && ir < PT_R && ic >= 0 && ic < PT_C) ? ir * PT_C + ic : -1;
-        fv[u] = 0.f; fu[u] = make_float2(0.f, 0.f);
-        if (okk[u]) {
-          const float* cp = reinterpret_cast<const float*>(&cells[ci]);
+      for (int u = 0; u < JB; ++u) {
+        const int r = rb + wv + PT_WAVES * u;                       // scalar
+        ol[u] = -1;
+        if (r < RH) {
+          const int T = ltab[r];
+          okk[u] = T >= 0 && lpc >= 0;
+          ins[u] = lcin && !(T & 0x40000000);
+          ol[u] = r * rp + tc;
+          const int ir = r - 3 - d;
+          os[u] = (okk[u] && ir >= 0 && ir < PT_R && icl >= 0 && icl < PT_C) ? ir * PT_C + icl : -1;
+          const float* cp = reinterpret_cast<const float*>(&cells[okk[u] ? (T & 0x3fffffff) + lpc : 0]);
           fv[u] = cp[2];                                                       // Cell: h v valid trav | time upper is_upper pad
           fu[u] = *reinterpret_cast<const float2*>(cp + 5);
         }
       }
 #pragma unroll
-      for (int u = 0; u < JB + EU; ++u) {
-        if (ol[u] < 0) continue;
-        float val = 0.f, msk = -1.f;
-        if (okk[u]) {
-          val = fu[u].x;
-          const float m = fv[u] + fu[u].y;
-          msk = ins[u] ? m : -m - 1.f;
-          if (os[u] >= 0) sval[os[u]] = fv[u];
+      for (int k = 0; k < EU; ++k) {
+        const int u = JB + k;
+        ol[u] = -1;
+        const int ebase = eb + k * PT_THREADS + wv * 64;            // scalar: first element of this wave
+        if (ebase < etotal) {
+          const int e = min(ebase + tc, etotal - 1);                // (the spare lanes of the last wave repeat its last element)
+          const int r = (int)__umulhi((unsigned int)e, S.emagic), cc = 64 + e - r * EC;
+          int dr, pc; bool cin;
+          col_terms(cc, dr, pc, cin);
+          const int T = rtab[r + 1 + dr];
+          okk[u] = T >= 0 && pc >= 0;
+          ins[u] = cin && !(T & 0x40000000);
+          ol[u] = r * rp + cc;
+          const int ir = r - 3 - d, ic = cc - 3 - d;
+          os[u] = (okk[u] && ir >= 0 && ir < PT_R && ic >= 0 && ic < PT_C) ? ir * PT_C + ic : -1;
+          const float* cp = reinterpret_cast<const float*>(&cells[okk[u] ? (T & 0x3fffffff) + pc : 0]);
+          fv[u] = cp[2];
+          fu[u] = *reinterpret_cast<const float2*>(cp + 5);
         }
-        rval[ol[u]] = val; rmsk[ol[u]] = msk;
+      }
+#pragma unroll
+      for (int u = 0; u < JB + EU; ++u) {
+        if (ol[u] < 0) continue;                                    // uniform
+        const float m = fv[u] + fu[u].y;
+        rval[ol[u]] = okk[u] ? fu[u].x : 0.f;
+        rmsk[ol[u]] = okk[u] ? (ins[u] ? m : -m - 1.f) : -1.f;
+        if (os[u] >= 0) sval[os[u]] = fv[u];
       }
     }
   }
@@ -547,7 +592,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
   // wave would otherwise drag all 64 lanes through the neighbour search (measured: 11 of 33 us with 1.5 % holes).  The dilated
   // value replaces the raw one IN PLACE: only cells with mask > 0.5 are ever sources and the masks are not touched, so a filled
   // hole cannot feed another hole (Jacobi semantics of the reference kernel), and the stencils below read one array.
-  unsigned short* holes = reinterpret_cast<unsigned short*>(sval + PT_R * PT_C);
+  unsigned short* holes = reinterpret_cast<unsigned short*>(rtab + ((RH + 3) & ~1));
   __shared__ unsigned int n_holes;
   if (threadIdx.x == 0) n_holes = 0u;
   __syncthreads();
@@ -578,86 +623,57 @@ __global__ __launch_bounds__(PT_THREADS) void k_post(KP P, TravW Wt, Cell* __res
   const int pcol = phys_col(P, col);
   const float* dil = rval + d * rp + d;          // dilated plane of the DW x DH region, pitch rp
   const int dp = rp;
-  // Every wave owns PT_R / 8 consecutive tile rows of its column.  Rows are processed in PAIRS with packed fp32 FMAs
-  // (v_pk_fma_f32: the two rows' taps sit in one 64-bit register pair, the weight is a scalar): the same fmaf chain per row,
-  // half the vector instructions of the 12 x 9-tap filter bank.
+  // Every wave owns PT_R / 8 consecutive tile rows of its column.  The four channels of a dilated 3x3 filter go through packed
+  // fp32 FMAs in PAIRS (v_pk_fma_f32: the two channels' weights are one aligned scalar register pair, the tap is broadcast): each
+  // channel keeps the reference's tap order, and the 1x1 output convolution is the same scalar chain over (filter, channel) as the
+  // unfused stage -- half the vector instructions of the 12 x 9-tap filter bank, identical sums.
   typedef float v2f __attribute__((ext_vector_type(2)));
   constexpr int RPW = PT_R >= PT_WAVES ? PT_R / PT_WAVES : 1;
-  auto finish_row = [&](int tr, float acc, bool have_acc) {      // traversability, normal, plane writes of one tile row
-    const int gr = tile_r + tr;
-    const long c = (long)local_row(P, phys_row(P, gr)) * C + pcol;
+  const bool col_in = STAGE == 0 && col >= 3 && col <= C - 4;
+  const bool col_n = col >= 1 && col <= C - 3;
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int tr = wv * RPW + k, gr = tile_r + tr;                 // scalar
+    if (tr >= PT_R || gr >= seg_e) break;
     const float* t0 = &dil[(tr + 3) * dp + (tc + 3)];
-    trav_in[c] = t0[0];
-    if (STAGE == 1) return;
-    if (have_acc) cells[c].trav = expf(-acc);
+    const long c = (long)(rtab[tr + 4 + d] & 0x3fffffff) + pcol;
+    const float h = t0[0];
+    trav_in[c] = h;
+    if (STAGE == 1) continue;
+    if (col_in && gr >= 3 && gr <= C - 4) {
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int dl = q + 1;
+        v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+#pragma unroll
+        for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) {
+            const float t = t0[(a2 - 1) * dl * dp + (b2 - 1) * dl];
+            const v2f tt = {t, t};
+            const float* w = Wt.w[q][a2 * 3 + b2];
+            s01 = __builtin_elementwise_fma((v2f){w[0], w[1]}, tt, s01);
+            s23 = __builtin_elementwise_fma((v2f){w[2], w[3]}, tt, s23);
+          }
+        acc = fmaf(Wt.wo[q][0], fabsf(s01.x), acc);
+        acc = fmaf(Wt.wo[q][1], fabsf(s01.y), acc);
+        acc = fmaf(Wt.wo[q][2], fabsf(s23.x), acc);
+        acc = fmaf(Wt.wo[q][3], fabsf(s23.y), acc);
+      }
+      cells[c].trav = exp_neg(acc);
+    }
     float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (gr >= 1 && gr <= C - 3 && col >= 1 && col <= C - 3 && sval[tr * PT_C + tc] > 0.5f) {
-      float h = t0[0], dzdx = t0[1] - h, dzdy = t0[dp] - h;
-      float ax = -dzdy / P.res_f, ay = -dzdx / P.res_f;
-      float nrm = sqrtf((ax * ax) + (ay * ay) + 1.0f);
-      nx = ax / nrm; ny = ay / nrm; nz = 1.0f / nrm;
+    if (col_n && gr >= 1 && gr <= C - 3 && sval[tr * PT_C + tc] > 0.5f) {
+      const float dzdx = t0[1] - h, dzdy = t0[dp] - h;
+      const float ax = -div_by(dzdy, P.res_f, P.inv_res_f), ay = -div_by(dzdx, P.res_f, P.inv_res_f);
+      const float x = (ax * ax) + (ay * ay) + 1.0f;                    // >= 1
+      const float s0 = __builtin_amdgcn_sqrtf(x), r0 = __builtin_amdgcn_rcpf(s0);
+      const float nrm = fmaf(fmaf(-s0, s0, x), 0.5f * r0, s0);        // one Newton step each on the root and its reciprocal
+      const float rn = fmaf(fmaf(-nrm, r0, 1.0f), r0, r0);
+      nx = div_by(ax, nrm, rn); ny = div_by(ay, nrm, rn); nz = div_by(1.0f, nrm, rn);
     }
     normal[c] = nx; normal[plane_stride + c] = ny; normal[2 * plane_stride + c] = nz;
-  };
-  const bool col_in = STAGE == 0 && col >= 3 && col <= C - 4;
-  if constexpr (RPW % 2 == 0) {
-#pragma unroll
-    for (int k = 0; k < RPW / 2; ++k) {
-      const int tr = wv * RPW + 2 * k, gr = tile_r + tr;
-      if (gr >= seg_e) break;
-      const bool row1 = gr + 1 < seg_e;
-      const bool in0 = col_in && gr >= 3 && gr <= C - 4, in1 = col_in && row1 && gr + 1 >= 3 && gr + 1 <= C - 4;
-      v2f acc = {0.f, 0.f};
-      if (in0 || in1) {
-        const float* t0 = &dil[(tr + 3) * dp + (tc + 3)];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int dl = q + 1;
-#pragma unroll
-          for (int ch = 0; ch < 4; ++ch) {
-            v2f sm = {0.f, 0.f};
-#pragma unroll
-            for (int a2 = 0; a2 < 3; ++a2)
-#pragma unroll
-              for (int b2 = 0; b2 < 3; ++b2) {
-                const float* pp = t0 + (a2 - 1) * dl * dp + (b2 - 1) * dl;
-                const v2f tv = {pp[0], pp[dp]};
-                const float w = Wt.w[q][ch * 9 + a2 * 3 + b2];
-                sm = __builtin_elementwise_fma((v2f){w, w}, tv, sm);
-              }
-            const float wo = Wt.wo[q * 4 + ch];
-            acc = __builtin_elementwise_fma((v2f){wo, wo}, __builtin_elementwise_abs(sm), acc);
-          }
-        }
-      }
-      finish_row(tr, acc.x, in0);
-      if (row1) finish_row(tr + 1, acc.y, in1);
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < RPW; ++k) {
-      const int tr = wv * RPW + k, gr = tile_r + tr;
-      if (tr >= PT_R || gr >= seg_e) break;
-      const bool in0 = col_in && gr >= 3 && gr <= C - 4;
-      float acc = 0.f;
-      if (in0) {
-        const float* t0 = &dil[(tr + 3) * dp + (tc + 3)];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int dl = q + 1;
-#pragma unroll
-          for (int ch = 0; ch < 4; ++ch) {
-            float sm = 0.f;
-#pragma unroll
-            for (int a2 = 0; a2 < 3; ++a2)
-#pragma unroll
-              for (int b2 = 0; b2 < 3; ++b2) sm = fmaf(Wt.w[q][ch * 9 + a2 * 3 + b2], t0[(a2 - 1) * dl * dp + (b2 - 1) * dl], sm);
-            acc = fmaf(Wt.wo[q * 4 + ch], fabsf(sm), acc);
-          }
-        }
-      }
-      finish_row(tr, acc, in0);
-    }
   }
 }
 
@@ -863,8 +879,8 @@ void launch_overlap(hipStream_t s, const KP& P, Cell* cells, int cmin, int cmax,
   if (w <= 0) return;
   hipLaunchKernelGGL(k_overlap, dim3(nblk(w * w)), dim3(EM_BLOCK), 0, s, P, cells, cmin, cmax, hmin, hmax);
 }
-static size_t post_lds_bytes(int R, int d) {      // raw (value, mask) region, validity of the interior, hole list
-  return sizeof(float) * ((size_t)2 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)R * PT_C) + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;
+static size_t post_lds_bytes(int R, int d) {      // raw (value, mask) region, validity of the interior, row table, hole list
+  return sizeof(float) * ((size_t)2 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)R * PT_C + (size_t)(R + 6 + 2 * d + 4)) + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;
 }
 int post_tile_rows(const KP& P) {
   static const int force_r = []() { const char* e = getenv("EMAP_POST_R"); int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32) ? v : 0; }();
@@ -880,17 +896,22 @@ int post_tile_rows(const KP& P) {
 void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, const float* w3, const float* wo, Cell* cells,
                  float* trav_in, float* normal, long plane_stride, int d, int nseg, const int* seg_b, const int* seg_e, int stage) {
   TravW W;
-  for (int i = 0; i < 36; ++i) { W.w[0][i] = w1[i]; W.w[1][i] = w2[i]; W.w[2][i] = w3[i]; }
-  for (int i = 0; i < 12; ++i) W.wo[i] = wo[i];
+  const float* wq[3] = {w1, w2, w3};                       // conv weights [channel][tap] -> [tap][channel]
+  for (int q = 0; q < 3; ++q)
+    for (int ch = 0; ch < 4; ++ch) {
+      for (int tap = 0; tap < 9; ++tap) W.w[q][tap][ch] = wq[q][ch * 9 + tap];
+      W.wo[q][ch] = wo[q * 4 + ch];
+    }
   const int R = post_tile_rows(P);
   PostSegs S; memset(&S, 0, sizeof S);
+  S.emagic = (unsigned int)((0x100000000ull + (unsigned long long)(6 + 2 * d) - 1ull) / (unsigned long long)(6 + 2 * d));
   int tiles = 0;
   for (int k = 0; k < nseg && S.n < 4; ++k) {
     if (seg_e[k] <= seg_b[k]) continue;
     S.b[S.n] = seg_b[k]; S.e[S.n] = seg_e[k]; S.t0[S.n] = tiles; tiles += (seg_e[k] - seg_b[k] + R - 1) / R; S.n++;
   }
   if (!tiles) return;
-  dim3 g((P.C + PT_C - 1) / PT_C, tiles), b(PT_THREADS);
+  dim3 g((P.C + PT_C - 1) / PT_C, tiles), b(R >= 32 ? POST_T32 : 512);
   const size_t lds = post_lds_bytes(R, d);
 #define POST_GO(RR, ST) do { auto kern = k_post<RR, ST>; static bool raised = false; \
     if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; } \
