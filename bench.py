@@ -122,7 +122,7 @@ STAGE_BYTES = {
     "overlap": lambda N, L: 0,
     "post": lambda N, L: 40 * L,
 }
-STAGE_KERNEL = {"hist": "k_bin_hist", "scan": "k_bin_scan1", "scatter": "k_bin_scatter", "gate": "k_tile_count", "fuse": "k_tile_fuse",
+STAGE_KERNEL = {"hist": "k_bin_hist", "scan": "k_bin_scan", "scatter": "k_bin_scatter", "gate": "k_tile_count", "fuse": "k_tile_fuse",
                 "commit": "k_commit", "rays": "k_rays<0, false", "average": "k_average", "overlap": "k_overlap", "post": "k_post"}
 
 
@@ -165,18 +165,25 @@ def event_overhead(lib, ctx):
 
 
 def stage_profile(lib, ctx, frame, reps, with_stats=True):
+    """HIP-event spacings of the stages, measured on the SAME kernels the timed frames run; the cell-visit count of the visibility
+    pass comes from two extra frames with the counting variant of k_rays (a few more vector instructions per step)"""
     from elevation_mapping_cupy_amd import _lib
-    lib.emap_enable_stage_timing(ctx, 2 if with_stats else 1)
+    lib.emap_enable_stage_timing(ctx, 1)
     acc = np.zeros(10)
     st = _lib.EmapStats()
-    visits = 0
     for i in range(reps):
-        frame(i, ct.byref(st) if with_stats else None)
+        frame(i, None)
         ms10 = (ct.c_float * 10)()
         lib.emap_get_stage_times(ctx, ms10)
-        acc += np.array(list(ms10)); visits += st.ray_visits
+        acc += np.array(list(ms10))
+    visits = 0
+    if with_stats:
+        lib.emap_enable_stage_timing(ctx, 2)
+        for i in range(2):
+            frame(reps + i, ct.byref(st))
+            visits += st.ray_visits / 2
     lib.emap_enable_stage_timing(ctx, 0)
-    return dict(zip(_lib.STAGES, (acc / reps).tolist())), visits / reps
+    return dict(zip(_lib.STAGES, (acc / reps).tolist())), visits
 
 
 def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step, visits, pmc_ok, stage_bytes=None):

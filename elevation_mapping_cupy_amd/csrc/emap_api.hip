@@ -22,11 +22,11 @@
 
 // launchers (emap_kernels.hip)
 void launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, ErrSlot*);
-void launch_gate(hipStream_t, const KP&, ErrSlot*, FrameDev*, int, double, double, float, int, int, double, unsigned int, unsigned int, int, double*, const double*);
+void launch_gate(hipStream_t, const GateArgs&, ErrSlot*, FrameDev*, int, double*, const double*);
 void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, const FrameDev*);
 void launch_commit(hipStream_t, const KP&, Cell*, const AccF*, const FrameDev*, unsigned long long*);
-void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, const Cell*, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*, const unsigned int*, int, const float*);
-void launch_ray_apply(hipStream_t, const KP&, Cell*, AccR*, unsigned long long*);
+void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, const Cell*, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*, const unsigned int*, int, const float*, const unsigned int*, const unsigned int*);
+void launch_ray_apply(hipStream_t, const KP&, Cell*, AccR*, unsigned long long*, const OverlapArgs&);
 void launch_average(hipStream_t, const KP&, Cell*, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*);
 static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
@@ -54,16 +54,16 @@ void launch_materialize(hipStream_t, const KP&, Cell*);
 void launch_band_clear(hipStream_t, const KP&, float*, int, long, int, int);
 
 // tile-binned scatter (emap_binned.hip)
-struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, pad_; };
+struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, TB; };
 struct BinTmp { int tile; unsigned int lc; float z, v; };
 struct BinRec { unsigned int lc_inl; float z, v; unsigned int i; };
 void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, BinTmp*, unsigned int*);
-void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*);
+void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*, unsigned int*);
 void launch_bin_scatter(hipStream_t, const KP&, const BinGeo&, const BinTmp*, long, const unsigned int*, const unsigned int*, BinRec*);
 void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, const Cell*, ErrSlot*);
 void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const float*, long, int,
                           const unsigned int*, float*, float*, long);
-void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cell*, AccF*, const FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*);
+void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cell*, AccF*, const FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&);
 #define BIN_MAX_T 16384
 #define BIN_MAX_B 2048
 
@@ -132,6 +132,8 @@ struct emap_ctx {
   int scatter_mode;                // 0 auto, 1 atomic, 2 binned
   int force_sub;                   // test hook: minimum bin height factor (emap_set_scatter_mode bits 8..15)
   bool frame_binned;               // the count stage of the current frame used the binned path
+  unsigned int* bin_sync;          // ticket counters of k_bin_scan (last_block_ticket), zero between launches
+  OverlapArgs ov_args;             // clear_overlap_map folded into the frame's rewriting kernels (on = 0: separate k_overlap launch)
   bool gate_possible;              // false inside emap_update when the host already knows that the drift gate cannot fire: the per-tile
                                    // error statistics are then skipped (they could not have any effect; err_sum / err_cnt report 0)
   BinGeo bg; BinTmp* bin_tmp; BinRec* bin_recs; unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;
@@ -186,6 +188,7 @@ static void build_kp(emap_ctx* ctx) {
   k.q_step = h ? q16((float)p.ray_step) : (float)p.ray_step;
   k.time_var = (float)p.time_variance; k.time_int = (float)p.time_interval; k.res_f = (float)p.resolution;
   k.inv_res_f = (float)(1.0 / p.resolution); k.half_w_f = 0.5f * (float)p.cell_n; k.cm1_f = (float)(p.cell_n - 1);
+  k.hw_int_f = (float)(p.cell_n / 2); k.hw_frac_f = (p.cell_n & 1) ? 0.5f : 0.0f; k.pad1 = 0.f;
 }
 
 // smallest float >= c (a < c  <=>  a < up(c) for float a) / largest float <= c (a > c <=> a > dn(c))
@@ -245,12 +248,14 @@ static int build_ray_tables(emap_ctx* ctx) {
     auto at = [&](int sg, int mag) { return full[(sg << 15) | mag]; };
     {   // AxisIdx<0, 2>: is the float formula exact for every half pattern (NaNs excluded: non-finite samples never march)?
       bool same = true;
-      const float inv = ctx->kp.inv_res_f, hw = ctx->kp.half_w_f, cm1 = ctx->kp.cm1_f;
+      // index = floor(q / res [+ 0.5 for odd cell_n]) + cell_n / 2, clamped: the floor is taken BEFORE the half width is added (a tiny
+      // negative coordinate would otherwise round up to exactly cell_n / 2 in fp32, where the reference's double truncates below it)
+      const float inv = ctx->kp.inv_res_f, hwi = ctx->kp.hw_int_f, hwf = ctx->kp.hw_frac_f, cm1 = ctx->kp.cm1_f;
       for (int b = 0; b < 65536 && same; ++b) {
         if ((b & 0x7fff) > 0x7c00) continue;
         unsigned short us = (unsigned short)b; _Float16 hf; memcpy(&hf, &us, 2);
-        const float q = (float)hf, v = fmaf(q, inv, hw);
-        const int got = (int)fminf(fmaxf(v, 0.0f), cm1) - ((q < 0.0f && v == hw) ? 1 : 0);
+        const float q = (float)hf, f = floorf(fmaf(q, inv, hwf)) + hwi;
+        const int got = (int)fminf(fmaxf(f, 0.0f), cm1);
         if (got != full[b]) same = false;
       }
       rt.formula_ok = same ? 1 : 0;
@@ -365,7 +370,7 @@ int emap_destroy(emap_ctx* ctx) {
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   delete ctx->workers;
   hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert); hipFree(ctx->inl_plane); hipFree(ctx->ray_thr);
-  hipFree(ctx->bin_tmp); hipFree(ctx->bin_recs); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start);
+  hipFree(ctx->bin_tmp); hipFree(ctx->bin_recs); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start); hipFree(ctx->bin_sync);
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   emap_comm_destroy(ctx);
@@ -418,11 +423,12 @@ int emap_create(const emap_params* params, const emap_strip* strip, int device, 
   alloc((void**)&ctx->trav_in, sizeof(float) * n); alloc((void**)&ctx->normal, sizeof(float) * 3 * n);
   alloc((void**)&ctx->scratch, sizeof(float) * n); alloc((void**)&ctx->slots, sizeof(ErrSlot) * EM_ERR_SLOTS);
   alloc((void**)&ctx->frame, sizeof(FrameDev));
-  alloc((void**)&ctx->inert, sizeof(unsigned long long) * ((size_t)ctx->strip.row_count * ((C + 63) / 64) + 1));
+  alloc((void**)&ctx->inert, sizeof(unsigned long long) * ((size_t)ctx->strip.row_count * ((C + 63) / 64) + 2));      // + an all-ones word behind the last row (k_rays)
   if (rc == EMAP_OK) {
     hipEventCreate(&ctx->t0); hipEventCreate(&ctx->t1);
     for (int i = 0; i <= ST_N; ++i) hipEventCreate(&ctx->ev[i]);
     hipMemsetAsync(ctx->trav_in, 0, sizeof(float) * n, ctx->stream);
+    hipMemsetAsync(ctx->inert + (size_t)ctx->strip.row_count * ((C + 63) / 64), 0xff, 2 * sizeof(unsigned long long), ctx->stream);
     hipMemsetAsync(ctx->normal, 0, sizeof(float) * 3 * n, ctx->stream);
     rc = emap_clear(ctx);
     if (rc == EMAP_OK) rc = build_ray_tables(ctx);
@@ -553,15 +559,15 @@ static bool bins_possible(const emap_ctx* ctx) { return bin_sub(ctx) > 0; }
 static int ensure_bins(emap_ctx* ctx) {
   const long n = ctx->n_pts;
   BinGeo& g = ctx->bg;
-  g.sub = bin_sub(ctx); g.pad_ = 0;
-  g.tiles_x = (ctx->prm.cell_n + 63) / 64; g.tiles_y = (ctx->strip.row_count + 16 * g.sub - 1) / (16 * g.sub); g.T = g.tiles_x * g.tiles_y;
+  g.sub = bin_sub(ctx);
+  g.tiles_x = (ctx->prm.cell_n + 63) / 64; g.tiles_y = (ctx->strip.row_count + 16 * g.sub - 1) / (16 * g.sub); g.T = g.tiles_x * g.tiles_y; g.TB = g.T + 1;
   long target = n >= 1000000 ? 4096 : 2048;
   if (const char* e = getenv("EMAP_BIN_CHUNK")) { long v = atol(e); if (v >= 256 && v <= 65536) target = v; }   // tuning knob
   long B = (n + target - 1) / target; if (B < 1) B = 1; if (B > BIN_MAX_B) B = BIN_MAX_B;
   long chunk = (n + B - 1) / B; chunk = ((chunk + 1023) / 1024) * 1024;   /* a multiple of every hist / scatter block size */
   g.B = (int)((n + chunk - 1) / chunk); if (g.B < 1) g.B = 1;
   g.chunk = chunk;
-  const size_t hist_need = (size_t)g.T * (size_t)g.B;
+  const size_t hist_need = (size_t)g.TB * (size_t)g.B;
   if (hist_need > ctx->bin_hist_cap) {
     CK(hipStreamSynchronize(ctx->stream));
     if (ctx->bin_hist) CK(hipFree(ctx->bin_hist));
@@ -570,8 +576,10 @@ static int ensure_bins(emap_ctx* ctx) {
     ctx->bin_hist_cap = hist_need;
   }
   if (!ctx->bin_tile_total) {
-    CK(hipMalloc((void**)&ctx->bin_tile_total, sizeof(unsigned int) * (BIN_MAX_T + 1)));
-    CK(hipMalloc((void**)&ctx->bin_tile_start, sizeof(unsigned int) * (BIN_MAX_T + 1)));
+    CK(hipMalloc((void**)&ctx->bin_tile_total, sizeof(unsigned int) * (BIN_MAX_T + 2)));
+    CK(hipMalloc((void**)&ctx->bin_tile_start, sizeof(unsigned int) * (BIN_MAX_T + 2)));
+    CK(hipMalloc((void**)&ctx->bin_sync, sizeof(unsigned int) * EM_TICKET_WORDS));
+    CK(hipMemsetAsync(ctx->bin_sync, 0, sizeof(unsigned int) * EM_TICKET_WORDS, ctx->stream));
   }
   if (n > ctx->bin_cap) {
     CK(hipStreamSynchronize(ctx->stream));
@@ -595,6 +603,16 @@ int emap_set_scatter_mode(emap_ctx* ctx, int32_t mode) {
   return EMAP_OK;
 }
 
+static GateArgs gate_args(emap_ctx* ctx, double position_noise, double orientation_noise) {
+  const emap_params& p = ctx->prm;
+  GateArgs g; memset(&g, 0, sizeof g);
+  g.enable = p.enable_drift_compensation; g.min_cnt = p.min_height_drift_cnt; g.max_drift = p.max_drift; g.alpha = (float)p.drift_compensation_alpha;
+  g.noise_ok = (position_noise > p.position_noise_thresh) || (orientation_noise > p.orientation_noise_thresh);
+  g.use_override = ctx->use_override ? 1 : 0; g.sum_override = ctx->sum_override; g.cnt_override = ctx->cnt_override;
+  g.n_points = (unsigned int)ctx->n_pts;
+  return g;
+}
+
 int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
   CKARG(ctx && R && t, "null argument"); NEED_POINTS();
   if (!ctx->in_update) ctx->gate_possible = true;          // the staged API always gathers the statistics
@@ -608,7 +626,7 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
     if (tm) CK(hipEventRecord(ctx->ev[ST_HIST], ctx->stream));
     launch_bin_hist(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_tmp, ctx->bin_hist);
     if (tm) CK(hipEventRecord(ctx->ev[ST_SCAN], ctx->stream));
-    launch_bin_scan(ctx->stream, ctx->bg, ctx->bin_hist, ctx->bin_tile_total, ctx->bin_tile_start);
+    launch_bin_scan(ctx->stream, ctx->bg, ctx->bin_hist, ctx->bin_tile_total, ctx->bin_tile_start, ctx->bin_sync);
     if (tm) CK(hipEventRecord(ctx->ev[ST_SCATTER], ctx->stream));
     launch_bin_scatter(ctx->stream, ctx->kp, ctx->bg, ctx->bin_tmp, ctx->n_pts, ctx->bin_hist, ctx->bin_tile_start, ctx->bin_recs);
     if (tm) CK(hipEventRecord(ctx->ev[ST_GATE], ctx->stream));        // the "gate" stage = per-tile error sums + k_gate
@@ -626,11 +644,7 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
 static int gate_impl(emap_ctx* ctx, double position_noise, double orientation_noise, int reduce_only, double* dev_out,
                      const double* dev_totals) {
   CK(hipSetDevice(ctx->device));
-  const emap_params& p = ctx->prm;
-  int noise_ok = (position_noise > p.position_noise_thresh) || (orientation_noise > p.orientation_noise_thresh);
-  launch_gate(ctx->stream, ctx->kp, ctx->slots, ctx->frame, p.enable_drift_compensation, p.min_height_drift_cnt, p.max_drift,
-              (float)p.drift_compensation_alpha, noise_ok, ctx->use_override ? 1 : 0, ctx->sum_override, ctx->cnt_override,
-              (unsigned int)ctx->n_pts, reduce_only, dev_out, dev_totals);
+  launch_gate(ctx->stream, gate_args(ctx, position_noise, orientation_noise), ctx->slots, ctx->frame, reduce_only, dev_out, dev_totals);
   CK(hipGetLastError());
   ctx->committed = false;
   return EMAP_OK;
@@ -679,10 +693,10 @@ static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool fus
       CK(hipMalloc((void**)&ctx->ray_thr, sizeof(float) * (size_t)((ctx->strip.row_count + 7) / 8 + 2) * ((ctx->prm.cell_n + 7) / 8)));
     }
     if (fuse_average && rays && ((ctx->kp.org_c | ctx->prm.cell_n) & 63) != 0 && !ctx->inert_zero)     // unaligned columns: the tile kernel ORs its ballots into the logical bitmap
-      CK(hipMemsetAsync(ctx->inert, 0, sizeof(unsigned long long) * ((size_t)ctx->strip.row_count * ((ctx->prm.cell_n + 63) / 64) + 1), ctx->stream));
+      CK(hipMemsetAsync(ctx->inert, 0, sizeof(unsigned long long) * ((size_t)ctx->strip.row_count * ((ctx->prm.cell_n + 63) / 64)), ctx->stream));
     if (fuse_average && rays) ctx->inert_zero = false;
     launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame, fuse_average, rays,
-                    ctx->cnt_plane, ctx->inert, ctx->inl_plane, ctx->ray_thr);
+                    ctx->cnt_plane, ctx->inert, ctx->inl_plane, ctx->ray_thr, ctx->ov_args);
     if (fuse_average) ctx->kp.mv.n = 0;   // every owned cell rewritten: pending map shifts are in memory now
     CK(hipGetLastError());
     return EMAP_OK;
@@ -725,7 +739,9 @@ int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
   const unsigned int* inl = ctx->rays_fused ? ctx->inl_plane : reinterpret_cast<const unsigned int*>(ctx->acc) + 1;
   launch_rays(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->rt, ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->accr,
               ctx->normal, ctx->ncells_alloc, ctx->frame, ctx->want_ray_stats, ctx->inert, inl, ctx->rays_fused ? 1 : (int)(sizeof(AccF) / 4),
-              ctx->rays_fused ? ctx->ray_thr : nullptr);
+              ctx->rays_fused ? ctx->ray_thr : nullptr,
+              ctx->frame_binned ? reinterpret_cast<const unsigned int*>(ctx->bin_recs) : nullptr,        // march in tile-sorted order
+              ctx->frame_binned ? ctx->bin_tile_start + ctx->bg.TB : nullptr);
   CK(hipGetLastError());
   return EMAP_OK;
 }
@@ -739,16 +755,23 @@ int emap_average(emap_ctx* ctx) {
   return EMAP_OK;
 }
 
+static OverlapArgs overlap_args(const emap_ctx* ctx, float t_z, bool on) {
+  const emap_params& p = ctx->prm;
+  int cell_range = (int)(p.overlap_clear_range_xy / p.resolution);     // elevation_mapping.py:88-91
+  if (cell_range < 0) cell_range = 0; if (cell_range > p.cell_n) cell_range = p.cell_n;
+  OverlapArgs o; memset(&o, 0, sizeof o);
+  o.on = on ? 1 : 0;
+  o.cmin = p.cell_n / 2 - cell_range / 2; o.cmax = p.cell_n / 2 + cell_range / 2;
+  o.hmin = t_z - (float)p.overlap_clear_range_z; o.hmax = t_z + (float)p.overlap_clear_range_z;
+  return o;
+}
+
 int emap_overlap_clear(emap_ctx* ctx, float t_z) {
   CKARG(ctx, "null ctx");
   CK(hipSetDevice(ctx->device));
   FLUSH();
-  const emap_params& p = ctx->prm;
-  int cell_range = (int)(p.overlap_clear_range_xy / p.resolution);     // elevation_mapping.py:88-91
-  if (cell_range < 0) cell_range = 0; if (cell_range > p.cell_n) cell_range = p.cell_n;
-  int cmin = p.cell_n / 2 - cell_range / 2, cmax = p.cell_n / 2 + cell_range / 2;
-  float hmin = t_z - (float)p.overlap_clear_range_z, hmax = t_z + (float)p.overlap_clear_range_z;
-  launch_overlap(ctx->stream, ctx->kp, ctx->cells, cmin, cmax, hmin, hmax);
+  const OverlapArgs o = overlap_args(ctx, t_z, true);
+  launch_overlap(ctx->stream, ctx->kp, ctx->cells, o.cmin, o.cmax, o.hmin, o.hmax);
   CK(hipGetLastError());
   return EMAP_OK;
 }
@@ -836,7 +859,12 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   // bitmap and the inlier plane, and the ray effects are applied by k_ray_apply ("average" stage) afterwards
   const bool fused_avg = ctx->frame_binned;
   const bool rays_on = p.enable_visibility_cleanup != 0;
-  if ((rc = fuse_impl(ctx, R, t, fused_avg, rays_on))) return rc;
+  // clear_overlap_map rides on the kernel that rewrites the cells last (tile kernel, or k_ray_apply after a visibility pass)
+  ctx->ov_args = overlap_args(ctx, t[2], p.enable_overlap_clearance && fused_avg);
+  const bool ov_folded = ctx->ov_args.on != 0;
+  rc = fuse_impl(ctx, R, t, fused_avg, rays_on);
+  const OverlapArgs ov = ctx->ov_args; ctx->ov_args.on = 0;
+  if (rc) return rc;
   STAGE(ST_COMMIT);
   ctx->rays_fused = fused_avg && rays_on;
   if (rays_on) {
@@ -847,11 +875,11 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
   if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane); ctx->kp.mv.n = 0; }
-  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert); ctx->inert_zero = true; }
+  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   STAGE(ST_OVERLAP);
-  if (p.enable_overlap_clearance && (rc = emap_overlap_clear(ctx, t[2]))) return rc;
+  if (p.enable_overlap_clearance && !ov_folded && (rc = emap_overlap_clear(ctx, t[2]))) return rc;
   STAGE(ST_POST);
   if ((rc = emap_post(ctx))) return rc;
   STAGE(ST_N);
@@ -1469,7 +1497,12 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   STAGE(ST_FUSE);
   const bool fused_avg = ctx->frame_binned;
   const bool rays_on = p.enable_visibility_cleanup != 0;
-  if ((rc = fuse_impl(ctx, R, t, fused_avg, rays_on))) return rc;
+  // clear_overlap_map rides on the kernel that rewrites the cells last (tile kernel, or k_ray_apply after a visibility pass)
+  ctx->ov_args = overlap_args(ctx, t[2], p.enable_overlap_clearance && fused_avg);
+  const bool ov_folded = ctx->ov_args.on != 0;
+  rc = fuse_impl(ctx, R, t, fused_avg, rays_on);
+  const OverlapArgs ov = ctx->ov_args; ctx->ov_args.on = 0;
+  if (rc) return rc;
   STAGE(ST_COMMIT);
   ctx->rays_fused = fused_avg && rays_on;
   if (rays_on) {
@@ -1481,11 +1514,11 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
   if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane); ctx->kp.mv.n = 0; }
-  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert); ctx->inert_zero = true; }
+  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   STAGE(ST_OVERLAP);
-  if (p.enable_overlap_clearance && (rc = emap_overlap_clear(ctx, t[2]))) return rc;
+  if (p.enable_overlap_clearance && !ov_folded && (rc = emap_overlap_clear(ctx, t[2]))) return rc;
   STAGE(ST_POST);                             // "post" = halo exchange + stencils
   if (ctx->comm_world > 1) {
     if ((rc = halo_exchange_start(ctx))) return rc;                                                 // exchange step 2 ...

@@ -7,7 +7,7 @@
 // workgroup in LDS:
 //   k_bin_hist     per chunk of points: geometry once (fp16-quirk transform, validity, cell), per-block LDS histogram
 //                  over tiles, 16-byte staging record per point (tile, cell-in-tile, z, noise)
-//   k_bin_scan1/2  exclusive scan of the (tile, block) histogram -> every block's write cursor, tile start offsets
+//   k_bin_scan     exclusive scan of the (tile, block) histogram -> every block's write cursor, tile start offsets
 //   k_bin_scatter  per chunk: LDS cursor -> 16-byte record at its sorted position (a pure permutation, no map access)
 //   k_tile_count   per tile: cells staged in LDS, drift-inlier test of every record (error_counting_kernel,
 //                  custom_kernels.py:317-335), wave-reduced error sums
@@ -27,7 +27,8 @@
 #define BIN_TC 64
 #define BIN_MAX_T 16384   /* LDS histogram / cursor arrays are dynamic: 4 B per tile */
 
-struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, pad_; };   // a bin = `sub` stacked 16x64 tiles (sub > 1 only for maps beyond 16384 tiles)
+struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, TB; };   // a bin = `sub` stacked 16x64 tiles (sub > 1 only for maps beyond 16384 tiles); TB = T + 1 sort bins:
+// the last one collects the valid points that fall OUTSIDE the owned cells -- they are not fused, but their rays are marched (k_rays walks the sorted records)
 struct __attribute__((aligned(16))) BinTmp { int tile; unsigned int lc; float z, v; };        // staging, point order
 struct __attribute__((aligned(16))) BinRec { unsigned int lc_inl; float z, v; unsigned int i; };  // sorted by tile
 
@@ -51,7 +52,7 @@ template <int MODE, int BLK>
 __global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
                                                         BinTmp* __restrict__ tmp, unsigned int* __restrict__ hist) {
   extern __shared__ unsigned int h[];
-  for (int t = threadIdx.x; t < G.T; t += BLK) h[t] = 0u;
+  for (int t = threadIdx.x; t < G.TB; t += BLK) h[t] = 0u;
   __syncthreads();
   const long base = (long)blockIdx.x * G.chunk;
   for (long k = threadIdx.x; k < G.chunk; k += BLK) {
@@ -67,16 +68,20 @@ __global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const 
       r.tile = (lrow / BR) * G.tiles_x + (pcol / BIN_TC);
       r.lc = (unsigned int)((lrow % BR) * BIN_TC + (pcol % BIN_TC));
       atomicAdd(&h[r.tile], 1u);
-    }
+    } else if (g.finite && g.valid) { r.tile = G.T; atomicAdd(&h[G.T], 1u); }      // ray only (custom_kernels.py:199-258 marches every valid point)
     tmp[i] = r;
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < G.T; t += BLK) hist[(long)t * G.B + blockIdx.x] = h[t];
+  for (int t = threadIdx.x; t < G.TB; t += BLK) hist[(long)t * G.B + blockIdx.x] = h[t];
 }
 
-// block t: exclusive scan of hist[t][0..B) in place, tile_total[t] = sum
-__global__ __launch_bounds__(EM_BLOCK) void k_bin_scan1(BinGeo G, unsigned int* __restrict__ hist, unsigned int* __restrict__ tile_total) {
+// block t: exclusive scan of hist[t][0..B) in place, tile_total[t] = sum; the LAST block to finish (ticket counter `sync`, re-armed
+// for the next frame) then scans the tile totals: tile_start[0..T] -- one launch instead of two (a launch costs ~4.5 us here, the
+// second scan was a single block).
+__global__ __launch_bounds__(EM_BLOCK) void k_bin_scan(BinGeo G, unsigned int* __restrict__ hist, unsigned int* __restrict__ tile_total,
+                                                        unsigned int* __restrict__ tile_start, unsigned int* __restrict__ sync) {
   __shared__ unsigned int sh[EM_BLOCK / 64];
+  __shared__ bool s_last;
   unsigned int* row = hist + (long)blockIdx.x * G.B;
   unsigned int running = 0;
   for (int b0 = 0; b0 < G.B; b0 += EM_BLOCK) {
@@ -86,20 +91,25 @@ __global__ __launch_bounds__(EM_BLOCK) void k_bin_scan1(BinGeo G, unsigned int* 
     if (b < G.B) row[b] = running + ex;
     running += tot;
   }
-  if (threadIdx.x == 0) tile_total[blockIdx.x] = running;
-}
-// one block: tile_start[0..T] = exclusive scan of tile_total
-__global__ __launch_bounds__(EM_BLOCK) void k_bin_scan2(BinGeo G, const unsigned int* __restrict__ tile_total, unsigned int* __restrict__ tile_start) {
-  __shared__ unsigned int sh[EM_BLOCK / 64];
-  unsigned int running = 0;
-  for (int t0 = 0; t0 < G.T; t0 += EM_BLOCK) {
+  if (threadIdx.x == 0) {
+    // the total goes out as a device-coherent store and is read back with device-coherent loads; only its ORDER against the
+    // ticket matters (wait for the store's acknowledgement).  An agent-scope fence would write back / invalidate the XCD's whole L2
+    // per workgroup (measured: 10 -> 30 us for this kernel).
+    __hip_atomic_store(&tile_total[blockIdx.x], running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);
+    s_last = last_block_ticket(sync, blockIdx.x, gridDim.x);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  running = 0;
+  for (int t0 = 0; t0 < G.TB; t0 += EM_BLOCK) {
     const int t = t0 + threadIdx.x;
-    unsigned int x = t < G.T ? tile_total[t] : 0u, tot;
+    unsigned int x = t < G.TB ? __hip_atomic_load(&tile_total[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u, tot;
     unsigned int ex = block_excl_scan(x, sh, tot);
-    if (t < G.T) tile_start[t] = running + ex;
+    if (t < G.TB) tile_start[t] = running + ex;
     running += tot;
   }
-  if (threadIdx.x == 0) tile_start[G.T] = running;
+  if (threadIdx.x == 0) tile_start[G.TB] = running;          // = number of sorted records (all valid points)
 }
 
 template <int BLK>
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, BinGeo G, const BinTm
                                                            const unsigned int* __restrict__ hist, const unsigned int* __restrict__ tile_start,
                                                            BinRec* __restrict__ recs) {
   extern __shared__ unsigned int cur[];
-  for (int t = threadIdx.x; t < G.T; t += BLK) cur[t] = tile_start[t] + hist[(long)t * G.B + blockIdx.x];
+  for (int t = threadIdx.x; t < G.TB; t += BLK) cur[t] = tile_start[t] + hist[(long)t * G.B + blockIdx.x];
   __syncthreads();
   const long base = (long)blockIdx.x * G.chunk;
   for (long k = threadIdx.x; k < G.chunk; k += BLK) {      // a pure permutation: staging record in, sorted record out, no map access
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
                                                          const unsigned int* __restrict__ tile_start, Cell* __restrict__ cells,
                                                          AccF* __restrict__ acc, const FrameDev* __restrict__ F,
                                                          unsigned int* __restrict__ cnt_plane, unsigned long long* __restrict__ inert,
-                                                         unsigned int* __restrict__ inl_plane, float* __restrict__ thr) {
+                                                         unsigned int* __restrict__ inl_plane, float* __restrict__ thr, OverlapArgs O) {
   constexpr int NC = BIN_TR * BIN_TC;
   __shared__ unsigned int s_pts[NC], s_inl[NC], s_cnt[NC], s_out[NC];
   __shared__ unsigned long long s_h[NC], s_v[NC], s_latest[NC];
@@ -255,6 +265,8 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
           if (RAYS && !quiet) visit_thr = m.valid < 0.5f ? ((m.is_upper < 0.5f || !(m.upper <= 3.0e38f)) ? INFINITY : m.upper) : m.h + 0.05f;
           if (RAYS && !(visit_thr >= -INFINITY)) visit_thr = INFINITY;                          // NaN heights: never filter
           average_cell(P, m, a);
+          // clear_overlap_map (:372-375) of a frame WITHOUT a visibility pass rides on this rewrite (with rays: k_ray_apply)
+          if (!RAYS && overlap_window(O, logi_row(P, P.row0 + lrow), logi_col(P, col))) overlap_cell(P, O, m);
           cells[c] = m;
           if (cnt_plane) cnt_plane[c] = s_cnt[lc];
           if (RAYS) inl_plane[c] = s_inl[lc];
@@ -310,8 +322,14 @@ static int env_block(const char* name, int dflt) {
 template <int BLK>
 static void launch_bin_hist_t(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride, BinTmp* tmp,
                               unsigned int* hist) {
-  if (P.mode == 0) hipLaunchKernelGGL((k_bin_hist<0, BLK>), dim3(G.B), dim3(BLK), sizeof(unsigned int) * G.T, s, P, T, G, pts, n, stride, tmp, hist);
-  else hipLaunchKernelGGL((k_bin_hist<1, BLK>), dim3(G.B), dim3(BLK), sizeof(unsigned int) * G.T, s, P, T, G, pts, n, stride, tmp, hist);
+  static bool raised = false;          // 16384 tiles + the ray-only bin: 4 bytes past the default 64 KB window
+  if (!raised) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_hist<0, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_hist<1, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    raised = true;
+  }
+  if (P.mode == 0) hipLaunchKernelGGL((k_bin_hist<0, BLK>), dim3(G.B), dim3(BLK), sizeof(unsigned int) * G.TB, s, P, T, G, pts, n, stride, tmp, hist);
+  else hipLaunchKernelGGL((k_bin_hist<1, BLK>), dim3(G.B), dim3(BLK), sizeof(unsigned int) * G.TB, s, P, T, G, pts, n, stride, tmp, hist);
 }
 void launch_bin_hist(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride, BinTmp* tmp,
                      unsigned int* hist) {
@@ -322,14 +340,20 @@ void launch_bin_hist(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G,
     default: launch_bin_hist_t<256>(s, P, T, G, pts, n, stride, tmp, hist);
   }
 }
-void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigned int* tile_total, unsigned int* tile_start) {
-  hipLaunchKernelGGL(k_bin_scan1, dim3(G.T), dim3(EM_BLOCK), 0, s, G, hist, tile_total);
-  hipLaunchKernelGGL(k_bin_scan2, dim3(1), dim3(EM_BLOCK), 0, s, G, tile_total, tile_start);
+void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigned int* tile_total, unsigned int* tile_start, unsigned int* sync) {
+  hipLaunchKernelGGL(k_bin_scan, dim3(G.TB), dim3(EM_BLOCK), 0, s, G, hist, tile_total, tile_start, sync);
 }
 void launch_bin_scatter(hipStream_t s, const KP& P, const BinGeo& G, const BinTmp* tmp, long n, const unsigned int* hist,
                         const unsigned int* tile_start, BinRec* recs) {
   static const int blk = env_block("EMAP_SCATTER_BLOCK", 512);
-  const size_t sh = sizeof(unsigned int) * G.T;
+  const size_t sh = sizeof(unsigned int) * G.TB;
+  static bool raised = false;
+  if (!raised) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    raised = true;
+  }
   switch (blk) {
     case 1024: hipLaunchKernelGGL(k_bin_scatter<1024>, dim3(G.B), dim3(1024), sh, s, P, G, tmp, n, hist, tile_start, recs); break;
     case 512: hipLaunchKernelGGL(k_bin_scatter<512>, dim3(G.B), dim3(512), sh, s, P, G, tmp, n, hist, tile_start, recs); break;
@@ -344,11 +368,11 @@ void launch_tile_count(hipStream_t s, const KP& P, const BinGeo& G, const BinRec
 // fuse_average: commit + average in the tile kernel (whole frames); rays: the visibility pass follows (bitmap + inlier plane wanted)
 void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cell* cells,
                      AccF* acc, const FrameDev* F, bool fuse_average, bool rays, unsigned int* cnt_plane, unsigned long long* inert,
-                     unsigned int* inl_plane, float* thr) {
+                     unsigned int* inl_plane, float* thr, const OverlapArgs& O) {
   const dim3 g(G.T, G.sub), b(TF_BLOCK);
-  if (fuse_average && rays) hipLaunchKernelGGL((k_tile_fuse<true, true>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr);
-  else if (fuse_average) hipLaunchKernelGGL((k_tile_fuse<true, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr);
-  else hipLaunchKernelGGL((k_tile_fuse<false, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr);
+  if (fuse_average && rays) hipLaunchKernelGGL((k_tile_fuse<true, true>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O);
+  else if (fuse_average) hipLaunchKernelGGL((k_tile_fuse<true, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O);
+  else hipLaunchKernelGGL((k_tile_fuse<false, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O);
 }
 
 // ---------------------------------------------------------------------------------------------------------

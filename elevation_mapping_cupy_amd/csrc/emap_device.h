@@ -68,7 +68,7 @@ struct KP {
   Moves mv;
   double res, half_w, snf, mt, ov, dcvi_half, trav_inlier, wall, mrl, cs, cos_thresh, mvd2, mhr, ra, rb, rc;
   double max_var, ray_step;
-  float init_var, ov_f, q_wm1, q_mrl, q_step, time_var, time_int, res_f, inv_res_f, half_w_f, cm1_f, pad1;
+  float init_var, ov_f, q_wm1, q_mrl, q_step, time_var, time_int, res_f, inv_res_f, half_w_f, cm1_f, hw_int_f, hw_frac_f, pad1;   // hw_int_f + hw_frac_f = cell_n / 2
 };
 
 // host-built tables of the visibility pass (emap_api.hip: build_ray_tables)
@@ -238,6 +238,72 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// ---- "last workgroup" ticket --------------------------------------------------------------------------------------------
+// One thread per workgroup calls this after its results are acknowledged; true for exactly one caller, the last.  Device-scope
+// atomics on ONE address serialise at ~10 ns each on MI355X (1024 workgroups on a single counter: +10 us, measured), so the
+// tickets form a two-level tree: sqrt(n) groups, each counter on its own 128-byte line.  Counters re-arm themselves.
+#define EM_TICKET_WORDS (1025 * 32)
+__device__ __forceinline__ bool last_block_ticket(unsigned int* __restrict__ sync, unsigned int bid, unsigned int nblocks) {
+  unsigned int gs = 1; while (gs * gs < nblocks) gs <<= 1;
+  const unsigned int g = bid / gs, ng = (nblocks + gs - 1) / gs, members = min(gs, nblocks - g * gs);
+  unsigned int* c1 = sync + 32 * (1 + g);
+  if (__hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != members - 1) return false;
+  __hip_atomic_store(c1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ng - 1) return false;
+  __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+// ---- drift gate (elevation_mapping.py:346-352) --------------------------------------------------------------------------
+// One wave: sums the error slots (integer => order independent), decides the shift, keeps additive_mean_error, re-arms the slots.
+// (Folding it into the last workgroup of k_tile_count was measured: no gain -- a small dependent launch costs ~1 us in the frame.)
+struct GateArgs {
+  int enable, noise_ok, use_override, pad0_;
+  double min_cnt, max_drift, sum_override;
+  float alpha; unsigned int cnt_override, n_points, pad_;
+};
+__device__ __forceinline__ void gate_eval(const GateArgs& A, ErrSlot* __restrict__ slots, FrameDev* __restrict__ F, int lane, int reduce_only,
+                                          double* __restrict__ dev_out, const double* __restrict__ dev_totals) {
+  long long s = 0; unsigned long long k = 0;
+  for (int j = lane; j < EM_ERR_SLOTS; j += 64) {
+    s += __hip_atomic_load(&slots[j].sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    k += __hip_atomic_load(&slots[j].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    slots[j].sum = 0; slots[j].cnt = 0;
+  }
+  s = wave_sum_ll(s); k = (unsigned long long)wave_sum_ll((long long)k);
+  if (lane != 0) return;
+  if (reduce_only) {
+    F->err_sum_fix = s; F->err_cnt = k; F->n_points = A.n_points; F->ray_visits = 0;
+    if (dev_out) { dev_out[0] = (double)s / EM_SCALE_E; dev_out[1] = (double)k; }
+    return;
+  }
+  if (!A.use_override && !dev_totals) { F->err_sum_fix = s; F->err_cnt = k; }
+  F->n_points = A.n_points; F->ray_visits = 0;
+  double sum = dev_totals ? dev_totals[0] : (A.use_override ? A.sum_override : (double)s / EM_SCALE_E);
+  float cnt = dev_totals ? (float)dev_totals[1] : (A.use_override ? (float)A.cnt_override : (float)k);
+  float shift = 0.0f; int fired = 0;
+  if (A.enable && (double)cnt > A.min_cnt && A.noise_ok) {
+    float mean = (float)sum / cnt;
+    fired = 1;
+    F->mean_error = mean;
+    F->additive_mean_error = F->additive_mean_error + mean;
+    if ((double)fabsf(mean) < A.max_drift) shift = mean * A.alpha;
+  }
+  F->shift = shift; F->gate_fired = fired;
+}
+
+// ---- clear_overlap_map (elevation_mapping.py:393-410) as an epilogue of the kernels that rewrite the cells anyway ----------
+struct OverlapArgs { int on, cmin, cmax, pad_; float hmin, hmax; };
+__device__ __forceinline__ bool overlap_window(const OverlapArgs& O, int lr, int lc) {      // logical row / column
+  return O.on && lr >= O.cmin && lr < O.cmax && lc >= O.cmin && lc < O.cmax;
+}
+__device__ __forceinline__ bool overlap_cell(const KP& P, const OverlapArgs& O, Cell& m) {
+  bool ch = false;
+  if (m.h < O.hmin || m.h > O.hmax) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; ch = true; }
+  if (m.upper < O.hmin || m.upper > O.hmax) { m.upper = 0.f; m.is_upper = 0.f; ch = true; }
+  return ch;
 }
 
 // Per-frame description of the RGB / semantic point fusion.  The leading members mirror emap_sem_spec (include/emap_hip.h);

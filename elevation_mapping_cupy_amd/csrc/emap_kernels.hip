@@ -49,34 +49,9 @@ __global__ __launch_bounds__(EM_BLOCK) void k_count(KP P, Pose T, const float* _
 // (integer => order independent), decides the shift, keeps additive_mean_error, re-arms the slots.
 // Row-strip contexts: `reduce_only` publishes the local sums (2 doubles, device memory) for the all-reduce and stops;
 // `dev_totals` (2 doubles, device memory, e.g. the all-reduced tensor) replaces the local sums in the gate.
-__global__ __launch_bounds__(64) void k_gate(KP P, ErrSlot* __restrict__ slots, FrameDev* __restrict__ F, int enable,
-                                             double min_cnt, double max_drift, float alpha, int noise_ok,
-                                             int use_override, double sum_override, unsigned int cnt_override,
-                                             unsigned int n_points, int reduce_only, double* __restrict__ dev_out,
-                                             const double* __restrict__ dev_totals) {
-  long long s = 0; unsigned long long k = 0;
-  for (int j = threadIdx.x; j < EM_ERR_SLOTS; j += 64) { s += slots[j].sum; k += slots[j].cnt; slots[j].sum = 0; slots[j].cnt = 0; }
-  s = wave_sum_ll(s); k = (unsigned long long)wave_sum_ll((long long)k);
-  if (threadIdx.x == 0) {
-    if (reduce_only) {
-      F->err_sum_fix = s; F->err_cnt = k; F->n_points = n_points; F->ray_visits = 0;
-      if (dev_out) { dev_out[0] = (double)s / EM_SCALE_E; dev_out[1] = (double)k; }
-      return;
-    }
-    if (!use_override && !dev_totals) { F->err_sum_fix = s; F->err_cnt = k; }
-    F->n_points = n_points; F->ray_visits = 0;
-    double sum = dev_totals ? dev_totals[0] : (use_override ? sum_override : (double)s / EM_SCALE_E);
-    float cnt = dev_totals ? (float)dev_totals[1] : (use_override ? (float)cnt_override : (float)k);
-    float shift = 0.0f; int fired = 0;
-    if (enable && (double)cnt > min_cnt && noise_ok) {
-      float mean = (float)sum / cnt;
-      fired = 1;
-      F->mean_error = mean;
-      F->additive_mean_error = F->additive_mean_error + mean;
-      if ((double)fabsf(mean) < max_drift) shift = mean * alpha;
-    }
-    F->shift = shift; F->gate_fired = fired;
-  }
+__global__ __launch_bounds__(64) void k_gate(GateArgs A, ErrSlot* __restrict__ slots, FrameDev* __restrict__ F, int reduce_only,
+                                             double* __restrict__ dev_out, const double* __restrict__ dev_totals) {
+  gate_eval(A, slots, F, threadIdx.x, reduce_only, dev_out, dev_totals);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -173,10 +148,11 @@ __device__ __forceinline__ void ray_upper_min(unsigned int* key_ptr, float nz) {
 // Cell index of a sample coordinate along one axis.  IDX selects how:
 //   0  the defining arithmetic (axis_idx: the reference's fp64 expression in reference_fp16 mode)
 //   1  reference_fp16 only: host-built table over the half bit pattern, staged in LDS (exact by construction)
-//   2  reference_fp16 only: one float fma + clamp + truncation (+ one patch) on the half-rounded coordinate -- the host proves it equal to the
+//   2  reference_fp16 only: one float fma + floor + add + clamp + truncation on the half-rounded coordinate -- the host proves it equal to the
 //      defining arithmetic for EVERY half bit pattern before selecting it (emap_api.hip: build_ray_tables), 5 VALU, no LDS
 template <int MODE, int IDX> struct AxisIdx {
   const unsigned short* t; unsigned int lo_m1, hi, span;   // IDX 1: per sign [small, idx(lo..hi-1), big]
+  float frac_v;                                            // IDX 2: hw_frac_f in a VECTOR register (the fma already has a scalar operand)
   __device__ __forceinline__ int operator()(const KP& P, float x) const {
     if constexpr (IDX == 1) {   // branch-free: clamp the magnitude into the tabulated range (sentinels hold the constant tails)
       const unsigned int b = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)x);
@@ -184,15 +160,21 @@ template <int MODE, int IDX> struct AxisIdx {
       const unsigned int m = min(max(mag, lo_m1), hi) - lo_m1;
       return (int)t[(sg ? span : 0u) + m];
     } else if constexpr (IDX == 2) {
+      // floor BEFORE the half width is added: a tiny negative coordinate would otherwise round up to exactly C/2 in fp32 where the
+      // reference's double stays just below it and truncates to C/2 - 1 (the integer add afterwards is exact)
       const float q = (float)(_Float16)x;
-      const float v = __builtin_fmaf(q, P.inv_res_f, P.half_w_f);
-      // the one place where the single fp32 rounding differs from the reference's double: a tiny negative coordinate, whose sum
-      // rounds UP to exactly C/2 (the double stays just below it and truncates to C/2 - 1)
-      return (int)__builtin_amdgcn_fmed3f(v, 0.0f, P.cm1_f) - (((q < 0.0f) & (v == P.half_w_f)) ? 1 : 0);
+      const float f = __builtin_floorf(__builtin_fmaf(q, P.inv_res_f, frac_v)) + P.hw_int_f;
+      return (int)__builtin_amdgcn_fmed3f(f, 0.0f, P.cm1_f);
     } else return axis_idx<MODE>(P, Qf<MODE>(x));
   }
 };
 
+// a * b + c on the low 24 bits of a and b (v_mad_u32_u24; the compiler's own pattern masks the operands first)
+__device__ __forceinline__ unsigned int mad24(unsigned int a, unsigned int b, unsigned int c) {
+  unsigned int r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
@@ -211,13 +193,17 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // range predicate, one bitmap bit; everything else happens only for the few cells that are neither known-and-fresh nor out.
 // (launch bounds: 8 waves per SIMD, i.e. two 1024-thread workgroups per CU -- measured: with 82 instead of 70 SGPRs the kernel
 // silently dropped to one workgroup per CU and ran 13 % slower)
-template <int MODE, bool STATS, int IDX, bool STRIP, int BLOCK>
-__global__ __launch_bounds__(BLOCK, 8) void k_rays(KP P, Pose T, RayTab Rt, const float* __restrict__ pts, long n, int stride,
+template <int MODE, bool STATS, int IDX, bool STRIP, int BLOCK, bool LMAP>
+#ifndef RAY_OCC
+#define RAY_OCC 8
+#endif
+__global__ __launch_bounds__(BLOCK, RAY_OCC) void k_rays(KP P, Pose T, RayTab Rt, const float* __restrict__ pts, long n, int stride,
                                                  const Cell* __restrict__ cells,
                                                  AccR* __restrict__ accr, const float* __restrict__ normal,
                                                  long plane_stride, FrameDev* __restrict__ F,
                                                  const unsigned long long* __restrict__ inert64,
-                                                 const unsigned int* __restrict__ inl, int inl_stride, const float* __restrict__ thr) {
+                                                 const unsigned int* __restrict__ inl, int inl_stride, const float* __restrict__ thr,
+                                                 const unsigned int* __restrict__ order, const unsigned int* __restrict__ n_sorted) {
   const unsigned int* __restrict__ inert = reinterpret_cast<const unsigned int*>(inert64);   // 32-bit words: cheaper shifts
   const unsigned int wpr32 = (unsigned int)((P.C + 63) / 64) * 2u;                           // 32-bit words per bitmap row
   // LDS words: [table (span)] [s_k (nS)] [queues (BLOCK/64 * 384)]
@@ -231,13 +217,31 @@ __global__ __launch_bounds__(BLOCK, 8) void k_rays(KP P, Pose T, RayTab Rt, cons
   }
   for (int k = threadIdx.x; k < nS; k += BLOCK) sS[k] = Rt.S[k];
   unsigned int* qbase = reinterpret_cast<unsigned int*>(sS + nS);                 // per-wave visit queues: 3 x 128 words each
+  // LMAP: the whole bitmap (+ the all-ones word behind it) is staged in LDS when it fits next to the queues (128 KB for a 1024^2
+  // map: one workgroup per CU, which costs nothing -- 4 and 8 waves per SIMD run this kernel equally fast).  A scattered 64-lane
+  // dword load keeps the CU's single texture addresser busy for ~45 clocks; the LDS serves it in a handful (measured: frame 0.495
+  // -> 0.449 ms at 1024^2 / 1 M rays).
+  unsigned int* smap = qbase + (BLOCK / 64) * 384;
+  if (LMAP) {
+    const unsigned int nw = (unsigned int)P.nrows * wpr32 + 2u;
+    for (unsigned int k = threadIdx.x; k < nw; k += BLOCK) smap[k] = inert[k];
+  }
   __syncthreads();
-  AxisIdx<MODE, IDX> aidx{reinterpret_cast<const unsigned short*>(slut32), (unsigned int)Rt.lo - 1u, (unsigned int)Rt.hi, span};
-  const long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+  float frac_v = P.hw_frac_f;
+  asm volatile("" : "+v"(frac_v));
+  AxisIdx<MODE, IDX> aidx{reinterpret_cast<const unsigned short*>(slut32), (unsigned int)Rt.lo - 1u, (unsigned int)Rt.hi, span, frac_v};
+  // Ray order.  All 64 lanes of a wave march until the LONGEST of their rays ends; with the cloud in sensor order a wave holds
+  // unrelated rays (mean length / longest ~ 0.55 for a uniform cloud).  On binned frames the counting sort by end-point tile is
+  // already there: `order` = the sorted 16-byte records (word 3: point index; valid points outside the owned cells sit in a last
+  // bin), *n_sorted their number -- a wave then marches 64 rays into the same 16 x 64 cell tile: equal lengths, neighbouring
+  // bitmap words.  The effects are order-independent accumulator updates: results are unchanged.
+  long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+  bool have = i < n;
+  if (order) { have = have && i < (long)*n_sorted; if (have) i = (long)order[i * 4 + 3]; }
   const int C = P.C;
   float gx = 0.f, gy = 0.f, gz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f, dec = 0.f;
   int kb = 0x7fffffff, ke = 0;                       // empty range: lanes without a (valid) ray never take part
-  if (i < n) {
+  if (have) {
     float rx_, ry_, rz_;
     load_point(pts, i, stride, rx_, ry_, rz_);
     Geo g = geometry<MODE>(P, T, rx_, ry_, rz_);
@@ -281,7 +285,6 @@ __global__ __launch_bounds__(BLOCK, 8) void k_rays(KP P, Pose T, RayTab Rt, cons
     }
   }
   const int wb = __builtin_amdgcn_readfirstlane(wave_min_i(kb)), we = __builtin_amdgcn_readfirstlane(wave_max_i(ke));   // SGPRs
-  const float* __restrict__ Sg = Rt.S;
   unsigned long long visits = 0;
   int last = -1;
   // Deferred cell work.  Only a few percent of the visits need the cell at all (it is neither known-and-fresh nor next to the
@@ -304,17 +307,22 @@ __global__ __launch_bounds__(BLOCK, 8) void k_rays(KP P, Pose T, RayTab Rt, cons
     const unsigned int c = (lrow + (unsigned int)P.halo) * (unsigned int)C + col;
     const float s = has ? qz[first + lane] : 0.f;
     const int src = has ? (int)ql[first + lane] : lane;
-    const float erx = __shfl(rx, src, 64), ery = __shfl(ry, src, 64), erz = __shfl(rz, src, 64), edec = __shfl(dec, src, 64);
+    // Block threshold first (written by k_tile_fuse<true, true>): no cell of this 8 x 8 block can be affected by a sample at or above it
+    // (unknown cells: their upper bound; known stale cells: height + 0.05 > every nz that passes the penetration test).  A random
+    // 32-byte cell costs a 128-byte line across the fabric -- 1.4 GB per frame before this filter; the table is 64 KB and L2 resident.
+    // It needs only the sample height (one lane exchange) and rejects ~99 % of the queued visits; the rest of the ray (six more
+    // exchanges, the distance test) is fetched only when some visit of the batch survives.
+    const float erz = __shfl(rz, src, 64);
+    const float nz = T.t[2] + erz * s;                                                   // the sample height, recomputed bit for bit
+    const bool live = has && !(thr && nz >= thr[(lrow >> 3) * (unsigned int)((C + 7) >> 3) + (col >> 3)]);
+    if (!__builtin_amdgcn_ballot_w64(live)) return;                                      // wave-uniform
+    const float erx = __shfl(rx, src, 64), ery = __shfl(ry, src, 64), edec = __shfl(dec, src, 64);
     const float egx = __shfl(gx, src, 64), egy = __shfl(gy, src, 64), egz = __shfl(gz, src, 64);
-    if (!has) return;
-    const float nx = T.t[0] + erx * s, ny = T.t[1] + ery * s, nz = T.t[2] + erz * s;     // the sample, recomputed bit for bit
+    if (!live) return;
+    const float nx = T.t[0] + erx * s, ny = T.t[1] + ery * s;
     const float ddx = egx - nx, ddy = egy - ny, ddz = egz - nz;
     const float d = Qf<MODE>(ddx * ddx + ddy * ddy + ddz * ddz);
     if (d < Rt.f_d_thresh) return;             // (double)d < 0.1: too close to the point (:225-226)
-    // Block threshold (written by k_tile_fuse<true, true>): no cell of this 8 x 8 block can be affected by a sample at or above it
-    // (unknown cells: their upper bound; known stale cells: height + 0.05 > every nz that passes the penetration test).  A random
-    // 32-byte cell costs a 128-byte line across the fabric -- 1.4 GB per frame before this filter; the table is 64 KB and L2 resident.
-    if (thr && nz >= thr[(lrow >> 3) * (unsigned int)((C + 7) >> 3) + (col >> 3)]) return;
     const float4* cp = reinterpret_cast<const float4*>(&cells[c]);
     const float4 m0 = cp[0], m1 = cp[1];       // h v valid trav | time upper is_upper pad
     if (m0.z < 0.5f) {                         // unknown cell: upper bound (:228-234)
@@ -336,49 +344,96 @@ __global__ __launch_bounds__(BLOCK, 8) void k_rays(KP P, Pose T, RayTab Rt, cons
       if (nz < m1.y || m1.z < 0.5f) ray_upper_min(&accr[c].upper_key, nz);
     }
   };
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  const v2f txy = {T.t[0], T.t[1]}, rxy = {rx, ry};
-  for (int k0 = wb; k0 < we; k0 += 64) {
-   const float vS = Sg[min(k0 + lane, nS - 1)];                // the next 64 steps, one per lane: s_k comes out of a register below
-   const int kn = __builtin_amdgcn_readfirstlane(min(64, we - k0));     // wave-uniform (SGPR)
-   for (int j = 0; j < kn; ++j) {
-    const int k = k0 + j;
-    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vS), j));    // wave-uniform
-    const v2f nxy = txy + rxy * s;                              // x, y of the sample (its height is only needed for queued visits)
-    const int ix = aidx(P, nxy.x), iy = aidx(P, nxy.y);
-    const int nidx = (int)(__umul24((unsigned int)ix, (unsigned int)C) + (unsigned int)iy);     // clamped to [0, cell_n - 1], cell_n <= 46340: 24-bit operands
-    // own sample & new cell (:209-210) [& owned by this strip]; border cells (:211) read as inert in the bitmap
-    // (measured: fetching the bitmap word unconditionally -- branch free -- is 10 % slower than this guarded form)
-    bool act;
-    unsigned int brow = (unsigned int)ix;                       // bitmap row: the logical row ...
-    if (STRIP) {
-      const bool mine = (unsigned int)(k - kb) < (unsigned int)(ke - kb);
-      brow = (unsigned int)(phys_row(P, ix) - P.row0);          // ... or, on strips, the local physical row (also the ownership test)
-      act = mine & (nidx != last) & (brow < (unsigned int)P.nrows);
-      last = mine ? nidx : last;
-    } else {
-      act = (k < ke) & (nidx != last);                          // (a lane beyond its last sample never acts again: `last` may run on)
-      last = nidx;
-    }
-    bool need = false;
-    if (act) {
-      if (STATS) visits += (max((unsigned int)(ix - 1), (unsigned int)(iy - 1)) < (unsigned int)(C - 2)) ? 1u : 0u;
-      const unsigned int off = __umul24(brow, wpr32 * 4u) + (((unsigned int)iy >> 3) & ~3u);   // byte offset of the word
-      const unsigned int w = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(inert) + off);
-      need = __builtin_amdgcn_ubfe(w, (unsigned int)iy, 1u) == 0u;     // bit iy & 31 clear: not (known + fresh), something may happen
-    }
+  // ---- the march ----------------------------------------------------------------------------------------------------------
+  // Measured on MI355X (tools/clockbench.hip, 8 waves per SIMD): a SIMD issues about ONE instruction per nanosecond whatever its
+  // kind -- a scalar instruction costs as much as a vector one, a branch (taken or not) about four.  The loop is therefore built
+  // to need almost no scalar instructions and one branch per FOUR steps:
+  //  * a lane stops at its own last sample by clamping the step, s = min(s_k, s_end): beyond its range the sample stays in the cell
+  //    it visited last, and the new-cell test (:209-210) then keeps the lane passive -- no step counter, no range compare (a lane
+  //    without a ray sits in the sensor's cell from the start); row strips keep the explicit range test (kb > 0);
+  //  * the bitmap word of a visit is requested for every lane (a passive lane reads the all-ones word behind the last row) and
+  //    looked at one group of four steps LATER: four loads in flight per wave, no branch around them, one ballot + branch per group
+  //    decides whether anything has to be queued at all;
+  //  * the groups alternate between two register sets (no copy has to wait for a load in flight).
+  auto push = [&](unsigned int w, unsigned int xy, float s) {      // bit iy & 31 clear: not (known + fresh), something may happen -> queue the visit
+    const bool need = __builtin_amdgcn_ubfe(w, xy, 1u) == 0u;
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(need);
     if (mask) {                                                 // wave-uniform
       if (need) {
         const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-        qc[pos] = ((unsigned int)ix << 16) | (unsigned int)iy; qz[pos] = s; ql[pos] = (unsigned int)lane;      // cell_n <= 46340: 16 bits each
+        qc[pos] = xy; qz[pos] = s; ql[pos] = (unsigned int)lane;
       }
       qn += __popcll(mask);
       __builtin_amdgcn_wave_barrier();
       if (qn >= 64) { qn -= 64; work(qn, 64); __builtin_amdgcn_wave_barrier(); }
     }
+  };
+  constexpr int GU = 4;                                         // steps per group
+  struct Group { unsigned int w[GU], xy[GU]; float s[GU]; };
+  auto consume = [&](const Group& g) {
+    unsigned int clear = 0u;                                    // some visit of the group hit a cell that is not (known + fresh)
+#pragma unroll
+    for (int u = 0; u < GU; ++u) clear |= ~g.w[u] >> (g.xy[u] & 31u);
+    if (__builtin_amdgcn_ballot_w64((clear & 1u) != 0u) == 0ull) return;     // the common case: one branch per four steps
+#pragma unroll
+    for (int u = 0; u < GU; ++u) push(g.w[u], g.xy[u], g.s[u]);
+  };
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f txy = {T.t[0], T.t[1]};
+  float vS = 0.f; int k0 = wb;
+  // loop constants that feed a second scalar operand slot live in vector registers (one scalar source per VALU instruction on
+  // gfx9: the compiler would otherwise re-materialise them with a v_mov in every step)
+  unsigned int ones_off = (unsigned int)P.nrows * wpr32 * 4u;
+  asm volatile("" : "+v"(ones_off));
+  float s_end = 0.f;                                            // the lane's last sample (0: none -- the lane then never leaves the sensor's cell)
+  if (!STRIP) {
+    if (ke > 0) s_end = sS[ke - 1];
+    if (ke <= 0) { rx = 0.f; ry = 0.f; last = (int)(__umul24((unsigned int)aidx(P, T.t[0]), (unsigned int)C) + (unsigned int)aidx(P, T.t[1])); }
+  }
+  const v2f rxy_m = {rx, ry};
+  auto step = [&](int j, unsigned int& w, unsigned int& xy, float& s_out) {
+    const float sk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vS), j));    // wave-uniform
+    float s = sk;
+    if (!STRIP) asm("v_min_f32 %0, %1, %2" : "=v"(s) : "s"(sk), "v"(s_end));
+    const v2f nxy = txy + rxy_m * s;                            // x, y of the sample (its height is only needed for queued visits)
+    const int ix = aidx(P, nxy.x), iy = aidx(P, nxy.y);
+    const int nidx = (int)(__umul24((unsigned int)ix, (unsigned int)C) + (unsigned int)iy);     // clamped to [0, cell_n - 1], cell_n <= 46340: 24-bit operands
+    // own sample & new cell (:209-210) [& owned by this strip]; border cells (:211) read as inert in the bitmap
+    bool act;
+    unsigned int brow = (unsigned int)ix;                       // bitmap row: the logical row ...
+    if (STRIP) {
+      const int k = k0 + j;
+      const bool mine = (unsigned int)(k - kb) < (unsigned int)(ke - kb);
+      brow = (unsigned int)(phys_row(P, ix) - P.row0);          // ... or, on strips, the local physical row (also the ownership test)
+      act = mine & (nidx != last) & (brow < (unsigned int)P.nrows);
+      last = mine ? nidx : last;
+    } else {
+      act = nidx != last;
+      last = nidx;
+    }
+    if (STATS) visits += (act && max((unsigned int)(ix - 1), (unsigned int)(iy - 1)) < (unsigned int)(C - 2)) ? 1u : 0u;
+    const unsigned int off_a = mad24(brow, wpr32 * 4u, ((unsigned int)iy >> 3) & ~3u);       // byte offset of the bitmap word
+    const unsigned int off = act ? off_a : ones_off;
+    w = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(LMAP ? smap : inert) + off);
+    xy = ((unsigned int)ix << 16) | (unsigned int)iy; s_out = s;      // cell_n <= 46340: 16 bits each
+  };
+  Group gA, gB;
+#pragma unroll
+  for (int u = 0; u < GU; ++u) { gA.w[u] = ~0u; gA.xy[u] = 0u; gA.s[u] = 0.f; gB.w[u] = ~0u; gB.xy[u] = 0u; gB.s[u] = 0.f; }
+  for (; k0 < we; k0 += 64) {
+   vS = sS[min(k0 + lane, nS - 1)];                            // the next 64 steps, one per lane (from the LDS copy: a global load here would make every
+                                                               // loop iteration wait for ALL vector loads in flight, including the pipelined bitmap words)
+   const int kn = __builtin_amdgcn_readfirstlane(min(64, we - k0));     // wave-uniform (SGPR)
+   for (int j = 0; j < kn; j += 2 * GU) {                      // (steps past `we` lie beyond every lane's range: they request nothing; j + 7 <= 63)
+#pragma unroll
+    for (int u = 0; u < GU; ++u) step(j + u, gA.w[u], gA.xy[u], gA.s[u]);
+    consume(gB);
+#pragma unroll
+    for (int u = 0; u < GU; ++u) step(j + GU + u, gB.w[u], gB.xy[u], gB.s[u]);
+    consume(gA);
    }
   }
+  consume(gB);
   __builtin_amdgcn_wave_barrier();
   if (qn > 0) work(0, qn);
   if (STATS) {
@@ -423,19 +478,26 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cell* __restrict__ c
 // inflation (custom_kernels.py:251-252), upper bound (:230-233, :254-255), then average_map_kernel's reset of cells whose
 // validity fell below 0.5 (:380-384); re-arms the accumulators.
 __global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cell* __restrict__ cells, AccR* __restrict__ accr,
-                                                        unsigned long long* __restrict__ inert) {
+                                                        unsigned long long* __restrict__ inert, OverlapArgs O) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
   if (li < (long)P.nrows * ((P.C + 63) / 64)) inert[li] = 0ull;      // the rays are done with the bitmap: leave it zeroed for the tile kernel's ORs
   long c = li + (long)P.halo * P.C;
   const AccR r = accr[c];
-  if (!(r.hits | r.upper_key)) return;
+  bool win = false;                                                  // clear_overlap_map follows the averaging (:372-375): centred window
+  if (O.on) { const int lrow = (int)(li / P.C); win = overlap_window(O, logi_row(P, P.row0 + lrow), logi_col(P, (int)(li - (long)lrow * P.C))); }
+  if (!(r.hits | r.upper_key) && !win) return;
   Cell m = cells[c];
-  if (r.hits) { m.valid = m.valid + (float)((double)r.dec / EM_SCALE_V); m.v = m.v + P.ov_f * (float)r.hits; }
-  if (r.upper_key) { m.upper = ord_float(~r.upper_key); m.is_upper = 1.0f; }
-  if (m.valid < 0.5f) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; }
-  cells[c] = m;
-  AccR z = {0, 0u, 0u}; accr[c] = z;
+  bool ch = false;
+  if (r.hits | r.upper_key) {
+    if (r.hits) { m.valid = m.valid + (float)((double)r.dec / EM_SCALE_V); m.v = m.v + P.ov_f * (float)r.hits; }
+    if (r.upper_key) { m.upper = ord_float(~r.upper_key); m.is_upper = 1.0f; }
+    if (m.valid < 0.5f) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; }
+    AccR z = {0, 0u, 0u}; accr[c] = z;
+    ch = true;
+  }
+  if (win) ch = overlap_cell(P, O, m) || ch;
+  if (ch) cells[c] = m;
 }
 
 // clear_overlap_map (elevation_mapping.py:393-410): centred window, one launch instead of ~12
@@ -447,10 +509,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_overlap(KP P, Cell* __restrict__ c
   long c = owned_cell(P, ix, iy);
   if (c < 0) return;
   Cell m = cells[c];
-  bool ch = false;
-  if (m.h < hmin || m.h > hmax) { m.h = 0.f; m.v = P.init_var; m.valid = 0.f; ch = true; }
-  if (m.upper < hmin || m.upper > hmax) { m.upper = 0.f; m.is_upper = 0.f; ch = true; }
-  if (ch) cells[c] = m;
+  const OverlapArgs O = {1, cmin, cmax, 0, hmin, hmax};
+  if (overlap_cell(P, O, m)) cells[c] = m;
 }
 
 // (The 12 x 9 taps are explicit fma chains in a fixed order; the reference's cuDNN summation order is unspecified, tolerance 1e-5.)
@@ -800,11 +860,8 @@ void launch_count(hipStream_t s, const KP& P, const Pose& T, const float* pts, l
   if (P.mode == 0) hipLaunchKernelGGL(k_count<0>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, slots);
   else hipLaunchKernelGGL(k_count<1>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, slots);
 }
-void launch_gate(hipStream_t s, const KP& P, ErrSlot* slots, FrameDev* F, int enable, double min_cnt, double max_drift,
-                 float alpha, int noise_ok, int use_override, double sum_override, unsigned int cnt_override, unsigned int n_points,
-                 int reduce_only, double* dev_out, const double* dev_totals) {
-  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, P, slots, F, enable, min_cnt, max_drift, alpha, noise_ok, use_override,
-                     sum_override, cnt_override, n_points, reduce_only, dev_out, dev_totals);
+void launch_gate(hipStream_t s, const GateArgs& A, ErrSlot* slots, FrameDev* F, int reduce_only, double* dev_out, const double* dev_totals) {
+  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, A, slots, F, reduce_only, dev_out, dev_totals);
 }
 void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, const Cell* cells, AccF* acc,
                  const FrameDev* F) {
@@ -816,32 +873,40 @@ void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, lo
 void launch_commit(hipStream_t s, const KP& P, Cell* cells, const AccF* acc, const FrameDev* F, unsigned long long* inert) {
   hipLaunchKernelGGL(k_commit, dim3((P.C + 63) / 64, P.nrows), dim3(64), 0, s, P, cells, acc, F, inert);
 }
-void launch_ray_apply(hipStream_t s, const KP& P, Cell* cells, AccR* accr, unsigned long long* inert) {
-  hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr, inert);
+void launch_ray_apply(hipStream_t s, const KP& P, Cell* cells, AccR* accr, unsigned long long* inert, const OverlapArgs& O) {
+  hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr, inert, O);
 }
+#ifndef RAY_BLOCK
 #define RAY_BLOCK 1024
+#endif
 template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
                                                                               long n, int stride, const Cell* cells, AccR* accr,
                                                                               const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert,
-                                                                              const unsigned int* inl, int inl_stride, const float* thr) {
+                                                                              const unsigned int* inl, int inl_stride, const float* thr, const unsigned int* order, const unsigned int* n_sorted) {
   const size_t lds = (IDX == 1 ? ((size_t)(Rt.hi - Rt.lo) + 2) * 4 : 0) + (size_t)Rt.nS * 4 + (size_t)(RAY_BLOCK / 64) * 3 * 128 * 4;
+  const size_t map_bytes = ((size_t)P.nrows * ((P.C + 63) / 64) * 2 + 2) * 4;       // bitmap + the all-ones word
+  static const bool lmap_off = getenv("EMAP_RAY_LMAP") && atoi(getenv("EMAP_RAY_LMAP")) == 0;     // tuning / test hook
+  const bool lmap = !lmap_off && lds + map_bytes <= 158 * 1024 && n >= 65536;        // (small clouds: staging 128 KB per workgroup would dominate)
   dim3 g((unsigned int)((n + RAY_BLOCK - 1) / RAY_BLOCK)), b(RAY_BLOCK);
-  auto kern = k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK>;
-  static bool raised = false;                          // per instantiation: the half -> index table + queues can exceed the default 64 KB window
-  if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; }
-  hipLaunchKernelGGL(kern, g, b, lds, s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr);
+  auto go = [&](auto kern, bool& raised, size_t bytes) {    // per instantiation: the half -> index table + queues [+ bitmap] can exceed the default 64 KB window
+    if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; }
+    hipLaunchKernelGGL(kern, g, b, bytes, s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
+  };
+  static bool raised0 = false, raised1 = false;
+  if (lmap) go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, true>, raised1, lds + map_bytes);
+  else go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, false>, raised0, lds);
 }
 template <int MODE, bool STATS> static void launch_rays_t(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
                                                           long n, int stride, const Cell* cells, AccR* accr,
                                                           const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert,
-                                                          const unsigned int* inl, int inl_stride, const float* thr) {
+                                                          const unsigned int* inl, int inl_stride, const float* thr, const unsigned int* order, const unsigned int* n_sorted) {
   const bool strip = P.nrows < P.C;
   // index method (AxisIdx): the float formula when the host proved it exact (reference_fp16) or when it IS the definition (fp32);
   // else the half -> index table if it fits the default LDS window next to the step table; else the defining arithmetic
   int idx = 0;
   if (MODE == 0 && Rt.formula_ok) idx = 2;
   else if (MODE == 0 && Rt.lut != nullptr && ((size_t)(Rt.hi - Rt.lo) + 2) * 4 + (size_t)Rt.nS * 4 <= 100 * 1024) idx = 1;
-#define RAYS_GO(I, S) launch_rays_i<MODE, STATS, I, S>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr)
+#define RAYS_GO(I, S) launch_rays_i<MODE, STATS, I, S>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted)
   if (MODE == 0) {
     if (idx == 2) { if (strip) RAYS_GO(2, true); else RAYS_GO(2, false); }
     else if (idx == 1) { if (strip) RAYS_GO(1, true); else RAYS_GO(1, false); }
@@ -853,14 +918,15 @@ template <int MODE, bool STATS> static void launch_rays_t(hipStream_t s, const K
 // plane of the tile kernel (stride 1) or the high halves of AccF::pts_inl (stride 10, offset 1) on the staged / atomic path
 void launch_rays(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts, long n, int stride, const Cell* cells,
                  AccR* accr, const float* normal, long plane_stride, FrameDev* F, bool stats,
-                 const unsigned long long* inert, const unsigned int* inl, int inl_stride, const float* thr) {
+                 const unsigned long long* inert, const unsigned int* inl, int inl_stride, const float* thr,
+                 const unsigned int* order, const unsigned int* n_sorted) {
   if (n <= 0) return;
   if (P.mode == 0) {
-    if (stats) launch_rays_t<0, true>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr);
-    else launch_rays_t<0, false>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr);
+    if (stats) launch_rays_t<0, true>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
+    else launch_rays_t<0, false>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
   } else {
-    if (stats) launch_rays_t<1, true>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr);
-    else launch_rays_t<1, false>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr);
+    if (stats) launch_rays_t<1, true>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
+    else launch_rays_t<1, false>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
   }
 }
 void launch_average(hipStream_t s, const KP& P, Cell* cells, AccF* acc, AccR* accr, const FrameDev* F, bool committed, bool rays,
