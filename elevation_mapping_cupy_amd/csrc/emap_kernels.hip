@@ -197,7 +197,7 @@ template <int MODE, bool STATS, int IDX, bool STRIP, int BLOCK, bool LMAP>
 #ifndef RAY_OCC
 #define RAY_OCC 8
 #endif
-__global__ __launch_bounds__(BLOCK, RAY_OCC) void k_rays(KP P, Pose T, RayTab Rt, const float* __restrict__ pts, long n, int stride,
+__global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T, RayTab Rt, const float* __restrict__ pts, long n, int stride,
                                                  const Cell* __restrict__ cells,
                                                  AccR* __restrict__ accr, const float* __restrict__ normal,
                                                  long plane_stride, FrameDev* __restrict__ F,
@@ -209,20 +209,26 @@ __global__ __launch_bounds__(BLOCK, RAY_OCC) void k_rays(KP P, Pose T, RayTab Rt
   // LDS words: [table (span)] [s_k (nS)] [queues (BLOCK/64 * 384)]
   extern __shared__ unsigned int slut32[];
   const unsigned int span = IDX == 1 ? (unsigned int)(Rt.hi - Rt.lo) + 2u : 0u;
-  float* sS = reinterpret_cast<float*>(slut32 + span);          // step table s_k in LDS for the per-ray binary searches
-  const int nS = Rt.nS;
+  float* sS = reinterpret_cast<float*>(slut32 + ((span + 3u) & ~3u));      // step table s_k in LDS (16-byte aligned, padded by 8 x +inf: the march reads float4)
+  const int nS = Rt.nS, nSp = ((nS + 3) & ~3) + 8;
   if (IDX == 1) {
     const unsigned int* src = reinterpret_cast<const unsigned int*>(Rt.lut);   // 2 signs * span u16 = span u32
     for (unsigned int k = threadIdx.x; k < span; k += BLOCK) slut32[k] = src[k];
   }
-  for (int k = threadIdx.x; k < nS; k += BLOCK) sS[k] = Rt.S[k];
-  unsigned int* qbase = reinterpret_cast<unsigned int*>(sS + nS);                 // per-wave visit queues: 3 x 128 words each
+  for (int k = threadIdx.x; k < nSp; k += BLOCK) sS[k] = k < nS ? Rt.S[k] : INFINITY;
+  unsigned int* qbase = reinterpret_cast<unsigned int*>(sS + nSp);                 // per-wave visit queues: 3 x 128 words each
   // LMAP: the whole bitmap (+ the all-ones word behind it) is staged in LDS when it fits next to the queues (128 KB for a 1024^2
   // map: one workgroup per CU, which costs nothing -- 4 and 8 waves per SIMD run this kernel equally fast).  A scattered 64-lane
   // dword load keeps the CU's single texture addresser busy for ~45 clocks; the LDS serves it in a handful (measured: frame 0.495
   // -> 0.449 ms at 1024^2 / 1 M rays).
-  unsigned int* smap = qbase + (BLOCK / 64) * 384;
+  // (the copy starts at an LDS offset aligned to the row pitch: the word address is then (row * pitch) + ((column part) | base), one
+  // v_and_or instead of an and + an add per step)
+  typedef __attribute__((address_space(3))) unsigned int lds_u32;
+  unsigned int map_align = 4u; while (map_align < wpr32 * 4u) map_align <<= 1;
+  const unsigned int q_end = (unsigned int)(size_t)(lds_u32*)(qbase + (BLOCK / 64) * 384);       // byte offset in LDS
+  const unsigned int smap_base = LMAP ? (q_end + map_align - 1u) & ~(map_align - 1u) : 0u;
   if (LMAP) {
+    lds_u32* smap = (lds_u32*)(size_t)smap_base;
     const unsigned int nw = (unsigned int)P.nrows * wpr32 + 2u;
     for (unsigned int k = threadIdx.x; k < nw; k += BLOCK) smap[k] = inert[k];
   }
@@ -286,7 +292,6 @@ __global__ __launch_bounds__(BLOCK, RAY_OCC) void k_rays(KP P, Pose T, RayTab Rt
   }
   const int wb = __builtin_amdgcn_readfirstlane(wave_min_i(kb)), we = __builtin_amdgcn_readfirstlane(wave_max_i(ke));   // SGPRs
   unsigned long long visits = 0;
-  int last = -1;
   // Deferred cell work.  Only a few percent of the visits need the cell at all (it is neither known-and-fresh nor next to the
   // ray's end point), but with 64 unrelated rays per wave almost every step has ONE such lane, and its dependent loads (cell ->
   // normals -> inlier count) then stall the whole wave for a memory round trip per step.  The march therefore only QUEUES those
@@ -371,67 +376,80 @@ __global__ __launch_bounds__(BLOCK, RAY_OCC) void k_rays(KP P, Pose T, RayTab Rt
   constexpr int GU = 4;                                         // steps per group
   struct Group { unsigned int w[GU], xy[GU]; float s[GU]; };
   auto consume = [&](const Group& g) {
-    unsigned int clear = 0u;                                    // some visit of the group hit a cell that is not (known + fresh)
+    unsigned int inert_all = 1u;                                // every visit of the group hit a (known + fresh) cell
 #pragma unroll
-    for (int u = 0; u < GU; ++u) clear |= ~g.w[u] >> (g.xy[u] & 31u);
-    if (__builtin_amdgcn_ballot_w64((clear & 1u) != 0u) == 0ull) return;     // the common case: one branch per four steps
+    for (int u = 0; u < GU; ++u) inert_all &= __builtin_amdgcn_ubfe(g.w[u], g.xy[u], 1u);      // bit iy & 31 of the word
+    if (__builtin_amdgcn_ballot_w64(inert_all == 0u) == 0ull) return;         // the common case: one branch per four steps
 #pragma unroll
     for (int u = 0; u < GU; ++u) push(g.w[u], g.xy[u], g.s[u]);
   };
   typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef _Float16 v2h __attribute__((ext_vector_type(2)));
   const v2f txy = {T.t[0], T.t[1]};
-  float vS = 0.f; int k0 = wb;
   // loop constants that feed a second scalar operand slot live in vector registers (one scalar source per VALU instruction on
   // gfx9: the compiler would otherwise re-materialise them with a v_mov in every step)
-  unsigned int ones_off = (unsigned int)P.nrows * wpr32 * 4u;
-  asm volatile("" : "+v"(ones_off));
+  unsigned int ones_off = (unsigned int)P.nrows * wpr32 * 4u + smap_base, base_v = smap_base, mask_v = 0x1ffffffcu;
+  asm volatile("" : "+v"(ones_off), "+v"(base_v), "+v"(mask_v));
+  auto cell_xy = [&](v2f n, int& ix, int& iy) -> unsigned int {                   // sample position -> cell, key (ix << 16) | iy   (cell_n <= 46340: 16 bits each)
+    if constexpr (IDX == 2) {
+      // both axes together: one packed conversion to half (v_cvt_pk_f16_f32), the two mixed-precision FMAs read its halves, one
+      // packed add of the half width -- AxisIdx<0, 2>'s arithmetic, operation for operation
+      const v2h h = __builtin_convertvector(n, v2h);
+      const unsigned int hb = __builtin_bit_cast(unsigned int, h);
+      float fx, fy;
+      asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(fx) : "v"(hb), "s"(P.inv_res_f), "v"(frac_v));
+      asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(fy) : "v"(hb), "s"(P.inv_res_f), "v"(frac_v));
+      const v2f f = (v2f){__builtin_floorf(fx), __builtin_floorf(fy)} + (v2f){P.hw_int_f, P.hw_int_f};
+      ix = (int)__builtin_amdgcn_fmed3f(f.x, 0.0f, P.cm1_f); iy = (int)__builtin_amdgcn_fmed3f(f.y, 0.0f, P.cm1_f);
+    } else { ix = aidx(P, n.x); iy = aidx(P, n.y); }
+    return ((unsigned int)ix << 16) | (unsigned int)iy;
+  };
+  unsigned int last_xy = 0xffffffffu;                           // the cell of the lane's previous sample (no cell: the first sample always acts)
   float s_end = 0.f;                                            // the lane's last sample (0: none -- the lane then never leaves the sensor's cell)
   if (!STRIP) {
     if (ke > 0) s_end = sS[ke - 1];
-    if (ke <= 0) { rx = 0.f; ry = 0.f; last = (int)(__umul24((unsigned int)aidx(P, T.t[0]), (unsigned int)C) + (unsigned int)aidx(P, T.t[1])); }
+    if (ke <= 0) { int ix0, iy0; rx = 0.f; ry = 0.f; last_xy = cell_xy(txy, ix0, iy0); }
   }
   const v2f rxy_m = {rx, ry};
-  auto step = [&](int j, unsigned int& w, unsigned int& xy, float& s_out) {
-    const float sk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vS), j));    // wave-uniform
+  int kg = STRIP ? (wb & ~(2 * GU - 1)) : 0;                    // first step of the current group (multiple of 8: the step table is read as float4)
+  auto step = [&](int k, float sk, unsigned int& w, unsigned int& xy_out, float& s_out) {
     float s = sk;
-    if (!STRIP) asm("v_min_f32 %0, %1, %2" : "=v"(s) : "s"(sk), "v"(s_end));
-    const v2f nxy = txy + rxy_m * s;                            // x, y of the sample (its height is only needed for queued visits)
-    const int ix = aidx(P, nxy.x), iy = aidx(P, nxy.y);
-    const int nidx = (int)(__umul24((unsigned int)ix, (unsigned int)C) + (unsigned int)iy);     // clamped to [0, cell_n - 1], cell_n <= 46340: 24-bit operands
+    if (!STRIP) asm("v_min_f32 %0, %1, %2" : "=v"(s) : "v"(sk), "v"(s_end));
+    int ixs, iys;
+    const unsigned int xy = cell_xy(txy + rxy_m * s, ixs, iys);           // x, y of the sample (its height is only needed for queued visits)
+    const unsigned int ix = (unsigned int)ixs, iy = (unsigned int)iys;
     // own sample & new cell (:209-210) [& owned by this strip]; border cells (:211) read as inert in the bitmap
     bool act;
-    unsigned int brow = (unsigned int)ix;                       // bitmap row: the logical row ...
+    unsigned int brow = ix;                                     // bitmap row: the logical row ...
     if (STRIP) {
-      const int k = k0 + j;
       const bool mine = (unsigned int)(k - kb) < (unsigned int)(ke - kb);
-      brow = (unsigned int)(phys_row(P, ix) - P.row0);          // ... or, on strips, the local physical row (also the ownership test)
-      act = mine & (nidx != last) & (brow < (unsigned int)P.nrows);
-      last = mine ? nidx : last;
+      brow = (unsigned int)(phys_row(P, (int)ix) - P.row0);     // ... or, on strips, the local physical row (also the ownership test)
+      act = mine & (xy != last_xy) & (brow < (unsigned int)P.nrows);
+      last_xy = mine ? xy : last_xy;
     } else {
-      act = nidx != last;
-      last = nidx;
+      act = xy != last_xy;
+      last_xy = xy;
     }
-    if (STATS) visits += (act && max((unsigned int)(ix - 1), (unsigned int)(iy - 1)) < (unsigned int)(C - 2)) ? 1u : 0u;
-    const unsigned int off_a = mad24(brow, wpr32 * 4u, ((unsigned int)iy >> 3) & ~3u);       // byte offset of the bitmap word
+    if (STATS) visits += (act && max(ix - 1u, iy - 1u) < (unsigned int)(C - 2)) ? 1u : 0u;
+    unsigned int colpart;                                       // ((iy >> 3) & ~3) | LDS base: byte offset of the word within its row
+    asm("v_and_or_b32 %0, %1, %3, %2" : "=v"(colpart) : "v"(iy >> 3), "v"(base_v), "v"(mask_v));      // (no VOP3 literals on gfx9: the mask is a register)
+    const unsigned int off_a = mad24(brow, wpr32 * 4u, colpart);
     const unsigned int off = act ? off_a : ones_off;
-    w = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(LMAP ? smap : inert) + off);
-    xy = ((unsigned int)ix << 16) | (unsigned int)iy; s_out = s;      // cell_n <= 46340: 16 bits each
+    if (LMAP) w = *(const lds_u32*)(size_t)off;
+    else w = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(inert) + off);
+    xy_out = xy; s_out = s;
   };
   Group gA, gB;
 #pragma unroll
   for (int u = 0; u < GU; ++u) { gA.w[u] = ~0u; gA.xy[u] = 0u; gA.s[u] = 0.f; gB.w[u] = ~0u; gB.xy[u] = 0u; gB.s[u] = 0.f; }
-  for (; k0 < we; k0 += 64) {
-   vS = sS[min(k0 + lane, nS - 1)];                            // the next 64 steps, one per lane (from the LDS copy: a global load here would make every
-                                                               // loop iteration wait for ALL vector loads in flight, including the pipelined bitmap words)
-   const int kn = __builtin_amdgcn_readfirstlane(min(64, we - k0));     // wave-uniform (SGPR)
-   for (int j = 0; j < kn; j += 2 * GU) {                      // (steps past `we` lie beyond every lane's range: they request nothing; j + 7 <= 63)
-#pragma unroll
-    for (int u = 0; u < GU; ++u) step(j + u, gA.w[u], gA.xy[u], gA.s[u]);
+  for (; kg < we; kg += 2 * GU) {                               // (steps past a lane's range request nothing; the table is padded by 8 entries)
+    const float4 s0 = *reinterpret_cast<const float4*>(sS + kg), s1 = *reinterpret_cast<const float4*>(sS + kg + GU);   // wave-uniform reads
+    step(kg + 0, s0.x, gA.w[0], gA.xy[0], gA.s[0]); step(kg + 1, s0.y, gA.w[1], gA.xy[1], gA.s[1]);
+    step(kg + 2, s0.z, gA.w[2], gA.xy[2], gA.s[2]); step(kg + 3, s0.w, gA.w[3], gA.xy[3], gA.s[3]);
     consume(gB);
-#pragma unroll
-    for (int u = 0; u < GU; ++u) step(j + GU + u, gB.w[u], gB.xy[u], gB.s[u]);
+    step(kg + 4, s1.x, gB.w[0], gB.xy[0], gB.s[0]); step(kg + 5, s1.y, gB.w[1], gB.xy[1], gB.s[1]);
+    step(kg + 6, s1.z, gB.w[2], gB.xy[2], gB.s[2]); step(kg + 7, s1.w, gB.w[3], gB.xy[3], gB.s[3]);
     consume(gA);
-   }
   }
   consume(gB);
   __builtin_amdgcn_wave_barrier();
@@ -883,13 +901,14 @@ template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(h
                                                                               long n, int stride, const Cell* cells, AccR* accr,
                                                                               const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert,
                                                                               const unsigned int* inl, int inl_stride, const float* thr, const unsigned int* order, const unsigned int* n_sorted) {
-  const size_t lds = (IDX == 1 ? ((size_t)(Rt.hi - Rt.lo) + 2) * 4 : 0) + (size_t)Rt.nS * 4 + (size_t)(RAY_BLOCK / 64) * 3 * 128 * 4;
-  const size_t map_bytes = ((size_t)P.nrows * ((P.C + 63) / 64) * 2 + 2) * 4;       // bitmap + the all-ones word
+  const size_t lds = (IDX == 1 ? (((size_t)(Rt.hi - Rt.lo) + 2 + 3) & ~(size_t)3) * 4 : 0) + (size_t)(((Rt.nS + 3) & ~3) + 8) * 4 + (size_t)(RAY_BLOCK / 64) * 3 * 128 * 4;
+  size_t map_bytes = ((size_t)P.nrows * ((P.C + 63) / 64) * 2 + 2) * 4;       // bitmap + the all-ones word ...
+  { size_t al = 4; while (al < (size_t)((P.C + 63) / 64) * 8) al <<= 1; map_bytes += al; }      // ... + alignment to the row pitch
   static const bool lmap_off = getenv("EMAP_RAY_LMAP") && atoi(getenv("EMAP_RAY_LMAP")) == 0;     // tuning / test hook
   const bool lmap = !lmap_off && lds + map_bytes <= 158 * 1024 && n >= 65536;        // (small clouds: staging 128 KB per workgroup would dominate)
   dim3 g((unsigned int)((n + RAY_BLOCK - 1) / RAY_BLOCK)), b(RAY_BLOCK);
   auto go = [&](auto kern, bool& raised, size_t bytes) {    // per instantiation: the half -> index table + queues [+ bitmap] can exceed the default 64 KB window
-    if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; }
+    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; }
     hipLaunchKernelGGL(kern, g, b, bytes, s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
   };
   static bool raised0 = false, raised1 = false;
