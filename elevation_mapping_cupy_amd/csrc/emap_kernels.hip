@@ -576,61 +576,58 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   for (int k = 1; k < 4; ++k) if (k < S.n && (int)blockIdx.y >= S.t0[k]) { seg_b = S.b[k]; seg_e = S.e[k]; ty = blockIdx.y - S.t0[k]; }
   constexpr int PT_THREADS = PT_R >= 32 ? POST_T32 : 512, PT_WAVES = PT_THREADS / 64;     // 32-row tiles: 16 waves, two output rows per thread
   extern __shared__ float lds[];
-  const int RW = PT_C + 6 + 2 * d, rp = RW + 1, RH = PT_R + 6 + 2 * d;     // staged (value, mask) region: tile + halo 3 + d
+  const int RW = PT_C + 6 + 2 * d, rp = RW + 1, RH = PT_R + 6 + 2 * d;     // staged region: tile + halo 3 + d
   const int DW = PT_C + 6, DH = PT_R + 6;                                   // region whose DILATED value is needed (halo 3)
-  float* rval = lds;                     // raw upper_bound; holes inside the DW x DH region are overwritten by their dilated value
-  float* rmsk = rval + RH * rp;          // mask >= 0; stored as -(mask)-1 when the cell is NOT is_inside (never a source)
-  float* sval = rmsk + RH * rp;          // is_valid of the PT_R x PT_C interior (normal filter)
-  int* rtab = reinterpret_cast<int*>(sval + PT_R * PT_C);     // RH + 2 row terms
+  // Region cell (r, c) = three consecutive floats at reg[(r * rp + c) * 3]: the raw upper_bound (holes inside the DW x DH region are
+  // overwritten by their dilated value), the mask >= 0 (stored as -(mask)-1 when the cell is NOT is_inside: never a source) and
+  // is_valid (normal filter).  One 12-byte LDS write per staged cell; a stride of three dwords across the lanes is conflict free.
+  float* reg = lds;
+  int* rtab = reinterpret_cast<int*>(reg + 3 * RH * rp);       // RH + 2 row terms
   const int C = P.C;
   const int tile_r = seg_b + ty * PT_R, tile_c = blockIdx.x * PT_C;      // logical row / column of the tile origin
   const int tc = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave index in an SGPR
   // staging.  The first 64 columns of the region go row-wise: one wave per region row, lane = column.  Everything that depends on
   // the row (circular origin, strip ownership, border) is computed ONCE per tile into a small LDS table, everything that depends
-  // on the column once per lane; a cell then costs one table read and one add for its address.  Tiles at the left / right map edge
-  // see the reference's flat-index row wrap (:403-407: column -1 of row r is column C-1 of row r-1): such a lane reads the table
-  // one row up or down.  The remaining 6 + 2d columns go as a linear walk over (row, column) pairs so that their lanes are full too.
-  // All loads of a round (valid: 1 dword; upper + is_upper: 2 dwords of the 32-B cell) are issued before any is consumed: a 44 x 76
-  // region (32-row tile, d = 3) is ONE round = one memory round trip.
+  // on the column once per lane, both as FLAG BITS of one integer (bit 31: no such cell, bit 30: border) -- the kernel is
+  // instruction-issue bound and lane-mask logic in scalar registers costs as much as arithmetic.  Tiles at the left / right map
+  // edge see the reference's flat-index row wrap (:403-407: column -1 of row r is column C-1 of row r-1): such a lane reads the
+  // table one row up or down.  The remaining 6 + 2d columns go as a linear walk over (row, column) pairs so that their lanes are
+  // full too.  All loads of a round (valid: 1 dword; upper + is_upper: 2 dwords of the 32-B cell) are issued before any is
+  // consumed: a 44 x 76 region (32-row tile, d = 3) is ONE round = one memory round trip.  A cell that does not exist loads
+  // (row 0, column 0) and is masked afterwards: no branch around the loads.
   {
     constexpr int JB = PT_R >= 32 ? 48 / PT_WAVES : 6, EU = PT_R >= 32 ? (528 + PT_THREADS - 1) / PT_THREADS : 2;     // rows per wave and edge cells per thread in one round
     const int r0 = tile_r - 3 - d, c0 = tile_c - 3 - d, EC = RW - 64;
     const int etotal = RH * EC;
-    // row table: region row j - 1 (one extra row on both sides for the flat-index carry) -> index of its first cell in the local
-    // arrays, -1: not in the map / strip; bit 30: a border row (never a dilation source)
+    // row table: region row j - 1 (one extra row on both sides for the flat-index carry) -> local row of the arrays (bits 0..23;
+    // 0 with bit 31 set: not in the map / strip), bit 30: a border row (never a dilation source)
     for (int j = threadIdx.x; j < RH + 2; j += PT_THREADS) {
       const int g = r0 - 1 + j;
       const bool in_map = g >= 0 && g <= C - 1;
       const int lr = in_map ? local_row(P, phys_row(P, g)) : -1;
-      rtab[j] = lr < 0 ? -1 : (lr * C) | ((g >= 1 && g <= C - 2) ? 0 : 0x40000000);
+      rtab[j] = lr < 0 ? (int)0x80000000 : lr | ((g >= 1 && g <= C - 2) ? 0 : 0x40000000);
     }
     __syncthreads();
-    auto col_terms = [&](int cc, int& dr, int& pc, bool& cin) {     // region column -> row carry, physical column, inside flag
+    auto col_terms = [&](int cc, int& dr, int& pc, int& flags) {     // region column -> row carry, physical column, flag bits
       int cl = c0 + cc; dr = 0;
       if (cl < 0) { cl += C; dr = -1; } else if (cl >= C) { cl -= C; dr = 1; }
-      cin = cl >= 1 && cl <= C - 2;
-      pc = cl < C ? phys_col(P, cl) : -1;                            // (a region wider than the map: columns past the wrap are unused)
+      flags = ((cl >= 1 && cl <= C - 2) ? 0 : 0x40000000) | (cl < C ? 0 : (int)0x80000000);      // (a region wider than the map: columns past the wrap are unused)
+      pc = cl < C ? phys_col(P, cl) : 0;
     };
-    int ldr, lpc; bool lcin;
-    col_terms(tc, ldr, lpc, lcin);
-    const int icl = tc - 3 - d;                                      // interior column of the lane's region column
+    int ldr, lpc, lfl;
+    col_terms(tc, ldr, lpc, lfl);
     const int* ltab = rtab + 1 + ldr;                                // the lane's view of the row table
     for (int rb = 0, eb = 0; rb < RH || eb < etotal; rb += PT_WAVES * JB, eb += PT_THREADS * EU) {
-      // per unit: LDS slot (-1: none), interior slot of the validity tile (-1: none), inside flag, the three dwords of the cell
-      // (cells that are not in the map / strip load cell 0 and are masked afterwards: no divergent branch around the loads)
-      float fv[JB + EU]; float2 fu[JB + EU]; int ol[JB + EU], os[JB + EU]; bool okk[JB + EU], ins[JB + EU];
+      float fv[JB + EU]; float2 fu[JB + EU]; int ol[JB + EU], tq[JB + EU];       // per unit: the cell's three dwords, LDS slot (-1: none), flags
 #pragma unroll
       for (int u = 0; u < JB; ++u) {
         const int r = rb + wv + PT_WAVES * u;                       // scalar
         ol[u] = -1;
         if (r < RH) {
           const int T = ltab[r];
-          okk[u] = T >= 0 && lpc >= 0;
-          ins[u] = lcin && !(T & 0x40000000);
-          ol[u] = r * rp + tc;
-          const int ir = r - 3 - d;
-          os[u] = (okk[u] && ir >= 0 && ir < PT_R && icl >= 0 && icl < PT_C) ? ir * PT_C + icl : -1;
-          const float* cp = reinterpret_cast<const float*>(&cells[okk[u] ? (T & 0x3fffffff) + lpc : 0]);
+          tq[u] = T | lfl;
+          ol[u] = (r * rp + tc) * 3;
+          const float* cp = reinterpret_cast<const float*>(&cells[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)lpc)]);
           fv[u] = cp[2];                                                       // Cell: h v valid trav | time upper is_upper pad
           fu[u] = *reinterpret_cast<const float2*>(cp + 5);
         }
@@ -643,26 +640,26 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
         if (ebase < etotal) {
           const int e = min(ebase + tc, etotal - 1);                // (the spare lanes of the last wave repeat its last element)
           const int r = (int)__umulhi((unsigned int)e, S.emagic), cc = 64 + e - r * EC;
-          int dr, pc; bool cin;
-          col_terms(cc, dr, pc, cin);
+          int dr, pc, fl;
+          col_terms(cc, dr, pc, fl);
           const int T = rtab[r + 1 + dr];
-          okk[u] = T >= 0 && pc >= 0;
-          ins[u] = cin && !(T & 0x40000000);
-          ol[u] = r * rp + cc;
-          const int ir = r - 3 - d, ic = cc - 3 - d;
-          os[u] = (okk[u] && ir >= 0 && ir < PT_R && ic >= 0 && ic < PT_C) ? ir * PT_C + ic : -1;
-          const float* cp = reinterpret_cast<const float*>(&cells[okk[u] ? (T & 0x3fffffff) + pc : 0]);
+          tq[u] = T | fl;
+          ol[u] = (r * rp + cc) * 3;
+          const float* cp = reinterpret_cast<const float*>(&cells[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)pc)]);
           fv[u] = cp[2];
           fu[u] = *reinterpret_cast<const float2*>(cp + 5);
         }
       }
 #pragma unroll
       for (int u = 0; u < JB + EU; ++u) {
-        if (ol[u] < 0) continue;                                    // uniform
+        if (u < JB ? rb + wv + PT_WAVES * u >= RH : eb + (u - JB) * PT_THREADS + wv * 64 >= etotal) continue;     // scalar: the unit was not loaded
+        const bool ok = tq[u] >= 0, inside = (tq[u] & 0x40000000) == 0;
         const float m = fv[u] + fu[u].y;
-        rval[ol[u]] = okk[u] ? fu[u].x : 0.f;
-        rmsk[ol[u]] = okk[u] ? (ins[u] ? m : -m - 1.f) : -1.f;
-        if (os[u] >= 0) sval[os[u]] = fv[u];
+        float3 o;
+        o.x = ok ? fu[u].x : 0.f;
+        o.y = ok ? (inside ? m : -m - 1.f) : -1.f;
+        o.z = ok ? fv[u] : 0.f;
+        *reinterpret_cast<float3*>(reg + ol[u]) = o;
       }
     }
   }
@@ -676,7 +673,7 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   __syncthreads();
   for (int r = wv; r < DH; r += PT_WAVES)
     for (int cc = tc; cc < DW; cc += 64) {
-      const float mraw = rmsk[(r + d) * rp + (cc + d)];
+      const float mraw = reg[((r + d) * rp + (cc + d)) * 3 + 1];
       const float own = mraw < 0.f ? -mraw - 1.f : mraw;
       if (own < 0.5f) holes[atomicAdd(&n_holes, 1u)] = (unsigned short)(r * DW + cc);
     }
@@ -691,7 +688,7 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
       const int dy0 = max(-d, s2 - d), dy1 = min(d, s2 + d);
       for (int dy = dy0; dy <= dy1; ++dy) {
         const int o = o0 + dy * rp + (s2 - dy);
-        if (rmsk[o] > 0.5f) { rval[o0] = rval[o]; found = true; break; }     // a hole's slot is never read by another search (its mask is < 0.5)
+        if (reg[o * 3 + 1] > 0.5f) { reg[o0 * 3] = reg[o * 3]; found = true; break; }     // a hole's slot is never read by another search (its mask is < 0.5)
       }
     }
   }
@@ -699,7 +696,7 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   const int col = tile_c + tc;                   // logical column
   if (col >= C) return;
   const int pcol = phys_col(P, col);
-  const float* dil = rval + d * rp + d;          // dilated plane of the DW x DH region, pitch rp
+  const float* dil = reg + (d * rp + d) * 3;     // dilated plane of the DW x DH region: element (row, column) at (row * dp + column) * 3
   const int dp = rp;
   // Every wave owns PT_R / 8 consecutive tile rows of its column.  The four channels of a dilated 3x3 filter go through packed
   // fp32 FMAs in PAIRS (v_pk_fma_f32: the two channels' weights are one aligned scalar register pair, the tap is broadcast): each
@@ -713,8 +710,8 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   for (int k = 0; k < RPW; ++k) {
     const int tr = wv * RPW + k, gr = tile_r + tr;                 // scalar
     if (tr >= PT_R || gr >= seg_e) break;
-    const float* t0 = &dil[(tr + 3) * dp + (tc + 3)];
-    const long c = (long)(rtab[tr + 4 + d] & 0x3fffffff) + pcol;
+    const float* t0 = &dil[((tr + 3) * dp + (tc + 3)) * 3];
+    const long c = (long)(rtab[tr + 4 + d] & 0xffffff) * C + pcol;
     const float h = t0[0];
     trav_in[c] = h;
     if (STAGE == 1) continue;
@@ -728,7 +725,7 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
         for (int a2 = 0; a2 < 3; ++a2)
 #pragma unroll
           for (int b2 = 0; b2 < 3; ++b2) {
-            const float t = t0[(a2 - 1) * dl * dp + (b2 - 1) * dl];
+            const float t = t0[((a2 - 1) * dl * dp + (b2 - 1) * dl) * 3];
             const v2f tt = {t, t};
             const float* w = Wt.w[q][a2 * 3 + b2];
             s01 = __builtin_elementwise_fma((v2f){w[0], w[1]}, tt, s01);
@@ -742,8 +739,8 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
       cells[c].trav = exp_neg(acc);
     }
     float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (col_n && gr >= 1 && gr <= C - 3 && sval[tr * PT_C + tc] > 0.5f) {
-      const float dzdx = t0[1] - h, dzdy = t0[dp] - h;
+    if (col_n && gr >= 1 && gr <= C - 3 && t0[2] > 0.5f) {                // (is_valid of the cell itself)
+      const float dzdx = t0[3] - h, dzdy = t0[3 * dp] - h;
       const float ax = -div_by(dzdy, P.res_f, P.inv_res_f), ay = -div_by(dzdx, P.res_f, P.inv_res_f);
       const float x = (ax * ax) + (ay * ay) + 1.0f;                    // >= 1
       const float s0 = __builtin_amdgcn_sqrtf(x), r0 = __builtin_amdgcn_rcpf(s0);
@@ -964,8 +961,8 @@ void launch_overlap(hipStream_t s, const KP& P, Cell* cells, int cmin, int cmax,
   if (w <= 0) return;
   hipLaunchKernelGGL(k_overlap, dim3(nblk(w * w)), dim3(EM_BLOCK), 0, s, P, cells, cmin, cmax, hmin, hmax);
 }
-static size_t post_lds_bytes(int R, int d) {      // raw (value, mask) region, validity of the interior, row table, hole list
-  return sizeof(float) * ((size_t)2 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)R * PT_C + (size_t)(R + 6 + 2 * d + 4)) + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;
+static size_t post_lds_bytes(int R, int d) {      // (value, mask, valid) region, row table, hole list
+  return sizeof(float) * ((size_t)3 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)(R + 6 + 2 * d + 4)) + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;
 }
 int post_tile_rows(const KP& P) {
   static const int force_r = []() { const char* e = getenv("EMAP_POST_R"); int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32) ? v : 0; }();
