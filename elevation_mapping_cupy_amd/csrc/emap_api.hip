@@ -259,6 +259,7 @@ static int build_ray_tables(emap_ctx* ctx) {
         if (got != full[b]) same = false;
       }
       rt.formula_ok = same ? 1 : 0;
+      ctx->kp.idx_formula = rt.formula_ok;       // the point passes index with the same formula (geometry())
       if (const char* e = getenv("EMAP_RAY_IDX")) { if (atoi(e) != 2) rt.formula_ok = 0; }     // test / tuning hook: force the table path
     }
     int lo = 0x7c00, hi = 1;

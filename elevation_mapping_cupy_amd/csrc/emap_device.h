@@ -60,7 +60,7 @@ struct FrameDev {                  // per-frame scalars that stay on the device 
 struct Moves { int n, pad_; int org_r[EM_MAX_MOVES], org_c[EM_MAX_MOVES], sr[EM_MAX_MOVES], sc[EM_MAX_MOVES]; float dz[EM_MAX_MOVES]; };
 
 struct KP {
-  int C, mode, row0, nrows, halo, edge, dil, pad0;
+  int C, mode, row0, nrows, halo, edge, dil, idx_formula;   // idx_formula: reference_fp16 cell index by the float formula (host-proven exact, build_ray_tables)
   // circular origin: logical cell (r, c) lives at physical row (r + org_r) mod C, column (c + org_c) mod C; row0 / nrows / halo
   // describe PHYSICAL rows (a strip keeps its rows when the map shifts).  norg_*: origin the stencil outputs (normal planes,
   // traversability_input) were written with -- the reference does not shift those (elevation_mapping.py:200-214).
@@ -98,6 +98,10 @@ __device__ __forceinline__ int sat_int(double v) {   // CUDA-style saturating co
 // (the reference always passes center 0: elevation_mapping.py:337-338,359-360).
 template <int MODE> __device__ __forceinline__ int axis_idx(const KP& P, float xq) {
   if constexpr (MODE == 0) {           // reference_fp16: the reference's own arithmetic (bit-exact indices)
+    if (P.idx_formula) {               // (uniform) ... or the float formula the host proved equal to it for every half value: no fp64 division
+      const float f = __builtin_floorf(__builtin_fmaf(xq, P.inv_res_f, P.hw_frac_f)) + P.hw_int_f;
+      return (int)__builtin_amdgcn_fmed3f(f, 0.0f, P.cm1_f);
+    }
     int i = sat_int((double)xq / P.res + P.half_w);
     float fi = Qf<MODE>((float)i);
     float r = fmaxf(fminf(fi, P.q_wm1), 0.0f);
