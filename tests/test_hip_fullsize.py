@@ -77,3 +77,34 @@ def test_point_order_does_not_matter_full_size(rays, weights):
         outs.append(m[[0, 1, 2, 4, 6]].tobytes())
         hip.close()
     assert outs[0] == outs[1]
+
+
+def test_ray_bitmap_in_lds_and_in_global_memory_agree(weights, tmp_path):
+    """k_rays stages the inert bitmap in LDS when it fits (1024^2: 128 KB); EMAP_RAY_LMAP=0 keeps it in global memory (the path of
+    larger maps).  Same frame, two processes (the switch is read once per process): identical maps, bit for bit."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import _fixtures as fx\n"
+        "from _util import make_pair\n"
+        "from oracle import emap_oracle as eo\n"
+        "w = np.load(%r); w = {k: w[k] for k in ('w1', 'w2', 'w3', 'w_out')}\n"
+        "hip, _ = make_pair(eo.YAML, 1024, 'reference_fp16', w)\n"
+        "R, t = fx.POSES['rotated']\n"
+        "for f in range(2):\n"
+        "    hip.update_map_with_kernel(fx.cloud(1024, 400000, 7 + f, dz=-0.1 * f), [], R, t.copy(), 0.0, 0.0)\n"
+        "    hip.update_time()\n"
+        "print(hashlib.sha1(hip.elevation_map.tobytes() + hip.normal_map.tobytes()).hexdigest())\n"
+    ) % (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden", "weights.npz"))
+    digests = []
+    for lmap in ("1", "0"):
+        env = dict(os.environ, EMAP_RAY_LMAP=lmap)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(out.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1]
