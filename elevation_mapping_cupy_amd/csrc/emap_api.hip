@@ -27,7 +27,7 @@ void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, c
 void launch_commit(hipStream_t, const KP&, Cell*, const AccF*, const FrameDev*, unsigned long long*);
 void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, const Cell*, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*, const unsigned int*, int, const float*, const unsigned int*, const unsigned int*);
 void launch_ray_apply(hipStream_t, const KP&, Cell*, AccR*, unsigned long long*, const OverlapArgs&);
-void launch_average(hipStream_t, const KP&, Cell*, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*);
+void launch_average(hipStream_t, const KP&, Cell*, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*, const OverlapArgs&);
 static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
 void launch_sem_finalize(hipStream_t, const KP&, const SemSpec&, const unsigned int*, double*, unsigned int*, float*, float*, long);
@@ -714,7 +714,7 @@ int emap_fuse_average(emap_ctx* ctx, const float R[9], const float t[3]) {
   const bool fused = ctx->frame_binned;
   int rc = fuse_impl(ctx, R, t, fused);
   if (rc) return rc;
-  if (!fused) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, false, ctx->cnt_plane); ctx->kp.mv.n = 0; }
+  if (!fused) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, false, ctx->cnt_plane, OverlapArgs{}); ctx->kp.mv.n = 0; }
   ctx->committed = false;
   CK(hipGetLastError());
   return EMAP_OK;
@@ -750,7 +750,7 @@ int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
 int emap_average(emap_ctx* ctx) {
   CKARG(ctx, "null ctx");
   CK(hipSetDevice(ctx->device));
-  launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, true, ctx->cnt_plane);
+  launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, true, ctx->cnt_plane, OverlapArgs{});
   ctx->committed = false; ctx->kp.mv.n = 0;       // (uncommitted: k_average wrote the pending map shifts out itself)
   CK(hipGetLastError());
   return EMAP_OK;
@@ -861,7 +861,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   const bool fused_avg = ctx->frame_binned;
   const bool rays_on = p.enable_visibility_cleanup != 0;
   // clear_overlap_map rides on the kernel that rewrites the cells last (tile kernel, or k_ray_apply after a visibility pass)
-  ctx->ov_args = overlap_args(ctx, t[2], p.enable_overlap_clearance && fused_avg);
+  ctx->ov_args = overlap_args(ctx, t[2], p.enable_overlap_clearance != 0);
   const bool ov_folded = ctx->ov_args.on != 0;
   rc = fuse_impl(ctx, R, t, fused_avg, rays_on);
   const OverlapArgs ov = ctx->ov_args; ctx->ov_args.on = 0;
@@ -875,7 +875,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
     if (rc) { ctx->rays_fused = false; return rc; }
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
-  if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane); ctx->kp.mv.n = 0; }
+  if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane, ov); ctx->kp.mv.n = 0; }
   else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
@@ -1499,7 +1499,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   const bool fused_avg = ctx->frame_binned;
   const bool rays_on = p.enable_visibility_cleanup != 0;
   // clear_overlap_map rides on the kernel that rewrites the cells last (tile kernel, or k_ray_apply after a visibility pass)
-  ctx->ov_args = overlap_args(ctx, t[2], p.enable_overlap_clearance && fused_avg);
+  ctx->ov_args = overlap_args(ctx, t[2], p.enable_overlap_clearance != 0);
   const bool ov_folded = ctx->ov_args.on != 0;
   rc = fuse_impl(ctx, R, t, fused_avg, rays_on);
   const OverlapArgs ov = ctx->ov_args; ctx->ov_args.on = 0;
@@ -1514,7 +1514,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
     if (rc) { ctx->rays_fused = false; return rc; }
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
-  if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane); ctx->kp.mv.n = 0; }
+  if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane, ov); ctx->kp.mv.n = 0; }
   else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());

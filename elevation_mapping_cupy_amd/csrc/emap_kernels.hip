@@ -468,7 +468,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
 template <bool COMMITTED, bool RAYS>
 __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cell* __restrict__ cells, AccF* __restrict__ acc,
                                                        AccR* __restrict__ accr, const FrameDev* __restrict__ F,
-                                                       unsigned int* __restrict__ cnt_out) {
+                                                       unsigned int* __restrict__ cnt_out, OverlapArgs O) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
   long c = li + (long)P.halo * P.C;
@@ -486,6 +486,10 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cell* __restrict__ c
   }
   if (cnt_out) cnt_out[c] = (unsigned int)(a.cnt_out & 0xffffffffull);   // survives for the semantic fusion (new_elmap plane 2)
   average_cell(P, m, a);
+  if (O.on) {                                       // clear_overlap_map (:372-375) rides on this rewrite (whole frames; staged API: k_overlap)
+    const int lrow = (int)(li / P.C);
+    if (overlap_window(O, logi_row(P, P.row0 + lrow), logi_col(P, (int)(li - (long)lrow * P.C)))) overlap_cell(P, O, m);
+  }
   cells[c] = m;
   if (a.pts_inl | a.cnt_out) { AccF z = {0ull, 0ull, 0ll, 0ll, 0ull}; acc[c] = z; }
 }
@@ -946,14 +950,14 @@ void launch_rays(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, co
   }
 }
 void launch_average(hipStream_t s, const KP& P, Cell* cells, AccF* acc, AccR* accr, const FrameDev* F, bool committed, bool rays,
-                    unsigned int* cnt_out) {
+                    unsigned int* cnt_out, const OverlapArgs& O) {
   dim3 g(nblk((long)P.nrows * P.C)), b(EM_BLOCK);
   if (committed) {
-    if (rays) hipLaunchKernelGGL((k_average<true, true>), g, b, 0, s, P, cells, acc, accr, F, cnt_out);
-    else hipLaunchKernelGGL((k_average<true, false>), g, b, 0, s, P, cells, acc, accr, F, cnt_out);
+    if (rays) hipLaunchKernelGGL((k_average<true, true>), g, b, 0, s, P, cells, acc, accr, F, cnt_out, O);
+    else hipLaunchKernelGGL((k_average<true, false>), g, b, 0, s, P, cells, acc, accr, F, cnt_out, O);
   } else {
-    if (rays) hipLaunchKernelGGL((k_average<false, true>), g, b, 0, s, P, cells, acc, accr, F, cnt_out);
-    else hipLaunchKernelGGL((k_average<false, false>), g, b, 0, s, P, cells, acc, accr, F, cnt_out);
+    if (rays) hipLaunchKernelGGL((k_average<false, true>), g, b, 0, s, P, cells, acc, accr, F, cnt_out, O);
+    else hipLaunchKernelGGL((k_average<false, false>), g, b, 0, s, P, cells, acc, accr, F, cnt_out, O);
   }
 }
 void launch_overlap(hipStream_t s, const KP& P, Cell* cells, int cmin, int cmax, float hmin, float hmax) {
