@@ -783,6 +783,9 @@ static void post_rows(emap_ctx* ctx, int nj, const int* j0, const int* j1, int s
   const int C = ctx->prm.cell_n;
   const int ls = ((ctx->strip.row_begin - ctx->kp.org_r) % C + C) % C;
   int sb[4], se[4], n = 0;
+  if (ctx->strip.row_count == C && nj == 1 && j0[0] == 0 && j1[0] == C) {      // the whole map: one interval, tiles aligned to logical row 0
+    sb[0] = 0; se[0] = C; n = 1; nj = 0;
+  }
   for (int k = 0; k < nj; ++k) {
     if (j1[k] <= j0[k]) continue;
     const int b = ls + j0[k], e = ls + j1[k];                             // unwrapped logical rows
