@@ -546,7 +546,7 @@ struct TravW { float w[3][9][4]; float wo[3][4]; };   // weights of the traversa
 // ---------------------------------------------------------------------------------------------------------
 #define PT_C 64
 #ifndef POST_T32
-#define POST_T32 512
+#define POST_T32 512   /* threads of a 32-row stencil tile: 8 waves, four output rows per thread, two workgroups per CU */
 #endif
 // PT_R = tile height: 16 for large maps (less halo amplification), 4 for small maps (4x more workgroups: a robot-scale
 // 200^2 map has only 52 tiles of 16 rows and the kernel time is then one workgroup's latency chain).
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   int seg_b = S.b[0], seg_e = S.e[0], ty = blockIdx.y;
 #pragma unroll
   for (int k = 1; k < 4; ++k) if (k < S.n && (int)blockIdx.y >= S.t0[k]) { seg_b = S.b[k]; seg_e = S.e[k]; ty = blockIdx.y - S.t0[k]; }
-  constexpr int PT_THREADS = PT_R >= 32 ? POST_T32 : 512, PT_WAVES = PT_THREADS / 64;     // 32-row tiles: 16 waves, two output rows per thread
+  constexpr int PT_THREADS = PT_R >= 32 ? POST_T32 : 512, PT_WAVES = PT_THREADS / 64;     // (POST_T32: compile-time knob of the A/B builds -- 256 and 1024 threads were measured slower)
   extern __shared__ float lds[];
   const int RW = PT_C + 6 + 2 * d, rp = RW + 1, RH = PT_R + 6 + 2 * d;     // staged region: tile + halo 3 + d
   const int DW = PT_C + 6, DH = PT_R + 6;                                   // region whose DILATED value is needed (halo 3)
