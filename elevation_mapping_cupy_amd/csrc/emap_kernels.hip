@@ -902,18 +902,24 @@ template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(h
                                                                               long n, int stride, const Cell* cells, AccR* accr,
                                                                               const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert,
                                                                               const unsigned int* inl, int inl_stride, const float* thr, const unsigned int* order, const unsigned int* n_sorted) {
-  const size_t lds = (IDX == 1 ? (((size_t)(Rt.hi - Rt.lo) + 2 + 3) & ~(size_t)3) * 4 : 0) + (size_t)(((Rt.nS + 3) & ~3) + 8) * 4 + (size_t)(RAY_BLOCK / 64) * 3 * 128 * 4;
+  constexpr int SMALL_BLOCK = 256;
+  // Small clouds (robot scale: 50 k rays = 49 workgroups of 1024) leave most of the 256 CUs idle while every wave walks its ~350
+  // dependent steps: 256-thread workgroups spread the same waves over four times as many CUs, one wave per SIMD.
+  const bool small = n < (long)128 * RAY_BLOCK;
+  const int block = small ? SMALL_BLOCK : RAY_BLOCK;
+  const size_t lds = (IDX == 1 ? (((size_t)(Rt.hi - Rt.lo) + 2 + 3) & ~(size_t)3) * 4 : 0) + (size_t)(((Rt.nS + 3) & ~3) + 8) * 4 + (size_t)(block / 64) * 3 * 128 * 4;
   size_t map_bytes = ((size_t)P.nrows * ((P.C + 63) / 64) * 2 + 2) * 4;       // bitmap + the all-ones word ...
   { size_t al = 4; while (al < (size_t)((P.C + 63) / 64) * 8) al <<= 1; map_bytes += al; }      // ... + alignment to the row pitch
   static const bool lmap_off = getenv("EMAP_RAY_LMAP") && atoi(getenv("EMAP_RAY_LMAP")) == 0;     // tuning / test hook
-  const bool lmap = !lmap_off && lds + map_bytes <= 158 * 1024 && n >= 65536;        // (small clouds: staging 128 KB per workgroup would dominate)
-  dim3 g((unsigned int)((n + RAY_BLOCK - 1) / RAY_BLOCK)), b(RAY_BLOCK);
+  const bool lmap = !lmap_off && !small && lds + map_bytes <= 158 * 1024;             // (small clouds: staging the bitmap per workgroup would dominate)
+  dim3 g((unsigned int)((n + block - 1) / block)), b(block);
   auto go = [&](auto kern, bool& raised, size_t bytes) {    // per instantiation: the half -> index table + queues [+ bitmap] can exceed the default 64 KB window
     if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; }
     hipLaunchKernelGGL(kern, g, b, bytes, s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
   };
-  static bool raised0 = false, raised1 = false;
-  if (lmap) go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, true>, raised1, lds + map_bytes);
+  static bool raised0 = false, raised1 = false, raised2 = false;
+  if (small) go(k_rays<MODE, STATS, IDX, STRIP, SMALL_BLOCK, false>, raised2, lds);
+  else if (lmap) go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, true>, raised1, lds + map_bytes);
   else go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, false>, raised0, lds);
 }
 template <int MODE, bool STATS> static void launch_rays_t(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
