@@ -193,7 +193,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // range predicate, one bitmap bit; everything else happens only for the few cells that are neither known-and-fresh nor out.
 // (launch bounds: 8 waves per SIMD, i.e. two 1024-thread workgroups per CU -- measured: with 82 instead of 70 SGPRs the kernel
 // silently dropped to one workgroup per CU and ran 13 % slower)
-template <int MODE, bool STATS, int IDX, bool STRIP, int BLOCK, bool LMAP>
+template <int MODE, bool STATS, int IDX, bool STRIP, int BLOCK, bool LMAP, int LPR>
 #ifndef RAY_OCC
 #define RAY_OCC 8
 #endif
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
   extern __shared__ unsigned int slut32[];
   const unsigned int span = IDX == 1 ? (unsigned int)(Rt.hi - Rt.lo) + 2u : 0u;
   float* sS = reinterpret_cast<float*>(slut32 + ((span + 3u) & ~3u));      // step table s_k in LDS (16-byte aligned, padded by 8 x +inf: the march reads float4)
-  const int nS = Rt.nS, nSp = ((nS + 3) & ~3) + 8;
+  const int nS = Rt.nS, nSp = ((nS + 3) & ~3) + 8 * LPR;
   if (IDX == 1) {
     const unsigned int* src = reinterpret_cast<const unsigned int*>(Rt.lut);   // 2 signs * span u16 = span u32
     for (unsigned int k = threadIdx.x; k < span; k += BLOCK) slut32[k] = src[k];
@@ -241,7 +241,12 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
   // already there: `order` = the sorted 16-byte records (word 3: point index; valid points outside the owned cells sit in a last
   // bin), *n_sorted their number -- a wave then marches 64 rays into the same 16 x 64 cell tile: equal lengths, neighbouring
   // bitmap words.  The effects are order-independent accumulator updates: results are unchanged.
-  long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+  // LPR lanes per ray (small clouds): lane `sub` of a ray marches the samples K = LPR * k + sub -- the march is a chain of ~350
+  // dependent steps per wave, which is pure latency when the cloud cannot fill the chip; four lanes per ray cut the chain to a quarter
+  // (each lane computes the cell of sample K - 1 itself for the new-cell test).
+  const long gi = (long)blockIdx.x * BLOCK + threadIdx.x;
+  const int sub = LPR > 1 ? (int)(gi % LPR) : 0;
+  long i = gi / LPR;
   bool have = i < n;
   if (order) { have = have && i < (long)*n_sorted; if (have) i = (long)order[i * 4 + 3]; }
   const int C = P.C;
@@ -411,10 +416,23 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     if (ke <= 0) { int ix0, iy0; rx = 0.f; ry = 0.f; last_xy = cell_xy(txy, ix0, iy0); }
   }
   const v2f rxy_m = {rx, ry};
-  int kg = STRIP ? (wb & ~(2 * GU - 1)) : 0;                    // first step of the current group (multiple of 8: the step table is read as float4)
+  int kg = STRIP ? ((wb / LPR) & ~(2 * GU - 1)) : 0;            // first (lane) step of the current group (multiple of 8: the step table is read as float4)
+  const int we_l = (we + LPR - 1) / LPR;                         // lane steps: lane `sub` of a ray marches the samples LPR * k + sub
   auto step = [&](int k, float sk, unsigned int& w, unsigned int& xy_out, float& s_out) {
     float s = sk;
-    if (!STRIP) asm("v_min_f32 %0, %1, %2" : "=v"(s) : "v"(sk), "v"(s_end));
+    unsigned int prev_xy = last_xy;                             // the cell of the previous sample
+    int K = k;                                                  // the sample index
+    if constexpr (LPR > 1) {                                    // several lanes per ray: own sample and its predecessor from the table, per lane
+      K = LPR * k + sub;
+      const int Kc = min(K, nSp - 1);
+      s = sS[Kc];
+      float sp = sS[max(Kc - 1, 0)];
+      if (!STRIP) { asm("v_min_f32 %0, %1, %2" : "=v"(s) : "v"(s), "v"(s_end)); asm("v_min_f32 %0, %1, %2" : "=v"(sp) : "v"(sp), "v"(s_end)); }
+      int ixp, iyp;
+      const unsigned int xyp = cell_xy(txy + rxy_m * sp, ixp, iyp);
+      if (!STRIP) prev_xy = K == 0 ? last_xy : xyp;             // (last_xy keeps its initial value here: none, or the sensor's cell for a lane without a ray)
+      else prev_xy = ((unsigned int)(K - 1 - kb) < (unsigned int)(ke - kb)) ? xyp : 0xffffffffu;
+    } else if (!STRIP) asm("v_min_f32 %0, %1, %2" : "=v"(s) : "v"(sk), "v"(s_end));
     int ixs, iys;
     const unsigned int xy = cell_xy(txy + rxy_m * s, ixs, iys);           // x, y of the sample (its height is only needed for queued visits)
     const unsigned int ix = (unsigned int)ixs, iy = (unsigned int)iys;
@@ -422,13 +440,13 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     bool act;
     unsigned int brow = ix;                                     // bitmap row: the logical row ...
     if (STRIP) {
-      const bool mine = (unsigned int)(k - kb) < (unsigned int)(ke - kb);
+      const bool mine = (unsigned int)(K - kb) < (unsigned int)(ke - kb);
       brow = (unsigned int)(phys_row(P, (int)ix) - P.row0);     // ... or, on strips, the local physical row (also the ownership test)
-      act = mine & (xy != last_xy) & (brow < (unsigned int)P.nrows);
-      last_xy = mine ? xy : last_xy;
+      act = mine & (xy != prev_xy) & (brow < (unsigned int)P.nrows);
+      if (LPR == 1) last_xy = mine ? xy : last_xy;
     } else {
-      act = xy != last_xy;
-      last_xy = xy;
+      act = xy != prev_xy;
+      if (LPR == 1) last_xy = xy;
     }
     if (STATS) visits += (act && max(ix - 1u, iy - 1u) < (unsigned int)(C - 2)) ? 1u : 0u;
     unsigned int colpart;                                       // ((iy >> 3) & ~3) | LDS base: byte offset of the word within its row
@@ -442,7 +460,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
   Group gA, gB;
 #pragma unroll
   for (int u = 0; u < GU; ++u) { gA.w[u] = ~0u; gA.xy[u] = 0u; gA.s[u] = 0.f; gB.w[u] = ~0u; gB.xy[u] = 0u; gB.s[u] = 0.f; }
-  for (; kg < we; kg += 2 * GU) {                               // (steps past a lane's range request nothing; the table is padded by 8 entries)
+  for (; kg < we_l; kg += 2 * GU) {                             // (steps past a lane's range request nothing; the table is padded by 8 entries)
     const float4 s0 = *reinterpret_cast<const float4*>(sS + kg), s1 = *reinterpret_cast<const float4*>(sS + kg + GU);   // wave-uniform reads
     step(kg + 0, s0.x, gA.w[0], gA.xy[0], gA.s[0]); step(kg + 1, s0.y, gA.w[1], gA.xy[1], gA.s[1]);
     step(kg + 2, s0.z, gA.w[2], gA.xy[2], gA.s[2]); step(kg + 3, s0.w, gA.w[3], gA.xy[3], gA.s[3]);
@@ -902,25 +920,26 @@ template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(h
                                                                               long n, int stride, const Cell* cells, AccR* accr,
                                                                               const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert,
                                                                               const unsigned int* inl, int inl_stride, const float* thr, const unsigned int* order, const unsigned int* n_sorted) {
-  constexpr int SMALL_BLOCK = 256;
+  constexpr int SMALL_BLOCK = 256, SMALL_LPR = 4;
   // Small clouds (robot scale: 50 k rays = 49 workgroups of 1024) leave most of the 256 CUs idle while every wave walks its ~350
   // dependent steps: 256-thread workgroups spread the same waves over four times as many CUs, one wave per SIMD.
   const bool small = n < (long)128 * RAY_BLOCK;
   const int block = small ? SMALL_BLOCK : RAY_BLOCK;
-  const size_t lds = (IDX == 1 ? (((size_t)(Rt.hi - Rt.lo) + 2 + 3) & ~(size_t)3) * 4 : 0) + (size_t)(((Rt.nS + 3) & ~3) + 8) * 4 + (size_t)(block / 64) * 3 * 128 * 4;
+  const int lpr = small ? SMALL_LPR : 1;
+  const size_t lds = (IDX == 1 ? (((size_t)(Rt.hi - Rt.lo) + 2 + 3) & ~(size_t)3) * 4 : 0) + (size_t)(((Rt.nS + 3) & ~3) + 8 * lpr) * 4 + (size_t)(block / 64) * 3 * 128 * 4;
   size_t map_bytes = ((size_t)P.nrows * ((P.C + 63) / 64) * 2 + 2) * 4;       // bitmap + the all-ones word ...
   { size_t al = 4; while (al < (size_t)((P.C + 63) / 64) * 8) al <<= 1; map_bytes += al; }      // ... + alignment to the row pitch
   static const bool lmap_off = getenv("EMAP_RAY_LMAP") && atoi(getenv("EMAP_RAY_LMAP")) == 0;     // tuning / test hook
   const bool lmap = !lmap_off && !small && lds + map_bytes <= 158 * 1024;             // (small clouds: staging the bitmap per workgroup would dominate)
-  dim3 g((unsigned int)((n + block - 1) / block)), b(block);
+  dim3 g((unsigned int)((n * lpr + block - 1) / block)), b(block);
   auto go = [&](auto kern, bool& raised, size_t bytes) {    // per instantiation: the half -> index table + queues [+ bitmap] can exceed the default 64 KB window
     if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; }
     hipLaunchKernelGGL(kern, g, b, bytes, s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
   };
   static bool raised0 = false, raised1 = false, raised2 = false;
-  if (small) go(k_rays<MODE, STATS, IDX, STRIP, SMALL_BLOCK, false>, raised2, lds);
-  else if (lmap) go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, true>, raised1, lds + map_bytes);
-  else go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, false>, raised0, lds);
+  if (small) go(k_rays<MODE, STATS, IDX, STRIP, SMALL_BLOCK, false, SMALL_LPR>, raised2, lds);
+  else if (lmap) go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, true, 1>, raised1, lds + map_bytes);
+  else go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, false, 1>, raised0, lds);
 }
 template <int MODE, bool STATS> static void launch_rays_t(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
                                                           long n, int stride, const Cell* cells, AccR* accr,
