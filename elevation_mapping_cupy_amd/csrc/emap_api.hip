@@ -21,36 +21,36 @@
 #include <vector>
 
 // launchers (emap_kernels.hip)
-void launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, ErrSlot*);
+void launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, Cells, AccF*, ErrSlot*);
 void launch_gate(hipStream_t, const GateArgs&, ErrSlot*, FrameDev*, int, double*, const double*);
-void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, const Cell*, AccF*, const FrameDev*);
-void launch_commit(hipStream_t, const KP&, Cell*, const AccF*, const FrameDev*, unsigned long long*);
-void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, const Cell*, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*, const unsigned int*, int, const float*, const unsigned int*, const unsigned int*);
-void launch_ray_apply(hipStream_t, const KP&, Cell*, AccR*, unsigned long long*, const OverlapArgs&);
-void launch_average(hipStream_t, const KP&, Cell*, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*, const OverlapArgs&);
+void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, Cells, AccF*, const FrameDev*);
+void launch_commit(hipStream_t, const KP&, Cells, const AccF*, const FrameDev*, unsigned long long*);
+void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, Cells, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*, const unsigned int*, int, const float*, const unsigned int*, const unsigned int*);
+void launch_ray_apply(hipStream_t, const KP&, Cells, AccR*, unsigned long long*, const OverlapArgs&);
+void launch_average(hipStream_t, const KP&, Cells, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*, const OverlapArgs&);
 static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
 void launch_sem_finalize(hipStream_t, const KP&, const SemSpec&, const unsigned int*, double*, unsigned int*, float*, float*, long);
 void launch_polygon_mask(hipStream_t, int, const int*, const int*, int, const int*, float*);
 void launch_dilate_planes(hipStream_t, int, int, const float*, const float*, float*, float*);
 struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; };
-void launch_image_corr(hipStream_t, const KP&, const CamArgs&, const Cell*, float*, unsigned char*);
+void launch_image_corr(hipStream_t, const KP&, const CamArgs&, Cells, float*, unsigned char*);
 void launch_image_fuse(hipStream_t, const KP&, int, float*, const float*, const float*, const unsigned char*, float, float, double);
 void launch_inpaint_sweep(hipStream_t, int, const float*, const float*, float*, float*, const unsigned int*, unsigned int*);
 void launch_min_sweep(hipStream_t, int, int, const float*, const float*, const float*, float*, float*, const unsigned int*, unsigned int*, bool);
 void launch_box3(hipStream_t, int, const float*, float*);
 void launch_erode(hipStream_t, int, int, const float*, float*);
-void launch_overlap(hipStream_t, const KP&, Cell*, int, int, float, float);
-void launch_var_time(hipStream_t, const KP&, Cell*, int, int);
+void launch_overlap(hipStream_t, const KP&, Cells, int, int, float, float);
+void launch_var_time(hipStream_t, const KP&, Cells, int, int);
 int post_tile_rows(const KP&);
-void launch_post(hipStream_t, const KP&, const float*, const float*, const float*, const float*, Cell*, float*, float*, long, int, int, const int*, const int*, int);
-void launch_get_plane(hipStream_t, const KP&, const Cell*, int, float*);
-void launch_publish(hipStream_t, const KP&, const Cell*, const float*, long, int, float, int, float*);
-void launch_set_plane(hipStream_t, const KP&, Cell*, int, const float*);
-void launch_fill_cells(hipStream_t, Cell*, long, const Cell&);
+void launch_post(hipStream_t, const KP&, const float*, const float*, const float*, const float*, Cells, float*, float*, long, int, int, const int*, const int*, int);
+void launch_get_plane(hipStream_t, const KP&, Cells, int, float*);
+void launch_publish(hipStream_t, const KP&, Cells, const float*, long, int, float, int, float*);
+void launch_set_plane(hipStream_t, const KP&, Cells, int, const float*);
+void launch_fill_cells(hipStream_t, Cells, long, const Cell&);
 void launch_point_index(hipStream_t, const KP&, const Pose&, const float*, long, int, int*, unsigned char*);
 void launch_plane_view(hipStream_t, const KP&, int, int, float*, float*, int);
-void launch_materialize(hipStream_t, const KP&, Cell*);
+void launch_materialize(hipStream_t, const KP&, Cells);
 void launch_band_clear(hipStream_t, const KP&, float*, int, long, int, int);
 
 // tile-binned scatter (emap_binned.hip)
@@ -60,10 +60,10 @@ struct BinRec { unsigned int lc_inl; float z, v; unsigned int i; };
 void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, BinTmp*, unsigned int*);
 void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*, unsigned int*);
 void launch_bin_scatter(hipStream_t, const KP&, const BinGeo&, const BinTmp*, long, const unsigned int*, const unsigned int*, BinRec*);
-void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, const Cell*, ErrSlot*);
+void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, ErrSlot*);
 void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const float*, long, int,
                           const unsigned int*, float*, float*, long);
-void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cell*, AccF*, const FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&);
+void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, AccF*, const FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&);
 #define BIN_MAX_T 16384
 #define BIN_MAX_B 2048
 
@@ -115,7 +115,7 @@ struct emap_ctx {
   hipStream_t stream;
   bool own_stream;
   long ncells_alloc;        // (rows + 2*halo) * C
-  Cell* cells;
+  Cells cells;                     // two planes of 16-byte half cells (emap_device.h)
   int torg_r, torg_c;              // origin traversability_input was written with (kp.norg_*: the normal planes)
   AccF* acc; AccR* accr;
   float* trav_in; float* normal;   // normal: 3 planes of ncells_alloc
@@ -365,7 +365,7 @@ int emap_destroy(emap_ctx* ctx) {
   if (!ctx) return EMAP_OK;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
-  hipFree(ctx->cells); hipFree(ctx->acc); hipFree(ctx->accr); hipFree(ctx->trav_in);
+  hipFree(ctx->cells.hot); hipFree(ctx->cells.cold); hipFree(ctx->acc); hipFree(ctx->accr); hipFree(ctx->trav_in);
   hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->plug_buf); hipFree(ctx->plug_cnt); hipFree(ctx->slots); hipFree(ctx->frame);
   for (int k = 0; k < 2; ++k) { hipFree(ctx->pts_dev[k]); if (ctx->pts_pin[k]) hipHostFree(ctx->pts_pin[k]); if (ctx->ev_copied[k]) hipEventDestroy(ctx->ev_copied[k]); if (ctx->ev_used[k]) hipEventDestroy(ctx->ev_used[k]); }
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
@@ -420,7 +420,7 @@ int emap_create(const emap_params* params, const emap_strip* strip, int device, 
   const long n = ctx->ncells_alloc;
   int rc = EMAP_OK;
   auto alloc = [&](void** p, size_t bytes) { if (rc == EMAP_OK && hipMalloc(p, bytes) != hipSuccess) { rc = EMAP_ERR_HIP; fprintf(stderr, "emap_create: hipMalloc(%zu) failed\n", bytes); } };
-  alloc((void**)&ctx->cells, sizeof(Cell) * n); alloc((void**)&ctx->acc, sizeof(AccF) * n); alloc((void**)&ctx->accr, sizeof(AccR) * n);
+  alloc((void**)&ctx->cells.hot, sizeof(float4) * n); alloc((void**)&ctx->cells.cold, sizeof(float4) * n); alloc((void**)&ctx->acc, sizeof(AccF) * n); alloc((void**)&ctx->accr, sizeof(AccR) * n);
   alloc((void**)&ctx->trav_in, sizeof(float) * n); alloc((void**)&ctx->normal, sizeof(float) * 3 * n);
   alloc((void**)&ctx->scratch, sizeof(float) * n); alloc((void**)&ctx->slots, sizeof(ErrSlot) * EM_ERR_SLOTS);
   alloc((void**)&ctx->frame, sizeof(FrameDev));
@@ -1331,8 +1331,9 @@ int emap_halo_pack(emap_ctx* ctx, int side, float* dev_buf) {
   const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
   if (H == 0) return EMAP_OK;
   CKARG(n >= H, "strip thinner than its halo");
-  const Cell* src = ctx->cells + (side == 0 ? H * C : (H + n - H) * C);   // first / last H owned rows
-  CK(hipMemcpyAsync(dev_buf, src, sizeof(Cell) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
+  const long off = side == 0 ? H * C : (H + n - H) * C;                   // first / last H owned rows; buffer = [hot rows][cold rows]
+  CK(hipMemcpyAsync(dev_buf, ctx->cells.hot + off, sizeof(float4) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
+  CK(hipMemcpyAsync(dev_buf + 4 * H * C, ctx->cells.cold + off, sizeof(float4) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
   return EMAP_OK;
 }
 int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf) {
@@ -1340,8 +1341,9 @@ int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf) {
   CK(hipSetDevice(ctx->device));
   const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
   if (H == 0) return EMAP_OK;
-  Cell* dst = ctx->cells + (side == 0 ? 0 : (H + n) * C);
-  CK(hipMemcpyAsync(dst, dev_buf, sizeof(Cell) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
+  const long off = side == 0 ? 0 : (H + n) * C;
+  CK(hipMemcpyAsync(ctx->cells.hot + off, dev_buf, sizeof(float4) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
+  CK(hipMemcpyAsync(ctx->cells.cold + off, dev_buf + 4 * H * C, sizeof(float4) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
   return EMAP_OK;
 }
 
@@ -1462,7 +1464,9 @@ static int ring_exchange(emap_ctx* ctx, char* base, size_t row_bytes, hipStream_
 static int halo_exchange_start(emap_ctx* ctx) {
   CK(hipEventRecord(ctx->ev_ready, ctx->stream));
   CK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_ready, 0));
-  int rc = ring_exchange(ctx, reinterpret_cast<char*>(ctx->cells), sizeof(Cell) * (size_t)ctx->prm.cell_n, ctx->comm_stream);
+  int rc = ring_exchange(ctx, reinterpret_cast<char*>(ctx->cells.hot), sizeof(float4) * (size_t)ctx->prm.cell_n, ctx->comm_stream);      // both half-cell planes
+  if (rc) return rc;
+  rc = ring_exchange(ctx, reinterpret_cast<char*>(ctx->cells.cold), sizeof(float4) * (size_t)ctx->prm.cell_n, ctx->comm_stream);
   if (rc) return rc;
   CK(hipEventRecord(ctx->ev_done, ctx->comm_stream));
   return EMAP_OK;

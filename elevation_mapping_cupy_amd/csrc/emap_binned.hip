@@ -141,7 +141,7 @@ __device__ __forceinline__ bool drift_inlier(const KP& P, const float4 m, float 
 // the tile is tested against its cell there -- the per-point gather of a random 32-byte cell (a whole 128-byte line per point,
 // 144 MB fetched for 48 MB needed, profiles/r01f_pmc_cfg2.json) is gone.  Wave-reduced sums go to the 256 padded slots.
 __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const BinRec* __restrict__ recs,
-                                                          const unsigned int* __restrict__ tile_start, const Cell* __restrict__ cells,
+                                                          const unsigned int* __restrict__ tile_start, Cells cells,
                                                           ErrSlot* __restrict__ slots) {
   constexpr int NC = BIN_TR * BIN_TC;
   __shared__ float4 s_cell[NC];
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const B
   {
     const int tr = threadIdx.x >> 6, tc = threadIdx.x & 63, lrow = row_base + tr, col = tx * BIN_TC + tc;   // 1024 threads = 16 x 64 cells
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lrow < P.nrows && col < P.C) { m = *reinterpret_cast<const float4*>(&cells[(long)(lrow + P.halo) * P.C + col]); cell_now(P, m, P.row0 + lrow, col); }
+    if (lrow < P.nrows && col < P.C) { m = cells.hot[(long)(lrow + P.halo) * P.C + col]; cell_now(P, m, P.row0 + lrow, col); }
     s_cell[threadIdx.x] = m;
   }
   __syncthreads();
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const B
 // by k_ray_apply.  AVG = false keeps the staged contract: AccF records for k_commit / k_rays / k_average.
 template <bool AVG, bool RAYS>
 __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const BinRec* __restrict__ recs,
-                                                         const unsigned int* __restrict__ tile_start, Cell* __restrict__ cells,
+                                                         const unsigned int* __restrict__ tile_start, Cells cells,
                                                          AccF* __restrict__ acc, const FrameDev* __restrict__ F,
                                                          unsigned int* __restrict__ cnt_plane, unsigned long long* __restrict__ inert,
                                                          unsigned int* __restrict__ inl_plane, float* __restrict__ thr, OverlapArgs O) {
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
       s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull;
       const int lrow = row_base + k / BIN_TC, colk = tx * BIN_TC + k % BIN_TC;
       float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lrow < P.nrows && colk < P.C) { m = *reinterpret_cast<const float4*>(&cells[(long)(lrow + P.halo) * P.C + colk]); cell_now(P, m, P.row0 + lrow, colk); }
+      if (lrow < P.nrows && colk < P.C) { m = cells.hot[(long)(lrow + P.halo) * P.C + colk]; cell_now(P, m, P.row0 + lrow, colk); }
       s_cell[k] = m;
     }
     __syncthreads();
@@ -255,8 +255,24 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
         a.sum_h = (long long)s_h[lc]; a.sum_v = (long long)s_v[lc]; a.latest = s_latest[lc];
         const long c = (long)(lrow + P.halo) * P.C + col;
         if (AVG) {
-          Cell m = cells[c];
-          cell_now(P, m, P.row0 + lrow, col);                  // pending map shifts are written out with this rewrite
+          // The hot half of the cell is in LDS already; the cold half (time, upper, is_upper) is READ only where something looks at it --
+          // a cell without points in front of a visibility pass (stale / unknown tests below), a cell of the overlap window -- and
+          // WRITTEN only where it changes: a fused cell (commit overwrites all of it), the overlap window, or the first frame after a
+          // map move (the pending moves are written out with this rewrite: the whole cell then takes the slow way).
+          const bool inwin = !RAYS && overlap_window(O, logi_row(P, P.row0 + lrow), logi_col(P, col));
+          Cell m;
+          bool wcold;
+          if (P.mv.n) {                                        // (uniform)
+            m = cells[c];
+            cell_now(P, m, P.row0 + lrow, col);
+            wcold = true;
+          } else {
+            const float4 hq = s_cell[lc];
+            const bool fused = s_cnt[lc] != 0u;
+            const float4 cq = ((RAYS && !fused) || inwin) ? cells.cold[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            m.h = hq.x; m.v = hq.y; m.valid = hq.z; m.trav = hq.w; m.time = cq.x; m.upper = cq.y; m.is_upper = cq.z; m.pad = 0.f;
+            wcold = fused;
+          }
           m.h += shift;
           commit_cell(P, m, a);
           quiet = (!(m.valid < 0.5f) && m.time < 0.5f) || border_cell(P, logi_row(P, P.row0 + lrow), logi_col(P, col));   // snapshot S1 (what the rays are defined on); border cells: see k_commit
@@ -266,8 +282,9 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
           if (RAYS && !(visit_thr >= -INFINITY)) visit_thr = INFINITY;                          // NaN heights: never filter
           average_cell(P, m, a);
           // clear_overlap_map (:372-375) of a frame WITHOUT a visibility pass rides on this rewrite (with rays: k_ray_apply)
-          if (!RAYS && overlap_window(O, logi_row(P, P.row0 + lrow), logi_col(P, col))) overlap_cell(P, O, m);
-          cells[c] = m;
+          if (inwin) wcold = overlap_cell(P, O, m) || wcold;
+          cells.hot[c] = make_float4(m.h, m.v, m.valid, m.trav);
+          if (wcold) cells.cold[c] = make_float4(m.time, m.upper, m.is_upper, m.valid);
           if (cnt_plane) cnt_plane[c] = s_cnt[lc];
           if (RAYS) inl_plane[c] = s_inl[lc];
         } else acc[c] = a;
@@ -360,13 +377,13 @@ void launch_bin_scatter(hipStream_t s, const KP& P, const BinGeo& G, const BinTm
     default: hipLaunchKernelGGL(k_bin_scatter<256>, dim3(G.B), dim3(256), sh, s, P, G, tmp, n, hist, tile_start, recs);
   }
 }
-void launch_tile_count(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, const Cell* cells,
+void launch_tile_count(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cells cells,
                        ErrSlot* slots) {
   static_assert(TF_BLOCK == BIN_TR * BIN_TC, "one thread per cell of a tile");
   hipLaunchKernelGGL(k_tile_count, dim3(G.T, G.sub), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, slots);
 }
 // fuse_average: commit + average in the tile kernel (whole frames); rays: the visibility pass follows (bitmap + inlier plane wanted)
-void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cell* cells,
+void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cells cells,
                      AccF* acc, const FrameDev* F, bool fuse_average, bool rays, unsigned int* cnt_plane, unsigned long long* inert,
                      unsigned int* inl_plane, float* thr, const OverlapArgs& O) {
   const dim3 g(G.T, G.sub), b(TF_BLOCK);

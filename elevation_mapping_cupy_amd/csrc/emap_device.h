@@ -14,10 +14,32 @@
 
 #define EM_BLOCK 256
 
+// A cell in REGISTERS.  In memory it is two 16-byte halves in two planes (struct Cells): the hot half (h, v, valid, trav) is what the
+// point passes stage per tile and what the drift statistics read; the cold half (time, upper, is_upper, valid') is what the stencil
+// pass reads -- valid' mirrors `valid` so that k_post needs ONE 16-byte load per cell.  A pass then moves only the half it needs
+// (interleaved 32-byte cells cost a whole sector for either half: k_tile_count fetched 32 MB for 16, k_post 46 MB for 17 and
+// wrote 4-byte `trav` fields into 32-byte sectors).
 struct __attribute__((aligned(32))) Cell {
   float h, v, valid, trav, time, upper, is_upper, pad;
 };
-static_assert(sizeof(Cell) == 32, "cell is one 32-byte sector");
+static_assert(sizeof(Cell) == 32, "cell");
+struct CellRef {                       // lets `Cell m = cells[c]` / `cells[c] = m` read as before
+  float4* hp; float4* cp;
+  __device__ __forceinline__ operator Cell() const {
+    const float4 a = *hp, b = *cp;
+    Cell m; m.h = a.x; m.v = a.y; m.valid = a.z; m.trav = a.w; m.time = b.x; m.upper = b.y; m.is_upper = b.z; m.pad = b.w;
+    return m;
+  }
+  __device__ __forceinline__ const CellRef& operator=(const Cell& m) const {
+    *hp = make_float4(m.h, m.v, m.valid, m.trav);
+    *cp = make_float4(m.time, m.upper, m.is_upper, m.valid);          // valid mirrored for the stencil pass
+    return *this;
+  }
+};
+struct Cells {
+  float4* hot; float4* cold;
+  __device__ __forceinline__ CellRef operator[](long i) const { return CellRef{hot + i, cold + i}; }
+};
 
 struct AccF {                      // zero == "nothing happened this frame"
   unsigned long long pts_inl;      // lo32: points per cell (newmap[4]); hi32: drift inliers per cell (newmap[3])

@@ -14,7 +14,7 @@
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(EM_BLOCK) void k_count(KP P, Pose T, const float* __restrict__ pts, long n, int stride,
-                                                     const Cell* __restrict__ cells, AccF* __restrict__ acc,
+                                                     Cells cells, AccF* __restrict__ acc,
                                                      ErrSlot* __restrict__ slots) {
   long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   long long e_fix = 0;
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_count(KP P, Pose T, const float* _
     Owned oc = owned(P, g.ix, g.iy);
     long c = (g.finite && g.valid && g.inside) ? oc.c : -1;
     if (c >= 0) {
-      float4 m = *reinterpret_cast<const float4*>(&cells[c]);   // h, v, valid, trav
+      float4 m = cells.hot[c];   // h, v, valid, trav
       cell_now(P, m, oc.prow, oc.pcol);
       bool inlier = m.z > 0.5f && (double)fabsf(m.x - g.z) < (double)m.y * P.mt && (double)m.y < P.dcvi_half &&
                     (double)m.w > P.trav_inlier;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64) void k_gate(GateArgs A, ErrSlot* __restrict__ s
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(EM_BLOCK) void k_fuse(KP P, Pose T, const float* __restrict__ pts, long n, int stride,
-                                                    const Cell* __restrict__ cells, AccF* __restrict__ acc,
+                                                    Cells cells, AccF* __restrict__ acc,
                                                     const FrameDev* __restrict__ F) {
   long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_fuse(KP P, Pose T, const float* __
   long c = (g.finite && g.valid && g.inside) ? oc.c : -1;
   if (c < 0) return;
   const float shift = F->shift;
-  float4 hv = *reinterpret_cast<const float4*>(&cells[c]);
+  float4 hv = cells.hot[c];
   cell_now(P, hv, oc.prow, oc.pcol);
   float map_h = hv.x + shift, map_v = hv.y;
   const unsigned int n_pts = (unsigned int)(acc[c].pts_inl & 0xffffffffull);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_fuse(KP P, Pose T, const float* __
 // is how k_rays implements `if (!is_inside(nidx)) continue` (:211) without a test of its own.  The bitmap is indexed by LOGICAL
 // column and, on single-strip contexts, logical row (strips: local physical row) -- what the march has at hand (bitmap_row).  Layout: one row of ceil(C / 64) 64-bit words per map row (a 64-column tile segment of a
 // row is exactly one word, so the tile kernel can store a wave ballot); grid: x = 64-column groups, y = rows, one wave per word.
-__global__ __launch_bounds__(64) void k_commit(KP P, Cell* __restrict__ cells, const AccF* __restrict__ acc,
+__global__ __launch_bounds__(64) void k_commit(KP P, Cells cells, const AccF* __restrict__ acc,
                                                const FrameDev* __restrict__ F, unsigned long long* __restrict__ inert) {
   // one wave = 64 LOGICAL columns of one owned physical row (so that its ballot is one aligned word of the logical bitmap)
   const int lrow = blockIdx.y, lcol = blockIdx.x * 64 + threadIdx.x, prow = P.row0 + lrow;
@@ -198,7 +198,7 @@ template <int MODE, bool STATS, int IDX, bool STRIP, int BLOCK, bool LMAP, int L
 #define RAY_OCC 8
 #endif
 __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T, RayTab Rt, const float* __restrict__ pts, long n, int stride,
-                                                 const Cell* __restrict__ cells,
+                                                 Cells cells,
                                                  AccR* __restrict__ accr, const float* __restrict__ normal,
                                                  long plane_stride, FrameDev* __restrict__ F,
                                                  const unsigned long long* __restrict__ inert64,
@@ -333,8 +333,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     const float ddx = egx - nx, ddy = egy - ny, ddz = egz - nz;
     const float d = Qf<MODE>(ddx * ddx + ddy * ddy + ddz * ddz);
     if (d < Rt.f_d_thresh) return;             // (double)d < 0.1: too close to the point (:225-226)
-    const float4* cp = reinterpret_cast<const float4*>(&cells[c]);
-    const float4 m0 = cp[0], m1 = cp[1];       // h v valid trav | time upper is_upper pad
+    const float4 m0 = cells.hot[c], m1 = cells.cold[c];       // h v valid trav | time upper is_upper valid'
     if (m0.z < 0.5f) {                         // unknown cell: upper bound (:228-234)
       if (nz < m1.y || m1.z < 0.5f) ray_upper_min(&accr[c].upper_key, nz);
       return;
@@ -484,7 +483,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
 // Streaming: reads 32+40(+16) B, writes 32 B (+zeroes) per cell.
 // ---------------------------------------------------------------------------------------------------------
 template <bool COMMITTED, bool RAYS>
-__global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cell* __restrict__ cells, AccF* __restrict__ acc,
+__global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cells cells, AccF* __restrict__ acc,
                                                        AccR* __restrict__ accr, const FrameDev* __restrict__ F,
                                                        unsigned int* __restrict__ cnt_out, OverlapArgs O) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
@@ -517,7 +516,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cell* __restrict__ c
 // a 16-byte stream over the ray accumulators with a read-modify-write of the few touched cells: validity decrement + variance
 // inflation (custom_kernels.py:251-252), upper bound (:230-233, :254-255), then average_map_kernel's reset of cells whose
 // validity fell below 0.5 (:380-384); re-arms the accumulators.
-__global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cell* __restrict__ cells, AccR* __restrict__ accr,
+__global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cells cells, AccR* __restrict__ accr,
                                                         unsigned long long* __restrict__ inert, OverlapArgs O) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
@@ -541,7 +540,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cell* __restrict__
 }
 
 // clear_overlap_map (elevation_mapping.py:393-410): centred window, one launch instead of ~12
-__global__ __launch_bounds__(EM_BLOCK) void k_overlap(KP P, Cell* __restrict__ cells, int cmin, int cmax, float hmin, float hmax) {
+__global__ __launch_bounds__(EM_BLOCK) void k_overlap(KP P, Cells cells, int cmin, int cmax, float hmin, float hmax) {
   int w = cmax - cmin;
   long k = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (k >= (long)w * w) return;
@@ -591,7 +590,7 @@ __device__ __forceinline__ float exp_neg(float a) {                         // e
 }
 
 template <int PT_R, int STAGE>
-__global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, TravW Wt, Cell* __restrict__ cells, float* __restrict__ trav_in,
+__global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, TravW Wt, Cells cells, float* __restrict__ trav_in,
                                                     float* __restrict__ normal, long plane_stride, int d, PostSegs S) {
   int seg_b = S.b[0], seg_e = S.e[0], ty = blockIdx.y;
 #pragma unroll
@@ -649,9 +648,8 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
           const int T = ltab[r];
           tq[u] = T | lfl;
           ol[u] = (r * rp + tc) * 3;
-          const float* cp = reinterpret_cast<const float*>(&cells[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)lpc)]);
-          fv[u] = cp[2];                                                       // Cell: h v valid trav | time upper is_upper pad
-          fu[u] = *reinterpret_cast<const float2*>(cp + 5);
+          const float4 q = cells.cold[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)lpc)];     // time upper is_upper valid': one load
+          fv[u] = q.w; fu[u] = make_float2(q.y, q.z);
         }
       }
 #pragma unroll
@@ -667,9 +665,8 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
           const int T = rtab[r + 1 + dr];
           tq[u] = T | fl;
           ol[u] = (r * rp + cc) * 3;
-          const float* cp = reinterpret_cast<const float*>(&cells[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)pc)]);
-          fv[u] = cp[2];
-          fu[u] = *reinterpret_cast<const float2*>(cp + 5);
+          const float4 q = cells.cold[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)pc)];
+          fv[u] = q.w; fu[u] = make_float2(q.y, q.z);
         }
       }
 #pragma unroll
@@ -758,7 +755,7 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
         acc = fmaf(Wt.wo[q][2], fabsf(s23.x), acc);
         acc = fmaf(Wt.wo[q][3], fabsf(s23.y), acc);
       }
-      cells[c].trav = exp_neg(acc);
+      cells.hot[c].w = exp_neg(acc);                  // trav: a 4-byte store into the 16-byte hot half
     }
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (col_n && gr >= 1 && gr <= C - 3 && t0[2] > 0.5f) {                // (is_valid of the cell itself)
@@ -775,27 +772,27 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
 }
 
 // update_variance + update_time (elevation_mapping.py:420-426)
-__global__ __launch_bounds__(EM_BLOCK) void k_var_time(KP P, Cell* __restrict__ cells, int do_var, int do_time) {
+__global__ __launch_bounds__(EM_BLOCK) void k_var_time(KP P, Cells cells, int do_var, int do_time) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
-  Cell* m = &cells[li + (long)P.halo * P.C];
+  const long ci = li + (long)P.halo * P.C;
   if (P.mv.n) {                                   // pending map shifts: the whole cell is written out first (uniform branch)
     const int lrow = (int)(li / P.C);
-    Cell c = *m;
+    Cell c = cells[ci];
     cell_now(P, c, P.row0 + lrow, (int)(li - (long)lrow * P.C));
     if (do_var) c.v = c.v + P.time_var * c.valid;
     if (do_time) c.time = c.time + P.time_int;
-    *m = c;
+    cells[ci] = c;
     return;
   }
-  if (do_var) m->v = m->v + P.time_var * m->valid;
-  if (do_time) m->time = m->time + P.time_int;
+  if (do_var) { float4 a = cells.hot[ci]; a.y = a.y + P.time_var * a.z; cells.hot[ci] = a; }     // variance lives in the hot half,
+  if (do_time) cells.cold[ci].x = cells.cold[ci].x + P.time_int;                                 // time in the cold one
 }
 
 // ---- layer read-back for publishing (get_map_with_name_ref, elevation_mapping.py:579-775): border stripped, both axes
 // flipped, NaN for unknown cells, +center_z for height layers -- one kernel + one D2H instead of several host passes.
 // kind: 0 elevation, 1 variance, 2 traversability, 3 time, 4 upper_bound, 5 is_upper_bound, 6..8 normal x/y/z
-__global__ __launch_bounds__(EM_BLOCK) void k_publish(KP P, const Cell* __restrict__ cells, const float* __restrict__ normal,
+__global__ __launch_bounds__(EM_BLOCK) void k_publish(KP P, Cells cells, const float* __restrict__ normal,
                                                        long plane_stride, int kind, float center_z, int only_above,
                                                        float* __restrict__ out) {
   const int C = P.C, M = C - 2;
@@ -832,15 +829,18 @@ __device__ __forceinline__ long view_cell(const KP& P, long li, int org_r, int o
   const int lr = local_row(P, wrap_up(r + org_r, P.C));
   return lr < 0 ? -1 : (long)lr * P.C + wrap_up(c + org_c, P.C);
 }
-__global__ __launch_bounds__(EM_BLOCK) void k_get_plane(KP P, const Cell* __restrict__ cells, int word, float* __restrict__ out) {
+__global__ __launch_bounds__(EM_BLOCK) void k_get_plane(KP P, Cells cells, int word, float* __restrict__ out) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
-  out[li] = reinterpret_cast<const float*>(&cells[view_cell(P, li, P.org_r, P.org_c)])[word];
+  const long ci = view_cell(P, li, P.org_r, P.org_c);
+  out[li] = word < 4 ? reinterpret_cast<const float*>(cells.hot + ci)[word] : reinterpret_cast<const float*>(cells.cold + ci)[word - 4];
 }
-__global__ __launch_bounds__(EM_BLOCK) void k_set_plane(KP P, Cell* __restrict__ cells, int word, const float* __restrict__ in) {
+__global__ __launch_bounds__(EM_BLOCK) void k_set_plane(KP P, Cells cells, int word, const float* __restrict__ in) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
-  reinterpret_cast<float*>(&cells[view_cell(P, li, P.org_r, P.org_c)])[word] = in[li];
+  const long ci = view_cell(P, li, P.org_r, P.org_c);
+  if (word < 4) reinterpret_cast<float*>(cells.hot + ci)[word] = in[li]; else reinterpret_cast<float*>(cells.cold + ci)[word - 4] = in[li];
+  if (word == 2) cells.cold[ci].w = in[li];                 // is_valid is mirrored in the cold half
 }
 // planar float arrays (semantic layers, normal planes, traversability_input): gather / scatter between the view and the array
 __global__ __launch_bounds__(EM_BLOCK) void k_plane_view(KP P, int org_r, int org_c, float* __restrict__ plane, float* __restrict__ view, int to_plane) {
@@ -852,14 +852,14 @@ __global__ __launch_bounds__(EM_BLOCK) void k_plane_view(KP P, int org_r, int or
 }
 // writes the pending map shifts into every owned cell (one full pass; needed only when something reads the map between a
 // move and the next frame)
-__global__ __launch_bounds__(EM_BLOCK) void k_materialize(KP P, Cell* __restrict__ cells) {
+__global__ __launch_bounds__(EM_BLOCK) void k_materialize(KP P, Cells cells) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
   const int lrow = (int)(li / P.C);
-  Cell* p = &cells[li + (long)P.halo * P.C];
-  Cell m = *p;
+  const long ci = li + (long)P.halo * P.C;
+  Cell m = cells[ci];
   cell_now(P, m, P.row0 + lrow, (int)(li - (long)lrow * P.C));
-  *p = m;
+  cells[ci] = m;
 }
 // zero-fills the band that a roll by (sr, sc) brought in (SemanticMap.shift_map_xy, semantic_map.py:127-136) in `nl` planes
 __global__ __launch_bounds__(EM_BLOCK) void k_band_clear(KP P, float* __restrict__ planes, int nl, long plane_stride, int sr, int sc) {
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_band_clear(KP P, float* __restrict
   if (!((sr > 0 && r < sr) || (sr < 0 && r >= P.C + sr) || (sc > 0 && c < sc) || (sc < 0 && c >= P.C + sc))) return;
   for (int l = 0; l < nl; ++l) planes[(long)l * plane_stride + li + (long)P.halo * P.C] = 0.0f;
 }
-__global__ __launch_bounds__(EM_BLOCK) void k_fill_cells(Cell* __restrict__ cells, long n, Cell v) {
+__global__ __launch_bounds__(EM_BLOCK) void k_fill_cells(Cells cells, long n, Cell v) {
   long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (i < n) cells[i] = v;
 }
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_point_index(KP P, Pose T, const fl
 // ---- launch wrappers used by emap_api.hip -------------------------------------------------------------
 static inline unsigned int nblk(long n) { return (unsigned int)((n + EM_BLOCK - 1) / EM_BLOCK); }
 
-void launch_count(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, const Cell* cells,
+void launch_count(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, Cells cells,
                   AccF* acc, ErrSlot* slots) {
   if (n <= 0) return;
   if (P.mode == 0) hipLaunchKernelGGL(k_count<0>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, slots);
@@ -900,24 +900,24 @@ void launch_count(hipStream_t s, const KP& P, const Pose& T, const float* pts, l
 void launch_gate(hipStream_t s, const GateArgs& A, ErrSlot* slots, FrameDev* F, int reduce_only, double* dev_out, const double* dev_totals) {
   hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, A, slots, F, reduce_only, dev_out, dev_totals);
 }
-void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, const Cell* cells, AccF* acc,
+void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, Cells cells, AccF* acc,
                  const FrameDev* F) {
   if (n <= 0) return;
   dim3 g(nblk(n)), b(EM_BLOCK);
   if (P.mode == 0) hipLaunchKernelGGL(k_fuse<0>, g, b, 0, s, P, T, pts, n, stride, cells, acc, F);
   else hipLaunchKernelGGL(k_fuse<1>, g, b, 0, s, P, T, pts, n, stride, cells, acc, F);
 }
-void launch_commit(hipStream_t s, const KP& P, Cell* cells, const AccF* acc, const FrameDev* F, unsigned long long* inert) {
+void launch_commit(hipStream_t s, const KP& P, Cells cells, const AccF* acc, const FrameDev* F, unsigned long long* inert) {
   hipLaunchKernelGGL(k_commit, dim3((P.C + 63) / 64, P.nrows), dim3(64), 0, s, P, cells, acc, F, inert);
 }
-void launch_ray_apply(hipStream_t s, const KP& P, Cell* cells, AccR* accr, unsigned long long* inert, const OverlapArgs& O) {
+void launch_ray_apply(hipStream_t s, const KP& P, Cells cells, AccR* accr, unsigned long long* inert, const OverlapArgs& O) {
   hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr, inert, O);
 }
 #ifndef RAY_BLOCK
 #define RAY_BLOCK 1024
 #endif
 template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
-                                                                              long n, int stride, const Cell* cells, AccR* accr,
+                                                                              long n, int stride, Cells cells, AccR* accr,
                                                                               const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert,
                                                                               const unsigned int* inl, int inl_stride, const float* thr, const unsigned int* order, const unsigned int* n_sorted) {
   constexpr int SMALL_BLOCK = 256, SMALL_LPR = 4;
@@ -942,7 +942,7 @@ template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(h
   else go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, false, 1>, raised0, lds);
 }
 template <int MODE, bool STATS> static void launch_rays_t(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
-                                                          long n, int stride, const Cell* cells, AccR* accr,
+                                                          long n, int stride, Cells cells, AccR* accr,
                                                           const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert,
                                                           const unsigned int* inl, int inl_stride, const float* thr, const unsigned int* order, const unsigned int* n_sorted) {
   const bool strip = P.nrows < P.C;
@@ -961,7 +961,7 @@ template <int MODE, bool STATS> static void launch_rays_t(hipStream_t s, const K
 }
 // `thr`: per 8 x 8 block visit threshold of k_tile_fuse<true, true> (nullptr: no filter).  `inl` / `inl_stride`: per-cell drift-inlier counts of the frame (newmap[3]) as 32-bit words with an element stride -- the dense
 // plane of the tile kernel (stride 1) or the high halves of AccF::pts_inl (stride 10, offset 1) on the staged / atomic path
-void launch_rays(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts, long n, int stride, const Cell* cells,
+void launch_rays(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts, long n, int stride, Cells cells,
                  AccR* accr, const float* normal, long plane_stride, FrameDev* F, bool stats,
                  const unsigned long long* inert, const unsigned int* inl, int inl_stride, const float* thr,
                  const unsigned int* order, const unsigned int* n_sorted) {
@@ -974,7 +974,7 @@ void launch_rays(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, co
     else launch_rays_t<1, false>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
   }
 }
-void launch_average(hipStream_t s, const KP& P, Cell* cells, AccF* acc, AccR* accr, const FrameDev* F, bool committed, bool rays,
+void launch_average(hipStream_t s, const KP& P, Cells cells, AccF* acc, AccR* accr, const FrameDev* F, bool committed, bool rays,
                     unsigned int* cnt_out, const OverlapArgs& O) {
   dim3 g(nblk((long)P.nrows * P.C)), b(EM_BLOCK);
   if (committed) {
@@ -985,7 +985,7 @@ void launch_average(hipStream_t s, const KP& P, Cell* cells, AccF* acc, AccR* ac
     else hipLaunchKernelGGL((k_average<false, false>), g, b, 0, s, P, cells, acc, accr, F, cnt_out, O);
   }
 }
-void launch_overlap(hipStream_t s, const KP& P, Cell* cells, int cmin, int cmax, float hmin, float hmax) {
+void launch_overlap(hipStream_t s, const KP& P, Cells cells, int cmin, int cmax, float hmin, float hmax) {
   long w = cmax - cmin;
   if (w <= 0) return;
   hipLaunchKernelGGL(k_overlap, dim3(nblk(w * w)), dim3(EM_BLOCK), 0, s, P, cells, cmin, cmax, hmin, hmax);
@@ -1004,7 +1004,7 @@ int post_tile_rows(const KP& P) {
   return R;
 }
 // outputs for up to four LOGICAL row intervals [seg_b[k], seg_e[k]) (owned by this strip, no circular seam inside); stage 1 = dilation only
-void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, const float* w3, const float* wo, Cell* cells,
+void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, const float* w3, const float* wo, Cells cells,
                  float* trav_in, float* normal, long plane_stride, int d, int nseg, const int* seg_b, const int* seg_e, int stage) {
   TravW W;
   const float* wq[3] = {w1, w2, w3};                       // conv weights [channel][tap] -> [tap][channel]
@@ -1031,21 +1031,21 @@ void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, c
   else { if (R == 4) POST_GO(4, 0); else if (R == 8) POST_GO(8, 0); else if (R == 32) POST_GO(32, 0); else POST_GO(16, 0); }
 #undef POST_GO
 }
-void launch_var_time(hipStream_t s, const KP& P, Cell* cells, int do_var, int do_time) {
+void launch_var_time(hipStream_t s, const KP& P, Cells cells, int do_var, int do_time) {
   hipLaunchKernelGGL(k_var_time, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, do_var, do_time);
 }
-void launch_publish(hipStream_t s, const KP& P, const Cell* cells, const float* normal, long plane_stride, int kind, float center_z,
+void launch_publish(hipStream_t s, const KP& P, Cells cells, const float* normal, long plane_stride, int kind, float center_z,
                     int only_above, float* out) {
   const long M = P.C - 2;
   hipLaunchKernelGGL(k_publish, dim3(nblk(M * M)), dim3(EM_BLOCK), 0, s, P, cells, normal, plane_stride, kind, center_z, only_above, out);
 }
-void launch_get_plane(hipStream_t s, const KP& P, const Cell* cells, int word, float* out) {
+void launch_get_plane(hipStream_t s, const KP& P, Cells cells, int word, float* out) {
   hipLaunchKernelGGL(k_get_plane, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, word, out);
 }
-void launch_set_plane(hipStream_t s, const KP& P, Cell* cells, int word, const float* in) {
+void launch_set_plane(hipStream_t s, const KP& P, Cells cells, int word, const float* in) {
   hipLaunchKernelGGL(k_set_plane, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, word, in);
 }
-void launch_fill_cells(hipStream_t s, Cell* cells, long n, const Cell& v) {
+void launch_fill_cells(hipStream_t s, Cells cells, long n, const Cell& v) {
   hipLaunchKernelGGL(k_fill_cells, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, cells, n, v);
 }
 void launch_point_index(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, int* idx, unsigned char* flags) {
@@ -1056,7 +1056,7 @@ void launch_point_index(hipStream_t s, const KP& P, const Pose& T, const float* 
 void launch_plane_view(hipStream_t s, const KP& P, int org_r, int org_c, float* plane, float* view, int to_plane) {
   hipLaunchKernelGGL(k_plane_view, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, org_r, org_c, plane, view, to_plane);
 }
-void launch_materialize(hipStream_t s, const KP& P, Cell* cells) {
+void launch_materialize(hipStream_t s, const KP& P, Cells cells) {
   hipLaunchKernelGGL(k_materialize, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells);
 }
 void launch_band_clear(hipStream_t s, const KP& P, float* planes, int nl, long plane_stride, int sr, int sc) {

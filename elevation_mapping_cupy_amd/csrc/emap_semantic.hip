@@ -262,7 +262,7 @@ struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; }
 
 __device__ __forceinline__ float l2_dist(int x0, int y0, int x1, int y1) { float dx = (float)(x0 - x1), dy = (float)(y0 - y1); return sqrtf(dx * dx + dy * dy); }
 
-__global__ __launch_bounds__(EM_BLOCK) void k_image_corr(KP P, CamArgs A, const Cell* __restrict__ cells, float* __restrict__ uv,
+__global__ __launch_bounds__(EM_BLOCK) void k_image_corr(KP P, CamArgs A, Cells cells, float* __restrict__ uv,
                                                           unsigned char* __restrict__ valid) {
   const int W = P.C; const long L = (long)W * W;
   const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
@@ -302,8 +302,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_image_corr(KP P, CamArgs A, const 
       if ((float)x0 == x1 && (float)y0 == y1) break;
       if (x0 >= 0 && y0 >= 0 && x0 < W && y0 < W) {
         const long idx = phys_col(P, y0) + (long)phys_row(P, x0) * W;
-        const float2 hv = *reinterpret_cast<const float2*>(&cells[idx]);     // h, (v)
-        if (cells[idx].valid != 0.f) {
+        const float4 hv = cells.hot[idx];     // h, (v), valid
+        if (hv.z != 0.f) {
           float dis = l2_dist(x0c, y0c, x0, y0);
           float rayheight = z0 + (dis / total_dis * delta_z);
           if ((double)hv.x - 0.10 > (double)rayheight) { ok = false; break; }
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_image_fuse(KP P, int kind, float* 
   }
 }
 
-void launch_image_corr(hipStream_t s, const KP& P, const CamArgs& A, const Cell* cells, float* uv, unsigned char* valid) {
+void launch_image_corr(hipStream_t s, const KP& P, const CamArgs& A, Cells cells, float* uv, unsigned char* valid) {
   hipLaunchKernelGGL(k_image_corr, dim3(nblk_((long)P.C * P.C)), dim3(EM_BLOCK), 0, s, P, A, cells, uv, valid);
 }
 void launch_image_fuse(hipStream_t s, const KP& P, int kind, float* sem, const float* image, const float* uv, const unsigned char* valid,
