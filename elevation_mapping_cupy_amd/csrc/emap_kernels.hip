@@ -604,6 +604,9 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   // is_valid (normal filter).  One 12-byte LDS write per staged cell; a stride of three dwords across the lanes is conflict free.
   float* reg = lds;
   int* rtab = reinterpret_cast<int*>(reg + 3 * RH * rp);       // RH + 2 row terms
+  unsigned short* holes = reinterpret_cast<unsigned short*>(rtab + ((RH + 3) & ~1));      // compacted list of the holes of the DW x DH region
+  __shared__ unsigned int n_holes;
+  if (threadIdx.x == 0) n_holes = 0u;
   const int C = P.C;
   const int tile_r = seg_b + ty * PT_R, tile_c = blockIdx.x * PT_C;      // logical row / column of the tile origin
   const int tc = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave index in an SGPR
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
     col_terms(tc, ldr, lpc, lfl);
     const int* ltab = rtab + 1 + ldr;                                // the lane's view of the row table
     for (int rb = 0, eb = 0; rb < RH || eb < etotal; rb += PT_WAVES * JB, eb += PT_THREADS * EU) {
-      float fv[JB + EU]; float2 fu[JB + EU]; int ol[JB + EU], tq[JB + EU];       // per unit: the cell's three dwords, LDS slot (-1: none), flags
+      float fv[JB + EU]; float2 fu[JB + EU]; int ol[JB + EU], tq[JB + EU], hp[JB + EU];       // per unit: the cell's three dwords, LDS slot (-1: none), flags, slot in the DW x DH region (-1: outside)
 #pragma unroll
       for (int u = 0; u < JB; ++u) {
         const int r = rb + wv + PT_WAVES * u;                       // scalar
@@ -648,6 +651,7 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
           const int T = ltab[r];
           tq[u] = T | lfl;
           ol[u] = (r * rp + tc) * 3;
+          hp[u] = ((unsigned int)(r - d) < (unsigned int)DH && (unsigned int)(tc - d) < (unsigned int)DW) ? (r - d) * DW + (tc - d) : -1;
           const float4 q = cells.cold[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)lpc)];     // time upper is_upper valid': one load
           fv[u] = q.w; fu[u] = make_float2(q.y, q.z);
         }
@@ -665,6 +669,7 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
           const int T = rtab[r + 1 + dr];
           tq[u] = T | fl;
           ol[u] = (r * rp + cc) * 3;
+          hp[u] = ((unsigned int)(r - d) < (unsigned int)DH && (unsigned int)(cc - d) < (unsigned int)DW && e == ebase + tc) ? (r - d) * DW + (cc - d) : -1;
           const float4 q = cells.cold[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)pc)];
           fv[u] = q.w; fu[u] = make_float2(q.y, q.z);
         }
@@ -679,23 +684,17 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
         o.y = ok ? (inside ? m : -m - 1.f) : -1.f;
         o.z = ok ? fv[u] : 0.f;
         *reinterpret_cast<float3*>(reg + ol[u]) = o;
+        // a hole of the region whose dilated value is needed: noted here, while its mask is in a register (cells outside the map are
+        // never sources and never outputs: not listed)
+        if (ok && m < 0.5f && hp[u] >= 0) holes[atomicAdd(&n_holes, 1u)] = (unsigned short)hp[u];
       }
     }
   }
-  // holes of the DW x DH region are first COMPACTED into an LDS list and then searched one hole per lane -- a hole-containing
-  // wave would otherwise drag all 64 lanes through the neighbour search (measured: 11 of 33 us with 1.5 % holes).  The dilated
-  // value replaces the raw one IN PLACE: only cells with mask > 0.5 are ever sources and the masks are not touched, so a filled
-  // hole cannot feed another hole (Jacobi semantics of the reference kernel), and the stencils below read one array.
-  unsigned short* holes = reinterpret_cast<unsigned short*>(rtab + ((RH + 3) & ~1));
-  __shared__ unsigned int n_holes;
-  if (threadIdx.x == 0) n_holes = 0u;
-  __syncthreads();
-  for (int r = wv; r < DH; r += PT_WAVES)
-    for (int cc = tc; cc < DW; cc += 64) {
-      const float mraw = reg[((r + d) * rp + (cc + d)) * 3 + 1];
-      const float own = mraw < 0.f ? -mraw - 1.f : mraw;
-      if (own < 0.5f) holes[atomicAdd(&n_holes, 1u)] = (unsigned short)(r * DW + cc);
-    }
+  // The holes of the DW x DH region were COMPACTED into an LDS list by the staging loop and are searched one hole per lane -- a
+  // hole-containing wave would otherwise drag all 64 lanes through the neighbour search (measured: 11 of 33 us with 1.5 % holes), and
+  // a separate detection pass over the region with its two barriers cost 5.8 us of a 23-us kernel even when there was no hole at all.
+  // The dilated value replaces the raw one IN PLACE: only cells with mask > 0.5 are ever sources and the masks are not touched, so a
+  // filled hole cannot feed another hole (Jacobi semantics of the reference kernel), and the stencils below read one array.
   __syncthreads();
   const unsigned int nh = n_holes;
   for (unsigned int hi = threadIdx.x; hi < nh; hi += PT_THREADS) {
@@ -711,7 +710,7 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
       }
     }
   }
-  __syncthreads();
+  if (nh) __syncthreads();                       // (uniform: every thread read the same count)
   const int col = tile_c + tc;                   // logical column
   if (col >= C) return;
   const int pcol = phys_col(P, col);
