@@ -573,20 +573,42 @@ struct TravW { float w[3][9][4]; float wo[3][4]; };   // weights of the traversa
 // Up to four logical row intervals per launch (a strip's rows around the circular seam, the boundary rows of a strip): a launch of a
 // few tiles alone costs a whole workgroup latency chain (~18 us measured), so the pieces go into ONE grid.
 struct PostSegs { int n, b[4], e[4], t0[4]; unsigned int emagic; };     // interval [b, e) starts at tile row t0 of the grid; emagic = ceil(2^32 / (6 + 2d))
-// cheap correctly-rounded-in-practice float helpers of the stencil epilogue (the IEEE division / sqrt / exp sequences of the
-// compiler cost ~55 vector instructions per cell here and the kernel is issue bound).  Error <= 1 ulp against the reference's
-// IEEE operations; the parity tolerance on traversability / normals is 1e-5 (cuDNN's summation order is unspecified anyway).
-__device__ __forceinline__ float div_by(float a, float b, float rb) {      // a / b with rb ~ 1/b (relative error <= 1 ulp)
-  const float q = a * rb;
-  return fmaf(fmaf(-q, b, a), rb, q);
+// Epilogue arithmetic of the stencil kernel.  The NORMALS feed a decision of the next frame's visibility pass (half rounding, then
+// |r . n| < cleanup_cos_thresh, custom_kernels.py:243-246), so their epilogue uses IEEE division and square root exactly like
+// normal_filter_kernel (custom_kernels.py:493-500) and the oracle: bit-identical planes, tests/test_hip_normals_exact.py.  (Round 2
+// used 1-ulp sequences there.  An exhaustive search over all 2^32 numerators showed the 3-instruction constant division
+// a * (1/res) + residual correct only for 1e-32 < |a| < 1e37, and guarding that range costs what the sequence saves.)
+// correctly rounded sqrt for x >= 1 (or +inf / NaN): v_sqrt_f32 is within 1 ulp, the two residuals pick the neighbour when it is the
+// nearer one -- the compiler's own IEEE sequence (sqrtf) without its input scaling for x < 2^-96 and its zero / infinity class test,
+// neither of which can apply here (x = nx^2 + ny^2 + 1; for x = inf every comparison below is false and inf stays).
+// NB __fsqrt_rn is NOT this: it lowers to the bare 1-ulp instruction.
+__device__ __forceinline__ float sqrt_rn_ge1(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+  s = rd <= 0.0f ? sd : s;
+  s = ru > 0.0f ? su : s;
+  return s;
 }
-__device__ __forceinline__ float exp_neg(float a) {                         // exp(-a), a >= 0
-  const float x = -a, L2E = 1.44269502f, L2E_LO = 1.92596299e-8f;
-  const float t = x * L2E;
-  float lo = fmaf(x, L2E, -t);
-  lo = fmaf(x, L2E_LO, lo);
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, lo * 0.693147182f, e);
+// exp(-a) of the traversability epilogue (traversability_filter.py:44, torch.exp in the reference), a >= 0.  Built from operations
+// that exist bit for bit on the host as well -- round-to-nearest-even, fused multiply-adds, ldexp -- so that the oracle evaluates the
+// SAME function (oracle/emap_oracle.c: exp_neg_det) and the traversability plane, which feeds the drift-inlier decision of the next
+// frame (custom_kernels.py:329: traversability > traversability_inlier), compares bit for bit: n = rint(x log2 e), r = x - n ln 2
+// (two-constant reduction), e^r by the degree-6 Taylor polynomial (|r| <= 0.347: truncation 1.2e-7 relative), 2^n by ldexp.  Within
+// 3 ulp of expf; the hardware exponential (v_exp_f32) is faster by 8 instructions per cell but not reproducible off the GPU.
+__device__ __forceinline__ float exp_neg(float a) {
+  const float x = -(!(a > 200.0f) ? a : 200.0f);                         // exp(-200) = 0 in fp32; NaN stays NaN
+  const float n = __builtin_rintf(x * 0x1.715476p+0f);
+  float r = __builtin_fmaf(n, -0x1.62e400p-1f, x);
+  r = __builtin_fmaf(n, -0x1.7f7d1cp-20f, r);
+  float p = 0x1.6c16c2p-10f;
+  p = __builtin_fmaf(p, r, 0x1.111112p-7f);
+  p = __builtin_fmaf(p, r, 0x1.555556p-5f);
+  p = __builtin_fmaf(p, r, 0x1.555556p-3f);
+  p = __builtin_fmaf(p, r, 0.5f);
+  p = __builtin_fmaf(p, r, 1.0f);
+  p = __builtin_fmaf(p, r, 1.0f);
+  return __builtin_amdgcn_ldexpf(p, (int)n);
 }
 
 template <int PT_R, int STAGE>
@@ -759,12 +781,9 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (col_n && gr >= 1 && gr <= C - 3 && t0[2] > 0.5f) {                // (is_valid of the cell itself)
       const float dzdx = t0[3] - h, dzdy = t0[3 * dp] - h;
-      const float ax = -div_by(dzdy, P.res_f, P.inv_res_f), ay = -div_by(dzdx, P.res_f, P.inv_res_f);
-      const float x = (ax * ax) + (ay * ay) + 1.0f;                    // >= 1
-      const float s0 = __builtin_amdgcn_sqrtf(x), r0 = __builtin_amdgcn_rcpf(s0);
-      const float nrm = fmaf(fmaf(-s0, s0, x), 0.5f * r0, s0);        // one Newton step each on the root and its reciprocal
-      const float rn = fmaf(fmaf(-nrm, r0, 1.0f), r0, r0);
-      nx = div_by(ax, nrm, rn); ny = div_by(ay, nrm, rn); nz = div_by(1.0f, nrm, rn);
+      const float ax = -dzdy / P.res_f, ay = -dzdx / P.res_f;           // IEEE: v_div_scale / v_div_fmas / v_div_fixup sequences
+      const float nrm = sqrt_rn_ge1((ax * ax) + (ay * ay) + 1.0f);
+      nx = ax / nrm; ny = ay / nrm; nz = 1.0f / nrm;
     }
     normal[c] = nx; normal[plane_stride + c] = ny; normal[2 * plane_stride + c] = nz;
   }

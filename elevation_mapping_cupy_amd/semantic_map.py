@@ -156,6 +156,10 @@ class SemanticMap:
             return np.zeros((0, self._emap.rows, self._emap.cell_n), np.float32)
         return np.stack([self._layer(i) for i in range(len(self.layer_names))], axis=0)
 
+    def get_layer(self, name_or_idx):
+        """one raw ``(rows, cell_n)`` layer (a 8192^2 map holds 268 MB per layer: read what you need, not the stack)"""
+        return self._layer(self.layer_names.index(name_or_idx) if isinstance(name_or_idx, str) else int(name_or_idx))
+
     def set_layer(self, name_or_idx, array):
         idx = self.layer_names.index(name_or_idx) if isinstance(name_or_idx, str) else int(name_or_idx)
         a = np.ascontiguousarray(array, np.float32)

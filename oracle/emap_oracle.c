@@ -365,7 +365,30 @@ void eo_dilate(int C, int d, const float* plane, const float* mask, float* out, 
 }
 
 /* traversability filter (traversability_filter.py:8-47): three dilated 3x3 correlations (4 ch each, no bias,
- * no padding) -> abs -> 1x1 conv -> exp(-x); written to plane 3 interior [3:-3,3:-3] (elevation_mapping.py:385-388) */
+ * no padding) -> abs -> 1x1 conv -> exp(-x); written to plane 3 interior [3:-3,3:-3] (elevation_mapping.py:385-388).
+ * The reference runs this through torch.nn.Conv2d (cuDNN / MIOpen): neither the summation order nor the use of fused
+ * multiply-adds is specified there, so the restatement fixes ONE order -- filter, channel, taps row-major, every step a fused
+ * multiply-add (what GPU convolution kernels issue) -- and is pinned against torch's CPU fp32 convolution within 1e-5
+ * (tests/test_oracle_golden.py).  On heights of magnitude H the orders differ by O(108 * ulp(H)), i.e. beyond 1e-5 for |H| > ~10 m. */
+/* exp(-a), a >= 0: the reference calls torch.exp (traversability_filter.py:44), whose last bits differ between back ends.  The
+ * restatement uses one fixed sequence of correctly rounded operations (rint, fmaf, ldexpf) that the HIP kernel repeats literally
+ * (emap_kernels.hip: exp_neg), so the plane -- an input of the next frame's drift-inlier decision, custom_kernels.py:329 -- compares
+ * bit for bit; within 3 ulp of expf (tests/test_oracle_golden.py pins it against expf / torch within 1e-5). */
+static inline float exp_neg_det(float a) {
+  const float x = -(!(a > 200.0f) ? a : 200.0f);
+  const float n = rintf(x * 0x1.715476p+0f);
+  float r = fmaf(n, -0x1.62e400p-1f, x);
+  r = fmaf(n, -0x1.7f7d1cp-20f, r);
+  float p = 0x1.6c16c2p-10f;
+  p = fmaf(p, r, 0x1.111112p-7f);
+  p = fmaf(p, r, 0x1.555556p-5f);
+  p = fmaf(p, r, 0x1.555556p-3f);
+  p = fmaf(p, r, 0.5f);
+  p = fmaf(p, r, 1.0f);
+  p = fmaf(p, r, 1.0f);
+  return ldexpf(p, n == n ? (int)n : 0);
+}
+float eo_exp_neg(float a) { return exp_neg_det(a); }
 void eo_traversability(const eo_params* P, const float* in, float* trav_plane) {
   const int C = P->cell_n;
   const float* w[3] = {P->w1, P->w2, P->w3};
@@ -374,12 +397,12 @@ void eo_traversability(const eo_params* P, const float* in, float* trav_plane) {
     float acc = 0.0f;
     for (int k = 0; k < 3; ++k) { const int dl = k + 1;
       for (int ch = 0; ch < 4; ++ch) {
-        float s = 0.0f;
+        float s = 0.0f;      /* fused multiply-adds, taps in row-major order: see the note above */
         for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
-          s += w[k][ch * 9 + a * 3 + b] * in[(long)(r + (a - 1) * dl) * C + (c + (b - 1) * dl)];
-        acc += P->w_out[k * 4 + ch] * fabsf(s);
+          s = fmaf(w[k][ch * 9 + a * 3 + b], in[(long)(r + (a - 1) * dl) * C + (c + (b - 1) * dl)], s);
+        acc = fmaf(P->w_out[k * 4 + ch], fabsf(s), acc);
       } }
-    trav_plane[(long)r * C + c] = expf(-acc);
+    trav_plane[(long)r * C + c] = exp_neg_det(acc);
   }
 }
 

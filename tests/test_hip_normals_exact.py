@@ -1,0 +1,63 @@
+"""GPU: the normal planes and the traversability plane are BIT-IDENTICAL to the oracle, not just within 1e-5.
+
+Why it matters: a normal feeds a decision one frame later -- the visibility pass rounds it to half precision and compares
+|ray . normal| with cleanup_cos_thresh (reference custom_kernels.py:243-246).  A 1-ulp difference in fp32 flips the half
+rounding with p ~ 2^-12 per component, and a flipped decision changes validity / variance of a cell by far more than 1e-5.
+normal_filter_kernel (custom_kernels.py:493-500) uses IEEE float division and sqrt; so do the oracle and k_post."""
+import numpy as np
+import pytest
+
+import _fixtures as fx
+from _util import make_pair
+from oracle import emap_oracle as eo
+
+pytestmark = pytest.mark.gpu
+C, N = 1024, 1_000_000
+
+
+@pytest.fixture(autouse=True)
+def _oracle_threads():
+    eo.set_threads(16)
+    yield
+    eo.set_threads(1)
+
+
+@pytest.mark.parametrize("rays", [False, True])
+def test_normals_bit_for_bit_on_warm_frames(rays, weights):
+    cfg = dict(eo.YAML, enable_visibility_cleanup=rays)
+    hip, orc = make_pair(cfg, C, "reference_fp16", weights)
+    R, t = fx.POSES["rotated"]
+    total_cells = 0
+    for f, dz in enumerate((0.0, -0.03, -0.07, 0.02)):
+        p = fx.cloud(C, N if not rays else 300_000, f, dz=dz)
+        hip.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0)
+        orc.update_map_with_kernel(p, R, t, 1.0, 1.0)
+        for _ in range(5):
+            hip.update_time(); orc.update_time()
+        hn, on = hip.normal_map, orc.normal_map
+        # the dilated plane both filters start from is a copy of map values: identical by construction, checked anyway
+        assert np.array_equal(hip.traversability_input, orc.traversability_input), "frame %d: traversability_input differs" % f
+        mism = int((hn.view(np.uint32) != on.view(np.uint32)).sum())
+        half_flips = int((hn.astype(np.float16).view(np.uint16) != on.astype(np.float16).view(np.uint16)).sum())
+        nz = int((on[2] != 0).sum())
+        # traversability: same fused multiply-add chains, same deterministic exp(-x) on both sides -> bit for bit as well
+        ht, ot = hip.get_layer_raw(3), orc.elevation_map[3]
+        assert ht.tobytes() == ot.tobytes(), "frame %d: %d traversability cells differ (max %g)" % (f, int((ht != ot).sum()), float(np.abs(ht - ot).max()))
+        total_cells += nz
+        assert mism == 0 and half_flips == 0, "frame %d: %d of %d normal components differ in fp32, %d after half rounding" % (
+            f, mism, 3 * nz, half_flips)
+    assert total_cells > (800_000 if not rays else 300_000)       # the filter really ran on a large part of the map
+
+
+def test_normals_bit_for_bit_robot_scale_fp32_mode(weights):
+    """the small-tile instantiations of the stencil kernel (4-row tiles) and the fp32 index mode"""
+    cfg = dict(eo.YAML)
+    hip, orc = make_pair(cfg, 202, "fp32", weights)
+    R, t = fx.POSES["identity"]
+    for f, dz in enumerate((0.0, -0.05, 0.04)):
+        p = fx.cloud(202, 50_000, 10 + f, dz=dz)
+        hip.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0)
+        orc.update_map_with_kernel(p, R, t, 1.0, 1.0)
+        hip.update_time(); orc.update_time()
+        assert hip.normal_map.tobytes() == orc.normal_map.tobytes(), "frame %d" % f
+        assert hip.get_layer_raw(3).tobytes() == orc.elevation_map[3].tobytes(), "frame %d: traversability" % f
