@@ -54,18 +54,16 @@ void launch_materialize(hipStream_t, const KP&, Cells);
 void launch_band_clear(hipStream_t, const KP&, float*, int, long, int, int);
 
 // tile-binned scatter (emap_binned.hip)
-struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, TB; };
-struct BinTmp { int tile; unsigned int lc; float z, v; };
-struct BinRec { unsigned int lc_inl; float z, v; unsigned int i; };
-void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, BinTmp*, unsigned int*);
+void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, unsigned int*, unsigned short*, unsigned int*);
 void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*, unsigned int*);
-void launch_bin_scatter(hipStream_t, const KP&, const BinGeo&, const BinTmp*, long, const unsigned int*, const unsigned int*, BinRec*);
+void launch_bin_scatter(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, const unsigned int*, const unsigned int*, BinRec*, const unsigned short*, const unsigned int*);
 void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, ErrSlot*);
 void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const float*, long, int,
                           const unsigned int*, float*, float*, long);
 void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, AccF*, const FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&);
 #define BIN_MAX_T 16384
 #define BIN_MAX_B 2048
+#define BIN_SUB 4096      /* points per compaction round of the strip variants (emap_binned.hip) */
 
 // timed stages of emap_update (emap_get_stage_times): hist+scan are 0 on the atomic path, where "scatter" is k_count
 enum { ST_HIST = 0, ST_SCAN, ST_SCATTER, ST_GATE, ST_FUSE, ST_COMMIT, ST_RAYS, ST_AVERAGE, ST_OVERLAP, ST_POST, ST_N };
@@ -136,7 +134,8 @@ struct emap_ctx {
   OverlapArgs ov_args;             // clear_overlap_map folded into the frame's rewriting kernels (on = 0: separate k_overlap launch)
   bool gate_possible;              // false inside emap_update when the host already knows that the drift gate cannot fire: the per-tile
                                    // error statistics are then skipped (they could not have any effect; err_sum / err_cnt report 0)
-  BinGeo bg; BinTmp* bin_tmp; BinRec* bin_recs; unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;
+  BinGeo bg; BinRec* bin_recs; unsigned short* bin_own; unsigned int* bin_own_cnt; long bin_own_cap; bool bin_strip;   // bin_own*: lists of the owned points per block (strip contexts without a visibility pass)
+  unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;
   // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
   float* img_uv; unsigned char* img_valid; float* img_buf; size_t img_cap;   // camera path
   float* sem_alpha;   // class_bayesian pseudo-counts (the reference's persistent new_map layers), sem_layers planes, on demand
@@ -371,7 +370,7 @@ int emap_destroy(emap_ctx* ctx) {
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   delete ctx->workers;
   hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert); hipFree(ctx->inl_plane); hipFree(ctx->ray_thr);
-  hipFree(ctx->bin_tmp); hipFree(ctx->bin_recs); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start); hipFree(ctx->bin_sync);
+  hipFree(ctx->bin_recs); hipFree(ctx->bin_own); hipFree(ctx->bin_own_cnt); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start); hipFree(ctx->bin_sync);
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   emap_comm_destroy(ctx);
@@ -557,18 +556,29 @@ static int bin_sub(const emap_ctx* ctx) {
   return 0;
 }
 static bool bins_possible(const emap_ctx* ctx) { return bin_sub(ctx) > 0; }
-static int ensure_bins(emap_ctx* ctx) {
+static int ensure_bins(emap_ctx* ctx, bool raybin) {
   const long n = ctx->n_pts;
   BinGeo& g = ctx->bg;
   g.sub = bin_sub(ctx);
   g.tiles_x = (ctx->prm.cell_n + 63) / 64; g.tiles_y = (ctx->strip.row_count + 16 * g.sub - 1) / (16 * g.sub); g.T = g.tiles_x * g.tiles_y; g.TB = g.T + 1;
+  g.pitch = (g.TB + 3) & ~3; g.raybin = raybin ? 1 : 0;
+  // strip contexts without a visibility pass: cheap ownership test + lane compaction in the point passes (emap_binned.hip)
+  ctx->bin_strip = ctx->strip.row_count < ctx->prm.cell_n && !raybin;
+  if (const char* e = getenv("EMAP_BIN_STRIP")) { if (atoi(e) == 0) ctx->bin_strip = false; }      // test / tuning hook
+  // Blocks: ~4096 points each, but every block carries a row of the (block, tile) matrix through three passes (written, scanned,
+  // read): keep the matrix (4 B x TB x B, x4) below the cloud's own traffic (12 B x n, x2) -- B <= n / (3 TB) -- without dropping
+  // under one block per CU.  (8192^2 / 16 M points: 2048 blocks of 16385 bins were 537 MB of matrix traffic per frame.)
   long target = n >= 1000000 ? 4096 : 2048;
   if (const char* e = getenv("EMAP_BIN_CHUNK")) { long v = atol(e); if (v >= 256 && v <= 65536) target = v; }   // tuning knob
-  long B = (n + target - 1) / target; if (B < 1) B = 1; if (B > BIN_MAX_B) B = BIN_MAX_B;
-  long chunk = (n + B - 1) / B; chunk = ((chunk + 1023) / 1024) * 1024;   /* a multiple of every hist / scatter block size */
+  long B = (n + target - 1) / target;
+  long bmax = n / (3L * g.TB); if (bmax < 256) bmax = 256; if (bmax > BIN_MAX_B) bmax = BIN_MAX_B;
+  if (B > bmax) B = bmax; if (B < 1) B = 1;
+  const long unit = ctx->bin_strip ? BIN_SUB : 1024;   /* a multiple of every hist / scatter block size [and of the compaction round] */
+  long chunk = (n + B - 1) / B; chunk = ((chunk + unit - 1) / unit) * unit;
+  if (ctx->bin_strip && chunk > 15 * BIN_SUB) chunk = 15 * BIN_SUB;       // 2-byte list entries index a round, not the chunk; keep the rounds bounded
   g.B = (int)((n + chunk - 1) / chunk); if (g.B < 1) g.B = 1;
   g.chunk = chunk;
-  const size_t hist_need = (size_t)g.TB * (size_t)g.B;
+  const size_t hist_need = (size_t)g.pitch * (size_t)g.B;
   if (hist_need > ctx->bin_hist_cap) {
     CK(hipStreamSynchronize(ctx->stream));
     if (ctx->bin_hist) CK(hipFree(ctx->bin_hist));
@@ -584,12 +594,19 @@ static int ensure_bins(emap_ctx* ctx) {
   }
   if (n > ctx->bin_cap) {
     CK(hipStreamSynchronize(ctx->stream));
-    if (ctx->bin_tmp) CK(hipFree(ctx->bin_tmp));
     if (ctx->bin_recs) CK(hipFree(ctx->bin_recs));
-    ctx->bin_tmp = nullptr; ctx->bin_recs = nullptr; ctx->bin_cap = 0;
-    CK(hipMalloc((void**)&ctx->bin_tmp, sizeof(BinTmp) * n));
+    ctx->bin_recs = nullptr; ctx->bin_cap = 0;
     CK(hipMalloc((void**)&ctx->bin_recs, sizeof(BinRec) * n));
     ctx->bin_cap = n;
+  }
+  if (ctx->bin_strip && (long)g.B * chunk > ctx->bin_own_cap) {
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->bin_own) CK(hipFree(ctx->bin_own));
+    if (ctx->bin_own_cnt) CK(hipFree(ctx->bin_own_cnt));
+    ctx->bin_own = nullptr; ctx->bin_own_cnt = nullptr; ctx->bin_own_cap = 0;
+    CK(hipMalloc((void**)&ctx->bin_own, sizeof(unsigned short) * (size_t)g.B * chunk));
+    CK(hipMalloc((void**)&ctx->bin_own_cnt, sizeof(unsigned int) * (size_t)BIN_MAX_B * 16));
+    ctx->bin_own_cap = (long)g.B * chunk;
   }
   return EMAP_OK;
 }
@@ -622,14 +639,18 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
   const bool binned = ctx->n_pts > 0 && (ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts >= 131072));   // measured crossover on MI355X: 60-135 k points for 202^2 .. 1024^2 maps
   ctx->frame_binned = binned;
   if (binned) {
-    int rc = ensure_bins(ctx); if (rc) return rc;
+    // the ray-only sort bin exists when the parameters enable the visibility pass (a staged emap_rays call on a context without it
+    // marches the cloud in its own order instead of the sorted records)
+    int rc = ensure_bins(ctx, ctx->prm.enable_visibility_cleanup != 0); if (rc) return rc;
     const bool tm = ctx->stage_timing && ctx->in_update;
+    const Pose pose = make_pose(ctx, R, t);
+    unsigned short* own = ctx->bin_strip ? ctx->bin_own : nullptr;
     if (tm) CK(hipEventRecord(ctx->ev[ST_HIST], ctx->stream));
-    launch_bin_hist(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_tmp, ctx->bin_hist);
+    launch_bin_hist(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, own, ctx->bin_own_cnt);
     if (tm) CK(hipEventRecord(ctx->ev[ST_SCAN], ctx->stream));
     launch_bin_scan(ctx->stream, ctx->bg, ctx->bin_hist, ctx->bin_tile_total, ctx->bin_tile_start, ctx->bin_sync);
     if (tm) CK(hipEventRecord(ctx->ev[ST_SCATTER], ctx->stream));
-    launch_bin_scatter(ctx->stream, ctx->kp, ctx->bg, ctx->bin_tmp, ctx->n_pts, ctx->bin_hist, ctx->bin_tile_start, ctx->bin_recs);
+    launch_bin_scatter(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, ctx->bin_tile_start, ctx->bin_recs, own, ctx->bin_own_cnt);
     if (tm) CK(hipEventRecord(ctx->ev[ST_GATE], ctx->stream));        // the "gate" stage = per-tile error sums + k_gate
     if (ctx->gate_possible) launch_tile_count(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->slots);
   } else {
@@ -738,11 +759,12 @@ int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
   CKARG(ctx->committed || ctx->rays_fused, "emap_rays needs emap_commit first (rays read snapshot S1)");
   // newmap[3]: the tile kernel's dense plane, or the high halves of AccF::pts_inl (5 x u64 records) on the staged / atomic path
   const unsigned int* inl = ctx->rays_fused ? ctx->inl_plane : reinterpret_cast<const unsigned int*>(ctx->acc) + 1;
+  const bool sorted = ctx->frame_binned && ctx->bg.raybin;      // the sorted records hold EVERY valid point only with the ray-only bin
   launch_rays(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->rt, ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->accr,
               ctx->normal, ctx->ncells_alloc, ctx->frame, ctx->want_ray_stats, ctx->inert, inl, ctx->rays_fused ? 1 : (int)(sizeof(AccF) / 4),
               ctx->rays_fused ? ctx->ray_thr : nullptr,
-              ctx->frame_binned ? reinterpret_cast<const unsigned int*>(ctx->bin_recs) : nullptr,        // march in tile-sorted order
-              ctx->frame_binned ? ctx->bin_tile_start + ctx->bg.TB : nullptr);
+              sorted ? reinterpret_cast<const unsigned int*>(ctx->bin_recs) : nullptr,        // march in tile-sorted order
+              sorted ? ctx->bin_tile_start + ctx->bg.TB : nullptr);
   CK(hipGetLastError());
   return EMAP_OK;
 }

@@ -5,20 +5,31 @@
 // An LDS atomic is ~100x cheaper, but LDS is per workgroup -- so the points are first counting-sorted by map TILE
 // (16 rows x 64 columns = 1024 cells, the same tile the stencil kernels use) and each tile is then reduced by ONE
 // workgroup in LDS:
-//   k_bin_hist     per chunk of points: geometry once (fp16-quirk transform, validity, cell), per-block LDS histogram
-//                  over tiles, 16-byte staging record per point (tile, cell-in-tile, z, noise)
-//   k_bin_scan     exclusive scan of the (tile, block) histogram -> every block's write cursor, tile start offsets
-//   k_bin_scatter  per chunk: LDS cursor -> 16-byte record at its sorted position (a pure permutation, no map access)
+//   k_bin_hist     per chunk of points: geometry (fp16-quirk transform, validity, cell), per-block LDS histogram over tiles; the
+//                  block's histogram goes out as ONE contiguous row of the (block, tile) matrix
+//   k_bin_scan     exclusive scan of every matrix COLUMN (64 columns per workgroup, staged through LDS in 256-byte row segments)
+//                  -> every block's write cursor per tile; the last workgroup then scans the tile totals -> tile start offsets
+//   k_bin_scatter  per chunk: geometry AGAIN from the 12-byte point (cheaper than carrying a 16-byte staging record per point
+//                  through HBM: the round trip was 32 of the sort's 92 MB in round 2), LDS cursor -> 16-byte record at its
+//                  sorted position (no map access)
 //   k_tile_count   per tile: cells staged in LDS, drift-inlier test of every record (error_counting_kernel,
 //                  custom_kernels.py:317-335), wave-reduced error sums
 //   k_tile_fuse    per tile: pass 1 counts points/inliers per cell in LDS (newmap[4], newmap[3]); pass 2 is the Kalman
 //                  update of custom_kernels.py:160-197 accumulated with LDS atomics (64-bit fixed point, ordered max);
-//                  the epilogue writes the 40-byte AccF records with plain coalesced stores.
-// Everything downstream (commit, rays, average, ...) is unchanged and the AccF contents are BIT-IDENTICAL to the
-// atomic path of emap_kernels.hip (integer / fixed-point accumulators are order independent), which stays as the
-// path for clouds below ~130 k points (two launches with atomics have the lower latency there).  The LDS histogram holds at
-// most 16384 bins: maps with more tiles (> 4096^2 cells per context) sort into bins of 2, 4, ... vertically stacked tiles and
-// the tile kernels reduce one tile of the bin per workgroup (blockIdx.y), re-reading the bin's records from L2.
+//                  the epilogue commits + averages the cells (or writes the 40-byte AccF records on the staged path).
+// The order of the records INSIDE a tile is not defined (LDS cursors) and nothing depends on it: every accumulation downstream is
+// an integer / fixed-point sum or an ordered maximum.  The AccF contents are BIT-IDENTICAL to the atomic path of emap_kernels.hip,
+// which stays as the path for clouds below ~130 k points (two launches with atomics have the lower latency there).  The LDS
+// histogram holds at most 16384 bins: maps with more tiles (> 4096^2 cells per context) sort into bins of 2, 4, ... vertically
+// stacked tiles and the tile kernels reduce one tile of the bin per workgroup (blockIdx.y), re-reading the bin's records from L2.
+//
+// Row strips (multi-GPU, the cloud is replicated): a strip owns 1/G of the rows, so 1/G of a uniform cloud.  Both point passes
+// first run a CHEAP ownership test (the x row of the transform + one axis index: ~25 instructions instead of the ~100 of the full
+// geometry with its square root and fp64 compares) and compact the surviving lanes through an LDS list, so that the full geometry,
+// the histogram atomics and the record writes shrink with G; only the 12-byte stream over the cloud does not.  The list of a
+// block's owned points is written once by k_bin_hist (2 bytes per owned point) and re-used by k_bin_scatter.  With a visibility
+// pass every VALID point marches a ray through the strip (custom_kernels.py:199-258), validity needs the full geometry, and the
+// test is skipped.
 #include "emap_device.h"
 #include <cstring>
 #include <cstdlib>
@@ -26,11 +37,9 @@
 #define BIN_TR 16
 #define BIN_TC 64
 #define BIN_MAX_T 16384   /* LDS histogram / cursor arrays are dynamic: 4 B per tile */
+#define BIN_SUB 4096      /* points per compaction round of the strip variants (2-byte list entries in LDS) */
 
-struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, TB; };   // a bin = `sub` stacked 16x64 tiles (sub > 1 only for maps beyond 16384 tiles); TB = T + 1 sort bins:
-// the last one collects the valid points that fall OUTSIDE the owned cells -- they are not fused, but their rays are marched (k_rays walks the sorted records)
-struct __attribute__((aligned(16))) BinTmp { int tile; unsigned int lc; float z, v; };        // staging, point order
-struct __attribute__((aligned(16))) BinRec { unsigned int lc_inl; float z, v; unsigned int i; };  // sorted by tile
+// (BinGeo, BinRec: emap_device.h)
 
 // exclusive scan over the 256 threads of a block; returns the block total in `total`
 __device__ __forceinline__ unsigned int block_excl_scan(unsigned int x, unsigned int* sh /*[4]*/, unsigned int& total) {
@@ -48,86 +57,185 @@ __device__ __forceinline__ unsigned int block_excl_scan(unsigned int x, unsigned
   return base + inc - x;
 }
 
-template <int MODE, int BLK>
-__global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
-                                                        BinTmp* __restrict__ tmp, unsigned int* __restrict__ hist) {
-  extern __shared__ unsigned int h[];
-  for (int t = threadIdx.x; t < G.TB; t += BLK) h[t] = 0u;
-  __syncthreads();
-  const long base = (long)blockIdx.x * G.chunk;
-  for (long k = threadIdx.x; k < G.chunk; k += BLK) {
-    const long i = base + k;
-    if (i >= n) break;
-    float rx, ry, rz;
-    load_point(pts, i, stride, rx, ry, rz);
-    Geo g = geometry<MODE>(P, T, rx, ry, rz);
-    BinTmp r; r.tile = -1; r.lc = 0u; r.z = g.z; r.v = g.v;
-    const int lrow = phys_row(P, g.ix) - P.row0, pcol = phys_col(P, g.iy);      // tiles are PHYSICAL: 16 owned rows x 64 columns of memory
-    if (g.finite && g.valid && g.inside && lrow >= 0 && lrow < P.nrows) {
-      const int BR = BIN_TR * G.sub;
-      r.tile = (lrow / BR) * G.tiles_x + (pcol / BIN_TC);
-      r.lc = (unsigned int)((lrow % BR) * BIN_TC + (pcol % BIN_TC));
-      atomicAdd(&h[r.tile], 1u);
-    } else if (g.finite && g.valid) { r.tile = G.T; atomicAdd(&h[G.T], 1u); }      // ray only (custom_kernels.py:199-258 marches every valid point)
-    tmp[i] = r;
+// sort bin of a point (-1: none) and its cell inside the bin.  Tiles are PHYSICAL: 16 owned rows x 64 columns of memory.
+__device__ __forceinline__ int bin_of(const KP& P, const BinGeo& G, const Geo& g, unsigned int& lc) {
+  const int lrow = phys_row(P, g.ix) - P.row0, pcol = phys_col(P, g.iy);
+  lc = 0u;
+  if (!(g.finite && g.valid)) return -1;
+  if (g.inside && lrow >= 0 && lrow < P.nrows) {
+    const int BR = BIN_TR * G.sub;
+    lc = (unsigned int)((lrow % BR) * BIN_TC + (pcol % BIN_TC));
+    return (lrow / BR) * G.tiles_x + (pcol / BIN_TC);
   }
-  __syncthreads();
-  for (int t = threadIdx.x; t < G.TB; t += BLK) hist[(long)t * G.B + blockIdx.x] = h[t];
+  return G.raybin ? G.T : -1;             // ray only (custom_kernels.py:199-258 marches every valid point)
 }
 
-// block t: exclusive scan of hist[t][0..B) in place, tile_total[t] = sum; the LAST block to finish (ticket counter `sync`, re-armed
-// for the next frame) then scans the tile totals: tile_start[0..T] -- one launch instead of two (a launch costs ~4.5 us here, the
-// second scan was a single block).
-__global__ __launch_bounds__(EM_BLOCK) void k_bin_scan(BinGeo G, unsigned int* __restrict__ hist, unsigned int* __restrict__ tile_total,
+// the cheap ownership test of the strip variants: only the x row of transform_p (custom_kernels.py:54-57) and its axis index
+template <int MODE> __device__ __forceinline__ bool row_owned(const KP& P, const Pose& T, float rx, float ry, float rz) {
+  const float qx = Qf<MODE>(rx), qy = Qf<MODE>(ry), qz = Qf<MODE>(rz);
+  const float x = T.Rq[0] * qx + T.Rq[1] * qy + T.Rq[2] * qz + T.tq[0];          // same expression as geometry(): same bits
+  const int ix = axis_idx<MODE>(P, Qf<MODE>(x));
+  return (unsigned int)(phys_row(P, ix) - P.row0) < (unsigned int)P.nrows;        // (NaN coordinates index like geometry(): dropped there)
+}
+
+// Appends the block-local indices of this round's surviving lanes to an LDS list (order irrelevant): one ballot, one LDS atomic
+// per wave.  *cnt must be zero before the round and is valid after the next barrier.
+__device__ __forceinline__ void compact_push(bool keep, unsigned int k_local, unsigned short* list, unsigned int* cnt) {
+  const unsigned long long m = __ballot(keep);
+  if (!m) return;                                            // wave-uniform
+  unsigned int base = 0u;
+  if ((threadIdx.x & 63) == 0) base = atomicAdd(cnt, (unsigned int)__popcll(m));
+  base = (unsigned int)__shfl((int)base, 0, 64);
+  if (keep) list[base + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = (unsigned short)k_local;
+}
+
+// STRIP: the context owns a row strip and no visibility pass follows (see the header): cheap test + lane compaction; the owned
+// points of round r of block b are listed in own[(b * chunk) + r * BIN_SUB ...], their number in own_cnt[b * rounds + r].
+template <int MODE, int BLK, bool STRIP>
+__global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
+                                                  unsigned int* __restrict__ hist, unsigned short* __restrict__ own,
+                                                  unsigned int* __restrict__ own_cnt) {
+  extern __shared__ unsigned int h[];
+  for (int t = threadIdx.x; t < G.TB; t += BLK) h[t] = 0u;
+  const long base = (long)blockIdx.x * G.chunk;
+  if (!STRIP) {
+    __syncthreads();
+    for (long k = threadIdx.x; k < G.chunk; k += BLK) {
+      const long i = base + k;
+      if (i >= n) break;
+      float rx, ry, rz;
+      load_point(pts, i, stride, rx, ry, rz);
+      unsigned int lc;
+      const int bin = bin_of(P, G, geometry<MODE>(P, T, rx, ry, rz), lc);
+      if (bin >= 0) atomicAdd(&h[bin], 1u);
+    }
+  } else {
+    unsigned short* list = reinterpret_cast<unsigned short*>(h + G.pitch);       // BIN_SUB entries
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(list + BIN_SUB);
+    const int rounds = (int)(G.chunk / BIN_SUB);
+    for (int r = 0; r < rounds; ++r) {
+      if (threadIdx.x == 0) *cnt = 0u;
+      __syncthreads();
+      const long rb = base + (long)r * BIN_SUB;
+      for (int k = threadIdx.x; k < BIN_SUB; k += BLK) {                          // uniform trip count (ballots)
+        const long i = rb + k;
+        bool keep = false;
+        if (i < n) { float rx, ry, rz; load_point(pts, i, stride, rx, ry, rz); keep = row_owned<MODE>(P, T, rx, ry, rz); }
+        compact_push(keep, (unsigned int)k, list, cnt);
+      }
+      __syncthreads();
+      const unsigned int m = *cnt;
+      if (threadIdx.x == 0) own_cnt[(long)blockIdx.x * rounds + r] = m;
+      for (unsigned int j = threadIdx.x; j < m; j += BLK) {
+        const unsigned int k = list[j];
+        own[rb + j] = (unsigned short)k;
+        float rx, ry, rz;
+        load_point(pts, rb + k, stride, rx, ry, rz);                              // second touch: L1 / L2
+        unsigned int lc;
+        const int bin = bin_of(P, G, geometry<MODE>(P, T, rx, ry, rz), lc);
+        if (bin >= 0) atomicAdd(&h[bin], 1u);
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  unsigned int* row = hist + (long)blockIdx.x * G.pitch;
+  for (int t = threadIdx.x; t < G.pitch; t += BLK) row[t] = t < G.TB ? h[t] : 0u;
+}
+
+// Column scan of the (block, tile) matrix hist[B][pitch]: workgroup g owns the 64 columns [64 g, 64 g + 64) -- one lane per column --
+// and its 16 waves share the rows: in a slab of 256 rows wave w takes 16 consecutive rows, requests all 16 of its 256-byte row
+// segments at once (the kernel is one memory round trip per slab, not bandwidth), sums them per column, exchanges the 16 partial
+// sums through LDS and writes its rows back as exclusive prefixes: hist[b][t] becomes the number of points of tile t in blocks < b,
+// tile_total[t] the column sum.  The LAST workgroup to finish (ticket counter `sync`, re-armed for the next frame) then scans the
+// tile totals: tile_start[0..TB] -- one launch instead of two.
+#define SCAN_TT 64
+#define SCAN_BLK 1024
+#define SCAN_RPW 16      /* rows per wave and slab */
+__global__ __launch_bounds__(SCAN_BLK) void k_bin_scan(BinGeo G, unsigned int* __restrict__ hist, unsigned int* __restrict__ tile_total,
                                                         unsigned int* __restrict__ tile_start, unsigned int* __restrict__ sync) {
+  constexpr int NW = SCAN_BLK / 64;
+  __shared__ unsigned int part[NW][SCAN_TT];
   __shared__ unsigned int sh[EM_BLOCK / 64];
   __shared__ bool s_last;
-  unsigned int* row = hist + (long)blockIdx.x * G.B;
-  unsigned int running = 0;
-  for (int b0 = 0; b0 < G.B; b0 += EM_BLOCK) {
-    const int b = b0 + threadIdx.x;
-    unsigned int x = b < G.B ? row[b] : 0u, tot;
-    unsigned int ex = block_excl_scan(x, sh, tot);
-    if (b < G.B) row[b] = running + ex;
-    running += tot;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = blockIdx.x * SCAN_TT + lane;
+  const bool col_ok = t < G.pitch;
+  unsigned int carry = 0u;                                 // per column (lane), identical in all waves
+  for (int sl = 0; sl < G.B; sl += NW * SCAN_RPW) {
+    const int r0 = sl + w * SCAN_RPW;
+    unsigned int v[SCAN_RPW];
+#pragma unroll
+    for (int j = 0; j < SCAN_RPW; ++j) v[j] = (col_ok && r0 + j < G.B) ? hist[(long)(r0 + j) * G.pitch + t] : 0u;
+    unsigned int sum = 0u;
+#pragma unroll
+    for (int j = 0; j < SCAN_RPW; ++j) sum += v[j];
+    part[w][lane] = sum;
+    __syncthreads();
+    unsigned int run = carry, tot = 0u;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { const unsigned int x = part[k][lane]; if (k < w) run += x; tot += x; }
+#pragma unroll
+    for (int j = 0; j < SCAN_RPW; ++j) { if (col_ok && r0 + j < G.B) hist[(long)(r0 + j) * G.pitch + t] = run; run += v[j]; }
+    carry += tot;
+    __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    // the total goes out as a device-coherent store and is read back with device-coherent loads; only its ORDER against the
-    // ticket matters (wait for the store's acknowledgement).  An agent-scope fence would write back / invalidate the XCD's whole L2
-    // per workgroup (measured: 10 -> 30 us for this kernel).
-    __hip_atomic_store(&tile_total[blockIdx.x], running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the totals go out as device-coherent stores and are read back with device-coherent loads; only their ORDER against the
+  // ticket matters (wait for the stores' acknowledgement).  An agent-scope fence would write back / invalidate the XCD's whole L2
+  // per workgroup (measured: 10 -> 30 us for this kernel).
+  if (w == 0) {
+    if (t < G.TB) __hip_atomic_store(&tile_total[t], carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_s_waitcnt(0);
-    s_last = last_block_ticket(sync, blockIdx.x, gridDim.x);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) s_last = last_block_ticket(sync, blockIdx.x, gridDim.x);
   }
   __syncthreads();
   if (!s_last) return;
-  running = 0;
-  for (int t0 = 0; t0 < G.TB; t0 += EM_BLOCK) {
-    const int t = t0 + threadIdx.x;
-    unsigned int x = t < G.TB ? __hip_atomic_load(&tile_total[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u, tot;
+  if (threadIdx.x >= EM_BLOCK) return;                     // the tail is a 256-thread scan (block_excl_scan); no barrier involves the others below
+  unsigned int running = 0;
+  for (int tb = 0; tb < G.TB; tb += EM_BLOCK) {
+    const int tt = tb + threadIdx.x;
+    unsigned int x = tt < G.TB ? __hip_atomic_load(&tile_total[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u, tot;
     unsigned int ex = block_excl_scan(x, sh, tot);
-    if (t < G.TB) tile_start[t] = running + ex;
+    if (tt < G.TB) tile_start[tt] = running + ex;
     running += tot;
   }
-  if (threadIdx.x == 0) tile_start[G.TB] = running;          // = number of sorted records (all valid points)
+  if (threadIdx.x == 0) tile_start[G.TB] = running;          // = number of sorted records
 }
 
-template <int BLK>
-__global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, BinGeo G, const BinTmp* __restrict__ tmp, long n,
-                                                           const unsigned int* __restrict__ hist, const unsigned int* __restrict__ tile_start,
-                                                           BinRec* __restrict__ recs) {
+template <int MODE, int BLK, bool STRIP>
+__global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
+                                                     const unsigned int* __restrict__ hist, const unsigned int* __restrict__ tile_start,
+                                                     BinRec* __restrict__ recs, const unsigned short* __restrict__ own,
+                                                     const unsigned int* __restrict__ own_cnt) {
   extern __shared__ unsigned int cur[];
-  for (int t = threadIdx.x; t < G.TB; t += BLK) cur[t] = tile_start[t] + hist[(long)t * G.B + blockIdx.x];
+  const unsigned int* row = hist + (long)blockIdx.x * G.pitch;
+  for (int t = threadIdx.x; t < G.TB; t += BLK) cur[t] = tile_start[t] + row[t];
   __syncthreads();
   const long base = (long)blockIdx.x * G.chunk;
-  for (long k = threadIdx.x; k < G.chunk; k += BLK) {      // a pure permutation: staging record in, sorted record out, no map access
-    const long i = base + k;
-    if (i >= n) break;
-    const BinTmp r = tmp[i];
-    if (r.tile < 0) continue;
-    const unsigned int pos = atomicAdd(&cur[r.tile], 1u);
-    BinRec o; o.lc_inl = r.lc; o.z = r.z; o.v = r.v; o.i = (unsigned int)i;
+  auto place = [&](long i) {                                 // geometry once more, LDS cursor -> sorted position; no map access
+    float rx, ry, rz;
+    load_point(pts, i, stride, rx, ry, rz);
+    const Geo g = geometry<MODE>(P, T, rx, ry, rz);
+    unsigned int lc;
+    const int bin = bin_of(P, G, g, lc);
+    if (bin < 0) return;
+    const unsigned int pos = atomicAdd(&cur[bin], 1u);
+    BinRec o; o.lc_inl = lc; o.z = g.z; o.v = g.v; o.i = (unsigned int)i;
     recs[pos] = o;
+  };
+  if (!STRIP) {
+    for (long k = threadIdx.x; k < G.chunk; k += BLK) {
+      const long i = base + k;
+      if (i >= n) break;
+      place(i);
+    }
+  } else {
+    const int rounds = (int)(G.chunk / BIN_SUB);
+    for (int r = 0; r < rounds; ++r) {
+      const long rb = base + (long)r * BIN_SUB;
+      const unsigned int m = own_cnt[(long)blockIdx.x * rounds + r];
+      for (unsigned int j = threadIdx.x; j < m; j += BLK) place(rb + own[rb + j]);
+    }
   }
 }
 
@@ -336,45 +444,61 @@ static int env_block(const char* name, int dflt) {
   if (const char* e = getenv(name)) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) return v; }
   return dflt;
 }
-template <int BLK>
-static void launch_bin_hist_t(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride, BinTmp* tmp,
-                              unsigned int* hist) {
-  static bool raised = false;          // 16384 tiles + the ray-only bin: 4 bytes past the default 64 KB window
-  if (!raised) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_hist<0, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_hist<1, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    raised = true;
-  }
-  if (P.mode == 0) hipLaunchKernelGGL((k_bin_hist<0, BLK>), dim3(G.B), dim3(BLK), sizeof(unsigned int) * G.TB, s, P, T, G, pts, n, stride, tmp, hist);
-  else hipLaunchKernelGGL((k_bin_hist<1, BLK>), dim3(G.B), dim3(BLK), sizeof(unsigned int) * G.TB, s, P, T, G, pts, n, stride, tmp, hist);
+// dynamic LDS of the two point passes: the histogram / cursor row [+ the compaction list and its counter on strips]
+static size_t bin_lds_bytes(const BinGeo& G, bool strip) { return sizeof(unsigned int) * G.pitch + (strip ? sizeof(unsigned short) * BIN_SUB + 16 : 0); }
+// hipFuncSetAttribute is per device: keep one flag per (kernel instantiation, device)
+#define EM_MAX_DEV 64
+template <class K> static void raise_lds(K kern, bool (&raised)[EM_MAX_DEV], int bytes) {
+  int dev = 0; (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= EM_MAX_DEV) dev = 0;
+  if (!raised[dev] && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) raised[dev] = true;
 }
-void launch_bin_hist(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride, BinTmp* tmp,
-                     unsigned int* hist) {
+template <int MODE, int BLK, bool STRIP>
+static void launch_bin_hist_i(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
+                              unsigned int* hist, unsigned short* own, unsigned int* own_cnt) {
+  static bool raised[EM_MAX_DEV];                  // 16384 tiles + the ray-only bin (+ list): past the default 64 KB window
+  raise_lds(k_bin_hist<MODE, BLK, STRIP>, raised, 80 * 1024);
+  hipLaunchKernelGGL((k_bin_hist<MODE, BLK, STRIP>), dim3(G.B), dim3(BLK), bin_lds_bytes(G, STRIP), s, P, T, G, pts, n, stride, hist, own, own_cnt);
+}
+template <int BLK>
+static void launch_bin_hist_t(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
+                              unsigned int* hist, unsigned short* own, unsigned int* own_cnt) {
+  if (own) { if (P.mode == 0) launch_bin_hist_i<0, BLK, true>(s, P, T, G, pts, n, stride, hist, own, own_cnt); else launch_bin_hist_i<1, BLK, true>(s, P, T, G, pts, n, stride, hist, own, own_cnt); }
+  else { if (P.mode == 0) launch_bin_hist_i<0, BLK, false>(s, P, T, G, pts, n, stride, hist, own, own_cnt); else launch_bin_hist_i<1, BLK, false>(s, P, T, G, pts, n, stride, hist, own, own_cnt); }
+}
+// own != nullptr selects the strip variants (cheap ownership test + lane compaction)
+void launch_bin_hist(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
+                     unsigned int* hist, unsigned short* own, unsigned int* own_cnt) {
   static const int blk = env_block("EMAP_HIST_BLOCK", 1024);
   switch (blk) {
-    case 1024: launch_bin_hist_t<1024>(s, P, T, G, pts, n, stride, tmp, hist); break;
-    case 512: launch_bin_hist_t<512>(s, P, T, G, pts, n, stride, tmp, hist); break;
-    default: launch_bin_hist_t<256>(s, P, T, G, pts, n, stride, tmp, hist);
+    case 1024: launch_bin_hist_t<1024>(s, P, T, G, pts, n, stride, hist, own, own_cnt); break;
+    case 512: launch_bin_hist_t<512>(s, P, T, G, pts, n, stride, hist, own, own_cnt); break;
+    default: launch_bin_hist_t<256>(s, P, T, G, pts, n, stride, hist, own, own_cnt);
   }
 }
 void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigned int* tile_total, unsigned int* tile_start, unsigned int* sync) {
-  hipLaunchKernelGGL(k_bin_scan, dim3(G.TB), dim3(EM_BLOCK), 0, s, G, hist, tile_total, tile_start, sync);
+  hipLaunchKernelGGL(k_bin_scan, dim3((G.TB + SCAN_TT - 1) / SCAN_TT), dim3(SCAN_BLK), 0, s, G, hist, tile_total, tile_start, sync);
 }
-void launch_bin_scatter(hipStream_t s, const KP& P, const BinGeo& G, const BinTmp* tmp, long n, const unsigned int* hist,
-                        const unsigned int* tile_start, BinRec* recs) {
+template <int MODE, int BLK, bool STRIP>
+static void launch_bin_scatter_i(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
+                                 const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const unsigned short* own, const unsigned int* own_cnt) {
+  static bool raised[EM_MAX_DEV];
+  raise_lds(k_bin_scatter<MODE, BLK, STRIP>, raised, 80 * 1024);
+  hipLaunchKernelGGL((k_bin_scatter<MODE, BLK, STRIP>), dim3(G.B), dim3(BLK), sizeof(unsigned int) * G.pitch, s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt);
+}
+template <int BLK>
+static void launch_bin_scatter_t(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
+                                 const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const unsigned short* own, const unsigned int* own_cnt) {
+  if (own) { if (P.mode == 0) launch_bin_scatter_i<0, BLK, true>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); else launch_bin_scatter_i<1, BLK, true>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); }
+  else { if (P.mode == 0) launch_bin_scatter_i<0, BLK, false>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); else launch_bin_scatter_i<1, BLK, false>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); }
+}
+void launch_bin_scatter(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
+                        const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const unsigned short* own, const unsigned int* own_cnt) {
   static const int blk = env_block("EMAP_SCATTER_BLOCK", 512);
-  const size_t sh = sizeof(unsigned int) * G.TB;
-  static bool raised = false;
-  if (!raised) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    raised = true;
-  }
   switch (blk) {
-    case 1024: hipLaunchKernelGGL(k_bin_scatter<1024>, dim3(G.B), dim3(1024), sh, s, P, G, tmp, n, hist, tile_start, recs); break;
-    case 512: hipLaunchKernelGGL(k_bin_scatter<512>, dim3(G.B), dim3(512), sh, s, P, G, tmp, n, hist, tile_start, recs); break;
-    default: hipLaunchKernelGGL(k_bin_scatter<256>, dim3(G.B), dim3(256), sh, s, P, G, tmp, n, hist, tile_start, recs);
+    case 1024: launch_bin_scatter_t<1024>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); break;
+    case 512: launch_bin_scatter_t<512>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); break;
+    default: launch_bin_scatter_t<256>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt);
   }
 }
 void launch_tile_count(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cells cells,

@@ -332,6 +332,14 @@ __device__ __forceinline__ bool overlap_cell(const KP& P, const OverlapArgs& O, 
   return ch;
 }
 
+// ---- tile-binned scatter (emap_binned.hip) --------------------------------------------------------------------------------
+// a bin = `sub` stacked 16 x 64 tiles (sub > 1 only for maps beyond 16384 tiles); TB = T + 1 sort bins: the last one collects the
+// valid points that fall OUTSIDE the owned cells when a visibility pass follows (raybin) -- they are not fused, but their rays are
+// marched (k_rays walks the sorted records).  B blocks of `chunk` points; pitch = row pitch of the (block, tile) matrix in words
+// (a multiple of 4).
+struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, TB, pitch, raybin; };
+struct __attribute__((aligned(16))) BinRec { unsigned int lc_inl; float z, v; unsigned int i; };  // sorted by tile
+
 // Per-frame description of the RGB / semantic point fusion.  The leading members mirror emap_sem_spec (include/emap_hip.h);
 // sum_K / sum_q are derived by emap_semantic_update: kinds 2 (class_bayesian) and 3 (bayesian_inference) reproduce the
 // reference launch decode id = i / K, layer = i % K with size N (fusion/pointcloud_class_bayesian.py:28-29,67;

@@ -592,7 +592,7 @@ __device__ __forceinline__ float sqrt_rn_ge1(float x) {
 }
 // exp(-a) of the traversability epilogue (traversability_filter.py:44, torch.exp in the reference), a >= 0.  Built from operations
 // that exist bit for bit on the host as well -- round-to-nearest-even, fused multiply-adds, ldexp -- so that the oracle evaluates the
-// SAME function (oracle/emap_oracle.c: exp_neg_det) and the traversability plane, which feeds the drift-inlier decision of the next
+// SAME function (the CPU checker restates this sequence literally) and the traversability plane, which feeds the drift-inlier decision of the next
 // frame (custom_kernels.py:329: traversability > traversability_inlier), compares bit for bit: n = rint(x log2 e), r = x - n ln 2
 // (two-constant reduction), e^r by the degree-6 Taylor polynomial (|r| <= 0.347: truncation 1.2e-7 relative), 2^n by ldexp.  Within
 // 3 ulp of expf; the hardware exponential (v_exp_f32) is faster by 8 instructions per cell but not reproducible off the GPU.

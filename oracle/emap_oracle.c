@@ -117,14 +117,17 @@ static inline int is_valid(const eo_params* P, float x_, float y_, float z_, flo
 typedef struct { float x, y, z, v; int idx, valid, inside, finite; } pt_t;
 
 /* Optional OpenMP parallelism over points / cells for bench.py's cpu_baseline leg ("all cores"): eo_set_threads(n).
- * With n == 1 (default; what every parity test uses) execution is sequential and bit-reproducible; with n > 1 the
- * accumulators are updated atomically (double adds in arbitrary order => last-bit differences, same contract). */
+ * Every accumulator of the contract is an INTEGER -- counts, and the three sums in fixed point (drift error Q27.36, new heights
+ * Q31.32, new variances and validity decrements Q23.40: each addend rounded to nearest once, llrint) -- so a result does not
+ * depend on the order of the points or on the thread count, and the HIP kernels (which accumulate the same integers in LDS / HBM)
+ * reproduce every plane BIT FOR BIT.  The reference itself accumulates with racing float32 atomics; any fixed summation order is
+ * one outcome it can produce within a few ulp, and the restatement stays pinned to its compiled kernels within 1e-5. */
+#define EO_SCALE_H 4294967296.0          /* 2^32 */
+#define EO_SCALE_V 1099511627776.0       /* 2^40 */
+#define EO_SCALE_E 68719476736.0         /* 2^36 */
 static int g_threads = 1;
 void eo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
-static inline void atomic_add_f64(double* p, double v) {
-  uint64_t* u = (uint64_t*)p; uint64_t old = __atomic_load_n(u, __ATOMIC_RELAXED), neu;
-  do { double d; memcpy(&d, &old, 8); d += v; memcpy(&neu, &d, 8); } while (!__atomic_compare_exchange_n(u, &old, neu, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
-}
+static inline long long fix_of(double x, double scale) { return llrint(x * scale); }   /* round to nearest even, like __double2ll_rn */
 static inline void atomic_max_u64(uint64_t* p, uint64_t v) {
   uint64_t old = __atomic_load_n(p, __ATOMIC_RELAXED);
   while (old < v && !__atomic_compare_exchange_n(p, &old, v, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
@@ -165,11 +168,11 @@ void eo_point_index(const eo_params* P, const float* pts, long n, long stride, c
   }
 }
 
-/* Phase A: error_counting_kernel (custom_kernels.py:280-345). err_sum is accumulated exactly (double). */
+/* Phase A: error_counting_kernel (custom_kernels.py:280-345). err_sum is accumulated in Q27.36 and returned as a double. */
 void eo_count(const eo_params* P, const float* map, const float* pts, long n, long stride, const float* R,
               const float* t, uint32_t* n_pts, uint32_t* n_inl, double* err_sum, uint32_t* err_cnt) {
   const long L = (long)P->cell_n * P->cell_n;
-  double es = 0.0; unsigned long ec = 0;
+  long long es = 0; unsigned long ec = 0;
 #pragma omp parallel for num_threads(g_threads) reduction(+ : es, ec) schedule(static) if (g_threads > 1)
   for (long i = 0; i < n; ++i) {
     pt_t g = point_geometry(P, pts + i * stride, R, t);
@@ -177,13 +180,13 @@ void eo_count(const eo_params* P, const float* map, const float* pts, long n, lo
     float h = map[g.idx], v = map[L + g.idx], valid = map[2 * L + g.idx], trav = map[3 * L + g.idx];
     if (valid > 0.5f && (double)fabsf(h - g.z) < (double)v * P->mahalanobis_thresh &&
         (double)v < P->drift_compensation_variance_inlier / 2.0 && (double)trav > P->traversability_inlier) {
-      es += (double)(g.z - h);
+      es += fix_of((double)(g.z - h), EO_SCALE_E);
       ec += 1;
       __atomic_fetch_add(&n_inl[g.idx], 1u, __ATOMIC_RELAXED);
     }
     __atomic_fetch_add(&n_pts[g.idx], 1u, __ATOMIC_RELAXED);
   }
-  *err_sum += es; *err_cnt += (uint32_t)ec;
+  *err_sum += (double)es / EO_SCALE_E; *err_cnt += (uint32_t)ec;
 }
 
 /* Phase A': drift gate (elevation_mapping.py:346-357). Returns the shift to add to plane 0 (0 if none);
@@ -205,8 +208,8 @@ float eo_gate(const eo_params* P, double err_sum, uint32_t err_cnt, double posit
  * (drift shift already applied). Accumulators only; `latest_h` = new_h of the accepted point with the
  * largest input index (sequential last-writer of :191). */
 void eo_fuse(const eo_params* P, const float* map, const float* pts, long n, long stride, const float* R,
-             const float* t, const uint32_t* n_pts, double* sum_h, double* sum_v, uint32_t* cnt, uint32_t* n_out,
-             float* latest_h) {
+             const float* t, const uint32_t* n_pts, long long* sum_h /* Q31.32 */, long long* sum_v /* Q23.40 */, uint32_t* cnt,
+             uint32_t* n_out, float* latest_h) {
   const long L = (long)P->cell_n * P->cell_n;
   if (g_threads <= 1) {
     for (long i = 0; i < n; ++i) {
@@ -218,7 +221,7 @@ void eo_fuse(const eo_params* P, const float* map, const float* pts, long n, lon
           (double)g.z < (double)map_h - (double)map_v * P->mahalanobis_thresh / (double)num_points) continue;
       float new_h = (map_h * g.v + g.z * map_v) / (map_v + g.v);
       float new_v = (map_v * g.v) / (map_v + g.v);
-      sum_h[g.idx] += (double)new_h; sum_v[g.idx] += (double)new_v; cnt[g.idx] += 1;
+      sum_h[g.idx] += fix_of((double)new_h, EO_SCALE_H); sum_v[g.idx] += fix_of((double)new_v, EO_SCALE_V); cnt[g.idx] += 1;
       latest_h[g.idx] = new_h;
     }
     return;
@@ -234,7 +237,8 @@ void eo_fuse(const eo_params* P, const float* map, const float* pts, long n, lon
         (double)g.z < (double)map_h - (double)map_v * P->mahalanobis_thresh / (double)num_points) continue;
     float new_h = (map_h * g.v + g.z * map_v) / (map_v + g.v);
     float new_v = (map_v * g.v) / (map_v + g.v);
-    atomic_add_f64(&sum_h[g.idx], (double)new_h); atomic_add_f64(&sum_v[g.idx], (double)new_v);
+    __atomic_fetch_add(&sum_h[g.idx], fix_of((double)new_h, EO_SCALE_H), __ATOMIC_RELAXED);
+    __atomic_fetch_add(&sum_v[g.idx], fix_of((double)new_v, EO_SCALE_V), __ATOMIC_RELAXED);
     __atomic_fetch_add(&cnt[g.idx], 1u, __ATOMIC_RELAXED);
     atomic_max_u64(&key[g.idx], ((uint64_t)(i + 1) << 32) | f2u(new_h));
   }
@@ -255,10 +259,10 @@ void eo_commit(const eo_params* P, float* map, const uint32_t* cnt, const uint32
 }
 
 /* Phase C: visibility-cleanup part of add_points_kernel (custom_kernels.py:198-259) against snapshot S1.
- * Outputs (accumulators, applied by eo_average): ray_dec = sum of validity decrements (exact, double),
+ * Outputs (accumulators, applied by eo_average): ray_dec = sum of validity decrements (Q23.40),
  * ray_hits = number of penetrations, ray_upper = min qualifying nz (init +INF). */
 void eo_rays(const eo_params* P, const float* map, const float* normal, const uint32_t* n_inl, const float* pts,
-             long n, long stride, const float* R, const float* t, double* ray_dec, uint32_t* ray_hits,
+             long n, long stride, const float* R, const float* t, long long* ray_dec, uint32_t* ray_hits,
              float* ray_upper, uint64_t* visits_out) {
   const long L = (long)P->cell_n * P->cell_n;
   uint64_t visits = 0;
@@ -295,8 +299,8 @@ void eo_rays(const eo_params* P, const float* map, const float* normal, const ui
         float ip = Q(rx) * Q(normal[nidx]) + Q(ry) * Q(normal[L + nidx]) + Q(rz) * Q(normal[2 * L + nidx]);
         if ((double)fabsf(ip) < P->cleanup_cos_thresh) continue;
         if ((double)(float)n_inl[nidx] > P->wall_num_thresh && (double)time < 1.0) continue;
-        const double dec = (double)(float)(-P->cleanup_step / ((double)ray_length / P->max_ray_length));
-        if (mt) { atomic_add_f64(&ray_dec[nidx], dec); __atomic_fetch_add(&ray_hits[nidx], 1u, __ATOMIC_RELAXED); }
+        const long long dec = fix_of((double)(float)(-P->cleanup_step / ((double)ray_length / P->max_ray_length)), EO_SCALE_V);
+        if (mt) { __atomic_fetch_add(&ray_dec[nidx], dec, __ATOMIC_RELAXED); __atomic_fetch_add(&ray_hits[nidx], 1u, __ATOMIC_RELAXED); }
         else { ray_dec[nidx] += dec; ray_hits[nidx] += 1; }
         if (nz < upper || is_upper < 0.5f) { if (mt) atomic_min_f32(&ray_upper[nidx], nz); else if (nz < ray_upper[nidx]) ray_upper[nidx] = nz; }
       }
@@ -306,21 +310,21 @@ void eo_rays(const eo_params* P, const float* map, const float* normal, const ui
 }
 
 /* Phase D: ray commit + average_map_kernel (custom_kernels.py:348-389) */
-void eo_average(const eo_params* P, float* map, const double* sum_h, const double* sum_v, const uint32_t* cnt,
-                const double* ray_dec, const uint32_t* ray_hits, const float* ray_upper) {
+void eo_average(const eo_params* P, float* map, const long long* sum_h, const long long* sum_v, const uint32_t* cnt,
+                const long long* ray_dec, const uint32_t* ray_hits, const float* ray_upper) {
   const long L = (long)P->cell_n * P->cell_n;
   const float ov = (float)P->outlier_variance;
 #pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
   for (long c = 0; c < L; ++c) {
     if (ray_hits && ray_hits[c]) {
-      map[2 * L + c] = map[2 * L + c] + (float)ray_dec[c];
+      map[2 * L + c] = map[2 * L + c] + (float)((double)ray_dec[c] / EO_SCALE_V);
       map[L + c] = map[L + c] + ov * (float)ray_hits[c];
     }
     if (ray_upper && ray_upper[c] < INFINITY) { map[5 * L + c] = ray_upper[c]; map[6 * L + c] = 1.0f; }
     float valid0 = map[2 * L + c];
     if (cnt[c] > 0) {
       float fc = (float)cnt[c];
-      float nh = (float)(sum_h[c] / (double)cnt[c]), nv = (float)(sum_v[c] / (double)cnt[c]);
+      float nh = (float)(((double)sum_h[c] / EO_SCALE_H) / (double)cnt[c]), nv = (float)(((double)sum_v[c] / EO_SCALE_V) / (double)cnt[c]);
       (void)fc;
       if ((double)nv > P->max_variance) { map[c] = 0; map[L + c] = (float)P->initial_variance; map[2 * L + c] = 0; }
       else { map[c] = nh; map[L + c] = nv; map[2 * L + c] = 1; }
@@ -697,7 +701,7 @@ void eo_frame(const eo_params* P, float* map, float* normal, float* trav_input, 
               const float* R, const float* t, double position_noise, double orientation_noise, eo_stats* st) {
   const int C = P->cell_n; const long L = (long)C * C;
   uint32_t* n_pts = calloc(L, 4); uint32_t* n_inl = calloc(L, 4); uint32_t* cnt = calloc(L, 4); uint32_t* n_out = calloc(L, 4);
-  double* sum_h = calloc(L, 8); double* sum_v = calloc(L, 8); float* latest = calloc(L, 4);
+  long long* sum_h = calloc(L, 8); long long* sum_v = calloc(L, 8); float* latest = calloc(L, 4);
   memset(st, 0, sizeof *st);
   eo_count(P, map, pts, n, stride, R, t, n_pts, n_inl, &st->err_sum, &st->err_cnt);
   st->shift = eo_gate(P, st->err_sum, st->err_cnt, position_noise, orientation_noise, &st->mean_error, &st->gate_fired);
@@ -707,7 +711,7 @@ void eo_frame(const eo_params* P, float* map, float* normal, float* trav_input, 
   }
   eo_fuse(P, map, pts, n, stride, R, t, n_pts, sum_h, sum_v, cnt, n_out, latest);
   eo_commit(P, map, cnt, n_out, latest);
-  double* ray_dec = NULL; uint32_t* ray_hits = NULL; float* ray_upper = NULL;
+  long long* ray_dec = NULL; uint32_t* ray_hits = NULL; float* ray_upper = NULL;
   if (P->enable_visibility_cleanup) {
     ray_dec = calloc(L, 8); ray_hits = calloc(L, 4); ray_upper = malloc(L * 4);
     for (long c = 0; c < L; ++c) ray_upper[c] = INFINITY;

@@ -171,7 +171,7 @@ class OracleMap:
     def fuse(self, points, R, t):
         pts, C = _pts(points), self.C
         R = np.ascontiguousarray(R, np.float32).ravel(); t = np.ascontiguousarray(t, np.float32)
-        sum_h, sum_v = np.zeros((C, C)), np.zeros((C, C))
+        sum_h, sum_v = np.zeros((C, C), np.int64), np.zeros((C, C), np.int64)      # fixed point: Q31.32, Q23.40 (emap_oracle.c)
         cnt, n_out, latest = np.zeros((C, C), np.uint32), np.zeros((C, C), np.uint32), np.zeros((C, C), np.float32)
         lib().eo_fuse(ct.byref(self.P), _p(self.elevation_map), _p(pts), ct.c_long(pts.shape[0]), ct.c_long(pts.shape[1]),
                       _p(R), _p(t), _p(self.last["n_pts"]), _p(sum_h), _p(sum_v), _p(cnt), _p(n_out), _p(latest))
@@ -184,7 +184,7 @@ class OracleMap:
     def rays(self, points, R, t):
         pts, C = _pts(points), self.C
         R = np.ascontiguousarray(R, np.float32).ravel(); t = np.ascontiguousarray(t, np.float32)
-        dec, hits = np.zeros((C, C)), np.zeros((C, C), np.uint32)
+        dec, hits = np.zeros((C, C), np.int64), np.zeros((C, C), np.uint32)          # dec: Q23.40
         upper = np.full((C, C), np.inf, np.float32)
         visits = ct.c_uint64(0)
         lib().eo_rays(ct.byref(self.P), _p(self.elevation_map), _p(self.normal_map), _p(self.last["n_inl"]), _p(pts),

@@ -30,3 +30,18 @@ def assert_planes_close(a, b, atol=1e-5, rtol=1e-5, names=PLANE_NAMES, max_bad=0
         name = names[k] if k < len(names) else str(k)
         assert n <= max_bad, "%s plane %s: %d cells differ, max |d| = %g (first at %s: %r vs %r)" % (
             what, name, n, np.nanmax(np.abs(x - y)), tuple(np.argwhere(bad)[0]), x[bad][0], y[bad][0])
+
+
+def assert_planes_equal(a, b, names=PLANE_NAMES, what=""):
+    """BIT-FOR-BIT equality of whole planes.  The oracle accumulates the same integers / fixed-point sums as the HIP kernels
+    (oracle/emap_oracle.c) and both use the same correctly rounded float operations, so any difference is a defect, not rounding."""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    for k in range(a.shape[0]):
+        x, y = a[k].view(np.uint32), b[k].view(np.uint32)
+        if not np.array_equal(x, y):
+            bad = x != y
+            name = names[k] if k < len(names) else str(k)
+            i = tuple(np.argwhere(bad)[0])
+            raise AssertionError("%s plane %s: %d cells differ bitwise, max |d| = %g (first at %s: %r vs %r)" % (
+                what, name, int(bad.sum()), float(np.nanmax(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)))), i, a[k][i], b[k][i]))

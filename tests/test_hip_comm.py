@@ -78,8 +78,13 @@ def _fake_rccl():
 
 
 @pytest.mark.parametrize("moves", [False, True])
-@pytest.mark.parametrize("world,cfg_name,C,N", [(2, "yaml", 130, 40000), (3, "yaml_norays", 202, 60000), (4, "default", 202, 40000)])
-def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, C, N, moves, weights):
+@pytest.mark.parametrize("world,cfg_name,C,N,scatter", [(2, "yaml", 130, 40000, "auto"), (3, "yaml_norays", 202, 60000, "auto"), (4, "default", 202, 40000, "auto"),
+                                                        # the tile-binned scatter on strips: without a visibility pass the point passes run the cheap
+                                                        # ownership test + lane compaction (k_bin_hist / k_bin_scatter<.., STRIP>), with one they keep the
+                                                        # ray-only bin; 8 strips of the 1024^2 map with a cloud large enough for the automatic choice
+                                                        (3, "yaml_norays", 202, 60000, "binned"), (4, "yaml", 130, 40000, "binned"),
+                                                        (8, "yaml_norays", 1024, 300000, "auto")])
+def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, C, N, scatter, moves, weights):
     """emap_comm_init + emap_update_sharded with SEVERAL ranks: the library's own orchestration (all-reduce between count and fuse,
     in-place halo send / recv on the second stream, interior / boundary stencil split) driven through a stand-in for the nine RCCL
     entry points whose ranks are threads of this process (RCCL refuses two ranks on one GPU).  Every strip must equal the rows of
@@ -99,6 +104,7 @@ def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, 
     clouds = [fx.cloud(C, N, f, dz=dz) for f, dz in enumerate((0.0, -0.02, -0.1))]
     MV = [(0.13, -0.3, 0.05), (-0.10, 0.17, -0.02), None] if moves else [None] * 3      # move_to between the frames: ring halo, normal rows (after a move a strip's view of the un-shifted normals has holes until the next frame)
     full = ElevationMap(parameter_from(cfg, C, "reference_fp16", weights))
+    full.set_scatter_mode(scatter)
     for p, mv in zip(clouds, MV):
         full.update_map_with_kernel(p, [], R, (t + full.center).astype(np.float32), 1.0, 1.0)
         for _ in range(6):
@@ -115,6 +121,7 @@ def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, 
     def run(rank):
         try:
             eng = HipStripEngine(parameter_from(cfg, C, "reference_fp16", weights), rank, world, 0, dev)
+            eng.map.set_scatter_mode(scatter)
             comm = NativeComm(eng, rank=rank, world=world, bootstrap=False, uid=bytes(uid), rccl_path=lib_path)
             comm.selftest()
             sm = ShardedElevationMap(eng, comm, cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])

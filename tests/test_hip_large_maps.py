@@ -6,7 +6,8 @@
   * config 5: 8192 x 8192 multi-modal map (height + RGB + 3 semantic layers), 16 M points: bins of 4 stacked tiles (sub = 4,
     emap_binned.hip), k_tile_semantic at size, 67 M cells (32-bit offsets into 16-byte planes of > 1 GiB).
 
-Indices / flags bit-exact, every plane within 1e-5 (north_star), colour layer bit-exact.  These tests need ~6 GB of host memory
+Indices / flags bit-exact, every core plane and the normals BIT FOR BIT (north_star asks for 1e-5), colour layer bit-exact, averaged
+semantic layers within 1e-6.  These tests need ~6 GB of host memory
 and a few tens of seconds of oracle time each; they stay inside `-m gpu`."""
 import threading
 
@@ -14,7 +15,7 @@ import numpy as np
 import pytest
 
 import _fixtures as fx
-from _util import assert_planes_close
+from _util import assert_planes_close, assert_planes_equal
 from oracle import emap_oracle as eo
 
 pytestmark = pytest.mark.gpu
@@ -61,8 +62,9 @@ def test_config4_4096_fp32_rays_vs_oracle(weights):
     assert np.array_equal(m[6], orc.elevation_map[6])
     assert np.array_equal(m[3], orc.elevation_map[3]), "traversability must be bit-exact"
     assert_planes_close(m, orc.elevation_map, what="config 4, 3 frames")
-    assert hip.normal_map.tobytes() == orc.normal_map.tobytes()
-    assert abs(hip.get_additive_mean_error() - float(orc.additive_mean_error)) < 1e-6
+    assert_planes_equal(m, orc.elevation_map, what="config 4, 3 frames")
+    assert_planes_equal(hip.normal_map, orc.normal_map, names=["nx", "ny", "nz"])
+    assert hip.get_additive_mean_error() == float(orc.additive_mean_error)
 
 
 def test_config4_four_strips_reproduce_the_single_context(weights):
@@ -141,8 +143,7 @@ def test_config5_8192_multimodal_vs_oracle(weights):
     for k in range(7):                                                   # plane by plane: 268 MB each
         a = hip.get_layer_raw(k)
         assert_planes_close(a[None], orc.elevation_map[k][None], names=[hip.layer_names_core[k]], what="config 5")
-        if k in (2, 3, 6):                                               # flags and the traversability plane: exact
-            assert np.array_equal(a, orc.elevation_map[k]), hip.layer_names_core[k]
+        assert_planes_equal(a[None], orc.elevation_map[k][None], names=[hip.layer_names_core[k]], what="config 5")
     for j, k in enumerate((7, 8, 9)):
         assert hip.get_layer_raw(k).tobytes() == orc.normal_map[j].tobytes(), "normal plane %d" % j
     assert np.array_equal(hip.semantic_map.get_layer("rgb").view(np.uint32), orc.semantic_map[0].view(np.uint32)), "colour layer must be bit-exact"

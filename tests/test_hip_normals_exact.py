@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import _fixtures as fx
-from _util import make_pair
+from _util import assert_planes_equal, make_pair
 from oracle import emap_oracle as eo
 
 pytestmark = pytest.mark.gpu
@@ -44,6 +44,7 @@ def test_normals_bit_for_bit_on_warm_frames(rays, weights):
         ht, ot = hip.get_layer_raw(3), orc.elevation_map[3]
         assert ht.tobytes() == ot.tobytes(), "frame %d: %d traversability cells differ (max %g)" % (f, int((ht != ot).sum()), float(np.abs(ht - ot).max()))
         total_cells += nz
+        assert_planes_equal(hip.elevation_map, orc.elevation_map, what="frame %d" % f)     # heights, variances, bounds: the same integers on both sides
         assert mism == 0 and half_flips == 0, "frame %d: %d of %d normal components differ in fp32, %d after half rounding" % (
             f, mism, 3 * nz, half_flips)
     assert total_cells > (800_000 if not rays else 300_000)       # the filter really ran on a large part of the map

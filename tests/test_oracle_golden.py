@@ -20,7 +20,9 @@ def _fresh_frame(cfg, C, N, pose):
     p = fx.cloud(C, N, 0)
     idx, valid, inside = om.point_index(p, R, t)
     om.count(p, R, t); om.gate(0, 0); om.fuse(p, R, t)
-    sums = (om.last["sum_h"].sum(), om.last["sum_v"].sum(), om.last["cnt"].sum(), om.last["n_inl"].sum(), om.last["n_pts"].sum())
+    # the accumulators are fixed point (Q31.32 / Q23.40): back to the reference's units for the known-answer comparison
+    sums = (om.last["sum_h"].astype(np.float64).sum() / 2.0 ** 32, om.last["sum_v"].astype(np.float64).sum() / 2.0 ** 40, om.last["cnt"].sum(),
+            om.last["n_inl"].sum(), om.last["n_pts"].sum())
     om.commit()
     if P.enable_visibility_cleanup:
         om.rays(p, R, t)
