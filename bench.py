@@ -510,6 +510,9 @@ def run_strips_native(a, rank, world, local_rank, rdv):
         lib.emap_comm_destroy(ctx)
         return False, None
 
+    nr = ct.c_int32(0)
+    rccl_ranks = int(nr.value) if lib.emap_comm_count(ctx, ct.byref(nr)) == 0 and nr.value else None    # ncclCommCount of the live communicator
+
     def reduce(vals, op):
         buf = (ct.c_double * len(vals))(*vals)
         if lib.emap_comm_allreduce_host(ctx, buf, len(vals), op):
@@ -594,7 +597,8 @@ def run_strips_native(a, rank, world, local_rank, rdv):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_text(a, C, N, multimodal) + "; %d row strips, cloud replicated to every rank" % world,
                        "index_mode": a.mode, "latency_ms": {"p10": round(pct[0], 4), "p50": round(pct[1], 4), "p90": round(pct[2], 4)},
-                       "halo_rows": halo, "parallelism": "row-strips x%d" % world, "ranks": world, "physical_devices": min(ndev, world),
+                       "halo_rows": halo, "parallelism": "row-strips x%d" % world, "ranks": world, "rccl_ranks": rccl_ranks,
+                       "physical_devices": min(ndev, world),
                        "strip_rows": rows, "strip_heights": "equal ray work (thin around the sensor)" if row_w is not None else "equal",
                        "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame, RCCL issued by the C library "
                                       "(halo exchange in place on a second stream); bootstrap: file rendezvous, no torch",

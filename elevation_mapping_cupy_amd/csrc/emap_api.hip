@@ -54,26 +54,26 @@ void launch_materialize(hipStream_t, const KP&, Cells);
 void launch_band_clear(hipStream_t, const KP&, float*, int, long, int, int);
 
 // tile-binned scatter (emap_binned.hip)
-void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, unsigned int*, unsigned short*, unsigned int*);
+void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, unsigned int*, BinStg*, unsigned int*);
 void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*, unsigned int*);
-void launch_bin_scatter(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, const unsigned int*, const unsigned int*, BinRec*, const unsigned short*, const unsigned int*);
+void launch_bin_scatter(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, const unsigned int*, const unsigned int*, BinRec*, const BinStg*, const unsigned int*);
 void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, ErrSlot*);
 void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const float*, long, int,
                           const unsigned int*, float*, float*, long);
-void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, AccF*, const FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&);
+void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, AccF*, FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&, const GateFold&);
 #define BIN_MAX_T 16384
 #define BIN_MAX_B 2048
-#define BIN_SUB 4096      /* points per compaction round of the strip variants (emap_binned.hip) */
 
 // timed stages of emap_update (emap_get_stage_times): hist+scan are 0 on the atomic path, where "scatter" is k_count
 enum { ST_HIST = 0, ST_SCAN, ST_SCATTER, ST_GATE, ST_FUSE, ST_COMMIT, ST_RAYS, ST_AVERAGE, ST_OVERLAP, ST_POST, ST_N };
 
-// the eight RCCL entry points of the path, bound with dlsym (no link-time dependency: the .so loads on machines without RCCL)
+// the ten RCCL entry points of the path, bound with dlsym (no link-time dependency: the .so loads on machines without RCCL)
 struct RcclApi {
   void* handle;
   decltype(&ncclGetUniqueId) GetUniqueId; decltype(&ncclCommInitRank) CommInitRank; decltype(&ncclCommDestroy) CommDestroy;
   decltype(&ncclAllReduce) AllReduce; decltype(&ncclSend) Send; decltype(&ncclRecv) Recv;
   decltype(&ncclGroupStart) GroupStart; decltype(&ncclGroupEnd) GroupEnd; decltype(&ncclGetErrorString) GetErrorString;
+  decltype(&ncclCommCount) CommCount;
 };
 
 // ---- asynchronous cloud upload (a1: ElevationMap.input_pointcloud, EM/elevation_mapping.py:456-458) ------------------------------
@@ -131,10 +131,11 @@ struct emap_ctx {
   int force_sub;                   // test hook: minimum bin height factor (emap_set_scatter_mode bits 8..15)
   bool frame_binned;               // the count stage of the current frame used the binned path
   unsigned int* bin_sync;          // ticket counters of k_bin_scan (last_block_ticket), zero between launches
+  GateFold gate_fold;              // multi-GPU frames: gate decision on the all-reduced totals folded into the tile kernel (mode 0: k_gate ran)
   OverlapArgs ov_args;             // clear_overlap_map folded into the frame's rewriting kernels (on = 0: separate k_overlap launch)
   bool gate_possible;              // false inside emap_update when the host already knows that the drift gate cannot fire: the per-tile
                                    // error statistics are then skipped (they could not have any effect; err_sum / err_cnt report 0)
-  BinGeo bg; BinRec* bin_recs; unsigned short* bin_own; unsigned int* bin_own_cnt; long bin_own_cap; bool bin_strip;   // bin_own*: lists of the owned points per block (strip contexts without a visibility pass)
+  BinGeo bg; BinRec* bin_recs; BinStg* bin_own; unsigned int* bin_own_cnt; long bin_own_cap; bool bin_strip;   // bin_own*: staged records of the owned points per block (strip contexts without a visibility pass)
   unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;
   // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
   float* img_uv; unsigned char* img_valid; float* img_buf; size_t img_cap;   // camera path
@@ -155,6 +156,7 @@ struct emap_ctx {
   bool want_ray_stats; bool in_update;
   // row-strip communicator (emap_comm_init): RCCL resolved at run time, exchange on its own stream so that it overlaps the interior stencils
   struct RcclApi* rccl; ncclComm_t comm; int comm_rank, comm_world;
+  float* gather_buf;            // cell_n x cell_n plane of emap_comm_gather_layer (on demand)
   hipStream_t comm_stream; hipEvent_t ev_ready, ev_done; double* comm_sums;   // [0..1] local err_sum / err_cnt, [2..3] totals, [4..36) emap_comm_allreduce_host
   std::string err;
 };
@@ -572,10 +574,11 @@ static int ensure_bins(emap_ctx* ctx, bool raybin) {
   if (const char* e = getenv("EMAP_BIN_CHUNK")) { long v = atol(e); if (v >= 256 && v <= 65536) target = v; }   // tuning knob
   long B = (n + target - 1) / target;
   long bmax = n / (3L * g.TB); if (bmax < 256) bmax = 256; if (bmax > BIN_MAX_B) bmax = BIN_MAX_B;
-  if (B > bmax) B = bmax; if (B < 1) B = 1;
-  const long unit = ctx->bin_strip ? BIN_SUB : 1024;   /* a multiple of every hist / scatter block size [and of the compaction round] */
+  if (B > bmax) B = bmax;
+  if (B > 256) B -= B % 256;       // whole rounds of workgroups on the 256 CUs (325 blocks = one and a quarter rounds ran as long as 512)
+  if (B < 1) B = 1;
+  const long unit = ctx->bin_strip ? 4096 : 1024;   /* a multiple of every hist / scatter block size [x 4 loads in flight on strips] */
   long chunk = (n + B - 1) / B; chunk = ((chunk + unit - 1) / unit) * unit;
-  if (ctx->bin_strip && chunk > 15 * BIN_SUB) chunk = 15 * BIN_SUB;       // 2-byte list entries index a round, not the chunk; keep the rounds bounded
   g.B = (int)((n + chunk - 1) / chunk); if (g.B < 1) g.B = 1;
   g.chunk = chunk;
   const size_t hist_need = (size_t)g.pitch * (size_t)g.B;
@@ -604,8 +607,8 @@ static int ensure_bins(emap_ctx* ctx, bool raybin) {
     if (ctx->bin_own) CK(hipFree(ctx->bin_own));
     if (ctx->bin_own_cnt) CK(hipFree(ctx->bin_own_cnt));
     ctx->bin_own = nullptr; ctx->bin_own_cnt = nullptr; ctx->bin_own_cap = 0;
-    CK(hipMalloc((void**)&ctx->bin_own, sizeof(unsigned short) * (size_t)g.B * chunk));
-    CK(hipMalloc((void**)&ctx->bin_own_cnt, sizeof(unsigned int) * (size_t)BIN_MAX_B * 16));
+    CK(hipMalloc((void**)&ctx->bin_own, 16 * (size_t)g.B * chunk));           // 16-byte staging records; only the owned share is ever touched
+    CK(hipMalloc((void**)&ctx->bin_own_cnt, sizeof(unsigned int) * (size_t)BIN_MAX_B));
     ctx->bin_own_cap = (long)g.B * chunk;
   }
   return EMAP_OK;
@@ -644,7 +647,7 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
     int rc = ensure_bins(ctx, ctx->prm.enable_visibility_cleanup != 0); if (rc) return rc;
     const bool tm = ctx->stage_timing && ctx->in_update;
     const Pose pose = make_pose(ctx, R, t);
-    unsigned short* own = ctx->bin_strip ? ctx->bin_own : nullptr;
+    BinStg* own = ctx->bin_strip ? ctx->bin_own : nullptr;
     if (tm) CK(hipEventRecord(ctx->ev[ST_HIST], ctx->stream));
     launch_bin_hist(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, own, ctx->bin_own_cnt);
     if (tm) CK(hipEventRecord(ctx->ev[ST_SCAN], ctx->stream));
@@ -709,16 +712,20 @@ static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool fus
   NEED_POINTS();
   CK(hipSetDevice(ctx->device));
   if (ctx->frame_binned) {
-    if (fuse_average && rays && !ctx->inl_plane) {
-      CK(hipMalloc((void**)&ctx->inl_plane, sizeof(unsigned int) * ctx->ncells_alloc));
-      CK(hipMemsetAsync(ctx->inl_plane, 0, sizeof(unsigned int) * ctx->ncells_alloc, ctx->stream));
-      CK(hipMalloc((void**)&ctx->ray_thr, sizeof(float) * (size_t)((ctx->strip.row_count + 7) / 8 + 2) * ((ctx->prm.cell_n + 7) / 8)));
+    if (fuse_average && rays && !ctx->inl_plane) {        // each buffer on its own: a failed second allocation must not leave the first one "done"
+      unsigned int* pl = nullptr;
+      CK(hipMalloc((void**)&pl, sizeof(unsigned int) * ctx->ncells_alloc));
+      if (hipMemsetAsync(pl, 0, sizeof(unsigned int) * ctx->ncells_alloc, ctx->stream) != hipSuccess) { hipFree(pl); ctx->err = "hipMemsetAsync(inl_plane)"; return EMAP_ERR_HIP; }
+      ctx->inl_plane = pl;
     }
+    if (fuse_average && rays && !ctx->ray_thr)
+      CK(hipMalloc((void**)&ctx->ray_thr, sizeof(float) * (size_t)((ctx->strip.row_count + 7) / 8 + 2) * ((ctx->prm.cell_n + 7) / 8)));
     if (fuse_average && rays && ((ctx->kp.org_c | ctx->prm.cell_n) & 63) != 0 && !ctx->inert_zero)     // unaligned columns: the tile kernel ORs its ballots into the logical bitmap
       CK(hipMemsetAsync(ctx->inert, 0, sizeof(unsigned long long) * ((size_t)ctx->strip.row_count * ((ctx->prm.cell_n + 63) / 64)), ctx->stream));
     if (fuse_average && rays) ctx->inert_zero = false;
     launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame, fuse_average, rays,
-                    ctx->cnt_plane, ctx->inert, ctx->inl_plane, ctx->ray_thr, ctx->ov_args);
+                    ctx->cnt_plane, ctx->inert, ctx->inl_plane, ctx->ray_thr, ctx->ov_args, ctx->gate_fold);
+    ctx->gate_fold.mode = 0;
     if (fuse_average) ctx->kp.mv.n = 0;   // every owned cell rewritten: pending map shifts are in memory now
     CK(hipGetLastError());
     return EMAP_OK;
@@ -1406,7 +1413,7 @@ static RcclApi* rccl_open(const char* path, std::string* why) {
 #define SYM(field, name) do { a->field = (decltype(a->field))dlsym(h, name); if (!a->field) { ok = false; *why = std::string("missing symbol ") + name; } } while (0)
   SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
   SYM(AllReduce, "ncclAllReduce"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GroupStart, "ncclGroupStart");
-  SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+  SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString"); SYM(CommCount, "ncclCommCount");
 #undef SYM
   if (!ok) { delete a; return nullptr; }   // the handle stays open: unloading a GPU runtime library is not safe
   return a;
@@ -1459,7 +1466,7 @@ int emap_comm_destroy(emap_ctx* ctx) {
   if (ctx->comm_stream) hipStreamDestroy(ctx->comm_stream);
   if (ctx->ev_ready) hipEventDestroy(ctx->ev_ready);
   if (ctx->ev_done) hipEventDestroy(ctx->ev_done);
-  hipFree(ctx->comm_sums);
+  hipFree(ctx->comm_sums); hipFree(ctx->gather_buf); ctx->gather_buf = nullptr;
   delete ctx->rccl;
   ctx->rccl = nullptr; ctx->comm = nullptr; ctx->comm_stream = nullptr; ctx->ev_ready = ctx->ev_done = nullptr; ctx->comm_sums = nullptr;
   return EMAP_OK;
@@ -1523,7 +1530,11 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   ctx->use_override = false;
   if ((rc = gate_impl(ctx, 0.0, 0.0, 1, ctx->comm_sums, nullptr))) return rc;                       // local sums -> device
   CKN(a->AllReduce(ctx->comm_sums, ctx->comm_sums + 2, 2, ncclFloat64, ncclSum, ctx->comm, ctx->stream));   // exchange step 1
-  if ((rc = gate_impl(ctx, position_noise, orientation_noise, 0, nullptr, ctx->comm_sums + 2))) return rc;
+  if (ctx->frame_binned) {        // the decision on the all-reduced totals rides in the head of the tile kernel
+    memset(&ctx->gate_fold, 0, sizeof ctx->gate_fold);
+    ctx->gate_fold.mode = 1; ctx->gate_fold.dev_totals = ctx->comm_sums + 2; ctx->gate_fold.A = gate_args(ctx, position_noise, orientation_noise);
+    ctx->committed = false;
+  } else if ((rc = gate_impl(ctx, position_noise, orientation_noise, 0, nullptr, ctx->comm_sums + 2))) return rc;
   STAGE(ST_FUSE);
   const bool fused_avg = ctx->frame_binned;
   const bool rays_on = p.enable_visibility_cleanup != 0;
@@ -1563,6 +1574,39 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
     for (int i = 0; i < ST_N; ++i) CK(hipEventElapsedTime(&ctx->stage_ms[i], ctx->ev[i], ctx->ev[i + 1]));
   }
   if (stats) return emap_get_stats(ctx, stats);
+  return EMAP_OK;
+}
+
+int emap_comm_count(emap_ctx* ctx, int32_t* ranks) {
+  CKARG(ctx && ranks && ctx->rccl && ctx->comm, "emap_comm_init has not been called");
+  int n = 0;
+  CKN(ctx->rccl->CommCount(ctx->comm, &n));
+  *ranks = n;
+  return EMAP_OK;
+}
+
+// One plane of the FULL map on every rank, assembled from the strips: every rank writes its rows (logical order) into a zeroed
+// cell_n x cell_n device plane and the planes are all-reduced (x + 0 + ... + 0 is exact for every x; only -0.0 comes back as +0.0).
+// Read-back for publishing on a sharded map; not on the per-frame path.
+int emap_comm_gather_layer(emap_ctx* ctx, int32_t plane, float* host_full_out) {
+  CKARG(ctx && ctx->rccl && ctx->comm, "emap_comm_init has not been called");
+  CKARG(host_full_out && plane >= 0 && plane < EMAP_PLANE_COUNT, "bad argument");
+  CK(hipSetDevice(ctx->device));
+  FLUSH();
+  const long C = ctx->prm.cell_n, rows = ctx->strip.row_count;
+  if (!ctx->gather_buf) CK(hipMalloc((void**)&ctx->gather_buf, sizeof(float) * (size_t)C * C));
+  if (plane < 7) launch_get_plane(ctx->stream, ctx->kp, ctx->cells, plane, ctx->scratch);
+  else if (plane == EMAP_PLANE_TRAV_INPUT) launch_plane_view(ctx->stream, ctx->kp, ctx->torg_r, ctx->torg_c, ctx->trav_in, ctx->scratch, 0);
+  else launch_plane_view(ctx->stream, ctx->kp, ctx->kp.norg_r, ctx->kp.norg_c, ctx->normal + (long)(plane - EMAP_PLANE_NORMAL_X) * ctx->ncells_alloc, ctx->scratch, 0);
+  CK(hipGetLastError());
+  CK(hipMemsetAsync(ctx->gather_buf, 0, sizeof(float) * (size_t)C * C, ctx->stream));
+  int32_t b = 0; emap_strip_logical_begin(ctx, &b);                       // view row j = logical row (b + j) mod cell_n
+  const long first = rows < C - b ? rows : C - b;
+  CK(hipMemcpyAsync(ctx->gather_buf + (size_t)b * C, ctx->scratch, sizeof(float) * (size_t)first * C, hipMemcpyDeviceToDevice, ctx->stream));
+  if (first < rows) CK(hipMemcpyAsync(ctx->gather_buf, ctx->scratch + (size_t)first * C, sizeof(float) * (size_t)(rows - first) * C, hipMemcpyDeviceToDevice, ctx->stream));
+  CKN(ctx->rccl->AllReduce(ctx->gather_buf, ctx->gather_buf, (size_t)C * C, ncclFloat32, ncclSum, ctx->comm, ctx->stream));
+  CK(hipMemcpyAsync(host_full_out, ctx->gather_buf, sizeof(float) * (size_t)C * C, hipMemcpyDeviceToHost, ctx->stream));
+  CK(hipStreamSynchronize(ctx->stream));
   return EMAP_OK;
 }
 

@@ -23,13 +23,15 @@
 // histogram holds at most 16384 bins: maps with more tiles (> 4096^2 cells per context) sort into bins of 2, 4, ... vertically
 // stacked tiles and the tile kernels reduce one tile of the bin per workgroup (blockIdx.y), re-reading the bin's records from L2.
 //
-// Row strips (multi-GPU, the cloud is replicated): a strip owns 1/G of the rows, so 1/G of a uniform cloud.  Both point passes
-// first run a CHEAP ownership test (the x row of the transform + one axis index: ~25 instructions instead of the ~100 of the full
-// geometry with its square root and fp64 compares) and compact the surviving lanes through an LDS list, so that the full geometry,
-// the histogram atomics and the record writes shrink with G; only the 12-byte stream over the cloud does not.  The list of a
-// block's owned points is written once by k_bin_hist (2 bytes per owned point) and re-used by k_bin_scatter.  With a visibility
-// pass every VALID point marches a ray through the strip (custom_kernels.py:199-258), validity needs the full geometry, and the
-// test is skipped.
+// Row strips (multi-GPU, the cloud is replicated): a strip owns 1/G of the rows, so 1/G of a uniform cloud.  k_bin_hist<.., STRIP>
+// first runs a CHEAP ownership test on every point (the x row of the transform + one axis index: ~25 instructions instead of the
+// ~120 of the full geometry with its square root and fp64 compares) and pushes the survivors on a per-WAVE LDS queue; whenever 64
+// are waiting the wave works them off with all lanes busy (full geometry, histogram atomic) and appends their 16-byte staging
+// records {bin | cell, z, noise, index} to the block's region of a staging array (1 KB coalesced bursts).  No block-wide barrier
+// inside the loop: the waves of a workgroup hide each other's memory latency.  k_bin_scatter<.., STRIP> then reads only the staged
+// records (N / G of them) and is a pure permutation.  So the full geometry, the atomics and the record traffic shrink with G; only
+// ONE 12-byte stream over the cloud per frame does not.  With a visibility pass every VALID point marches a ray through the strip
+// (custom_kernels.py:199-258), validity needs the full geometry, and the non-strip kernels run (same records, ray-only bin).
 #include "emap_device.h"
 #include <cstring>
 #include <cstdlib>
@@ -37,7 +39,7 @@
 #define BIN_TR 16
 #define BIN_TC 64
 #define BIN_MAX_T 16384   /* LDS histogram / cursor arrays are dynamic: 4 B per tile */
-#define BIN_SUB 4096      /* points per compaction round of the strip variants (2-byte list entries in LDS) */
+#define BIN_QCAP 128      /* entries of a wave's compaction queue (strip variants): < 64 pending + <= 64 pushed per step */
 
 // (BinGeo, BinRec: emap_device.h)
 
@@ -78,24 +80,16 @@ template <int MODE> __device__ __forceinline__ bool row_owned(const KP& P, const
   return (unsigned int)(phys_row(P, ix) - P.row0) < (unsigned int)P.nrows;        // (NaN coordinates index like geometry(): dropped there)
 }
 
-// Appends the block-local indices of this round's surviving lanes to an LDS list (order irrelevant): one ballot, one LDS atomic
-// per wave.  *cnt must be zero before the round and is valid after the next barrier.
-__device__ __forceinline__ void compact_push(bool keep, unsigned int k_local, unsigned short* list, unsigned int* cnt) {
-  const unsigned long long m = __ballot(keep);
-  if (!m) return;                                            // wave-uniform
-  unsigned int base = 0u;
-  if ((threadIdx.x & 63) == 0) base = atomicAdd(cnt, (unsigned int)__popcll(m));
-  base = (unsigned int)__shfl((int)base, 0, 64);
-  if (keep) list[base + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = (unsigned short)k_local;
-}
+// staging record of the strip variants: what k_bin_scatter needs to place a point, computed once by k_bin_hist
+struct __attribute__((aligned(16))) BinStg { unsigned int key; float z, v; unsigned int i; };      // key = (bin << 16) | cell in bin
 
-// STRIP: the context owns a row strip and no visibility pass follows (see the header): cheap test + lane compaction; the owned
-// points of round r of block b are listed in own[(b * chunk) + r * BIN_SUB ...], their number in own_cnt[b * rounds + r].
+// STRIP: the context owns a row strip and no visibility pass follows (see the header).  The staged records of block b are
+// stg[b * chunk ...], their number stg_cnt[b].
 template <int MODE, int BLK, bool STRIP>
 __global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
-                                                  unsigned int* __restrict__ hist, unsigned short* __restrict__ own,
-                                                  unsigned int* __restrict__ own_cnt) {
-  extern __shared__ unsigned int h[];
+                                                  unsigned int* __restrict__ hist, BinStg* __restrict__ stg,
+                                                  unsigned int* __restrict__ stg_cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int h[];
   for (int t = threadIdx.x; t < G.TB; t += BLK) h[t] = 0u;
   const long base = (long)blockIdx.x * G.chunk;
   if (!STRIP) {
@@ -110,33 +104,52 @@ __global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const 
       if (bin >= 0) atomicAdd(&h[bin], 1u);
     }
   } else {
-    unsigned short* list = reinterpret_cast<unsigned short*>(h + G.pitch);       // BIN_SUB entries
-    unsigned int* cnt = reinterpret_cast<unsigned int*>(list + BIN_SUB);
-    const int rounds = (int)(G.chunk / BIN_SUB);
-    for (int r = 0; r < rounds; ++r) {
-      if (threadIdx.x == 0) *cnt = 0u;
-      __syncthreads();
-      const long rb = base + (long)r * BIN_SUB;
-      for (int k = threadIdx.x; k < BIN_SUB; k += BLK) {                          // uniform trip count (ballots)
-        const long i = rb + k;
-        bool keep = false;
-        if (i < n) { float rx, ry, rz; load_point(pts, i, stride, rx, ry, rz); keep = row_owned<MODE>(P, T, rx, ry, rz); }
-        compact_push(keep, (unsigned int)k, list, cnt);
-      }
-      __syncthreads();
-      const unsigned int m = *cnt;
-      if (threadIdx.x == 0) own_cnt[(long)blockIdx.x * rounds + r] = m;
-      for (unsigned int j = threadIdx.x; j < m; j += BLK) {
-        const unsigned int k = list[j];
-        own[rb + j] = (unsigned short)k;
-        float rx, ry, rz;
-        load_point(pts, rb + k, stride, rx, ry, rz);                              // second touch: L1 / L2
+    float4* q = reinterpret_cast<float4*>(h + G.pitch) + (threadIdx.x >> 6) * BIN_QCAP;      // this wave's queue: (x, y, z, index)
+    unsigned int* blk_cnt = h + G.pitch + (BLK / 64) * BIN_QCAP * 4;
+    if (threadIdx.x == 0) *blk_cnt = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    BinStg* out = stg + base;
+    int qn = 0;                                                    // wave-uniform number of queued points
+    auto work = [&](int first, int count) {                        // queue entries [first, first + count), count <= 64: the whole wave
+      bool keep = false;
+      BinStg r; r.key = 0u; r.z = 0.f; r.v = 0.f; r.i = 0u;
+      if (lane < count) {
+        const float4 e = q[first + lane];
+        const Geo g = geometry<MODE>(P, T, e.x, e.y, e.z);
         unsigned int lc;
-        const int bin = bin_of(P, G, geometry<MODE>(P, T, rx, ry, rz), lc);
-        if (bin >= 0) atomicAdd(&h[bin], 1u);
+        const int bin = bin_of(P, G, g, lc);
+        if (bin >= 0) { atomicAdd(&h[bin], 1u); keep = true; r.key = ((unsigned int)bin << 16) | lc; r.z = g.z; r.v = g.v; r.i = __float_as_uint(e.w); }
       }
-      __syncthreads();
+      const unsigned long long m = __ballot(keep);
+      if (!m) return;
+      unsigned int b0 = 0u;
+      if (lane == 0) b0 = atomicAdd(blk_cnt, (unsigned int)__popcll(m));
+      b0 = (unsigned int)__shfl((int)b0, 0, 64);
+      if (keep) out[b0 + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = r;
+    };
+    auto push = [&](bool own, float x, float y, float z, long i) {
+      const unsigned long long m = __ballot(own);
+      if (!m) return;                                              // wave-uniform
+      if (own) q[qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = make_float4(x, y, z, __uint_as_float((unsigned int)i));
+      qn += __popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      if (qn >= 64) { qn -= 64; work(qn, 64); __builtin_amdgcn_wave_barrier(); }
+    };
+    for (long k0 = threadIdx.x; k0 < G.chunk; k0 += 4 * BLK) {     // uniform trip count (chunk is a multiple of 4 * BLK); four loads in flight
+      float x[4], y[4], z[4]; bool in[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = base + k0 + (long)u * BLK;
+        in[u] = i < n; x[u] = y[u] = z[u] = 0.f;
+        if (in[u]) load_point(pts, i, stride, x[u], y[u], z[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) push(in[u] && row_owned<MODE>(P, T, x[u], y[u], z[u]), x[u], y[u], z[u], base + k0 + (long)u * BLK);
     }
+    if (qn > 0) work(0, qn);
+    __syncthreads();
+    if (threadIdx.x == 0) stg_cnt[blockIdx.x] = *blk_cnt;
   }
   __syncthreads();
   unsigned int* row = hist + (long)blockIdx.x * G.pitch;
@@ -205,36 +218,34 @@ __global__ __launch_bounds__(SCAN_BLK) void k_bin_scan(BinGeo G, unsigned int* _
 template <int MODE, int BLK, bool STRIP>
 __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
                                                      const unsigned int* __restrict__ hist, const unsigned int* __restrict__ tile_start,
-                                                     BinRec* __restrict__ recs, const unsigned short* __restrict__ own,
-                                                     const unsigned int* __restrict__ own_cnt) {
+                                                     BinRec* __restrict__ recs, const BinStg* __restrict__ stg,
+                                                     const unsigned int* __restrict__ stg_cnt) {
   extern __shared__ unsigned int cur[];
   const unsigned int* row = hist + (long)blockIdx.x * G.pitch;
   for (int t = threadIdx.x; t < G.TB; t += BLK) cur[t] = tile_start[t] + row[t];
   __syncthreads();
   const long base = (long)blockIdx.x * G.chunk;
-  auto place = [&](long i) {                                 // geometry once more, LDS cursor -> sorted position; no map access
-    float rx, ry, rz;
-    load_point(pts, i, stride, rx, ry, rz);
-    const Geo g = geometry<MODE>(P, T, rx, ry, rz);
-    unsigned int lc;
-    const int bin = bin_of(P, G, g, lc);
-    if (bin < 0) return;
-    const unsigned int pos = atomicAdd(&cur[bin], 1u);
-    BinRec o; o.lc_inl = lc; o.z = g.z; o.v = g.v; o.i = (unsigned int)i;
-    recs[pos] = o;
-  };
   if (!STRIP) {
-    for (long k = threadIdx.x; k < G.chunk; k += BLK) {
+    for (long k = threadIdx.x; k < G.chunk; k += BLK) {      // geometry once more, LDS cursor -> sorted position; no map access
       const long i = base + k;
       if (i >= n) break;
-      place(i);
+      float rx, ry, rz;
+      load_point(pts, i, stride, rx, ry, rz);
+      const Geo g = geometry<MODE>(P, T, rx, ry, rz);
+      unsigned int lc;
+      const int bin = bin_of(P, G, g, lc);
+      if (bin < 0) continue;
+      const unsigned int pos = atomicAdd(&cur[bin], 1u);
+      BinRec o; o.lc_inl = lc; o.z = g.z; o.v = g.v; o.i = (unsigned int)i;
+      recs[pos] = o;
     }
   } else {
-    const int rounds = (int)(G.chunk / BIN_SUB);
-    for (int r = 0; r < rounds; ++r) {
-      const long rb = base + (long)r * BIN_SUB;
-      const unsigned int m = own_cnt[(long)blockIdx.x * rounds + r];
-      for (unsigned int j = threadIdx.x; j < m; j += BLK) place(rb + own[rb + j]);
+    const unsigned int m = stg_cnt[blockIdx.x];              // a pure permutation of the block's staged records
+    for (unsigned int j = threadIdx.x; j < m; j += BLK) {
+      const BinStg r = stg[base + j];
+      const unsigned int pos = atomicAdd(&cur[r.key >> 16], 1u);
+      BinRec o; o.lc_inl = r.key & 0xffffu; o.z = r.z; o.v = r.v; o.i = r.i;
+      recs[pos] = o;
     }
   }
 }
@@ -300,21 +311,22 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const B
 template <bool AVG, bool RAYS>
 __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const BinRec* __restrict__ recs,
                                                          const unsigned int* __restrict__ tile_start, Cells cells,
-                                                         AccF* __restrict__ acc, const FrameDev* __restrict__ F,
+                                                         AccF* __restrict__ acc, FrameDev* __restrict__ F,
                                                          unsigned int* __restrict__ cnt_plane, unsigned long long* __restrict__ inert,
-                                                         unsigned int* __restrict__ inl_plane, float* __restrict__ thr, OverlapArgs O) {
+                                                         unsigned int* __restrict__ inl_plane, float* __restrict__ thr, OverlapArgs O, GateFold GF) {
   constexpr int NC = BIN_TR * BIN_TC;
   __shared__ unsigned int s_pts[NC], s_inl[NC], s_cnt[NC], s_out[NC];
   __shared__ unsigned long long s_h[NC], s_v[NC], s_latest[NC];
   __shared__ float4 s_cell[NC];            // (h, v, valid, trav) of the tile's cells, staged once (coalesced): no per-record gather
+  __shared__ float s_shift;
   const int t = blockIdx.x, ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
   const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
-  const float shift = F->shift;
   const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6, col = tx * BIN_TC + tc;
   {                                               // blockIdx.y = which 16 x 64 tile of the bin (sub == 1 up to 16384 tiles)
     const int sb = blockIdx.y, row_base = (ty * G.sub + sb) * BIN_TR;
     if (row_base >= P.nrows) return;              // uniform, before any barrier
     const unsigned int sel = (unsigned int)sb;
+    if (threadIdx.x == 0) s_shift = GF.mode ? gate_fold(GF, F, blockIdx.x == 0 && blockIdx.y == 0) : F->shift;      // only pass 2 needs it
     for (int k = threadIdx.x; k < NC; k += TF_BLOCK) {
       s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull;
       const int lrow = row_base + k / BIN_TC, colk = tx * BIN_TC + k % BIN_TC;
@@ -331,6 +343,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
       if ((!AVG || RAYS) && drift_inlier(P, s_cell[lcb & 1023u], r.z)) atomicAdd(&s_inl[lcb & 1023u], 1u);   // newmap[3]: only the ray pass reads it
     }
     __syncthreads();
+    const float shift = s_shift;
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += TF_BLOCK) {          // pass 2: custom_kernels.py:160-197
       const BinRec r = recs[k];
       const unsigned int lcb = r.lc_inl & 0x7fffffffu;
@@ -444,31 +457,24 @@ static int env_block(const char* name, int dflt) {
   if (const char* e = getenv(name)) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) return v; }
   return dflt;
 }
-// dynamic LDS of the two point passes: the histogram / cursor row [+ the compaction list and its counter on strips]
-static size_t bin_lds_bytes(const BinGeo& G, bool strip) { return sizeof(unsigned int) * G.pitch + (strip ? sizeof(unsigned short) * BIN_SUB + 16 : 0); }
-// hipFuncSetAttribute is per device: keep one flag per (kernel instantiation, device)
-#define EM_MAX_DEV 64
-template <class K> static void raise_lds(K kern, bool (&raised)[EM_MAX_DEV], int bytes) {
-  int dev = 0; (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= EM_MAX_DEV) dev = 0;
-  if (!raised[dev] && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) raised[dev] = true;
-}
+// dynamic LDS of the histogram pass: the histogram row [+ the waves' compaction queues and the block's staging counter on strips]
+static size_t bin_lds_bytes(const BinGeo& G, bool strip, int blk) { return sizeof(unsigned int) * G.pitch + (strip ? (size_t)(blk / 64) * BIN_QCAP * 16 + 16 : 0); }
 template <int MODE, int BLK, bool STRIP>
 static void launch_bin_hist_i(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
-                              unsigned int* hist, unsigned short* own, unsigned int* own_cnt) {
-  static bool raised[EM_MAX_DEV];                  // 16384 tiles + the ray-only bin (+ list): past the default 64 KB window
-  raise_lds(k_bin_hist<MODE, BLK, STRIP>, raised, 80 * 1024);
-  hipLaunchKernelGGL((k_bin_hist<MODE, BLK, STRIP>), dim3(G.B), dim3(BLK), bin_lds_bytes(G, STRIP), s, P, T, G, pts, n, stride, hist, own, own_cnt);
+                              unsigned int* hist, BinStg* own, unsigned int* own_cnt) {
+  static LdsRaised raised;                         // 16384 tiles + the ray-only bin (+ queues): past the default 64 KB window
+  raise_lds(k_bin_hist<MODE, BLK, STRIP>, raised, 112 * 1024);
+  hipLaunchKernelGGL((k_bin_hist<MODE, BLK, STRIP>), dim3(G.B), dim3(BLK), bin_lds_bytes(G, STRIP, BLK), s, P, T, G, pts, n, stride, hist, own, own_cnt);
 }
 template <int BLK>
 static void launch_bin_hist_t(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
-                              unsigned int* hist, unsigned short* own, unsigned int* own_cnt) {
+                              unsigned int* hist, BinStg* own, unsigned int* own_cnt) {
   if (own) { if (P.mode == 0) launch_bin_hist_i<0, BLK, true>(s, P, T, G, pts, n, stride, hist, own, own_cnt); else launch_bin_hist_i<1, BLK, true>(s, P, T, G, pts, n, stride, hist, own, own_cnt); }
   else { if (P.mode == 0) launch_bin_hist_i<0, BLK, false>(s, P, T, G, pts, n, stride, hist, own, own_cnt); else launch_bin_hist_i<1, BLK, false>(s, P, T, G, pts, n, stride, hist, own, own_cnt); }
 }
 // own != nullptr selects the strip variants (cheap ownership test + lane compaction)
 void launch_bin_hist(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
-                     unsigned int* hist, unsigned short* own, unsigned int* own_cnt) {
+                     unsigned int* hist, BinStg* own, unsigned int* own_cnt) {
   static const int blk = env_block("EMAP_HIST_BLOCK", 1024);
   switch (blk) {
     case 1024: launch_bin_hist_t<1024>(s, P, T, G, pts, n, stride, hist, own, own_cnt); break;
@@ -481,19 +487,19 @@ void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigne
 }
 template <int MODE, int BLK, bool STRIP>
 static void launch_bin_scatter_i(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
-                                 const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const unsigned short* own, const unsigned int* own_cnt) {
-  static bool raised[EM_MAX_DEV];
+                                 const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const BinStg* own, const unsigned int* own_cnt) {
+  static LdsRaised raised;
   raise_lds(k_bin_scatter<MODE, BLK, STRIP>, raised, 80 * 1024);
   hipLaunchKernelGGL((k_bin_scatter<MODE, BLK, STRIP>), dim3(G.B), dim3(BLK), sizeof(unsigned int) * G.pitch, s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt);
 }
 template <int BLK>
 static void launch_bin_scatter_t(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
-                                 const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const unsigned short* own, const unsigned int* own_cnt) {
+                                 const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const BinStg* own, const unsigned int* own_cnt) {
   if (own) { if (P.mode == 0) launch_bin_scatter_i<0, BLK, true>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); else launch_bin_scatter_i<1, BLK, true>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); }
   else { if (P.mode == 0) launch_bin_scatter_i<0, BLK, false>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); else launch_bin_scatter_i<1, BLK, false>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); }
 }
 void launch_bin_scatter(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
-                        const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const unsigned short* own, const unsigned int* own_cnt) {
+                        const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const BinStg* own, const unsigned int* own_cnt) {
   static const int blk = env_block("EMAP_SCATTER_BLOCK", 512);
   switch (blk) {
     case 1024: launch_bin_scatter_t<1024>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); break;
@@ -508,12 +514,12 @@ void launch_tile_count(hipStream_t s, const KP& P, const BinGeo& G, const BinRec
 }
 // fuse_average: commit + average in the tile kernel (whole frames); rays: the visibility pass follows (bitmap + inlier plane wanted)
 void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cells cells,
-                     AccF* acc, const FrameDev* F, bool fuse_average, bool rays, unsigned int* cnt_plane, unsigned long long* inert,
-                     unsigned int* inl_plane, float* thr, const OverlapArgs& O) {
+                     AccF* acc, FrameDev* F, bool fuse_average, bool rays, unsigned int* cnt_plane, unsigned long long* inert,
+                     unsigned int* inl_plane, float* thr, const OverlapArgs& O, const GateFold& GF) {
   const dim3 g(G.T, G.sub), b(TF_BLOCK);
-  if (fuse_average && rays) hipLaunchKernelGGL((k_tile_fuse<true, true>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O);
-  else if (fuse_average) hipLaunchKernelGGL((k_tile_fuse<true, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O);
-  else hipLaunchKernelGGL((k_tile_fuse<false, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O);
+  if (fuse_average && rays) hipLaunchKernelGGL((k_tile_fuse<true, true>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF);
+  else if (fuse_average) hipLaunchKernelGGL((k_tile_fuse<true, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF);
+  else hipLaunchKernelGGL((k_tile_fuse<false, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -270,6 +270,15 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 // One thread per workgroup calls this after its results are acknowledged; true for exactly one caller, the last.  Device-scope
 // atomics on ONE address serialise at ~10 ns each on MI355X (1024 workgroups on a single counter: +10 us, measured), so the
 // tickets form a two-level tree: sqrt(n) groups, each counter on its own 128-byte line.  Counters re-arm themselves.
+// Memory model note: the data a workgroup publishes before it takes its ticket goes out as a RELAXED agent-scope atomic store followed
+// by s_waitcnt (the store has been acknowledged by the memory side), and the winner reads it back with relaxed agent-scope atomic
+// loads.  There is no release / acquire pair: an agent-scope release makes every workgroup write back its XCD's L2 (measured: scan
+// 10 -> 30 us).  This ordering is a property of gfx950's device-coherent (sc1) accesses, not of the HIP memory model -- hence the
+// guard below -- and it is pinned by tests/test_hip_large_maps.py::test_sort_offsets_under_stress (16384 sort bins, many frames,
+// binned vs atomic scatter bit for bit).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "last_block_ticket / k_bin_scan order their hand-off with gfx950 device-coherent stores + s_waitcnt; re-derive it for another target"
+#endif
 #define EM_TICKET_WORDS (1025 * 32)
 __device__ __forceinline__ bool last_block_ticket(unsigned int* __restrict__ sync, unsigned int bid, unsigned int nblocks) {
   unsigned int gs = 1; while (gs * gs < nblocks) gs <<= 1;
@@ -320,6 +329,29 @@ __device__ __forceinline__ void gate_eval(const GateArgs& A, ErrSlot* __restrict
   F->shift = shift; F->gate_fired = fired;
 }
 
+// Multi-GPU frames: the gate decision on the ALL-REDUCED drift totals rides in the head of the tile kernel (every workgroup reads
+// the two doubles and decides for itself -- the same value everywhere; workgroup (0, 0) also keeps the frame record): one dependent
+// launch less between the all-reduce and the fusion.  mode 0: not folded (the shift comes from FrameDev, written by k_gate).
+// (Single-GPU frames keep k_gate: folding the reduction of the 256 error slots into every tile workgroup was measured in round 3 --
+// k_gate's 4.6 us disappeared, k_tile_fuse grew by 3.0 us, the frame did not move.)
+struct GateFold { int mode, pad_; const double* dev_totals; GateArgs A; };
+__device__ __forceinline__ float gate_fold(const GateFold& g, FrameDev* __restrict__ F, bool keeper) {
+  const double sum = g.dev_totals[0];
+  const float cnt = (float)g.dev_totals[1];
+  float shift = 0.0f, mean = 0.0f; int fired = 0;
+  if (g.A.enable && (double)cnt > g.A.min_cnt && g.A.noise_ok) {
+    mean = (float)sum / cnt;
+    fired = 1;
+    if ((double)fabsf(mean) < g.A.max_drift) shift = mean * g.A.alpha;
+  }
+  if (keeper) {
+    F->n_points = g.A.n_points; F->ray_visits = 0;
+    if (fired) { F->mean_error = mean; F->additive_mean_error = F->additive_mean_error + mean; }
+    F->shift = shift; F->gate_fired = fired;
+  }
+  return shift;
+}
+
 // ---- clear_overlap_map (elevation_mapping.py:393-410) as an epilogue of the kernels that rewrite the cells anyway ----------
 struct OverlapArgs { int on, cmin, cmax, pad_; float hmin, hmax; };
 __device__ __forceinline__ bool overlap_window(const OverlapArgs& O, int lr, int lc) {      // logical row / column
@@ -339,6 +371,22 @@ __device__ __forceinline__ bool overlap_cell(const KP& P, const OverlapArgs& O, 
 // (a multiple of 4).
 struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, TB, pitch, raybin; };
 struct __attribute__((aligned(16))) BinRec { unsigned int lc_inl; float z, v; unsigned int i; };  // sorted by tile
+struct BinStg;                                                                                     // staging record of the strip variants
+
+// ---- host: raising a kernel's dynamic LDS limit beyond the default 64 KB ---------------------------------------------------
+// hipFuncSetAttribute applies to the CURRENT DEVICE, so the "already raised" flag is kept per (kernel instantiation, device) --
+// a process may hold contexts on several devices (thread-mode strips) -- and only set once the call has succeeded.  Racing threads
+// at worst repeat the (idempotent) call.
+#define EM_MAX_DEV 64
+struct LdsRaised { bool dev[EM_MAX_DEV]; };
+template <class K> static inline bool raise_lds(K kern, LdsRaised& r, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EM_MAX_DEV) dev = 0;
+  if (r.dev[dev]) return true;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  r.dev[dev] = true;
+  return true;
+}
 
 // Per-frame description of the RGB / semantic point fusion.  The leading members mirror emap_sem_spec (include/emap_hip.h);
 // sum_K / sum_q are derived by emap_semantic_update: kinds 2 (class_bayesian) and 3 (bayesian_inference) reproduce the

@@ -950,11 +950,11 @@ template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(h
   static const bool lmap_off = getenv("EMAP_RAY_LMAP") && atoi(getenv("EMAP_RAY_LMAP")) == 0;     // tuning / test hook
   const bool lmap = !lmap_off && !small && lds + map_bytes <= 158 * 1024;             // (small clouds: staging the bitmap per workgroup would dominate)
   dim3 g((unsigned int)((n * lpr + block - 1) / block)), b(block);
-  auto go = [&](auto kern, bool& raised, size_t bytes) {    // per instantiation: the half -> index table + queues [+ bitmap] can exceed the default 64 KB window
-    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; }
+  auto go = [&](auto kern, LdsRaised& raised, size_t bytes) {    // per instantiation and device: the half -> index table + queues [+ bitmap] can exceed the default 64 KB window
+    if (!raise_lds(kern, raised, 158 * 1024) && bytes > 64 * 1024) return;      // (the launch below would fail: hipGetLastError reports it to the caller)
     hipLaunchKernelGGL(kern, g, b, bytes, s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
   };
-  static bool raised0 = false, raised1 = false, raised2 = false;
+  static LdsRaised raised0, raised1, raised2;
   if (small) go(k_rays<MODE, STATS, IDX, STRIP, SMALL_BLOCK, false, SMALL_LPR>, raised2, lds);
   else if (lmap) go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, true, 1>, raised1, lds + map_bytes);
   else go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, false, 1>, raised0, lds);
@@ -1042,8 +1042,8 @@ void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, c
   if (!tiles) return;
   dim3 g((P.C + PT_C - 1) / PT_C, tiles), b(R >= 32 ? POST_T32 : 512);
   const size_t lds = post_lds_bytes(R, d);
-#define POST_GO(RR, ST) do { auto kern = k_post<RR, ST>; static bool raised = false; \
-    if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); raised = true; } \
+#define POST_GO(RR, ST) do { auto kern = k_post<RR, ST>; static LdsRaised raised; \
+    raise_lds(kern, raised, 158 * 1024); \
     hipLaunchKernelGGL(kern, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, S); } while (0)
   if (stage == 1) { if (R == 4) POST_GO(4, 1); else if (R == 8) POST_GO(8, 1); else if (R == 32) POST_GO(32, 1); else POST_GO(16, 1); }
   else { if (R == 4) POST_GO(4, 0); else if (R == 8) POST_GO(8, 0); else if (R == 32) POST_GO(32, 0); else POST_GO(16, 0); }

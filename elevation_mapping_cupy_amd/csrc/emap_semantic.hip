@@ -182,12 +182,8 @@ void launch_min_sweep(hipStream_t s, int C, int d, const float* orig_mask, const
                       const unsigned int* prev_unfilled, unsigned int* unfilled, bool is_max) {
   dim3 g((C + MF_C - 1) / MF_C, (C + MF_R - 1) / MF_R), b(EM_BLOCK);
   size_t lds = (size_t)2 * (MF_R + 2 * d) * (MF_C + 2 * d + 1) * sizeof(float);
-  static bool raised = false;        // window radii up to 32 need more than the default 64 KB of dynamic LDS (gfx950: 160 KB per CU)
-  if (!raised) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_min_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_min_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    raised = true;
-  }
+  static LdsRaised raised_max, raised_min;     // window radii up to 32 need more than the default 64 KB of dynamic LDS (gfx950: 160 KB per CU)
+  if (is_max) raise_lds(k_min_sweep<true>, raised_max, 158 * 1024); else raise_lds(k_min_sweep<false>, raised_min, 158 * 1024);
   if (is_max) hipLaunchKernelGGL(k_min_sweep<true>, g, b, lds, s, C, d, orig_mask, val, msk, oval, omsk, prev_unfilled, unfilled);
   else hipLaunchKernelGGL(k_min_sweep<false>, g, b, lds, s, C, d, orig_mask, val, msk, oval, omsk, prev_unfilled, unfilled);
 }

@@ -40,19 +40,28 @@ def _hull_ring(cells):
 
 
 class LazyPlanes:
-    """What a plugin receives as ``elevation_map`` / ``semantic_map``: indexable like the reference's ``(L, C, C)`` array, but a
-    plane only crosses PCIe when the plugin actually touches it (the built-in plugins run on the device and never do)."""
+    """What a plugin receives as ``elevation_map`` / ``semantic_map``: behaves like the reference's ``(L, rows, C)`` array -- ``shape``,
+    ``dtype``, ``ndim``, indexing, iteration, arithmetic, ``copy()`` and every other ndarray attribute work -- but a plane only crosses
+    PCIe when the plugin actually touches it (the built-in plugins run on the device and never do).  Integer indexing fetches one
+    plane; anything else materialises the stack once and delegates to NumPy."""
 
-    def __init__(self, n, fetch, device_map=None):
-        self._n, self._fetch, self._cache = int(n), fetch, {}
-        self.shape = (self._n,)
+    def __init__(self, n, fetch, device_map=None, rows=None, cols=None):
+        self._n, self._fetch, self._cache, self._full = int(n), fetch, {}, None
+        if rows is None and device_map is not None:
+            rows, cols = device_map.rows, device_map.cell_n
+        self.shape = (self._n, int(rows or 0), int(cols or 0))
+        self.dtype = np.dtype(np.float32)
+        self.ndim = 3
         self.device_map = device_map          # the ElevationMap whose live core planes these are (built-in plugins read them on the device)
 
     def __len__(self):
         return self._n
 
     def _plane(self, k):
-        k = int(k) % self._n if self._n else int(k)
+        k = int(k)
+        if not -self._n <= k < self._n:
+            raise IndexError("layer index %d out of range for %d layers" % (k, self._n))
+        k %= self._n
         if k not in self._cache:
             self._cache[k] = self._fetch(k)
         return self._cache[k]
@@ -62,9 +71,37 @@ class LazyPlanes:
             return self._plane(key)
         return np.asarray(self)[key]
 
+    def __iter__(self):
+        return (self._plane(k) for k in range(self._n))
+
     def __array__(self, dtype=None, copy=None):
-        a = np.stack([self._plane(k) for k in range(self._n)], axis=0) if self._n else np.zeros((0, 0, 0), np.float32)
-        return a.astype(dtype) if dtype is not None else a
+        if self._full is None:
+            self._full = (np.stack([self._plane(k) for k in range(self._n)], axis=0) if self._n
+                          else np.zeros(self.shape, np.float32))
+        return self._full.astype(dtype) if dtype is not None else self._full
+
+    def __getattr__(self, name):              # copy, sum, mean, astype, T, ...: whatever an ndarray offers
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(np.asarray(self), name)
+
+    __hash__ = None
+
+
+def _forward_operators():
+    """arithmetic and comparisons of a LazyPlanes act on the materialised stack, like the reference's cupy array would"""
+    def binary(name):
+        return lambda self, other: getattr(np.asarray(self), name)(np.asarray(other) if isinstance(other, LazyPlanes) else other)
+
+    def unary(name):
+        return lambda self: getattr(np.asarray(self), name)()
+    for o in ("add", "radd", "sub", "rsub", "mul", "rmul", "truediv", "rtruediv", "pow", "lt", "le", "gt", "ge", "eq", "ne"):
+        setattr(LazyPlanes, "__%s__" % o, binary("__%s__" % o))
+    for o in ("neg", "abs"):
+        setattr(LazyPlanes, "__%s__" % o, unary("__%s__" % o))
+
+
+_forward_operators()
 
 
 class ElevationMap:
@@ -458,7 +495,7 @@ class ElevationMap:
     def _require_full_map(self, what):
         if self._strip is not None:
             raise EmapError("%s works on a full map; this context holds the row strip [%d, %d) -- gather the strips first "
-                            "(ShardedElevationMap)" % (what, self.row_begin, self.row_begin + self.rows))
+                            "(ShardedElevationMap.gather(name) assembles the full plane on every rank)" % (what, self.row_begin, self.row_begin + self.rows))
 
     def _stripped_layer(self, name):
         """border-stripped, unflipped layer as the reference's get_* accessors return it (:598-680, :740-765)"""
@@ -490,7 +527,7 @@ class ElevationMap:
             sem = self.semantic_map
             self.plugin_manager.update_with_name(
                 name, LazyPlanes(7, self.get_layer_raw, device_map=self), self.layer_names,
-                LazyPlanes(len(sem.layer_names), sem._layer) if sem is not None else None,
+                LazyPlanes(len(sem.layer_names), sem._layer, rows=self.rows, cols=self.cell_n) if sem is not None else None,
                 self.semantic_map.layer_names if self.semantic_map is not None else [],
                 self.base_rotation, self.semantic_map.elements_to_shift if self.semantic_map is not None else {})
             m = self.plugin_manager.get_map_with_name(name)
@@ -632,7 +669,7 @@ class ElevationMap:
             sem = self.semantic_map
             self.plugin_manager.update_with_name(
                 name, LazyPlanes(7, self.get_layer_raw, device_map=self), self.layer_names,
-                LazyPlanes(len(sem.layer_names), sem._layer) if sem is not None else None,
+                LazyPlanes(len(sem.layer_names), sem._layer, rows=self.rows, cols=self.cell_n) if sem is not None else None,
                 self.semantic_map.layer_names if self.semantic_map is not None else [],
                 self.base_rotation, self.semantic_map.elements_to_shift if self.semantic_map is not None else {})
             return self.plugin_manager.get_map_with_name(name)

@@ -15,6 +15,18 @@ def _zeros(*shape):
     return field(default_factory=lambda: np.zeros(shape, np.float32))
 
 
+class _WeightsUnpickler(pickle.Unpickler):
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"), ("numpy", "dtype"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("collections", "OrderedDict"),
+                ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+                ("_codecs", "encode")}          # protocol-2 pickles rebuild an array's bytes with _codecs.encode(str, "latin1")
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("weight file refers to %s.%s: only numpy arrays in a dict are accepted" % (module, name))
+
+
 @dataclass
 class Parameter:
     resolution: float = 0.04
@@ -97,9 +109,10 @@ class Parameter:
     device: int = 0
 
     def load_weights(self, filename):
-        """Same file format as the reference (pickled dict of numpy arrays, parameter.py:227-238)."""
+        """Same file format as the reference (pickled dict of numpy arrays, parameter.py:227-238).  A pickle can run arbitrary
+        code when it is opened: only the classes such a file needs (numpy array reconstruction, dict / OrderedDict) are resolved."""
         with open(filename, "rb") as f:
-            weights = pickle.load(f)
+            weights = _WeightsUnpickler(f).load()
         self.w1 = np.asarray(weights["conv1.weight"], np.float32)
         self.w2 = np.asarray(weights["conv2.weight"], np.float32)
         self.w3 = np.asarray(weights["conv3.weight"], np.float32)

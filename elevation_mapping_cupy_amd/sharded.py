@@ -109,6 +109,14 @@ class TorchComm:
         if self.host_sync:
             self.torch.cuda.synchronize(self.device)
 
+    def all_gather_object(self, obj):
+        if self.world == 1:
+            return [obj]
+        self._drain()
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
@@ -175,6 +183,19 @@ class NativeComm:
 
     def selftest(self):
         self.e._chk(self.e.lib.emap_comm_selftest(self.e.ctx))
+
+    def gather_layer(self, plane_id):
+        """(cell_n, cell_n) plane of the FULL map on every rank (emap_comm_gather_layer: an exact all-reduce of zero-padded planes)"""
+        C = self.e.C
+        out = np.empty((C, C), np.float32)
+        self.e._chk(self.e.lib.emap_comm_gather_layer(self.e.ctx, int(plane_id), out.ctypes.data_as(ct.POINTER(ct.c_float))))
+        return out
+
+    def rccl_ranks(self):
+        """size of the live RCCL communicator as RCCL reports it (ncclCommCount)"""
+        n = ct.c_int32(0)
+        self.e._chk(self.e.lib.emap_comm_count(self.e.ctx, ct.byref(n)))
+        return int(n.value)
 
     def _oob(self, t):
         """tensor for the out-of-band (bootstrap) channel: CPU when gloo is available, else on the strip's device"""
@@ -339,6 +360,23 @@ class ShardedElevationMap:
     def __init__(self, engine, comm, enable_visibility_cleanup, enable_overlap_clearance):
         self.e, self.comm = engine, comm
         self.rays_on, self.overlap_on = bool(enable_visibility_cleanup), bool(enable_overlap_clearance)
+
+    def gather(self, name):
+        """one plane of the FULL map, assembled from the strips, on every rank (collective).  ``name``: a core layer name, "normal_x" /
+        "normal_y" / "normal_z" or "traversability_input".  Row r of the result is logical map row r, like the single-context map."""
+        from ._lib import PLANES
+        pid = PLANES[name] if isinstance(name, str) else int(name)
+        if hasattr(self.comm, "gather_layer"):
+            return self.comm.gather_layer(pid)
+        # generic communicators (torch.distributed / gloo): all-gather of (logical begin, rows) through the comm's object channel
+        m = self.e.map
+        mine = (m.logical_row_begin, m.get_layer_raw(pid))
+        parts = self.comm.all_gather_object(mine)
+        C = mine[1].shape[1]
+        full = np.zeros((C, C), np.float32)
+        for b, rows in parts:
+            full[(b + np.arange(rows.shape[0])) % C] = rows
+        return full
 
     def move_to(self, position, R):
         self.e.move_to(position, R)

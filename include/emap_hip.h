@@ -235,10 +235,17 @@ int emap_comm_unique_id(const char* rccl_path, uint8_t id_out[128]);
 int emap_comm_init(emap_ctx* ctx, const char* rccl_path, const uint8_t id[128], int32_t rank, int32_t world);
 int emap_comm_destroy(emap_ctx* ctx);
 int emap_comm_selftest(emap_ctx* ctx);
+/* number of ranks RCCL itself reports for the communicator (ncclCommCount): what a launcher prints as evidence that the
+ * strips really talk through one RCCL communicator of that size */
+int emap_comm_count(emap_ctx* ctx, int32_t* ranks);
 /* out-of-band reductions over the ranks through the communicator itself (barriers and timing reductions of a launcher:
  * no second bootstrap channel needed once RCCL is up): all-reduce of n <= 16 host doubles, op 0 = sum, 1 = max, in place;
  * blocks until the result is back on the host, i.e. it is also a barrier behind all work enqueued on the strip's stream. */
 int emap_comm_allreduce_host(emap_ctx* ctx, double* inout, int32_t n, int32_t op);
+/* one plane (EMAP_PLANE_*) of the FULL map on every rank: the strips' rows placed at their logical rows in a zeroed cell_n x cell_n
+ * plane, all-reduced (exact: x + 0; -0.0 returns as +0.0).  Collective; for read-back / publishing, not on the per-frame path.
+ * The reference has one map object and reads it directly (get_map_with_name_ref, elevation_mapping.py:720-775). */
+int emap_comm_gather_layer(emap_ctx* ctx, int32_t plane, float* host_full_out);
 int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise,
                         emap_stats* stats /* may be NULL: no host synchronisation */);
 

@@ -6,8 +6,16 @@ path are pure array code: the drift gate (``update_map_with_kernel``, :346-357),
 ``update_variance`` / ``update_time`` (:420-426) and the map shift (``move_to`` / ``move`` / ``pad_value`` / ``shift_map_xy`` /
 ``shift_map_z``, :139-226).  This module parses the file with ``ast``, takes those function bodies (and the gate's ``if``
 statement) unmodified, compiles them with ``cp = xp = numpy`` and binds them to a small state object.  Nothing of the reference
-is copied into the repository; without /root/reference ``available()`` is False and the committed golden vectors
-(tests/golden/host_steps.npz, made by tests/golden/make_golden.py from this module) stand in.
+is copied into the repository.  The committed golden vectors (tests/golden/host_steps.npz, made by tests/golden/make_golden.py from
+this module) are the DEFAULT pin; executing the reference file live is opt-in:
+
+* ``available()`` is True only when ``EMAP_REF_EXEC=1`` is set AND the file exists (the reference tree is untrusted public content:
+  nothing of it runs unless the person at the keyboard asks for it; ``EMAP_REF_FILE`` overrides the path for a hermetic regeneration);
+* before anything is compiled, ``_vet`` walks the extracted syntax trees and rejects every construct the known host code does not
+  need: imports, nested function / class definitions, lambdas, ``global`` / ``nonlocal``, ``with`` (except ``with self.map_lock``) / ``try`` / ``raise`` / ``del``,
+  awaits / yields, dunder names and dunder attributes, string formatting, and every call or attribute chain whose root is not one of
+  ``self`` / ``cp`` / ``xp`` / ``np`` / a local variable / a whitelisted builtin (``int``, ``float``, ``abs``, ``min``, ``max``, ``len``, ``range``,
+  ``print``).  The namespace handed to ``exec`` carries no ``__builtins__`` beyond that list.
 """
 from __future__ import annotations
 
@@ -18,13 +26,53 @@ import types
 
 import numpy as np
 
-REF_FILE = "/root/reference/elevation_mapping_cupy/script/elevation_mapping_cupy/elevation_mapping.py"
+REF_FILE = os.environ.get("EMAP_REF_FILE", "/root/reference/elevation_mapping_cupy/script/elevation_mapping_cupy/elevation_mapping.py")
+_SAFE_BUILTINS = {"int": int, "float": float, "abs": abs, "min": min, "max": max, "len": len, "range": range, "print": print, "bool": bool}
+_ROOTS = {"self", "cp", "xp", "np"}
 METHODS = ("clear_overlap_map", "update_variance", "update_time", "move", "move_to", "pad_value", "shift_map_xy", "shift_map_z",
            "shift_translation_to_map_center")
 
 
 def available():
-    return os.path.isfile(REF_FILE)
+    """live execution of the reference's host code: explicit opt-in only (the golden vectors are the default pin)"""
+    return os.environ.get("EMAP_REF_EXEC", "0") == "1" and os.path.isfile(REF_FILE)
+
+
+class UnsafeReferenceCode(RuntimeError):
+    pass
+
+
+def _vet(node, what, extra_locals=()):
+    """reject anything beyond plain array arithmetic on self / cp / xp / np before the tree is compiled (see the module docstring)"""
+    banned = (ast.Import, ast.ImportFrom, ast.ClassDef, ast.Lambda, ast.Global, ast.Nonlocal, ast.AsyncWith, ast.Try, ast.Raise,
+              ast.Delete, ast.Await, ast.Yield, ast.YieldFrom, ast.AsyncFunctionDef, ast.AsyncFor, ast.JoinedStr, ast.NamedExpr, ast.Starred)
+    top = node
+    local = set(extra_locals)
+    for n in ast.walk(top):
+        if isinstance(n, ast.arg):
+            local.add(n.arg)
+        elif isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store):
+            local.add(n.id)
+    for n in ast.walk(top):
+        if isinstance(n, banned) or (isinstance(n, ast.FunctionDef) and n is not top):
+            raise UnsafeReferenceCode("%s: %s at line %s is not allowed" % (what, type(n).__name__, getattr(n, "lineno", "?")))
+        if isinstance(n, ast.With):          # the reference guards its map with `with self.map_lock:` -- nothing else may be entered
+            for it in n.items:
+                e = it.context_expr
+                if not (it.optional_vars is None and isinstance(e, ast.Attribute) and e.attr == "map_lock" and isinstance(e.value, ast.Name) and e.value.id == "self"):
+                    raise UnsafeReferenceCode("%s: `with` on something other than self.map_lock (line %s)" % (what, n.lineno))
+        if isinstance(n, ast.Name) and n.id.startswith("__"):
+            raise UnsafeReferenceCode("%s: dunder name %r" % (what, n.id))
+        if isinstance(n, ast.Attribute) and n.attr.startswith("_"):
+            raise UnsafeReferenceCode("%s: private / dunder attribute %r" % (what, n.attr))
+        if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in local and n.id not in _ROOTS and n.id not in _SAFE_BUILTINS:
+            raise UnsafeReferenceCode("%s: free name %r at line %s" % (what, n.id, n.lineno))
+        if isinstance(n, ast.Call):
+            f = n.func
+            while isinstance(f, (ast.Attribute, ast.Subscript, ast.Call)):
+                f = f.value if not isinstance(f, ast.Call) else f.func
+            if not (isinstance(f, ast.Name) and (f.id in _ROOTS or f.id in _SAFE_BUILTINS or f.id in local)):
+                raise UnsafeReferenceCode("%s: call rooted at %s (line %s)" % (what, ast.dump(f)[:60], n.lineno))
 
 
 class _Sem:
@@ -41,7 +89,7 @@ def _namespace():
     xp = types.ModuleType("numpy_as_cupy")
     xp.__dict__.update(np.__dict__)
     xp.asnumpy = lambda a: np.asarray(a)          # cupy-only helper used by get_position
-    return {"cp": xp, "xp": xp, "np": np}
+    return {"cp": xp, "xp": xp, "np": np, "__builtins__": dict(_SAFE_BUILTINS)}
 
 
 def load():
@@ -50,6 +98,8 @@ def load():
     cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "ElevationMap")
     fns = {n.name: n for n in cls.body if isinstance(n, ast.FunctionDef)}
     ns = _namespace()
+    for m in METHODS:
+        _vet(fns[m], m)
     mod = ast.Module(body=[fns[m] for m in METHODS], type_ignores=[])
     exec(compile(mod, REF_FILE, "exec"), ns)
     # the drift gate: the `if self.param.enable_drift_compensation and error_cnt > ...` statement of update_map_with_kernel
@@ -60,6 +110,7 @@ def load():
             gate_if = node
             break
     assert gate_if is not None, "drift gate not found in the reference"
+    _vet(gate_if, "drift gate", ("self", "error", "error_cnt", "position_noise", "orientation_noise"))
     args = ast.arguments(posonlyargs=[], args=[ast.arg(a) for a in ("self", "error", "error_cnt", "position_noise", "orientation_noise")],
                          kwonlyargs=[], kw_defaults=[], defaults=[])
     gfn = ast.FunctionDef(name="drift_gate", args=args, body=[gate_if], decorator_list=[], lineno=gate_if.lineno, col_offset=0)

@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY.  An in-process stand-in for the nine RCCL entry points libemap_hip.so resolves with dlopen
+// TEST INFRASTRUCTURE ONLY.  An in-process stand-in for the ten RCCL entry points libemap_hip.so resolves with dlopen
 // (emap_comm_init): several "ranks" are THREADS of one process driving strip contexts on ONE GPU -- RCCL itself refuses two ranks
 // on one device, and the test box has one.  Semantics kept from RCCL: ncclCommInitRank is a rendezvous of all ranks;
 // ncclAllReduce returns the sum to every rank; grouped ncclSend / ncclRecv pair up by (source, destination) in issue order and a
@@ -54,23 +54,30 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   return ncclSuccess;
 }
 ncclResult_t ncclCommDestroy(ncclComm_t comm) { delete comm; return ncclSuccess; }
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) { *count = comm->nranks; return ncclSuccess; }
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "fake rccl error"; }
 
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op, ncclComm_t c, hipStream_t stream) {
-  if (dtype != 8 || (op != 0 && op != 2)) return ncclInvalidArgument;  // ncclFloat64 with ncclSum / ncclMax: all the path uses
+  if ((dtype != 8 && dtype != 7) || (op != 0 && op != 2)) return ncclInvalidArgument;  // ncclFloat64 / ncclFloat32 with ncclSum / ncclMax: all the path uses
   if (hipStreamSynchronize(stream) != hipSuccess) return ncclInternalError;
+  const size_t esz = dtype == 8 ? 8 : 4;
   Shared* sh = c->sh;
   std::unique_lock<std::mutex> l(sh->m);
   const int gen = sh->ar_gen;
   sh->ar_src[c->rank] = send; sh->ar_dst[c->rank] = recv; sh->ar_count = count;
   if (++sh->ar_arrived == sh->nranks) {
-    std::vector<double> tot(count, 0.0), tmp(count);
+    std::vector<double> tot(count, 0.0);
+    std::vector<char> raw(count * esz);
     for (int r = 0; r < sh->nranks; ++r) {
-      if (hipMemcpy(tmp.data(), sh->ar_src[r], count * 8, hipMemcpyDeviceToHost) != hipSuccess) return ncclInternalError;
-      for (size_t k = 0; k < count; ++k) tot[k] = (op == 0) ? tot[k] + tmp[k] : (r == 0 ? tmp[k] : (tmp[k] > tot[k] ? tmp[k] : tot[k]));
+      if (hipMemcpy(raw.data(), sh->ar_src[r], count * esz, hipMemcpyDeviceToHost) != hipSuccess) return ncclInternalError;
+      for (size_t k = 0; k < count; ++k) {
+        const double x = dtype == 8 ? reinterpret_cast<const double*>(raw.data())[k] : (double)reinterpret_cast<const float*>(raw.data())[k];
+        tot[k] = (op == 0) ? tot[k] + x : (r == 0 ? x : (x > tot[k] ? x : tot[k]));
+      }
     }
+    if (dtype == 7) { float* f = reinterpret_cast<float*>(raw.data()); for (size_t k = 0; k < count; ++k) f[k] = (float)tot[k]; }
     for (int r = 0; r < sh->nranks; ++r)
-      if (hipMemcpy(sh->ar_dst[r], tot.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess) return ncclInternalError;
+      if (hipMemcpy(sh->ar_dst[r], dtype == 8 ? (const void*)tot.data() : (const void*)raw.data(), count * esz, hipMemcpyHostToDevice) != hipSuccess) return ncclInternalError;
     sh->ar_arrived = 0; sh->ar_gen++;
     sh->cv.notify_all();
   } else sh->cv.wait(l, [&] { return sh->ar_gen != gen; });

@@ -16,7 +16,6 @@ Fixtures (all inputs are regenerated from seeds by tests/_fixtures.py, only outp
 import hashlib
 import json
 import os
-import pickle
 import sys
 
 import numpy as np
@@ -31,7 +30,8 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 
 def weights():
-    w = pickle.load(open("/root/reference/elevation_mapping_cupy/config/core/weights.dat", "rb"))
+    from elevation_mapping_cupy_amd.parameter import _WeightsUnpickler      # numpy arrays in a dict only: the file is untrusted content
+    w = _WeightsUnpickler(open("/root/reference/elevation_mapping_cupy/config/core/weights.dat", "rb")).load()
     np.savez(os.path.join(OUT, "weights.npz"), w1=w["conv1.weight"], w2=w["conv2.weight"], w3=w["conv3.weight"],
              w_out=w["conv_final.weight"])
 

@@ -124,6 +124,7 @@ def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, 
             eng.map.set_scatter_mode(scatter)
             comm = NativeComm(eng, rank=rank, world=world, bootstrap=False, uid=bytes(uid), rccl_path=lib_path)
             comm.selftest()
+            assert comm.rccl_ranks() == world
             sm = ShardedElevationMap(eng, comm, cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
             for p, mv in zip(clouds, MV):
                 eng.bind_points(p)
@@ -133,7 +134,8 @@ def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, 
                 if mv is not None:
                     sm.move_to(np.array(mv, np.float64), np.eye(3))
             eng.sync()
-            out[rank] = (eng.map.logical_row_begin, eng.map.rows, eng.map.elevation_map, eng.map.normal_map, eng.map.get_additive_mean_error())
+            full = (sm.gather("elevation"), sm.gather("normal_z")) if scatter == "binned" else None      # collective read-back of whole planes
+            out[rank] = (eng.map.logical_row_begin, eng.map.rows, eng.map.elevation_map, eng.map.normal_map, eng.map.get_additive_mean_error(), full)
             eng.lib.emap_comm_destroy(eng.ctx)
         except Exception as e:  # pragma: no cover
             errs.append(e)
@@ -143,7 +145,11 @@ def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, 
     [x.join(timeout=120) for x in th]
     assert not any(x.is_alive() for x in th), "a rank is stuck in the exchange"
     assert not errs, errs
-    for b, rows, m, nm, add in out:
+    for b, rows, m, nm, add, full in out:
+        if full is not None and not moves:                        # (after a move a strip's un-shifted normals have holes: see above)
+            assert np.array_equal(full[0], want[0]) and np.array_equal(full[1], want_n[2]), "gathered planes differ"
+        elif full is not None:
+            assert np.array_equal(full[0], want[0]), "gathered elevation differs"
         idx = (b + np.arange(rows)) % C                           # the strip's view: logical rows b, b + 1, ... of the full map
         assert m.tobytes() == np.take(want, idx, axis=1).tobytes(), "strip whose view starts at logical row %d differs" % b
         assert nm.tobytes() == np.take(want_n, idx, axis=1).tobytes()

@@ -33,6 +33,9 @@ class OracleStripEngine:
         mask = np.ones(C, bool); mask[self.r0:self.r1] = False
         self.om.elevation_map[:, mask, :] = rng.uniform(-5, 5, (7, int(mask.sum()), C)).astype(np.float32)
         self.recv = [torch.zeros((7, max(self.H, 1), C), dtype=torch.float32) for _ in range(2)]
+        # what ShardedElevationMap.gather reads from an engine: the strip's first logical row and its rows of a plane
+        import types
+        self.map = types.SimpleNamespace(logical_row_begin=self.r0, get_layer_raw=lambda pid: self.om.elevation_map[pid, self.r0:self.r1].copy())
 
     def bind_points(self, p):
         self.p = p
@@ -95,8 +98,9 @@ def _worker(rank, world, port, outdir, cfg_name, C, N):
         sm.update(R, t, 1.0, 1.0)
         for _ in range(6):
             eng.update_time()
+    full_h = sm.gather("elevation")                        # collective: the whole plane on every rank
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), r0=eng.r0, r1=eng.r1, emap=eng.om.elevation_map[:, eng.r0:eng.r1],
-             normal=eng.om.normal_map[:, eng.r0:eng.r1], add_err=np.float32(eng.om.additive_mean_error))
+             normal=eng.om.normal_map[:, eng.r0:eng.r1], add_err=np.float32(eng.om.additive_mean_error), full_h=full_h)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -123,9 +127,11 @@ def test_strips_equal_single_process(world, cfg_name, C, N, weights):
         g = np.load(os.path.join(outdir, "rank%d.npz" % r))
         r0, r1 = int(g["r0"]), int(g["r1"])
         covered[r0:r1] = True
-        assert np.allclose(g["emap"], ref.elevation_map[:, r0:r1], atol=1e-6, rtol=1e-6, equal_nan=True), "rank %d planes" % r
-        assert np.allclose(g["normal"], ref.normal_map[:, r0:r1], atol=1e-6), "rank %d normals" % r
-        assert abs(float(g["add_err"]) - float(ref.additive_mean_error)) < 1e-6
+        # integer / fixed-point accumulators on both sides: the strips reproduce the single map bit for bit
+        assert g["emap"].tobytes() == ref.elevation_map[:, r0:r1].tobytes(), "rank %d planes" % r
+        assert g["normal"].tobytes() == ref.normal_map[:, r0:r1].tobytes(), "rank %d normals" % r
+        assert float(g["add_err"]) == float(ref.additive_mean_error)
+        assert g["full_h"].tobytes() == ref.elevation_map[0].tobytes(), "rank %d: gathered plane" % r
     assert covered.all()
 
 
