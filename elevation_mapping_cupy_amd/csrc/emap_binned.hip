@@ -256,6 +256,22 @@ __device__ __forceinline__ bool drift_inlier(const KP& P, const float4 m, float 
 }
 
 #define TF_BLOCK 1024   /* threads per tile of the tile kernels */
+// The hot halves (h, v, valid, trav) of one 16 x 64 tile -> LDS, one wave per tile row.  Without pending map moves this is a pure
+// copy of 1 KB per row: gfx950's LDS-DMA (no VGPR round trip, no ds_write); cells beyond the map / strip read as zero.  With pending
+// moves the cells pass through cell_now() in registers.  The caller's next __syncthreads() publishes the tile.
+__device__ __forceinline__ void stage_hot_tile(const KP& P, Cells cells, float4* s_cell, int row_base, int tx) {
+  const int tr = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tc = threadIdx.x & 63, lrow = row_base + tr, col = tx * BIN_TC + tc;   // 1024 threads = 16 x 64 cells
+  const bool in = lrow < P.nrows && col < P.C;
+  const float4* src = cells.hot + ((long)(lrow + P.halo) * P.C + col);
+  if (P.mv.n == 0) {                                       // (uniform)
+    if (in) lds_dma16(src, s_cell + tr * BIN_TC);
+    else s_cell[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) { m = *src; cell_now(P, m, P.row0 + lrow, col); }
+    s_cell[threadIdx.x] = m;
+  }
+}
 // Error sums of the drift compensation, per tile: the tile's cells are staged ONCE, coalesced, in LDS and every sorted record of
 // the tile is tested against its cell there -- the per-point gather of a random 32-byte cell (a whole 128-byte line per point,
 // 144 MB fetched for 48 MB needed, profiles/r01f_pmc_cfg2.json) is gone.  Wave-reduced sums go to the 256 padded slots.
@@ -268,12 +284,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const B
   const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
   const int row_base = (ty * G.sub + (int)blockIdx.y) * BIN_TR;
   if (row_base >= P.nrows || r0 == r1) return;
-  {
-    const int tr = threadIdx.x >> 6, tc = threadIdx.x & 63, lrow = row_base + tr, col = tx * BIN_TC + tc;   // 1024 threads = 16 x 64 cells
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lrow < P.nrows && col < P.C) { m = cells.hot[(long)(lrow + P.halo) * P.C + col]; cell_now(P, m, P.row0 + lrow, col); }
-    s_cell[threadIdx.x] = m;
-  }
+  stage_hot_tile(P, cells, s_cell, row_base, tx);
   __syncthreads();
   const unsigned int sel = blockIdx.y;
   for (unsigned int kb = r0; kb < r1; kb += TF_BLOCK) {     // uniform trip count: the wave reductions need all lanes
@@ -327,13 +338,8 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
     if (row_base >= P.nrows) return;              // uniform, before any barrier
     const unsigned int sel = (unsigned int)sb;
     if (threadIdx.x == 0) s_shift = GF.mode ? gate_fold(GF, F, blockIdx.x == 0 && blockIdx.y == 0) : F->shift;      // only pass 2 needs it
-    for (int k = threadIdx.x; k < NC; k += TF_BLOCK) {
-      s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull;
-      const int lrow = row_base + k / BIN_TC, colk = tx * BIN_TC + k % BIN_TC;
-      float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lrow < P.nrows && colk < P.C) { m = cells.hot[(long)(lrow + P.halo) * P.C + colk]; cell_now(P, m, P.row0 + lrow, colk); }
-      s_cell[k] = m;
-    }
+    stage_hot_tile(P, cells, s_cell, row_base, tx);
+    for (int k = threadIdx.x; k < NC; k += TF_BLOCK) { s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull; }
     __syncthreads();
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += TF_BLOCK) {          // pass 1: newmap[4] / newmap[3]
       const BinRec r = recs[k];

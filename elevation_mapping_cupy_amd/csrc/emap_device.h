@@ -373,6 +373,18 @@ struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, TB, pitch, rayb
 struct __attribute__((aligned(16))) BinRec { unsigned int lc_inl; float z, v; unsigned int i; };  // sorted by tile
 struct BinStg;                                                                                     // staging record of the strip variants
 
+// ---- gfx950 LDS-DMA: 64 lanes x 16 bytes from global memory straight into LDS (global_load_lds_dwordx4) -------------------------
+// lane i's 16 bytes land at lds_base + 16 i (lds_base must be wave-uniform); the copy is ordered for readers by the vmcnt(0) the
+// compiler places in front of the next __syncthreads().  For PURE copies of 16-byte records: no VGPR round trip, no ds_write.
+typedef __attribute__((address_space(3))) void em_lds_void;
+typedef __attribute__((address_space(1))) const void em_glb_void;
+__device__ __forceinline__ void lds_dma16(const void* gsrc_lane, void* lds_base_uniform) {
+  __builtin_amdgcn_global_load_lds((em_glb_void*)gsrc_lane, (em_lds_void*)lds_base_uniform, 16, 0, 0);
+}
+__device__ __forceinline__ void lds_dma16_at(const void* gsrc_lane, unsigned int lds_byte_offset_uniform) {      // destination given as an LDS byte offset
+  __builtin_amdgcn_global_load_lds((em_glb_void*)gsrc_lane, (em_lds_void*)(size_t)lds_byte_offset_uniform, 16, 0, 0);
+}
+
 // ---- host: raising a kernel's dynamic LDS limit beyond the default 64 KB ---------------------------------------------------
 // hipFuncSetAttribute applies to the CURRENT DEVICE, so the "already raised" flag is kept per (kernel instantiation, device) --
 // a process may hold contexts on several devices (thread-mode strips) -- and only set once the call has succeeded.  Racing threads

@@ -227,10 +227,14 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
   unsigned int map_align = 4u; while (map_align < wpr32 * 4u) map_align <<= 1;
   const unsigned int q_end = (unsigned int)(size_t)(lds_u32*)(qbase + (BLOCK / 64) * 384);       // byte offset in LDS
   const unsigned int smap_base = LMAP ? (q_end + map_align - 1u) & ~(map_align - 1u) : 0u;
-  if (LMAP) {
+  if (LMAP) {     // a pure copy: LDS-DMA, one kilobyte per wave instruction (the row pitch is a multiple of 16 bytes); the two trailing all-ones words by hand
     lds_u32* smap = (lds_u32*)(size_t)smap_base;
-    const unsigned int nw = (unsigned int)P.nrows * wpr32 + 2u;
-    for (unsigned int k = threadIdx.x; k < nw; k += BLOCK) smap[k] = inert[k];
+    const unsigned int nb = (unsigned int)P.nrows * wpr32 * 4u;                 // bytes of the bitmap proper
+    const char* src = reinterpret_cast<const char*>(inert);
+    const unsigned int wave0 = (unsigned int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 1024u, lane16 = (threadIdx.x & 63u) * 16u;
+    for (unsigned int off = wave0; off < nb; off += (BLOCK / 64) * 1024u)
+      if (off + lane16 < nb) lds_dma16_at(src + off + lane16, smap_base + off);
+    if (threadIdx.x < 2) smap[nb / 4u + threadIdx.x] = inert[nb / 4u + threadIdx.x];
   }
   __syncthreads();
   float frac_v = P.hw_frac_f;
@@ -611,6 +615,172 @@ __device__ __forceinline__ float exp_neg(float a) {
   return __builtin_amdgcn_ldexpf(p, (int)n);
 }
 
+// One output cell of the fused stencils: traversability_input (the dilated value), the traversability filter and the normal.
+// t0 = the cell's dilated value inside an LDS plane with element stride ES (floats) and row pitch dp (elements).  The four channels
+// of a dilated 3x3 filter go through packed fp32 FMAs in PAIRS (v_pk_fma_f32: the two channels' weights are one aligned scalar
+// register pair, the tap is broadcast): each channel keeps the reference's tap order, and the 1x1 output convolution is the same
+// scalar chain over (filter, channel) as the unfused stage -- half the vector instructions of the 12 x 9-tap filter bank.
+template <int STAGE, int ES>
+__device__ __forceinline__ void post_cell(const KP& P, const TravW& Wt, const float* t0, int dp, float own_valid, bool do_trav, bool do_normal,
+                                          Cells cells, float* __restrict__ trav_in, float* __restrict__ normal, long plane_stride, long c) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const float h = t0[0];
+  trav_in[c] = h;
+  if (STAGE == 1) return;
+  if (do_trav) {
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int dl = q + 1;
+      v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+#pragma unroll
+      for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) {
+          const float t = t0[((a2 - 1) * dl * dp + (b2 - 1) * dl) * ES];
+          const v2f tt = {t, t};
+          const float* w = Wt.w[q][a2 * 3 + b2];
+          s01 = __builtin_elementwise_fma((v2f){w[0], w[1]}, tt, s01);
+          s23 = __builtin_elementwise_fma((v2f){w[2], w[3]}, tt, s23);
+        }
+      acc = fmaf(Wt.wo[q][0], fabsf(s01.x), acc);
+      acc = fmaf(Wt.wo[q][1], fabsf(s01.y), acc);
+      acc = fmaf(Wt.wo[q][2], fabsf(s23.x), acc);
+      acc = fmaf(Wt.wo[q][3], fabsf(s23.y), acc);
+    }
+    cells.hot[c].w = exp_neg(acc);                  // trav: a 4-byte store into the 16-byte hot half
+  }
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  if (do_normal && own_valid > 0.5f) {                                  // (is_valid of the cell itself)
+    const float dzdx = t0[ES] - h, dzdy = t0[ES * dp] - h;
+    const float ax = -dzdy / P.res_f, ay = -dzdx / P.res_f;           // IEEE: v_div_scale / v_div_fmas / v_div_fixup sequences
+    const float nrm = sqrt_rn_ge1((ax * ax) + (ay * ay) + 1.0f);
+    nx = ax / nrm; ny = ay / nrm; nz = 1.0f / nrm;
+  }
+  normal[c] = nx; normal[plane_stride + c] = ny; normal[2 * plane_stride + c] = nz;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_post_dma: the same fused stencils with the region staged by gfx950's LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes
+// straight from HBM into LDS, no VGPR round trip, no ds_write).  The region is a pure copy of 16-byte cold halves (time, upper,
+// is_upper, valid'), so a wave moves one region row per instruction: lane = column, the LDS destination is wave-uniform base +
+// 16 x lane (what the instruction offers), the SOURCE address is per lane -- which is where the circular origin, the strip's local
+// rows and the reference's flat-index row wrap (:403-407) go.  Every wave computes the row terms it needs in registers (one
+// region row per lane, fetched with a lane permute): no table and no barrier in front of the loads.  Cells that do not exist
+// (beyond the map or the strip's rows) are read from a constant cell with mask 1 (never a hole) whose position excludes it as a
+// source in the (rare) hole search.  A second, LDS-only pass extracts the value plane the stencils read (unit stride: free of bank
+// conflicts -- tap reads on the 16-byte records would be 4-way conflicts) and lists the holes.
+// Measured (round 3, MI355X, event spacing, three sessions): with 16-row tiles (46 KB of LDS: three workgroups per CU) 244-252 us
+// at 4096^2 against 256-275 us for round 2's register-staged k_post, 22.1-22.9 vs 22.9 us at 1024^2 -- a gain of 2-10 %, not the
+// third the instruction count suggested: the kernel is not purely issue bound; with 32-row tiles (72 KB: two per CU) 265 / 24.1 us;
+// with the 4-row tiles of robot-scale maps 12.0 vs 9.7 us (those keep k_post).
+// Two dead ends on the way: the 12-byte DMA form (upper, is_upper, valid' only) still writes its lanes at a 16-byte LDS stride
+// (tools/dbg/dma12.hip), so it cannot produce conflict-free three-dword records; and a "lean" register-staged rewrite of the
+// staging loops (same structure as here, loads through VGPRs) compiled to 106 VGPRs and ran 30 % slower than round 2's kernel.
+// Large dilation radii (more than 62 region rows) keep k_post.
+// ---------------------------------------------------------------------------------------------------------
+struct NullCold { float time, upper, is_upper, valid; };
+__device__ const NullCold k_null_cold = {0.f, 0.f, 0.f, 1.f};
+
+template <int PT_R, int STAGE>
+__global__ __launch_bounds__(512) void k_post_dma(KP P, TravW Wt, Cells cells, float* __restrict__ trav_in,
+                                                  float* __restrict__ normal, long plane_stride, int d, PostSegs S) {
+  int seg_b = S.b[0], seg_e = S.e[0], ty = blockIdx.y;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) if (k < S.n && (int)blockIdx.y >= S.t0[k]) { seg_b = S.b[k]; seg_e = S.e[k]; ty = blockIdx.y - S.t0[k]; }
+  constexpr int PT_THREADS = 512, PT_WAVES = PT_THREADS / 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int RW = PT_C + 6 + 2 * d, RH = PT_R + 6 + 2 * d, vp = RW + 1;     // staged region: tile + halo 3 + d (RH + 2 <= 64); vp: pitch of the value plane
+  const int DW = PT_C + 6, DH = PT_R + 6;                                   // region whose DILATED value is needed (halo 3)
+  float4* raw = reinterpret_cast<float4*>(lds);                             // [RH][RW] cold halves as they lie in HBM
+  float* val = lds + 4 * RH * RW;                                           // [RH][vp] upper_bound, holes of the DW x DH region overwritten by their dilated value
+  int* rtab = reinterpret_cast<int*>(val + RH * vp);                        // RH + 2 row terms (hole search, epilogue)
+  unsigned short* holes = reinterpret_cast<unsigned short*>(rtab + ((RH + 3) & ~1));
+  __shared__ unsigned int n_holes;
+  if (threadIdx.x == 0) n_holes = 0u;
+  const int C = P.C;
+  const int tile_r = seg_b + ty * PT_R, tile_c = blockIdx.x * PT_C;        // logical row / column of the tile origin
+  const int tc = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r0 = tile_r - 3 - d, c0 = tile_c - 3 - d;
+  // row term of region row lane - 1 (one extra row on both sides for the flat-index carry): local row of the arrays (bits 0..23;
+  // bit 31 set: not in the map / strip), bit 30: a border row (never a dilation source)
+  int rowT;
+  {
+    const int g = r0 - 1 + tc;
+    const bool in_map = g >= 0 && g <= C - 1 && tc < RH + 2;
+    const int lr = in_map ? local_row(P, phys_row(P, g)) : -1;
+    rowT = lr < 0 ? (int)0x80000000 : lr | ((g >= 1 && g <= C - 2) ? 0 : 0x40000000);
+    if (wv == 0 && tc < RH + 2) rtab[tc] = rowT;                   // visible after the barrier below
+  }
+  auto col_terms = [&](int cc, int& dr, int& pc, int& flags) {     // region column -> row carry, physical column, flag bits
+    int cl = c0 + cc; dr = 0;
+    if (cl < 0) { cl += C; dr = -1; } else if (cl >= C) { cl -= C; dr = 1; }
+    flags = ((cl >= 1 && cl <= C - 2) ? 0 : 0x40000000) | ((cl >= 0 && cl < C) ? 0 : (int)0x80000000);      // (a region wider than the map: columns past the wrap are unused)
+    pc = (cl >= 0 && cl < C) ? phys_col(P, cl) : 0;
+  };
+  const int nchunk = (RW + 63) >> 6;
+  for (int k = 0; k < nchunk; ++k) {                               // phase 1: one DMA instruction per (region row, 64 columns)
+    const int cc = k * 64 + tc;
+    int dr, pc, fl;
+    col_terms(cc, dr, pc, fl);
+    for (int r = wv; r < RH; r += PT_WAVES) {
+      const int T = __shfl(rowT, r + 1 + dr, 64) | fl;             // (every lane takes part in the permute: a disabled source lane would read as 0)
+      const float4* src = T >= 0 ? cells.cold + (long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)pc)
+                                 : reinterpret_cast<const float4*>(&k_null_cold);
+      if (cc < RW) lds_dma16(src, raw + r * RW + k * 64);
+    }
+  }
+  __syncthreads();                                                 // (drains the DMA queue: the compiler places vmcnt(0) in front of the barrier)
+  for (int k = 0; k < nchunk; ++k) {                               // phase 2: value plane + hole list, LDS only
+    const int cc = k * 64 + tc;
+    const bool cwin = (unsigned int)(cc - d) < (unsigned int)DW;
+    if (cc < RW)
+      for (int r = wv; r < RH; r += PT_WAVES) {
+        const float4 q = raw[r * RW + cc];
+        val[r * vp + cc] = q.y;
+        // a hole of the region whose dilated value is needed (the constant cell of non-existent positions has mask 1: never listed)
+        if (q.z + q.w < 0.5f && cwin && (unsigned int)(r - d) < (unsigned int)DH) holes[atomicAdd(&n_holes, 1u)] = (unsigned short)((r - d) * DW + (cc - d));
+      }
+  }
+  __syncthreads();
+  // Hole search, one hole per lane: first hit on ascending anti-diagonals == the reference's scan order with its signed dx+dy
+  // criterion (:429-436).  Sources are cells with mask > 0.5 that exist and are is_inside (custom_kernels.py:34-44); a source is
+  // never a hole, so the in-place writes cannot feed another search (Jacobi semantics of the reference kernel).
+  const unsigned int nh = n_holes;
+  for (unsigned int hi = threadIdx.x; hi < nh; hi += PT_THREADS) {
+    const int pos = holes[hi], r = pos / DW + d, cc = pos - (pos / DW) * DW + d;
+    bool found = false;
+    for (int s2 = -2 * d; s2 <= 2 * d && !found; ++s2) {
+      const int dy0 = max(-d, s2 - d), dy1 = min(d, s2 + d);
+      for (int dy = dy0; dy <= dy1; ++dy) {
+        const int rs = r + dy, cs = cc + (s2 - dy);
+        const float4 q = raw[rs * RW + cs];
+        if (q.z + q.w > 0.5f) {
+          int dr, pc, fl;
+          col_terms(cs, dr, pc, fl);
+          if (((rtab[rs + 1 + dr] | fl) & (int)0xC0000000) == 0) { val[r * vp + cc] = q.y; found = true; break; }
+        }
+      }
+    }
+  }
+  if (nh) __syncthreads();                       // (uniform: every thread read the same count)
+  const int col = tile_c + tc;                   // logical column
+  if (col >= C) return;
+  const int pcol = phys_col(P, col);
+  constexpr int RPW = PT_R >= PT_WAVES ? PT_R / PT_WAVES : 1;
+  const bool col_in = STAGE == 0 && col >= 3 && col <= C - 4;
+  const bool col_n = col >= 1 && col <= C - 3;
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int tr = wv * RPW + k, gr = tile_r + tr;                 // scalar
+    if (tr >= PT_R || gr >= seg_e) break;
+    const int rr = tr + 3 + d, rc = tc + 3 + d;
+    const long c = (long)(rtab[rr + 1] & 0xffffff) * C + pcol;
+    post_cell<STAGE, 1>(P, Wt, &val[rr * vp + rc], vp, raw[rr * RW + rc].w, col_in && gr >= 3 && gr <= C - 4, col_n && gr >= 1 && gr <= C - 3, cells, trav_in,
+                        normal, plane_stride, c);
+  }
+}
+
 template <int PT_R, int STAGE>
 __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, TravW Wt, Cells cells, float* __restrict__ trav_in,
                                                     float* __restrict__ normal, long plane_stride, int d, PostSegs S) {
@@ -742,7 +912,6 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   // fp32 FMAs in PAIRS (v_pk_fma_f32: the two channels' weights are one aligned scalar register pair, the tap is broadcast): each
   // channel keeps the reference's tap order, and the 1x1 output convolution is the same scalar chain over (filter, channel) as the
   // unfused stage -- half the vector instructions of the 12 x 9-tap filter bank, identical sums.
-  typedef float v2f __attribute__((ext_vector_type(2)));
   constexpr int RPW = PT_R >= PT_WAVES ? PT_R / PT_WAVES : 1;
   const bool col_in = STAGE == 0 && col >= 3 && col <= C - 4;
   const bool col_n = col >= 1 && col <= C - 3;
@@ -752,40 +921,7 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
     if (tr >= PT_R || gr >= seg_e) break;
     const float* t0 = &dil[((tr + 3) * dp + (tc + 3)) * 3];
     const long c = (long)(rtab[tr + 4 + d] & 0xffffff) * C + pcol;
-    const float h = t0[0];
-    trav_in[c] = h;
-    if (STAGE == 1) continue;
-    if (col_in && gr >= 3 && gr <= C - 4) {
-      float acc = 0.f;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int dl = q + 1;
-        v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
-#pragma unroll
-        for (int a2 = 0; a2 < 3; ++a2)
-#pragma unroll
-          for (int b2 = 0; b2 < 3; ++b2) {
-            const float t = t0[((a2 - 1) * dl * dp + (b2 - 1) * dl) * 3];
-            const v2f tt = {t, t};
-            const float* w = Wt.w[q][a2 * 3 + b2];
-            s01 = __builtin_elementwise_fma((v2f){w[0], w[1]}, tt, s01);
-            s23 = __builtin_elementwise_fma((v2f){w[2], w[3]}, tt, s23);
-          }
-        acc = fmaf(Wt.wo[q][0], fabsf(s01.x), acc);
-        acc = fmaf(Wt.wo[q][1], fabsf(s01.y), acc);
-        acc = fmaf(Wt.wo[q][2], fabsf(s23.x), acc);
-        acc = fmaf(Wt.wo[q][3], fabsf(s23.y), acc);
-      }
-      cells.hot[c].w = exp_neg(acc);                  // trav: a 4-byte store into the 16-byte hot half
-    }
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (col_n && gr >= 1 && gr <= C - 3 && t0[2] > 0.5f) {                // (is_valid of the cell itself)
-      const float dzdx = t0[3] - h, dzdy = t0[3 * dp] - h;
-      const float ax = -dzdy / P.res_f, ay = -dzdx / P.res_f;           // IEEE: v_div_scale / v_div_fmas / v_div_fixup sequences
-      const float nrm = sqrt_rn_ge1((ax * ax) + (ay * ay) + 1.0f);
-      nx = ax / nrm; ny = ay / nrm; nz = 1.0f / nrm;
-    }
-    normal[c] = nx; normal[plane_stride + c] = ny; normal[2 * plane_stride + c] = nz;
+    post_cell<STAGE, 3>(P, Wt, t0, dp, t0[2], col_in && gr >= 3 && gr <= C - 4, col_n && gr >= 1 && gr <= C - 3, cells, trav_in, normal, plane_stride, c);
   }
 }
 
@@ -1008,8 +1144,17 @@ void launch_overlap(hipStream_t s, const KP& P, Cells cells, int cmin, int cmax,
   if (w <= 0) return;
   hipLaunchKernelGGL(k_overlap, dim3(nblk(w * w)), dim3(EM_BLOCK), 0, s, P, cells, cmin, cmax, hmin, hmax);
 }
-static size_t post_lds_bytes(int R, int d) {      // (value, mask, valid) region, row table, hole list
+static size_t post_lds_bytes(int R, int d) {      // k_post: (value, mask, valid) region, row table, hole list
   return sizeof(float) * ((size_t)3 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)(R + 6 + 2 * d + 4)) + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;
+}
+static size_t post_dma_lds_bytes(int R, int d) {  // k_post_dma: 16-byte region cells + value plane, row table, hole list
+  const size_t RH = R + 6 + 2 * d, RW = PT_C + 6 + 2 * d;
+  return 16 * RH * RW + 4 * RH * (RW + 1) + 4 * (RH + 4) + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;
+}
+// true: the LDS-DMA kernel handles this (tile height, radius) -- one lane per region row for the row terms, three workgroups per CU
+static bool post_use_dma(int R, int d) {
+  static const bool dma_off = getenv("EMAP_POST_DMA") && atoi(getenv("EMAP_POST_DMA")) == 0;     // A/B and test hook: round 2's kernel
+  return !dma_off && R >= 16 && R + 8 + 2 * d <= 64 && post_dma_lds_bytes(R, d) <= 52 * 1024;     // (4-row tiles of robot-scale maps: 12.0 vs 9.7 us, measured)
 }
 int post_tile_rows(const KP& P) {
   static const int force_r = []() { const char* e = getenv("EMAP_POST_R"); int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32) ? v : 0; }();
@@ -1018,7 +1163,8 @@ int post_tile_rows(const KP& P) {
   else if ((long)P.nrows * P.C <= 512L * 512L) R = 4;
   else if (post_lds_bytes(32, P.dil) > 60 * 1024) R = 16;             // large dilation radii: keep two workgroups per CU
   else R = (long)((P.C + PT_C - 1) / PT_C) * ((P.nrows + 31) / 32) >= 512 ? 32 : 16;
-  while (R > 4 && post_lds_bytes(R, P.dil) > 150 * 1024) R /= 2;      // dilation radii up to 32: the staged region must fit the 160 KB LDS
+  if (!force_r && R == 32 && post_use_dma(16, P.dil)) R = 16;        // the DMA kernel wants three workgroups per CU: 16-row tiles (measured, see k_post_dma)
+  while (R > 4 && !post_use_dma(R, P.dil) && post_lds_bytes(R, P.dil) > 150 * 1024) R /= 2;      // dilation radii up to 32: the staged region must fit the 160 KB LDS
   return R;
 }
 // outputs for up to four LOGICAL row intervals [seg_b[k], seg_e[k]) (owned by this strip, no circular seam inside); stage 1 = dilation only
@@ -1040,13 +1186,17 @@ void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, c
     S.b[S.n] = seg_b[k]; S.e[S.n] = seg_e[k]; S.t0[S.n] = tiles; tiles += (seg_e[k] - seg_b[k] + R - 1) / R; S.n++;
   }
   if (!tiles) return;
-  dim3 g((P.C + PT_C - 1) / PT_C, tiles), b(R >= 32 ? POST_T32 : 512);
-  const size_t lds = post_lds_bytes(R, d);
-#define POST_GO(RR, ST) do { auto kern = k_post<RR, ST>; static LdsRaised raised; \
+  const bool dma = post_use_dma(R, d);
+  dim3 g((P.C + PT_C - 1) / PT_C, tiles), b(dma ? 512 : (R >= 32 ? POST_T32 : 512));
+  const size_t lds = dma ? post_dma_lds_bytes(R, d) : post_lds_bytes(R, d);
+#define POST_GO(KERN, RR, ST) do { auto kern = KERN<RR, ST>; static LdsRaised raised; \
     raise_lds(kern, raised, 158 * 1024); \
     hipLaunchKernelGGL(kern, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, S); } while (0)
-  if (stage == 1) { if (R == 4) POST_GO(4, 1); else if (R == 8) POST_GO(8, 1); else if (R == 32) POST_GO(32, 1); else POST_GO(16, 1); }
-  else { if (R == 4) POST_GO(4, 0); else if (R == 8) POST_GO(8, 0); else if (R == 32) POST_GO(32, 0); else POST_GO(16, 0); }
+#define POST_ALL(KERN) do { \
+    if (stage == 1) { if (R == 4) POST_GO(KERN, 4, 1); else if (R == 8) POST_GO(KERN, 8, 1); else if (R == 32) POST_GO(KERN, 32, 1); else POST_GO(KERN, 16, 1); } \
+    else { if (R == 4) POST_GO(KERN, 4, 0); else if (R == 8) POST_GO(KERN, 8, 0); else if (R == 32) POST_GO(KERN, 32, 0); else POST_GO(KERN, 16, 0); } } while (0)
+  if (dma) POST_ALL(k_post_dma); else POST_ALL(k_post);
+#undef POST_ALL
 #undef POST_GO
 }
 void launch_var_time(hipStream_t s, const KP& P, Cells cells, int do_var, int do_time) {
