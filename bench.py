@@ -32,6 +32,40 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+PROFILE_ROUND = "r03"  # tag of the committed rocprofv3 summaries under profiles/ that this round's numbers refer to
+
+
+def source_stamp():
+    """sha256 over the kernel sources: every file under profiles/ is stamped with it (tools/profile_round.sh), and a profile is only
+    quoted next to a live measurement when its stamp equals the stamp of the sources the loaded library was built from"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "elevation_mapping_cupy_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode()); h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def rocprof_kernel_us(workload, kernel_prefix):
+    """average duration (us) of a kernel in profiles/<round>_<workload>_kernel_stats.txt -- None when the file is missing or was taken
+    with other kernel sources (its '# source_stamp:' line)"""
+    f = os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.txt" % (PROFILE_ROUND, workload))
+    if not os.path.exists(f):
+        return None, None
+    lines = open(f).read().splitlines()
+    stamp = next((ln.split(":", 1)[1].strip() for ln in lines if ln.startswith("# source_stamp:")), None)
+    if stamp != source_stamp():
+        return None, "profiles/%s: taken with other kernel sources (stamp %s, now %s)" % (os.path.basename(f), stamp, source_stamp())
+    for ln in lines:
+        name = ln.replace("void ", "", 1).lstrip()
+        if name.startswith(kernel_prefix):
+            tok = ln[86:].split()
+            try:
+                return float(tok[1]), "profiles/%s (avg of %s launches)" % (os.path.basename(f), tok[0])
+            except (IndexError, ValueError):
+                pass
+    return None, None
 
 
 def parse(argv=None):
@@ -39,14 +73,15 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"],
-                    help="cfg2/cfg3: BASELINE configs[1]/[2] (1024^2, 1 M points); cfg5: 8192^2 multi-modal map "
-                         "(height + RGB + 3 semantic layers), 16 M points, fp32 index mode, rays/overlap off")
-    ap.add_argument("--points", type=int, default=None, help="default 1 M (cfg2/cfg3) or 16 M (cfg5)")
-    ap.add_argument("--cell-n", type=int, default=None, help="default 1024 (cfg2/cfg3) or 8192 (cfg5)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="cfg2/cfg3: BASELINE configs[1]/[2] (1024^2, 1 M points); cfg4: configs[3] (4096^2, 4 M points, fp32 index mode, "
+                         "rays + overlap on); cfg5: 8192^2 multi-modal map (height + RGB + 3 semantic layers), 16 M points, fp32 index "
+                         "mode, rays/overlap off")
+    ap.add_argument("--points", type=int, default=None, help="default 1 M (cfg2/cfg3), 4 M (cfg4) or 16 M (cfg5)")
+    ap.add_argument("--cell-n", type=int, default=None, help="default 1024 (cfg2/cfg3), 4096 (cfg4) or 8192 (cfg5)")
     ap.add_argument("--mode", default="reference_fp16", choices=["reference_fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-cfg3", action="store_true", help="skip the config.cfg3 sub-measurement of the default cfg2 line")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the config.cfg3 and config.cfg1 sub-measurements of the default cfg2 line")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
     ap.add_argument("--scatter", default="auto", choices=["auto", "atomic", "binned"])
     ap.add_argument("--sort-clouds", default="none", choices=["none", "tile", "angle"],
@@ -56,9 +91,10 @@ def parse(argv=None):
                     help="experiment: shift the map by this many cells before the frames (circular origin off the tile grid)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous plumbing only, no GPU work (CPU test hook)")
     a = ap.parse_args(argv)
-    big = a.workload == "cfg5"
-    a.cell_n = a.cell_n or (8192 if big else 1024)
-    a.points = a.points or (16_000_000 if big else 1_000_000)
+    a.cell_n = a.cell_n or {"cfg5": 8192, "cfg4": 4096}.get(a.workload, 1024)
+    a.points = a.points or {"cfg5": 16_000_000, "cfg4": 4_000_000}.get(a.workload, 1_000_000)
+    if a.cell_n > 2049:
+        a.mode = "fp32"              # the reference's half-precision helpers cannot address more than 2049 cells per axis
     return a
 
 
@@ -123,7 +159,7 @@ STAGE_BYTES = {
     "post": lambda N, L: 40 * L,
 }
 STAGE_KERNEL = {"hist": "k_bin_hist", "scan": "k_bin_scan", "scatter": "k_bin_scatter", "gate": "k_tile_count", "fuse": "k_tile_fuse",
-                "commit": "k_commit", "rays": "k_rays<0, false", "average": "k_average", "overlap": "k_overlap", "post": "k_post"}
+                "commit": "k_commit", "rays": "k_rays<", "average": "k_ray_apply", "overlap": "k_overlap", "post": "k_post"}
 
 
 def load_weights():
@@ -186,6 +222,23 @@ def stage_profile(lib, ctx, frame, reps, with_stats=True):
     return dict(zip(_lib.STAGES, (acc / reps).tolist())), visits
 
 
+def cold_start(em, frame, n=10):
+    """the visibility pass on an UNKNOWN map: clear(), then n frames with per-stage events -- every visit of an unknown cell min-reduces
+    its upper bound, so the first frames are the pass's worst case (k_rays event spacing per frame, its maximum and the steady median)"""
+    lib, ctx = em._lib, em._ctx
+    em.clear()
+    lib.emap_enable_stage_timing(ctx, 1)
+    rays = []
+    for i in range(n):
+        frame(i, None)
+        ms10 = (ct.c_float * 10)()
+        lib.emap_get_stage_times(ctx, ms10)
+        rays.append(float(ms10[6]))
+    lib.emap_enable_stage_timing(ctx, 0)
+    return {"rays_ms_per_frame": [round(x, 4) for x in rays], "max": round(max(rays), 4), "median_last5": round(float(np.median(rays[-5:])), 4),
+            "max_over_median": round(max(rays) / max(float(np.median(rays[-5:])), 1e-9), 2)}
+
+
 def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step, visits, pmc_ok, stage_bytes=None):
     sb = stage_bytes or {k: f(N, L) for k, f in STAGE_BYTES.items()}
     cand = {k: v for k, v in stage_ms.items() if sb[k] > 0}
@@ -199,14 +252,24 @@ def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step
     # HBM traffic of the dominant kernel: from the committed rocprofv3 PMC passes of this same command
     # (tools/profile_round.sh -> profiles/pmc_<workload>.json; counters cannot be read from inside the process)
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
+    pmc_file = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (PROFILE_ROUND, workload))
     if pmc_ok and os.path.exists(pmc_file):
         kern = STAGE_KERNEL[dom]
-        for name, rec in json.load(open(pmc_file))["kernels"].items():
-            if name.startswith(kern):
-                traffic, traffic_src = rec["hbm_bytes"], "profiles/pmc_%s.json (%s)" % (workload, name)
+        pj = json.load(open(pmc_file))
+        if pj.get("source_stamp") == source_stamp():
+            for name, rec in pj["kernels"].items():
+                if name.startswith(kern):
+                    traffic, traffic_src = rec["hbm_bytes"], "profiles/%s (%s)" % (os.path.basename(pmc_file), name)
+    # the kernel's average duration in the committed rocprofv3 summary of this command (only when taken with THESE kernel sources):
+    # `frac` is quoted from it so that the line and profiles/ agree; the live event spacing stays beside it
+    kus, ksrc = rocprof_kernel_us(workload, STAGE_KERNEL[dom]) if pmc_ok else (None, None)
+    frac_events = achieved / HBM_PEAK_GBS
+    if kus:
+        achieved = dom_bytes / (kus * 1e-6) / 1e9
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_source": "kernel_us_rocprof" if kus else "event spacing (kernel_ms)",
+            "kernel_us_rocprof": kus, "kernel_us_rocprof_source": ksrc, "frac_event_spacing": round(frac_events, 4),
+            "source_stamp": source_stamp(), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": int(dom_bytes), "kernel_ms": round(dom_ms, 5), "kernel_ms_net": round(max(dom_ms - ev_overhead, 0.0), 5),
             "event_pair_overhead_ms": round(ev_overhead, 5),
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},   # raw event spacings (overhead included)
@@ -288,7 +351,7 @@ def cpu_baseline(a, cfg, C, N, clouds_host, weights, R, t):
 
 def workload_text(a, C, N, multimodal):
     return "%s: %dx%d map, %d uniform-random points/frame, core_param.yaml values, %s" % (
-        a.workload, C, C, N, "rays+overlap on" if a.workload == "cfg3" else
+        a.workload, C, C, N, "rays+overlap on" if a.workload in ("cfg3", "cfg4") else
         ("height + RGB + 3 semantic layers, fp32 index mode" if multimodal else "add_points + variance fusion, rays/overlap off"))
 
 
@@ -399,14 +462,43 @@ def run_single(a, local_rank=0):
         wall3, ms3 = timed(em3, fr3, k3)
         lat3 = latencies(em3, fr3, min(k3, 10))
         st3, vis3 = stage_profile(em3._lib, em3._ctx, fr3, min(k3, 8))
+        cold = cold_start(em3, fr3)
         r3 = roofline(st3, ev_overhead, N, L, "cfg3", frame_bytes, ms3 / k3, vis3, pmc_ok)
         cfg3 = {"workload": "cfg3: same map and clouds with enable_visibility_cleanup + enable_overlap_clearance",
                 "value": round(N * k3 / wall3 / 1e6, 2), "unit": "Mpoints/s", "steps": k3, "ms_per_step": round(wall3 * 1e3 / k3, 5),
                 "latency_ms": {"p10": round(lat3[0], 4), "p50": round(lat3[1], 4), "p90": round(lat3[2], 4)},
                 "dominant_kernel": r3["kernel"], "kernel_ms": r3["kernel_ms"], "frac": r3["frac"], "traffic": r3["traffic"],
                 "ray_visits_per_frame": r3["ray_visits_per_frame"], "ray_visits_per_s": r3["ray_visits_per_s"],
-                "stage_ms": r3["stage_ms"]}
+                "stage_ms": r3["stage_ms"], "cold_start_ms": cold}
         em3.close()
+
+    # ---- config.cfg1: robot scale -- the 200 x 200 (+ border) map and 50 k-point clouds the reference ships with (BASELINE configs[0]
+    # on the GPU), without and with the visibility pass: per-frame latency is what a user of the drop-in sees first
+    cfg1 = None
+    if a.workload == "cfg2" and not a.no_cfg3 and not multimodal:
+        C1, N1 = 202, 50_000
+        h1 = host_clouds(a, C1, N1, False)
+        d1 = []
+        for p_ in h1:
+            dd = hip.malloc(p_.nbytes); hip.h2d(dd, p_); d1.append(dd)
+        cfg1 = {"workload": "cfg1: %dx%d map, %d uniform-random points/frame, core_param.yaml values, device-resident clouds" % (C1, C1, N1)}
+        for tag, wl in (("fusion_only", "cfg2"), ("rays_overlap", "cfg3")):
+            par1 = parameter_from(workload_cfg(wl), C1, a.mode if C1 <= 2049 else "fp32", weights); par1.device = local_rank
+            em1 = ElevationMap(par1)
+            l1, c1 = em1._lib, em1._ctx
+
+            def fr1(i, stats=None, l1=l1, c1=c1):
+                rc = l1.emap_set_points_device(c1, d1[i % len(d1)], ct.c_int64(N1), ct.c_int64(3))
+                rc = rc or l1.emap_update(c1, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
+                if rc:
+                    raise RuntimeError(l1.emap_last_error(c1).decode())
+            warm(em1, fr1)
+            k1 = max(20, min(a.steps * 4, 200))
+            wall1, _ = timed(em1, fr1, k1)
+            lat1 = latencies(em1, fr1, 40)
+            cfg1[tag] = {"ms_per_step": round(wall1 * 1e3 / k1, 5), "Mpoints_s": round(N1 * k1 / wall1 / 1e6, 1), "steps": k1,
+                         "latency_ms": {"p10": round(lat1[0], 4), "p50": round(lat1[1], 4), "p90": round(lat1[2], 4)}}
+            em1.close()
 
     # ---- the reference's real entry point: input_pointcloud with a HOST cloud (float64 as the ROS wrapper passes it, float32) -----
     # never part of `value`; the upload is asynchronous (host-side cast into pinned memory, DMA overlapping the previous frame)
@@ -432,6 +524,10 @@ def run_single(a, local_rank=0):
         h2d["note"] = ("input_pointcloud(host cloud): frames per second through the reference's entry point; pcie_bound_ms = the time a plain "
                        "pinned hipMemcpy of the caller's bytes (24 / 12 per point) takes at pinned_h2d_GBs")
 
+    if a.workload in ("cfg3", "cfg4"):
+        config_cold = cold_start(emap, frame)
+    else:
+        config_cold = None
     cpu = None
     if not a.no_cpu_baseline and not multimodal:
         cpu = cpu_baseline(a, cfg, C, N, clouds_host, weights, R, t)
@@ -439,6 +535,10 @@ def run_single(a, local_rank=0):
     config = {"workload": workload_text(a, C, N, multimodal), "index_mode": a.mode,
               "latency_ms": {"p10": round(p10, 4), "p50": round(p50, 4), "p90": round(p90, 4)},
               "device_ms_per_step": round(ms_dev / a.steps, 5), "cloud": "device resident (H2D excluded)"}
+    if config_cold:
+        config["cold_start_ms"] = config_cold
+    if cfg1:
+        config["cfg1"] = cfg1
     if cfg3:
         config["cfg3"] = cfg3
     if h2d:

@@ -31,6 +31,9 @@ void launch_average(hipStream_t, const KP&, Cells, AccF*, AccR*, const FrameDev*
 static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
 void launch_sem_finalize(hipStream_t, const KP&, const SemSpec&, const unsigned int*, double*, unsigned int*, float*, float*, long);
+struct SemRaw { int op, stride, K, n_max; long size, cells; double alpha; };
+void launch_semraw_acc(hipStream_t, const SemRaw&, const float*, const int*, const int*, const float*, const int*, float*, unsigned int*);
+void launch_semraw_fin(hipStream_t, const SemRaw&, float*, const unsigned int*, const int*, const float*, const float*, float*);
 void launch_polygon_mask(hipStream_t, int, const int*, const int*, int, const int*, float*);
 void launch_dilate_planes(hipStream_t, int, int, const float*, const float*, float*, float*);
 struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; };
@@ -1071,6 +1074,68 @@ int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], cons
   launch_sem_points(ctx->stream, ctx->kp, make_pose(ctx, R, t), S, ctx->pts, ctx->n_pts, ctx->stride, ctx->sem_sums, ctx->sem_col, ctx->ncells_alloc);
   launch_sem_finalize(ctx->stream, ctx->kp, S, ctx->cnt_plane, ctx->sem_sums, ctx->sem_col, ctx->sem, ctx->sem_alpha, ctx->ncells_alloc);
   CK(hipGetLastError());
+  return EMAP_OK;
+}
+
+// ---- the reference's semantic kernel factories on caller arrays (EM/kernels/custom_semantic_kernels.py) ------------------------
+// Host arrays in, host arrays out (the factories of the compat package hand NumPy arrays over); device buffers live for the call.
+namespace {
+struct DevBuf {           // a device copy of a host array for the duration of a call
+  void* d = nullptr; size_t bytes = 0; void* back = nullptr;
+  hipError_t put(const void* host, size_t n, hipStream_t s, void* write_back) {
+    bytes = n; back = write_back;
+    if (!n) return hipSuccess;
+    hipError_t e = hipMalloc(&d, n);
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(d, host, n, hipMemcpyHostToDevice, s);
+  }
+  hipError_t get(hipStream_t s) { return (back && bytes) ? hipMemcpyAsync(back, d, bytes, hipMemcpyDeviceToHost, s) : hipSuccess; }
+  ~DevBuf() { if (d) hipFree(d); }
+};
+}  // namespace
+
+int emap_semantic_accumulate(emap_ctx* ctx, int32_t op, const float* points, int64_t n_rows, int32_t stride, const int32_t* pcl_chan,
+                             const int32_t* map_lay, int32_t n_ch, int64_t size, int64_t cells, void* newmap_inout, int32_t newmap_layers,
+                             const float* max_pt, const int32_t* max_id, int32_t n_max) {
+  CKARG(ctx && points && newmap_inout && op >= 0 && op <= 4, "bad argument");
+  CKARG(n_rows >= 0 && stride >= 3 && n_ch >= 1 && n_ch <= 64 && size >= 0 && cells > 0 && newmap_layers >= 1, "bad shape");
+  CKARG(op == 2 ? (max_pt && max_id && n_max >= 1 && size <= n_rows) : (pcl_chan && map_lay && size <= n_rows * (int64_t)n_ch), "bad channel description / size");
+  CK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  DevBuf P, PC, ML, MP, MI, NM;
+  CK(P.put(points, sizeof(float) * (size_t)n_rows * stride, st, nullptr));
+  if (pcl_chan) { CK(PC.put(pcl_chan, sizeof(int) * n_ch, st, nullptr)); CK(ML.put(map_lay, sizeof(int) * n_ch, st, nullptr)); }
+  if (op == 2) { CK(MP.put(max_pt, sizeof(float) * (size_t)n_rows * n_max, st, nullptr)); CK(MI.put(max_id, sizeof(int) * (size_t)n_rows * n_max, st, nullptr)); }
+  CK(NM.put(newmap_inout, 4 * (size_t)newmap_layers * cells, st, newmap_inout));
+  SemRaw A; memset(&A, 0, sizeof A);
+  A.op = op; A.stride = stride; A.K = n_ch; A.n_max = n_max; A.size = size; A.cells = cells;
+  launch_semraw_acc(st, A, (const float*)P.d, (const int*)PC.d, (const int*)ML.d, (const float*)MP.d, (const int*)MI.d, (float*)NM.d, (unsigned int*)NM.d);
+  CK(hipGetLastError());
+  CK(NM.get(st));
+  CK(hipStreamSynchronize(st));
+  return EMAP_OK;
+}
+
+int emap_semantic_finalize(emap_ctx* ctx, int32_t op, void* newmap_inout, int32_t newmap_layers, const int32_t* map_lay, int32_t n_ch, int64_t size,
+                           int64_t cells, const float* new_elmap3, const float* sum_mean, int32_t sum_layers, float* map_inout, int32_t map_layers, double alpha) {
+  CKARG(ctx && newmap_inout && map_lay && map_inout && op >= 0 && op <= 3, "bad argument");
+  CKARG(n_ch >= 1 && n_ch <= 64 && size >= 0 && size <= cells * (int64_t)n_ch && cells > 0 && newmap_layers >= 1 && map_layers >= 1, "bad shape");
+  CKARG(op == 3 || new_elmap3, "the accepted-point counts (new_elmap plane 2) are needed");
+  CKARG(op != 2 || (sum_mean && sum_layers >= n_ch), "bayesian_inference needs sum_mean");
+  CK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  DevBuf NM, ML, EL, SM, MP;
+  CK(NM.put(newmap_inout, 4 * (size_t)newmap_layers * cells, st, op == 2 ? newmap_inout : nullptr));
+  CK(ML.put(map_lay, sizeof(int) * n_ch, st, nullptr));
+  if (new_elmap3) CK(EL.put(new_elmap3, sizeof(float) * 3 * (size_t)cells, st, nullptr));
+  if (sum_mean) CK(SM.put(sum_mean, sizeof(float) * (size_t)sum_layers * cells, st, nullptr));
+  CK(MP.put(map_inout, sizeof(float) * (size_t)map_layers * cells, st, map_inout));
+  SemRaw A; memset(&A, 0, sizeof A);
+  A.op = op; A.K = n_ch; A.size = size; A.cells = cells; A.alpha = alpha;
+  launch_semraw_fin(st, A, (float*)NM.d, (const unsigned int*)NM.d, (const int*)ML.d, (const float*)EL.d, (const float*)SM.d, (float*)MP.d);
+  CK(hipGetLastError());
+  CK(NM.get(st)); CK(MP.get(st));
+  CK(hipStreamSynchronize(st));
   return EMAP_OK;
 }
 

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
       static_assert(BIN_TR == TF_BLOCK / 64, "one wave per tile row");
       const int tr = wv, lrow = row_base + tr;
       const bool live = col < P.C && lrow < P.nrows;
-      bool quiet = false;
+      bool quiet = false, other = false;  // other: neither quiet nor unknown-without-a-bound (see the block thresholds below)
       float visit_thr = -INFINITY;        // a ray sample at or above this height cannot affect the cell (k_rays' block filter)
       if (live) {
         const int lc = tr * BIN_TC + tc;
@@ -407,6 +407,8 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
           // h > nz + 0.01 - min(v, 1) * 0.05 implies nz < h + 0.04
           if (RAYS && !quiet) visit_thr = m.valid < 0.5f ? ((m.is_upper < 0.5f || !(m.upper <= 3.0e38f)) ? INFINITY : m.upper) : m.h + 0.05f;
           if (RAYS && !(visit_thr >= -INFINITY)) visit_thr = INFINITY;                          // NaN heights: never filter
+          // a cell the rays can only give an upper bound to (unknown, no bound yet): the ray kernel needs nothing of it but its key
+          if (RAYS && !quiet) other = !(m.valid < 0.5f && m.is_upper < 0.5f);
           average_cell(P, m, a);
           // clear_overlap_map (:372-375) of a frame WITHOUT a visibility pass rides on this rewrite (with rays: k_ray_apply)
           if (inwin) wcold = overlap_cell(P, O, m) || wcold;
@@ -436,18 +438,27 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
             }
           }
         }
-        // block thresholds: max over 8 columns (lanes) and 8 rows (waves) through the ordered-uint image of the float
-        unsigned int* s_thr = s_pts;                           // the counters are dead by now: 2 block rows x 8 block columns
+        // block thresholds: max over 8 columns (lanes) and 8 rows (waves) through the ordered-uint image of the float.  +INF is kept
+        // for VIRGIN blocks only -- every cell quiet or unknown without a bound, the state of a cleared map and of the band a map
+        // shift brings in: there a visit needs nothing but the cell's key (k_rays skips both cell loads); a block that ALSO holds
+        // other cells gets the largest finite float instead (filters nothing either)
+        unsigned int* s_thr = s_pts;                           // the counters are dead by now: 2 block rows x 8 block columns (+ 16 "other" flags)
         __syncthreads();
-        if (threadIdx.x < 16) s_thr[threadIdx.x] = 0u;         // float_ord(x) > 0 for every x
+        if (threadIdx.x < 32) s_thr[threadIdx.x] = 0u;         // float_ord(x) > 0 for every x
         __syncthreads();
         unsigned int o = float_ord(visit_thr);
         o = max(o, (unsigned int)__shfl_xor((int)o, 1, 64)); o = max(o, (unsigned int)__shfl_xor((int)o, 2, 64)); o = max(o, (unsigned int)__shfl_xor((int)o, 4, 64));
-        if ((tc & 7) == 0) atomicMax(&s_thr[(tr >> 3) * 8 + (tc >> 3)], o);
+        const unsigned long long ob = __ballot(other);
+        if ((tc & 7) == 0) {
+          atomicMax(&s_thr[(tr >> 3) * 8 + (tc >> 3)], o);
+          if ((ob >> tc) & 0xffull) s_thr[16 + (tr >> 3) * 8 + (tc >> 3)] = 1u;       // (racing writers store the same value)
+        }
         __syncthreads();
         if (threadIdx.x < 16) {
           const int br = (row_base >> 3) + (threadIdx.x >> 3), bc = tx * 8 + (threadIdx.x & 7);
-          if (br * 8 < P.nrows && bc * 8 < P.C) thr[(long)br * ((P.C + 7) >> 3) + bc] = ord_float(s_thr[threadIdx.x]);
+          float bt = ord_float(s_thr[threadIdx.x]);
+          if (bt == INFINITY && s_thr[16 + threadIdx.x]) bt = 3.4028234664e38f;
+          if (br * 8 < P.nrows && bc * 8 < P.C) thr[(long)br * ((P.C + 7) >> 3) + bc] = bt;
         }
       }
     }

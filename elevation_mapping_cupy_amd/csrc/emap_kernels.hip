@@ -328,7 +328,8 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     // exchanges, the distance test) is fetched only when some visit of the batch survives.
     const float erz = __shfl(rz, src, 64);
     const float nz = T.t[2] + erz * s;                                                   // the sample height, recomputed bit for bit
-    const bool live = has && !(thr && nz >= thr[(lrow >> 3) * (unsigned int)((C + 7) >> 3) + (col >> 3)]);
+    const float bthr = (has && thr) ? thr[(lrow >> 3) * (unsigned int)((C + 7) >> 3) + (col >> 3)] : 3.4028234664e38f;
+    const bool live = has && !(nz >= bthr);
     if (!__builtin_amdgcn_ballot_w64(live)) return;                                      // wave-uniform
     const float erx = __shfl(rx, src, 64), ery = __shfl(ry, src, 64), edec = __shfl(dec, src, 64);
     const float egx = __shfl(gx, src, 64), egy = __shfl(gy, src, 64), egz = __shfl(gz, src, 64);
@@ -337,6 +338,9 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     const float ddx = egx - nx, ddy = egy - ny, ddz = egz - nz;
     const float d = Qf<MODE>(ddx * ddx + ddy * ddy + ddz * ddz);
     if (d < Rt.f_d_thresh) return;             // (double)d < 0.1: too close to the point (:225-226)
+    // a VIRGIN block (+INF: every cell quiet or unknown without a bound -- a cleared map, the band a map shift brings in): the
+    // visit can only lower the cell's upper bound (:228-234 with is_upper_bound < 0.5), no cell load needed
+    if (bthr == INFINITY) { ray_upper_min(&accr[c].upper_key, nz); return; }
     const float4 m0 = cells.hot[c], m1 = cells.cold[c];       // h v valid trav | time upper is_upper valid'
     if (m0.z < 0.5f) {                         // unknown cell: upper bound (:228-234)
       if (nz < m1.y || m1.z < 0.5f) ray_upper_min(&accr[c].upper_key, nz);

@@ -437,3 +437,79 @@ __global__ __launch_bounds__(EM_BLOCK) void k_erode(int C, int k, const float* _
 void launch_erode(hipStream_t s, int C, int k, const float* in, float* out) {
   hipLaunchKernelGGL(k_erode, dim3(nblk_((long)C * C)), dim3(EM_BLOCK), 0, s, C, k, in, out);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// The nine kernel factories of EM/kernels/custom_semantic_kernels.py as they are: raw-array elementwise kernels over `size`
+// elements whose points carry (cell index, valid, inside) in their first three columns (what add_points_kernel leaves there,
+// custom_kernels.py:260-262) -- the staged surface behind compat/elevation_mapping_cupy/kernels/custom_semantic_kernels.py.
+// (The per-frame path fuses accumulate + finalise per tile in LDS: k_tile_semantic.)  Float accumulation uses float atomics like the
+// reference (order dependent in the last bit there too).
+// ---------------------------------------------------------------------------------------------------------
+struct SemRaw { int op, stride, K, n_max; long size, cells; double alpha; };
+enum { SR_SUM = 0, SR_SUM_COMPACT, SR_SUM_MAX, SR_ALPHA, SR_ADD_COLOR };                   // accumulate ops (:9-51, :54-86, :89-123, :126-164, :270-318)
+enum { SF_AVERAGE = 0, SF_CLASS_AVERAGE, SF_BAYESIAN, SF_COLOR_AVERAGE };                  // finalise ops (:167-194, :233-267, :197-230, :320-375)
+__global__ __launch_bounds__(EM_BLOCK) void k_semraw_acc(SemRaw A, const float* __restrict__ p, const int* __restrict__ pcl_chan, const int* __restrict__ map_lay,
+                                                          const float* __restrict__ max_pt, const int* __restrict__ max_id, float* __restrict__ newmap,
+                                                          unsigned int* __restrict__ color_map) {
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= A.size) return;
+  if (A.op == SR_SUM_MAX) {
+    const int idx = (int)p[i * A.stride];
+    if (p[i * A.stride + 1] != 0.0f && p[i * A.stride + 2] != 0.0f)
+      for (int it = 0; it < A.n_max; ++it) atomicAdd(&newmap[A.cells * max_id[i * A.n_max + it] + idx], max_pt[i * A.n_max + it]);
+    return;
+  }
+  const long id = i / A.K; const int layer = (int)(i % A.K);
+  const int idx = (int)p[id * A.stride];
+  if (!(p[id * A.stride + 1] != 0.0f && p[id * A.stride + 2] != 0.0f)) return;
+  const float feat = p[id * A.stride + pcl_chan[layer]];
+  switch (A.op) {
+    case SR_SUM: atomicAdd(&newmap[A.cells * map_lay[layer] + idx], feat); break;
+    case SR_SUM_COMPACT: atomicAdd(&newmap[A.cells * layer + idx], feat); break;
+    case SR_ALPHA: { float theta_max = 0.f; int arg_max = 0; if (feat >= theta_max) { arg_max = map_lay[layer]; theta_max = feat; }
+                     atomicAdd(&newmap[A.cells * arg_max + idx], theta_max); break; }
+    default: { const unsigned int color = __float_as_uint(feat);
+               atomicAdd(&color_map[A.cells * (layer * 3) + idx], (color & 0xFF0000u) >> 16);
+               atomicAdd(&color_map[A.cells * (layer * 3 + 1) + idx], (color & 0xFF00u) >> 8);
+               atomicAdd(&color_map[A.cells * (layer * 3 + 2) + idx], color & 0xFFu);
+               atomicAdd(&color_map[A.cells * (A.K * 3) + idx], 1u); }
+  }
+}
+__global__ __launch_bounds__(EM_BLOCK) void k_semraw_fin(SemRaw A, float* __restrict__ newmap, const unsigned int* __restrict__ color_map,
+                                                          const int* __restrict__ map_lay, const float* __restrict__ new_elmap, const float* __restrict__ sum_mean,
+                                                          float* __restrict__ map) {
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= A.size) return;
+  const long id = i / A.K; const int layer = (int)(i % A.K);
+  const long j = A.cells * map_lay[layer] + id;
+  if (A.op == SF_COLOR_AVERAGE) {
+    const unsigned int cnt = color_map[A.cells * (A.K * 3) + id];
+    if (cnt > 0) {
+      const unsigned int r = color_map[A.cells * (layer * 3) + id] / (1 * cnt), g = color_map[A.cells * (layer * 3 + 1) + id] / (1 * cnt),
+                         b = color_map[A.cells * (layer * 3 + 2) + id] / (1 * cnt);
+      map[j] = __uint_as_float((r << 16) + (g << 8) + b);
+    }
+    return;
+  }
+  const float cnt = new_elmap[A.cells * 2 + id];
+  if (!(cnt > 0)) return;
+  if (A.op == SF_AVERAGE) map[j] = newmap[j] / (1 * cnt);
+  else if (A.op == SF_CLASS_AVERAGE) {
+    const float prev = map[j];
+    if (prev == 0) map[j] = newmap[j] / (1 * cnt);
+    else map[j] = (float)(A.alpha * prev + (1 - A.alpha) * newmap[j] / (cnt));          // ${alpha} is a double literal in the reference's source
+  } else {
+    const float feat_ml = sum_mean[A.cells * layer + id] / cnt, feat_old = map[j], sigma_old = newmap[j], sigma = 1.0f;
+    const float feat_new = sigma * feat_old / (cnt * sigma_old + sigma) + cnt * sigma_old * feat_ml / (cnt * sigma_old + sigma);
+    const float sigma_new = sigma * sigma_old / (cnt * sigma_old + sigma);
+    map[j] = feat_new; newmap[j] = sigma_new;
+  }
+}
+void launch_semraw_acc(hipStream_t s, const SemRaw& A, const float* p, const int* pcl_chan, const int* map_lay, const float* max_pt, const int* max_id,
+                       float* newmap, unsigned int* color_map) {
+  if (A.size > 0) hipLaunchKernelGGL(k_semraw_acc, dim3(nblk_(A.size)), dim3(EM_BLOCK), 0, s, A, p, pcl_chan, map_lay, max_pt, max_id, newmap, color_map);
+}
+void launch_semraw_fin(hipStream_t s, const SemRaw& A, float* newmap, const unsigned int* color_map, const int* map_lay, const float* new_elmap,
+                       const float* sum_mean, float* map) {
+  if (A.size > 0) hipLaunchKernelGGL(k_semraw_fin, dim3(nblk_(A.size)), dim3(EM_BLOCK), 0, s, A, newmap, color_map, map_lay, new_elmap, sum_mean, map);
+}

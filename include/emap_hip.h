@@ -160,7 +160,23 @@ int emap_semantic_configure(emap_ctx* ctx, int32_t n_layers);                 /*
 int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], const emap_sem_spec* spec); /* after emap_update */
 int emap_semantic_get_layer(emap_ctx* ctx, int32_t layer, float* host_out);
 int emap_semantic_set_layer(emap_ctx* ctx, int32_t layer, const float* host_in);
-int emap_semantic_clear(emap_ctx* ctx);                                        /* SemanticMap.clear (layers only, :47-49) */
+int emap_semantic_clear(emap_ctx* ctx);
+
+/* ---- the reference's semantic KERNEL FACTORIES on caller arrays (EM/kernels/custom_semantic_kernels.py) -------------------
+ * Raw-array elementwise kernels over `size` elements; the points carry (cell index, valid, inside) in their first three columns
+ * (what add_points_kernel leaves there, custom_kernels.py:260-262).  Host arrays in and out, for the staged / test surface
+ * (compat/elevation_mapping_cupy/kernels); the per-frame path is emap_semantic_update.
+ *   accumulate op: 0 sum_kernel (:9-51), 1 sum_compact_kernel (:54-86), 2 sum_max_kernel (:89-123), 3 alpha_kernel (:126-164),
+ *                  4 add_color_kernel (:270-318; newmap_inout is the uint32 colour map of 3 n_ch + 1 planes)
+ *   finalize op:   0 average_kernel (:167-194), 1 class_average_kernel (:233-267), 2 bayesian_inference_kernel (:197-230; newmap
+ *                  = the variance planes, updated in place), 3 color_average_kernel (:320-375; newmap = the uint32 colour map)
+ * new_elmap3: the (3, cells) planes the reference hands over, of which plane 2 (accepted points per cell) is read. */
+int emap_semantic_accumulate(emap_ctx* ctx, int32_t op, const float* points, int64_t n_rows, int32_t stride, const int32_t* pcl_chan,
+                             const int32_t* map_lay, int32_t n_ch, int64_t size, int64_t cells, void* newmap_inout, int32_t newmap_layers,
+                             const float* max_pt, const int32_t* max_id, int32_t n_max);
+int emap_semantic_finalize(emap_ctx* ctx, int32_t op, void* newmap_inout, int32_t newmap_layers, const int32_t* map_lay, int32_t n_ch, int64_t size,
+                           int64_t cells, const float* new_elmap3, const float* sum_mean, int32_t sum_layers, float* map_inout, int32_t map_layers,
+                           double alpha);                                        /* SemanticMap.clear (layers only, :47-49) */
 int emap_semantic_get_alpha(emap_ctx* ctx, int32_t layer, float* host_out);    /* SemanticMap.new_map[layer] of a class_bayesian layer */
 int emap_semantic_set_alpha(emap_ctx* ctx, int32_t layer, const float* host_in);
 

@@ -123,6 +123,8 @@ def _instantiate(p):
         ks["alpha"] = (cb.alpha_kernel(res, C, C), f32)
         ks["sum_compact"] = (bi.sum_compact_kernel(res, C, C), f32)
         ks["bayesian_inference"] = (bi.bayesian_inference_kernel(C, C), f32)
+    if p.get("sum_max_kernel"):          # EM/kernels/custom_semantic_kernels.py:89-123 (max_id is an int array in its caller, fusion/pointcloud_class_max.py)
+        ks["sem_sum_max"] = (sk.sum_max_kernel(res, C, C), dict(f32, T="int"))
     if p.get("polygon_kernel"):
         # safety-polygon service (reference elevation_mapping.py:283, 837-889): `raw int16 polygon_n` is a concrete type
         ks["polygon_mask"] = (ck.polygon_mask_kernel(C, C, res), dict(f32, int16="short"))
@@ -257,6 +259,8 @@ PREBUILD = {
     "bayes66": with_(PARAM_YAML, cell_n=66, bayes_kernels=True),
     "polygon130": with_(PARAM_DEFAULT, cell_n=130, polygon_kernel=True),
     "maxfilter34": with_(PARAM_DEFAULT, cell_n=34, max_filter_sizes=(1, 2)),
+    # the toy maps of the reference's own kernel tests (EM/tests/test_semantic_kernels.py: 4 x 4 cells, resolution 0.9)
+    "toy4": with_(PARAM_YAML, cell_n=4, resolution=0.9, bayes_kernels=True, sum_max_kernel=True),
     # wall-skip fixture (tests/_warm.py): two drift inliers in a cell already exceed wall_num_thresh
     "wall202": with_(PARAM_DEFAULT, wall_num_thresh=1),
 }

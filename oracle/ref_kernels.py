@@ -109,6 +109,9 @@ class RefKernels:
     def sum_compact(self, p, R, t, pcl_chan, map_lay, pcl_channels, sum_mean, size):
         self._call("sum_compact", [p, R, t, pcl_chan, map_lay, pcl_channels, sum_mean], size)
 
+    def sem_sum_max(self, p, max_pt, max_id, pcl_chan, map_lay, pcl_channels, newmap, size):
+        self._call("sem_sum_max", [p, max_pt, max_id, pcl_chan, map_lay, pcl_channels, newmap], size)
+
     def bayesian_inference(self, pcl_chan, map_lay, pcl_channels, new_elmap, newmap, sum_mean, smap, size):
         self._call("bayesian_inference", [pcl_chan, map_lay, pcl_channels, new_elmap, newmap, sum_mean, smap], size)
 

@@ -115,3 +115,51 @@ def single_points(C, K, seed):
     p = cloud(C, K, 7000 + seed)
     names = ["rotated", "identity"]
     return [(p[k:k + 1].copy(), names[k % 2]) for k in range(K)]
+
+
+def semantic_kernel_cases():
+    """Inputs of the raw semantic kernels (EM/kernels/custom_semantic_kernels.py) on the 4 x 4 toy map of the reference's own tests
+    (EM/tests/test_semantic_kernels.py:25-307: three points in cell 1, all valid and inside) plus a richer draw on the same map:
+    20 points over all 16 cells with some invalid / outside rows, negative class probabilities, previous layer values.
+    Returns {case: dict of arrays}; points rows are (idx, valid, inside, ch0, ch1, ch2)."""
+    toy = np.array([[1, 1, 1, 0.3, 0.3, 0.0], [1, 1, 1, 0.1, 0.2, 0.0], [1, 1, 1, 0.1, 0.2, 0.0]], np.float32)
+    rng = np.random.default_rng(2024)
+    rich = np.zeros((20, 6), np.float32)
+    rich[:, 0] = rng.integers(0, 16, 20)
+    rich[:, 1] = rng.uniform(0, 1, 20) < 0.85
+    rich[:, 2] = rng.uniform(0, 1, 20) < 0.85
+    rich[:, 3:6] = rng.uniform(-0.3, 1.0, (20, 3))
+    out = {}
+    for name, pts in (("toy", toy), ("rich", rich)):
+        n = pts.shape[0]
+        col = pts.copy()
+        col[:, 3] = rng.integers(0, 1 << 24, n, dtype=np.uint32).view(np.float32)     # packed 0x00RRGGBB in channel 3 for the colour kernels
+        elmap = np.zeros((3, 4, 4), np.float32)
+        elmap[2] = np.bincount(pts[(pts[:, 1] != 0) & (pts[:, 2] != 0), 0].astype(int), minlength=16).reshape(4, 4)
+        prev = rng.uniform(0, 1, (4, 4, 4)).astype(np.float32) * (rng.uniform(0, 1, (4, 4, 4)) < 0.6)
+        out[name] = dict(points=pts, points_color=col, pcl_ids=np.array([3, 4], np.int32), layer_ids=np.array([1, 2], np.int32),
+                         new_elmap=elmap, prev=prev.astype(np.float32), sigma=rng.uniform(0.1, 2.0, (4, 4, 4)).astype(np.float32),
+                         max_pt=rng.uniform(0, 1, (n, 2)).astype(np.float32), max_id=rng.integers(0, 4, (n, 2)).astype(np.int32))
+    return out
+
+
+def semantic_kernel_run(K, c):
+    """K: an object with the reference kernels' call surface (oracle/ref_kernels.RefKernels)"""
+    pts, col, pc, ml, el = c["points"], c["points_color"], c["pcl_ids"], c["layer_ids"], c["new_elmap"]
+    n, stride, nch = pts.shape[0], pts.shape[1], pc.shape[0]
+    chn = np.array([stride, nch, 2], np.int32)
+    R = np.eye(3, dtype=np.float32).ravel().copy(); t = np.zeros(3, np.float32)
+    out = {}
+    newmap = np.zeros((4, 4, 4), np.float32); smap = c["prev"].copy()
+    K.sem_sum(pts, R, t, pc, ml, chn, smap, newmap, n * nch); out["sum_newmap"] = newmap.copy()
+    avg = c["prev"].copy(); K.sem_average(newmap, pc, ml, chn, el, avg, 16 * nch); out["average_map"] = avg
+    cav = c["prev"].copy(); K.sem_class_average(newmap, pc, ml, chn, el, cav, 16 * nch); out["class_average_map"] = cav
+    sm = np.zeros((nch, 4, 4), np.float32); K.sum_compact(pts, R, t, pc, ml, chn, sm, n * nch); out["sum_compact"] = sm.copy()
+    bmap = c["prev"].copy(); sig = c["sigma"].copy()
+    K.bayesian_inference(pc, ml, chn, el, sig, sm, bmap, 16 * nch); out["bayes_map"] = bmap; out["bayes_sigma"] = sig
+    al = np.zeros((4, 4, 4), np.float32); K.alpha(pts, pc, ml, chn, al, n * nch); out["alpha_newmap"] = al
+    mx = np.zeros((4, 4, 4), np.float32); K.sem_sum_max(pts, c["max_pt"], c["max_id"], pc, ml, chn, mx, n); out["sum_max_newmap"] = mx
+    cpc, cml = np.array([3], np.int32), np.array([0], np.int32); cch = np.array([stride, 1], np.int32)
+    cm = np.zeros((4, 4, 4), np.uint32); K.sem_add_color(col, R, t, cpc, cml, cch, cm, n); out["color_map"] = cm.copy()
+    cs = c["prev"].copy(); K.sem_color_average(cm, cpc, cml, cch, cs, 16); out["color_average_map"] = cs
+    return out

@@ -12,6 +12,7 @@ Fixtures (all inputs are regenerated from seeds by tests/_fixtures.py, only outp
                          idx/valid/inside columns) for identity and rotated poses
   stencil_*.npz          dilation (radius 1,2,3,10 incl. flat-index wrap) and normal filter outputs on random planes
   semantic_yaml66.npz    sum/average/class_average/colour kernels
+  semantic_toy.npz       all nine raw semantic kernels on the 4 x 4 toy map of the reference's own kernel tests
 """
 import hashlib
 import json
@@ -253,6 +254,18 @@ def host_steps():
     print("host steps:", sorted(save))
 
 
+def semantic_toy():
+    """the nine raw semantic kernels (EM/kernels/custom_semantic_kernels.py) on the toy inputs of tests/_fixtures.py:
+    semantic_kernel_cases, through the reference's own kernel source compiled for the host (parameter set toy4)"""
+    rk = ref_kernels.RefKernels(build_ref.PREBUILD["toy4"])
+    save = {}
+    for case, c in fx.semantic_kernel_cases().items():
+        for name, arr in fx.semantic_kernel_run(rk, c).items():
+            save["%s_%s" % (case, name)] = arr
+    np.savez_compressed(os.path.join(OUT, "semantic_toy.npz"), **save)
+    print("semantic toy:", sorted(save))
+
+
 GATE_CASES = [(12.5, 200, 1.0, 1.0), (-3.0, 150, 0.0, 1.0), (40.0, 200, 1.0, 0.0), (5.0, 100, 1.0, 1.0), (5.0, 101, 0.0, 0.0),
               (0.0, 0, 1.0, 1.0), (-19.0, 200, 1.0, 1.0)]
 MOVE_SEQUENCE = [("move_to", (0.13, -0.3, 0.05)), ("move_to", (0.13, -0.3, 0.05)), ("move", (-0.21, 0.09, -0.02)),
@@ -260,7 +273,7 @@ MOVE_SEQUENCE = [("move_to", (0.13, -0.3, 0.05)), ("move_to", (0.13, -0.3, 0.05)
 
 
 if __name__ == "__main__":      # python tests/golden/make_golden.py [core semantic66 bayes66 warm_single host_steps]
-    todo = sys.argv[1:] or ["core", "semantic66", "bayes66", "warm_single", "host_steps"]
+    todo = sys.argv[1:] or ["core", "semantic66", "bayes66", "warm_single", "host_steps", "semantic_toy"]
     for name in todo:
         globals()[name]()
     print(sorted(os.listdir(OUT)))

@@ -186,3 +186,15 @@ def test_openmp_baseline_mode_equals_sequential_oracle(weights):
         maps[nt] = (om.elevation_map.copy(), om.normal_map.copy())
     eo.set_threads(1)
     assert np.allclose(maps[1][0], maps[4][0], atol=1e-6, rtol=1e-6) and np.allclose(maps[1][1], maps[4][1], atol=1e-6)
+
+
+def test_semantic_toy_golden_matches_the_compiled_reference_kernels():
+    """tests/golden/semantic_toy.npz is what the reference's own semantic kernels yield on the toy inputs (only where they can be built)"""
+    from oracle import build_ref, ref_kernels
+    if not ref_kernels.available(build_ref.PREBUILD["toy4"]):
+        pytest.skip("reference kernels for the toy map are neither prebuilt nor buildable here")
+    rk = ref_kernels.RefKernels(build_ref.PREBUILD["toy4"])
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "semantic_toy.npz"))
+    for case, c in fx.semantic_kernel_cases().items():
+        for name, arr in fx.semantic_kernel_run(rk, c).items():
+            assert np.array_equal(arr.view(np.uint32), g["%s_%s" % (case, name)].view(np.uint32)), (case, name)

@@ -7,6 +7,7 @@ TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
+(cd $R && python -c "import bench; print(bench.source_stamp())") > $O/source_stamp.txt      # which kernel sources these databases belong to
 cd /tmp && export TMPDIR=/tmp
 for wl in cfg2 cfg3; do
   steps=20; [ $wl = cfg3 ] && steps=8
@@ -21,6 +22,7 @@ ls -R $O | head -40
 python $R/bench.py > $O/bench_cfg2.json 2>> $O/bench_err.log
 python $R/bench.py --workload cfg3 --steps 20 > $O/bench_cfg3.json 2>> $O/bench_err.log
 python $R/bench.py --pre-shift 37 21 --no-cpu-baseline > $O/bench_cfg2_shifted.json 2>> $O/bench_err.log
-python $R/bench.py --cell-n 202 --points 50000 --no-cpu-baseline > $O/bench_cfg1.json 2>> $O/bench_err.log
+python $R/bench.py --cell-n 202 --points 50000 --no-cpu-baseline --no-cfg3 > $O/bench_cfg1.json 2>> $O/bench_err.log
+timeout 600 python $R/bench.py --workload cfg4 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_cfg4.json 2>> $O/bench_err.log
 timeout 600 python $R/bench.py --workload cfg5 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_cfg5.json 2>> $O/bench_err.log
 tail -3 $O/bench_err.log
