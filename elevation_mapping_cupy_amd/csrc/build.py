@@ -1,4 +1,4 @@
-"""Builds libemap_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake: two translation units."""
+"""Builds libemap_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake: five translation units."""
 from __future__ import annotations
 
 import os
@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(os.path.dirname(HERE), "libemap_hip.so")
-SOURCES = ["emap_kernels.hip", "emap_binned.hip", "emap_semantic.hip", "emap_api.hip"]
+SOURCES = ["emap_kernels.hip", "emap_binned.hip", "emap_semantic.hip", "emap_api.hip", "emap_inpaint_host.hip"]
 DEPS = SOURCES + ["emap_device.h", os.path.join("..", "..", "include", "emap_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

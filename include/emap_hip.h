@@ -204,6 +204,11 @@ int emap_erode(emap_ctx* ctx, const float* host_in, int32_t kernel_size, int32_t
  * mean of the known 8-neighbours. Values stay in [0, 255], integers. */
 int emap_inpaint_u8(emap_ctx* ctx, const float* host_image, const float* host_known, int32_t max_sweeps, float* host_out,
                     int32_t* sweeps_run_or_null);
+/* Inpainting plugin, method "telea" (EM/plugins/inpainting.py:59: cv2.inpaint(h, mask, 1, cv2.INPAINT_TELEA) on the host): Telea's
+ * fast-marching fill of the pixels with mask != 0 in an 8-bit image, HOST arrays in and out, no context needed -- a serial
+ * priority-queue algorithm that the reference also runs on the CPU.  A restatement of the published algorithm (OpenCV is absent
+ * offline: parity with its values is not pinned). */
+int emap_inpaint_telea_u8(const uint8_t* image, const uint8_t* mask, int32_t rows, int32_t cols, int32_t radius, uint8_t* out);
 
 /* ---- camera path: ElevationMap.input_image (EM/elevation_mapping.py:468-562).
  * emap_image_correspondence = image_to_map_correspondence_kernel (EM/kernels/custom_image_kernels.py:9-157): x1, y1 = camera

@@ -191,9 +191,11 @@ def test_device_side_layer_readback_matches_reference_postprocessing(only_above)
         assert np.allclose(out64, out, equal_nan=True), name
 
 
-def test_inpainting_substitute_properties():
-    """OpenCV's Telea arithmetic is unpinned (absent third-party library); the substitute must satisfy what any
-    inpainting of the reference's 8-bit pipeline satisfies."""
+@pytest.mark.parametrize("method", ["telea", "front"])
+def test_inpainting_properties(method):
+    """OpenCV's Telea arithmetic is unpinned (absent third-party library); both fills -- the fast-marching restatement on the host
+    (tests/test_inpaint_telea.py) and the device-side front propagation -- must satisfy what any inpainting of the reference's 8-bit
+    pipeline satisfies."""
     from elevation_mapping_cupy_amd.plugins.inpainting import Inpainting
     C = 130
     hip, _ = make_pair(eo.DEFAULTS, C)
@@ -204,7 +206,7 @@ def test_inpainting_substitute_properties():
     e[2] = rng.uniform(0, 1, (C, C)) > 0.3
     e[2][40:70, 50:90] = 0
     e[0][e[2] < 0.5] = 0.0                                  # unknown cells hold garbage
-    ip = Inpainting(cell_n=C, emap=hip)
+    ip = Inpainting(cell_n=C, emap=hip, method=method)
     out = np.asarray(ip(e, hip.layer_names, None, []), np.float64)
     known = e[2] >= 0.5
     hmin, hmax = e[0][known].min(), e[0][known].max()
@@ -214,7 +216,7 @@ def test_inpainting_substitute_properties():
     assert out.min() >= hmin - 1e-6 and out.max() <= hmax + 1e-6             # stays inside the range of the known data
     truth = (0.5 * np.sin(xx / 17.0) + 0.3 * np.cos(yy / 11.0))
     assert np.abs(out[~known] - truth[~known]).mean() < 0.05                 # and is a sensible reconstruction of the smooth surface
-    assert 1 <= ip.sweeps_run <= 40
+    assert method == "telea" or 1 <= ip.sweeps_run <= 40
 
 
 def test_builtin_plugins_read_the_live_map_on_the_device(weights, tmp_path):
