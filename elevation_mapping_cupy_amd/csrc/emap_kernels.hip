@@ -624,45 +624,44 @@ __device__ __forceinline__ float exp_neg(float a) {
 // of a dilated 3x3 filter go through packed fp32 FMAs in PAIRS (v_pk_fma_f32: the two channels' weights are one aligned scalar
 // register pair, the tap is broadcast): each channel keeps the reference's tap order, and the 1x1 output convolution is the same
 // scalar chain over (filter, channel) as the unfused stage -- half the vector instructions of the 12 x 9-tap filter bank.
-template <int STAGE, int ES>
-__device__ __forceinline__ void post_cell(const KP& P, const TravW& Wt, const float* t0, int dp, float own_valid, bool do_trav, bool do_normal,
-                                          Cells cells, float* __restrict__ trav_in, float* __restrict__ normal, long plane_stride, long c) {
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  const float h = t0[0];
-  trav_in[c] = h;
-  if (STAGE == 1) return;
-  if (do_trav) {
-    float acc = 0.f;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int dl = q + 1;
-      v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
-#pragma unroll
-      for (int a2 = 0; a2 < 3; ++a2)
-#pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2) {
-          const float t = t0[((a2 - 1) * dl * dp + (b2 - 1) * dl) * ES];
-          const v2f tt = {t, t};
-          const float* w = Wt.w[q][a2 * 3 + b2];
-          s01 = __builtin_elementwise_fma((v2f){w[0], w[1]}, tt, s01);
-          s23 = __builtin_elementwise_fma((v2f){w[2], w[3]}, tt, s23);
-        }
-      acc = fmaf(Wt.wo[q][0], fabsf(s01.x), acc);
-      acc = fmaf(Wt.wo[q][1], fabsf(s01.y), acc);
-      acc = fmaf(Wt.wo[q][2], fabsf(s23.x), acc);
-      acc = fmaf(Wt.wo[q][3], fabsf(s23.y), acc);
-    }
-    cells.hot[c].w = exp_neg(acc);                  // trav: a 4-byte store into the 16-byte hot half
-  }
-  float nx = 0.f, ny = 0.f, nz = 0.f;
-  if (do_normal && own_valid > 0.5f) {                                  // (is_valid of the cell itself)
-    const float dzdx = t0[ES] - h, dzdy = t0[ES * dp] - h;
-    const float ax = -dzdy / P.res_f, ay = -dzdx / P.res_f;           // IEEE: v_div_scale / v_div_fmas / v_div_fixup sequences
-    const float nrm = sqrt_rn_ge1((ax * ax) + (ay * ay) + 1.0f);
-    nx = ax / nrm; ny = ay / nrm; nz = 1.0f / nrm;
-  }
-  normal[c] = nx; normal[plane_stride + c] = ny; normal[2 * plane_stride + c] = nz;
-}
+// A MACRO, not a function: as an inlined function the compiler keeps all 120 weights live across the unrolled rows and spills them
+// through v_readlane / v_writelane (+370 instructions per wave, +2 us: measured in round 3); expanded in the row loop it reloads
+// them per row with scalar loads.
+#define POST_CELL(ES, t0, dp, own_valid, do_trav, do_normal, c)                                                          \
+  do {                                                                                                                    \
+    typedef float v2f __attribute__((ext_vector_type(2)));                                                               \
+    const float h = (t0)[0];                                                                                              \
+    trav_in[c] = h;                                                                                                       \
+    if (STAGE == 1) break;                                                                                                \
+    if (do_trav) {                                                                                                        \
+      float acc = 0.f;                                                                                                    \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                                     \
+        const int dl = q + 1;                                                                                             \
+        v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};                                                                           \
+        _Pragma("unroll") for (int a2 = 0; a2 < 3; ++a2)                                                                  \
+          _Pragma("unroll") for (int b2 = 0; b2 < 3; ++b2) {                                                              \
+            const float t = (t0)[((a2 - 1) * dl * (dp) + (b2 - 1) * dl) * (ES)];                                          \
+            const v2f tt = {t, t};                                                                                        \
+            const float* w = Wt.w[q][a2 * 3 + b2];                                                                        \
+            s01 = __builtin_elementwise_fma((v2f){w[0], w[1]}, tt, s01);                                                  \
+            s23 = __builtin_elementwise_fma((v2f){w[2], w[3]}, tt, s23);                                                  \
+          }                                                                                                               \
+        acc = fmaf(Wt.wo[q][0], fabsf(s01.x), acc);                                                                       \
+        acc = fmaf(Wt.wo[q][1], fabsf(s01.y), acc);                                                                       \
+        acc = fmaf(Wt.wo[q][2], fabsf(s23.x), acc);                                                                       \
+        acc = fmaf(Wt.wo[q][3], fabsf(s23.y), acc);                                                                       \
+      }                                                                                                                   \
+      cells.hot[c].w = exp_neg(acc);                  /* trav: a 4-byte store into the 16-byte hot half */                \
+    }                                                                                                                     \
+    float nx = 0.f, ny = 0.f, nz = 0.f;                                                                                   \
+    if ((do_normal) && (own_valid) > 0.5f) {                              /* (is_valid of the cell itself) */             \
+      const float dzdx = (t0)[ES] - h, dzdy = (t0)[(ES) * (dp)] - h;                                                      \
+      const float ax = -dzdy / P.res_f, ay = -dzdx / P.res_f;           /* IEEE: v_div_scale / v_div_fmas / v_div_fixup */ \
+      const float nrm = sqrt_rn_ge1((ax * ax) + (ay * ay) + 1.0f);                                                        \
+      nx = ax / nrm; ny = ay / nrm; nz = 1.0f / nrm;                                                                      \
+    }                                                                                                                     \
+    normal[c] = nx; normal[plane_stride + c] = ny; normal[2 * plane_stride + c] = nz;                                     \
+  } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
 // k_post_dma: the same fused stencils with the region staged by gfx950's LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes
@@ -780,8 +779,9 @@ __global__ __launch_bounds__(512) void k_post_dma(KP P, TravW Wt, Cells cells, f
     if (tr >= PT_R || gr >= seg_e) break;
     const int rr = tr + 3 + d, rc = tc + 3 + d;
     const long c = (long)(rtab[rr + 1] & 0xffffff) * C + pcol;
-    post_cell<STAGE, 1>(P, Wt, &val[rr * vp + rc], vp, raw[rr * RW + rc].w, col_in && gr >= 3 && gr <= C - 4, col_n && gr >= 1 && gr <= C - 3, cells, trav_in,
-                        normal, plane_stride, c);
+    const float* t0 = &val[rr * vp + rc];
+    const float own_valid = raw[rr * RW + rc].w;
+    POST_CELL(1, t0, vp, own_valid, col_in && gr >= 3 && gr <= C - 4, col_n && gr >= 1 && gr <= C - 3, c);
   }
 }
 
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
     if (tr >= PT_R || gr >= seg_e) break;
     const float* t0 = &dil[((tr + 3) * dp + (tc + 3)) * 3];
     const long c = (long)(rtab[tr + 4 + d] & 0xffffff) * C + pcol;
-    post_cell<STAGE, 3>(P, Wt, t0, dp, t0[2], col_in && gr >= 3 && gr <= C - 4, col_n && gr >= 1 && gr <= C - 3, cells, trav_in, normal, plane_stride, c);
+    POST_CELL(3, t0, dp, t0[2], col_in && gr >= 3 && gr <= C - 4, col_n && gr >= 1 && gr <= C - 3, c);
   }
 }
 
@@ -1158,7 +1158,8 @@ static size_t post_dma_lds_bytes(int R, int d) {  // k_post_dma: 16-byte region 
 // true: the LDS-DMA kernel handles this (tile height, radius) -- one lane per region row for the row terms, three workgroups per CU
 static bool post_use_dma(int R, int d) {
   static const bool dma_off = getenv("EMAP_POST_DMA") && atoi(getenv("EMAP_POST_DMA")) == 0;     // A/B and test hook: round 2's kernel
-  return !dma_off && R >= 16 && R + 8 + 2 * d <= 64 && post_dma_lds_bytes(R, d) <= 52 * 1024;     // (4-row tiles of robot-scale maps: 12.0 vs 9.7 us, measured)
+  static const long lds_kb = []() { const char* e = getenv("EMAP_POST_DMA_LDS_KB"); long v = e ? atol(e) : 0; return v >= 16 && v <= 150 ? v : 52; }();   // tuning knob
+  return !dma_off && R >= 16 && R + 8 + 2 * d <= 64 && (long)post_dma_lds_bytes(R, d) <= lds_kb * 1024;     // (4-row tiles of robot-scale maps: 12.0 vs 9.7 us, measured)
 }
 int post_tile_rows(const KP& P) {
   static const int force_r = []() { const char* e = getenv("EMAP_POST_R"); int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32) ? v : 0; }();
@@ -1167,7 +1168,11 @@ int post_tile_rows(const KP& P) {
   else if ((long)P.nrows * P.C <= 512L * 512L) R = 4;
   else if (post_lds_bytes(32, P.dil) > 60 * 1024) R = 16;             // large dilation radii: keep two workgroups per CU
   else R = (long)((P.C + PT_C - 1) / PT_C) * ((P.nrows + 31) / 32) >= 512 ? 32 : 16;
-  if (!force_r && R == 32 && post_use_dma(16, P.dil)) R = 16;        // the DMA kernel wants three workgroups per CU: 16-row tiles (measured, see k_post_dma)
+  // the DMA kernel wants three workgroups per CU, i.e. 16-row tiles -- where it was measured ahead: maps of many workgroup rounds
+  // (4096^2: 244-252 vs 256-275 us).  At 1024^2 (one round of 512 workgroups) rocprofv3 puts it BEHIND the register-staged kernel
+  // (20.8 vs 18.4 us; equal in event spacing): such maps keep k_post with 32-row tiles.
+  static const long min_side = []() { const char* e = getenv("EMAP_POST_DMA_MIN_SIDE"); long v = e ? atol(e) : 0; return v >= 1 ? v : 2048; }();            // tuning knob
+  if (!force_r && R == 32 && !post_use_dma(32, P.dil) && post_use_dma(16, P.dil) && (long)P.nrows * P.C >= min_side * min_side) R = 16;
   while (R > 4 && !post_use_dma(R, P.dil) && post_lds_bytes(R, P.dil) > 150 * 1024) R /= 2;      // dilation radii up to 32: the staged region must fit the 160 KB LDS
   return R;
 }
