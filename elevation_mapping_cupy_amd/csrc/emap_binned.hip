@@ -569,13 +569,25 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
     for (int k = threadIdx.x; k < SEM_GROUP * NC; k += EM_BLOCK) (&s_sum[0][0])[k] = 0.0;
     if (ride && g0 == 0) for (int k = threadIdx.x; k < 4 * NC; k += EM_BLOCK) (&s_col[0][0])[k] = 0u;
     __syncthreads();
+    // The channel values of a point are gathered by point index from the cloud (rows of `stride` floats: a random row per record).
+    // When the group's channels (and the colour channel riding along) lie within four consecutive columns -- the usual x y z rgb f1
+    // f2 f3 cloud -- ONE 16-byte load fetches them all instead of one dword load per channel (each a request of its own to the same
+    // one or two cache lines: the gathers were most of this kernel's time at 16 M points).
+    int cmin = SEM_MAX_CH + 4096, cmax = 0;
+    for (int q = 0; q < ng; ++q) { cmin = min(cmin, S.sum_chan[g0 + q]); cmax = max(cmax, S.sum_chan[g0 + q]); }
+    if (ride && g0 == 0) { cmin = min(cmin, S.col_chan[0]); cmax = max(cmax, S.col_chan[0]); }
+    const bool wide = cmax - cmin < 4 && cmin + 4 <= stride;          // (uniform) the 16 bytes stay inside the point's row
+    struct __attribute__((packed, aligned(4))) P4 { float a, b, c, d; };
+    auto pick = [](const P4& w, int j) { return j == 0 ? w.a : (j == 1 ? w.b : (j == 2 ? w.c : w.d)); };
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {
       const BinRec r = recs[k];
       if (((r.lc_inl & 0x7fffffffu) >> 10) != sel) continue;
       const unsigned int lc = r.lc_inl & 1023u;
       const float* p = pts + (long)r.i * stride;
+      P4 w4 = {0.f, 0.f, 0.f, 0.f};
+      if (wide) w4 = *reinterpret_cast<const P4*>(p + cmin);
       for (int q = 0; q < ng; ++q) {
-        const float v = p[S.sum_chan[g0 + q]];
+        const float v = wide ? pick(w4, S.sum_chan[g0 + q] - cmin) : p[S.sum_chan[g0 + q]];
         const int kind = S.sum_kind[g0 + q];
         if (kind >= 2) {                                                              // compact kernels: id * K + q < N, theta >= 0
           if ((long)r.i * S.sum_K[g0 + q] + S.sum_q[g0 + q] >= n) continue;
@@ -584,7 +596,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
         unsafeAtomicAdd(&s_sum[q][lc], (double)v);
       }
       if (ride && g0 == 0) {
-        const unsigned int color = __float_as_uint(p[S.col_chan[0]]);
+        const unsigned int color = __float_as_uint(wide ? pick(w4, S.col_chan[0] - cmin) : p[S.col_chan[0]]);
         atomicAdd(&s_col[0][lc], (color & 0xFF0000u) >> 16);
         atomicAdd(&s_col[1][lc], (color & 0xFF00u) >> 8);
         atomicAdd(&s_col[2][lc], color & 0xFFu);

@@ -1168,11 +1168,17 @@ int post_tile_rows(const KP& P) {
   else if ((long)P.nrows * P.C <= 512L * 512L) R = 4;
   else if (post_lds_bytes(32, P.dil) > 60 * 1024) R = 16;             // large dilation radii: keep two workgroups per CU
   else R = (long)((P.C + PT_C - 1) / PT_C) * ((P.nrows + 31) / 32) >= 512 ? 32 : 16;
-  // the DMA kernel wants three workgroups per CU, i.e. 16-row tiles -- where it was measured ahead: maps of many workgroup rounds
-  // (4096^2: 244-252 vs 256-275 us).  At 1024^2 (one round of 512 workgroups) rocprofv3 puts it BEHIND the register-staged kernel
-  // (20.8 vs 18.4 us; equal in event spacing): such maps keep k_post with 32-row tiles.
-  static const long min_side = []() { const char* e = getenv("EMAP_POST_DMA_MIN_SIDE"); long v = e ? atol(e) : 0; return v >= 1 ? v : 2048; }();            // tuning knob
-  if (!force_r && R == 32 && !post_use_dma(32, P.dil) && post_use_dma(16, P.dil) && (long)P.nrows * P.C >= min_side * min_side) R = 16;
+  // the DMA kernel wants three workgroups per CU, i.e. 16-row tiles -- and only where it was MEASURED ahead of the register-staged
+  // kernel (event spacing, MI355X, round 3): 2048^2 57.7 vs 57.2 us (equal), 4096^2 231 vs 264 us (-12 %), 6144^2 737 vs 610 us
+  // (+21 %), 8192^2 1894 vs 1186 us (+60 %, sparse map) / 1414 vs 982 us (cfg5); at 1024^2 (one round of 512 workgroups) rocprofv3
+  // puts it behind as well (20.8 vs 18.4 us).  The degradation with the map's ROW PITCH (96 / 128 KB between consecutive rows of a
+  // region) is not understood -- the sources and the 12 ... 44 rows a workgroup touches are the same in both kernels -- so the window
+  // is set from the measurements: 3072^2 <= cells < 5120^2 (BASELINE configs[3]).  EMAP_POST_DMA_WINDOW="lo hi" (side lengths) overrides.
+  static long win_lo = 3072, win_hi = 5120;
+  static const bool win_env = []() { const char* e = getenv("EMAP_POST_DMA_WINDOW"); long a = 0, b = 0; if (e && sscanf(e, "%ld %ld", &a, &b) == 2 && a >= 1 && b > a) { win_lo = a; win_hi = b; } return true; }();
+  (void)win_env;
+  const long cells = (long)P.nrows * P.C;
+  if (!force_r && R == 32 && !post_use_dma(32, P.dil) && post_use_dma(16, P.dil) && cells >= win_lo * win_lo && cells < win_hi * win_hi) R = 16;
   while (R > 4 && !post_use_dma(R, P.dil) && post_lds_bytes(R, P.dil) > 150 * 1024) R /= 2;      // dilation radii up to 32: the staged region must fit the 160 KB LDS
   return R;
 }
@@ -1195,7 +1201,9 @@ void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, c
     S.b[S.n] = seg_b[k]; S.e[S.n] = seg_e[k]; S.t0[S.n] = tiles; tiles += (seg_e[k] - seg_b[k] + R - 1) / R; S.n++;
   }
   if (!tiles) return;
-  const bool dma = post_use_dma(R, d);
+  const long cells_ = (long)P.nrows * P.C;
+  static const bool win_forced = getenv("EMAP_POST_DMA_WINDOW") != nullptr || getenv("EMAP_POST_R") != nullptr;
+  const bool dma = post_use_dma(R, d) && (win_forced || (R == 16 && cells_ >= 3072L * 3072L && cells_ < 5120L * 5120L));
   dim3 g((P.C + PT_C - 1) / PT_C, tiles), b(dma ? 512 : (R >= 32 ? POST_T32 : 512));
   const size_t lds = dma ? post_dma_lds_bytes(R, d) : post_lds_bytes(R, d);
 #define POST_GO(KERN, RR, ST) do { auto kern = KERN<RR, ST>; static LdsRaised raised; \
