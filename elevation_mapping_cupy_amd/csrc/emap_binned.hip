@@ -43,22 +43,6 @@
 
 // (BinGeo, BinRec: emap_device.h)
 
-// exclusive scan over the 256 threads of a block; returns the block total in `total`
-__device__ __forceinline__ unsigned int block_excl_scan(unsigned int x, unsigned int* sh /*[4]*/, unsigned int& total) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  unsigned int inc = x;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { unsigned int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
-  if (lane == 63) sh[w] = inc;
-  __syncthreads();
-  unsigned int base = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < EM_BLOCK / 64; ++k) { unsigned int s = sh[k]; if (k < w) base += s; tot += s; }
-  __syncthreads();
-  total = tot;
-  return base + inc - x;
-}
-
 // sort bin of a point (-1: none) and its cell inside the bin.  Tiles are PHYSICAL: 16 owned rows x 64 columns of memory.
 __device__ __forceinline__ int bin_of(const KP& P, const BinGeo& G, const Geo& g, unsigned int& lc) {
   const int lrow = phys_row(P, g.ix) - P.row0, pcol = phys_col(P, g.iy);
@@ -169,7 +153,6 @@ __global__ __launch_bounds__(SCAN_BLK) void k_bin_scan(BinGeo G, unsigned int* _
                                                         unsigned int* __restrict__ tile_start, unsigned int* __restrict__ sync) {
   constexpr int NW = SCAN_BLK / 64;
   __shared__ unsigned int part[NW][SCAN_TT];
-  __shared__ unsigned int sh[EM_BLOCK / 64];
   __shared__ bool s_last;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = blockIdx.x * SCAN_TT + lane;
   const bool col_ok = t < G.pitch;
@@ -203,16 +186,23 @@ __global__ __launch_bounds__(SCAN_BLK) void k_bin_scan(BinGeo G, unsigned int* _
   }
   __syncthreads();
   if (!s_last) return;
-  if (threadIdx.x >= EM_BLOCK) return;                     // the tail is a 256-thread scan (block_excl_scan); no barrier involves the others below
-  unsigned int running = 0;
-  for (int tb = 0; tb < G.TB; tb += EM_BLOCK) {
-    const int tt = tb + threadIdx.x;
-    unsigned int x = tt < G.TB ? __hip_atomic_load(&tile_total[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u, tot;
-    unsigned int ex = block_excl_scan(x, sh, tot);
-    if (tt < G.TB) tile_start[tt] = running + ex;
-    running += tot;
-  }
-  if (threadIdx.x == 0) tile_start[G.TB] = running;          // = number of sorted records
+  // the tail: exclusive scan of the TB tile totals by all 1024 threads -- every thread a run of consecutive tiles (two passes over
+  // its run around ONE block-wide scan of the run sums; the 64 rounds of a 256-thread scan cost 30 us at 16385 bins)
+  const int per = (G.TB + SCAN_BLK - 1) / SCAN_BLK, t_lo = min(G.TB, (int)threadIdx.x * per), t_hi = min(G.TB, t_lo + per);
+  unsigned int mine = 0u;
+  for (int tt = t_lo; tt < t_hi; ++tt) mine += __hip_atomic_load(&tile_total[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned int inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+  __syncthreads();                                            // part[][] is free again (every wave has left the slab loop)
+  if (lane == 63) part[0][w] = inc;
+  __syncthreads();
+  unsigned int base = 0u, total = 0u;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) { const unsigned int x = part[0][k]; if (k < w) base += x; total += x; }
+  unsigned int run = base + inc - mine;
+  for (int tt = t_lo; tt < t_hi; ++tt) { tile_start[tt] = run; run += __hip_atomic_load(&tile_total[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if (threadIdx.x == 0) tile_start[G.TB] = total;             // = number of sorted records
 }
 
 template <int MODE, int BLK, bool STRIP>

@@ -1178,7 +1178,7 @@ int post_tile_rows(const KP& P) {
   static const bool win_env = []() { const char* e = getenv("EMAP_POST_DMA_WINDOW"); long a = 0, b = 0; if (e && sscanf(e, "%ld %ld", &a, &b) == 2 && a >= 1 && b > a) { win_lo = a; win_hi = b; } return true; }();
   (void)win_env;
   const long cells = (long)P.nrows * P.C;
-  if (!force_r && R == 32 && !post_use_dma(32, P.dil) && post_use_dma(16, P.dil) && cells >= win_lo * win_lo && cells < win_hi * win_hi) R = 16;
+  if (!force_r && R == 32 && !post_use_dma(32, P.dil) && post_use_dma(16, P.dil) && cells >= win_lo * win_lo && cells < win_hi * win_hi && P.C < win_hi) R = 16;      // (the row pitch counts: strips of wider maps keep k_post)
   while (R > 4 && !post_use_dma(R, P.dil) && post_lds_bytes(R, P.dil) > 150 * 1024) R /= 2;      // dilation radii up to 32: the staged region must fit the 160 KB LDS
   return R;
 }
@@ -1203,7 +1203,7 @@ void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, c
   if (!tiles) return;
   const long cells_ = (long)P.nrows * P.C;
   static const bool win_forced = getenv("EMAP_POST_DMA_WINDOW") != nullptr || getenv("EMAP_POST_R") != nullptr;
-  const bool dma = post_use_dma(R, d) && (win_forced || (R == 16 && cells_ >= 3072L * 3072L && cells_ < 5120L * 5120L));
+  const bool dma = post_use_dma(R, d) && (win_forced || (R == 16 && cells_ >= 3072L * 3072L && cells_ < 5120L * 5120L && P.C < 5120));
   dim3 g((P.C + PT_C - 1) / PT_C, tiles), b(dma ? 512 : (R >= 32 ? POST_T32 : 512));
   const size_t lds = dma ? post_dma_lds_bytes(R, d) : post_lds_bytes(R, d);
 #define POST_GO(KERN, RR, ST) do { auto kern = KERN<RR, ST>; static LdsRaised raised; \
