@@ -538,7 +538,8 @@ void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* 
 // ---------------------------------------------------------------------------------------------------------
 typedef SemSpec SemSpecB;
 #define SEM_GROUP 4
-__global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemSpecB S, const BinRec* __restrict__ recs,
+#define SEM_BLK 1024     /* one wave per tile row: 32 waves per CU with two workgroups (256 threads left the CU at 12 waves: the kernel is a chain of short, latency-bound phases) */
+__global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSpecB S, const BinRec* __restrict__ recs,
                                                              const unsigned int* __restrict__ tile_start, const float* __restrict__ pts,
                                                              long n, int stride, const unsigned int* __restrict__ cnt_plane,
                                                              float* __restrict__ sem, float* __restrict__ alpha_planes, long plane) {
@@ -556,8 +557,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
   const bool ride = S.n_col == 1 && S.n_sum > 0;
   for (int g0 = 0; g0 < S.n_sum; g0 += SEM_GROUP) {
     const int ng = min(SEM_GROUP, S.n_sum - g0);
-    for (int k = threadIdx.x; k < SEM_GROUP * NC; k += EM_BLOCK) (&s_sum[0][0])[k] = 0.0;
-    if (ride && g0 == 0) for (int k = threadIdx.x; k < 4 * NC; k += EM_BLOCK) (&s_col[0][0])[k] = 0u;
+    for (int k = threadIdx.x; k < SEM_GROUP * NC; k += SEM_BLK) (&s_sum[0][0])[k] = 0.0;
+    if (ride && g0 == 0) for (int k = threadIdx.x; k < 4 * NC; k += SEM_BLK) (&s_col[0][0])[k] = 0u;
     __syncthreads();
     // The channel values of a point are gathered by point index from the cloud (rows of `stride` floats: a random row per record).
     // When the group's channels (and the colour channel riding along) lie within four consecutive columns -- the usual x y z rgb f1
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
     const bool wide = cmax - cmin < 4 && cmin + 4 <= stride;          // (uniform) the 16 bytes stay inside the point's row
     struct __attribute__((packed, aligned(4))) P4 { float a, b, c, d; };
     auto pick = [](const P4& w, int j) { return j == 0 ? w.a : (j == 1 ? w.b : (j == 2 ? w.c : w.d)); };
-    for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {
+    for (unsigned int k = r0 + threadIdx.x; k < r1; k += SEM_BLK) {
       const BinRec r = recs[k];
       if (((r.lc_inl & 0x7fffffffu) >> 10) != sel) continue;
       const unsigned int lc = r.lc_inl & 1023u;
@@ -595,8 +596,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
     }
     __syncthreads();
     if (col < P.C) {
-      for (int k = 0; k < BIN_TR / 4; ++k) {
-        const int tr = wv + 4 * k, lrow = row_base + tr;
+      for (int k = 0; k < BIN_TR / (SEM_BLK / 64); ++k) {
+        const int tr = wv + (SEM_BLK / 64) * k, lrow = row_base + tr;
         if (lrow >= P.nrows) break;
         const long c = (long)(lrow + P.halo) * P.C + col;
         const unsigned int cnt = cnt_plane[c];               // accepted HEIGHT points (new_elmap plane 2, :185)
@@ -631,8 +632,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
     __syncthreads();
   }
   if (S.any_bayes && col < P.C) {     // class_bayesian: theta = alpha / sum(alpha) over its layers, same thread <-> same cells as above
-    for (int k = 0; k < BIN_TR / 4; ++k) {
-      const int tr = wv + 4 * k, lrow = row_base + tr;
+    for (int k = 0; k < BIN_TR / (SEM_BLK / 64); ++k) {
+      const int tr = wv + (SEM_BLK / 64) * k, lrow = row_base + tr;
       if (lrow >= P.nrows) break;
       const long c = (long)(lrow + P.halo) * P.C + col;
       float tot = 0.0f;
@@ -645,9 +646,9 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
     const int K = S.n_col;
     // the reference's launch-size quirk (fusion/pointcloud_color.py:143): element e = id * K + layer only exists for e < N,
     // and ONE counter plane is shared by all K layers
-    for (int k = threadIdx.x; k < NC; k += EM_BLOCK) s_col[3][k] = 0u;
+    for (int k = threadIdx.x; k < NC; k += SEM_BLK) s_col[3][k] = 0u;
     __syncthreads();
-    for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {
+    for (unsigned int k = r0 + threadIdx.x; k < r1; k += SEM_BLK) {
       const BinRec r = recs[k];
       if (((r.lc_inl & 0x7fffffffu) >> 10) != sel) continue;
       const unsigned int lc = r.lc_inl & 1023u;
@@ -655,9 +656,9 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
     }
     __syncthreads();
     for (int l = 0; l < K; ++l) {
-      for (int k = threadIdx.x; k < 3 * NC; k += EM_BLOCK) (&s_col[0][0])[k] = 0u;
+      for (int k = threadIdx.x; k < 3 * NC; k += SEM_BLK) (&s_col[0][0])[k] = 0u;
       __syncthreads();
-      for (unsigned int k = r0 + threadIdx.x; k < r1; k += EM_BLOCK) {
+      for (unsigned int k = r0 + threadIdx.x; k < r1; k += SEM_BLK) {
         const BinRec r = recs[k];
         if ((long)r.i * K + l >= n || ((r.lc_inl & 0x7fffffffu) >> 10) != sel) continue;
         const unsigned int lc = r.lc_inl & 1023u;
@@ -668,8 +669,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
       }
       __syncthreads();
       if (col < P.C) {
-        for (int k = 0; k < BIN_TR / 4; ++k) {
-          const int tr = wv + 4 * k, lrow = row_base + tr, lc = tr * BIN_TC + tc;
+        for (int k = 0; k < BIN_TR / (SEM_BLK / 64); ++k) {
+          const int tr = wv + (SEM_BLK / 64) * k, lrow = row_base + tr, lc = tr * BIN_TC + tc;
           if (lrow >= P.nrows) break;
           const unsigned int cn = s_col[3][lc];
           if (cn == 0) continue;
@@ -683,5 +684,5 @@ __global__ __launch_bounds__(EM_BLOCK) void k_tile_semantic(KP P, BinGeo G, SemS
 }
 void launch_tile_semantic(hipStream_t s, const KP& P, const BinGeo& G, const SemSpec& S, const BinRec* recs, const unsigned int* tile_start,
                           const float* pts, long n, int stride, const unsigned int* cnt_plane, float* sem, float* alpha_planes, long plane) {
-  hipLaunchKernelGGL(k_tile_semantic, dim3(G.T, G.sub), dim3(EM_BLOCK), 0, s, P, G, S, recs, tile_start, pts, n, stride, cnt_plane, sem, alpha_planes, plane);
+  hipLaunchKernelGGL(k_tile_semantic, dim3(G.T, G.sub), dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, pts, n, stride, cnt_plane, sem, alpha_planes, plane);
 }
