@@ -48,7 +48,7 @@ def source_stamp():
 
 
 def rocprof_kernel_us(workload, kernel_prefix):
-    """average duration (us) of a kernel in profiles/<round>_<workload>_kernel_stats.txt -- None when the file is missing or was taken
+    """median duration (us) of a kernel in profiles/<round>_<workload>_kernel_stats.txt -- None when the file is missing or was taken
     with other kernel sources (its '# source_stamp:' line)"""
     f = os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.txt" % (PROFILE_ROUND, workload))
     if not os.path.exists(f):
@@ -61,8 +61,8 @@ def rocprof_kernel_us(workload, kernel_prefix):
         name = ln.replace("void ", "", 1).lstrip()
         if name.startswith(kernel_prefix):
             tok = ln[86:].split()
-            try:
-                return float(tok[1]), "profiles/%s (avg of %s launches)" % (os.path.basename(f), tok[0])
+            try:     # columns: calls, avg_us, median_us, ...: the MEDIAN (the first launches after clear() / the warm-up's time ticks are not steady state)
+                return float(tok[2]), "profiles/%s (median of %s launches; average %s us)" % (os.path.basename(f), tok[0], tok[1])
             except (IndexError, ValueError):
                 pass
     return None, None
@@ -260,7 +260,7 @@ def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step
             for name, rec in pj["kernels"].items():
                 if name.startswith(kern):
                     traffic, traffic_src = rec["hbm_bytes"], "profiles/%s (%s)" % (os.path.basename(pmc_file), name)
-    # the kernel's average duration in the committed rocprofv3 summary of this command (only when taken with THESE kernel sources):
+    # the kernel's median duration in the committed rocprofv3 summary of this command (only when taken with THESE kernel sources):
     # `frac` is quoted from it so that the line and profiles/ agree; the live event spacing stays beside it
     kus, ksrc = rocprof_kernel_us(workload, STAGE_KERNEL[dom]) if pmc_ok else (None, None)
     frac_events = achieved / HBM_PEAK_GBS
