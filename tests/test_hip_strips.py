@@ -103,8 +103,8 @@ def test_strip_contexts_reproduce_single_context(world, cfg_name, C, weights):
         assert add == full.get_additive_mean_error()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_strips_fuse_rgb_and_semantic_channels_like_the_single_context(world, weights):
+@pytest.mark.parametrize("world,scatter", [(2, "auto"), (3, "auto"), (2, "binned"), (3, "binned")])
+def test_strips_fuse_rgb_and_semantic_channels_like_the_single_context(world, scatter, weights):
     """BASELINE config 5 on strips: the extra cloud channels are fused per cell into the strip's own layers (no exchange step);
     colour layer bit-exact, averaged layers bit-exact too (same LDS reduction per tile or the same atomics per cell)."""
     import torch
@@ -124,6 +124,7 @@ def test_strips_fuse_rgb_and_semantic_channels_like_the_single_context(world, we
         p.pointcloud_channel_fusions = dict(FUS)
         return p
     full = ElevationMap(par())
+    full.set_scatter_mode(scatter)
     for p in clouds:
         full.input_pointcloud(p, CH, R, t.copy() + full.center, 1.0, 1.0)
         full.update_time()
@@ -135,6 +136,7 @@ def test_strips_fuse_rgb_and_semantic_channels_like_the_single_context(world, we
     def run(rank):
         try:
             eng = HipStripEngine(par(), rank, world, 0, dev)
+            eng.map.set_scatter_mode(scatter)          # binned: the strip point passes stage and carry the channels (emap_binned.hip)
             sm = ShardedElevationMap(eng, ThreadComm(rank, world, shared), False, cfg["enable_overlap_clearance"])
             for p in clouds:
                 eng.bind_points(p)
