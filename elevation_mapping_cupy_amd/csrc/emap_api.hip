@@ -36,7 +36,11 @@ void launch_semraw_acc(hipStream_t, const SemRaw&, const float*, const int*, con
 void launch_semraw_fin(hipStream_t, const SemRaw&, float*, const unsigned int*, const int*, const float*, const float*, float*);
 void launch_polygon_mask(hipStream_t, int, const int*, const int*, int, const int*, float*);
 void launch_dilate_planes(hipStream_t, int, int, const float*, const float*, float*, float*);
-struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; };
+struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; double tol; };
+struct CmaxSpec { int n; int chan[8]; int layer[8]; };
+void launch_cmax_ids(hipStream_t, const KP&, const CmaxSpec&, const float*, long, int, const float*, long, unsigned char*, unsigned char*);
+void launch_cmax_sum(hipStream_t, const KP&, const Pose&, const CmaxSpec&, const float*, long, int, const int*, long long*, long);
+void launch_cmax_select(hipStream_t, const KP&, const CmaxSpec&, int, const long long*, long, unsigned char*, unsigned char*, const unsigned int*, float*, float*, float*);
 void launch_image_corr(hipStream_t, const KP&, const CamArgs&, Cells, float*, unsigned char*);
 void launch_image_fuse(hipStream_t, const KP&, int, float*, const float*, const float*, const unsigned char*, float, float, double);
 void launch_inpaint_sweep(hipStream_t, int, const float*, const float*, float*, float*, const unsigned int*, unsigned int*);
@@ -142,6 +146,7 @@ struct emap_ctx {
   unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;
   // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
   float* img_uv; unsigned char* img_valid; float* img_buf; size_t img_cap;   // camera path
+  double img_tol; bool img_tol_set;   // tolerance_z_collision of the occlusion walk (0.10 unless emap_image_set_tolerance was called)
   float* sem_alpha;   // class_bayesian pseudo-counts (the reference's persistent new_map layers), sem_layers planes, on demand
   int sem_layers; float* sem; double* sem_sums; unsigned int* sem_col; unsigned int* cnt_plane;
   // point cloud
@@ -1139,6 +1144,69 @@ int emap_semantic_finalize(emap_ctx* ctx, int32_t op, void* newmap_inout, int32_
   return EMAP_OK;
 }
 
+// ---- pointcloud_class_max (EM/fusion/pointcloud_class_max.py:80-126; kernels: emap_semantic.hip) ------------------------------
+// The class-id planes (the reference's elements_to_shift["id_max"]) live in the layers' persistent planes (sem_alpha): they move
+// with the map and read back through emap_semantic_get_alpha as uint32 bit patterns.  `prev_unique` is the fusion's unique_id array
+// of the previous frame ([0] before the first: :59).  The reference gathers unique_id[id_max] (:86) -- the planes hold class VALUES,
+// so that is only defined while every stored value is a valid position; values beyond the array are ignored here (CuPy would read
+// out of bounds).
+int emap_semantic_class_max(emap_ctx* ctx, const float R[9], const float t[3], int32_t n_ch, const int32_t* chan, const int32_t* layer,
+                            const uint32_t* prev_unique, int32_t n_prev, uint32_t* unique_out, int32_t unique_cap, int32_t* n_unique_out) {
+  CKARG(ctx && R && t && chan && layer && unique_out && n_unique_out && n_ch >= 1 && n_ch <= 8 && n_prev >= 0 && (n_prev == 0 || prev_unique), "bad argument");
+  NEED_POINTS();
+  for (int k = 0; k < n_ch; ++k)
+    CKARG(layer[k] >= 0 && layer[k] < ctx->sem_layers && chan[k] >= 3 && chan[k] < ctx->stride, "bad channel/layer index");
+  CK(hipSetDevice(ctx->device));
+  { int rc = ensure_alpha(ctx); if (rc) return rc; }
+  hipStream_t st = ctx->stream;
+  CmaxSpec S; memset(&S, 0, sizeof S);
+  S.n = n_ch; for (int k = 0; k < n_ch; ++k) { S.chan[k] = chan[k]; S.layer[k] = layer[k]; }
+  const long plane = ctx->ncells_alloc;
+  // (1) the ids of this frame and of the map
+  unsigned char* d_seen = nullptr;
+  CK(hipMalloc((void**)&d_seen, 2 * 65536));
+  struct Free { void* p; ~Free() { if (p) hipFree(p); } } f_seen{d_seen};
+  CK(hipMemsetAsync(d_seen, 0, 2 * 65536, st));
+  launch_cmax_ids(st, ctx->kp, S, ctx->pts, ctx->n_pts, ctx->stride, ctx->sem_alpha, plane, d_seen, d_seen + 65536);
+  CK(hipGetLastError());
+  std::vector<unsigned char> seen(2 * 65536);
+  CK(hipMemcpyAsync(seen.data(), d_seen, 2 * 65536, hipMemcpyDeviceToHost, st));
+  CK(hipStreamSynchronize(st));
+  const uint32_t zero_id = 0;
+  if (n_prev == 0) { prev_unique = &zero_id; n_prev = 1; }
+  std::vector<unsigned char> in_set(65536, 0);
+  for (int v = 0; v < 65536; ++v) {
+    if (seen[v]) in_set[v] = 1;                                                            // unique(pt_id) (:84)
+    if (seen[65536 + v] && v < n_prev && prev_unique[v] < 65536u) in_set[prev_unique[v]] = 1;      // unique(unique_id[id_max]) (:86)
+  }
+  std::vector<uint32_t> uniq; std::vector<int> pos(65536, 0);
+  for (int v = 0; v < 65536; ++v) if (in_set[v]) { pos[v] = (int)uniq.size(); uniq.push_back((uint32_t)v); }
+  const int U = (int)uniq.size();
+  CKARG(U <= unique_cap, "unique_out too small for the class ids of this frame");
+  const size_t sum_bytes = sizeof(long long) * (size_t)U * plane;
+  CKARG(sum_bytes <= ((size_t)16 << 30), "class_max: (classes x cells) probability sums beyond 16 GB");
+  // (2) probability sums per (class, cell)
+  long long* d_sum = nullptr; int* d_pos = nullptr; unsigned int* d_uniq = nullptr; unsigned char* d_flags = nullptr; float* d_new = nullptr;
+  CK(hipMalloc((void**)&d_sum, sum_bytes)); Free f_sum{d_sum};
+  CK(hipMalloc((void**)&d_pos, sizeof(int) * 65536)); Free f_pos{d_pos};
+  CK(hipMalloc((void**)&d_uniq, sizeof(unsigned int) * U)); Free f_uniq{d_uniq};
+  CK(hipMalloc((void**)&d_flags, 2 * (size_t)U)); Free f_flags{d_flags};
+  CK(hipMalloc((void**)&d_new, sizeof(float) * (size_t)n_ch * plane)); Free f_new{d_new};
+  CK(hipMemsetAsync(d_sum, 0, sum_bytes, st));
+  CK(hipMemsetAsync(d_flags, 0, 2 * (size_t)U, st));
+  CK(hipMemsetAsync(d_new, 0, sizeof(float) * (size_t)n_ch * plane, st));
+  CK(hipMemcpyAsync(d_pos, pos.data(), sizeof(int) * 65536, hipMemcpyHostToDevice, st));
+  CK(hipMemcpyAsync(d_uniq, uniq.data(), sizeof(unsigned int) * U, hipMemcpyHostToDevice, st));
+  launch_cmax_sum(st, ctx->kp, make_pose(ctx, R, t), S, ctx->pts, ctx->n_pts, ctx->stride, d_pos, d_sum, plane);
+  // (3) + (4): per layer the maximum and its class, the winners' planes zeroed in between; then the normalisation
+  launch_cmax_select(st, ctx->kp, S, U, d_sum, plane, d_flags, d_flags + U, d_uniq, d_new, ctx->sem_alpha, ctx->sem);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(st));              // the host vectors and the temporaries end with the call
+  memcpy(unique_out, uniq.data(), sizeof(uint32_t) * U);
+  *n_unique_out = U;
+  return EMAP_OK;
+}
+
 static int sem_view(emap_ctx* ctx, float* planes, int32_t layer, float* host, bool to_device) {   // semantic layers share the map's origin
   const size_t bytes = sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n;
   if (to_device) CK(hipMemcpyAsync(ctx->scratch, host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -1306,7 +1374,7 @@ int emap_image_correspondence(emap_ctx* ctx, float x1, float y1, float z1, const
   if (!ctx->img_uv) { CK(hipMalloc((void**)&ctx->img_uv, sizeof(float) * 2 * L)); CK(hipMalloc((void**)&ctx->img_valid, L)); }
   CamArgs A;
   memcpy(A.P, P, sizeof A.P); memcpy(A.K, K, sizeof A.K); memcpy(A.D, D, sizeof A.D); memcpy(A.center, center, sizeof A.center);
-  A.x1 = x1; A.y1 = y1; A.z1 = z1; A.ih = image_height; A.iw = image_width;
+  A.x1 = x1; A.y1 = y1; A.z1 = z1; A.ih = image_height; A.iw = image_width; A.tol = ctx->img_tol_set ? ctx->img_tol : 0.10;
   launch_image_corr(ctx->stream, ctx->kp, A, ctx->cells, ctx->img_uv, ctx->img_valid);
   CK(hipGetLastError());
   return EMAP_OK;
@@ -1322,7 +1390,7 @@ int emap_image_get_correspondence(emap_ctx* ctx, float* uv_host, uint8_t* valid_
 }
 int emap_image_fuse(emap_ctx* ctx, int32_t kind, int32_t layer, const float* host_image, int32_t n_planes, int32_t height, int32_t width,
                     double alpha) {
-  CKARG(ctx && host_image && (kind == 0 || kind == 1) && layer >= 0 && layer < ctx->sem_layers, "bad argument");
+  CKARG(ctx && host_image && kind >= 0 && kind <= 2 && layer >= 0 && layer < ctx->sem_layers, "bad argument");
   CKARG(ctx->img_uv, "emap_image_correspondence must run first");
   CKARG(n_planes >= (kind == 1 ? 3 : 1) && height > 0 && width > 0, "bad image shape");
   CK(hipSetDevice(ctx->device));
@@ -1339,6 +1407,33 @@ int emap_image_fuse(emap_ctx* ctx, int32_t kind, int32_t layer, const float* hos
                     (float)height, (float)width, alpha);
   CK(hipGetLastError());
   CK(hipStreamSynchronize(ctx->stream));   // host image is only borrowed for the call
+  return EMAP_OK;
+}
+
+int emap_image_set_tolerance(emap_ctx* ctx, double tolerance_z_collision) {
+  CKARG(ctx && tolerance_z_collision == tolerance_z_collision, "bad argument");
+  ctx->img_tol = tolerance_z_collision; ctx->img_tol_set = true;
+  return EMAP_OK;
+}
+// the three *_correspondences_to_map kernels on caller arrays (the factories of the compat package): one (cell_n, cell_n) plane in,
+// one out; cells without a valid correspondence keep their value (the reference's else branch copies sem_map to new_sem_map)
+int emap_image_fuse_arrays(emap_ctx* ctx, int32_t kind, const float* sem_plane, const float* host_image, int32_t n_planes, int32_t height,
+                           int32_t width, const float* uv, const uint8_t* valid, double alpha, float* out_plane) {
+  CKARG(ctx && sem_plane && host_image && uv && valid && out_plane && kind >= 0 && kind <= 2, "bad argument");
+  CKARG(n_planes >= (kind == 1 ? 3 : 1) && height > 0 && width > 0, "bad image shape");
+  CK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t L = (size_t)ctx->prm.cell_n * ctx->prm.cell_n;
+  DevBuf S, I, U, V;
+  CK(S.put(sem_plane, sizeof(float) * L, st, out_plane));
+  CK(I.put(host_image, sizeof(float) * (size_t)n_planes * height * width, st, nullptr));
+  CK(U.put(uv, sizeof(float) * 2 * L, st, nullptr));
+  CK(V.put(valid, L, st, nullptr));
+  KP kp = ctx->kp; kp.org_r = kp.org_c = 0;               // caller arrays are logical: no circular origin
+  launch_image_fuse(st, kp, kind, (float*)S.d, (const float*)I.d, (const float*)U.d, (const unsigned char*)V.d, (float)height, (float)width, alpha);
+  CK(hipGetLastError());
+  CK(S.get(st));
+  CK(hipStreamSynchronize(st));
   return EMAP_OK;
 }
 

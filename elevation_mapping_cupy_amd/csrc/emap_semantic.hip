@@ -249,12 +249,109 @@ void launch_inpaint_sweep(hipStream_t s, int C, const float* val, const float* m
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// pointcloud_class_max (reference EM/fusion/pointcloud_class_max.py:12-123): every class_max channel of a point carries one
+// (probability, class id) pair packed into a float -- low 16 bits an IEEE half, high 16 bits the id (decode_max, :62-78).  Per
+// frame the reference (1) takes the sorted set of ids seen in the cloud and in the map's id planes, (2) sums the probabilities per
+// (class, cell) over the valid, inside points (sum_max_kernel, :12-47), (3) for the fusion's layers in turn stores the per-cell
+// maximum over the classes and its class id, then sets the planes of ALL classes that were a maximum in SOME cell to zero (:119-121),
+// (4) normalises the layers of a cell by their sum (:123-126).  The sums here are exact: a half is an integer multiple of 2^-24, so
+// 64-bit integers in units of 2^-24 hold every partial sum and the result does not depend on the order of the atomics (the
+// reference's float atomics round after every addition).  Host side (the set union, the whole-plane zeroing between layers):
+// emap_api.hip emap_semantic_class_max.
+// ---------------------------------------------------------------------------------------------------------
+struct CmaxSpec { int n; int chan[8]; int layer[8]; };
+__global__ __launch_bounds__(EM_BLOCK) void k_cmax_ids(const float* __restrict__ pts, long n, int stride, CmaxSpec S,
+                                                        unsigned char* __restrict__ seen) {
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  for (int it = 0; it < S.n; ++it) seen[__float_as_uint(pts[i * stride + S.chan[it]]) >> 16] = 1;       // every point, valid or not (:82-84)
+}
+// ids stored in the map's id planes (elements_to_shift["id_max"], kept in the layers' persistent planes): values < 65536 only
+__global__ __launch_bounds__(EM_BLOCK) void k_cmax_prev_ids(KP P, CmaxSpec S, const float* __restrict__ id_planes, long plane,
+                                                             unsigned char* __restrict__ seen_prev) {
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= (long)P.nrows * P.C) return;
+  const long c = (long)P.halo * P.C + i;
+  for (int it = 0; it < S.n; ++it) { const unsigned int v = __float_as_uint(id_planes[(long)S.layer[it] * plane + c]); if (v < 65536u) seen_prev[v] = 1; }
+}
+template <int MODE>
+__global__ __launch_bounds__(EM_BLOCK) void k_cmax_sum(KP P, Pose T, CmaxSpec S, const float* __restrict__ pts, long n, int stride,
+                                                        const int* __restrict__ pos, long long* __restrict__ prob_sum, long plane) {
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float rx, ry, rz;
+  load_point(pts, i, stride, rx, ry, rz);
+  const Geo g = geometry<MODE>(P, T, rx, ry, rz);
+  const long c = (g.finite && g.valid && g.inside) ? owned_cell(P, g.ix, g.iy) : -1;
+  if (c < 0) return;
+  for (int it = 0; it < S.n; ++it) {
+    const unsigned int bits = __float_as_uint(pts[i * stride + S.chan[it]]);
+    const unsigned short hb = (unsigned short)(bits & 0xffffu);
+    _Float16 h; __builtin_memcpy(&h, &hb, 2);
+    const float prob = (float)h;
+    if (!(fabsf(prob) <= 65504.0f)) continue;                      // inf / NaN probabilities add nothing (the reference would poison the sum)
+    const long long fix = (long long)(prob * 16777216.0f);          // exact: halves are multiples of 2^-24
+    atomicAdd(reinterpret_cast<unsigned long long*>(&prob_sum[(long)pos[bits >> 16] * plane + c]), (unsigned long long)fix);
+  }
+}
+// one layer of step (3): maximum over the classes (planes already set to zero count as 0, like the reference's zeroed planes), FIRST
+// class on ties (cp.argmax); the winning classes are flagged in `used` and zeroed for the next layer by k_cmax_merge
+__global__ __launch_bounds__(EM_BLOCK) void k_cmax_top(KP P, int U, const long long* __restrict__ prob_sum, long plane,
+                                                        const unsigned char* __restrict__ zeroed, unsigned char* __restrict__ used,
+                                                        const unsigned int* __restrict__ unique_id, float* __restrict__ new_plane,
+                                                        float* __restrict__ id_plane) {
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= (long)P.nrows * P.C) return;
+  const long c = (long)P.halo * P.C + i;
+  float best = 0.f; int arg = 0;
+  for (int u = 0; u < U; ++u) {
+    const float v = zeroed[u] ? 0.f : (float)((double)prob_sum[(long)u * plane + c] * (1.0 / 16777216.0));      // the exact sum, rounded once
+    if (u == 0 || v > best) { best = v; arg = u; }
+  }
+  new_plane[c] = best;
+  id_plane[c] = __uint_as_float(unique_id[arg]);
+  used[arg] = 1;
+}
+__global__ void k_cmax_merge(int U, unsigned char* __restrict__ zeroed, unsigned char* __restrict__ used) {
+  for (int u = threadIdx.x; u < U; u += blockDim.x) { if (used[u]) zeroed[u] = 1; used[u] = 0; }
+}
+__global__ __launch_bounds__(EM_BLOCK) void k_cmax_norm(KP P, CmaxSpec S, const float* __restrict__ newp, float* __restrict__ sem, long plane) {
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (i >= (long)P.nrows * P.C) return;
+  const long c = (long)P.halo * P.C + i;
+  float sum = 0.f;
+  for (int it = 0; it < S.n; ++it) sum += newp[(long)it * plane + c];
+  if (sum == 0.f) sum = 1.f;
+  for (int it = 0; it < S.n; ++it) sem[(long)S.layer[it] * plane + c] = newp[(long)it * plane + c] / sum;
+}
+void launch_cmax_ids(hipStream_t s, const KP& P, const CmaxSpec& S, const float* pts, long n, int stride, const float* id_planes, long plane,
+                     unsigned char* seen, unsigned char* seen_prev) {
+  if (n > 0) hipLaunchKernelGGL(k_cmax_ids, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, pts, n, stride, S, seen);
+  hipLaunchKernelGGL(k_cmax_prev_ids, dim3(nblk_((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, S, id_planes, plane, seen_prev);
+}
+void launch_cmax_sum(hipStream_t s, const KP& P, const Pose& T, const CmaxSpec& S, const float* pts, long n, int stride, const int* pos,
+                     long long* prob_sum, long plane) {
+  if (n <= 0) return;
+  if (P.mode == 0) hipLaunchKernelGGL(k_cmax_sum<0>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, pos, prob_sum, plane);
+  else hipLaunchKernelGGL(k_cmax_sum<1>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, pos, prob_sum, plane);
+}
+void launch_cmax_select(hipStream_t s, const KP& P, const CmaxSpec& S, int U, const long long* prob_sum, long plane, unsigned char* zeroed,
+                        unsigned char* used, const unsigned int* unique_id, float* newp, float* id_planes, float* sem) {
+  for (int it = 0; it < S.n; ++it) {
+    hipLaunchKernelGGL(k_cmax_top, dim3(nblk_((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, U, prob_sum, plane, zeroed, used, unique_id,
+                       newp + (long)it * plane, id_planes + (long)S.layer[it] * plane);
+    hipLaunchKernelGGL(k_cmax_merge, dim3(1), dim3(256), 0, s, U, zeroed, used);
+  }
+  hipLaunchKernelGGL(k_cmax_norm, dim3(nblk_((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, S, newp, sem, plane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Camera path.  image_to_map_correspondence_kernel (reference EM/kernels/custom_image_kernels.py:
 // 9-157): every known cell is projected into the image (P = K [R|t], optional radtan distortion) and a Bresenham walk
 // towards the camera cell rejects it when terrain in between rises above the line of sight.  Per cell, race free.
 // exponential_/color_correspondences_to_map_kernel (:195-271) then sample the image per cell.
 // ---------------------------------------------------------------------------------------------------------
-struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; };
+struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; double tol; };      // tol = tolerance_z_collision (:9; 0.10 in the reference's call)
 
 __device__ __forceinline__ float l2_dist(int x0, int y0, int x1, int y1) { float dx = (float)(x0 - x1), dy = (float)(y0 - y1); return sqrtf(dx * dx + dy * dy); }
 
@@ -302,7 +399,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_image_corr(KP P, CamArgs A, Cells 
         if (hv.z != 0.f) {
           float dis = l2_dist(x0c, y0c, x0, y0);
           float rayheight = z0 + (dis / total_dis * delta_z);
-          if ((double)hv.x - 0.10 > (double)rayheight) { ok = false; break; }
+          if ((double)hv.x - A.tol > (double)rayheight) { ok = false; break; }
         }
       }
       const int e2 = 2 * error;
@@ -324,6 +421,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_image_fuse(KP P, int kind, float* 
   const int x0 = (int)(i / P.C), y0 = (int)(i - (long)x0 * P.C);
   const long pc = (long)phys_row(P, x0) * P.C + phys_col(P, y0);           // the layer is stored with the map's circular origin
   if (kind == 0) sem[pc] = (float)((double)sem[pc] * (1 - alpha) + alpha * (double)image[idx]);
+  else if (kind == 2) sem[pc] = image[idx];                                 // average_correspondences_to_map_kernel (:160-192): the sample replaces the value
   else {
     const int ig = (int)(iw * ih + (float)idx), ib = (int)(iw * ih * 2 + (float)idx);
     const unsigned int r = (unsigned int)image[idx], g = (unsigned int)image[ig], b = (unsigned int)image[ib];

@@ -27,7 +27,7 @@ class FusionManager(object):
 
     def register_plugin(self, plugin):
         """``plugin`` = module name under ``elevation_mapping_cupy_amd.fusion`` (e.g. ``pointcloud_average``).
-        The one reference fusion without a device implementation (pointcloud_class_max) is reported and skipped."""
+        A module that does not exist here is reported when a channel asks for it, and skipped."""
         try:
             m = importlib.import_module("." + plugin, package="elevation_mapping_cupy_amd.fusion")
         except ImportError:

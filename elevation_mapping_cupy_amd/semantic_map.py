@@ -108,6 +108,9 @@ class SemanticMap:
             if plug is None:
                 continue
             pcl_ids, layer_ids = self.get_indices_fusion(process_channels, fusion, self.layer_specs_points)
+            if plug.kind == "class_max":      # a frame of its own on the device (per-layer maxima over exact class sums)
+                plug.fuse(emap, pcl_ids, layer_ids, R, t)
+                continue
             for ch, ly in zip(pcl_ids, layer_ids):
                 if plug.kind == "color":
                     if nc >= 4:
@@ -176,6 +179,10 @@ class SemanticMap:
         idx = self.layer_names.index(name_or_idx) if isinstance(name_or_idx, str) else int(name_or_idx)
         a = np.ascontiguousarray(array, np.float32)
         self._emap._chk(self._emap._lib.emap_semantic_set_alpha(self._emap._ctx, idx, f32p(a)))
+
+    def get_id_max(self, name_or_idx):
+        """class-id plane of a ``class_max`` layer (the reference's ``elements_to_shift["id_max"][layer]``, uint32; moves with the map)"""
+        return self.get_alpha(name_or_idx).view(np.uint32)
 
     def get_index(self, name):
         return self.layer_names.index(name) if name in self.layer_names else -1

@@ -162,6 +162,15 @@ int emap_semantic_get_layer(emap_ctx* ctx, int32_t layer, float* host_out);
 int emap_semantic_set_layer(emap_ctx* ctx, int32_t layer, const float* host_in);
 int emap_semantic_clear(emap_ctx* ctx);
 
+/* pointcloud_class_max (EM/fusion/pointcloud_class_max.py:80-126) on the bound cloud: channels chan[k] carry (half probability |
+ * class id << 16) packed in a float, layer[k] the k-th of the fusion's layers (n_ch <= 8).  Per frame: sorted union of the ids in the
+ * cloud and in the map's id planes; per (class, cell) the EXACT sum of the probabilities of the valid, inside points (64-bit integers
+ * in units of 2^-24); per layer in turn the per-cell maximum over the classes and its id, the planes of all winning classes set to
+ * zero before the next layer; the layers of a cell normalised by their sum.  The id planes are the layers' persistent planes
+ * (emap_semantic_get_alpha returns them as uint32 bit patterns; they move with the map).  prev_unique / unique_out: the fusion's
+ * unique_id array of the previous / this frame (n_prev = 0 before the first frame). */
+int emap_semantic_class_max(emap_ctx* ctx, const float R[9], const float t[3], int32_t n_ch, const int32_t* chan, const int32_t* layer,
+                            const uint32_t* prev_unique, int32_t n_prev, uint32_t* unique_out, int32_t unique_cap, int32_t* n_unique_out);
 /* ---- the reference's semantic KERNEL FACTORIES on caller arrays (EM/kernels/custom_semantic_kernels.py) -------------------
  * Raw-array elementwise kernels over `size` elements; the points carry (cell index, valid, inside) in their first three columns
  * (what add_points_kernel leaves there, custom_kernels.py:260-262).  Host arrays in and out, for the staged / test surface
@@ -213,13 +222,19 @@ int emap_inpaint_telea_u8(const uint8_t* image, const uint8_t* mask, int32_t row
 /* ---- camera path: ElevationMap.input_image (EM/elevation_mapping.py:468-562).
  * emap_image_correspondence = image_to_map_correspondence_kernel (EM/kernels/custom_image_kernels.py:9-157): x1, y1 = camera
  * cell (uint32 valued), z1 = camera height above the map centre, P = K [R|t] row major, D = 5 radtan coefficients (all 0 =
- * none).  emap_image_fuse = exponential_ (kind 0, alpha 0.7 in the reference) / color_ (kind 1, planes 0..2 = r,g,b)
- * correspondences_to_map_kernel (:195-271) applied to semantic layer `layer` with a host image (n_planes, H, W) float32. */
+ * none).  emap_image_fuse = exponential_ (kind 0, alpha 0.7 in the reference) / color_ (kind 1, planes 0..2 = r,g,b) / average_
+ * (kind 2: the sample replaces the value, :160-192) correspondences_to_map_kernel applied to semantic layer `layer` with a host image
+ * (n_planes, H, W) float32.  emap_image_set_tolerance = the factory parameter tolerance_z_collision of the occlusion walk (:9; the
+ * reference's only call passes 0.10, the default).  emap_image_fuse_arrays = the same three kernels on caller arrays (one
+ * (cell_n, cell_n) semantic plane in, one out, uv (2, cell_n, cell_n), valid (cell_n, cell_n) bytes): what the kernel factories bind. */
 int emap_image_correspondence(emap_ctx* ctx, float x1, float y1, float z1, const float P[12], const float K[9], const float D[5],
                               float image_height, float image_width, const float center[3]);
 int emap_image_get_correspondence(emap_ctx* ctx, float* uv_host /* (2, cell_n, cell_n) */, uint8_t* valid_host);
 int emap_image_fuse(emap_ctx* ctx, int32_t kind, int32_t layer, const float* host_image, int32_t n_planes, int32_t height,
                     int32_t width, double alpha);
+int emap_image_set_tolerance(emap_ctx* ctx, double tolerance_z_collision);
+int emap_image_fuse_arrays(emap_ctx* ctx, int32_t kind, const float* sem_plane, const float* host_image, int32_t n_planes, int32_t height,
+                           int32_t width, const float* uv, const uint8_t* valid, double alpha, float* out_plane);
 
 /* ---- safety-polygon service: polygon_mask_kernel (EM/kernels/custom_kernels.py:509-651) as launched by
  * ElevationMap.get_polygon_traversability (EM/elevation_mapping.py:837-889).  `polygon_xy` = (n, 2) float32 world

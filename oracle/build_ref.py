@@ -116,6 +116,7 @@ def _instantiate(p):
                                       {"x1", "y1", "z1", "image_height", "image_width"})
         ks["image_exponential"] = (ik.exponential_correspondences_to_map_kernel(C, C, 0.7), f32, {"map_idx", "image_height", "image_width"})
         ks["image_color"] = (ik.color_correspondences_to_map_kernel(C, C), f32, {"map_idx", "image_height", "image_width"})
+        ks["image_average"] = (ik.average_correspondences_to_map_kernel(C, C), f32, {"map_idx", "image_height", "image_width"})   # defined, never launched by the reference
     if p.get("bayes_kernels"):
         # point fusions that keep their kernels inside the plugin module (reference fusion/pointcloud_class_bayesian.py:12-53,
         # fusion/pointcloud_bayesian_inference.py:12-83)

@@ -645,6 +645,7 @@ void eo_image_fuse(const eo_params* P, int kind, float* sem, const float* image,
     if (!valid[i]) continue;
     int idx = (int)((float)(int)uv[i] + (float)(int)uv[L + i] * image_width);
     if (kind == 0) sem[i] = (float)((double)sem[i] * (1 - alpha) + alpha * (double)image[idx]);
+    else if (kind == 2) sem[i] = image[idx];      /* average_correspondences_to_map_kernel (custom_image_kernels.py:160-192): despite its name, a plain replace */
     else {
       int ig = (int)(image_width * image_height + (float)idx), ib = (int)(image_width * image_height * 2 + (float)idx);
       unsigned int r = (unsigned int)image[idx], g = (unsigned int)image[ig], b = (unsigned int)image[ib];

@@ -359,9 +359,9 @@ def image_correspondence(P, emap, x1, y1, z1, Pm, K, D, image_height, image_widt
 
 
 def image_fuse(P, kind, sem_plane, image, uv, valid, image_height, image_width, alpha=0.7):
-    """in-place update of one semantic plane; kind 'exponential' (image (H,W)) or 'color' (image (3,H,W))"""
+    """in-place update of one semantic plane; kind 'exponential' / 'average' (image (H,W)) or 'color' (image (3,H,W))"""
     img = np.ascontiguousarray(image, np.float32)
-    lib().eo_image_fuse(ct.byref(P), ct.c_int({"exponential": 0, "color": 1}[kind]), _p(sem_plane), _p(img), _p(uv), _p(valid),
+    lib().eo_image_fuse(ct.byref(P), ct.c_int({"exponential": 0, "color": 1, "average": 2}[kind]), _p(sem_plane), _p(img), _p(uv), _p(valid),
                         ct.c_float(image_height), ct.c_float(image_width), ct.c_double(alpha))
 
 

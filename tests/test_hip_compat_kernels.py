@@ -84,3 +84,44 @@ def test_stencil_and_mask_factories(weights):
                                                       np.zeros(4, np.float32), m, size=C * C)
     assert 0 < m.sum() < C * C and set(np.unique(m)) <= {0.0, 1.0}
     assert callable(K.sum_kernel(0.9, 4, 4))            # the semantic factories: tests/test_hip_semantic_factories.py
+
+
+@pytest.mark.parametrize("dist", [False, True])
+def test_image_factories(dist, weights):
+    """EM/kernels/custom_image_kernels.py through the factories: the correspondence kernel (projection, radtan, Bresenham occlusion
+    walk) and the three samplers -- exact against the oracle, which equals the reference's own kernel source
+    (tests/test_oracle_vs_reference_source.py::test_image_correspondence_and_fusions)."""
+    from elevation_mapping_cupy import kernels as K
+    C = 98
+    cfg = dict(eo.YAML, enable_visibility_cleanup=False)
+    om = eo.OracleMap(eo.make_params(cfg, cell_n=C, weights=weights))
+    R0, t0 = fx.POSES["identity"]
+    p = fx.cloud(C, 20000, 0); p[:, 2] += 0.3 * np.sin(p[:, 0] * 2.0)           # relief => occlusions
+    om.update_map_with_kernel(p, R0, t0)
+    Kc, D, R, t, H, W = fx.camera_case(C, 1, dist)
+    center = np.array([0.1, -0.2, 0.05], np.float32)
+    Pm, x1, y1, z1 = fx.camera_inputs(center, C, 0.04, Kc, R, t)
+    uv_o, va_o = eo.image_correspondence(om.P, om.elevation_map, x1, y1, z1, Pm.ravel(), Kc.ravel(), D, H, W, center)
+    uv = np.zeros((2, C, C), np.float32); va = np.zeros((C, C), np.bool_)
+    K.image_to_map_correspondence_kernel(0.04, C, C, 0.10)(om.elevation_map.copy(), x1, y1, z1, Pm.ravel().copy(), Kc.ravel().copy(), D.copy(),
+                                                             H, W, center, uv, va, size=C * C)
+    assert va.sum() > 50 and np.array_equal(va, va_o.astype(bool)) and np.array_equal(uv, uv_o)
+    # a tighter collision tolerance rejects more cells (the factory parameter reaches the kernel)
+    va2 = np.zeros((C, C), np.bool_)
+    K.image_to_map_correspondence_kernel(0.04, C, C, -0.05)(om.elevation_map.copy(), x1, y1, z1, Pm.ravel().copy(), Kc.ravel().copy(), D.copy(),
+                                                              H, W, center, np.zeros_like(uv), va2, size=C * C)
+    assert va2.sum() < va.sum() and not (va2 & ~va).any()
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0, 1, (3, H, W)).astype(np.float32)
+    rgb = rng.integers(0, 256, (3, H, W)).astype(np.float32)
+    sem = rng.uniform(0, 1, (3, C, C)).astype(np.float32)
+    new = np.zeros_like(sem)
+    K.exponential_correspondences_to_map_kernel(C, C, 0.7)(sem, 0, img[1], uv, va, H, W, new, size=C * C)
+    K.color_correspondences_to_map_kernel(C, C)(sem, 1, rgb, uv, va, H, W, new, size=C * C)
+    K.average_correspondences_to_map_kernel(C, C)(sem, 2, img[2], uv, va, H, W, new, size=C * C)
+    want = sem.copy()
+    eo.image_fuse(om.P, "exponential", want[0], img[1], uv_o, va_o, H, W, 0.7)
+    eo.image_fuse(om.P, "color", want[1], rgb, uv_o, va_o, H, W)
+    eo.image_fuse(om.P, "average", want[2], img[2], uv_o, va_o, H, W)
+    assert np.array_equal(new.view(np.uint32), want.view(np.uint32))
+    assert (new[2] != sem[2]).sum() == va.sum()

@@ -130,6 +130,15 @@ def test_image_correspondence_and_fusions(dist, weights):
     eo.image_fuse(om.P, "exponential", mine[0], img[1], uv, va, H, W, 0.7)
     eo.image_fuse(om.P, "color", mine[1], rgb, uv, va, H, W)
     assert np.array_equal(mine[0], new_r[0]) and np.array_equal(mine[1].view(np.uint32), new_r[1].view(np.uint32))
+    # average_correspondences_to_map_kernel (custom_image_kernels.py:160-192; defined by the reference, launched by none of its fusions)
+    if hasattr(rk.lib, "ref_image_average"):
+        new_a = np.zeros_like(sem)
+        rk.image_fuse("average", sem.copy(), 0, img[2].copy(), uv_r, va_r, H, W, new_a)
+        mine_a = sem[0].copy()
+        eo.image_fuse(om.P, "average", mine_a, img[2], uv, va, H, W)
+        assert np.array_equal(mine_a, new_a[0]) and (mine_a != sem[0]).sum() == va_r.sum()
+    else:
+        pytest.fail("oracle/_ref was built before image_average was added: rebuild (python -m oracle.build_ref)")
 
 
 @pytest.mark.parametrize("center", [(0.0, 0.0), (0.52, -0.28)])
