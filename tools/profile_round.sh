@@ -18,11 +18,4 @@ for wl in cfg2 cfg3; do
   done
 done
 ls -R $O | head -40
-# bench lines of the round (one JSON line each): default (cfg2 + config.cfg3), cfg3, shifted map, robot scale, cfg5 on one GPU
-python $R/bench.py > $O/bench_cfg2.json 2>> $O/bench_err.log
-python $R/bench.py --workload cfg3 --steps 20 > $O/bench_cfg3.json 2>> $O/bench_err.log
-python $R/bench.py --pre-shift 37 21 --no-cpu-baseline > $O/bench_cfg2_shifted.json 2>> $O/bench_err.log
-python $R/bench.py --cell-n 202 --points 50000 --no-cpu-baseline --no-cfg3 > $O/bench_cfg1.json 2>> $O/bench_err.log
-timeout 600 python $R/bench.py --workload cfg4 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_cfg4.json 2>> $O/bench_err.log
-timeout 600 python $R/bench.py --workload cfg5 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_cfg5.json 2>> $O/bench_err.log
-tail -3 $O/bench_err.log
+bash $R/tools/bench_lines.sh $TAG
