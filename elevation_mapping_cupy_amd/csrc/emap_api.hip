@@ -1153,6 +1153,8 @@ int emap_semantic_finalize(emap_ctx* ctx, int32_t op, void* newmap_inout, int32_
 int emap_semantic_class_max(emap_ctx* ctx, const float R[9], const float t[3], int32_t n_ch, const int32_t* chan, const int32_t* layer,
                             const uint32_t* prev_unique, int32_t n_prev, uint32_t* unique_out, int32_t unique_cap, int32_t* n_unique_out) {
   CKARG(ctx && R && t && chan && layer && unique_out && n_unique_out && n_ch >= 1 && n_ch <= 8 && n_prev >= 0 && (n_prev == 0 || prev_unique), "bad argument");
+  // the id set and the planes zeroed between two layers are properties of the WHOLE map: a row strip would take them from its own rows
+  CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "class_max: single-strip contexts only");
   NEED_POINTS();
   for (int k = 0; k < n_ch; ++k)
     CKARG(layer[k] >= 0 && layer[k] < ctx->sem_layers && chan[k] >= 3 && chan[k] < ctx->stride, "bad channel/layer index");
