@@ -77,37 +77,25 @@ def _fake_rccl():
     return out
 
 
-@pytest.mark.parametrize("moves", [False, True])
-@pytest.mark.parametrize("world,cfg_name,C,N,scatter", [(2, "yaml", 130, 40000, "auto"), (3, "yaml_norays", 202, 60000, "auto"), (4, "default", 202, 40000, "auto"),
-                                                        # the tile-binned scatter on strips: without a visibility pass the point passes run the cheap
-                                                        # ownership test + lane compaction (k_bin_hist / k_bin_scatter<.., STRIP>), with one they keep the
-                                                        # ray-only bin; 8 strips of the 1024^2 map with a cloud large enough for the automatic choice
-                                                        (3, "yaml_norays", 202, 60000, "binned"), (4, "yaml", 130, 40000, "binned"),
-                                                        (8, "yaml_norays", 1024, 300000, "auto")])
-def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, C, N, scatter, moves, weights):
-    """emap_comm_init + emap_update_sharded with SEVERAL ranks: the library's own orchestration (all-reduce between count and fuse,
-    in-place halo send / recv on the second stream, interior / boundary stencil split) driven through a stand-in for the nine RCCL
-    entry points whose ranks are threads of this process (RCCL refuses two ranks on one GPU).  Every strip must equal the rows of
-    the single-context map bit for bit."""
+def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_fp16", check_gather=None):
+    """frames = [(cloud, R, t, position_noise, orientation_noise, n_update_time, move_to vector or None), ...]: one single-context
+    map and `world` strip contexts (threads, in-process RCCL stand-in) run the same frames; every strip must equal the rows of the
+    single-context map bit for bit.  Returns nothing; asserts."""
     import ctypes as ct
     import threading
     import torch
     from elevation_mapping_cupy_amd.configs import parameter_from
     from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
     from elevation_mapping_cupy_amd.sharded import HipStripEngine, NativeComm, ShardedElevationMap
-    from oracle import emap_oracle as eo
     lib_path = _fake_rccl()
-    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML if cfg_name.startswith("yaml") else {})
-    if cfg_name.endswith("norays"):
-        cfg["enable_visibility_cleanup"] = False
-    R, t = fx.POSES["rotated"]
-    clouds = [fx.cloud(C, N, f, dz=dz) for f, dz in enumerate((0.0, -0.02, -0.1))]
-    MV = [(0.13, -0.3, 0.05), (-0.10, 0.17, -0.02), None] if moves else [None] * 3      # move_to between the frames: ring halo, normal rows (after a move a strip's view of the un-shifted normals has holes until the next frame)
-    full = ElevationMap(parameter_from(cfg, C, "reference_fp16", weights))
+    full = ElevationMap(parameter_from(cfg, C, mode, weights))
     full.set_scatter_mode(scatter)
-    for p, mv in zip(clouds, MV):
-        full.update_map_with_kernel(p, [], R, (t + full.center).astype(np.float32), 1.0, 1.0)
-        for _ in range(6):
+    t_rel = []                                                    # the map-centre relative translation the single context computes (float32: t_world - center)
+    for p, R, t, pn, on, nt, mv in frames:
+        tw = (t + full.center).astype(np.float32)
+        t_rel.append(tw - full.center)
+        full.update_map_with_kernel(p, [], R, tw, pn, on)
+        for _ in range(nt):
             full.update_time()
         if mv is not None:
             full.move_to(np.array(mv, np.float64), np.eye(3))
@@ -120,22 +108,22 @@ def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, 
 
     def run(rank):
         try:
-            eng = HipStripEngine(parameter_from(cfg, C, "reference_fp16", weights), rank, world, 0, dev)
+            eng = HipStripEngine(parameter_from(cfg, C, mode, weights), rank, world, 0, dev)
             eng.map.set_scatter_mode(scatter)
             comm = NativeComm(eng, rank=rank, world=world, bootstrap=False, uid=bytes(uid), rccl_path=lib_path)
             comm.selftest()
             assert comm.rccl_ranks() == world
             sm = ShardedElevationMap(eng, comm, cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
-            for p, mv in zip(clouds, MV):
+            for (p, R, _t, pn, on, nt, mv), t in zip(frames, t_rel):
                 eng.bind_points(p)
-                sm.update(R, t, 1.0, 1.0)                        # (map-centre relative t: the sensor rides with the centre)
-                for _ in range(6):
+                sm.update(R, t, pn, on)                          # (map-centre relative t: the sensor rides with the centre)
+                for _ in range(nt):
                     eng.update_time()
                 if mv is not None:
                     sm.move_to(np.array(mv, np.float64), np.eye(3))
             eng.sync()
-            full = (sm.gather("elevation"), sm.gather("normal_z")) if scatter == "binned" else None      # collective read-back of whole planes
-            out[rank] = (eng.map.logical_row_begin, eng.map.rows, eng.map.elevation_map, eng.map.normal_map, eng.map.get_additive_mean_error(), full)
+            gathered = (sm.gather("elevation"), sm.gather("normal_z")) if check_gather else None      # collective read-back of whole planes
+            out[rank] = (eng.map.logical_row_begin, eng.map.rows, eng.map.elevation_map, eng.map.normal_map, eng.map.get_additive_mean_error(), gathered)
             eng.lib.emap_comm_destroy(eng.ctx)
         except Exception as e:  # pragma: no cover
             errs.append(e)
@@ -145,12 +133,63 @@ def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, 
     [x.join(timeout=120) for x in th]
     assert not any(x.is_alive() for x in th), "a rank is stuck in the exchange"
     assert not errs, errs
-    for b, rows, m, nm, add, full in out:
-        if full is not None and not moves:                        # (after a move a strip's un-shifted normals have holes: see above)
-            assert np.array_equal(full[0], want[0]) and np.array_equal(full[1], want_n[2]), "gathered planes differ"
-        elif full is not None:
-            assert np.array_equal(full[0], want[0]), "gathered elevation differs"
+    for b, rows, m, nm, add, gathered in out:
+        if gathered is not None and check_gather == "all":        # (after a move a strip's un-shifted normals have holes until the next frame)
+            assert np.array_equal(gathered[0], want[0]) and np.array_equal(gathered[1], want_n[2]), "gathered planes differ"
+        elif gathered is not None:
+            assert np.array_equal(gathered[0], want[0]), "gathered elevation differs"
         idx = (b + np.arange(rows)) % C                           # the strip's view: logical rows b, b + 1, ... of the full map
         assert m.tobytes() == np.take(want, idx, axis=1).tobytes(), "strip whose view starts at logical row %d differs" % b
-        assert nm.tobytes() == np.take(want_n, idx, axis=1).tobytes()
+        assert nm.tobytes() == np.take(want_n, idx, axis=1).tobytes(), "normals of the strip at logical row %d differ" % b
         assert add == want_add
+
+
+@pytest.mark.parametrize("moves", [False, True])
+@pytest.mark.parametrize("world,cfg_name,C,N,scatter", [(2, "yaml", 130, 40000, "auto"), (3, "yaml_norays", 202, 60000, "auto"), (4, "default", 202, 40000, "auto"),
+                                                        # the tile-binned scatter on strips: without a visibility pass the point passes run the cheap
+                                                        # ownership test + lane compaction (k_bin_hist / k_bin_scatter<.., STRIP>), with one they keep the
+                                                        # ray-only bin; 8 strips of the 1024^2 map with a cloud large enough for the automatic choice
+                                                        (3, "yaml_norays", 202, 60000, "binned"), (4, "yaml", 130, 40000, "binned"),
+                                                        (8, "yaml_norays", 1024, 300000, "auto")])
+def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, C, N, scatter, moves, weights):
+    """emap_comm_init + emap_update_sharded with SEVERAL ranks: the library's own orchestration (all-reduce between count and fuse,
+    in-place halo send / recv on the second stream, interior / boundary stencil split) driven through a stand-in for the nine RCCL
+    entry points whose ranks are threads of this process (RCCL refuses two ranks on one GPU).  Every strip must equal the rows of
+    the single-context map bit for bit."""
+    from oracle import emap_oracle as eo
+    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML if cfg_name.startswith("yaml") else {})
+    if cfg_name.endswith("norays"):
+        cfg["enable_visibility_cleanup"] = False
+    R, t = fx.POSES["rotated"]
+    # move_to between the frames: ring halo, normal rows (after a move a strip's view of the un-shifted normals has holes until the next frame)
+    MV = [(0.13, -0.3, 0.05), (-0.10, 0.17, -0.02), None] if moves else [None] * 3
+    frames = [(fx.cloud(C, N, f, dz=dz), R, t, 1.0, 1.0, 6, mv) for (f, dz), mv in zip(enumerate((0.0, -0.02, -0.1)), MV)]
+    _strips_vs_single(world, cfg, C, frames, scatter, weights, check_gather=None if scatter != "binned" else ("elevation" if moves else "all"))
+
+
+@pytest.mark.parametrize("k", range(10))
+def test_fuzz_strips_bitwise(k, weights):
+    """seeded random strip scenarios (world size, map size, index mode, feature toggles, scatter path, per-frame poses, decay passes,
+    small map moves between frames): strips == single context, bit for bit"""
+    from oracle import emap_oracle as eo
+    rng = np.random.default_rng(9100 + k)
+    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML if rng.random() < 0.6 else {})
+    for key in ("enable_visibility_cleanup", "enable_overlap_clearance", "enable_edge_sharpen", "enable_drift_compensation"):
+        cfg[key] = bool(rng.random() < 0.7)
+    cfg["dilation_size"] = int(rng.integers(1, 4))
+    C = int(rng.choice([130, 157, 202, 257, 300]))
+    world = int(rng.integers(2, 7))
+    mode = "reference_fp16" if rng.random() < 0.6 else "fp32"
+    scatter = ["auto", "binned", "atomic"][int(rng.integers(0, 3))]
+    frames = []
+    for f in range(3):
+        a = rng.uniform(-0.4, 0.4, 3)
+        R = fx.rot(*a)
+        t = np.array([rng.uniform(-0.6, 0.6), rng.uniform(-0.6, 0.6), rng.uniform(0.7, 1.3)], np.float32)
+        p = fx.cloud(C, int(rng.integers(5000, 60000)), 50 * k + f, dz=float(rng.uniform(-0.2, 0.05)))
+        if rng.random() < 0.5:
+            p[::211, int(rng.integers(0, 3))] = np.nan
+        noise = 1.0 if rng.random() < 0.6 else 0.0
+        mv = (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.3, 0.3)), 0.0) if (f < 2 and rng.random() < 0.5) else None     # <= 7 rows: the halo ring hands the seam rows round
+        frames.append((p, R, t, noise, noise, int(rng.integers(0, 9)), mv))
+    _strips_vs_single(world, cfg, C, frames, scatter, weights, mode=mode)
