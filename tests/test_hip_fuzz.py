@@ -82,3 +82,69 @@ def test_fuzz_frames_bitwise(k, weights):
             hip.move(v); orc.move(v)
             assert np.array_equal(hip.center, orc.center), what
         assert_planes_equal(hip.elevation_map, orc.elevation_map, what=what + " after decay / move")
+
+
+@pytest.mark.parametrize("k", range(16))
+def test_fuzz_semantic_channels(k, weights):
+    """random channel layouts of a multi-modal cloud (1 .. 7 extra columns; average / class_average / at most one colour channel in
+    any order, so the tile kernel's group loop, its one-load gather of adjacent columns and the colour channel riding along are all
+    hit), both scatter paths, two frames: averaged layers within 1e-6, the packed colour layer exact."""
+    rng = np.random.default_rng(8200 + k)
+    C = int(rng.choice([66, 98, 130, 202]))
+    K = int(rng.integers(1, 8))
+    kinds = [str(rng.choice(["average", "class_average"])) for _ in range(K)]
+    if rng.random() < 0.7:
+        kinds[int(rng.integers(0, K))] = "color"
+    names = ["ch%d" % j for j in range(K)]
+    mode = "reference_fp16" if rng.random() < 0.6 else "fp32"
+    hip, orc = make_pair(dict(eo.YAML, enable_visibility_cleanup=bool(rng.random() < 0.5)), C, mode, weights)
+    hip.param.pointcloud_channel_fusions = {n: kd for n, kd in zip(names, kinds)}
+    hip.set_scatter_mode("binned" if rng.random() < 0.6 else "atomic")
+    R, t = _pose(rng)
+    groups = {kd: [(3 + j, j) for j in range(K) if kinds[j] == kd] for kd in ("average", "class_average", "color")}
+    for f in range(2):
+        N = int(rng.integers(4000, 50000))
+        p = fx.cloud(C, N, 300 * k + f, extra=K)
+        m = min(p[::3].shape[0], p[1::3].shape[0])
+        p[::3][:m, :2] = p[1::3][:m, :2]
+        for j in range(K):
+            if kinds[j] == "color":
+                p[:, 3 + j] = rng.integers(0, 1 << 24, N, dtype=np.uint32).view(np.float32)
+        hip.input_pointcloud(p, ["x", "y", "z"] + names, R, t.copy(), 0.0, 0.0)
+        orc.update_map_with_kernel(p, R, t, 0.0, 0.0)
+        orc.semantic_update(p, R, t, average=groups["average"], class_average=groups["class_average"], color=groups["color"], alpha=0.5, n_layers=K)
+        hip.update_time(); orc.update_time()
+        sm = hip.semantic_map.semantic_map
+        what = "scenario %d (C=%d, kinds=%s, %s), frame %d" % (k, C, kinds, mode, f)
+        assert hip.semantic_map.layer_names == names
+        for j in range(K):
+            if kinds[j] == "color":
+                assert np.array_equal(sm[j].view(np.uint32), orc.semantic_map[j].view(np.uint32)), what + ": colour layer %d" % j
+            else:
+                assert np.allclose(sm[j], orc.semantic_map[j], atol=1e-6, rtol=1e-5), what + ": layer %d" % j
+        assert_planes_equal(hip.elevation_map, orc.elevation_map, what=what)
+
+
+@pytest.mark.parametrize("scatter", ["atomic", "binned"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_edge_cloud_sizes(scatter, dtype, weights):
+    """clouds of 0, 1, 63 .. 4097 points, all-NaN and all-outside clouds, growing and shrinking between frames (buffer regrowth of
+    the upload path and of the sort), float32 and float64 host clouds through input_pointcloud: every frame bit for bit"""
+    C = 130
+    hip, orc = make_pair(dict(eo.YAML), C, "reference_fp16", weights)
+    hip.set_scatter_mode(scatter)
+    R, t = fx.POSES["rotated"]
+    sizes = [0, 1, 63, 64, 65, 4095, 4096, 4097, 20000, 2, 0, 9000]
+    for f, N in enumerate(sizes):
+        p = fx.cloud(C, N, 400 + f, dz=-0.01 * f)
+        if f == 5:
+            p[:] = np.nan                                               # nothing survives the NaN filter (elevation_mapping.py:458)
+        if f == 7:
+            p[:, :2] *= 10.0                                            # every point outside the map
+        hip.input_pointcloud(p.astype(dtype), ["x", "y", "z"], R, t.copy(), 1.0, 1.0)
+        pv = p[~np.isnan(p).any(axis=1)]                                # the oracle's frame takes the filtered cloud, like update_map_with_kernel
+        orc.update_map_with_kernel(pv, R, t, 1.0, 1.0)
+        hip.update_time(); orc.update_time()
+        what = "%s %s frame %d (N=%d)" % (scatter, np.dtype(dtype).name, f, N)
+        assert_planes_equal(hip.elevation_map, orc.elevation_map, what=what)
+        assert_planes_equal(hip.normal_map, orc.normal_map, names=["nx", "ny", "nz"], what=what)
