@@ -10,9 +10,10 @@ from oracle import emap_oracle as eo
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("dist", [False, True])
-def test_input_image_matches_oracle(dist, weights):
-    C = 98
+def test_input_image_matches_oracle(dist, seed, weights):
+    C = [98, 130, 66][seed % 3]
     cfg = dict(eo.YAML, enable_visibility_cleanup=False)
     hip, orc = make_pair(cfg, C, "reference_fp16", weights)
     hip.param.image_channel_fusions = {"rgb": "color", "default": "exponential"}
@@ -22,7 +23,7 @@ def test_input_image_matches_oracle(dist, weights):
     orc.update_map_with_kernel(p, R0, t0)
     hip.move_to(np.array([0.12, -0.2, 0.05], np.float32), np.eye(3))          # non-trivial map centre
     orc.elevation_map = hip.elevation_map                                    # same shifted state
-    K, D, R, t, H, W = fx.camera_case(C, 1, dist)
+    K, D, R, t, H, W = fx.camera_case(C, seed, dist)
     rng = np.random.default_rng(5)
     feat = rng.uniform(0, 1, (H, W)).astype(np.float32)
     rgb = rng.integers(0, 256, (3, H, W)).astype(np.float32)
