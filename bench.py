@@ -57,15 +57,18 @@ def rocprof_kernel_us(workload, kernel_prefix):
     stamp = next((ln.split(":", 1)[1].strip() for ln in lines if ln.startswith("# source_stamp:")), None)
     if stamp != source_stamp():
         return None, "profiles/%s: taken with other kernel sources (stamp %s, now %s)" % (os.path.basename(f), stamp, source_stamp())
+    best, best_total = (None, None), -1.0
     for ln in lines:
         name = ln.replace("void ", "", 1).lstrip()
         if name.startswith(kernel_prefix):
             tok = ln[86:].split()
             try:     # columns: calls, avg_us, median_us, ...: the MEDIAN (the first launches after clear() / the warm-up's time ticks are not steady state)
-                return float(tok[2]), "profiles/%s (median of %s launches; average %s us)" % (os.path.basename(f), tok[0], tok[1])
+                calls, avg, med = float(tok[0]), float(tok[1]), float(tok[2])
             except (IndexError, ValueError):
-                pass
-    return None, None
+                continue
+            if calls * avg > best_total:      # several template variants can match (202^2 frames, the counting variant of k_rays): the workload's own has the most time
+                best_total, best = calls * avg, (med, "profiles/%s (median of %s launches; average %s us)" % (os.path.basename(f), tok[0], tok[1]))
+    return best
 
 
 def parse(argv=None):
@@ -257,9 +260,11 @@ def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step
         kern = STAGE_KERNEL[dom]
         pj = json.load(open(pmc_file))
         if pj.get("source_stamp") == source_stamp():
-            for name, rec in pj["kernels"].items():
-                if name.startswith(kern):
-                    traffic, traffic_src = rec["hbm_bytes"], "profiles/%s (%s)" % (os.path.basename(pmc_file), name)
+            most = -1.0
+            for name, rec in pj["kernels"].items():       # several template variants can match (the default run also times the 202^2 map): the workload's own moved the most bytes in total
+                if name.startswith(kern) and rec["hbm_bytes"] * float(rec.get("launches", 1)) > most:
+                    most = rec["hbm_bytes"] * float(rec.get("launches", 1))
+                    traffic, traffic_src = rec["hbm_bytes"], "profiles/%s (%s, median of %d launches)" % (os.path.basename(pmc_file), name, rec.get("launches", 0))
     # the kernel's median duration in the committed rocprofv3 summary of this command (only when taken with THESE kernel sources):
     # `frac` is quoted from it so that the line and profiles/ agree; the live event spacing stays beside it
     kus, ksrc = rocprof_kernel_us(workload, STAGE_KERNEL[dom]) if pmc_ok else (None, None)

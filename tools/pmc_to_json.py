@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """rocprofv3 PMC databases (separate FETCH_SIZE / WRITE_SIZE passes, as MI355X_MICROARCH.md prescribes) -> per-kernel
-HBM traffic per launch.  Correction (gfx950, calibrated on k_var_time which reads and writes exactly 32 B/cell of a
+HBM traffic per launch (median over the launches).  Correction (gfx950, calibrated on k_var_time which reads and writes exactly 32 B/cell of a
 1024^2 map: FETCH_SIZE 16 394 KB vs 32 768 KB read, WRITE_SIZE 32 768 KB vs 32 768 KB written):
 bytes_read = 2 * FETCH_SIZE KB * 1024, bytes_written = WRITE_SIZE KB * 1024.
 usage: pmc_to_json.py <fetch.db> <write.db> [source stamp] > profiles/rNN_pmc_<workload>.json"""
@@ -11,9 +11,19 @@ import sys
 
 
 def per_kernel(db, counter):
+    """kernel -> (MEDIAN over its dispatches, number of dispatches): one row per dispatch in the database; the median is the steady
+    state (the first frames after clear() -- bench.py's cold-start block -- move several times the bytes of a warm frame)"""
     cur = sqlite3.connect(db).cursor()
-    rows = cur.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name=? group by kernel_name", (counter,)).fetchall()
-    return {re.sub(r"\(.*", "", r[0]).replace("void ", "").strip(): (r[1], r[2]) for r in rows}
+    rows = cur.execute("select kernel_name, value from counters_collection where counter_name=? order by kernel_name, dispatch_id", (counter,)).fetchall()
+    by = {}
+    for name, v in rows:
+        by.setdefault(re.sub(r"\(.*", "", name).replace("void ", "").strip(), []).append(v)
+    out = {}
+    for k, vals in by.items():
+        vals.sort()
+        n = len(vals)
+        out[k] = ((vals[n // 2] if n % 2 else 0.5 * (vals[n // 2 - 1] + vals[n // 2])), n)
+    return out
 
 
 def main(fetch_db, write_db, stamp=None):
