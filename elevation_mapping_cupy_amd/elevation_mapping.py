@@ -367,6 +367,18 @@ class ElevationMap:
     def update_time(self):
         self._chk(self._lib.emap_update_time(self._ctx))
 
+    def update_normal(self, dilated_map):
+        """normal map from a given (dilated) height plane and the current ``is_valid`` (reference :564-577: ``normal_map *= 0`` + the
+        normal filter kernel).  Inside a frame the stencil launch does this on the device planes; this public form takes a host plane:
+        it becomes the stencil stage's input, the stage runs, and the two planes the reference's method does not touch (the
+        traversability it would also rewrite, the stage's input plane) are put back."""
+        with self.map_lock:
+            keep_trav, keep_in = self.get_layer_raw("traversability"), self.get_layer_raw("traversability_input")
+            self.set_layer_raw("traversability_input", np.asarray(dilated_map, np.float32))
+            self.stage("traversability_normals")
+            self.set_layer_raw("traversability", keep_trav)
+            self.set_layer_raw("traversability_input", keep_in)
+
     def update_upper_bound_with_valid_elevation(self):
         m = self.elevation_map
         mask = m[2] > 0.5

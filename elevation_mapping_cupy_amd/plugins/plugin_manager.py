@@ -122,7 +122,10 @@ class PluginManager(object):
             args += [semantic_map, semantic_params, rotation]
         else:
             args += [semantic_map, semantic_params, rotation, elements_to_shift]
-        self.layers[idx] = np.asarray(plugin(*args), np.float32)
+        out = plugin(*args)
+        if out is None:                    # (semantic_traversability without its input layer: the reference prints and returns nothing)
+            return
+        self.layers[idx] = np.asarray(out, np.float32)
 
     def get_map_with_name(self, name: str):
         idx = self.get_layer_index_with_name(name)
