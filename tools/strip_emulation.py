@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"])
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--gs", type=int, nargs="*", default=[1, 2, 4, 8])
+    ap.add_argument("--rays", action="store_true", help="visibility clean-up + overlap clearance on (cfg3's parameters); strips of equal RAY work "
+                    "(sharded.ray_balanced_weights: thin around the sensor) unless --equal-strips")
+    ap.add_argument("--equal-strips", action="store_true")
     a = ap.parse_args()
     import bench
     from elevation_mapping_cupy_amd import _lib, sharded
@@ -39,7 +42,7 @@ def main():
     C, N = ba.cell_n, ba.points
     multimodal = a.workload == "cfg5"
     mode = "fp32" if C > 2049 else "reference_fp16"
-    cfg = bench.workload_cfg("cfg2")                       # rays / overlap off: the strip-friendly stages (rays: see DESIGN.md section 7)
+    cfg = bench.workload_cfg("cfg3" if a.rays else "cfg2")  # default: rays / overlap off, the strip-friendly stages (rays: see DESIGN.md section 7)
     weights = bench.load_weights()
     hip = bench.Hip(); hip.set_device(0)
     clouds_host = bench.host_clouds(ba, C, N, multimodal)
@@ -56,7 +59,10 @@ def main():
         if multimodal:
             par.pointcloud_channel_fusions = {"rgb": "color", "default": "average"}
         halo = sharded.halo_rows_needed(par.dilation_size, G)
-        r0, r1 = sharded.strip_rows(C, G, rank, None)
+        row_w = None
+        if a.rays and G > 1 and not a.equal_strips:
+            row_w = sharded.ray_balanced_weights(C, float(cfg["resolution"]), float(cfg["max_ray_length"]), halo, G)
+        r0, r1 = sharded.strip_rows(C, G, rank, row_w)
         em = ElevationMap(par, strip=(r0, r1 - r0, halo) if G > 1 else None)
         lib, ctx = em._lib, em._ctx
         if multimodal:
@@ -93,7 +99,9 @@ def main():
         net = {k: round(max(v - ev, 0.0), 5) for k, v in stage_ms.items()}
         return ms.value / a.steps, net, [int(r0), int(r1)]
 
-    out = {"workload": bench.workload_text(ba, C, N, multimodal).replace("cfg5", a.workload).replace("cfg2", a.workload), "index_mode": mode, "steps": a.steps,
+    out = {"workload": bench.workload_text(ba, C, N, multimodal).replace("cfg5", a.workload).replace("cfg2", a.workload) + (
+               "; WITH visibility clean-up + overlap clearance, strips of %s" % ("equal height" if a.equal_strips else "equal ray work") if a.rays else ""),
+           "index_mode": mode, "steps": a.steps,
            "method": "every strip context of the G-way split run on ONE MI355X one after another (replicated device-resident cloud); "
                      "frame_ms = device time of K back-to-back emap_update frames / K; stage_ms_net = hipEvent spacing of a stage minus the "
                      "spacing of an empty event pair", "splits": {}}
