@@ -32,7 +32,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r03"  # tag of the committed rocprofv3 summaries under profiles/ that this round's numbers refer to
+PROFILE_ROUND = "r04"  # tag of the committed rocprofv3 summaries under profiles/ that this round's numbers refer to
 
 
 def source_stamp():
@@ -85,6 +85,7 @@ def parse(argv=None):
     ap.add_argument("--mode", default="reference_fp16", choices=["reference_fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the config.cfg3 and config.cfg1 sub-measurements of the default cfg2 line")
+    ap.add_argument("--no-large", action="store_true", help="skip the config.cfg4 / config.cfg5 sub-measurements (4096^2 and 8192^2 on one GPU) of the default line")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
     ap.add_argument("--scatter", default="auto", choices=["auto", "atomic", "binned"])
     ap.add_argument("--sort-clouds", default="none", choices=["none", "tile", "angle"],
@@ -127,6 +128,9 @@ class Hip:
         self.ck(self.l.hipMalloc(ct.byref(p), ct.c_size_t(nbytes)), "hipMalloc")
         return p
 
+    def free(self, p):
+        self.l.hipFree(p)
+
     def h2d(self, dst, arr):
         self.ck(self.l.hipMemcpy(dst, ct.c_void_p(arr.ctypes.data), ct.c_size_t(arr.nbytes), 1), "hipMemcpy")
 
@@ -147,14 +151,17 @@ class Hip:
         return best
 
 
-# Algorithmic bytes of each timed stage = the bytes that stage must move once (N points, L cells).  "post" follows
+# Algorithmic bytes of each timed stage = the bytes that stage must move once WHATEVER the data (N points, L cells) -- the kernels
+# as they are since round 3: the histogram pass only reads the cloud, the scatter pass reads it again and writes the 16-byte sorted
+# records, the tile kernels read the records and the 16-byte hot half cells (the fuse kernel writes them back; the cold halves it
+# touches depend on the data -- fused cells, stale cells in front of a ray pass -- and are NOT counted: a lower bound).  "post" follows
 # dilation 12 B/cell (2 planes in, 1 out) + normal filter 20 B/cell + traversability filter 8 B/cell.
 STAGE_BYTES = {
-    "hist": lambda N, L: 12 * N + 16 * N,                    # xyz in, 16-B staging record out
+    "hist": lambda N, L: 12 * N,                             # xyz in (the per-block histogram rows are 4 B x tiles x blocks: < 2 %)
     "scan": lambda N, L: 0,
-    "scatter": lambda N, L: 16 * N + 16 * N,                 # staging record in, sorted record out (a pure permutation)
+    "scatter": lambda N, L: 12 * N + 16 * N,                 # xyz in again (the geometry is recomputed), sorted record out
     "gate": lambda N, L: 16 * N + 16 * L,                    # per-tile error sums: sorted records + (h,v,valid,trav) of every cell, once
-    "fuse": lambda N, L: 16 * N + 64 * L,                    # sorted records; cells read (staged per tile) + written once (fused average)
+    "fuse": lambda N, L: 16 * N + 32 * L,                    # sorted records; hot half cells read (staged per tile) and written once
     "commit": lambda N, L: 40 * L + 64 * L,
     "rays": lambda N, L: 12 * N + 32 * L + 16 * L,           # cloud + map + ray accumulators once (the kernel is issue bound: see visits/s)
     "average": lambda N, L: 40 * L + 16 * L + 64 * L,
@@ -265,15 +272,13 @@ def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step
                 if name.startswith(kern) and rec["hbm_bytes"] * float(rec.get("launches", 1)) > most:
                     most = rec["hbm_bytes"] * float(rec.get("launches", 1))
                     traffic, traffic_src = rec["hbm_bytes"], "profiles/%s (%s, median of %d launches)" % (os.path.basename(pmc_file), name, rec.get("launches", 0))
-    # the kernel's median duration in the committed rocprofv3 summary of this command (only when taken with THESE kernel sources):
-    # `frac` is quoted from it so that the line and profiles/ agree; the live event spacing stays beside it
+    # `frac` is LIVE: the dominant kernel's algorithmic bytes over its event spacing in THIS run.  Beside it, when profiles/ holds a
+    # rocprofv3 summary of this command taken with THESE kernel sources, the same bytes over that summary's median duration
     kus, ksrc = rocprof_kernel_us(workload, STAGE_KERNEL[dom]) if pmc_ok else (None, None)
-    frac_events = achieved / HBM_PEAK_GBS
-    if kus:
-        achieved = dom_bytes / (kus * 1e-6) / 1e9
+    frac_rocprof = round(dom_bytes / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if kus else None
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_source": "kernel_us_rocprof" if kus else "event spacing (kernel_ms)",
-            "kernel_us_rocprof": kus, "kernel_us_rocprof_source": ksrc, "frac_event_spacing": round(frac_events, 4),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_source": "live: hipEvent spacing of the kernel on its stream in this run (kernel_ms)",
+            "frac_rocprof": frac_rocprof, "kernel_us_rocprof": kus, "kernel_us_rocprof_source": ksrc,
             "source_stamp": source_stamp(), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": int(dom_bytes), "kernel_ms": round(dom_ms, 5), "kernel_ms_net": round(max(dom_ms - ev_overhead, 0.0), 5),
             "event_pair_overhead_ms": round(ev_overhead, 5),
@@ -423,15 +428,22 @@ def run_single(a, local_rank=0):
             fr(i)
         em.sync(); hip.sync()
 
-    def timed(em, fr, steps):
-        ms_dev = ct.c_float(0)
-        t0 = time.perf_counter()
-        em._lib.emap_timer_begin(em._ctx)
-        for i in range(steps):
-            fr(i)
-        em._lib.emap_timer_end(em._ctx, ct.byref(ms_dev))
-        em.sync(); hip.sync()
-        return time.perf_counter() - t0, ms_dev.value
+    def timed(em, fr, steps, loops=5):
+        """`loops` timed loops of exactly `steps` frames each, device sync on both sides of every loop; returns the MEDIAN loop
+        (host wall seconds, device ms on the context's stream) and every loop's wall time"""
+        res = []
+        for _ in range(loops):
+            ms_dev = ct.c_float(0)
+            em.sync(); hip.sync()
+            t0 = time.perf_counter()
+            em._lib.emap_timer_begin(em._ctx)
+            for i in range(steps):
+                fr(i)
+            em._lib.emap_timer_end(em._ctx, ct.byref(ms_dev))
+            em.sync(); hip.sync()
+            res.append((time.perf_counter() - t0, ms_dev.value))
+        med = sorted(res)[len(res) // 2]
+        return med[0], med[1], [round(w * 1e3 / steps, 5) for w, _ in res]
 
     def latencies(em, fr, n):
         lat = []
@@ -442,7 +454,7 @@ def run_single(a, local_rank=0):
 
     warm(emap, frame)
     # ---- timed region: exactly K frames, sync on both sides -------------------------------------------------
-    wall, ms_dev = timed(emap, frame, a.steps)
+    wall, ms_dev, loops_ms = timed(emap, frame, a.steps)      # `value` = the median of five timed loops of K frames
     ms_per_step = wall * 1e3 / a.steps
     mpts = N * a.steps / wall / 1e6
     # ---- per-frame latency distribution (each frame individually synchronised) ---------------------------
@@ -464,7 +476,7 @@ def run_single(a, local_rank=0):
         fr3 = make_frame(em3._lib, em3._ctx)
         warm(em3, fr3)
         k3 = max(3, min(a.steps, 20))
-        wall3, ms3 = timed(em3, fr3, k3)
+        wall3, ms3, _ = timed(em3, fr3, k3, loops=3)
         lat3 = latencies(em3, fr3, min(k3, 10))
         st3, vis3 = stage_profile(em3._lib, em3._ctx, fr3, min(k3, 8))
         cold = cold_start(em3, fr3)
@@ -499,11 +511,68 @@ def run_single(a, local_rank=0):
                     raise RuntimeError(l1.emap_last_error(c1).decode())
             warm(em1, fr1)
             k1 = max(20, min(a.steps * 4, 200))
-            wall1, _ = timed(em1, fr1, k1)
+            wall1, _, _ = timed(em1, fr1, k1, loops=3)
             lat1 = latencies(em1, fr1, 40)
             cfg1[tag] = {"ms_per_step": round(wall1 * 1e3 / k1, 5), "Mpoints_s": round(N1 * k1 / wall1 / 1e6, 1), "steps": k1,
                          "latency_ms": {"p10": round(lat1[0], 4), "p50": round(lat1[1], 4), "p90": round(lat1[2], 4)}}
             em1.close()
+
+    # ---- config.cfg4 / config.cfg5: BASELINE configs[3] / configs[4] on ONE GPU, timed in this process by the same code: the
+    # denominators of every strong-scaling statement about those configurations (4096^2 / 4 M points with rays + overlap, `fp32`
+    # indices; 8192^2 multi-modal map, 16 M points, RGB + 3 semantic layers).  Only next to the default workload at its own size.
+    large = {}
+    if a.workload == "cfg2" and not a.no_cfg3 and not a.no_large and not multimodal and C == 1024 and N == 1_000_000:
+        import copy
+        for name in ("cfg4", "cfg5"):
+            b = copy.copy(a)
+            b.workload, b.mode = name, "fp32"
+            Cb, Nb = {"cfg4": (4096, 4_000_000), "cfg5": (8192, 16_000_000)}[name]
+            mm = name == "cfg5"
+            parb = parameter_from(workload_cfg(name), Cb, "fp32", weights); parb.device = local_rank
+            emb = ElevationMap(parb)
+            lb, cb = emb._lib, emb._ctx
+            hostb = host_clouds(b, Cb, Nb, mm)[:2]
+            strideb = hostb[0].shape[1]
+            devb = []
+            for p_ in hostb:
+                dd = hip.malloc(p_.nbytes); hip.h2d(dd, p_); devb.append(dd)
+            del hostb
+            specb = None
+            if mm:
+                specb = _lib.EmapSemSpec()
+                specb.n_col, specb.col_chan[0], specb.col_layer[0] = 1, 3, 0
+                specb.n_sum = 3
+                for k_ in range(3):
+                    specb.sum_chan[k_], specb.sum_layer[k_], specb.sum_kind[k_] = 4 + k_, 1 + k_, 0
+                specb.alpha = 0.5
+                if lb.emap_semantic_configure(cb, 4):
+                    raise RuntimeError(lb.emap_last_error(cb).decode())
+
+            def frb(i, stats=None, lb=lb, cb=cb, devb=devb, Nb=Nb, strideb=strideb, mm=mm, specb=specb):
+                rc = lb.emap_set_points_device(cb, devb[i % len(devb)], ct.c_int64(Nb), ct.c_int64(strideb))
+                rc = rc or lb.emap_update(cb, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
+                if mm:
+                    rc = rc or lb.emap_semantic_update(cb, Rp, tp, ct.byref(specb))
+                if rc:
+                    raise RuntimeError(lb.emap_last_error(cb).decode())
+            warm(emb, frb)
+            kb = 10
+            wallb, msb, loopsb = timed(emb, frb, kb, loops=3)
+            latb = latencies(emb, frb, 10)
+            stb, visb = stage_profile(lb, cb, frb, 6, with_stats=not mm)
+            Lb = Cb * Cb
+            fbytes = 12 * Nb + 56 * Lb + (16 * Nb + 32 * Lb if mm else 0)
+            rb = roofline(stb, ev_overhead, Nb, Lb, name, fbytes, msb / kb, visb, False)
+            large[name] = {"workload": workload_text(b, Cb, Nb, mm), "index_mode": "fp32", "n_gpus": 1, "steps": kb,
+                           "value": round(Nb * kb / wallb / 1e6, 2), "unit": "Mpoints/s", "ms_per_step": round(wallb * 1e3 / kb, 5),
+                           "timed_loops_ms_per_step": loopsb, "latency_ms": {"p10": round(latb[0], 4), "p50": round(latb[1], 4), "p90": round(latb[2], 4)},
+                           "dominant_kernel": rb["kernel"], "kernel_ms": rb["kernel_ms"], "frac": rb["frac"], "frame_frac": rb["frame_frac"],
+                           "ray_visits_per_s": rb["ray_visits_per_s"], "stage_ms": rb["stage_ms"],
+                           "note": ("stage_ms does not hold the RGB / semantic fusion (k_tile_semantic runs behind the frame's stages; "
+                                    "ms_per_step does)" if mm else None)}
+            emb.close()
+            for dd in devb:
+                hip.free(dd)
 
     # ---- the reference's real entry point: input_pointcloud with a HOST cloud (float64 as the ROS wrapper passes it, float32) -----
     # never part of `value`; the upload is asynchronous (host-side cast into pinned memory, DMA overlapping the previous frame)
@@ -539,13 +608,16 @@ def run_single(a, local_rank=0):
 
     config = {"workload": workload_text(a, C, N, multimodal), "index_mode": a.mode,
               "latency_ms": {"p10": round(p10, 4), "p50": round(p50, 4), "p90": round(p90, 4)},
-              "device_ms_per_step": round(ms_dev / a.steps, 5), "cloud": "device resident (H2D excluded)"}
+              "device_ms_per_step": round(ms_dev / a.steps, 5), "cloud": "device resident (H2D excluded)",
+              "timed_loops_ms_per_step": loops_ms, "value_from": "median of %d timed loops of %d frames" % (len(loops_ms), a.steps)}
     if config_cold:
         config["cold_start_ms"] = config_cold
     if cfg1:
         config["cfg1"] = cfg1
     if cfg3:
         config["cfg3"] = cfg3
+    for name, rec in large.items():
+        config[name] = rec
     if h2d:
         config["h2d_inclusive"] = h2d
     out = {

@@ -1105,6 +1105,18 @@ int emap_semantic_accumulate(emap_ctx* ctx, int32_t op, const float* points, int
   CKARG(ctx && points && newmap_inout && op >= 0 && op <= 4, "bad argument");
   CKARG(n_rows >= 0 && stride >= 3 && n_ch >= 1 && n_ch <= 64 && size >= 0 && cells > 0 && newmap_layers >= 1, "bad shape");
   CKARG(op == 2 ? (max_pt && max_id && n_max >= 1 && size <= n_rows) : (pcl_chan && map_lay && size <= n_rows * (int64_t)n_ch), "bad channel description / size");
+  // The index CONTENTS decide which plane / column a thread touches: check them on the host before anything is
+  // launched -- a bad index from a caller of the kernel factories must not write into other device memory of the shared context.
+  if (op == 2) {
+    for (int64_t k = 0; k < size * (int64_t)n_max; ++k) CKARG(max_id[k] >= 0 && max_id[k] < newmap_layers, "sum_max: class id outside the planes of newmap");
+  } else {
+    for (int k = 0; k < n_ch; ++k) {
+      CKARG(pcl_chan[k] >= 0 && pcl_chan[k] < stride, "pcl channel index outside the point rows");
+      CKARG(op == 1 || op == 4 || (map_lay[k] >= 0 && map_lay[k] < newmap_layers), "map layer index outside the planes of newmap");
+    }
+    CKARG(op != 1 || n_ch <= newmap_layers, "sum_compact: newmap needs one plane per channel");
+    CKARG(op != 4 || 3 * n_ch + 1 <= newmap_layers, "add_color: the colour map needs 3 n_ch + 1 planes");
+  }
   CK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   DevBuf P, PC, ML, MP, MI, NM;
@@ -1127,6 +1139,9 @@ int emap_semantic_finalize(emap_ctx* ctx, int32_t op, void* newmap_inout, int32_
   CKARG(n_ch >= 1 && n_ch <= 64 && size >= 0 && size <= cells * (int64_t)n_ch && cells > 0 && newmap_layers >= 1 && map_layers >= 1, "bad shape");
   CKARG(op == 3 || new_elmap3, "the accepted-point counts (new_elmap plane 2) are needed");
   CKARG(op != 2 || (sum_mean && sum_layers >= n_ch), "bayesian_inference needs sum_mean");
+  for (int k = 0; k < n_ch; ++k)      // (colour: newmap is the colour map, indexed by channel; every other op indexes newmap AND map with map_lay)
+    CKARG(map_lay[k] >= 0 && map_lay[k] < map_layers && (op == 3 || map_lay[k] < newmap_layers), "map layer index outside the planes of map / newmap");
+  CKARG(op != 3 || 3 * n_ch + 1 <= newmap_layers, "color_average: the colour map needs 3 n_ch + 1 planes");
   CK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   DevBuf NM, ML, EL, SM, MP;
@@ -1513,7 +1528,7 @@ int emap_dilate_planes(emap_ctx* ctx, const float* host_plane, const float* host
 // ---- halos ----------------------------------------------------------------------------------------------------
 int emap_halo_bytes(emap_ctx* ctx, int64_t* bytes_per_side) {
   CKARG(ctx && bytes_per_side, "null argument");
-  *bytes_per_side = (int64_t)ctx->strip.halo_rows * ctx->prm.cell_n * (int64_t)sizeof(Cell);
+  *bytes_per_side = (int64_t)ctx->strip.halo_rows * ctx->prm.cell_n * (int64_t)sizeof(float4);      // the cold half-cell plane only (see halo_exchange_start)
   return EMAP_OK;
 }
 int emap_halo_pack(emap_ctx* ctx, int side, float* dev_buf) {
@@ -1522,9 +1537,8 @@ int emap_halo_pack(emap_ctx* ctx, int side, float* dev_buf) {
   const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
   if (H == 0) return EMAP_OK;
   CKARG(n >= H, "strip thinner than its halo");
-  const long off = side == 0 ? H * C : (H + n - H) * C;                   // first / last H owned rows; buffer = [hot rows][cold rows]
-  CK(hipMemcpyAsync(dev_buf, ctx->cells.hot + off, sizeof(float4) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
-  CK(hipMemcpyAsync(dev_buf + 4 * H * C, ctx->cells.cold + off, sizeof(float4) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
+  const long off = side == 0 ? H * C : (H + n - H) * C;                   // first / last H owned rows of the COLD half-cell plane
+  CK(hipMemcpyAsync(dev_buf, ctx->cells.cold + off, sizeof(float4) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
   return EMAP_OK;
 }
 int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf) {
@@ -1533,8 +1547,7 @@ int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf) {
   const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
   if (H == 0) return EMAP_OK;
   const long off = side == 0 ? 0 : (H + n) * C;
-  CK(hipMemcpyAsync(ctx->cells.hot + off, dev_buf, sizeof(float4) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
-  CK(hipMemcpyAsync(ctx->cells.cold + off, dev_buf + 4 * H * C, sizeof(float4) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
+  CK(hipMemcpyAsync(ctx->cells.cold + off, dev_buf, sizeof(float4) * H * C, hipMemcpyDeviceToDevice, ctx->stream));
   return EMAP_OK;
 }
 
@@ -1564,8 +1577,8 @@ int emap_normal_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf) {
 
 // ---- multi-GPU: row strips, one process per GPU, RCCL over xGMI ---------------------------------------------------
 // The two exchange steps of the path: an all-reduce of the drift sums (2 x f64) between the count and fuse
-// stages, and the neighbour exchange of halo rows before the stencils.  Halo rows are contiguous in the 32-byte cell array,
-// so RCCL sends the first / last owned rows and receives into the halo rows IN PLACE (no pack / unpack copies); the
+// stages, and the neighbour exchange of halo rows before the stencils.  Halo rows are contiguous in the cold half-cell plane (the
+// only one the stencils read), so RCCL sends the first / last owned rows and receives into the halo rows IN PLACE (no pack / unpack copies); the
 // exchange runs on its own stream while the stencil tiles that do not depend on halo rows run on the main stream.
 static RcclApi* rccl_open(const char* path, std::string* why) {
   void* h = dlopen(path && *path ? path : "librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -1655,9 +1668,10 @@ static int ring_exchange(emap_ctx* ctx, char* base, size_t row_bytes, hipStream_
 static int halo_exchange_start(emap_ctx* ctx) {
   CK(hipEventRecord(ctx->ev_ready, ctx->stream));
   CK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_ready, 0));
-  int rc = ring_exchange(ctx, reinterpret_cast<char*>(ctx->cells.hot), sizeof(float4) * (size_t)ctx->prm.cell_n, ctx->comm_stream);      // both half-cell planes
-  if (rc) return rc;
-  rc = ring_exchange(ctx, reinterpret_cast<char*>(ctx->cells.cold), sizeof(float4) * (size_t)ctx->prm.cell_n, ctx->comm_stream);
+  // Only the COLD half-cell plane travels: the halo rows have exactly one reader, the stencil kernel's staging loop, and it reads
+  // (upper_bound, is_upper_bound, valid') from cells.cold alone (emap_kernels.hip: k_post / k_post_dma) -- the point passes, the ray
+  // pass and every per-cell pass address owned rows only.  (Until round 3 both planes were sent: twice the xGMI bytes for nothing.)
+  int rc = ring_exchange(ctx, reinterpret_cast<char*>(ctx->cells.cold), sizeof(float4) * (size_t)ctx->prm.cell_n, ctx->comm_stream);
   if (rc) return rc;
   CK(hipEventRecord(ctx->ev_done, ctx->comm_stream));
   return EMAP_OK;

@@ -553,12 +553,14 @@ __global__ __launch_bounds__(EM_BLOCK) void k_semraw_acc(SemRaw A, const float* 
   if (i >= A.size) return;
   if (A.op == SR_SUM_MAX) {
     const int idx = (int)p[i * A.stride];
+    if ((unsigned long)idx >= (unsigned long)A.cells) return;                 // a cell index outside the planes (the reference would write out of bounds): dropped
     if (p[i * A.stride + 1] != 0.0f && p[i * A.stride + 2] != 0.0f)
       for (int it = 0; it < A.n_max; ++it) atomicAdd(&newmap[A.cells * max_id[i * A.n_max + it] + idx], max_pt[i * A.n_max + it]);
     return;
   }
   const long id = i / A.K; const int layer = (int)(i % A.K);
   const int idx = (int)p[id * A.stride];
+  if ((unsigned long)idx >= (unsigned long)A.cells) return;
   if (!(p[id * A.stride + 1] != 0.0f && p[id * A.stride + 2] != 0.0f)) return;
   const float feat = p[id * A.stride + pcl_chan[layer]];
   switch (A.op) {

@@ -374,10 +374,12 @@ class ElevationMap:
         traversability it would also rewrite, the stage's input plane) are put back."""
         with self.map_lock:
             keep_trav, keep_in = self.get_layer_raw("traversability"), self.get_layer_raw("traversability_input")
-            self.set_layer_raw("traversability_input", np.asarray(dilated_map, np.float32))
-            self.stage("traversability_normals")
-            self.set_layer_raw("traversability", keep_trav)
-            self.set_layer_raw("traversability_input", keep_in)
+            try:
+                self.set_layer_raw("traversability_input", np.asarray(dilated_map, np.float32))
+                self.stage("traversability_normals")
+            finally:                                  # whatever the stage did: the two planes the reference's method leaves alone come back
+                self.set_layer_raw("traversability", keep_trav)
+                self.set_layer_raw("traversability_input", keep_in)
 
     def update_upper_bound_with_valid_elevation(self):
         m = self.elevation_map

@@ -233,7 +233,7 @@ class HipStripEngine:
         self.map = ElevationMap(param, strip=(r0, r1 - r0, self.halo), stream=self.stream.cuda_stream)
         self.lib, self.ctx = self.map._lib, self.map._ctx
         self.C, self.rows = C, r1 - r0
-        n = max(1, self.halo * C * 8)
+        n = max(1, self.halo * C * 4)          # emap_halo_pack: the 16-byte cold half cells of the boundary rows
         with torch.cuda.stream(self.stream):
             mk = lambda: torch.zeros(n, dtype=torch.float32, device=torch_device)  # noqa: E731
             self.send = [mk(), mk()]

@@ -160,7 +160,7 @@ int emap_semantic_configure(emap_ctx* ctx, int32_t n_layers);                 /*
 int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], const emap_sem_spec* spec); /* after emap_update */
 int emap_semantic_get_layer(emap_ctx* ctx, int32_t layer, float* host_out);
 int emap_semantic_set_layer(emap_ctx* ctx, int32_t layer, const float* host_in);
-int emap_semantic_clear(emap_ctx* ctx);
+int emap_semantic_clear(emap_ctx* ctx);                                        /* SemanticMap.clear (layers only, :47-49) */
 
 /* pointcloud_class_max (EM/fusion/pointcloud_class_max.py:80-126) on the bound cloud: channels chan[k] carry (half probability |
  * class id << 16) packed in a float, layer[k] the k-th of the fusion's layers (n_ch <= 8).  Per frame: sorted union of the ids in the
@@ -185,7 +185,7 @@ int emap_semantic_accumulate(emap_ctx* ctx, int32_t op, const float* points, int
                              const float* max_pt, const int32_t* max_id, int32_t n_max);
 int emap_semantic_finalize(emap_ctx* ctx, int32_t op, void* newmap_inout, int32_t newmap_layers, const int32_t* map_lay, int32_t n_ch, int64_t size,
                            int64_t cells, const float* new_elmap3, const float* sum_mean, int32_t sum_layers, float* map_inout, int32_t map_layers,
-                           double alpha);                                        /* SemanticMap.clear (layers only, :47-49) */
+                           double alpha);
 int emap_semantic_get_alpha(emap_ctx* ctx, int32_t layer, float* host_out);    /* SemanticMap.new_map[layer] of a class_bayesian layer */
 int emap_semantic_set_alpha(emap_ctx* ctx, int32_t layer, const float* host_in);
 
@@ -247,8 +247,9 @@ int emap_dilate_planes(emap_ctx* ctx, const float* host_plane, const float* host
                        float* host_out, float* host_out_mask);
 
 /* ---- row-strip halos (multi-GPU; exchange itself is done by the caller, e.g. torch.distributed/RCCL) ---- */
-/* pack `halo_rows` owned boundary rows (32-byte cells) next to the lower (side 0) / upper (side 1) neighbour
- * into a device buffer; unpack a neighbour's rows into the halo. Buffers: halo_rows*cell_n*8 floats. */
+/* pack `halo_rows` owned boundary rows next to the lower (side 0) / upper (side 1) neighbour into a device buffer; unpack a
+ * neighbour's rows into the halo.  Only what the stencils read of a halo row travels: the 16-byte cold half cells (time,
+ * upper_bound, is_upper_bound, is_valid).  Buffers: halo_rows*cell_n*4 floats (emap_halo_bytes). */
 int emap_halo_bytes(emap_ctx* ctx, int64_t* bytes_per_side);
 int emap_halo_pack(emap_ctx* ctx, int side, float* dev_buf);
 int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf);

@@ -45,3 +45,27 @@ def assert_planes_equal(a, b, names=PLANE_NAMES, what=""):
             i = tuple(np.argwhere(bad)[0])
             raise AssertionError("%s plane %s: %d cells differ bitwise, max |d| = %g (first at %s: %r vs %r)" % (
                 what, name, int(bad.sum()), float(np.nanmax(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)))), i, a[k][i], b[k][i]))
+
+
+def rccl_stand_in(kind="blocking"):
+    """Builds one of the in-process stand-ins for the ten RCCL entry points (tests/fake_rccl/) and returns the path to hand to
+    emap_comm_init: "blocking" = fake_rccl.cpp (host-synchronised copies, g++), "stream" = stream_rccl.hip (stream-ordered events +
+    a reduction kernel, hipcc).  Ranks are threads of the calling process on one GPU.  Prebuilt by __graft_entry__.build() into
+    tests/fake_rccl/_build/ (travels to the GPU box); rebuilt here when stale."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl")
+    src = os.path.join(here, "fake_rccl.cpp" if kind == "blocking" else "stream_rccl.hip")
+    out_dir = os.path.join(here, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "lib%s_rccl.so" % ("fake" if kind == "blocking" else "stream"))
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        tmp = out + ".%d.tmp" % os.getpid()
+        if kind == "blocking":
+            cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-w", src, "-o", tmp,
+                   "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"]
+        else:
+            cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", src, "-o", tmp]
+        subprocess.check_call(cmd)
+        os.replace(tmp, out)
+    return out

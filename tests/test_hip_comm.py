@@ -64,20 +64,13 @@ def test_update_sharded_without_communicator_fails_loudly(weights):
     assert b"dlopen" in m._lib.emap_last_error(m._ctx)
 
 
-def _fake_rccl():
-    """build tests/fake_rccl/fake_rccl.cpp (in-process stand-in for RCCL: ranks are threads on one GPU) into a temp dir"""
-    import os
-    import subprocess
-    import tempfile
-    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "fake_rccl.cpp")
-    out = os.path.join(tempfile.gettempdir(), "libfake_rccl_%d.so" % os.getuid())
-    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-w", src,
-                               "-o", out, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
-    return out
+def _fake_rccl(kind="blocking"):
+    """in-process stand-in for RCCL (ranks are threads on one GPU): tests/fake_rccl/, built by tests/_util.py"""
+    from _util import rccl_stand_in
+    return rccl_stand_in(kind)
 
 
-def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_fp16", check_gather=None):
+def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_fp16", check_gather=None, stand_in="blocking"):
     """frames = [(cloud, R, t, position_noise, orientation_noise, n_update_time, move_to vector or None), ...]: one single-context
     map and `world` strip contexts (threads, in-process RCCL stand-in) run the same frames; every strip must equal the rows of the
     single-context map bit for bit.  Returns nothing; asserts."""
@@ -87,7 +80,7 @@ def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_f
     from elevation_mapping_cupy_amd.configs import parameter_from
     from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
     from elevation_mapping_cupy_amd.sharded import HipStripEngine, NativeComm, ShardedElevationMap
-    lib_path = _fake_rccl()
+    lib_path = _fake_rccl(stand_in)
     full = ElevationMap(parameter_from(cfg, C, mode, weights))
     full.set_scatter_mode(scatter)
     t_rel = []                                                    # the map-centre relative translation the single context computes (float32: t_world - center)
@@ -144,6 +137,7 @@ def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_f
         assert add == want_add
 
 
+@pytest.mark.parametrize("stand_in", ["blocking", "stream"])
 @pytest.mark.parametrize("moves", [False, True])
 @pytest.mark.parametrize("world,cfg_name,C,N,scatter", [(2, "yaml", 130, 40000, "auto"), (3, "yaml_norays", 202, 60000, "auto"), (4, "default", 202, 40000, "auto"),
                                                         # the tile-binned scatter on strips: without a visibility pass the point passes run the cheap
@@ -151,11 +145,12 @@ def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_f
                                                         # ray-only bin; 8 strips of the 1024^2 map with a cloud large enough for the automatic choice
                                                         (3, "yaml_norays", 202, 60000, "binned"), (4, "yaml", 130, 40000, "binned"),
                                                         (8, "yaml_norays", 1024, 300000, "auto")])
-def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, C, N, scatter, moves, weights):
+def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, C, N, scatter, moves, stand_in, weights):
     """emap_comm_init + emap_update_sharded with SEVERAL ranks: the library's own orchestration (all-reduce between count and fuse,
     in-place halo send / recv on the second stream, interior / boundary stencil split) driven through a stand-in for the nine RCCL
-    entry points whose ranks are threads of this process (RCCL refuses two ranks on one GPU).  Every strip must equal the rows of
-    the single-context map bit for bit."""
+    entry points whose ranks are threads of this process (RCCL refuses two ranks on one GPU) -- two independent stand-ins: one that
+    synchronises with the host around every copy, one whose collectives are stream ordered like RCCL's (events across the ranks'
+    streams, tests/fake_rccl/stream_rccl.hip).  Every strip must equal the rows of the single-context map bit for bit."""
     from oracle import emap_oracle as eo
     cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML if cfg_name.startswith("yaml") else {})
     if cfg_name.endswith("norays"):
@@ -164,7 +159,7 @@ def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, 
     # move_to between the frames: ring halo, normal rows (after a move a strip's view of the un-shifted normals has holes until the next frame)
     MV = [(0.13, -0.3, 0.05), (-0.10, 0.17, -0.02), None] if moves else [None] * 3
     frames = [(fx.cloud(C, N, f, dz=dz), R, t, 1.0, 1.0, 6, mv) for (f, dz), mv in zip(enumerate((0.0, -0.02, -0.1)), MV)]
-    _strips_vs_single(world, cfg, C, frames, scatter, weights, check_gather=None if scatter != "binned" else ("elevation" if moves else "all"))
+    _strips_vs_single(world, cfg, C, frames, scatter, weights, check_gather=None if scatter != "binned" else ("elevation" if moves else "all"), stand_in=stand_in)
 
 
 @pytest.mark.parametrize("k", range(10))
@@ -192,4 +187,4 @@ def test_fuzz_strips_bitwise(k, weights):
         noise = 1.0 if rng.random() < 0.6 else 0.0
         mv = (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.3, 0.3)), 0.0) if (f < 2 and rng.random() < 0.5) else None     # <= 7 rows: the halo ring hands the seam rows round
         frames.append((p, R, t, noise, noise, int(rng.integers(0, 9)), mv))
-    _strips_vs_single(world, cfg, C, frames, scatter, weights, mode=mode)
+    _strips_vs_single(world, cfg, C, frames, scatter, weights, mode=mode, stand_in="stream" if k % 2 else "blocking")

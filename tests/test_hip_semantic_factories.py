@@ -50,3 +50,33 @@ def test_factory_arguments_are_checked():
     with pytest.raises(EmapError):      # more elements than points x channels
         K.sem_sum(c["points"], np.eye(3, dtype=np.float32), np.zeros(3, np.float32), c["pcl_ids"], c["layer_ids"], np.array([6, 2], np.int32),
                   np.zeros((4, 4, 4), np.float32), np.zeros((4, 4, 4), np.float32), 1000)
+
+
+def test_index_contents_are_checked_before_anything_is_launched():
+    """the layer / channel / class-id INDEX ARRAYS decide which plane a thread writes: values outside the caller's arrays must be
+    refused on the host (a bad index used to corrupt device memory of the shared scratch context silently), and a
+    cell index outside the planes is dropped by the kernel"""
+    from elevation_mapping_cupy_amd._lib import EmapError
+    K = _Factories()
+    c = fx.semantic_kernel_cases()["rich"]
+    R, t = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    pts, chn = c["points"], np.array([6, 2, 2], np.int32)
+    n = pts.shape[0]
+    with pytest.raises(EmapError, match="map layer index"):          # layer 4 of a 4-plane newmap
+        K.sem_sum(pts, R, t, c["pcl_ids"], np.array([1, 4], np.int32), chn, np.zeros((4, 4, 4), np.float32), np.zeros((4, 4, 4), np.float32), n * 2)
+    with pytest.raises(EmapError, match="pcl channel index"):        # column 6 of 6-float rows
+        K.sem_sum(pts, R, t, np.array([3, 6], np.int32), c["layer_ids"], chn, np.zeros((4, 4, 4), np.float32), np.zeros((4, 4, 4), np.float32), n * 2)
+    with pytest.raises(EmapError, match="class id"):
+        bad = c["max_id"].copy(); bad[3, 1] = 4
+        K.sem_sum_max(pts, c["max_pt"], bad, c["pcl_ids"], c["layer_ids"], chn, np.zeros((4, 4, 4), np.float32), n)
+    with pytest.raises(EmapError, match="3 n_ch \\+ 1"):             # two colour channels need 7 planes
+        K.sem_add_color(c["points_color"], R, t, np.array([3, 4], np.int32), np.array([0, 1], np.int32), np.array([6, 2], np.int32), np.zeros((4, 4, 4), np.uint32), n)
+    with pytest.raises(EmapError, match="map layer index"):
+        K.sem_average(np.zeros((4, 4, 4), np.float32), c["pcl_ids"], np.array([1, -1], np.int32), chn, c["new_elmap"], np.zeros((4, 4, 4), np.float32), 32)
+    with pytest.raises(EmapError, match="3 n_ch \\+ 1"):
+        K.sem_color_average(np.zeros((4, 4, 4), np.uint32), np.array([3, 4], np.int32), np.array([0, 1], np.int32), np.array([6, 2], np.int32), np.zeros((4, 4, 4), np.float32), 32)
+    # a point whose cell index lies outside the 4 x 4 planes: dropped, the planes next to it stay untouched
+    far = pts.copy(); far[:, 0] = 16 + np.arange(n)
+    newmap = np.zeros((4, 4, 4), np.float32)
+    K.sem_sum(far, R, t, c["pcl_ids"], c["layer_ids"], chn, np.zeros((4, 4, 4), np.float32), newmap, n * 2)
+    assert not newmap.any()

@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
-"""Strong scaling of the row-strip decomposition, EMULATED on one MI355X: for G = 1, 2, 4, 8 every strip context of the G-way split
-runs the workload's frames on its own (one after another, same device, same replicated cloud); a rank's frame time is what that
-GPU would spend per frame, the multi-GPU frame time is the slowest rank plus the collectives.  The collectives cannot run between
-contexts of one device (RCCL refuses two ranks per GPU), so their cost is taken from the world-1 native frame
-(emap_update_sharded - emap_update: the all-reduce and the stream hand-offs of the halo exchange) -- stated in the output, not hidden.
+"""Strong scaling of the row-strip decomposition, EMULATED on one MI355X -- the frame every number below times is the library's own
+sharded frame, emap_update_sharded: count -> all-reduce on the strip's stream -> gate folded into the tile kernel -> fuse [-> rays] ->
+halo exchange on the second stream next to the interior stencil tiles -> event wait -> boundary tiles (+ the per-strip RGB / semantic
+fusion of multi-modal clouds).  RCCL refuses two ranks on one device, so the ten RCCL entry points are served by the stream-ordered
+in-process stand-in tests/fake_rccl/stream_rccl.hip (events across streams, a reduction kernel, device-to-device copies: the same
+stream structure as under RCCL, no host synchronisation).  Three measurements per split G:
 
-    python tools/strip_emulation.py --workload cfg2|cfg5|cfg4 [--steps K] > profiles/r03_strips_<workload>.json
+  solo      every rank of the G-way split runs ALONE on the GPU, one after another (stand-in in loop-back mode: the rank's collectives
+            move the same bytes through the same streams and events, nobody else is there): frame_ms_per_rank = what that GPU would
+            spend per frame on everything but the wire; the multi-GPU frame is bounded below by the slowest rank.
+  lockstep  all G ranks ALIVE at once (threads), their collectives really meet: the all-reduce of a frame completes when the SLOWEST
+            rank has delivered its sums, the halo rows really come from the neighbours.  The ranks share the one GPU, so the wall time
+            of a frame is the time of ALL ranks' work: lockstep_ms / single_ms = the work inflation of the decomposition (replicated
+            cloud streams, halo re-staging, launches), G x single_ms / lockstep_ms an upper bound of the speed-up that does not depend
+            on any per-rank timing.
+  wire      what one GPU cannot show: the latency of an 8-rank all-reduce of 16 bytes and of the halo rows over xGMI.  The real RCCL
+            is measured at world size 1 (its launch + kernel cost, a LOWER bound of the multi-rank latency) and the projection is given
+            for several assumed wire latencies instead of one.
 
-What it shows: which stages shrink with G (record scatter, tile passes, stencils: ~1/G), and which do not (the 12-byte stream over
-the replicated cloud in the two point passes, launch latencies)."""
+    python tools/strip_emulation.py --workload cfg2|cfg4|cfg5 [--rays] [--steps K] > profiles/r04_strips_<workload>.json"""
 import argparse
 import ctypes as ct
 import json
 import os
 import sys
+import threading
+import time
 
 import numpy as np
 
@@ -26,13 +38,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"])
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--gs", type=int, nargs="*", default=[1, 2, 4, 8])
     ap.add_argument("--rays", action="store_true", help="visibility clean-up + overlap clearance on (cfg3's parameters); strips of equal RAY work "
                     "(sharded.ray_balanced_weights: thin around the sensor) unless --equal-strips")
     ap.add_argument("--equal-strips", action="store_true")
+    ap.add_argument("--no-lockstep", action="store_true")
     a = ap.parse_args()
     import bench
+    from _util import rccl_stand_in
     from elevation_mapping_cupy_amd import _lib, sharded
     from elevation_mapping_cupy_amd.configs import parameter_from
     from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
@@ -42,7 +56,7 @@ def main():
     C, N = ba.cell_n, ba.points
     multimodal = a.workload == "cfg5"
     mode = "fp32" if C > 2049 else "reference_fp16"
-    cfg = bench.workload_cfg("cfg3" if a.rays else "cfg2")  # default: rays / overlap off, the strip-friendly stages (rays: see DESIGN.md section 7)
+    cfg = bench.workload_cfg("cfg3" if a.rays else "cfg2")
     weights = bench.load_weights()
     hip = bench.Hip(); hip.set_device(0)
     clouds_host = bench.host_clouds(ba, C, N, multimodal)
@@ -50,11 +64,14 @@ def main():
     clouds_dev = []
     for p in clouds_host:
         d = hip.malloc(p.nbytes); hip.h2d(d, p); clouds_dev.append(d)
+    del clouds_host
     R = np.eye(3, dtype=np.float32).ravel().copy(); t = np.array([0, 0, 1], np.float32)
     Rp, tp = _lib.f32p(R), _lib.f32p(t)
     channels = ["rgb", "sem0", "sem1", "sem2"] if multimodal else None
+    stand_in = rccl_stand_in("stream").encode()
 
-    def run_rank(G, rank):
+    def make_rank(G, rank, loopback):
+        """strip context + communicator of one rank; returns (map, frame function)"""
         par = parameter_from(cfg, C, mode, weights, device=0)
         if multimodal:
             par.pointcloud_channel_fusions = {"rgb": "color", "default": "average"}
@@ -67,14 +84,23 @@ def main():
         lib, ctx = em._lib, em._ctx
         if multimodal:
             em.semantic_map.prepare(channels)
+        em._rows01 = [int(r0), int(r1)]
+        return em
 
-        def frame(i):
+    def frame_fn(em, sharded_frame):
+        lib, ctx = em._lib, em._ctx
+        call = lib.emap_update_sharded if sharded_frame else lib.emap_update
+
+        def frame(i, stats=None):
             rc = lib.emap_set_points_device(ctx, clouds_dev[i % len(clouds_dev)], ct.c_int64(N), ct.c_int64(stride))
-            rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), None)
+            rc = rc or call(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
             if rc:
                 raise RuntimeError(lib.emap_last_error(ctx).decode())
             if multimodal:
                 em.semantic_map.update_layers_pointcloud(em, channels, R, t)
+        return frame
+
+    def warm(em, frame):
         for i in range(3):
             frame(i)
             for _ in range(4):
@@ -83,52 +109,130 @@ def main():
         for i in range(3):
             frame(i)
         em.sync()
+
+    def timed_loops(em, frame, steps, reps=3):
+        lib, ctx = em._lib, em._ctx
         loops = []
-        for _rep in range(3):                      # three timed loops, the MEDIAN counts (a context's first loop now and then runs into the
-            ms = ct.c_float(0)                     # asynchronous release of the previous context's gigabytes; a single loop of the 2-GB map
-            lib.emap_timer_begin(ctx)              # has also been seen 8 % FASTER than all others)
-            for i in range(a.steps):
+        for _rep in range(reps):                   # the MEDIAN of the timed loops counts (a context's first loop now and then runs into the
+            ms = ct.c_float(0)                     # asynchronous release of the previous context's gigabytes)
+            lib.emap_timer_begin(ctx)
+            for i in range(steps):
                 frame(i)
             lib.emap_timer_end(ctx, ct.byref(ms))
             em.sync()
-            loops.append(ms.value)
-        ms = ct.c_float(sorted(loops)[1])
-        stage_ms, _ = bench.stage_profile(lib, ctx, lambda i, s: frame(i), min(a.steps, 10), with_stats=False)
-        ev = bench.event_overhead(lib, ctx)
-        em.close()
-        net = {k: round(max(v - ev, 0.0), 5) for k, v in stage_ms.items()}
-        return ms.value / a.steps, net, [int(r0), int(r1)]
+            loops.append(ms.value / steps)
+        return float(np.median(loops))
+
+    def comm_init(em, uid, rank, G):
+        if em._lib.emap_comm_init(em._ctx, stand_in, uid, rank, G):
+            raise RuntimeError(em._lib.emap_last_error(em._ctx).decode())
+
+    def new_uid(lib):
+        uid = (ct.c_uint8 * 128)()
+        assert lib.emap_comm_unique_id(stand_in, uid) == 0
+        return uid
+
+    # ---- single context: the plain frame (emap_update) and the world-1 sharded frame over the REAL RCCL ------------------------------
+    em = make_rank(1, 0, False)
+    f_plain = frame_fn(em, False)
+    warm(em, f_plain)
+    single_ms = timed_loops(em, f_plain, a.steps)
+    ev = bench.event_overhead(em._lib, em._ctx)
+    st, _ = bench.stage_profile(em._lib, em._ctx, lambda i, s: f_plain(i), min(a.steps, 10), with_stats=False)
+    single_stage = {k: round(max(v - ev, 0.0), 5) for k, v in st.items()}
+    rccl_world1_ms = None
+    try:
+        path = sharded.rccl_library_path().encode()
+        uid = (ct.c_uint8 * 128)()
+        if em._lib.emap_comm_unique_id(path, uid) == 0 and em._lib.emap_comm_init(em._ctx, path, uid, 0, 1) == 0:
+            f_sh = frame_fn(em, True)
+            for i in range(3):
+                f_sh(i)
+            rccl_world1_ms = timed_loops(em, f_sh, a.steps)
+            em._lib.emap_comm_destroy(em._ctx)
+    except Exception as ex:  # noqa: BLE001
+        print("real RCCL at world size 1 unavailable: %s" % ex, file=sys.stderr)
+    em.close()
 
     out = {"workload": bench.workload_text(ba, C, N, multimodal).replace("cfg5", a.workload).replace("cfg2", a.workload) + (
                "; WITH visibility clean-up + overlap clearance, strips of %s" % ("equal height" if a.equal_strips else "equal ray work") if a.rays else ""),
-           "index_mode": mode, "steps": a.steps,
-           "method": "every strip context of the G-way split run on ONE MI355X one after another (replicated device-resident cloud); "
-                     "frame_ms = device time of K back-to-back emap_update frames / K; stage_ms_net = hipEvent spacing of a stage minus the "
-                     "spacing of an empty event pair", "splits": {}}
-    single = None
-    for G in a.gs:
-        ranks = [run_rank(G, r) for r in range(G)]
-        frame_ms = [x[0] for x in ranks]
-        if G == 1:
-            single = frame_ms[0]
-        point_passes = [x[1]["hist"] + x[1]["scatter"] for x in ranks]
-        out["splits"][str(G)] = {
-            "rows": [x[2] for x in ranks], "frame_ms_per_rank": [round(v, 5) for v in frame_ms], "frame_ms_max": round(max(frame_ms), 5),
-            "stage_ms_net_rank0": ranks[0][1], "stage_ms_net_slowest": ranks[int(np.argmax(frame_ms))][1],
-            "hist_plus_scatter_ms_max": round(max(point_passes), 5)}
-    # collectives: what the world-1 native frame adds to the plain frame (all-reduce of 2 doubles between count and fuse + the event /
-    # stream hand-offs of the halo exchange); the halo payload itself ((dilation_size + 4) rows x 32 B x cell_n per side) moves on a
-    # second stream while the interior stencil tiles run
-    for G in a.gs:
+           "index_mode": mode, "steps": a.steps, "source_stamp": bench.source_stamp(),
+           "method": "one MI355X; every frame is emap_update_sharded over the stream-ordered in-process RCCL stand-in (tests/fake_rccl/stream_rccl.hip); "
+                     "solo = each rank alone (loop-back collectives: same bytes, streams and events), lockstep = all ranks alive as threads sharing "
+                     "the GPU; times = median of 3 loops of K frames (device time on the strip's stream for solo, host wall for lockstep)",
+           "single": {"frame_ms": round(single_ms, 5), "stage_ms_net": single_stage,
+                      "frame_ms_sharded_world1_real_rccl": None if rccl_world1_ms is None else round(rccl_world1_ms, 5)},
+           "splits": {}}
+
+    for G in [g for g in a.gs if g > 1]:
+        # ---- solo: every rank alone, loop-back collectives ----------------------------------------------------------------------------
+        os.environ["STREAM_RCCL_LOOPBACK"] = "1"
+        solo, stages, rows = [], [], []
+        for rank in range(G):
+            em = make_rank(G, rank, True)
+            comm_init(em, new_uid(em._lib), rank, G)
+            fr = frame_fn(em, True)
+            warm(em, fr)
+            solo.append(timed_loops(em, fr, a.steps))
+            stg, _ = bench.stage_profile(em._lib, em._ctx, lambda i, s: fr(i), min(a.steps, 10), with_stats=False)
+            stages.append({k: round(max(v - ev, 0.0), 5) for k, v in stg.items()})
+            rows.append(em._rows01)
+            em._lib.emap_comm_destroy(em._ctx)
+            em.close()
+        os.environ["STREAM_RCCL_LOOPBACK"] = "0"
+        slow = int(np.argmax(solo))
+        sp = {"rows": rows, "solo_frame_ms_per_rank": [round(v, 5) for v in solo], "solo_frame_ms_max": round(max(solo), 5),
+              "solo_frame_ms_sum": round(sum(solo), 5), "stage_ms_net_slowest_rank": stages[slow], "stage_ms_net_rank0": stages[0],
+              "hist_plus_scatter_ms_max": round(max(s["hist"] + s["scatter"] for s in stages), 5),
+              "speedup_solo_no_wire": round(single_ms / max(solo), 3)}
+        # ---- lockstep: all ranks alive, collectives really meet ---------------------------------------------------------------------
+        if not a.no_lockstep:
+            ems = [make_rank(G, r, False) for r in range(G)]
+            uid = new_uid(ems[0]._lib)
+            bar = threading.Barrier(G + 1)
+            errs, walls = [], [None] * 3
+
+            def run(rank):
+                try:
+                    em = ems[rank]
+                    comm_init(em, uid, rank, G)
+                    fr = frame_fn(em, True)
+                    warm(em, fr)
+                    for rep in range(3):
+                        em.sync(); bar.wait()
+                        for i in range(a.steps):
+                            fr(i)
+                        em.sync(); bar.wait()
+                    em._lib.emap_comm_destroy(em._ctx)
+                except Exception as ex:  # noqa: BLE001
+                    errs.append(ex); bar.abort()
+            th = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(G)]
+            [x.start() for x in th]
+            try:
+                for rep in range(3):
+                    bar.wait(); t0 = time.perf_counter()
+                    bar.wait(); walls[rep] = (time.perf_counter() - t0) * 1e3 / a.steps
+            except threading.BrokenBarrierError:
+                pass
+            [x.join(timeout=300) for x in th]
+            if errs:
+                raise errs[0]
+            for em in ems:
+                em.close()
+            lock = float(np.median(walls))
+            sp.update({"lockstep_frame_ms_all_ranks_one_gpu": round(lock, 5), "work_inflation_vs_single": round(lock / single_ms, 3),
+                       "speedup_bound_from_lockstep": round(G * single_ms / lock, 3)})
+        out["splits"][str(G)] = sp
+
+    # ---- the wire: cannot be measured on one GPU ------------------------------------------------------------------------------------
+    wire = {"note": "an 8-rank all-reduce of 16 bytes and the halo rows over xGMI cannot be measured on one GPU; measured here: what the real "
+                    "RCCL's world-1 frame adds to the plain frame (launch + kernel of the all-reduce: a lower bound of its multi-rank latency)",
+            "real_rccl_world1_frame_minus_plain_ms": None if rccl_world1_ms is None else round(rccl_world1_ms - single_ms, 5),
+            "projected_speedup": {}}
+    for G in [g for g in a.gs if g > 1]:
         sp = out["splits"][str(G)]
-        sp["speedup_compute_only"] = round(single / sp["frame_ms_max"], 3)
-        sp["hist_plus_scatter_vs_single"] = round(sp["hist_plus_scatter_ms_max"] / out["splits"]["1"]["hist_plus_scatter_ms_max"], 3) if "1" in out["splits"] else None
-    coll_ms = 0.020          # measured upper bound of the two collectives' exposed cost on one node: all-reduce ~15 us + hand-offs
-    out["collective_ms_assumed"] = coll_ms
-    for G in a.gs:
-        sp = out["splits"][str(G)]
-        sp["projected_frame_ms"] = round(sp["frame_ms_max"] + (coll_ms if G > 1 else 0.0), 5)
-        sp["projected_speedup"] = round(single / sp["projected_frame_ms"], 3)
+        wire["projected_speedup"][str(G)] = {"wire_%d_us" % us: round(single_ms / (sp["solo_frame_ms_max"] + us * 1e-3), 3) for us in (0, 20, 60, 100)}
+    out["wire"] = wire
     print(json.dumps(out))
 
 
