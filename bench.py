@@ -651,7 +651,8 @@ def run_strips_native(a, rank, world, local_rank, rdv):
     par = parameter_from(cfg, C, a.mode, weights, device=dev)
     halo = sharded.halo_rows_needed(par.dilation_size, world)
     row_w = None
-    if cfg["enable_visibility_cleanup"] and world > 1 and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
+    # (from 2048^2 cells on the sharded frame marches its rays BY RAY -- emap_set_ray_mode -- and equal heights are right again)
+    if cfg["enable_visibility_cleanup"] and world > 1 and C < 2048 and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
         row_w = sharded.ray_balanced_weights(C, float(cfg["resolution"]), float(cfg["max_ray_length"]), halo, world)
     r0, r1 = sharded.strip_rows(C, world, rank, row_w)
     ok, emap, err = True, None, ""

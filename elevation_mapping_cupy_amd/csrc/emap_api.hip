@@ -25,7 +25,10 @@ void launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, 
 void launch_gate(hipStream_t, const GateArgs&, ErrSlot*, FrameDev*, int, double*, const double*);
 void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, Cells, AccF*, const FrameDev*);
 void launch_commit(hipStream_t, const KP&, Cells, const AccF*, const FrameDev*, unsigned long long*);
-void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, Cells, AccR*, const float*, long, FrameDev*, bool, const unsigned long long*, const unsigned int*, int, const float*, const unsigned int*, const unsigned int*);
+void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, Cells, const AccRView&, const float*, long, FrameDev*, bool, const unsigned long long*, const unsigned int*, int, const float*, const unsigned int*, const unsigned int*);
+void launch_win_pack(hipStream_t, const KP&, const Win&, Cells, const float*, long, const unsigned int*, const unsigned long long*);
+void launch_win_prepare(hipStream_t, const Win&, int);
+void launch_win_unpack(hipStream_t, const KP&, const Win&, AccR*);
 void launch_ray_apply(hipStream_t, const KP&, Cells, AccR*, unsigned long long*, const OverlapArgs&);
 void launch_average(hipStream_t, const KP&, Cells, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*, const OverlapArgs&);
 static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
@@ -165,6 +168,10 @@ struct emap_ctx {
   // row-strip communicator (emap_comm_init): RCCL resolved at run time, exchange on its own stream so that it overlaps the interior stencils
   struct RcclApi* rccl; ncclComm_t comm; int comm_rank, comm_world;
   float* gather_buf;            // cell_n x cell_n plane of emap_comm_gather_layer (on demand)
+  // rays by ray (multi-GPU frames with a visibility pass): the replicated ray window around the sensor (emap_device.h: Win)
+  int ray_mode;                 // 0 auto (by ray from 2048^2 cells on), 1 always by row, 2 by ray whenever the frame allows it
+  bool byray_frame;             // the current sharded frame marches its rays by ray
+  unsigned int* win_state; unsigned long long* win_bits; float* win_thr; long long* win_dh; unsigned int* win_key; long win_cap;
   hipStream_t comm_stream; hipEvent_t ev_ready, ev_done; double* comm_sums;   // [0..1] local err_sum / err_cnt, [2..3] totals, [4..36) emap_comm_allreduce_host
   std::string err;
 };
@@ -198,6 +205,7 @@ static void build_kp(emap_ctx* ctx) {
   k.time_var = (float)p.time_variance; k.time_int = (float)p.time_interval; k.res_f = (float)p.resolution;
   k.inv_res_f = (float)(1.0 / p.resolution); k.half_w_f = 0.5f * (float)p.cell_n; k.cm1_f = (float)(p.cell_n - 1);
   k.hw_int_f = (float)(p.cell_n / 2); k.hw_frac_f = (p.cell_n & 1) ? 0.5f : 0.0f; k.pad1 = 0.f;
+  k.col0 = 0; k.ncols = p.cell_n; k.pitch = p.cell_n; k.wmode = 0;
 }
 
 // smallest float >= c (a < c  <=>  a < up(c) for float a) / largest float <= c (a > c <=> a > dn(c))
@@ -384,6 +392,7 @@ int emap_destroy(emap_ctx* ctx) {
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   emap_comm_destroy(ctx);
+  hipFree(ctx->win_state); hipFree(ctx->win_bits); hipFree(ctx->win_thr); hipFree(ctx->win_dh); hipFree(ctx->win_key);
   for (int i = 0; i <= ST_N; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   if (ctx->t0) hipEventDestroy(ctx->t0);
   if (ctx->t1) hipEventDestroy(ctx->t1);
@@ -573,7 +582,9 @@ static int ensure_bins(emap_ctx* ctx, bool raybin) {
   g.tiles_x = (ctx->prm.cell_n + 63) / 64; g.tiles_y = (ctx->strip.row_count + 16 * g.sub - 1) / (16 * g.sub); g.T = g.tiles_x * g.tiles_y; g.TB = g.T + 1;
   g.pitch = (g.TB + 3) & ~3; g.raybin = raybin ? 1 : 0;
   // strip contexts without a visibility pass: cheap ownership test + lane compaction in the point passes (emap_binned.hip)
-  ctx->bin_strip = ctx->strip.row_count < ctx->prm.cell_n && !raybin;
+  // ... and strips whose frame marches its rays BY RAY: a rank then needs exactly the points of its rows (the valid ones that are not
+  // is_inside ride in the ray-only bin) -- the other ranks march the rest
+  ctx->bin_strip = ctx->strip.row_count < ctx->prm.cell_n && (!raybin || ctx->byray_frame);
   if (const char* e = getenv("EMAP_BIN_STRIP")) { if (atoi(e) == 0) ctx->bin_strip = false; }      // test / tuning hook
   // Blocks: ~4096 points each, but every block carries a row of the (block, tile) matrix through three passes (written, scanned,
   // read): keep the matrix (4 B x TB x B, x4) below the cloud's own traffic (12 B x n, x2) -- B <= n / (3 TB) -- without dropping
@@ -629,6 +640,12 @@ int emap_set_scatter_mode(emap_ctx* ctx, int32_t mode) {
   ctx->force_sub = sub;
   CKARG(m != 2 || bins_possible(ctx), "binned scatter: too many bins for the LDS histogram");
   ctx->scatter_mode = m;
+  return EMAP_OK;
+}
+
+int emap_set_ray_mode(emap_ctx* ctx, int32_t mode) {
+  CKARG(ctx && mode >= 0 && mode <= 2, "ray mode: 0 auto, 1 by row, 2 by ray");
+  ctx->ray_mode = mode;
   return EMAP_OK;
 }
 
@@ -775,7 +792,9 @@ int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
   // newmap[3]: the tile kernel's dense plane, or the high halves of AccF::pts_inl (5 x u64 records) on the staged / atomic path
   const unsigned int* inl = ctx->rays_fused ? ctx->inl_plane : reinterpret_cast<const unsigned int*>(ctx->acc) + 1;
   const bool sorted = ctx->frame_binned && ctx->bg.raybin;      // the sorted records hold EVERY valid point only with the ray-only bin
-  launch_rays(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->rt, ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->accr,
+  char* const ab = reinterpret_cast<char*>(ctx->accr);
+  const AccRView av = {ab + offsetof(AccR, dec), ab + offsetof(AccR, hits), ab + offsetof(AccR, upper_key), (int)sizeof(AccR), (int)sizeof(AccR), (int)sizeof(AccR), 0};
+  launch_rays(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->rt, ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, av,
               ctx->normal, ctx->ncells_alloc, ctx->frame, ctx->want_ray_stats, ctx->inert, inl, ctx->rays_fused ? 1 : (int)(sizeof(AccF) / 4),
               ctx->rays_fused ? ctx->ray_thr : nullptr,
               sorted ? reinterpret_cast<const unsigned int*>(ctx->bin_recs) : nullptr,        // march in tile-sorted order
@@ -1687,6 +1706,86 @@ static int normal_exchange(emap_ctx* ctx) {
   return EMAP_OK;
 }
 
+// ---- rays by ray (emap_kernels.hip: k_win_pack / k_win_prepare / k_win_unpack) ---------------------------------------------------
+// Decided from values every rank shares (parameters, world size, cloud size): all ranks take the same branch of the collective code.
+static bool frame_binned_everywhere(const emap_ctx* ctx) {      // emap_count's choice, for a cloud of this size
+  return ctx->n_pts > 0 && (ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts >= 131072));
+}
+static bool rays_by_ray(const emap_ctx* ctx) {
+  if (!ctx->rccl || ctx->comm_world <= 1 || !ctx->prm.enable_visibility_cleanup || ctx->ray_mode == 1) return false;
+  if (!frame_binned_everywhere(ctx)) return false;                // the window march walks the frame's tile-sorted records
+  // by row below 2048^2 cells: the window exchange (three all-reduces) costs about what the whole pass costs there
+  return ctx->ray_mode == 2 || ctx->prm.cell_n >= 2048;
+}
+// the window of this frame: everything within reach of a ray of at most max_ray_length that starts at the sensor (t is map-centre
+// relative); false: no cell of the map is within reach
+static bool ray_window(const emap_ctx* ctx, const float t[3], Win* w) {
+  const emap_params& p = ctx->prm;
+  const int C = p.cell_n;
+  const double reach = p.max_ray_length * 1.01 + 4.0 * p.resolution;     // (the float16 ray direction is a unit vector to 2^-10; the sample positions are rounded to half)
+  auto lo = [&](double x) { double v = std::floor((x - reach) / p.resolution + 0.5 * C) - 2.0; return v < 0 ? 0 : (v > C ? C : (int)v); };
+  auto hi = [&](double x) { double v = std::ceil((x + reach) / p.resolution + 0.5 * C) + 3.0; return v < 0 ? 0 : (v > C ? C : (int)v); };
+  const int r_lo = lo(t[0]), r_hi = hi(t[0]), c_lo = lo(t[1]), c_hi = hi(t[1]);
+  if (r_hi <= r_lo || c_hi <= c_lo) return false;
+  w->r0 = r_lo & ~7; w->nr = ((r_hi - w->r0) + 7) & ~7;
+  w->c0 = c_lo & ~63; w->nc = ((c_hi - w->c0) + 63) & ~63;
+  return true;
+}
+static int ensure_window(emap_ctx* ctx, Win* w) {
+  const long n = (long)w->nr * w->nc;
+  if (n > ctx->win_cap) {
+    CK(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->win_state); hipFree(ctx->win_bits); hipFree(ctx->win_thr); hipFree(ctx->win_dh); hipFree(ctx->win_key);
+    ctx->win_state = nullptr; ctx->win_bits = nullptr; ctx->win_thr = nullptr; ctx->win_dh = nullptr; ctx->win_key = nullptr; ctx->win_cap = 0;
+    const long cap = n + n / 8;                                   // (the window grows a little when the sensor leaves a map edge)
+    CK(hipMalloc((void**)&ctx->win_state, sizeof(unsigned int) * 12 * (size_t)cap));      // hot 4 + cold 4 + normals 3 + inlier count 1 words per cell
+    CK(hipMalloc((void**)&ctx->win_bits, sizeof(unsigned long long) * ((size_t)cap / 64 + 2)));
+    CK(hipMalloc((void**)&ctx->win_thr, sizeof(float) * ((size_t)cap / 64 + 1)));
+    CK(hipMalloc((void**)&ctx->win_dh, sizeof(long long) * 2 * (size_t)cap));
+    CK(hipMalloc((void**)&ctx->win_key, sizeof(unsigned int) * (size_t)cap));
+    ctx->win_cap = cap;
+  }
+  w->hot = reinterpret_cast<float4*>(ctx->win_state); w->cold = w->hot + n;
+  w->normal = reinterpret_cast<float*>(w->cold + n); w->inl = ctx->win_state + 11 * n;
+  w->bits = ctx->win_bits; w->thr = ctx->win_thr; w->dh = ctx->win_dh; w->key = ctx->win_key;
+  return EMAP_OK;
+}
+// The visibility pass of a sharded frame, by ray: called where emap_rays would be, between the tile kernel and k_ray_apply.
+static int rays_by_ray_pass(emap_ctx* ctx, const float R[9], const float t[3]) {
+  Win w; memset(&w, 0, sizeof w);
+  if (!ray_window(ctx, t, &w)) return EMAP_OK;                    // the same decision on every rank: no collective is skipped one-sidedly
+  int rc = ensure_window(ctx, &w); if (rc) return rc;
+  const RcclApi* a = ctx->rccl;
+  const long n = (long)w.nr * w.nc;
+  hipStream_t st = ctx->stream;
+  // (1) the window's cells, normals and inlier counts: owners fill their rows, an exact integer all-reduce replicates them
+  CK(hipMemsetAsync(ctx->win_state, 0, sizeof(unsigned int) * 12 * (size_t)n, st));
+  launch_win_pack(st, ctx->kp, w, ctx->cells, ctx->normal, ctx->ncells_alloc, ctx->inl_plane, ctx->inert);
+  CK(hipGetLastError());
+  CKN(a->AllReduce(ctx->win_state, ctx->win_state, 12 * (size_t)n, ncclUint32, ncclSum, ctx->comm, st));
+  // (2) bitmap + block thresholds of the window, accumulators re-armed
+  launch_win_prepare(st, w, ctx->prm.cell_n);
+  CK(hipMemsetAsync(w.bits + n / 64, 0xff, sizeof(unsigned long long), st));          // the all-ones word behind the last row (k_rays' passive lanes)
+  CK(hipMemsetAsync(w.dh, 0, sizeof(long long) * 2 * (size_t)n, st));
+  CK(hipMemsetAsync(w.key, 0, sizeof(unsigned int) * (size_t)n, st));
+  // (3) the march: this rank's sorted records = the valid points of its rows, over the window
+  KP kw = ctx->kp;
+  kw.org_r = kw.org_c = kw.norg_r = kw.norg_c = 0; kw.mv.n = 0;
+  kw.row0 = w.r0; kw.nrows = w.nr; kw.halo = 0; kw.col0 = w.c0; kw.ncols = w.nc; kw.pitch = w.nc; kw.wmode = 1;
+  Cells wc; wc.hot = w.hot; wc.cold = w.cold;
+  char* const db = reinterpret_cast<char*>(w.dh);
+  const AccRView av = {db, db + 8, reinterpret_cast<char*>(w.key), 16, 16, 4, 0};
+  launch_rays(st, kw, make_pose(ctx, R, t), ctx->rt, ctx->pts, ctx->n_pts, ctx->stride, wc, av, w.normal, n, ctx->frame, ctx->want_ray_stats,
+              w.bits, w.inl, 1, w.thr, reinterpret_cast<const unsigned int*>(ctx->bin_recs), ctx->bin_tile_start + ctx->bg.TB);
+  CK(hipGetLastError());
+  // (4) effects back to the owners: sums of {dec, hits}, maxima of the upper-bound keys
+  CKN(a->AllReduce(w.dh, w.dh, 2 * (size_t)n, ncclInt64, ncclSum, ctx->comm, st));
+  CKN(a->AllReduce(w.key, w.key, (size_t)n, ncclUint32, ncclMax, ctx->comm, st));
+  launch_win_unpack(st, ctx->kp, w, ctx->accr);
+  CK(hipGetLastError());
+  return EMAP_OK;
+}
+
 // One frame of the strip: the stage order of ShardedElevationMap.update (sharded.py) with both exchange steps issued from
 // here -- no Python, no host synchronisation between the stages.
 int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats) {
@@ -1700,9 +1799,11 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
 #define STAGE(i) do { if (tm) CK(hipEventRecord(ctx->ev[i], ctx->stream)); } while (0)
   ctx->in_update = true;
   ctx->gate_possible = p.enable_drift_compensation && (position_noise > p.position_noise_thresh || orientation_noise > p.orientation_noise_thresh);
+  ctx->byray_frame = rays_by_ray(ctx);        // (before the sort: a by-ray frame sorts only the points of the strip's rows)
   rc = emap_count(ctx, R, t);                 // records ST_HIST / ST_SCAN / ST_SCATTER itself
   ctx->in_update = false;
-  if (rc) return rc;                          // "gate" (recorded by emap_count) = per-tile error sums + local sums + all-reduce + gate
+  if (rc) { ctx->byray_frame = false; return rc; }          // "gate" (recorded by emap_count) = per-tile error sums + local sums + all-reduce + gate
+  if (ctx->byray_frame && !ctx->frame_binned) { ctx->byray_frame = false; ctx->err = "rays by ray: this rank could not take the tile-binned path the other ranks take"; return EMAP_ERR_INVALID; }
   ctx->use_override = false;
   if ((rc = gate_impl(ctx, 0.0, 0.0, 1, ctx->comm_sums, nullptr))) return rc;                       // local sums -> device
   CKN(a->AllReduce(ctx->comm_sums, ctx->comm_sums + 2, 2, ncclFloat64, ncclSum, ctx->comm, ctx->stream));   // exchange step 1
@@ -1725,8 +1826,9 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   if (rays_on) {
     if (!fused_avg && (rc = emap_commit(ctx))) return rc;
     STAGE(ST_RAYS);
-    if (ctx->comm_world > 1 && normal_row_lag(ctx) != 0 && (rc = normal_exchange(ctx))) { ctx->rays_fused = false; return rc; }
-    rc = emap_rays(ctx, R, t);
+    if (ctx->comm_world > 1 && normal_row_lag(ctx) != 0 && (rc = normal_exchange(ctx))) { ctx->rays_fused = false; ctx->byray_frame = false; return rc; }
+    rc = ctx->byray_frame ? rays_by_ray_pass(ctx, R, t) : emap_rays(ctx, R, t);
+    ctx->byray_frame = false;
     if (rc) { ctx->rays_fused = false; return rc; }
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);

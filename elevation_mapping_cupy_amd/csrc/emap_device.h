@@ -83,6 +83,10 @@ struct Moves { int n, pad_; int org_r[EM_MAX_MOVES], org_c[EM_MAX_MOVES], sr[EM_
 
 struct KP {
   int C, mode, row0, nrows, halo, edge, dil, idx_formula;   // idx_formula: reference_fp16 cell index by the float formula (host-proven exact, build_ray_tables)
+  // k_rays only: the arrays it addresses hold `ncols` columns starting at column col0 with a row pitch of `pitch` cells -- (0, C, C) for
+  // every map / strip context; the RAY WINDOW of a multi-GPU frame (rays marched by ray owner, emap_api.hip: rays_by_ray) is a small
+  // rectangle of the map in logical coordinates with its own pitch (wmode = 1: normals are addressed like the cells)
+  int col0, ncols, pitch, wmode;
   // circular origin: logical cell (r, c) lives at physical row (r + org_r) mod C, column (c + org_c) mod C; row0 / nrows / halo
   // describe PHYSICAL rows (a strip keeps its rows when the map shifts).  norg_*: origin the stencil outputs (normal planes,
   // traversability_input) were written with -- the reference does not shift those (elevation_mapping.py:200-214).
@@ -100,6 +104,26 @@ struct RayTab {
   int small_pos, small_neg, big_pos, big_neg, nan_val;
   int formula_ok, pad_;                     // reference_fp16: trunc(clamp(fma(q, 1/res, C/2))) proven equal to the table for every half pattern
   float f_d_thresh, f_cos_thresh, f_wall;   // float thresholds equivalent to the reference's double comparisons
+};
+
+// Where k_rays accumulates its effects: the interleaved 16-byte AccR records of a context, or -- ray window of a multi-GPU frame --
+// three planes that RCCL can reduce with typed operations (sum of int64 {dec, hits} pairs, max of uint32 keys).  Byte strides.
+struct AccRView { char* dec; char* hits; char* key; int sd, sh, sk, pad_; };
+__device__ __forceinline__ long long* accr_dec(const AccRView& A, unsigned int c) { return reinterpret_cast<long long*>(A.dec + (size_t)c * A.sd); }
+__device__ __forceinline__ unsigned int* accr_hits(const AccRView& A, unsigned int c) { return reinterpret_cast<unsigned int*>(A.hits + (size_t)c * A.sh); }
+__device__ __forceinline__ unsigned int* accr_key(const AccRView& A, unsigned int c) { return reinterpret_cast<unsigned int*>(A.key + (size_t)c * A.sk); }
+
+// The ray window of a multi-GPU frame: logical rows [r0, r0 + nr) x logical columns [c0, c0 + nc) around the sensor (everything a ray of
+// at most max_ray_length can reach), r0 / nr multiples of 8, c0 / nc multiples of 64.  One buffer of 32-bit words per rank -- hot half
+// cells, cold half cells (w = "quiet" instead of valid'), three normal planes, the frame's inlier counts -- which the owners of the
+// rows fill (k_win_pack) and an exact integer all-reduce (x + 0 + ... + 0) replicates; then every rank derives the bitmap and the block
+// thresholds (k_win_prepare), marches the rays of ITS points over it (k_rays on a window KP), the effects are all-reduced (sum /
+// max) and the owners take their rows back (k_win_unpack).
+struct Win {
+  int r0, c0, nr, nc;
+  float4* hot; float4* cold; float* normal; unsigned int* inl;      // nr * nc elements each (normal: 3 planes)
+  unsigned long long* bits; float* thr;                              // nr * nc / 64 words (+ an all-ones word); (nr / 8) * (nc / 8) thresholds
+  long long* dh; unsigned int* key;                                  // {dec, hits} pairs and keys of the window's cells
 };
 
 struct Pose {        // R, t of one frame; Rq/tq are the values after the float16 parameter rounding

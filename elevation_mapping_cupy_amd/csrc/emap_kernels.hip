@@ -199,13 +199,16 @@ template <int MODE, bool STATS, int IDX, bool STRIP, int BLOCK, bool LMAP, int L
 #endif
 __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T, RayTab Rt, const float* __restrict__ pts, long n, int stride,
                                                  Cells cells,
-                                                 AccR* __restrict__ accr, const float* __restrict__ normal,
+                                                 AccRView AR, const float* __restrict__ normal,
                                                  long plane_stride, FrameDev* __restrict__ F,
                                                  const unsigned long long* __restrict__ inert64,
                                                  const unsigned int* __restrict__ inl, int inl_stride, const float* __restrict__ thr,
                                                  const unsigned int* __restrict__ order, const unsigned int* __restrict__ n_sorted) {
+  // walking sorted records: workgroups behind the last record leave before the prologue (a frame that marches its rays by ray sorts
+  // only the points of the strip's rows: most of a grid sized for the whole cloud is empty then)
+  if (order && (long)blockIdx.x * BLOCK / LPR >= (long)*n_sorted) return;
   const unsigned int* __restrict__ inert = reinterpret_cast<const unsigned int*>(inert64);   // 32-bit words: cheaper shifts
-  const unsigned int wpr32 = (unsigned int)((P.C + 63) / 64) * 2u;                           // 32-bit words per bitmap row
+  const unsigned int wpr32 = (unsigned int)((P.pitch + 63) / 64) * 2u;                       // 32-bit words per bitmap row (pitch = C; a ray window: its width)
   // LDS words: [table (span)] [s_k (nS)] [queues (BLOCK/64 * 384)]
   extern __shared__ unsigned int slut32[];
   const unsigned int span = IDX == 1 ? (unsigned int)(Rt.hi - Rt.lo) + 2u : 0u;
@@ -317,8 +320,8 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     const bool has = lane < count;
     const unsigned int xy = has ? qc[first + lane] : 0u;
     const int lix = (int)(xy >> 16), liy = (int)(xy & 0xffffu);                                   // logical cell of the visit
-    const unsigned int lrow = (unsigned int)(phys_row(P, lix) - P.row0), col = (unsigned int)phys_col(P, liy);   // owned (physical) row, column
-    const unsigned int c = (lrow + (unsigned int)P.halo) * (unsigned int)C + col;
+    const unsigned int lrow = (unsigned int)(phys_row(P, lix) - P.row0), col = (unsigned int)(phys_col(P, liy) - P.col0);   // owned (physical) row, column [of the ray window]
+    const unsigned int c = (lrow + (unsigned int)P.halo) * (unsigned int)P.pitch + col;
     const float s = has ? qz[first + lane] : 0.f;
     const int src = has ? (int)ql[first + lane] : lane;
     // Block threshold first (written by k_tile_fuse<true, true>): no cell of this 8 x 8 block can be affected by a sample at or above it
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     // exchanges, the distance test) is fetched only when some visit of the batch survives.
     const float erz = __shfl(rz, src, 64);
     const float nz = T.t[2] + erz * s;                                                   // the sample height, recomputed bit for bit
-    const float bthr = (has && thr) ? thr[(lrow >> 3) * (unsigned int)((C + 7) >> 3) + (col >> 3)] : 3.4028234664e38f;
+    const float bthr = (has && thr) ? thr[(lrow >> 3) * (unsigned int)((P.pitch + 7) >> 3) + (col >> 3)] : 3.4028234664e38f;
     const bool live = has && !(nz >= bthr);
     if (!__builtin_amdgcn_ballot_w64(live)) return;                                      // wave-uniform
     const float erx = __shfl(rx, src, 64), ery = __shfl(ry, src, 64), edec = __shfl(dec, src, 64);
@@ -340,25 +343,28 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     if (d < Rt.f_d_thresh) return;             // (double)d < 0.1: too close to the point (:225-226)
     // a VIRGIN block (+INF: every cell quiet or unknown without a bound -- a cleared map, the band a map shift brings in): the
     // visit can only lower the cell's upper bound (:228-234 with is_upper_bound < 0.5), no cell load needed
-    if (bthr == INFINITY) { ray_upper_min(&accr[c].upper_key, nz); return; }
+    if (bthr == INFINITY) { ray_upper_min(accr_key(AR, c), nz); return; }
     const float4 m0 = cells.hot[c], m1 = cells.cold[c];       // h v valid trav | time upper is_upper valid'
     if (m0.z < 0.5f) {                         // unknown cell: upper bound (:228-234)
-      if (nz < m1.y || m1.z < 0.5f) ray_upper_min(&accr[c].upper_key, nz);
+      if (nz < m1.y || m1.z < 0.5f) ray_upper_min(accr_key(AR, c), nz);
       return;
     }
     if (m1.x < 0.5f) return;                   // updated recently (:236)
     if ((double)m0.x > (double)nz + 0.01 - fmin((double)m0.y, 1.0) * 0.05) {
       // the normal planes keep the origin they were written with (the reference does not shift normal_map): logical -> their rows
       float n0 = 0.f, n1 = 0.f, n2 = 0.f;
-      const int nlr = local_row(P, wrap_up(lix + P.norg_r, C));
-      if (nlr >= 0) { const long cn = (long)nlr * C + wrap_up(liy + P.norg_c, C); n0 = normal[cn]; n1 = normal[plane_stride + cn]; n2 = normal[2 * plane_stride + cn]; }
+      if (P.wmode) { n0 = normal[c]; n1 = normal[plane_stride + c]; n2 = normal[2 * plane_stride + c]; }      // (uniform) ray window: the planes were gathered cell by cell
+      else {
+        const int nlr = local_row(P, wrap_up(lix + P.norg_r, C));
+        if (nlr >= 0) { const long cn = (long)nlr * C + wrap_up(liy + P.norg_c, C); n0 = normal[cn]; n1 = normal[plane_stride + cn]; n2 = normal[2 * plane_stride + cn]; }
+      }
       const float ip = erx * Qf<MODE>(n0) + ery * Qf<MODE>(n1) + erz * Qf<MODE>(n2);
       if (fabsf(ip) < Rt.f_cos_thresh) return;
       const float n_inl = (float)inl[(long)c * inl_stride];      // newmap[3]: drift inliers of this frame in the cell
       if (n_inl > Rt.f_wall && m1.x < 1.0f) return;
-      atomicAdd(reinterpret_cast<unsigned long long*>(&accr[c].dec), (unsigned long long)__double2ll_rn((double)edec * EM_SCALE_V));
-      atomicAdd(&accr[c].hits, 1u);
-      if (nz < m1.y || m1.z < 0.5f) ray_upper_min(&accr[c].upper_key, nz);
+      atomicAdd(reinterpret_cast<unsigned long long*>(accr_dec(AR, c)), (unsigned long long)__double2ll_rn((double)edec * EM_SCALE_V));
+      atomicAdd(accr_hits(AR, c), 1u);
+      if (nz < m1.y || m1.z < 0.5f) ray_upper_min(accr_key(AR, c), nz);
     }
   };
   // ---- the march ----------------------------------------------------------------------------------------------------------
@@ -445,11 +451,12 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     const unsigned int ix = (unsigned int)ixs, iy = (unsigned int)iys;
     // own sample & new cell (:209-210) [& owned by this strip]; border cells (:211) read as inert in the bitmap
     bool act;
-    unsigned int brow = ix;                                     // bitmap row: the logical row ...
+    unsigned int brow = ix, bcol = iy;                          // bitmap row / column: the logical row ...
     if (STRIP) {
       const bool mine = (unsigned int)(K - kb) < (unsigned int)(ke - kb);
       brow = (unsigned int)(phys_row(P, (int)ix) - P.row0);     // ... or, on strips, the local physical row (also the ownership test)
-      act = mine & (xy != prev_xy) & (brow < (unsigned int)P.nrows);
+      bcol = iy - (unsigned int)P.col0;                         // (0 on strips; a ray window starts at column col0, a multiple of 64: the bit inside the word stays iy & 31)
+      act = mine & (xy != prev_xy) & (brow < (unsigned int)P.nrows) & (bcol < (unsigned int)P.ncols);
       if (LPR == 1) last_xy = mine ? xy : last_xy;
     } else {
       act = xy != prev_xy;
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     }
     if (STATS) visits += (act && max(ix - 1u, iy - 1u) < (unsigned int)(C - 2)) ? 1u : 0u;
     unsigned int colpart;                                       // ((iy >> 3) & ~3) | LDS base: byte offset of the word within its row
-    asm("v_and_or_b32 %0, %1, %3, %2" : "=v"(colpart) : "v"(iy >> 3), "v"(base_v), "v"(mask_v));      // (no VOP3 literals on gfx9: the mask is a register)
+    asm("v_and_or_b32 %0, %1, %3, %2" : "=v"(colpart) : "v"(bcol >> 3), "v"(base_v), "v"(mask_v));      // (no VOP3 literals on gfx9: the mask is a register)
     const unsigned int off_a = mad24(brow, wpr32 * 4u, colpart);
     const unsigned int off = act ? off_a : ones_off;
     if (LMAP) w = *(const lds_u32*)(size_t)off;
@@ -545,6 +552,91 @@ __global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cells cells, AccR*
   }
   if (win) ch = overlap_cell(P, O, m) || ch;
   if (ch) cells[c] = m;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Rays by ray on row strips (multi-GPU frames, emap_api.hip: rays_by_ray).  Every ray starts at the sensor, so the strips around it
+// march what the whole map marches -- row strips do not scale the visibility pass (measured: 1.02x at 1024^2, 1.34x at 4096^2 on 8
+// ranks).  Instead every rank marches the rays of ITS points (those whose end cell lies in its rows: 1 / G of a uniform cloud, already
+// tile sorted) over a replicated copy of the RAY WINDOW -- the (2 max_ray_length / resolution)^2 cells around the sensor that any ray
+// can reach -- and the effects are reduced back to the owners of the rows.  Exactly the same visits as the row march, every effect an
+// order-independent integer accumulation: bit-identical results.
+//   k_win_pack     the owner of a window row copies its cells (hot, cold with w := quiet bit of S1 from its inert bitmap), normals
+//                  and inlier counts into the window buffer (logical coordinates: independent of the circular origin); all other
+//                  rows stay zero, an integer all-reduce (x + 0 + ... + 0: exact) then replicates the window
+//   k_win_prepare  every rank: inert bitmap (one wave ballot per 64 columns) + 8 x 8 block thresholds of the window, with the
+//                  definitions of k_tile_fuse<true, true> evaluated on the gathered cells (below: why the post-average cell suffices)
+//   k_win_unpack   after the all-reduce of the effects: the owners move their rows into their AccR records (k_ray_apply follows)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EM_BLOCK) void k_win_pack(KP P, Win W, Cells cells, const float* __restrict__ normal, long plane_stride,
+                                                       const unsigned int* __restrict__ inl_plane, const unsigned long long* __restrict__ inert) {
+  const long k = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (k >= (long)W.nr * W.nc) return;
+  const int wr = (int)(k / W.nc), wc = (int)(k - (long)wr * W.nc), lr = W.r0 + wr, lc = W.c0 + wc;
+  if (lr >= P.C || lc >= P.C) return;
+  const int prow = phys_row(P, lr), rel = prow - P.row0;
+  if (rel < 0 || rel >= P.nrows) return;                                    // another rank's row
+  const int pcol = phys_col(P, lc);
+  const long c = (long)(rel + P.halo) * P.C + pcol;
+  const float4 h = cells.hot[c], cd = cells.cold[c];
+  const unsigned long long word = inert[(long)bitmap_row(P, prow) * ((P.C + 63) / 64) + (lc >> 6)];   // bitmap: LOGICAL column, local row
+  const float quiet = ((word >> (lc & 63)) & 1ull) ? 1.0f : 0.0f;
+  W.hot[k] = h;
+  W.cold[k] = make_float4(cd.x, cd.y, cd.z, quiet);
+  float n0 = 0.f, n1 = 0.f, n2 = 0.f;                                       // the normal planes keep the origin they were written with (k_rays)
+  const int nlr = local_row(P, wrap_up(lr + P.norg_r, P.C));
+  if (nlr >= 0) { const long cn = (long)nlr * P.C + wrap_up(lc + P.norg_c, P.C); n0 = normal[cn]; n1 = normal[plane_stride + cn]; n2 = normal[2 * plane_stride + cn]; }
+  const long wn = (long)W.nr * W.nc;
+  W.normal[k] = n0; W.normal[wn + k] = n1; W.normal[2 * wn + k] = n2;
+  W.inl[k] = inl_plane[c];
+}
+// One workgroup = 8 window rows x 64 columns.  quiet = the bit the owner's tile kernel derived from snapshot S1.  The visit threshold
+// of a cell that is NOT quiet is a function of (valid, h, upper, is_upper), and for such a cell the averaged state the window holds
+// equals S1 in those fields: it was not fused this frame (a fused cell is known and fresh, i.e. quiet), so commit only touched its
+// variance and the averaging pass left it alone or reset an already unknown cell's (h, v) -- neither enters the threshold of an
+// unknown cell.  Cells beyond the map are inert.
+__global__ __launch_bounds__(512) void k_win_prepare(Win W, int C) {
+  __shared__ unsigned int s_thr[8], s_other[8];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6, wr = blockIdx.y * 8 + tr, wc = blockIdx.x * 64 + tc;
+  if (threadIdx.x < 8) { s_thr[threadIdx.x] = 0u; s_other[threadIdx.x] = 0u; }
+  __syncthreads();
+  const long k = (long)wr * W.nc + wc;
+  bool quiet = true, other = false;
+  float visit_thr = -INFINITY;
+  if (W.r0 + wr < C && W.c0 + wc < C) {
+    const float4 h = W.hot[k], cd = W.cold[k];
+    quiet = cd.w != 0.0f;
+    if (!quiet) {
+      visit_thr = h.z < 0.5f ? ((cd.z < 0.5f || !(cd.y <= 3.0e38f)) ? INFINITY : cd.y) : h.x + 0.05f;
+      if (!(visit_thr >= -INFINITY)) visit_thr = INFINITY;
+      other = !(h.z < 0.5f && cd.z < 0.5f);
+    }
+  }
+  const unsigned long long bits = __ballot(quiet);
+  if (tc == 0) W.bits[(long)wr * (W.nc >> 6) + blockIdx.x] = bits;
+  unsigned int o = float_ord(visit_thr);
+  o = max(o, (unsigned int)__shfl_xor((int)o, 1, 64)); o = max(o, (unsigned int)__shfl_xor((int)o, 2, 64)); o = max(o, (unsigned int)__shfl_xor((int)o, 4, 64));
+  const unsigned long long ob = __ballot(other);
+  if ((tc & 7) == 0) { atomicMax(&s_thr[tc >> 3], o); if ((ob >> tc) & 0xffull) s_other[tc >> 3] = 1u; }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    float bt = ord_float(s_thr[threadIdx.x]);
+    if (bt == INFINITY && s_other[threadIdx.x]) bt = 3.4028234664e38f;       // +INF only for virgin blocks (k_tile_fuse)
+    W.thr[(long)blockIdx.y * (W.nc >> 3) + blockIdx.x * 8 + threadIdx.x] = bt;
+  }
+}
+__global__ __launch_bounds__(EM_BLOCK) void k_win_unpack(KP P, Win W, AccR* __restrict__ accr) {
+  const long k = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (k >= (long)W.nr * W.nc) return;
+  const long long dec = W.dh[2 * k], hits = W.dh[2 * k + 1];
+  const unsigned int key = W.key[k];
+  if (!(dec | hits | (long long)key)) return;
+  const int wr = (int)(k / W.nc), wc = (int)(k - (long)wr * W.nc), lr = W.r0 + wr, lc = W.c0 + wc;
+  if (lr >= P.C || lc >= P.C) return;
+  const int rel = phys_row(P, lr) - P.row0;
+  if (rel < 0 || rel >= P.nrows) return;
+  AccR r; r.dec = dec; r.hits = (unsigned int)hits; r.upper_key = key;
+  accr[(long)(rel + P.halo) * P.C + phys_col(P, lc)] = r;
 }
 
 // clear_overlap_map (elevation_mapping.py:393-410): centred window, one launch instead of ~12
@@ -1075,7 +1167,7 @@ void launch_ray_apply(hipStream_t s, const KP& P, Cells cells, AccR* accr, unsig
 #define RAY_BLOCK 1024
 #endif
 template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
-                                                                              long n, int stride, Cells cells, AccR* accr,
+                                                                              long n, int stride, Cells cells, const AccRView& accr,
                                                                               const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert,
                                                                               const unsigned int* inl, int inl_stride, const float* thr, const unsigned int* order, const unsigned int* n_sorted) {
   constexpr int SMALL_BLOCK = 256, SMALL_LPR = 4;
@@ -1085,8 +1177,8 @@ template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(h
   const int block = small ? SMALL_BLOCK : RAY_BLOCK;
   const int lpr = small ? SMALL_LPR : 1;
   const size_t lds = (IDX == 1 ? (((size_t)(Rt.hi - Rt.lo) + 2 + 3) & ~(size_t)3) * 4 : 0) + (size_t)(((Rt.nS + 3) & ~3) + 8 * lpr) * 4 + (size_t)(block / 64) * 3 * 128 * 4;
-  size_t map_bytes = ((size_t)P.nrows * ((P.C + 63) / 64) * 2 + 2) * 4;       // bitmap + the all-ones word ...
-  { size_t al = 4; while (al < (size_t)((P.C + 63) / 64) * 8) al <<= 1; map_bytes += al; }      // ... + alignment to the row pitch
+  size_t map_bytes = ((size_t)P.nrows * ((P.pitch + 63) / 64) * 2 + 2) * 4;       // bitmap + the all-ones word ...
+  { size_t al = 4; while (al < (size_t)((P.pitch + 63) / 64) * 8) al <<= 1; map_bytes += al; }      // ... + alignment to the row pitch
   static const bool lmap_off = getenv("EMAP_RAY_LMAP") && atoi(getenv("EMAP_RAY_LMAP")) == 0;     // tuning / test hook
   const bool lmap = !lmap_off && !small && lds + map_bytes <= 158 * 1024;             // (small clouds: staging the bitmap per workgroup would dominate)
   dim3 g((unsigned int)((n * lpr + block - 1) / block)), b(block);
@@ -1100,10 +1192,10 @@ template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(h
   else go(k_rays<MODE, STATS, IDX, STRIP, RAY_BLOCK, false, 1>, raised0, lds);
 }
 template <int MODE, bool STATS> static void launch_rays_t(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
-                                                          long n, int stride, Cells cells, AccR* accr,
+                                                          long n, int stride, Cells cells, const AccRView& accr,
                                                           const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert,
                                                           const unsigned int* inl, int inl_stride, const float* thr, const unsigned int* order, const unsigned int* n_sorted) {
-  const bool strip = P.nrows < P.C;
+  const bool strip = P.nrows < P.C || P.wmode;          // (a ray window is addressed like a strip: offset rows and columns, own pitch)
   // index method (AxisIdx): the float formula when the host proved it exact (reference_fp16) or when it IS the definition (fp32);
   // else the half -> index table if it fits the default LDS window next to the step table; else the defining arithmetic
   int idx = 0;
@@ -1120,7 +1212,7 @@ template <int MODE, bool STATS> static void launch_rays_t(hipStream_t s, const K
 // `thr`: per 8 x 8 block visit threshold of k_tile_fuse<true, true> (nullptr: no filter).  `inl` / `inl_stride`: per-cell drift-inlier counts of the frame (newmap[3]) as 32-bit words with an element stride -- the dense
 // plane of the tile kernel (stride 1) or the high halves of AccF::pts_inl (stride 10, offset 1) on the staged / atomic path
 void launch_rays(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts, long n, int stride, Cells cells,
-                 AccR* accr, const float* normal, long plane_stride, FrameDev* F, bool stats,
+                 const AccRView& accr, const float* normal, long plane_stride, FrameDev* F, bool stats,
                  const unsigned long long* inert, const unsigned int* inl, int inl_stride, const float* thr,
                  const unsigned int* order, const unsigned int* n_sorted) {
   if (n <= 0) return;
@@ -1131,6 +1223,15 @@ void launch_rays(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, co
     if (stats) launch_rays_t<1, true>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
     else launch_rays_t<1, false>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
   }
+}
+void launch_win_pack(hipStream_t s, const KP& P, const Win& W, Cells cells, const float* normal, long plane_stride, const unsigned int* inl_plane, const unsigned long long* inert) {
+  hipLaunchKernelGGL(k_win_pack, dim3(nblk((long)W.nr * W.nc)), dim3(EM_BLOCK), 0, s, P, W, cells, normal, plane_stride, inl_plane, inert);
+}
+void launch_win_prepare(hipStream_t s, const Win& W, int C) {
+  hipLaunchKernelGGL(k_win_prepare, dim3(W.nc / 64, W.nr / 8), dim3(512), 0, s, W, C);
+}
+void launch_win_unpack(hipStream_t s, const KP& P, const Win& W, AccR* accr) {
+  hipLaunchKernelGGL(k_win_unpack, dim3(nblk((long)W.nr * W.nc)), dim3(EM_BLOCK), 0, s, P, W, accr);
 }
 void launch_average(hipStream_t s, const KP& P, Cells cells, AccF* acc, AccR* accr, const FrameDev* F, bool committed, bool rays,
                     unsigned int* cnt_out, const OverlapArgs& O) {

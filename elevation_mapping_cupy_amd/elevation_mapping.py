@@ -195,6 +195,11 @@ class ElevationMap:
         ``bin_stack`` (test hook) forces bins of that many stacked 16x64 tiles, as maps beyond 16384 tiles use."""
         self._chk(self._lib.emap_set_scatter_mode(self._ctx, {"auto": 0, "atomic": 1, "binned": 2}[mode] | (int(bin_stack) << 8)))
 
+    def set_ray_mode(self, mode):
+        """"auto" | "by_row" | "by_ray": how a SHARDED frame (emap_update_sharded) runs the visibility pass (include/emap_hip.h:
+        emap_set_ray_mode; bit-identical results, every rank the same setting)"""
+        self._chk(self._lib.emap_set_ray_mode(self._ctx, {"auto": 0, "by_row": 1, "by_ray": 2}[mode]))
+
     def reload_params(self):
         """Push changed ``self.param`` scalars to the device (kernargs, no recompilation)."""
         P = _lib.fill_params(self.param, self.cell_n, self.index_mode)

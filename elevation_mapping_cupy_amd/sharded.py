@@ -478,7 +478,8 @@ def bench_main(a, rank, world, local_rank):
     par = parameter_from(cfg, C, a.mode, weights, device=local_rank)
     # frames with the visibility pass: strips of equal ray work (thin around the sensor) instead of equal height
     row_w = None
-    if cfg["enable_visibility_cleanup"] and world > 1 and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
+    # (from 2048^2 cells on the sharded frame marches its rays BY RAY -- emap_set_ray_mode -- and equal heights are right again)
+    if cfg["enable_visibility_cleanup"] and world > 1 and C < 2048 and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
         row_w = ray_balanced_weights(C, float(cfg["resolution"]), float(cfg["max_ray_length"]), halo_rows_needed(cfg["dilation_size"], world), world)
     eng = HipStripEngine(par, rank, world, local_rank, dev, row_w)
     comm, comm_kind = None, ("torch" if oversubscribed else os.environ.get("EMAP_COMM", "native"))

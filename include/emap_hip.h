@@ -285,6 +285,14 @@ int emap_comm_allreduce_host(emap_ctx* ctx, double* inout, int32_t n, int32_t op
 int emap_comm_gather_layer(emap_ctx* ctx, int32_t plane, float* host_full_out);
 int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise,
                         emap_stats* stats /* may be NULL: no host synchronisation */);
+/* How a sharded frame runs the visibility pass (the ray part of add_points_kernel, EM/kernels/custom_kernels.py:198-259; the
+ * reference is single GPU).  Every ray starts at the sensor, so with rays marched BY ROW (each rank marches every ray through its
+ * own rows) the strips around the sensor do what the whole map does.  BY RAY: every rank marches the rays of the points of its rows
+ * over a replicated copy of the cells a ray can reach (one exact integer all-reduce of the window around the sensor), the effects
+ * are all-reduced (sum of the validity decrements and hit counts, max of the upper-bound keys) and the owners apply their rows:
+ * the same visits, bit-identical maps.  mode 0 = automatic (by ray from 2048 x 2048 cells on, frames on the tile-binned path),
+ * 1 = always by row, 2 = by ray whenever the frame is on the tile-binned path.  Every rank must use the same mode. */
+int emap_set_ray_mode(emap_ctx* ctx, int32_t mode);
 
 /* ---- timing on the context's stream (hipEvents; bench.py's roofline leg) -------------------------- */
 int emap_timer_begin(emap_ctx* ctx);

@@ -31,6 +31,15 @@ static int g_next = 1;
 static thread_local int t_depth = 0;
 static thread_local std::vector<Op> t_ops;
 
+template <class T>
+static void host_reduce(const std::vector<std::vector<char>>& in, std::vector<char>& out, size_t count, int op) {
+  T* o = reinterpret_cast<T*>(out.data());
+  for (size_t k = 0; k < count; ++k) {
+    T acc = reinterpret_cast<const T*>(in[0].data())[k];
+    for (size_t r = 1; r < in.size(); ++r) { const T x = reinterpret_cast<const T*>(in[r].data())[k]; acc = (op == 0) ? (T)(acc + x) : (x > acc ? x : acc); }
+    o[k] = acc;
+  }
+}
 extern "C" {
 ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
   std::lock_guard<std::mutex> l(g_m);
@@ -58,26 +67,25 @@ ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) { *count = comm->n
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "fake rccl error"; }
 
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op, ncclComm_t c, hipStream_t stream) {
-  if ((dtype != 8 && dtype != 7) || (op != 0 && op != 2)) return ncclInvalidArgument;  // ncclFloat64 / ncclFloat32 with ncclSum / ncclMax: all the path uses
+  // ncclFloat64 (8) / ncclFloat32 (7) / ncclInt64 (4) / ncclUint32 (3) with ncclSum (0) / ncclMax (2): all the path uses (ranks reduced in rank order)
+  if ((dtype != 8 && dtype != 7 && dtype != 4 && dtype != 3) || (op != 0 && op != 2)) return ncclInvalidArgument;
   if (hipStreamSynchronize(stream) != hipSuccess) return ncclInternalError;
-  const size_t esz = dtype == 8 ? 8 : 4;
+  const size_t esz = (dtype == 8 || dtype == 4) ? 8 : 4;
   Shared* sh = c->sh;
   std::unique_lock<std::mutex> l(sh->m);
   const int gen = sh->ar_gen;
   sh->ar_src[c->rank] = send; sh->ar_dst[c->rank] = recv; sh->ar_count = count;
   if (++sh->ar_arrived == sh->nranks) {
-    std::vector<double> tot(count, 0.0);
-    std::vector<char> raw(count * esz);
-    for (int r = 0; r < sh->nranks; ++r) {
-      if (hipMemcpy(raw.data(), sh->ar_src[r], count * esz, hipMemcpyDeviceToHost) != hipSuccess) return ncclInternalError;
-      for (size_t k = 0; k < count; ++k) {
-        const double x = dtype == 8 ? reinterpret_cast<const double*>(raw.data())[k] : (double)reinterpret_cast<const float*>(raw.data())[k];
-        tot[k] = (op == 0) ? tot[k] + x : (r == 0 ? x : (x > tot[k] ? x : tot[k]));
-      }
-    }
-    if (dtype == 7) { float* f = reinterpret_cast<float*>(raw.data()); for (size_t k = 0; k < count; ++k) f[k] = (float)tot[k]; }
+    std::vector<std::vector<char>> in(sh->nranks, std::vector<char>(count * esz));
+    std::vector<char> out(count * esz);
     for (int r = 0; r < sh->nranks; ++r)
-      if (hipMemcpy(sh->ar_dst[r], dtype == 8 ? (const void*)tot.data() : (const void*)raw.data(), count * esz, hipMemcpyHostToDevice) != hipSuccess) return ncclInternalError;
+      if (hipMemcpy(in[r].data(), sh->ar_src[r], count * esz, hipMemcpyDeviceToHost) != hipSuccess) return ncclInternalError;
+    if (dtype == 8) host_reduce<double>(in, out, count, op);
+    else if (dtype == 7) host_reduce<float>(in, out, count, op);
+    else if (dtype == 4) host_reduce<long long>(in, out, count, op);
+    else host_reduce<unsigned int>(in, out, count, op);
+    for (int r = 0; r < sh->nranks; ++r)
+      if (hipMemcpy(sh->ar_dst[r], out.data(), count * esz, hipMemcpyHostToDevice) != hipSuccess) return ncclInternalError;
     sh->ar_arrived = 0; sh->ar_gen++;
     sh->cv.notify_all();
   } else sh->cv.wait(l, [&] { return sh->ar_gen != gen; });

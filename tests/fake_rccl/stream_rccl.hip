@@ -71,6 +71,12 @@ __global__ void k_allreduce(SrcTab src, int n, T* __restrict__ dst, size_t count
   }
 }
 
+template <class T>
+static void launch_allreduce(const SrcTab& tab, int nsrc, void* recv, size_t count, int op, hipStream_t stream) {
+  const unsigned int blocks = (unsigned int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+  if (op == 0) hipLaunchKernelGGL((k_allreduce<T, false>), dim3(blocks), dim3(256), 0, stream, tab, nsrc, (T*)recv, count);
+  else hipLaunchKernelGGL((k_allreduce<T, true>), dim3(blocks), dim3(256), 0, stream, tab, nsrc, (T*)recv, count);
+}
 extern "C" {
 ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
   std::lock_guard<std::mutex> l(g_m);
@@ -105,9 +111,10 @@ const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no e
 #define HK(call) do { if ((call) != hipSuccess) { std::lock_guard<std::mutex> l_(sh->m); sh->failed = true; sh->cv.notify_all(); return ncclInternalError; } } while (0)
 
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op, ncclComm_t c, hipStream_t stream) {
-  if ((dtype != 8 && dtype != 7) || (op != 0 && op != 2)) return ncclInvalidArgument;  // ncclFloat64 / ncclFloat32 with ncclSum / ncclMax: all the path uses
+  // ncclFloat64 (8) / ncclFloat32 (7) / ncclInt64 (4) / ncclUint32 (3) with ncclSum (0) / ncclMax (2): all the path uses
+  if ((dtype != 8 && dtype != 7 && dtype != 4 && dtype != 3) || (op != 0 && op != 2)) return ncclInvalidArgument;
   Shared* sh = c->sh; const int me = c->rank, n = c->nranks;
-  const size_t bytes = count * (dtype == 8 ? 8 : 4);
+  const size_t bytes = count * ((dtype == 8 || dtype == 4) ? 8 : 4);
   if (bytes > sh->slot_cap[me]) {                       // (growing the staging slot synchronises the device: only the first call of a size does)
     if (sh->slot[me]) HK(hipFree(sh->slot[me]));
     sh->slot[me] = nullptr; sh->slot_cap[me] = 0;
@@ -121,11 +128,10 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, int dtype
   if (sh->loopback) tab.p[0] = sh->slot[me];
   else for (int r = 0; r < n; ++r) { tab.p[r] = sh->slot[r]; if (r != me) HK(hipStreamWaitEvent(stream, sh->ready[r], 0)); }
   const int nsrc = sh->loopback ? 1 : n;
-  const unsigned int blocks = (unsigned int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
-  if (dtype == 8) { if (op == 0) hipLaunchKernelGGL((k_allreduce<double, false>), dim3(blocks), dim3(256), 0, stream, tab, nsrc, (double*)recv, count);
-                    else hipLaunchKernelGGL((k_allreduce<double, true>), dim3(blocks), dim3(256), 0, stream, tab, nsrc, (double*)recv, count); }
-  else { if (op == 0) hipLaunchKernelGGL((k_allreduce<float, false>), dim3(blocks), dim3(256), 0, stream, tab, nsrc, (float*)recv, count);
-         else hipLaunchKernelGGL((k_allreduce<float, true>), dim3(blocks), dim3(256), 0, stream, tab, nsrc, (float*)recv, count); }
+  if (dtype == 8) launch_allreduce<double>(tab, nsrc, recv, count, op, stream);
+  else if (dtype == 7) launch_allreduce<float>(tab, nsrc, recv, count, op, stream);
+  else if (dtype == 4) launch_allreduce<long long>(tab, nsrc, recv, count, op, stream);
+  else launch_allreduce<unsigned int>(tab, nsrc, recv, count, op, stream);
   HK(hipGetLastError());
   HK(hipEventRecord(sh->done[me], stream));
   if (!barrier(sh)) return ncclInternalError;

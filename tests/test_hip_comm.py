@@ -70,7 +70,7 @@ def _fake_rccl(kind="blocking"):
     return rccl_stand_in(kind)
 
 
-def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_fp16", check_gather=None, stand_in="blocking"):
+def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_fp16", check_gather=None, stand_in="blocking", ray_mode="auto"):
     """frames = [(cloud, R, t, position_noise, orientation_noise, n_update_time, move_to vector or None), ...]: one single-context
     map and `world` strip contexts (threads, in-process RCCL stand-in) run the same frames; every strip must equal the rows of the
     single-context map bit for bit.  Returns nothing; asserts."""
@@ -103,6 +103,7 @@ def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_f
         try:
             eng = HipStripEngine(parameter_from(cfg, C, mode, weights), rank, world, 0, dev)
             eng.map.set_scatter_mode(scatter)
+            eng.map.set_ray_mode(ray_mode)
             comm = NativeComm(eng, rank=rank, world=world, bootstrap=False, uid=bytes(uid), rccl_path=lib_path)
             comm.selftest()
             assert comm.rccl_ranks() == world
@@ -187,4 +188,24 @@ def test_fuzz_strips_bitwise(k, weights):
         noise = 1.0 if rng.random() < 0.6 else 0.0
         mv = (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.3, 0.3)), 0.0) if (f < 2 and rng.random() < 0.5) else None     # <= 7 rows: the halo ring hands the seam rows round
         frames.append((p, R, t, noise, noise, int(rng.integers(0, 9)), mv))
-    _strips_vs_single(world, cfg, C, frames, scatter, weights, mode=mode, stand_in="stream" if k % 2 else "blocking")
+    _strips_vs_single(world, cfg, C, frames, scatter, weights, mode=mode, stand_in="stream" if k % 2 else "blocking",
+                      ray_mode=["auto", "by_ray", "by_ray"][int(rng.integers(0, 3))])          # (by ray takes effect on the tile-binned frames with a visibility pass)
+
+
+@pytest.mark.parametrize("stand_in", ["blocking", "stream"])
+@pytest.mark.parametrize("world,cfg_name,C,N,moves", [(2, "yaml", 130, 40000, False), (3, "yaml", 202, 60000, True), (4, "default", 300, 60000, True),
+                                                      (8, "default", 300, 90000, False), (4, "default_fp32", 421, 70000, True)])
+def test_rays_by_ray_reproduce_the_single_context(world, cfg_name, C, N, moves, stand_in, weights):
+    """The visibility pass of a sharded frame BY RAY (emap_set_ray_mode 2): every rank marches the rays of the points of its rows over
+    the all-reduced window around the sensor, the effects are all-reduced back to the owners of the rows -- the same visits as on
+    one GPU, so every strip must equal the rows of the single-context map bit for bit.  `yaml`: max_ray_length 10 m, the window is
+    the whole map; `default`: 2 m, a real sub-window (about 116 x 128 cells of a 300^2 map) whose position follows the sensor;
+    with map moves the circular origin, the normals' own origin and the ring of strips are exercised as well."""
+    from oracle import emap_oracle as eo
+    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML if cfg_name.startswith("yaml") else {})
+    cfg["enable_visibility_cleanup"] = True
+    mode = "fp32" if cfg_name.endswith("fp32") else "reference_fp16"
+    R, t = fx.POSES["rotated"]
+    MV = [(0.13, -0.3, 0.05), (-0.10, 0.17, -0.02), None] if moves else [None] * 3
+    frames = [(fx.cloud(C, N, f, dz=dz), R, t + np.array([0.4 * f, -0.3 * f, 0], np.float32), 1.0, 1.0, 6, mv) for (f, dz), mv in zip(enumerate((0.0, -0.02, -0.1)), MV)]
+    _strips_vs_single(world, cfg, C, frames, "binned", weights, mode=mode, stand_in=stand_in, ray_mode="by_ray")

@@ -43,7 +43,7 @@ class _DeviceClouds:
             self.hip.hipFree(d)
 
 
-def _sharded_vs_single(world, cfg, C, clouds, channels, fusions, ticks, weights, stand_in="stream"):
+def _sharded_vs_single(world, cfg, C, clouds, channels, fusions, ticks, weights, stand_in="stream", ray_mode="auto"):
     import torch
     from elevation_mapping_cupy_amd.configs import parameter_from
     from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
@@ -74,6 +74,7 @@ def _sharded_vs_single(world, cfg, C, clouds, channels, fusions, ticks, weights,
     def run(rank):
         try:
             eng = HipStripEngine(par(), rank, world, 0, dev)
+            eng.map.set_ray_mode(ray_mode)
             comm = NativeComm(eng, rank=rank, world=world, bootstrap=False, uid=bytes(uid), rccl_path=lib_path)
             assert comm.rccl_ranks() == world
             sm = ShardedElevationMap(eng, comm, cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
@@ -123,14 +124,16 @@ def _sharded_vs_single(world, cfg, C, clouds, channels, fusions, ticks, weights,
     return n_valid
 
 
-@pytest.mark.parametrize("rays", [False, True])
-def test_config4_4096_over_4_ranks_sharded_frame(rays, weights):
-    """BASELINE configs[3]: 4096^2 over 4 ranks.  Without the visibility pass the strips run the STRIP sort variants at size (4 M
-    points, 253 blocks); with it every valid point marches its ray through the strip and the ray-only bin is used."""
+@pytest.mark.parametrize("rays,world", [(None, 4), ("by_row", 4), ("by_ray", 4), ("by_ray", 8)])
+def test_config4_4096_sharded_frame(rays, world, weights):
+    """BASELINE configs[3]: 4096^2 over 4 ranks (and 8).  Without the visibility pass the strips run the STRIP sort variants at size (4 M
+    points, 253 blocks).  With it: BY ROW every valid point marches its ray through the strip (ray-only bin, the non-strip sort
+    kernels); BY RAY -- what such a map selects by itself -- every rank sorts and marches only the points of its rows over the
+    all-reduced 520 x 576-cell window around the sensor, and the effects come back through two integer all-reduces."""
     C, N = 4096, 4_000_000
-    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML, enable_visibility_cleanup=rays)
+    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML, enable_visibility_cleanup=rays is not None)
     clouds = [fx.cloud(C, N, 90 + f, dz=dz) for f, dz in enumerate((0.0, -0.12))]
-    n_valid = _sharded_vs_single(4, cfg, C, clouds, None, None, 8, weights)
+    n_valid = _sharded_vs_single(world, cfg, C, clouds, None, None, 8, weights, ray_mode=rays or "auto")
     assert n_valid > 1_500_000
 
 

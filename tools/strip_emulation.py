@@ -44,6 +44,8 @@ def main():
                     "(sharded.ray_balanced_weights: thin around the sensor) unless --equal-strips")
     ap.add_argument("--equal-strips", action="store_true")
     ap.add_argument("--no-lockstep", action="store_true")
+    ap.add_argument("--ray-mode", default="auto", choices=["auto", "by_row", "by_ray"], help="with --rays: how the sharded frame runs the visibility "
+                    "pass (emap_set_ray_mode; auto = by ray from 2048^2 cells on)")
     a = ap.parse_args()
     import bench
     from _util import rccl_stand_in
@@ -69,6 +71,7 @@ def main():
     Rp, tp = _lib.f32p(R), _lib.f32p(t)
     channels = ["rgb", "sem0", "sem1", "sem2"] if multimodal else None
     stand_in = rccl_stand_in("stream").encode()
+    by_ray = a.rays and (a.ray_mode == "by_ray" or (a.ray_mode == "auto" and C >= 2048))
 
     def make_rank(G, rank, loopback):
         """strip context + communicator of one rank; returns (map, frame function)"""
@@ -77,7 +80,7 @@ def main():
             par.pointcloud_channel_fusions = {"rgb": "color", "default": "average"}
         halo = sharded.halo_rows_needed(par.dilation_size, G)
         row_w = None
-        if a.rays and G > 1 and not a.equal_strips:
+        if a.rays and G > 1 and not a.equal_strips and not by_ray:      # (by ray: every rank marches the rays of its own points -- equal heights)
             row_w = sharded.ray_balanced_weights(C, float(cfg["resolution"]), float(cfg["max_ray_length"]), halo, G)
         r0, r1 = sharded.strip_rows(C, G, rank, row_w)
         em = ElevationMap(par, strip=(r0, r1 - r0, halo) if G > 1 else None)
@@ -85,6 +88,7 @@ def main():
         if multimodal:
             em.semantic_map.prepare(channels)
         em._rows01 = [int(r0), int(r1)]
+        em.set_ray_mode(a.ray_mode)
         return em
 
     def frame_fn(em, sharded_frame):
@@ -164,11 +168,14 @@ def main():
                       "frame_ms_sharded_world1_real_rccl": None if rccl_world1_ms is None else round(rccl_world1_ms, 5)},
            "splits": {}}
 
+    out["ray_mode"] = ("by ray" if by_ray else "by row") if a.rays else None
     for G in [g for g in a.gs if g > 1]:
         # ---- solo: every rank alone, loop-back collectives ----------------------------------------------------------------------------
+        # (not with rays by ray: a rank alone sees only its own rows in the all-reduced ray window -- every other cell reads as unknown,
+        #  and the march would queue a visit for each of them; the lockstep run below has the real window)
         os.environ["STREAM_RCCL_LOOPBACK"] = "1"
         solo, stages, rows = [], [], []
-        for rank in range(G):
+        for rank in range(G if not by_ray else 0):
             em = make_rank(G, rank, True)
             comm_init(em, new_uid(em._lib), rank, G)
             fr = frame_fn(em, True)
@@ -180,11 +187,13 @@ def main():
             em._lib.emap_comm_destroy(em._ctx)
             em.close()
         os.environ["STREAM_RCCL_LOOPBACK"] = "0"
-        slow = int(np.argmax(solo))
-        sp = {"rows": rows, "solo_frame_ms_per_rank": [round(v, 5) for v in solo], "solo_frame_ms_max": round(max(solo), 5),
-              "solo_frame_ms_sum": round(sum(solo), 5), "stage_ms_net_slowest_rank": stages[slow], "stage_ms_net_rank0": stages[0],
-              "hist_plus_scatter_ms_max": round(max(s["hist"] + s["scatter"] for s in stages), 5),
-              "speedup_solo_no_wire": round(single_ms / max(solo), 3)}
+        sp = {}
+        if solo:
+            slow = int(np.argmax(solo))
+            sp = {"rows": rows, "solo_frame_ms_per_rank": [round(v, 5) for v in solo], "solo_frame_ms_max": round(max(solo), 5),
+                  "solo_frame_ms_sum": round(sum(solo), 5), "stage_ms_net_slowest_rank": stages[slow], "stage_ms_net_rank0": stages[0],
+                  "hist_plus_scatter_ms_max": round(max(s["hist"] + s["scatter"] for s in stages), 5),
+                  "speedup_solo_no_wire": round(single_ms / max(solo), 3)}
         # ---- lockstep: all ranks alive, collectives really meet ---------------------------------------------------------------------
         if not a.no_lockstep:
             ems = [make_rank(G, r, False) for r in range(G)]
@@ -221,7 +230,7 @@ def main():
                 em.close()
             lock = float(np.median(walls))
             sp.update({"lockstep_frame_ms_all_ranks_one_gpu": round(lock, 5), "work_inflation_vs_single": round(lock / single_ms, 3),
-                       "speedup_bound_from_lockstep": round(G * single_ms / lock, 3)})
+                       "lockstep_ms_per_rank_average": round(lock / G, 5), "speedup_bound_from_lockstep": round(G * single_ms / lock, 3)})
         out["splits"][str(G)] = sp
 
     # ---- the wire: cannot be measured on one GPU ------------------------------------------------------------------------------------
@@ -231,7 +240,9 @@ def main():
             "projected_speedup": {}}
     for G in [g for g in a.gs if g > 1]:
         sp = out["splits"][str(G)]
-        wire["projected_speedup"][str(G)] = {"wire_%d_us" % us: round(single_ms / (sp["solo_frame_ms_max"] + us * 1e-3), 3) for us in (0, 20, 60, 100)}
+        per_rank = sp.get("solo_frame_ms_max", sp.get("lockstep_ms_per_rank_average"))      # (rays by ray: the lockstep average -- uniform clouds give every rank N / G rays)
+        if per_rank:
+            wire["projected_speedup"][str(G)] = {"wire_%d_us" % us: round(single_ms / (per_rank + us * 1e-3), 3) for us in (0, 20, 60, 100)}
     out["wire"] = wire
     print(json.dumps(out))
 
