@@ -85,6 +85,8 @@ def parse(argv=None):
     ap.add_argument("--mode", default="reference_fp16", choices=["reference_fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the config.cfg3 and config.cfg1 sub-measurements of the default cfg2 line")
+    ap.add_argument("--interleaved-cloud", action="store_true", help="cfg5: bind the multi-modal cloud as interleaved (N, 3 + K) device rows instead of "
+                    "the de-interleaved layout an uploaded cloud has (emap_upload_points)")
     ap.add_argument("--no-large", action="store_true", help="skip the config.cfg4 / config.cfg5 sub-measurements (4096^2 and 8192^2 on one GPU) of the default line")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
     ap.add_argument("--scatter", default="auto", choices=["auto", "atomic", "binned"])
@@ -198,6 +200,37 @@ def host_clouds(a, C, N, multimodal):
                 key = np.arctan2(p_[:, 1], p_[:, 0])
             clouds[k_] = np.ascontiguousarray(p_[np.argsort(key, kind="stable")])
     return clouds
+
+
+def device_clouds(hip, clouds_host, split):
+    """device-resident copies of the clouds.  Clouds with extra channels are bound DE-INTERLEAVED by default -- an (N, 3) xyz matrix and
+    an (N, K) channel matrix, the layout emap_upload_points (input_pointcloud) gives every uploaded cloud -- or, with split = False,
+    as the interleaved (N, 3 + K) rows update_map_with_kernel takes from a caller that already holds a device array"""
+    out = []
+    for p in clouds_host:
+        K = p.shape[1] - 3
+        if split and K > 0:
+            xyz, ch = np.ascontiguousarray(p[:, :3]), np.ascontiguousarray(p[:, 3:])
+            dx = hip.malloc(xyz.nbytes); hip.h2d(dx, xyz)
+            dc = hip.malloc(ch.nbytes); hip.h2d(dc, ch)
+            out.append(("split", dx, dc, K))
+        else:
+            d = hip.malloc(p.nbytes); hip.h2d(d, p)
+            out.append(("rows", d, None, p.shape[1]))
+    return out
+
+
+def bind_cloud(lib, ctx, cl, N):
+    if cl[0] == "split":
+        return lib.emap_set_points_device_split(ctx, cl[1], cl[2], ct.c_int64(N), ct.c_int64(cl[3]))
+    return lib.emap_set_points_device(ctx, cl[1], ct.c_int64(N), ct.c_int64(cl[3]))
+
+
+def free_clouds(hip, clouds):
+    for cl in clouds:
+        hip.free(cl[1])
+        if cl[2] is not None:
+            hip.free(cl[2])
 
 
 def event_overhead(lib, ctx):
@@ -396,17 +429,14 @@ def run_single(a, local_rank=0):
         spec.alpha = 0.5
         if lib.emap_semantic_configure(ctx, 4):
             raise RuntimeError(lib.emap_last_error(ctx).decode())
-    stride = clouds_host[0].shape[1]
-    clouds_dev = []
-    for p in clouds_host:
-        d = hip.malloc(p.nbytes); hip.h2d(d, p); clouds_dev.append(d)
+    clouds_dev = device_clouds(hip, clouds_host, not a.interleaved_cloud)
     R = np.eye(3, dtype=np.float32).ravel().copy()
     t = np.array([0, 0, 1], np.float32)
     Rp, tp = _lib.f32p(R), _lib.f32p(t)
 
     def make_frame(lib, ctx):
         def frame(i, stats=None):
-            rc = lib.emap_set_points_device(ctx, clouds_dev[i % NCLOUD], ct.c_int64(N), ct.c_int64(stride))
+            rc = bind_cloud(lib, ctx, clouds_dev[i % NCLOUD], N)
             rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
             if multimodal:
                 rc = rc or lib.emap_semantic_update(ctx, Rp, tp, ct.byref(spec))
@@ -532,10 +562,7 @@ def run_single(a, local_rank=0):
             emb = ElevationMap(parb)
             lb, cb = emb._lib, emb._ctx
             hostb = host_clouds(b, Cb, Nb, mm)[:2]
-            strideb = hostb[0].shape[1]
-            devb = []
-            for p_ in hostb:
-                dd = hip.malloc(p_.nbytes); hip.h2d(dd, p_); devb.append(dd)
+            devb = device_clouds(hip, hostb, True)
             del hostb
             specb = None
             if mm:
@@ -548,8 +575,8 @@ def run_single(a, local_rank=0):
                 if lb.emap_semantic_configure(cb, 4):
                     raise RuntimeError(lb.emap_last_error(cb).decode())
 
-            def frb(i, stats=None, lb=lb, cb=cb, devb=devb, Nb=Nb, strideb=strideb, mm=mm, specb=specb):
-                rc = lb.emap_set_points_device(cb, devb[i % len(devb)], ct.c_int64(Nb), ct.c_int64(strideb))
+            def frb(i, stats=None, lb=lb, cb=cb, devb=devb, Nb=Nb, mm=mm, specb=specb):
+                rc = bind_cloud(lb, cb, devb[i % len(devb)], Nb)
                 rc = rc or lb.emap_update(cb, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
                 if mm:
                     rc = rc or lb.emap_semantic_update(cb, Rp, tp, ct.byref(specb))
@@ -569,10 +596,9 @@ def run_single(a, local_rank=0):
                            "dominant_kernel": rb["kernel"], "kernel_ms": rb["kernel_ms"], "frac": rb["frac"], "frame_frac": rb["frame_frac"],
                            "ray_visits_per_s": rb["ray_visits_per_s"], "stage_ms": rb["stage_ms"],
                            "note": ("stage_ms does not hold the RGB / semantic fusion (k_tile_semantic runs behind the frame's stages; "
-                                    "ms_per_step does)" if mm else None)}
+                                    "ms_per_step does); cloud bound de-interleaved: (N, 3) xyz + (N, 4) channels, as emap_upload_points leaves an uploaded cloud" if mm else None)}
             emb.close()
-            for dd in devb:
-                hip.free(dd)
+            free_clouds(hip, devb)
 
     # ---- the reference's real entry point: input_pointcloud with a HOST cloud (float64 as the ROS wrapper passes it, float32) -----
     # never part of `value`; the upload is asynchronous (host-side cast into pinned memory, DMA overlapping the previous frame)
@@ -703,21 +729,18 @@ def run_strips_native(a, rank, world, local_rank, rdv):
     hip = Hip(); hip.set_device(dev)
     clouds_host = host_clouds(a, C, N, multimodal)
     NCLOUD = len(clouds_host)
-    stride = clouds_host[0].shape[1]
     channels = None
     if multimodal:
         channels = ["rgb", "sem0", "sem1", "sem2"]
         par.pointcloud_channel_fusions = {"rgb": "color", "default": "average"}
         emap.semantic_map.prepare(channels)
-    clouds_dev = []
-    for p in clouds_host:
-        d = hip.malloc(p.nbytes); hip.h2d(d, p); clouds_dev.append(d)
+    clouds_dev = device_clouds(hip, clouds_host, not a.interleaved_cloud)
     R = np.eye(3, dtype=np.float32).ravel().copy()
     t = np.array([0, 0, 1], np.float32)
     Rp, tp = _lib.f32p(R), _lib.f32p(t)
 
     def frame(i, stats=None):
-        rc = lib.emap_set_points_device(ctx, clouds_dev[i % NCLOUD], ct.c_int64(N), ct.c_int64(stride))
+        rc = bind_cloud(lib, ctx, clouds_dev[i % NCLOUD], N)
         rc = rc or lib.emap_update_sharded(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
         if rc:
             raise RuntimeError(lib.emap_last_error(ctx).decode())

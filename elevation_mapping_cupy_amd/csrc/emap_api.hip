@@ -32,7 +32,7 @@ void launch_win_unpack(hipStream_t, const KP&, const Win&, AccR*);
 void launch_ray_apply(hipStream_t, const KP&, Cells, AccR*, unsigned long long*, const OverlapArgs&);
 void launch_average(hipStream_t, const KP&, Cells, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*, const OverlapArgs&);
 static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
-void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, double*, unsigned int*, long);
+void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, const ChanView&, double*, unsigned int*, long);
 void launch_sem_finalize(hipStream_t, const KP&, const SemSpec&, const unsigned int*, double*, unsigned int*, float*, float*, long);
 struct SemRaw { int op, stride, K, n_max; long size, cells; double alpha; };
 void launch_semraw_acc(hipStream_t, const SemRaw&, const float*, const int*, const int*, const float*, const int*, float*, unsigned int*);
@@ -41,8 +41,8 @@ void launch_polygon_mask(hipStream_t, int, const int*, const int*, int, const in
 void launch_dilate_planes(hipStream_t, int, int, const float*, const float*, float*, float*);
 struct CamArgs { float P[12], K[9], D[5], center[3]; float x1, y1, z1, ih, iw; double tol; };
 struct CmaxSpec { int n; int chan[8]; int layer[8]; };
-void launch_cmax_ids(hipStream_t, const KP&, const CmaxSpec&, const float*, long, int, const float*, long, unsigned char*, unsigned char*);
-void launch_cmax_sum(hipStream_t, const KP&, const Pose&, const CmaxSpec&, const float*, long, int, const int*, long long*, long);
+void launch_cmax_ids(hipStream_t, const KP&, const CmaxSpec&, const ChanView&, long, const float*, long, unsigned char*, unsigned char*);
+void launch_cmax_sum(hipStream_t, const KP&, const Pose&, const CmaxSpec&, const float*, long, int, const ChanView&, const int*, long long*, long);
 void launch_cmax_select(hipStream_t, const KP&, const CmaxSpec&, int, const long long*, long, unsigned char*, unsigned char*, const unsigned int*, float*, float*, float*);
 void launch_image_corr(hipStream_t, const KP&, const CamArgs&, Cells, float*, unsigned char*);
 void launch_image_fuse(hipStream_t, const KP&, int, float*, const float*, const float*, const unsigned char*, float, float, double);
@@ -68,7 +68,7 @@ void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const f
 void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*, unsigned int*);
 void launch_bin_scatter(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, const unsigned int*, const unsigned int*, BinRec*, const BinStg*, const unsigned int*);
 void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, ErrSlot*);
-void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const float*, long, int,
+void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const ChanView&, long,
                           const unsigned int*, float*, float*, long);
 void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, AccF*, FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&, const GateFold&);
 #define BIN_MAX_T 16384
@@ -157,7 +157,8 @@ struct emap_ctx {
   float* pts_pin[2]; long pin_cap[2];      // pinned host slots the clouds are converted / copied into
   hipEvent_t ev_copied[2], ev_used[2];     // DMA of slot done (copy stream) / the frame that read the slot's device buffer done (main stream)
   int up_slot; bool up_used[2]; hipStream_t copy_stream; Workers* workers;
-  const float* pts; long n_pts; int stride;
+  const float* pts; long n_pts; int stride;         // xyz of the bound cloud: rows of `stride` floats (3 for a de-interleaved cloud)
+  ChanView chan; int n_cols;                        // its extra channels (emap_device.h: ChanView); n_cols = columns of the caller's matrix (3 + K)
   int* tail_idx; unsigned char* tail_flags; long tail_cap;
   // frame state
   double pos_noise, ori_noise; bool use_override; double sum_override; unsigned int cnt_override;
@@ -482,7 +483,7 @@ int emap_upload_points(emap_ctx* ctx, const void* host, int64_t n, int64_t strid
   CKARG(n >= 0 && stride >= 3 && stride < 4096 && (dtype == 0 || dtype == 1), "bad point buffer description");
   CKARG(n == 0 || host, "null host buffer");
   CK(hipSetDevice(ctx->device));
-  const long tot = (long)n * stride;
+  const long tot = (long)n * stride + (stride > 3 ? 64 : 0);      // (+ the padding in front of the channel matrix)
   if (!ctx->copy_stream) {
     CK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k) { CK(hipEventCreateWithFlags(&ctx->ev_copied[k], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ctx->ev_used[k], hipEventDisableTiming)); }
@@ -507,30 +508,62 @@ int emap_upload_points(emap_ctx* ctx, const void* host, int64_t n, int64_t strid
     CK(hipHostMalloc((void**)&ctx->pts_pin[sl], sizeof(float) * tot, hipHostMallocDefault));
     ctx->pin_cap[sl] = tot;
   }
+  // A cloud with extra channels is DE-INTERLEAVED on the way: the workers write xyz as an (n, 3) matrix and the K channels as an
+  // (n, K) matrix behind it (at a 256-byte boundary) -- the conversion touches every element anyway -- so that the frame's point
+  // passes stream 12 bytes per point instead of 12 + 4 K and the semantic fusion reads one K-float record per point.
+  const long K = stride - 3, chan_off = K ? ((3 * (long)n + 63) & ~63L) : 0;
   if (tot > 0) {
     float* pin = ctx->pts_pin[sl];
-    const long chunk = 1L << 19;                                    // 2 MB of float32 per DMA
-    for (long c0 = 0; c0 < tot; c0 += chunk) {
-      const long c1 = c0 + chunk < tot ? c0 + chunk : tot;
+    const long cp = (1L << 19) / stride > 0 ? (1L << 19) / stride : 1;      // points per chunk: about 2 MB of float32 per DMA
+    for (long p0 = 0; p0 < (long)n; p0 += cp) {
+      const long p1 = p0 + cp < (long)n ? p0 + cp : (long)n;
       ctx->workers->run([&](int w, int nw) {
-        const long per = (c1 - c0 + nw - 1) / nw, a = c0 + (long)w * per, b = a + per < c1 ? a + per : c1;
-        if (dtype == 0) { if (b > a) memcpy(pin + a, static_cast<const float*>(host) + a, sizeof(float) * (size_t)(b - a)); }
-        else { const double* src = static_cast<const double*>(host); for (long i = a; i < b; ++i) pin[i] = (float)src[i]; }   // fp32 cast (:456)
+        const long per = (p1 - p0 + nw - 1) / nw, a = p0 + (long)w * per, b = a + per < p1 ? a + per : p1;
+        if (b <= a) return;
+        if (K == 0) {
+          if (dtype == 0) memcpy(pin + 3 * a, static_cast<const float*>(host) + 3 * a, sizeof(float) * 3 * (size_t)(b - a));
+          else { const double* src = static_cast<const double*>(host); for (long i = 3 * a; i < 3 * b; ++i) pin[i] = (float)src[i]; }   // fp32 cast (:456)
+        } else if (dtype == 0) {
+          const float* src = static_cast<const float*>(host);
+          for (long i = a; i < b; ++i) {
+            const float* r = src + i * stride;
+            pin[3 * i] = r[0]; pin[3 * i + 1] = r[1]; pin[3 * i + 2] = r[2];
+            for (long k = 0; k < K; ++k) pin[chan_off + K * i + k] = r[3 + k];
+          }
+        } else {
+          const double* src = static_cast<const double*>(host);
+          for (long i = a; i < b; ++i) {
+            const double* r = src + i * stride;
+            pin[3 * i] = (float)r[0]; pin[3 * i + 1] = (float)r[1]; pin[3 * i + 2] = (float)r[2];
+            for (long k = 0; k < K; ++k) pin[chan_off + K * i + k] = (float)r[3 + k];
+          }
+        }
       });
-      CK(hipMemcpyAsync(ctx->pts_dev[sl] + c0, pin + c0, sizeof(float) * (size_t)(c1 - c0), hipMemcpyHostToDevice, ctx->copy_stream));
+      CK(hipMemcpyAsync(ctx->pts_dev[sl] + 3 * p0, pin + 3 * p0, sizeof(float) * 3 * (size_t)(p1 - p0), hipMemcpyHostToDevice, ctx->copy_stream));
+      if (K) CK(hipMemcpyAsync(ctx->pts_dev[sl] + chan_off + K * p0, pin + chan_off + K * p0, sizeof(float) * (size_t)K * (size_t)(p1 - p0), hipMemcpyHostToDevice, ctx->copy_stream));
     }
     CK(hipEventRecord(ctx->ev_copied[sl], ctx->copy_stream));
     CK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[sl], 0));     // kernels enqueued from now on see the cloud; nothing waits on the host
     ctx->up_used[sl] = true;
   }
-  ctx->pts = ctx->pts_dev[sl]; ctx->n_pts = (long)n; ctx->stride = (int)stride;
+  ctx->pts = ctx->pts_dev[sl]; ctx->n_pts = (long)n; ctx->stride = 3; ctx->n_cols = (int)stride;
+  ctx->chan.p = K ? ctx->pts_dev[sl] + chan_off : ctx->pts_dev[sl]; ctx->chan.stride = K ? (int)K : 3; ctx->chan.col0 = K ? 3 : 0;
+  return EMAP_OK;
+}
+
+int emap_set_points_device_split(emap_ctx* ctx, const float* xyz_dev, const float* chan_dev, int64_t n, int64_t n_chan) {
+  CKARG(ctx, "null ctx");
+  CKARG(n >= 0 && n_chan >= 0 && n_chan < 4093 && (n == 0 || (xyz_dev && (n_chan == 0 || chan_dev))), "bad device point buffers");
+  ctx->pts = xyz_dev; ctx->n_pts = (long)n; ctx->stride = 3; ctx->n_cols = 3 + (int)n_chan;
+  ctx->chan.p = n_chan ? chan_dev : xyz_dev; ctx->chan.stride = n_chan ? (int)n_chan : 3; ctx->chan.col0 = n_chan ? 3 : 0;
   return EMAP_OK;
 }
 
 int emap_set_points_device(emap_ctx* ctx, const float* dev, int64_t n, int64_t stride) {
   CKARG(ctx, "null ctx");
   CKARG(n >= 0 && stride >= 3 && stride < 4096 && (n == 0 || dev), "bad device point buffer");
-  ctx->pts = dev; ctx->n_pts = (long)n; ctx->stride = (int)stride;
+  ctx->pts = dev; ctx->n_pts = (long)n; ctx->stride = (int)stride; ctx->n_cols = (int)stride;
+  ctx->chan.p = dev; ctx->chan.stride = (int)stride; ctx->chan.col0 = 0;            // interleaved rows: the channels sit behind xyz
   return EMAP_OK;
 }
 
@@ -1074,9 +1107,9 @@ int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], cons
   CKARG(spec->n_sum >= 0 && spec->n_sum <= SEM_MAX_CH && spec->n_col >= 0 && spec->n_col <= 4, "too many channels");
   CKARG(ctx->cnt_plane, "emap_semantic_configure must be called before the frame (the average pass records the counts)");
   for (int k = 0; k < spec->n_sum; ++k)
-    CKARG(spec->sum_layer[k] >= 0 && spec->sum_layer[k] < ctx->sem_layers && spec->sum_chan[k] >= 3 && spec->sum_chan[k] < ctx->stride, "bad channel/layer index");
+    CKARG(spec->sum_layer[k] >= 0 && spec->sum_layer[k] < ctx->sem_layers && spec->sum_chan[k] >= 3 && spec->sum_chan[k] < ctx->n_cols, "bad channel/layer index");
   for (int k = 0; k < spec->n_col; ++k)
-    CKARG(spec->col_layer[k] >= 0 && spec->col_layer[k] < ctx->sem_layers && spec->col_chan[k] >= 3 && spec->col_chan[k] < ctx->stride, "bad colour channel/layer index");
+    CKARG(spec->col_layer[k] >= 0 && spec->col_layer[k] < ctx->sem_layers && spec->col_chan[k] >= 3 && spec->col_chan[k] < ctx->n_cols, "bad colour channel/layer index");
   CK(hipSetDevice(ctx->device));
   SemSpec S; memset(&S, 0, sizeof S); memcpy(&S, spec, sizeof *spec);
   int nk[4] = {0, 0, 0, 0};
@@ -1090,12 +1123,12 @@ int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], cons
   S.any_bayes = nk[2] > 0;
   if (S.any_bayes) { int rc = ensure_alpha(ctx); if (rc) return rc; }
   if (ctx->frame_binned) {   // the frame's tile-sorted records are still valid: reduce in LDS, no global atomics
-    launch_tile_semantic(ctx->stream, ctx->kp, ctx->bg, S, ctx->bin_recs, ctx->bin_tile_start, ctx->pts, ctx->n_pts, ctx->stride,
+    launch_tile_semantic(ctx->stream, ctx->kp, ctx->bg, S, ctx->bin_recs, ctx->bin_tile_start, ctx->chan, ctx->n_pts,
                          ctx->cnt_plane, ctx->sem, ctx->sem_alpha, ctx->ncells_alloc);
     CK(hipGetLastError());
     return EMAP_OK;
   }
-  launch_sem_points(ctx->stream, ctx->kp, make_pose(ctx, R, t), S, ctx->pts, ctx->n_pts, ctx->stride, ctx->sem_sums, ctx->sem_col, ctx->ncells_alloc);
+  launch_sem_points(ctx->stream, ctx->kp, make_pose(ctx, R, t), S, ctx->pts, ctx->n_pts, ctx->stride, ctx->chan, ctx->sem_sums, ctx->sem_col, ctx->ncells_alloc);
   launch_sem_finalize(ctx->stream, ctx->kp, S, ctx->cnt_plane, ctx->sem_sums, ctx->sem_col, ctx->sem, ctx->sem_alpha, ctx->ncells_alloc);
   CK(hipGetLastError());
   return EMAP_OK;
@@ -1191,7 +1224,7 @@ int emap_semantic_class_max(emap_ctx* ctx, const float R[9], const float t[3], i
   CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "class_max: single-strip contexts only");
   NEED_POINTS();
   for (int k = 0; k < n_ch; ++k)
-    CKARG(layer[k] >= 0 && layer[k] < ctx->sem_layers && chan[k] >= 3 && chan[k] < ctx->stride, "bad channel/layer index");
+    CKARG(layer[k] >= 0 && layer[k] < ctx->sem_layers && chan[k] >= 3 && chan[k] < ctx->n_cols, "bad channel/layer index");
   CK(hipSetDevice(ctx->device));
   { int rc = ensure_alpha(ctx); if (rc) return rc; }
   hipStream_t st = ctx->stream;
@@ -1203,7 +1236,7 @@ int emap_semantic_class_max(emap_ctx* ctx, const float R[9], const float t[3], i
   CK(hipMalloc((void**)&d_seen, 2 * 65536));
   struct Free { void* p; ~Free() { if (p) hipFree(p); } } f_seen{d_seen};
   CK(hipMemsetAsync(d_seen, 0, 2 * 65536, st));
-  launch_cmax_ids(st, ctx->kp, S, ctx->pts, ctx->n_pts, ctx->stride, ctx->sem_alpha, plane, d_seen, d_seen + 65536);
+  launch_cmax_ids(st, ctx->kp, S, ctx->chan, ctx->n_pts, ctx->sem_alpha, plane, d_seen, d_seen + 65536);
   CK(hipGetLastError());
   std::vector<unsigned char> seen(2 * 65536);
   CK(hipMemcpyAsync(seen.data(), d_seen, 2 * 65536, hipMemcpyDeviceToHost, st));
@@ -1233,7 +1266,7 @@ int emap_semantic_class_max(emap_ctx* ctx, const float R[9], const float t[3], i
   CK(hipMemsetAsync(d_new, 0, sizeof(float) * (size_t)n_ch * plane, st));
   CK(hipMemcpyAsync(d_pos, pos.data(), sizeof(int) * 65536, hipMemcpyHostToDevice, st));
   CK(hipMemcpyAsync(d_uniq, uniq.data(), sizeof(unsigned int) * U, hipMemcpyHostToDevice, st));
-  launch_cmax_sum(st, ctx->kp, make_pose(ctx, R, t), S, ctx->pts, ctx->n_pts, ctx->stride, d_pos, d_sum, plane);
+  launch_cmax_sum(st, ctx->kp, make_pose(ctx, R, t), S, ctx->pts, ctx->n_pts, ctx->stride, ctx->chan, d_pos, d_sum, plane);
   // (3) + (4): per layer the maximum and its class, the winners' planes zeroed in between; then the normalisation
   launch_cmax_select(st, ctx->kp, S, U, d_sum, plane, d_flags, d_flags + U, d_uniq, d_new, ctx->sem_alpha, ctx->sem);
   CK(hipGetLastError());

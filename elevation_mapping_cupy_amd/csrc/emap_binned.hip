@@ -540,10 +540,12 @@ typedef SemSpec SemSpecB;
 #define SEM_GROUP 4
 #define SEM_BLK 1024     /* one wave per tile row: 32 waves per CU with two workgroups (256 threads left the CU at 12 waves: the kernel is a chain of short, latency-bound phases) */
 __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSpecB S, const BinRec* __restrict__ recs,
-                                                             const unsigned int* __restrict__ tile_start, const float* __restrict__ pts,
-                                                             long n, int stride, const unsigned int* __restrict__ cnt_plane,
+                                                             const unsigned int* __restrict__ tile_start, ChanView V,
+                                                             long n, const unsigned int* __restrict__ cnt_plane,
                                                              float* __restrict__ sem, float* __restrict__ alpha_planes, long plane) {
   constexpr int NC = BIN_TR * BIN_TC;
+  const float* __restrict__ chp = V.p - V.col0;          // (a local restrict pointer: the gathers below must stay free to run ahead of the plane stores)
+  const long chs = V.stride;
   __shared__ double s_sum[SEM_GROUP][NC];
   __shared__ unsigned int s_col[4][NC];                 // r, g, b, count of ONE colour layer at a time
   const int t = blockIdx.x, ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
@@ -567,14 +569,14 @@ __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSp
     int cmin = SEM_MAX_CH + 4096, cmax = 0;
     for (int q = 0; q < ng; ++q) { cmin = min(cmin, S.sum_chan[g0 + q]); cmax = max(cmax, S.sum_chan[g0 + q]); }
     if (ride && g0 == 0) { cmin = min(cmin, S.col_chan[0]); cmax = max(cmax, S.col_chan[0]); }
-    const bool wide = cmax - cmin < 4 && cmin + 4 <= stride;          // (uniform) the 16 bytes stay inside the point's row
+    const bool wide = cmax - cmin < 4 && cmin >= V.col0 && cmin - V.col0 + 4 <= V.stride;          // (uniform) the 16 bytes stay inside the point's row
     struct __attribute__((packed, aligned(4))) P4 { float a, b, c, d; };
     auto pick = [](const P4& w, int j) { return j == 0 ? w.a : (j == 1 ? w.b : (j == 2 ? w.c : w.d)); };
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += SEM_BLK) {
       const BinRec r = recs[k];
       if (((r.lc_inl & 0x7fffffffu) >> 10) != sel) continue;
       const unsigned int lc = r.lc_inl & 1023u;
-      const float* p = pts + (long)r.i * stride;
+      const float* __restrict__ p = chp + (long)r.i * chs;
       P4 w4 = {0.f, 0.f, 0.f, 0.f};
       if (wide) w4 = *reinterpret_cast<const P4*>(p + cmin);
       for (int q = 0; q < ng; ++q) {
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSp
         const BinRec r = recs[k];
         if ((long)r.i * K + l >= n || ((r.lc_inl & 0x7fffffffu) >> 10) != sel) continue;
         const unsigned int lc = r.lc_inl & 1023u;
-        const unsigned int color = __float_as_uint(pts[(long)r.i * stride + S.col_chan[l]]);
+        const unsigned int color = __float_as_uint(chp[(long)r.i * chs + S.col_chan[l]]);
         atomicAdd(&s_col[0][lc], (color & 0xFF0000u) >> 16);
         atomicAdd(&s_col[1][lc], (color & 0xFF00u) >> 8);
         atomicAdd(&s_col[2][lc], color & 0xFFu);
@@ -683,6 +685,6 @@ __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSp
   }
 }
 void launch_tile_semantic(hipStream_t s, const KP& P, const BinGeo& G, const SemSpec& S, const BinRec* recs, const unsigned int* tile_start,
-                          const float* pts, long n, int stride, const unsigned int* cnt_plane, float* sem, float* alpha_planes, long plane) {
-  hipLaunchKernelGGL(k_tile_semantic, dim3(G.T, G.sub), dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, pts, n, stride, cnt_plane, sem, alpha_planes, plane);
+                          const ChanView& V, long n, const unsigned int* cnt_plane, float* sem, float* alpha_planes, long plane) {
+  hipLaunchKernelGGL(k_tile_semantic, dim3(G.T, G.sub), dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, V, n, cnt_plane, sem, alpha_planes, plane);
 }

@@ -283,6 +283,14 @@ __device__ __forceinline__ void load_point(const float* __restrict__ pts, long i
   else { const float* p = pts + i * (long)stride; x = p[0]; y = p[1]; z = p[2]; }
 }
 
+// Where the EXTRA channels of the bound cloud live (RGB, semantic features: columns >= 3 of the caller's (N, 3 + K) matrix).  An
+// interleaved device cloud: the same rows as xyz (p = the cloud, stride = 3 + K, col0 = 0).  A cloud uploaded through
+// emap_upload_points (or bound with emap_set_points_device_split) is DE-INTERLEAVED: xyz as an (N, 3) matrix -- the point passes of
+// a frame then stream 12 bytes per point instead of 12 + 4 K -- and the channels as an (N, K) matrix of their own (p = that matrix,
+// stride = K, col0 = 3): with K = 4 every point's channels are ONE aligned 16-byte record.
+struct ChanView { const float* p; int stride, col0; };
+__device__ __forceinline__ const float* chan_row(const ChanView& V, long i) { return V.p + i * (long)V.stride - V.col0; }      // row[c] = channel column c of point i
+
 // 64-lane sum (DPP-free portable form; executed once per wave and only when an inlier exists)
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll

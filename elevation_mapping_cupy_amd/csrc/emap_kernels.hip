@@ -893,22 +893,19 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   float* reg = lds;
   int* rtab = reinterpret_cast<int*>(reg + 3 * RH * rp);       // RH + 2 row terms
   unsigned short* holes = reinterpret_cast<unsigned short*>(rtab + ((RH + 3) & ~1));      // compacted list of the holes of the DW x DH region
-  __shared__ unsigned int n_holes;
-  if (threadIdx.x == 0) n_holes = 0u;
+  __shared__ unsigned int n_holes, s_special;
+  if (threadIdx.x == 0) { n_holes = 0u; s_special = 0u; }
+  __syncthreads();
   const int C = P.C;
   const int tile_r = seg_b + ty * PT_R, tile_c = blockIdx.x * PT_C;      // logical row / column of the tile origin
   const int tc = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave index in an SGPR
-  // staging.  The first 64 columns of the region go row-wise: one wave per region row, lane = column.  Everything that depends on
-  // the row (circular origin, strip ownership, border) is computed ONCE per tile into a small LDS table, everything that depends
-  // on the column once per lane, both as FLAG BITS of one integer (bit 31: no such cell, bit 30: border) -- the kernel is
-  // instruction-issue bound and lane-mask logic in scalar registers costs as much as arithmetic.  Tiles at the left / right map
-  // edge see the reference's flat-index row wrap (:403-407: column -1 of row r is column C-1 of row r-1): such a lane reads the
-  // table one row up or down.  The remaining 6 + 2d columns go as a linear walk over (row, column) pairs so that their lanes are
-  // full too.  All loads of a round (valid: 1 dword; upper + is_upper: 2 dwords of the 32-B cell) are issued before any is
-  // consumed: a 44 x 76 region (32-row tile, d = 3) is ONE round = one memory round trip.  A cell that does not exist loads
-  // (row 0, column 0) and is masked afterwards: no branch around the loads.
+  // staging.  The first 64 columns of the region go row-wise: one wave per region row, lane = column, up to six rows' loads in flight
+  // per wave (a 44 x 76 region -- 32-row tile, d = 3 -- is one memory round trip); the remaining 6 + 2d columns go as a linear walk over
+  // (row, column) pairs so that their lanes are full too.  Everything that depends on the row (circular origin, strip ownership,
+  // border) is computed ONCE per tile into a small LDS table.  Two forms of the walk (round 4): INTERIOR tiles need nothing else;
+  // tiles along the map's edges carry the row table's and the column's flag bits (bit 31: no such cell, bit 30: border cell) and the
+  // reference's flat-index row wrap (:403-407: column -1 of row r is column C - 1 of row r - 1).
   {
-    constexpr int JB = PT_R >= 32 ? 48 / PT_WAVES : 6, EU = PT_R >= 32 ? (528 + PT_THREADS - 1) / PT_THREADS : 2;     // rows per wave and edge cells per thread in one round
     const int r0 = tile_r - 3 - d, c0 = tile_c - 3 - d, EC = RW - 64;
     const int etotal = RH * EC;
     // row table: region row j - 1 (one extra row on both sides for the flat-index carry) -> local row of the arrays (bits 0..23;
@@ -917,64 +914,92 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
       const int g = r0 - 1 + j;
       const bool in_map = g >= 0 && g <= C - 1;
       const int lr = in_map ? local_row(P, phys_row(P, g)) : -1;
-      rtab[j] = lr < 0 ? (int)0x80000000 : lr | ((g >= 1 && g <= C - 2) ? 0 : 0x40000000);
+      const int rt = lr < 0 ? (int)0x80000000 : lr | ((g >= 1 && g <= C - 2) ? 0 : 0x40000000);
+      rtab[j] = rt;
+      if ((rt & (int)0xC0000000) && j >= 1 && j <= RH) s_special = 1u;      // a region row that does not exist here or is a border row (racing writers store the same value)
     }
     __syncthreads();
-    auto col_terms = [&](int cc, int& dr, int& pc, int& flags) {     // region column -> row carry, physical column, flag bits
-      int cl = c0 + cc; dr = 0;
-      if (cl < 0) { cl += C; dr = -1; } else if (cl >= C) { cl -= C; dr = 1; }
-      flags = ((cl >= 1 && cl <= C - 2) ? 0 : 0x40000000) | (cl < C ? 0 : (int)0x80000000);      // (a region wider than the map: columns past the wrap are unused)
-      pc = cl < C ? phys_col(P, cl) : 0;
-    };
-    int ldr, lpc, lfl;
-    col_terms(tc, ldr, lpc, lfl);
-    const int* ltab = rtab + 1 + ldr;                                // the lane's view of the row table
-    for (int rb = 0, eb = 0; rb < RH || eb < etotal; rb += PT_WAVES * JB, eb += PT_THREADS * EU) {
-      float fv[JB + EU]; float2 fu[JB + EU]; int ol[JB + EU], tq[JB + EU], hp[JB + EU];       // per unit: the cell's three dwords, LDS slot (-1: none), flags, slot in the DW x DH region (-1: outside)
+    // INTERIOR tiles -- every cell of the staged region exists, none is a border cell, no column leaves the map (so there is no
+    // flat-index row carry): all but the tiles along the map's (or the strip's missing) edges, 82 % of the tiles at 1024^2, 98 % at
+    // 8192^2.  Their staging needs none of the flag logic below: per region cell one address (row term x pitch + physical column), one
+    // 16-byte load, one add, one 12-byte LDS write, one compare for the hole list -- about a dozen instructions instead of the ~85 of
+    // the general path, which was 40 % of this kernel's instructions (round 4; the kernel is issue bound at every map size:
+    // tools/exp_post_pitch.py).  The LDS contents are the same bit for bit.
+    const bool interior = s_special == 0u && c0 >= 1 && c0 + RW - 1 <= C - 2;      // (uniform)
+    if (interior) {
+      constexpr int U = PT_R >= 32 ? 6 : (PT_R >= 16 ? 4 : 2);               // region rows per wave with their loads in flight together
+      const unsigned int pc0 = (unsigned int)phys_col(P, c0 + tc);
+      for (int rb = wv; rb < RH; rb += PT_WAVES * U) {
+        float4 q[U];
 #pragma unroll
-      for (int u = 0; u < JB; ++u) {
-        const int r = rb + wv + PT_WAVES * u;                       // scalar
-        ol[u] = -1;
-        if (r < RH) {
-          const int T = ltab[r];
-          tq[u] = T | lfl;
-          ol[u] = (r * rp + tc) * 3;
-          hp[u] = ((unsigned int)(r - d) < (unsigned int)DH && (unsigned int)(tc - d) < (unsigned int)DW) ? (r - d) * DW + (tc - d) : -1;
-          const float4 q = cells.cold[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)lpc)];     // time upper is_upper valid': one load
-          fv[u] = q.w; fu[u] = make_float2(q.y, q.z);
+        for (int u = 0; u < U; ++u) {
+          const int r = rb + u * PT_WAVES;                                    // scalar
+          if (r < RH) q[u] = cells.cold[(long)(__umul24((unsigned int)rtab[r + 1], (unsigned int)C) + pc0)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = rb + u * PT_WAVES;
+          if (r >= RH) continue;
+          const float m = q[u].w + q[u].z;
+          float3 o; o.x = q[u].y; o.y = m; o.z = q[u].w;
+          *reinterpret_cast<float3*>(reg + (r * rp + tc) * 3) = o;
+          if (m < 0.5f && (unsigned int)(r - d) < (unsigned int)DH && (unsigned int)(tc - d) < (unsigned int)DW) holes[atomicAdd(&n_holes, 1u)] = (unsigned short)((r - d) * DW + (tc - d));
         }
       }
-#pragma unroll
-      for (int k = 0; k < EU; ++k) {
-        const int u = JB + k;
-        ol[u] = -1;
-        const int ebase = eb + k * PT_THREADS + wv * 64;            // scalar: first element of this wave
-        if (ebase < etotal) {
-          const int e = min(ebase + tc, etotal - 1);                // (the spare lanes of the last wave repeat its last element)
-          const int r = (int)__umulhi((unsigned int)e, S.emagic), cc = 64 + e - r * EC;
-          int dr, pc, fl;
-          col_terms(cc, dr, pc, fl);
-          const int T = rtab[r + 1 + dr];
-          tq[u] = T | fl;
-          ol[u] = (r * rp + cc) * 3;
-          hp[u] = ((unsigned int)(r - d) < (unsigned int)DH && (unsigned int)(cc - d) < (unsigned int)DW && e == ebase + tc) ? (r - d) * DW + (cc - d) : -1;
-          const float4 q = cells.cold[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)pc)];
-          fv[u] = q.w; fu[u] = make_float2(q.y, q.z);
-        }
+      // the remaining 6 + 2d columns: a linear walk over (row, column) pairs, full lanes
+      for (int eb = threadIdx.x; eb < etotal; eb += PT_THREADS) {
+        const int r = (int)__umulhi((unsigned int)eb, S.emagic), cc = 64 + eb - r * EC;
+        const float4 q1 = cells.cold[(long)(__umul24((unsigned int)rtab[r + 1], (unsigned int)C) + (unsigned int)phys_col(P, c0 + cc))];
+        const float m = q1.w + q1.z;
+        float3 o; o.x = q1.y; o.y = m; o.z = q1.w;
+        *reinterpret_cast<float3*>(reg + (r * rp + cc) * 3) = o;
+        if (m < 0.5f && (unsigned int)(r - d) < (unsigned int)DH && (unsigned int)(cc - d) < (unsigned int)DW) holes[atomicAdd(&n_holes, 1u)] = (unsigned short)((r - d) * DW + (cc - d));
       }
-#pragma unroll
-      for (int u = 0; u < JB + EU; ++u) {
-        if (u < JB ? rb + wv + PT_WAVES * u >= RH : eb + (u - JB) * PT_THREADS + wv * 64 >= etotal) continue;     // scalar: the unit was not loaded
-        const bool ok = tq[u] >= 0, inside = (tq[u] & 0x40000000) == 0;
-        const float m = fv[u] + fu[u].y;
+    } else {
+      // Tiles along the map's edges (or next to rows a strip does not hold): the same walk with the flag bits of the row table (bit 31:
+      // no such row, bit 30: border row) and of the column (the same two bits + the flat-index row carry dr of the reference's
+      // addressing, :403-407: column -1 of row r is column C - 1 of row r - 1 -- such a lane reads the row table one row up or down).
+      // A cell that does not exist loads cell (0, 0) of the arrays and is masked afterwards: no branch around the loads.
+      auto col_terms = [&](int cc, int& dr, int& pc, int& flags) {     // region column -> row carry, physical column, flag bits
+        int cl = c0 + cc; dr = 0;
+        if (cl < 0) { cl += C; dr = -1; } else if (cl >= C) { cl -= C; dr = 1; }
+        flags = ((cl >= 1 && cl <= C - 2) ? 0 : 0x40000000) | (cl < C ? 0 : (int)0x80000000);      // (a region wider than the map: columns past the wrap are unused)
+        pc = cl < C ? phys_col(P, cl) : 0;
+      };
+      auto put = [&](int r, int cc, int tqv, const float4& q1) {
+        const bool ok = tqv >= 0, inside = (tqv & 0x40000000) == 0;
+        const float m = q1.w + q1.z;
         float3 o;
-        o.x = ok ? fu[u].x : 0.f;
-        o.y = ok ? (inside ? m : -m - 1.f) : -1.f;
-        o.z = ok ? fv[u] : 0.f;
-        *reinterpret_cast<float3*>(reg + ol[u]) = o;
-        // a hole of the region whose dilated value is needed: noted here, while its mask is in a register (cells outside the map are
-        // never sources and never outputs: not listed)
-        if (ok && m < 0.5f && hp[u] >= 0) holes[atomicAdd(&n_holes, 1u)] = (unsigned short)hp[u];
+        o.x = ok ? q1.y : 0.f;
+        o.y = ok ? (inside ? m : -m - 1.f) : -1.f;                  // mask >= 0; stored as -(mask) - 1 when the cell is not is_inside: never a source
+        o.z = ok ? q1.w : 0.f;
+        *reinterpret_cast<float3*>(reg + (r * rp + cc) * 3) = o;
+        // a hole of the region whose dilated value is needed (cells outside the map are never sources and never outputs: not listed)
+        if (ok && m < 0.5f && (unsigned int)(r - d) < (unsigned int)DH && (unsigned int)(cc - d) < (unsigned int)DW) holes[atomicAdd(&n_holes, 1u)] = (unsigned short)((r - d) * DW + (cc - d));
+      };
+      int ldr, lpc, lfl;
+      col_terms(tc, ldr, lpc, lfl);
+      const int* ltab = rtab + 1 + ldr;                              // the lane's view of the row table
+      constexpr int U = PT_R >= 32 ? 6 : (PT_R >= 16 ? 4 : 2);
+      for (int rb = wv; rb < RH; rb += PT_WAVES * U) {
+        float4 q[U]; int tq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = rb + u * PT_WAVES;                            // scalar
+          if (r < RH) { const int T = ltab[r]; tq[u] = T | lfl; q[u] = cells.cold[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)lpc)]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = rb + u * PT_WAVES;
+          if (r < RH) put(r, tc, tq[u], q[u]);
+        }
+      }
+      for (int eb = threadIdx.x; eb < etotal; eb += PT_THREADS) {
+        const int r = (int)__umulhi((unsigned int)eb, S.emagic), cc = 64 + eb - r * EC;
+        int dr, pc, fl;
+        col_terms(cc, dr, pc, fl);
+        const int T = rtab[r + 1 + dr];
+        put(r, cc, T | fl, cells.cold[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)pc)]);
       }
     }
   }

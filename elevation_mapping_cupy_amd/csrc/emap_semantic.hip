@@ -9,7 +9,7 @@
 
 
 template <int MODE>
-__global__ __launch_bounds__(EM_BLOCK) void k_sem_sum(KP P, Pose T, SemSpec S, const float* __restrict__ pts, long n, int stride,
+__global__ __launch_bounds__(EM_BLOCK) void k_sem_sum(KP P, Pose T, SemSpec S, const float* __restrict__ pts, long n, int stride, ChanView V,
                                                        double* __restrict__ sums, long plane) {
   long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_sem_sum(KP P, Pose T, SemSpec S, c
   Geo g = geometry<MODE>(P, T, rx, ry, rz);
   long c = (g.finite && g.valid && g.inside) ? owned_cell(P, g.ix, g.iy) : -1;   // valid && inside (:41-45)
   if (c < 0) return;
-  const float* p = pts + i * (long)stride;
+  const float* p = chan_row(V, i);
   for (int k = 0; k < S.n_sum; ++k) {
     const float v = p[S.sum_chan[k]];
     if (S.sum_kind[k] >= 2) {
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_sem_sum(KP P, Pose T, SemSpec S, c
 // (fusion/pointcloud_color.py:143): with K colour channels only the first N/K points contribute
 // and the shared counter is incremented once per (point, layer).  Reproduced literally.
 template <int MODE>
-__global__ __launch_bounds__(EM_BLOCK) void k_sem_color(KP P, Pose T, SemSpec S, const float* __restrict__ pts, long n, int stride,
+__global__ __launch_bounds__(EM_BLOCK) void k_sem_color(KP P, Pose T, SemSpec S, const float* __restrict__ pts, long n, int stride, ChanView V,
                                                          unsigned int* __restrict__ col, long plane) {
   long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_sem_color(KP P, Pose T, SemSpec S,
   Geo g = geometry<MODE>(P, T, rx, ry, rz);
   long c = (g.finite && g.valid && g.inside) ? owned_cell(P, g.ix, g.iy) : -1;
   if (c < 0) return;
-  unsigned int color = __float_as_uint(pts[id * (long)stride + S.col_chan[layer]]);
+  unsigned int color = __float_as_uint(chan_row(V, id)[S.col_chan[layer]]);
   atomicAdd(&col[(long)(layer * 3) * plane + c], (color & 0xFF0000u) >> 16);
   atomicAdd(&col[(long)(layer * 3 + 1) * plane + c], (color & 0xFF00u) >> 8);
   atomicAdd(&col[(long)(layer * 3 + 2) * plane + c], color & 0xFFu);
@@ -103,16 +103,16 @@ __global__ __launch_bounds__(EM_BLOCK) void k_sem_finalize(KP P, SemSpec S, cons
 
 static inline unsigned int nblk_(long n) { return (unsigned int)((n + EM_BLOCK - 1) / EM_BLOCK); }
 
-void launch_sem_points(hipStream_t s, const KP& P, const Pose& T, const SemSpec& S, const float* pts, long n, int stride,
+void launch_sem_points(hipStream_t s, const KP& P, const Pose& T, const SemSpec& S, const float* pts, long n, int stride, const ChanView& V,
                        double* sums, unsigned int* col, long plane) {
   if (n <= 0) return;
   if (S.n_sum > 0) {
-    if (P.mode == 0) hipLaunchKernelGGL(k_sem_sum<0>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, sums, plane);
-    else hipLaunchKernelGGL(k_sem_sum<1>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, sums, plane);
+    if (P.mode == 0) hipLaunchKernelGGL(k_sem_sum<0>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, V, sums, plane);
+    else hipLaunchKernelGGL(k_sem_sum<1>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, V, sums, plane);
   }
   if (S.n_col > 0) {
-    if (P.mode == 0) hipLaunchKernelGGL(k_sem_color<0>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, col, plane);
-    else hipLaunchKernelGGL(k_sem_color<1>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, col, plane);
+    if (P.mode == 0) hipLaunchKernelGGL(k_sem_color<0>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, V, col, plane);
+    else hipLaunchKernelGGL(k_sem_color<1>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, V, col, plane);
   }
 }
 void launch_sem_finalize(hipStream_t s, const KP& P, const SemSpec& S, const unsigned int* cnt_plane, double* sums, unsigned int* col,
@@ -260,11 +260,11 @@ void launch_inpaint_sweep(hipStream_t s, int C, const float* val, const float* m
 // emap_api.hip emap_semantic_class_max.
 // ---------------------------------------------------------------------------------------------------------
 struct CmaxSpec { int n; int chan[8]; int layer[8]; };
-__global__ __launch_bounds__(EM_BLOCK) void k_cmax_ids(const float* __restrict__ pts, long n, int stride, CmaxSpec S,
+__global__ __launch_bounds__(EM_BLOCK) void k_cmax_ids(ChanView V, long n, CmaxSpec S,
                                                         unsigned char* __restrict__ seen) {
   const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (i >= n) return;
-  for (int it = 0; it < S.n; ++it) seen[__float_as_uint(pts[i * stride + S.chan[it]]) >> 16] = 1;       // every point, valid or not (:82-84)
+  for (int it = 0; it < S.n; ++it) seen[__float_as_uint(chan_row(V, i)[S.chan[it]]) >> 16] = 1;       // every point, valid or not (:82-84)
 }
 // ids stored in the map's id planes (elements_to_shift["id_max"], kept in the layers' persistent planes): values < 65536 only
 __global__ __launch_bounds__(EM_BLOCK) void k_cmax_prev_ids(KP P, CmaxSpec S, const float* __restrict__ id_planes, long plane,
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_cmax_prev_ids(KP P, CmaxSpec S, co
   for (int it = 0; it < S.n; ++it) { const unsigned int v = __float_as_uint(id_planes[(long)S.layer[it] * plane + c]); if (v < 65536u) seen_prev[v] = 1; }
 }
 template <int MODE>
-__global__ __launch_bounds__(EM_BLOCK) void k_cmax_sum(KP P, Pose T, CmaxSpec S, const float* __restrict__ pts, long n, int stride,
+__global__ __launch_bounds__(EM_BLOCK) void k_cmax_sum(KP P, Pose T, CmaxSpec S, const float* __restrict__ pts, long n, int stride, ChanView V,
                                                         const int* __restrict__ pos, long long* __restrict__ prob_sum, long plane) {
   const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_cmax_sum(KP P, Pose T, CmaxSpec S,
   const long c = (g.finite && g.valid && g.inside) ? owned_cell(P, g.ix, g.iy) : -1;
   if (c < 0) return;
   for (int it = 0; it < S.n; ++it) {
-    const unsigned int bits = __float_as_uint(pts[i * stride + S.chan[it]]);
+    const unsigned int bits = __float_as_uint(chan_row(V, i)[S.chan[it]]);
     const unsigned short hb = (unsigned short)(bits & 0xffffu);
     _Float16 h; __builtin_memcpy(&h, &hb, 2);
     const float prob = (float)h;
@@ -324,16 +324,16 @@ __global__ __launch_bounds__(EM_BLOCK) void k_cmax_norm(KP P, CmaxSpec S, const 
   if (sum == 0.f) sum = 1.f;
   for (int it = 0; it < S.n; ++it) sem[(long)S.layer[it] * plane + c] = newp[(long)it * plane + c] / sum;
 }
-void launch_cmax_ids(hipStream_t s, const KP& P, const CmaxSpec& S, const float* pts, long n, int stride, const float* id_planes, long plane,
+void launch_cmax_ids(hipStream_t s, const KP& P, const CmaxSpec& S, const ChanView& V, long n, const float* id_planes, long plane,
                      unsigned char* seen, unsigned char* seen_prev) {
-  if (n > 0) hipLaunchKernelGGL(k_cmax_ids, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, pts, n, stride, S, seen);
+  if (n > 0) hipLaunchKernelGGL(k_cmax_ids, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, V, n, S, seen);
   hipLaunchKernelGGL(k_cmax_prev_ids, dim3(nblk_((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, S, id_planes, plane, seen_prev);
 }
-void launch_cmax_sum(hipStream_t s, const KP& P, const Pose& T, const CmaxSpec& S, const float* pts, long n, int stride, const int* pos,
+void launch_cmax_sum(hipStream_t s, const KP& P, const Pose& T, const CmaxSpec& S, const float* pts, long n, int stride, const ChanView& V, const int* pos,
                      long long* prob_sum, long plane) {
   if (n <= 0) return;
-  if (P.mode == 0) hipLaunchKernelGGL(k_cmax_sum<0>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, pos, prob_sum, plane);
-  else hipLaunchKernelGGL(k_cmax_sum<1>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, pos, prob_sum, plane);
+  if (P.mode == 0) hipLaunchKernelGGL(k_cmax_sum<0>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, V, pos, prob_sum, plane);
+  else hipLaunchKernelGGL(k_cmax_sum<1>, dim3(nblk_(n)), dim3(EM_BLOCK), 0, s, P, T, S, pts, n, stride, V, pos, prob_sum, plane);
 }
 void launch_cmax_select(hipStream_t s, const KP& P, const CmaxSpec& S, int U, const long long* prob_sum, long plane, unsigned char* zeroed,
                         unsigned char* used, const unsigned int* unique_id, float* newp, float* id_planes, float* sem) {

@@ -322,6 +322,13 @@ class ElevationMap:
         self._n_bound = n
         self._bound_host = None
 
+    def bind_points_device_split(self, xyz_ptr, chan_ptr, n, n_chan):
+        """Bind a device-resident cloud that is already de-interleaved: xyz ``(n, 3)`` and the extra channels ``(n, n_chan)``, both
+        row-major float32 (the layout ``bind_points`` / ``input_pointcloud`` give an uploaded cloud)."""
+        self._chk(self._lib.emap_set_points_device_split(self._ctx, ct.c_void_p(xyz_ptr), ct.c_void_p(chan_ptr), ct.c_int64(n), ct.c_int64(n_chan)))
+        self._n_bound = n
+        self._bound_host = None
+
     @staticmethod
     def _rt(R, t):
         R = np.ascontiguousarray(np.asarray(R, np.float32).reshape(9))

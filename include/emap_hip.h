@@ -90,10 +90,16 @@ int emap_clear(emap_ctx* ctx);
 
 /* ---- point cloud ------------------------------------------------------------------------------------ */
 /* ElevationMap.input_pointcloud's H2D + cast (EM/elevation_mapping.py:456): rows of `stride` elements,
- * xyz first; dtype 0 = float32, 1 = float64.  Rows with NaN in xyz are skipped inside the kernels (:458). */
+ * xyz first; dtype 0 = float32, 1 = float64.  Rows with NaN in xyz are skipped inside the kernels (:458).
+ * A cloud with extra channels (stride > 3) is de-interleaved while it is converted: on the device it is an (n, 3) xyz matrix
+ * and an (n, stride - 3) channel matrix (the reference keeps the interleaved rows and strides over them in every kernel). */
 int emap_upload_points(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype);
 /* bind a device-resident float32 cloud without copying (update_map_with_kernel takes device arrays, :316) */
 int emap_set_points_device(emap_ctx* ctx, const float* dev, int64_t n, int64_t stride);
+/* the same for a cloud that is already de-interleaved on the device (what emap_upload_points produces): xyz (n, 3) and the
+ * extra channels (n, n_chan), both row-major float32; channel column c of the caller's (n, 3 + n_chan) numbering is column
+ * c - 3 of chan_dev */
+int emap_set_points_device_split(emap_ctx* ctx, const float* xyz_dev, const float* chan_dev, int64_t n, int64_t n_chan);
 /* tail of add_points_kernel (custom_kernels.py:260-262): per point cell idx, is_valid, is_inside */
 int emap_point_index(emap_ctx* ctx, const float R[9], const float t[3], int32_t* idx, uint8_t* valid, uint8_t* inside);
 

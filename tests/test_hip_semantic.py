@@ -156,3 +156,50 @@ def test_class_bayesian_accumulates_over_frames_and_moves_with_the_map(scatter):
     assert np.array_equal(hip.semantic_map.get_alpha("p0"), want)
     hip.clear()
     assert np.array_equal(hip.semantic_map.get_alpha("p0"), want) and not hip.semantic_map.semantic_map.any()
+
+
+@pytest.mark.parametrize("scatter", ["atomic", "binned"])
+def test_device_cloud_layouts_agree(scatter):
+    """the same multi-modal cloud bound three ways -- uploaded from the host (de-interleaved by emap_upload_points), device resident as
+    interleaved (N, 7) rows (emap_set_points_device), device resident de-interleaved (emap_set_points_device_split) -- must give the
+    same map and the same semantic layers bit for bit; a channel index beyond the cloud's columns is refused for every layout"""
+    import ctypes as ct
+    from elevation_mapping_cupy_amd._lib import EmapError
+    C, N = 130, 30000
+    R, t = fx.POSES["rotated"]
+    hipl = ct.CDLL("libamdhip64.so")
+
+    def dev(a):
+        a = np.ascontiguousarray(a, np.float32)
+        d = ct.c_void_p()
+        assert hipl.hipMalloc(ct.byref(d), ct.c_size_t(a.nbytes)) == 0 and hipl.hipMemcpy(d, ct.c_void_p(a.ctypes.data), ct.c_size_t(a.nbytes), 1) == 0
+        return d
+    out = []
+    for layout in ("upload", "rows", "split"):
+        hip, _ = _hip(C)
+        hip.set_scatter_mode(scatter)
+        keep = []
+        for f in range(2):
+            p = fx.semantic_cloud(C, N, 20 + f)
+            if layout == "upload":
+                hip.bind_points(p)
+            elif layout == "rows":
+                d = dev(p); keep.append(d)
+                hip.bind_points_device(d.value, N, 7)
+            else:
+                dx, dc = dev(p[:, :3]), dev(p[:, 3:]); keep += [dx, dc]
+                hip.bind_points_device_split(dx.value, dc.value, N, 4)
+            hip.update_map_with_kernel(None, CH[3:], R, t.copy(), 1.0, 1.0)
+            hip.update_time()
+        out.append((hip.elevation_map, hip.semantic_map.semantic_map))
+        with pytest.raises(EmapError, match="channel/layer index"):
+            from elevation_mapping_cupy_amd._lib import EmapSemSpec, f32p
+            spec = EmapSemSpec(); spec.n_sum = 1; spec.sum_chan[0] = 7; spec.sum_layer[0] = 0
+            Rf = np.ascontiguousarray(R, np.float32).ravel().copy()
+            hip._chk(hip._lib.emap_semantic_update(hip._ctx, f32p(Rf), f32p(t.copy()), ct.byref(spec)))
+        hip.close()
+        for d in keep:
+            hipl.hipFree(d)
+    for e, s in out[1:]:
+        assert e.tobytes() == out[0][0].tobytes() and s.tobytes() == out[0][1].tobytes()
+    assert (out[0][1][3].view(np.uint32) != 0).sum() > 1000

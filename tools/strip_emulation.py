@@ -44,6 +44,7 @@ def main():
                     "(sharded.ray_balanced_weights: thin around the sensor) unless --equal-strips")
     ap.add_argument("--equal-strips", action="store_true")
     ap.add_argument("--no-lockstep", action="store_true")
+    ap.add_argument("--interleaved-cloud", action="store_true", help="cfg5: interleaved (N, 7) device rows instead of the de-interleaved layout of an uploaded cloud")
     ap.add_argument("--ray-mode", default="auto", choices=["auto", "by_row", "by_ray"], help="with --rays: how the sharded frame runs the visibility "
                     "pass (emap_set_ray_mode; auto = by ray from 2048^2 cells on)")
     a = ap.parse_args()
@@ -62,10 +63,7 @@ def main():
     weights = bench.load_weights()
     hip = bench.Hip(); hip.set_device(0)
     clouds_host = bench.host_clouds(ba, C, N, multimodal)
-    stride = clouds_host[0].shape[1]
-    clouds_dev = []
-    for p in clouds_host:
-        d = hip.malloc(p.nbytes); hip.h2d(d, p); clouds_dev.append(d)
+    clouds_dev = bench.device_clouds(hip, clouds_host, not a.interleaved_cloud)
     del clouds_host
     R = np.eye(3, dtype=np.float32).ravel().copy(); t = np.array([0, 0, 1], np.float32)
     Rp, tp = _lib.f32p(R), _lib.f32p(t)
@@ -96,7 +94,7 @@ def main():
         call = lib.emap_update_sharded if sharded_frame else lib.emap_update
 
         def frame(i, stats=None):
-            rc = lib.emap_set_points_device(ctx, clouds_dev[i % len(clouds_dev)], ct.c_int64(N), ct.c_int64(stride))
+            rc = bench.bind_cloud(lib, ctx, clouds_dev[i % len(clouds_dev)], N)
             rc = rc or call(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
             if rc:
                 raise RuntimeError(lib.emap_last_error(ctx).decode())
