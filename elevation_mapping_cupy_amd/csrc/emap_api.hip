@@ -1214,9 +1214,9 @@ int emap_semantic_finalize(emap_ctx* ctx, int32_t op, void* newmap_inout, int32_
 // ---- pointcloud_class_max (EM/fusion/pointcloud_class_max.py:80-126; kernels: emap_semantic.hip) ------------------------------
 // The class-id planes (the reference's elements_to_shift["id_max"]) live in the layers' persistent planes (sem_alpha): they move
 // with the map and read back through emap_semantic_get_alpha as uint32 bit patterns.  `prev_unique` is the fusion's unique_id array
-// of the previous frame ([0] before the first: :59).  The reference gathers unique_id[id_max] (:86) -- the planes hold class VALUES,
-// so that is only defined while every stored value is a valid position; values beyond the array are ignored here (CuPy would read
-// out of bounds).
+// of the previous frame ([0] before the first: :59).  The reference gathers unique_id[id_max] (:85) -- the planes hold class VALUES
+// and the table is indexed with them; positions beyond the table wrap around (CuPy's integer-array indexing), reproduced here and
+// pinned by the reference's own statements executed from its file (tests/golden/class_max_ref66.npz).
 int emap_semantic_class_max(emap_ctx* ctx, const float R[9], const float t[3], int32_t n_ch, const int32_t* chan, const int32_t* layer,
                             const uint32_t* prev_unique, int32_t n_prev, uint32_t* unique_out, int32_t unique_cap, int32_t* n_unique_out) {
   CKARG(ctx && R && t && chan && layer && unique_out && n_unique_out && n_ch >= 1 && n_ch <= 8 && n_prev >= 0 && (n_prev == 0 || prev_unique), "bad argument");
@@ -1246,7 +1246,7 @@ int emap_semantic_class_max(emap_ctx* ctx, const float R[9], const float t[3], i
   std::vector<unsigned char> in_set(65536, 0);
   for (int v = 0; v < 65536; ++v) {
     if (seen[v]) in_set[v] = 1;                                                            // unique(pt_id) (:84)
-    if (seen[65536 + v] && v < n_prev && prev_unique[v] < 65536u) in_set[prev_unique[v]] = 1;      // unique(unique_id[id_max]) (:86)
+    if (seen[65536 + v] && prev_unique[v % n_prev] < 65536u) in_set[prev_unique[v % n_prev]] = 1;      // unique(unique_id[id_max]) (:85): positions beyond the table wrap around, like CuPy's integer-array gather
   }
   std::vector<uint32_t> uniq; std::vector<int> pos(65536, 0);
   for (int v = 0; v < 65536; ++v) if (in_set[v]) { pos[v] = (int)uniq.size(); uniq.push_back((uint32_t)v); }

@@ -126,6 +126,8 @@ def _instantiate(p):
         ks["bayesian_inference"] = (bi.bayesian_inference_kernel(C, C), f32)
     if p.get("sum_max_kernel"):          # EM/kernels/custom_semantic_kernels.py:89-123 (max_id is an int array in its caller, fusion/pointcloud_class_max.py)
         ks["sem_sum_max"] = (sk.sum_max_kernel(res, C, C), dict(f32, T="int"))
+    if p.get("class_max_kernel"):        # the kernel the class_max fusion keeps in its own module (EM/fusion/pointcloud_class_max.py:12-47); max_id = the uint32 class positions
+        ks["cmax_sum_max"] = (_fusion_module("pointcloud_class_max").sum_max_kernel(res, C, C), dict(f32, T="unsigned int"))
     if p.get("polygon_kernel"):
         # safety-polygon service (reference elevation_mapping.py:283, 837-889): `raw int16 polygon_n` is a concrete type
         ks["polygon_mask"] = (ck.polygon_mask_kernel(C, C, res), dict(f32, int16="short"))
@@ -262,6 +264,7 @@ PREBUILD = {
     "maxfilter34": with_(PARAM_DEFAULT, cell_n=34, max_filter_sizes=(1, 2)),
     # the toy maps of the reference's own kernel tests (EM/tests/test_semantic_kernels.py: 4 x 4 cells, resolution 0.9)
     "toy4": with_(PARAM_YAML, cell_n=4, resolution=0.9, bayes_kernels=True, sum_max_kernel=True),
+    "classmax66": with_(PARAM_YAML, cell_n=66, class_max_kernel=True),
     # wall-skip fixture (tests/_warm.py): two drift inliers in a cell already exceed wall_num_thresh
     "wall202": with_(PARAM_DEFAULT, wall_num_thresh=1),
 }

@@ -6,8 +6,13 @@ tests/test_hip_semantic_factories.py through ``oracle/ref_kernels.py: sem_sum_ma
 Two deliberate definitions where the reference is not defined:
 * the probability sums are the EXACT sums rounded once to float32 (the reference's float atomics round after every addition, in an
   order the GPU picks); every half is a multiple of 2^-24, so float64 accumulation is exact here;
-* ``self.unique_id[elements_to_shift["id_max"]]`` (:86) gathers with class VALUES as positions; positions beyond the array (CuPy
-  reads out of bounds there, NumPy raises) are ignored."""
+* ``self.unique_id[elements_to_shift["id_max"]]`` (:85) gathers with class VALUES as positions; positions beyond the table WRAP
+  AROUND, as CuPy's integer-array indexing does (a documented difference from NumPy, which raises) -- since round 4; before, they
+  were ignored.
+
+Round 4: the reference's own statements are executed from its file as well (oracle/ref_fusion.py -> tests/golden/class_max_ref66.npz);
+tests/test_class_max_reference.py compares this restatement with them: ids and the id table exact, probabilities within float32
+summation order (the one deviation that remains, by design: exact sums)."""
 import numpy as np
 
 
@@ -31,9 +36,8 @@ class ClassMaxOracle:
         C = self.cell_n
         max_pt, pt_id = decode_max(points_all[:, pcl_ids])            # :81
         unique_idm = np.unique(pt_id)                                  # :83
-        stored = id_max.reshape(-1)
-        stored = stored[stored < self.unique_id.size]                 # out-of-range gathers: undefined in the reference, ignored
-        unique_ida = np.unique(self.unique_id[stored])                 # :84
+        stored = id_max.reshape(-1).astype(np.int64) % self.unique_id.size      # positions beyond the table wrap around (CuPy)
+        unique_ida = np.unique(self.unique_id[stored])                 # :85
         self.unique_id = np.unique(np.concatenate((unique_idm, unique_ida))).astype(np.uint32)      # :86
         prob = np.zeros((len(self.unique_id), C * C), np.float64)     # :88 (float64: exact)
         pos = np.searchsorted(self.unique_id, pt_id)                   # :90-92

@@ -42,7 +42,7 @@ class UnsafeReferenceCode(RuntimeError):
     pass
 
 
-def _vet(node, what, extra_locals=()):
+def _vet(node, what, extra_locals=(), extra_builtins=()):
     """reject anything beyond plain array arithmetic on self / cp / xp / np before the tree is compiled (see the module docstring)"""
     banned = (ast.Import, ast.ImportFrom, ast.ClassDef, ast.Lambda, ast.Global, ast.Nonlocal, ast.AsyncWith, ast.Try, ast.Raise,
               ast.Delete, ast.Await, ast.Yield, ast.YieldFrom, ast.AsyncFunctionDef, ast.AsyncFor, ast.JoinedStr, ast.NamedExpr, ast.Starred)
@@ -65,13 +65,13 @@ def _vet(node, what, extra_locals=()):
             raise UnsafeReferenceCode("%s: dunder name %r" % (what, n.id))
         if isinstance(n, ast.Attribute) and n.attr.startswith("_"):
             raise UnsafeReferenceCode("%s: private / dunder attribute %r" % (what, n.attr))
-        if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in local and n.id not in _ROOTS and n.id not in _SAFE_BUILTINS:
+        if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in local and n.id not in _ROOTS and n.id not in _SAFE_BUILTINS and n.id not in extra_builtins:
             raise UnsafeReferenceCode("%s: free name %r at line %s" % (what, n.id, n.lineno))
         if isinstance(n, ast.Call):
             f = n.func
             while isinstance(f, (ast.Attribute, ast.Subscript, ast.Call)):
                 f = f.value if not isinstance(f, ast.Call) else f.func
-            if not (isinstance(f, ast.Name) and (f.id in _ROOTS or f.id in _SAFE_BUILTINS or f.id in local)):
+            if not (isinstance(f, ast.Name) and (f.id in _ROOTS or f.id in _SAFE_BUILTINS or f.id in extra_builtins or f.id in local)):
                 raise UnsafeReferenceCode("%s: call rooted at %s (line %s)" % (what, ast.dump(f)[:60], n.lineno))
 
 

@@ -266,6 +266,24 @@ def semantic_toy():
     print("semantic toy:", sorted(save))
 
 
+def class_max_ref():
+    """the class_max fusion as the REFERENCE computes it: ClassMax.decode_max / __call__ executed from the reference file (oracle/ref_fusion.py:
+    NumPy with CuPy's gather semantics) over its own sum_max_kernel compiled for the host (parameter set classmax66), on the four
+    frames of tests/_classmax.py; cell indices / flags of the points from the oracle (pinned elsewhere against the reference kernels)"""
+    import _classmax as cmx
+    from oracle import emap_oracle as eo, ref_fusion
+    os.environ["EMAP_REF_EXEC"] = "1"                    # regeneration = the explicit request to execute the reference's host code
+    rk = ref_kernels.RefKernels(build_ref.PREBUILD["classmax66"])
+    RefClassMax = ref_fusion.load(rk)
+    orc = eo.OracleMap(eo.make_params(dict(eo.YAML, enable_visibility_cleanup=False), cell_n=cmx.C))
+    R, t = fx.POSES["rotated"]
+    save = {}
+    for f, (sem, ids, uniq) in enumerate(cmx.reference_frames(RefClassMax, lambda p: orc.point_index(p, R, t))):
+        save["sem%d" % f] = sem; save["ids%d" % f] = ids; save["unique%d" % f] = uniq
+        print("class_max frame", f, "unique_id", uniq.tolist(), "cells", int((sem[0] > 0).sum()), int((sem[1] > 0).sum()))
+    np.savez_compressed(os.path.join(OUT, "class_max_ref66.npz"), **save)
+
+
 GATE_CASES = [(12.5, 200, 1.0, 1.0), (-3.0, 150, 0.0, 1.0), (40.0, 200, 1.0, 0.0), (5.0, 100, 1.0, 1.0), (5.0, 101, 0.0, 0.0),
               (0.0, 0, 1.0, 1.0), (-19.0, 200, 1.0, 1.0)]
 MOVE_SEQUENCE = [("move_to", (0.13, -0.3, 0.05)), ("move_to", (0.13, -0.3, 0.05)), ("move", (-0.21, 0.09, -0.02)),
@@ -273,7 +291,7 @@ MOVE_SEQUENCE = [("move_to", (0.13, -0.3, 0.05)), ("move_to", (0.13, -0.3, 0.05)
 
 
 if __name__ == "__main__":      # python tests/golden/make_golden.py [core semantic66 bayes66 warm_single host_steps]
-    todo = sys.argv[1:] or ["core", "semantic66", "bayes66", "warm_single", "host_steps", "semantic_toy"]
+    todo = sys.argv[1:] or ["core", "semantic66", "bayes66", "warm_single", "host_steps", "semantic_toy", "class_max_ref"]
     for name in todo:
         globals()[name]()
     print(sorted(os.listdir(OUT)))
