@@ -142,7 +142,14 @@ __global__ __launch_bounds__(64) void k_commit(KP P, Cells cells, const AccF* __
 // only grows, a stale smaller value can only cause a redundant atomic, never a missed one.
 __device__ __forceinline__ void ray_upper_min(unsigned int* key_ptr, float nz) {
   const unsigned int key = ~float_ord(nz);
+#ifdef RAY_KEY_NT_LOAD
   if (__builtin_nontemporal_load(key_ptr) < key) atomicMax(key_ptr, key);
+#else
+  // a DEVICE-COHERENT load (sc1): the atomics execute at the memory side, so a plain / nt load keeps seeing the value its own XCD's L2
+  // cached before the other seven XCDs raised the key -- and every visit below that stale value issues another atomic (the first
+  // frame after clear(), where every visit of the 39 % unknown cells comes here: measured in round 4)
+  if (__hip_atomic_load(key_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < key) atomicMax(key_ptr, key);
+#endif
 }
 
 // Cell index of a sample coordinate along one axis.  IDX selects how:
