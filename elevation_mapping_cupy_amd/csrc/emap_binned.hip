@@ -240,6 +240,19 @@ __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, Pose T, BinGeo G, con
   }
 }
 
+// Which (bin, tile of the bin) a workgroup of a tile kernel handles.  sub == 1: one workgroup per bin, in order.  sub > 1 (maps beyond
+// 16384 tiles): the `sub` workgroups of a bin all walk the bin's records and keep those of their own tile -- so they are placed 8
+// apart inside a group of 8 * sub consecutive workgroups: workgroup l runs on XCD l % 8 (observed dispatch rule, for speed only), the
+// siblings of a bin then share ONE XCD's L2 and start within a few dozen dispatches of each other: the bin's records come from HBM
+// once instead of `sub` times (round 4; before, the siblings were T workgroups apart: 16384 dispatches, nothing left in any cache).
+__device__ __forceinline__ void bin_of_block(const BinGeo& G, int& t, int& sb) {
+  const unsigned int l = blockIdx.x;
+  if (G.sub == 1) { t = (int)l; sb = 0; return; }
+  const unsigned int span = 8u * (unsigned int)G.sub, g = l / span, r = l - g * span;
+  sb = (int)(r >> 3); t = (int)(g * 8u + (r & 7u));            // (t may reach past the last bin in the final group: the callers return)
+}
+static inline unsigned int tile_grid(const BinGeo& G) { return G.sub == 1 ? (unsigned int)G.T : (unsigned int)(((G.T + 7) / 8) * 8 * G.sub); }
+
 // drift-inlier test of error_counting_kernel (custom_kernels.py:317-335) on the (h, v, valid, trav) of a cell
 __device__ __forceinline__ bool drift_inlier(const KP& P, const float4 m, float z) {
   return m.z > 0.5f && (double)fabsf(m.x - z) < (double)m.y * P.mt && (double)m.y < P.dcvi_half && (double)m.w > P.trav_inlier;
@@ -270,13 +283,16 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const B
                                                           ErrSlot* __restrict__ slots) {
   constexpr int NC = BIN_TR * BIN_TC;
   __shared__ float4 s_cell[NC];
-  const int t = blockIdx.x, ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
+  int t, sb;
+  bin_of_block(G, t, sb);
+  if (t >= G.T) return;
+  const int ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
   const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
-  const int row_base = (ty * G.sub + (int)blockIdx.y) * BIN_TR;
+  const int row_base = (ty * G.sub + sb) * BIN_TR;
   if (row_base >= P.nrows || r0 == r1) return;
   stage_hot_tile(P, cells, s_cell, row_base, tx);
   __syncthreads();
-  const unsigned int sel = blockIdx.y;
+  const unsigned int sel = (unsigned int)sb;
   for (unsigned int kb = r0; kb < r1; kb += TF_BLOCK) {     // uniform trip count: the wave reductions need all lanes
     const unsigned int k = kb + threadIdx.x;
     long long e_fix = 0; unsigned int inl = 0;
@@ -320,14 +336,17 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
   __shared__ unsigned long long s_h[NC], s_v[NC], s_latest[NC];
   __shared__ float4 s_cell[NC];            // (h, v, valid, trav) of the tile's cells, staged once (coalesced): no per-record gather
   __shared__ float s_shift;
-  const int t = blockIdx.x, ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
+  int t, sb;                                      // sb = which 16 x 64 tile of the bin (sub == 1 up to 16384 tiles)
+  bin_of_block(G, t, sb);
+  if (t >= G.T) return;                           // uniform, before any barrier
+  const int ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
   const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
   const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6, col = tx * BIN_TC + tc;
-  {                                               // blockIdx.y = which 16 x 64 tile of the bin (sub == 1 up to 16384 tiles)
-    const int sb = blockIdx.y, row_base = (ty * G.sub + sb) * BIN_TR;
+  {
+    const int row_base = (ty * G.sub + sb) * BIN_TR;
     if (row_base >= P.nrows) return;              // uniform, before any barrier
     const unsigned int sel = (unsigned int)sb;
-    if (threadIdx.x == 0) s_shift = GF.mode ? gate_fold(GF, F, blockIdx.x == 0 && blockIdx.y == 0) : F->shift;      // only pass 2 needs it
+    if (threadIdx.x == 0) s_shift = GF.mode ? gate_fold(GF, F, blockIdx.x == 0) : F->shift;      // only pass 2 needs it (workgroup 0 = bin 0, tile 0: always present)
     stage_hot_tile(P, cells, s_cell, row_base, tx);
     for (int k = threadIdx.x; k < NC; k += TF_BLOCK) { s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull; }
     __syncthreads();
@@ -517,13 +536,13 @@ void launch_bin_scatter(hipStream_t s, const KP& P, const Pose& T, const BinGeo&
 void launch_tile_count(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cells cells,
                        ErrSlot* slots) {
   static_assert(TF_BLOCK == BIN_TR * BIN_TC, "one thread per cell of a tile");
-  hipLaunchKernelGGL(k_tile_count, dim3(G.T, G.sub), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, slots);
+  hipLaunchKernelGGL(k_tile_count, dim3(tile_grid(G)), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, slots);
 }
 // fuse_average: commit + average in the tile kernel (whole frames); rays: the visibility pass follows (bitmap + inlier plane wanted)
 void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cells cells,
                      AccF* acc, FrameDev* F, bool fuse_average, bool rays, unsigned int* cnt_plane, unsigned long long* inert,
                      unsigned int* inl_plane, float* thr, const OverlapArgs& O, const GateFold& GF) {
-  const dim3 g(G.T, G.sub), b(TF_BLOCK);
+  const dim3 g(tile_grid(G)), b(TF_BLOCK);
   if (fuse_average && rays) hipLaunchKernelGGL((k_tile_fuse<true, true>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF);
   else if (fuse_average) hipLaunchKernelGGL((k_tile_fuse<true, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF);
   else hipLaunchKernelGGL((k_tile_fuse<false, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF);
@@ -548,12 +567,15 @@ __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSp
   const long chs = V.stride;
   __shared__ double s_sum[SEM_GROUP][NC];
   __shared__ unsigned int s_col[4][NC];                 // r, g, b, count of ONE colour layer at a time
-  const int t = blockIdx.x, ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
+  int t, sb;
+  bin_of_block(G, t, sb);                              // sb = which 16 x 64 tile of the bin
+  if (t >= G.T) return;
+  const int ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
   const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
   const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6, col = tx * BIN_TC + tc;
-  const int row_base = (ty * G.sub + (int)blockIdx.y) * BIN_TR;       // blockIdx.y = which 16 x 64 tile of the bin
+  const int row_base = (ty * G.sub + sb) * BIN_TR;
   if (row_base >= P.nrows) return;
-  const unsigned int sel = blockIdx.y;
+  const unsigned int sel = (unsigned int)sb;
   // one colour channel next to averaged channels (the usual rgb + features cloud): its accumulation rides along the first
   // group's record loop, so every point row is gathered once
   const bool ride = S.n_col == 1 && S.n_sum > 0;
@@ -686,5 +708,5 @@ __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSp
 }
 void launch_tile_semantic(hipStream_t s, const KP& P, const BinGeo& G, const SemSpec& S, const BinRec* recs, const unsigned int* tile_start,
                           const ChanView& V, long n, const unsigned int* cnt_plane, float* sem, float* alpha_planes, long plane) {
-  hipLaunchKernelGGL(k_tile_semantic, dim3(G.T, G.sub), dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, V, n, cnt_plane, sem, alpha_planes, plane);
+  hipLaunchKernelGGL(k_tile_semantic, dim3(tile_grid(G)), dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, V, n, cnt_plane, sem, alpha_planes, plane);
 }
