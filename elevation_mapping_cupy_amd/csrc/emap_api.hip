@@ -53,7 +53,7 @@ void launch_erode(hipStream_t, int, int, const float*, float*);
 void launch_overlap(hipStream_t, const KP&, Cells, int, int, float, float);
 void launch_var_time(hipStream_t, const KP&, Cells, int, int);
 int post_tile_rows(const KP&);
-void launch_post(hipStream_t, const KP&, const float*, const float*, const float*, const float*, Cells, float*, float*, long, int, int, const int*, const int*, int);
+void launch_post(hipStream_t, const KP&, const float*, const float*, const float*, const float*, Cells, float*, float*, long, int, int, const int*, const int*, int, int);
 void launch_get_plane(hipStream_t, const KP&, Cells, int, float*);
 void launch_publish(hipStream_t, const KP&, Cells, const float*, long, int, float, int, float*);
 void launch_set_plane(hipStream_t, const KP&, Cells, int, const float*);
@@ -868,7 +868,7 @@ int emap_overlap_clear(emap_ctx* ctx, float t_z) {
 
 // Stencil stages.  The kernels work on LOGICAL rows; a strip owns the physical rows [row_begin, row_begin + row_count), i.e. the
 // logical rows ls + j (mod cell_n), j = 0 .. row_count-1, with ls = (row_begin - org_r) mod cell_n: one or two logical intervals.
-static void post_rows(emap_ctx* ctx, int nj, const int* j0, const int* j1, int stage) {      // outputs for the strip's rows j0[k] <= j < j1[k]
+static void post_rows(emap_ctx* ctx, int nj, const int* j0, const int* j1, int stage, int tile_rows = 0) {      // outputs for the strip's rows j0[k] <= j < j1[k]
   const int C = ctx->prm.cell_n;
   const int ls = ((ctx->strip.row_begin - ctx->kp.org_r) % C + C) % C;
   int sb[4], se[4], n = 0;
@@ -883,7 +883,7 @@ static void post_rows(emap_ctx* ctx, int nj, const int* j0, const int* j1, int s
     else { sb[n] = b; se[n] = C; n++; sb[n] = 0; se[n] = e - C; n++; }    // the circular seam lies inside: never inside one tile
   }
   launch_post(ctx->stream, ctx->kp, ctx->prm.w1, ctx->prm.w2, ctx->prm.w3, ctx->prm.w_out, ctx->cells, ctx->trav_in, ctx->normal,
-              ctx->ncells_alloc, ctx->prm.dilation_size, n, sb, se, stage);
+              ctx->ncells_alloc, ctx->prm.dilation_size, n, sb, se, stage, tile_rows);
 }
 
 int emap_dilate(emap_ctx* ctx) {          // dilation_filter_kernel alone: traversability_input (k_post, stage 1)
@@ -911,7 +911,8 @@ int emap_post_part(emap_ctx* ctx, int32_t part) {
   const int jb0[2] = {0, hi}, je0[2] = {lo, n}, z = 0;
   if (part == 0) post_rows(ctx, 1, &z, &n, 0);
   else if (part == 1) post_rows(ctx, 1, &lo, &hi, 0);
-  else post_rows(ctx, 2, jb0, je0, 0);               // at most 3 logical intervals: the seam lies in one of the two boundary bands
+  else { int tr = 4; while (tr < reach && tr < 32) tr *= 2;      // the boundary bands are `reach` rows high: tiles of that height, not the strip's 32-row tiles
+         post_rows(ctx, 2, jb0, je0, 0, tr); }          // at most 3 logical intervals: the seam lies in one of the two boundary bands
   if (part != 1) { ctx->kp.norg_r = ctx->torg_r = ctx->kp.org_r; ctx->kp.norg_c = ctx->torg_c = ctx->kp.org_c; }   // outputs carry the current origin
   CK(hipGetLastError());
   return EMAP_OK;

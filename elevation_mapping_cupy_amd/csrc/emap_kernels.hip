@@ -1316,8 +1316,10 @@ int post_tile_rows(const KP& P) {
   return R;
 }
 // outputs for up to four LOGICAL row intervals [seg_b[k], seg_e[k]) (owned by this strip, no circular seam inside); stage 1 = dilation only
+// tile_rows: 0 = the size post_tile_rows picks for the whole strip; else the tile height for THIS launch (the boundary bands of a strip
+// are dilation_size + 4 rows high: 32-row tiles would stage 44 region rows for 7 output rows)
 void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, const float* w3, const float* wo, Cells cells,
-                 float* trav_in, float* normal, long plane_stride, int d, int nseg, const int* seg_b, const int* seg_e, int stage) {
+                 float* trav_in, float* normal, long plane_stride, int d, int nseg, const int* seg_b, const int* seg_e, int stage, int tile_rows) {
   TravW W;
   const float* wq[3] = {w1, w2, w3};                       // conv weights [channel][tap] -> [tap][channel]
   for (int q = 0; q < 3; ++q)
@@ -1325,7 +1327,8 @@ void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, c
       for (int tap = 0; tap < 9; ++tap) W.w[q][tap][ch] = wq[q][ch * 9 + tap];
       W.wo[q][ch] = wo[q * 4 + ch];
     }
-  const int R = post_tile_rows(P);
+  int R = post_tile_rows(P);
+  if (tile_rows == 4 || tile_rows == 8 || tile_rows == 16 || tile_rows == 32) { if (tile_rows < R && post_lds_bytes(tile_rows, d) <= 150 * 1024) R = tile_rows; }
   PostSegs S; memset(&S, 0, sizeof S);
   S.emagic = (unsigned int)((0x100000000ull + (unsigned long long)(6 + 2 * d) - 1ull) / (unsigned long long)(6 + 2 * d));
   int tiles = 0;

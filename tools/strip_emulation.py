@@ -44,6 +44,7 @@ def main():
                     "(sharded.ray_balanced_weights: thin around the sensor) unless --equal-strips")
     ap.add_argument("--equal-strips", action="store_true")
     ap.add_argument("--no-lockstep", action="store_true")
+    ap.add_argument("--skip-single", action="store_true", help="profiling aid: run the single context only briefly (its kernels would mix into a rocprofv3 --stats summary of the strips)")
     ap.add_argument("--interleaved-cloud", action="store_true", help="cfg5: interleaved (N, 7) device rows instead of the de-interleaved layout of an uploaded cloud")
     ap.add_argument("--ray-mode", default="auto", choices=["auto", "by_row", "by_ray"], help="with --rays: how the sharded frame runs the visibility "
                     "pass (emap_set_ray_mode; auto = by ray from 2048^2 cells on)")
@@ -137,8 +138,10 @@ def main():
     # ---- single context: the plain frame (emap_update) and the world-1 sharded frame over the REAL RCCL ------------------------------
     em = make_rank(1, 0, False)
     f_plain = frame_fn(em, False)
+    if a.skip_single:                 # (profiling runs of the strips alone: rocprofv3 --stats aggregates by kernel name)
+        warm = lambda e, f: [f(i) for i in range(2)] and e.sync()      # noqa: E731
     warm(em, f_plain)
-    single_ms = timed_loops(em, f_plain, a.steps)
+    single_ms = timed_loops(em, f_plain, a.steps if not a.skip_single else 1, reps=3 if not a.skip_single else 1)
     ev = bench.event_overhead(em._lib, em._ctx)
     st, _ = bench.stage_profile(em._lib, em._ctx, lambda i, s: f_plain(i), min(a.steps, 10), with_stats=False)
     single_stage = {k: round(max(v - ev, 0.0), 5) for k, v in st.items()}
