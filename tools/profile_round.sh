@@ -11,10 +11,10 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for wl in cfg2 cfg3; do
   steps=20; [ $wl = cfg3 ] && steps=8
-  rocprofv3 --kernel-trace --stats -d $O/${wl}_trace -- python $R/bench.py --workload $wl --steps $steps --warmup 3 --no-cpu-baseline > $O/${wl}_trace.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/${wl}_trace -- python $R/bench.py --workload $wl --steps $steps --warmup 3 --no-cpu-baseline --no-large > $O/${wl}_trace.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
     n=$(echo $c | cut -d" " -f1)
-    rocprofv3 --kernel-trace --pmc $c -d $O/${wl}_pmc_$n -- python $R/bench.py --workload $wl --steps 6 --warmup 2 --no-cpu-baseline > $O/${wl}_pmc_$n.log 2>&1
+    rocprofv3 --kernel-trace --pmc $c -d $O/${wl}_pmc_$n -- python $R/bench.py --workload $wl --steps 6 --warmup 2 --no-cpu-baseline --no-large > $O/${wl}_pmc_$n.log 2>&1
   done
 done
 ls -R $O | head -40
