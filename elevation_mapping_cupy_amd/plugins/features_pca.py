@@ -1,7 +1,12 @@
 """``FeaturesPca`` plugin (reference EM/plugins/features_pca.py:14-96): the layers whose names match ``process_layer_names`` (clipped
 to [-1, 1]) are the feature vector of a cell; its first three principal components, each scaled to 0..255 over the map, make the
 packed 0x00RRGGBB colour of the cell.  Host code in the reference too (``.get()`` + scikit-learn); the PCA here is the same
-definition (centred data, SVD, components' signs fixed like scikit-learn's ``svd_flip``) without the dependency."""
+definition (centred data, SVD, components' signs fixed like scikit-learn's ``svd_flip``) without the dependency.
+
+Which scikit-learn this matches: the sign convention is the v-based ``svd_flip`` of scikit-learn >= 1.5 with its exact
+("full") solver; older releases flip by the LEFT singular vectors and pick the randomized solver above 500 samples, so a component --
+and with it a colour channel -- can come out inverted relative to such an environment (the reference pins no version).  Fewer than
+three matching layers: the missing components are zero columns here, scikit-learn raises."""
 import re
 from typing import List
 
