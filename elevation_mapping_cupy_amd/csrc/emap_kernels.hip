@@ -140,16 +140,19 @@ __global__ __launch_bounds__(64) void k_commit(KP P, Cells cells, const AccF* __
 // min-reduce of nz into the ordered-uint key.  Thousands of rays cross the same unknown cell and an atomic costs
 // ~44 ns/Mop whatever the address pattern, so test first with a plain (possibly stale => conservative) load: the key
 // only grows, a stale smaller value can only cause a redundant atomic, never a missed one.
-__device__ __forceinline__ void ray_upper_min(unsigned int* key_ptr, float nz) {
-  const unsigned int key = ~float_ord(nz);
+__device__ __forceinline__ unsigned int ray_key_load(const unsigned int* key_ptr) {
 #ifdef RAY_KEY_NT_LOAD
-  if (__builtin_nontemporal_load(key_ptr) < key) atomicMax(key_ptr, key);
+  return __builtin_nontemporal_load(key_ptr);
 #else
   // a DEVICE-COHERENT load (sc1): the atomics execute at the memory side, so a plain / nt load keeps seeing the value its own XCD's L2
   // cached before the other seven XCDs raised the key -- and every visit below that stale value issues another atomic (the first
   // frame after clear(), where every visit of the 39 % unknown cells comes here: measured in round 4)
-  if (__hip_atomic_load(key_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < key) atomicMax(key_ptr, key);
+  return __hip_atomic_load(key_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
+}
+__device__ __forceinline__ void ray_upper_min(unsigned int* key_ptr, float nz) {
+  const unsigned int key = ~float_ord(nz);
+  if (ray_key_load(key_ptr) < key) atomicMax(key_ptr, key);
 }
 
 // Cell index of a sample coordinate along one axis.  IDX selects how:
@@ -343,36 +346,82 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     if (!__builtin_amdgcn_ballot_w64(live)) return;                                      // wave-uniform
     const float erx = __shfl(rx, src, 64), ery = __shfl(ry, src, 64), edec = __shfl(dec, src, 64);
     const float egx = __shfl(gx, src, 64), egy = __shfl(gy, src, 64), egz = __shfl(gz, src, 64);
-    if (!live) return;
-    const float nx = T.t[0] + erx * s, ny = T.t[1] + ery * s;
-    const float ddx = egx - nx, ddy = egy - ny, ddz = egz - nz;
-    const float d = Qf<MODE>(ddx * ddx + ddy * ddy + ddz * ddz);
-    if (d < Rt.f_d_thresh) return;             // (double)d < 0.1: too close to the point (:225-226)
-    // a VIRGIN block (+INF: every cell quiet or unknown without a bound -- a cleared map, the band a map shift brings in): the
-    // visit can only lower the cell's upper bound (:228-234 with is_upper_bound < 0.5), no cell load needed
-    if (bthr == INFINITY) { ray_upper_min(accr_key(AR, c), nz); return; }
-    const float4 m0 = cells.hot[c], m1 = cells.cold[c];       // h v valid trav | time upper is_upper valid'
-    if (m0.z < 0.5f) {                         // unknown cell: upper bound (:228-234)
-      if (nz < m1.y || m1.z < 0.5f) ray_upper_min(accr_key(AR, c), nz);
+    // What the visit contributes: a decrement + a hit (the penetration branch) and / or a lower upper bound.  Rays that end in one
+    // tile travel together, so many of the 64 visits of a batch meet in the SAME cell at the same step -- after a long occlusion
+    // (every cell stale) or a clear() (every cell unknown) each of them used to cost two or three device atomics at ~45 ns/Mop, the
+    // whole frame 35x the steady one.  The contributions are integers under add / max, so the wave first combines the visits of a
+    // cell in LDS (32 slots hashed by cell, carved out of the 64 queue entries this batch has just vacated) and one lane per slot
+    // goes out to memory; a visit whose slot went to another cell goes out by itself.  Any grouping gives the same bits.
+    long long c_dec = 0; unsigned int c_key = 0u, c_hit = 0u; bool contrib = false;
+    if (live) {
+      const float nx = T.t[0] + erx * s, ny = T.t[1] + ery * s;
+      const float ddx = egx - nx, ddy = egy - ny, ddz = egz - nz;
+      const float d = Qf<MODE>(ddx * ddx + ddy * ddy + ddz * ddz);
+      if (!(d < Rt.f_d_thresh)) {                // (double)d < 0.1: too close to the point (:225-226)
+        // a VIRGIN block (+INF: every cell quiet or unknown without a bound -- a cleared map, the band a map shift brings in): the
+        // visit can only lower the cell's upper bound (:228-234 with is_upper_bound < 0.5), no cell load needed
+        if (bthr == INFINITY) { contrib = true; c_key = ~float_ord(nz); }
+        else {
+          const float4 m0 = cells.hot[c], m1 = cells.cold[c];       // h v valid trav | time upper is_upper valid'
+          if (m0.z < 0.5f) {                       // unknown cell: upper bound (:228-234)
+            if (nz < m1.y || m1.z < 0.5f) { contrib = true; c_key = ~float_ord(nz); }
+          } else if (!(m1.x < 0.5f) &&             // not updated recently (:236)
+                     (double)m0.x > (double)nz + 0.01 - fmin((double)m0.y, 1.0) * 0.05) {
+            // the normal planes keep the origin they were written with (the reference does not shift normal_map): logical -> their rows
+            float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+            if (P.wmode) { n0 = normal[c]; n1 = normal[plane_stride + c]; n2 = normal[2 * plane_stride + c]; }      // (uniform) ray window: the planes were gathered cell by cell
+            else {
+              const int nlr = local_row(P, wrap_up(lix + P.norg_r, C));
+              if (nlr >= 0) { const long cn = (long)nlr * C + wrap_up(liy + P.norg_c, C); n0 = normal[cn]; n1 = normal[plane_stride + cn]; n2 = normal[2 * plane_stride + cn]; }
+            }
+            const float ip = erx * Qf<MODE>(n0) + ery * Qf<MODE>(n1) + erz * Qf<MODE>(n2);
+            if (!(fabsf(ip) < Rt.f_cos_thresh)) {
+              const float n_inl = (float)inl[(long)c * inl_stride];      // newmap[3]: drift inliers of this frame in the cell
+              if (!(n_inl > Rt.f_wall && m1.x < 1.0f)) {
+                contrib = true; c_hit = 1u;
+                c_dec = __double2ll_rn((double)edec * EM_SCALE_V);
+                if (nz < m1.y || m1.z < 0.5f) c_key = ~float_ord(nz);
+              }
+            }
+          }
+        }
+      }
+    }
+    const unsigned long long cm = __builtin_amdgcn_ballot_w64(contrib);
+    if (!cm) return;                                                   // wave-uniform
+    auto flush = [&](unsigned int cc, long long d_sum, unsigned int hits, unsigned int key) {
+      if (hits) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(accr_dec(AR, cc)), (unsigned long long)d_sum);
+        atomicAdd(accr_hits(AR, cc), hits);
+      }
+      if (key) { unsigned int* kp = accr_key(AR, cc); if (ray_key_load(kp) < key) atomicMax(kp, key); }
+    };
+    if (!__builtin_amdgcn_ballot_w64(c_hit != 0u) || __popcll(cm) < 4) {
+      // upper bounds only (the frames after clear(), a band a shift brought in) or next to nothing to combine: the visits of one step
+      // sit in the queue in lane order, so the rays that share a cell are mostly NEIGHBOURS -- a visit is dropped when the next
+      // lane's lowers the same cell at least as far (the lowest of a run always goes out), the rest goes out directly
+      const unsigned int cn = (unsigned int)__shfl_down((int)c, 1, 64), kn = (unsigned int)__shfl_down((int)c_key, 1, 64);
+      const bool covered = !c_hit && lane < 63 && cn == c && c_key <= kn;
+      if (contrib && !covered) flush(c, c_dec, c_hit, c_key);
       return;
     }
-    if (m1.x < 0.5f) return;                   // updated recently (:236)
-    if ((double)m0.x > (double)nz + 0.01 - fmin((double)m0.y, 1.0) * 0.05) {
-      // the normal planes keep the origin they were written with (the reference does not shift normal_map): logical -> their rows
-      float n0 = 0.f, n1 = 0.f, n2 = 0.f;
-      if (P.wmode) { n0 = normal[c]; n1 = normal[plane_stride + c]; n2 = normal[2 * plane_stride + c]; }      // (uniform) ray window: the planes were gathered cell by cell
-      else {
-        const int nlr = local_row(P, wrap_up(lix + P.norg_r, C));
-        if (nlr >= 0) { const long cn = (long)nlr * C + wrap_up(liy + P.norg_c, C); n0 = normal[cn]; n1 = normal[plane_stride + cn]; n2 = normal[2 * plane_stride + cn]; }
-      }
-      const float ip = erx * Qf<MODE>(n0) + ery * Qf<MODE>(n1) + erz * Qf<MODE>(n2);
-      if (fabsf(ip) < Rt.f_cos_thresh) return;
-      const float n_inl = (float)inl[(long)c * inl_stride];      // newmap[3]: drift inliers of this frame in the cell
-      if (n_inl > Rt.f_wall && m1.x < 1.0f) return;
-      atomicAdd(reinterpret_cast<unsigned long long*>(accr_dec(AR, c)), (unsigned long long)__double2ll_rn((double)edec * EM_SCALE_V));
-      atomicAdd(accr_hits(AR, c), 1u);
-      if (nz < m1.y || m1.z < 0.5f) ray_upper_min(accr_key(AR, c), nz);
+    // slots: tag | key in the batch's qc entries, hits in its ql entries, the 64-bit sums in its qz entries (8-byte aligned: one word of slack)
+    unsigned int* a_tag = qc + first;  unsigned int* a_key = a_tag + 32;  unsigned int* a_hit = ql + first;
+    unsigned long long* a_dec = reinterpret_cast<unsigned long long*>(qz + ((first + 1) & ~1));
+    __builtin_amdgcn_wave_barrier();                                   // (the batch was read into registers above)
+    if (lane < 32) { a_tag[lane] = 0xffffffffu; a_key[lane] = 0u; a_hit[lane] = 0u; a_dec[lane] = 0ull; }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned int slot = (c * 0x9E3779B1u) >> 27;
+    if (contrib) a_tag[slot] = c;                                      // one of the cells that hash here wins the slot
+    __builtin_amdgcn_wave_barrier();
+    const bool member = contrib && a_tag[slot] == c;
+    if (member) {
+      if (c_hit) { atomicAdd(&a_dec[slot], (unsigned long long)c_dec); atomicAdd(&a_hit[slot], 1u); }
+      if (c_key) atomicMax(&a_key[slot], c_key);
     }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32) { const unsigned int cc = a_tag[lane]; if (cc != 0xffffffffu) flush(cc, (long long)a_dec[lane], a_hit[lane], a_key[lane]); }
+    if (contrib && !member) flush(c, c_dec, c_hit, c_key);
   };
   // ---- the march ----------------------------------------------------------------------------------------------------------
   // Measured on MI355X (tools/clockbench.hip, 8 waves per SIMD): a SIMD issues about ONE instruction per nanosecond whatever its
