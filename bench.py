@@ -87,6 +87,7 @@ def parse(argv=None):
     ap.add_argument("--no-cfg3", action="store_true", help="skip the config.cfg3 and config.cfg1 sub-measurements of the default cfg2 line")
     ap.add_argument("--interleaved-cloud", action="store_true", help="cfg5: bind the multi-modal cloud as interleaved (N, 3 + K) device rows instead of "
                     "the de-interleaved layout an uploaded cloud has (emap_upload_points)")
+    ap.add_argument("--no-terrain", action="store_true", help="skip config.cfg3.terrain (the cfg3 frame on a spatially coherent, scan-ordered scene)")
     ap.add_argument("--no-large", action="store_true", help="skip the config.cfg4 / config.cfg5 sub-measurements (4096^2 and 8192^2 on one GPU) of the default line")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
     ap.add_argument("--scatter", default="auto", choices=["auto", "atomic", "binned"])
@@ -434,9 +435,12 @@ def run_single(a, local_rank=0):
     t = np.array([0, 0, 1], np.float32)
     Rp, tp = _lib.f32p(R), _lib.f32p(t)
 
-    def make_frame(lib, ctx):
+    def make_frame(lib, ctx, cl_dev=None, n_pts=None):
+        cl_dev = cl_dev or clouds_dev
+        n_pts = n_pts or N
+
         def frame(i, stats=None):
-            rc = bind_cloud(lib, ctx, clouds_dev[i % NCLOUD], N)
+            rc = bind_cloud(lib, ctx, cl_dev[i % len(cl_dev)], n_pts)
             rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
             if multimodal:
                 rc = rc or lib.emap_semantic_update(ctx, Rp, tp, ct.byref(spec))
@@ -518,6 +522,27 @@ def run_single(a, local_rank=0):
                 "ray_visits_per_frame": r3["ray_visits_per_frame"], "ray_visits_per_s": r3["ray_visits_per_s"],
                 "stage_ms": r3["stage_ms"], "cold_start_ms": cold}
         em3.close()
+        # ---- the same frame on a spatially COHERENT scene: scan-ordered beams ray-cast at a terrain with walls (tests/_fixtures.py:
+        # terrain_cloud) instead of white noise -- neighbouring beams end in neighbouring cells and travel through the same cells,
+        # rays do not dive under the ground they measured, 11 % of the cells are ever seen (density ~ 1/range).  Sensor noise and a
+        # scene that keeps changing (every second obstacle moves between the clouds) as a robot would see it.
+        if C == 1024 and N == 1_000_000 and not a.no_terrain:
+            import _fixtures as fx
+            th = [fx.terrain_cloud(C, 2000, 500, s_, shift=sh) for s_, sh in enumerate((0.0, 0.4, -0.3, 0.2))]
+            td = device_clouds(hip, th, True)
+            emt = ElevationMap(par3); emt.set_scatter_mode(a.scatter)
+            frt = make_frame(emt._lib, emt._ctx, td, th[0].shape[0])
+            warm(emt, frt)
+            wallt, mst, _ = timed(emt, frt, k3, loops=3)
+            stt, vist = stage_profile(emt._lib, emt._ctx, frt, min(k3, 8))
+            valid_t = float((emt.get_layer_raw(2) > 0.5).mean())
+            coldt = cold_start(emt, frt)
+            cfg3["terrain"] = {"workload": "cfg3 on a coherent scene: 2000 x 500 scan-ordered beams ray-cast at rolling ground with moving walls, 1 cm range noise",
+                               "ms_per_step": round(wallt * 1e3 / k3, 5), "value": round(th[0].shape[0] * k3 / wallt / 1e6, 2), "unit": "Mpoints/s",
+                               "valid_cell_fraction": round(valid_t, 4), "ray_visits_per_frame": int(vist),
+                               "stage_ms": {k_: round(v_, 5) for k_, v_ in stt.items() if v_ > 0}, "cold_start_ms": coldt}
+            emt.close()
+            free_clouds(hip, td)
 
     # ---- config.cfg1: robot scale -- the 200 x 200 (+ border) map and 50 k-point clouds the reference ships with (BASELINE configs[0]
     # on the GPU), without and with the visibility pass: per-frame latency is what a user of the drop-in sees first

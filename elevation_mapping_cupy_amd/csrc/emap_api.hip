@@ -65,12 +65,12 @@ void launch_band_clear(hipStream_t, const KP&, float*, int, long, int, int);
 
 // tile-binned scatter (emap_binned.hip)
 void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, unsigned int*, BinStg*, unsigned int*);
-void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*, unsigned int*);
+void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*, unsigned int*, const SplitView&);
 void launch_bin_scatter(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, const unsigned int*, const unsigned int*, BinRec*, const BinStg*, const unsigned int*);
-void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, ErrSlot*);
+void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, ErrSlot*, const SplitView&, long);
 void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const ChanView&, long,
                           const unsigned int*, float*, float*, long);
-void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, AccF*, FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&, const GateFold&);
+void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, AccF*, FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&, const GateFold&, const SplitView&, long);
 #define BIN_MAX_T 16384
 #define BIN_MAX_B 2048
 
@@ -141,6 +141,10 @@ struct emap_ctx {
   int force_sub;                   // test hook: minimum bin height factor (emap_set_scatter_mode bits 8..15)
   bool frame_binned;               // the count stage of the current frame used the binned path
   unsigned int* bin_sync;          // ticket counters of k_bin_scan (last_block_ticket), zero between launches
+  SplitView split;                 // heavy tiles reduced by several workgroups (emap_device.h); split.on: this frame's scan listed them
+  void* split_mem;                 // one allocation behind split's arrays
+  volatile unsigned int* split_need;   // host-mapped word: the parts the last scan the device has finished would have listed
+  bool split_dirty;                // k_tile_count has filled slots that no k_tile_fuse has cleared yet
   GateFold gate_fold;              // multi-GPU frames: gate decision on the all-reduced totals folded into the tile kernel (mode 0: k_gate ran)
   OverlapArgs ov_args;             // clear_overlap_map folded into the frame's rewriting kernels (on = 0: separate k_overlap launch)
   bool gate_possible;              // false inside emap_update when the host already knows that the drift gate cannot fire: the per-tile
@@ -389,7 +393,7 @@ int emap_destroy(emap_ctx* ctx) {
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   delete ctx->workers;
   hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert); hipFree(ctx->inl_plane); hipFree(ctx->ray_thr);
-  hipFree(ctx->bin_recs); hipFree(ctx->bin_own); hipFree(ctx->bin_own_cnt); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start); hipFree(ctx->bin_sync);
+  hipFree(ctx->bin_recs); hipFree(ctx->bin_own); hipFree(ctx->bin_own_cnt); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start); hipFree(ctx->bin_sync); hipFree(ctx->split_mem); if (ctx->split_need) hipHostFree((void*)ctx->split_need);
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   emap_comm_destroy(ctx);
@@ -647,6 +651,26 @@ static int ensure_bins(emap_ctx* ctx, bool raybin) {
     CK(hipMalloc((void**)&ctx->bin_sync, sizeof(unsigned int) * EM_TICKET_WORDS));
     CK(hipMemsetAsync(ctx->bin_sync, 0, sizeof(unsigned int) * EM_TICKET_WORDS, ctx->stream));
   }
+  if (!ctx->split_mem) {           // scratch of the heavy tiles (SplitView): 40 bytes per cell of SPLIT_MAX_SLOTS tiles + the lists, zero between frames
+    const size_t cells = (size_t)SPLIT_MAX_SLOTS * SPLIT_CELLS;
+    const size_t words = (size_t)(BIN_MAX_T + 2) + SPLIT_MAX_EXTRA + 8 + SPLIT_MAX_SLOTS + 4 * cells, bytes = 4 * words + 8 * 3 * cells + 64;
+    void* m = nullptr;
+    CK(hipMalloc(&m, bytes));
+    if (hipMemsetAsync(m, 0, bytes, ctx->stream) != hipSuccess) { hipFree(m); ctx->err = "hipMemsetAsync(split scratch)"; return EMAP_ERR_HIP; }
+    ctx->split_mem = m;
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(m);          // the 64-bit planes first (alignment)
+    ctx->split.h = q; ctx->split.v = q + cells; ctx->split.latest = q + 2 * cells;
+    unsigned int* u = reinterpret_cast<unsigned int*>(q + 3 * cells);
+    ctx->split.pts = u; ctx->split.inl = u + cells; ctx->split.cnt = u + 2 * cells; ctx->split.out = u + 3 * cells; u += 4 * cells;
+    ctx->split.tick = u; u += SPLIT_MAX_SLOTS;
+    ctx->split.tile_slot = u; u += BIN_MAX_T + 2;
+    ctx->split.extra = u; u += SPLIT_MAX_EXTRA;
+    ctx->split.n_extra = u;
+    CK(hipHostMalloc((void**)&ctx->split_need, 64, hipHostMallocMapped));
+    *ctx->split_need = 0u;
+    CK(hipHostGetDevicePointer((void**)&ctx->split.need_host, const_cast<unsigned int*>(ctx->split_need), 0));
+    ctx->split.on = 0;
+  }
   if (n > ctx->bin_cap) {
     CK(hipStreamSynchronize(ctx->stream));
     if (ctx->bin_recs) CK(hipFree(ctx->bin_recs));
@@ -709,11 +733,26 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
     if (tm) CK(hipEventRecord(ctx->ev[ST_HIST], ctx->stream));
     launch_bin_hist(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, own, ctx->bin_own_cnt);
     if (tm) CK(hipEventRecord(ctx->ev[ST_SCAN], ctx->stream));
-    launch_bin_scan(ctx->stream, ctx->bg, ctx->bin_hist, ctx->bin_tile_total, ctx->bin_tile_start, ctx->bin_sync);
+    // heavy tiles are split only when k_tile_count runs in this frame (it leaves the per-cell counts k_tile_fuse's parts need)
+    static const bool split_off = getenv("EMAP_SPLIT") && atoi(getenv("EMAP_SPLIT")) == 0;      // A/B and test hook
+    ctx->split.on = ctx->gate_possible && !split_off ? 1 : 0;
+    {   // extra workgroups of this frame's tile kernels: what the most recent finished scan asked for, + 25 % (a heavy tile that finds
+        // no room is reduced by its own workgroup alone); the first frame of a cloud with heavy tiles therefore runs unsplit
+      static const int cap_forced = getenv("EMAP_SPLIT_CAP") ? atoi(getenv("EMAP_SPLIT_CAP")) : -1;      // test hook
+      const unsigned int need = *ctx->split_need;
+      long cap = need ? (long)need + need / 4 + 8 : 0;
+      if (cap_forced >= 0) cap = cap_forced;
+      if (cap > (long)SPLIT_MAX_EXTRA) cap = SPLIT_MAX_EXTRA;
+      ctx->split.cap = (int)((cap + 7) & ~7L);
+    }
+    if (ctx->split.on && ctx->split_dirty)            // a count stage whose fuse stage never came (staged API): its slots are still filled
+      CK(hipMemsetAsync(ctx->split_mem, 0, (size_t)SPLIT_MAX_SLOTS * SPLIT_CELLS * 40 + 4 * SPLIT_MAX_SLOTS, ctx->stream));
+    ctx->split_dirty = ctx->split.on != 0;
+    launch_bin_scan(ctx->stream, ctx->bg, ctx->bin_hist, ctx->bin_tile_total, ctx->bin_tile_start, ctx->bin_sync, ctx->split);
     if (tm) CK(hipEventRecord(ctx->ev[ST_SCATTER], ctx->stream));
     launch_bin_scatter(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, ctx->bin_tile_start, ctx->bin_recs, own, ctx->bin_own_cnt);
     if (tm) CK(hipEventRecord(ctx->ev[ST_GATE], ctx->stream));        // the "gate" stage = per-tile error sums + k_gate
-    if (ctx->gate_possible) launch_tile_count(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->slots);
+    if (ctx->gate_possible) launch_tile_count(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->slots, ctx->split, ctx->n_pts);
   } else {
     if (ctx->stage_timing && ctx->in_update)
       for (int e = ST_HIST; e <= ST_SCATTER; ++e) CK(hipEventRecord(ctx->ev[e], ctx->stream));
@@ -782,7 +821,8 @@ static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool fus
       CK(hipMemsetAsync(ctx->inert, 0, sizeof(unsigned long long) * ((size_t)ctx->strip.row_count * ((ctx->prm.cell_n + 63) / 64)), ctx->stream));
     if (fuse_average && rays) ctx->inert_zero = false;
     launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame, fuse_average, rays,
-                    ctx->cnt_plane, ctx->inert, ctx->inl_plane, ctx->ray_thr, ctx->ov_args, ctx->gate_fold);
+                    ctx->cnt_plane, ctx->inert, ctx->inl_plane, ctx->ray_thr, ctx->ov_args, ctx->gate_fold, ctx->split, ctx->n_pts);
+    ctx->split_dirty = false;
     ctx->gate_fold.mode = 0;
     if (fuse_average) ctx->kp.mv.n = 0;   // every owned cell rewritten: pending map shifts are in memory now
     CK(hipGetLastError());

@@ -150,10 +150,12 @@ __global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const 
 #define SCAN_BLK 1024
 #define SCAN_RPW 16      /* rows per wave and slab */
 __global__ __launch_bounds__(SCAN_BLK) void k_bin_scan(BinGeo G, unsigned int* __restrict__ hist, unsigned int* __restrict__ tile_total,
-                                                        unsigned int* __restrict__ tile_start, unsigned int* __restrict__ sync) {
+                                                        unsigned int* __restrict__ tile_start, unsigned int* __restrict__ sync, SplitView SV) {
   constexpr int NW = SCAN_BLK / 64;
   __shared__ unsigned int part[NW][SCAN_TT];
+  __shared__ unsigned int s_nslot, s_nextra;                // heavy tiles of this frame (SplitView, emap_device.h)
   __shared__ bool s_last;
+  if (threadIdx.x == 0) { s_nslot = 0u; s_nextra = 0u; }   // (published by the barriers of the slab loop / the ticket hand-off below)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = blockIdx.x * SCAN_TT + lane;
   const bool col_ok = t < G.pitch;
   unsigned int carry = 0u;                                 // per column (lane), identical in all waves
@@ -201,8 +203,30 @@ __global__ __launch_bounds__(SCAN_BLK) void k_bin_scan(BinGeo G, unsigned int* _
 #pragma unroll
   for (int k = 0; k < NW; ++k) { const unsigned int x = part[0][k]; if (k < w) base += x; total += x; }
   unsigned int run = base + inc - mine;
-  for (int tt = t_lo; tt < t_hi; ++tt) { tile_start[tt] = run; run += __hip_atomic_load(&tile_total[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  for (int tt = t_lo; tt < t_hi; ++tt) {
+    const unsigned int n_t = __hip_atomic_load(&tile_total[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tile_start[tt] = run; run += n_t;
+    if (SV.on && tt < G.T) {                                  // heavy tile: a slot per stacked tile of the bin, an extra workgroup per further part
+      if (n_t > SPLIT_CAP) {                                  // (tile_slot is read for such tiles only)
+        const unsigned int np = split_parts(n_t);
+        const unsigned int s0 = atomicAdd(&s_nslot, (unsigned int)G.sub), e0 = atomicAdd(&s_nextra, np - 1u);
+        const bool fits = s0 + (unsigned int)G.sub <= SPLIT_MAX_SLOTS && e0 + np - 1u <= (unsigned int)SV.cap;     // (cap: the extra workgroups of this frame's launches)
+        for (unsigned int q = 1u; q < np; ++q) if (e0 + q - 1u < (unsigned int)SV.cap) SV.extra[e0 + q - 1u] = fits ? (((unsigned int)tt << 8) | q) : SPLIT_NONE;
+        SV.tile_slot[tt] = fits ? s0 : SPLIT_NONE;
+      }
+    }
+  }
   if (threadIdx.x == 0) tile_start[G.TB] = total;             // = number of sorted records
+  if (SV.on) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      *SV.n_extra = min(s_nextra, (unsigned int)SV.cap);
+      if (s_nextra != SV.n_extra[1]) {                       // what the NEXT frames' launches should provide (host-mapped: a store across PCIe, only when it changes)
+        SV.n_extra[1] = s_nextra;
+        __hip_atomic_store(SV.need_host, s_nextra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 template <int MODE, int BLK, bool STRIP>
@@ -251,7 +275,49 @@ __device__ __forceinline__ void bin_of_block(const BinGeo& G, int& t, int& sb) {
   const unsigned int span = 8u * (unsigned int)G.sub, g = l / span, r = l - g * span;
   sb = (int)(r >> 3); t = (int)(g * 8u + (r & 7u));            // (t may reach past the last bin in the final group: the callers return)
 }
-static inline unsigned int tile_grid(const BinGeo& G) { return G.sub == 1 ? (unsigned int)G.T : (unsigned int)(((G.T + 7) / 8) * 8 * G.sub); }
+__host__ __device__ __forceinline__ unsigned int tile_grid(const BinGeo& G) { return G.sub == 1 ? (unsigned int)G.T : (unsigned int)(((G.T + 7) / 8) * 8 * G.sub); }
+// tile (bin t, stacked tile sb) of workgroup l of the tile grid
+__device__ __forceinline__ void bin_of_index(const BinGeo& G, unsigned int l, int& t, int& sb) {
+  if (G.sub == 1) { t = (int)l; sb = 0; return; }
+  const unsigned int span = 8u * (unsigned int)G.sub, g = l / span, r = l - g * span;
+  sb = (int)(r >> 3); t = (int)(g * 8u + (r & 7u));            // (t may reach past the last bin in the final group: the callers return)
+}
+// What a workgroup reduces: tile `sb` of bin t, records [r0, r1) = part `part` of the bin's np parts; slot: the tile's scratch slot
+// when np > 1; first: the first workgroup of the tile grid proper.  false: nothing (a grid slot past the last bin / the last listed
+// part).  Uniform per workgroup.
+// The further parts of heavy tiles run in EXTRA workgroups IN FRONT of the tile grid (SV.cap x sub of them; they start first).  The
+// tile kernels run in whole rounds of workgroups (1024 tiles = two rounds of 512 resident workgroups at 1024^2), and 64 more that only
+// look at an empty list and leave cost the uniform benchmark 1.1-1.4 us per kernel wherever they sit in the grid (measured; so did
+// letting every workgroup take listed parts off a shared counter after its own tile: the second copy of the body doubled the
+// kernel's LDS).  So the host launches only as many as the LAST frame it has heard of needed (k_bin_scan reports the need through a
+// host-mapped word; emap_api.hip: split_capacity) and the scan lists no more parts than that: a tile that does not fit is reduced
+// by its own workgroup alone -- slower, same bits.  A cloud without heavy tiles launches none.
+// SPLIT = false (no extra workgroups in this launch: nothing can be split) compiles to the plain one-workgroup-per-tile kernels.
+struct TileWork { int t, sb; unsigned int r0, r1, slot, np, part; bool first; };
+template <bool SPLIT>
+__device__ __forceinline__ bool tile_work(const BinGeo& G, const SplitView& SV, const unsigned int* __restrict__ tile_start, TileWork& w) {
+  const unsigned int eg = SPLIT ? (unsigned int)SV.cap * (unsigned int)G.sub : 0u;
+  w.part = 0u; w.first = blockIdx.x == eg;
+  if (blockIdx.x >= eg) { bin_of_index(G, blockIdx.x - eg, w.t, w.sb); if (w.t >= G.T) return false; }
+  else {
+    const unsigned int x = blockIdx.x, e = x / (unsigned int)G.sub;
+    if (e >= *SV.n_extra) return false;
+    const unsigned int item = SV.extra[e];
+    if (item == SPLIT_NONE) return false;                          // (the part of a tile the lists had no room for)
+    w.sb = (int)(x - e * (unsigned int)G.sub); w.t = (int)(item >> 8); w.part = item & 255u;
+  }
+  const unsigned int R0 = tile_start[w.t], R1 = tile_start[w.t + 1], n = R1 - R0;
+  w.np = 1u; w.slot = SPLIT_NONE; w.r0 = R0; w.r1 = R1;
+  if (SPLIT && n > SPLIT_CAP) {                                  // a heavy tile (uniform); the scan's tail listed it -- or found no room
+    const unsigned int s0 = SV.tile_slot[w.t];
+    if (s0 != SPLIT_NONE) {
+      w.np = split_parts(n); w.slot = s0 + (unsigned int)w.sb;
+      const unsigned int len = (n + w.np - 1u) / w.np;
+      w.r0 = min(R1, R0 + w.part * len); w.r1 = min(R1, w.r0 + len);
+    }
+  }
+  return true;
+}
 
 // drift-inlier test of error_counting_kernel (custom_kernels.py:317-335) on the (h, v, valid, trav) of a cell
 __device__ __forceinline__ bool drift_inlier(const KP& P, const float4 m, float z) {
@@ -278,19 +344,20 @@ __device__ __forceinline__ void stage_hot_tile(const KP& P, Cells cells, float4*
 // Error sums of the drift compensation, per tile: the tile's cells are staged ONCE, coalesced, in LDS and every sorted record of
 // the tile is tested against its cell there -- the per-point gather of a random 32-byte cell (a whole 128-byte line per point,
 // 144 MB fetched for 48 MB needed, profiles/r01f_pmc_cfg2.json) is gone.  Wave-reduced sums go to the 256 padded slots.
-__global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const BinRec* __restrict__ recs,
-                                                          const unsigned int* __restrict__ tile_start, Cells cells,
-                                                          ErrSlot* __restrict__ slots) {
+template <bool SPLIT>
+__device__ __forceinline__ void tile_count_body(const KP& P, const BinGeo& G, const BinRec* __restrict__ recs, Cells cells,
+                                                ErrSlot* __restrict__ slots, const SplitView& SV, const TileWork& w) {
   constexpr int NC = BIN_TR * BIN_TC;
   __shared__ float4 s_cell[NC];
-  int t, sb;
-  bin_of_block(G, t, sb);
-  if (t >= G.T) return;
+  __shared__ unsigned int s_pts[NC], s_inl[NC];             // parts of a heavy tile only: per-cell counts for k_tile_fuse
+  const int t = w.t, sb = w.sb;
   const int ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
-  const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
+  const unsigned int r0 = w.r0, r1 = w.r1;
   const int row_base = (ty * G.sub + sb) * BIN_TR;
   if (row_base >= P.nrows || r0 == r1) return;
+  const bool split = SPLIT && w.np > 1u;                             // (uniform)
   stage_hot_tile(P, cells, s_cell, row_base, tx);
+  if (split) { s_pts[threadIdx.x] = 0u; s_inl[threadIdx.x] = 0u; }
   __syncthreads();
   const unsigned int sel = (unsigned int)sb;
   for (unsigned int kb = r0; kb < r1; kb += TF_BLOCK) {     // uniform trip count: the wave reductions need all lanes
@@ -302,6 +369,7 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const B
       if ((lcb >> 10) == sel) {
         const float4 m = s_cell[lcb & 1023u];
         if (drift_inlier(P, m, r.z)) { inl = 1; e_fix = __double2ll_rn((double)(r.z - m.x) * EM_SCALE_E); }
+        if (split) { atomicAdd(&s_pts[lcb & 1023u], 1u); if (inl) atomicAdd(&s_inl[lcb & 1023u], 1u); }
       }
     }
     if (__any(inl)) {
@@ -314,6 +382,19 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const B
       }
     }
   }
+  if (split) {
+    __syncthreads();
+    const unsigned int i = w.slot * SPLIT_CELLS + threadIdx.x;
+    if (s_pts[threadIdx.x]) atomicAdd(&SV.pts[i], s_pts[threadIdx.x]);
+    if (s_inl[threadIdx.x]) atomicAdd(&SV.inl[i], s_inl[threadIdx.x]);
+  }
+}
+template <bool SPLIT>
+__global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const BinRec* __restrict__ recs,
+                                                          const unsigned int* __restrict__ tile_start, Cells cells,
+                                                          ErrSlot* __restrict__ slots, SplitView SV) {
+  TileWork w;
+  if (tile_work<SPLIT>(G, SV, tile_start, w)) tile_count_body<SPLIT>(P, G, recs, cells, slots, SV, w);
 }
 
 // AVG = true (whole frames, emap_update): the epilogue commits AND averages the tile in registers and writes the 32-byte cells
@@ -325,31 +406,36 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const B
 // rays additionally need is written here too: the inert bitmap (one wave ballot = one 64-bit word per tile row) and newmap[3],
 // the per-cell drift-inlier counts (`inl_plane`, read only when a ray penetrates a cell).  The ray effects are applied afterwards
 // by k_ray_apply.  AVG = false keeps the staged contract: AccF records for k_commit / k_rays / k_average.
-template <bool AVG, bool RAYS>
-__global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const BinRec* __restrict__ recs,
-                                                         const unsigned int* __restrict__ tile_start, Cells cells,
-                                                         AccF* __restrict__ acc, FrameDev* __restrict__ F,
-                                                         unsigned int* __restrict__ cnt_plane, unsigned long long* __restrict__ inert,
-                                                         unsigned int* __restrict__ inl_plane, float* __restrict__ thr, OverlapArgs O, GateFold GF) {
+template <bool AVG, bool RAYS, bool SPLIT>
+__device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, const BinRec* __restrict__ recs, Cells cells,
+                                               AccF* __restrict__ acc, FrameDev* __restrict__ F,
+                                               unsigned int* __restrict__ cnt_plane, unsigned long long* __restrict__ inert,
+                                               unsigned int* __restrict__ inl_plane, float* __restrict__ thr, const OverlapArgs& O, const GateFold& GF,
+                                               const SplitView& SV, const TileWork& w) {
   constexpr int NC = BIN_TR * BIN_TC;
   __shared__ unsigned int s_pts[NC], s_inl[NC], s_cnt[NC], s_out[NC];
   __shared__ unsigned long long s_h[NC], s_v[NC], s_latest[NC];
   __shared__ float4 s_cell[NC];            // (h, v, valid, trav) of the tile's cells, staged once (coalesced): no per-record gather
   __shared__ float s_shift;
-  int t, sb;                                      // sb = which 16 x 64 tile of the bin (sub == 1 up to 16384 tiles)
-  bin_of_block(G, t, sb);
-  if (t >= G.T) return;                           // uniform, before any barrier
+  __shared__ bool s_final;
+  const int t = w.t, sb = w.sb;
   const int ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
-  const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
+  const unsigned int r0 = w.r0, r1 = w.r1;
+  const bool split = SPLIT && w.np > 1u;                   // (uniform)
   const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6, col = tx * BIN_TC + tc;
   {
     const int row_base = (ty * G.sub + sb) * BIN_TR;
-    if (row_base >= P.nrows) return;              // uniform, before any barrier
+    if (row_base >= P.nrows) return;              // uniform
     const unsigned int sel = (unsigned int)sb;
-    if (threadIdx.x == 0) s_shift = GF.mode ? gate_fold(GF, F, blockIdx.x == 0) : F->shift;      // only pass 2 needs it (workgroup 0 = bin 0, tile 0: always present)
+    if (threadIdx.x == 0) s_shift = GF.mode ? gate_fold(GF, F, w.first) : F->shift;      // only pass 2 needs it (the first workgroup of the tile grid = bin 0, tile 0: always present)
     stage_hot_tile(P, cells, s_cell, row_base, tx);
     for (int k = threadIdx.x; k < NC; k += TF_BLOCK) { s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull; }
     __syncthreads();
+    if (split) {                                                               // a heavy tile: the WHOLE tile's counts, left in the slot by k_tile_count's parts
+      static_assert(NC == TF_BLOCK && NC == (int)SPLIT_CELLS, "one thread per cell of a slot");
+      s_pts[threadIdx.x] = SV.pts[w.slot * SPLIT_CELLS + threadIdx.x];
+      if (!AVG || RAYS) s_inl[threadIdx.x] = SV.inl[w.slot * SPLIT_CELLS + threadIdx.x];     // (as below: only the ray pass reads newmap[3])
+    } else
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += TF_BLOCK) {          // pass 1: newmap[4] / newmap[3]
       const BinRec r = recs[k];
       const unsigned int lcb = r.lc_inl & 0x7fffffffu;
@@ -377,6 +463,41 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
       atomicMax(&s_latest[lc], ((unsigned long long)(r.i + 1u) << 32) | (unsigned long long)__float_as_uint(new_h));
     }
     __syncthreads();
+    if (split) {
+      // This part's sums join the tile's slot (device atomics: integer adds and an ordered maximum, any order gives the same bits),
+      // then a ticket: the part that arrives LAST owns the tile -- it reads the totals back (device-coherent loads: the atomics were
+      // performed at the memory side, not in this XCD's L2), leaves slot and ticket zeroed for the next frame and runs the epilogue.
+      const unsigned int i = w.slot * SPLIT_CELLS + threadIdx.x;
+      if (s_cnt[threadIdx.x] | s_out[threadIdx.x]) {
+        if (s_cnt[threadIdx.x]) {
+          atomicAdd(&SV.h[i], s_h[threadIdx.x]); atomicAdd(&SV.v[i], s_v[threadIdx.x]);
+          atomicAdd(&SV.cnt[i], s_cnt[threadIdx.x]); atomicMax(&SV.latest[i], s_latest[threadIdx.x]);
+        }
+        if (s_out[threadIdx.x]) atomicAdd(&SV.out[i], s_out[threadIdx.x]);
+      }
+      __threadfence();                                       // release: the sums are performed before the ticket is taken
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const unsigned int arrived = __hip_atomic_fetch_add(&SV.tick[w.slot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_final = arrived == w.np - 1u;
+        if (s_final) __hip_atomic_store(&SV.tick[w.slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (!s_final) return;                                  // (uniform)
+      __threadfence();                                       // acquire
+      s_h[threadIdx.x] = __hip_atomic_load(&SV.h[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_v[threadIdx.x] = __hip_atomic_load(&SV.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_latest[threadIdx.x] = __hip_atomic_load(&SV.latest[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_cnt[threadIdx.x] = __hip_atomic_load(&SV.cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_out[threadIdx.x] = __hip_atomic_load(&SV.out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (s_cnt[threadIdx.x] | s_out[threadIdx.x]) {
+        __hip_atomic_store(&SV.h[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&SV.v[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&SV.latest[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&SV.cnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&SV.out[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (s_pts[threadIdx.x]) { __hip_atomic_store(&SV.pts[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&SV.inl[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      __syncthreads();
+    }
     {
       static_assert(BIN_TR == TF_BLOCK / 64, "one wave per tile row");
       const int tr = wv, lrow = row_base + tr;
@@ -473,6 +594,15 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const Bi
     }
   }
 }
+template <bool AVG, bool RAYS, bool SPLIT>
+__global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const BinRec* __restrict__ recs,
+                                                         const unsigned int* __restrict__ tile_start, Cells cells,
+                                                         AccF* __restrict__ acc, FrameDev* __restrict__ F,
+                                                         unsigned int* __restrict__ cnt_plane, unsigned long long* __restrict__ inert,
+                                                         unsigned int* __restrict__ inl_plane, float* __restrict__ thr, OverlapArgs O, GateFold GF, SplitView SV) {
+  TileWork w;                                     // sb = which 16 x 64 tile of the bin (sub == 1 up to 16384 tiles); for a heavy tile: a part of its records
+  if (tile_work<SPLIT>(G, SV, tile_start, w)) tile_fuse_body<AVG, RAYS, SPLIT>(P, G, recs, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF, SV, w);
+}
 
 static inline unsigned int nb(long n) { return (unsigned int)((n + EM_BLOCK - 1) / EM_BLOCK); }
 
@@ -508,8 +638,8 @@ void launch_bin_hist(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G,
     default: launch_bin_hist_t<256>(s, P, T, G, pts, n, stride, hist, own, own_cnt);
   }
 }
-void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigned int* tile_total, unsigned int* tile_start, unsigned int* sync) {
-  hipLaunchKernelGGL(k_bin_scan, dim3((G.TB + SCAN_TT - 1) / SCAN_TT), dim3(SCAN_BLK), 0, s, G, hist, tile_total, tile_start, sync);
+void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigned int* tile_total, unsigned int* tile_start, unsigned int* sync, const SplitView& SV) {
+  hipLaunchKernelGGL(k_bin_scan, dim3((G.TB + SCAN_TT - 1) / SCAN_TT), dim3(SCAN_BLK), 0, s, G, hist, tile_total, tile_start, sync, SV);
 }
 template <int MODE, int BLK, bool STRIP>
 static void launch_bin_scatter_i(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
@@ -534,18 +664,25 @@ void launch_bin_scatter(hipStream_t s, const KP& P, const Pose& T, const BinGeo&
   }
 }
 void launch_tile_count(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cells cells,
-                       ErrSlot* slots) {
+                       ErrSlot* slots, const SplitView& SV, long n) {
   static_assert(TF_BLOCK == BIN_TR * BIN_TC, "one thread per cell of a tile");
-  hipLaunchKernelGGL(k_tile_count, dim3(tile_grid(G)), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, slots);
+  (void)n;
+  if (SV.on && SV.cap > 0) hipLaunchKernelGGL(k_tile_count<true>, dim3((unsigned int)SV.cap * G.sub + tile_grid(G)), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, slots, SV);
+  else hipLaunchKernelGGL(k_tile_count<false>, dim3(tile_grid(G)), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, slots, SV);
 }
 // fuse_average: commit + average in the tile kernel (whole frames); rays: the visibility pass follows (bitmap + inlier plane wanted)
 void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cells cells,
                      AccF* acc, FrameDev* F, bool fuse_average, bool rays, unsigned int* cnt_plane, unsigned long long* inert,
-                     unsigned int* inl_plane, float* thr, const OverlapArgs& O, const GateFold& GF) {
-  const dim3 g(tile_grid(G)), b(TF_BLOCK);
-  if (fuse_average && rays) hipLaunchKernelGGL((k_tile_fuse<true, true>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF);
-  else if (fuse_average) hipLaunchKernelGGL((k_tile_fuse<true, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF);
-  else hipLaunchKernelGGL((k_tile_fuse<false, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF);
+                     unsigned int* inl_plane, float* thr, const OverlapArgs& O, const GateFold& GF, const SplitView& SV, long n) {
+  (void)n;
+  const bool split = SV.on && SV.cap > 0;
+  const dim3 g((split ? (unsigned int)SV.cap * G.sub : 0u) + tile_grid(G)), b(TF_BLOCK);
+#define EM_FUSE(A, R) do { if (split) hipLaunchKernelGGL((k_tile_fuse<A, R, true>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF, SV); \
+                            else hipLaunchKernelGGL((k_tile_fuse<A, R, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF, SV); } while (0)
+  if (fuse_average && rays) EM_FUSE(true, true);
+  else if (fuse_average) EM_FUSE(true, false);
+  else EM_FUSE(false, false);
+#undef EM_FUSE
 }
 
 // ---------------------------------------------------------------------------------------------------------

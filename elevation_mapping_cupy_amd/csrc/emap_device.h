@@ -405,6 +405,46 @@ struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, TB, pitch, rayb
 struct __attribute__((aligned(16))) BinRec { unsigned int lc_inl; float z, v; unsigned int i; };  // sorted by tile
 struct BinStg;                                                                                     // staging record of the strip variants
 
+// ---- HEAVY tiles: the records of one tile reduced by SEVERAL workgroups --------------------------------------------------------
+// One workgroup per tile is the right grain for a uniform cloud (1 M points / 1024 tiles: one trip of 1024 threads per tile).  A
+// sensor delivers the opposite: the ground next to it is sampled hundreds of times per cell, and ONE tile of a scan-ordered,
+// ray-cast cloud (tests/_fixtures.py: terrain_cloud) holds 300 k of its 1 M points -- that workgroup then issues ~80 instructions
+// per record on one CU's four SIMDs while 255 CUs idle (k_tile_count 58 us, k_tile_fuse 148 us against 14 / 16 on the uniform
+// cloud).  So a tile with more than SPLIT_CAP records is cut into parts of <= SPLIT_CAP consecutive records; part 0 runs in the
+// tile's own workgroup, parts 1.. in EXTRA workgroups in front of the grid (k_bin_scan's tail lists them: the first place that
+// knows the tile totals; emap_binned.hip: tile_work for how many the host launches).  Everything the parts accumulate is an integer sum or an ordered maximum, so the parts of a tile
+// merge through device atomics into the tile's SLOT of a small scratch array, in any order, bit for bit:
+//   k_tile_count  every part adds its error sums to the slots as before, and its per-cell point / drift-inlier counts (newmap[4],
+//                 newmap[3] -- k_tile_fuse's first pass) to the slot;
+//   k_tile_fuse   every part reads the whole tile's counts from the slot, runs the Kalman pass over ITS records in LDS, adds its
+//                 partial sums to the slot and takes a ticket; the part that arrives last reads the totals back, clears the slot
+//                 and the ticket, and runs the tile's epilogue (commit + average + bitmap + thresholds) as if it had seen every
+//                 record.  Nobody waits for anybody.
+// Tiles of <= SPLIT_CAP records (every tile of a uniform cloud) take the old path; what they pay is one word of k_bin_scan's
+// tail per tile and one scalar load per workgroup.  Needs k_tile_count in the frame (the
+// drift gate's statistics: on unless the caller rules the gate out) -- otherwise nothing is split.
+#define SPLIT_CAP 16384u         /* records per part: 16 trips of the 1024 threads */
+#define SPLIT_MAX_PARTS 64u
+#define SPLIT_MAX_SLOTS 1024u    /* tiles (x stacked tiles of a bin) split in one frame */
+#define SPLIT_MAX_EXTRA 4096u
+#define SPLIT_NONE 0xffffffffu
+#define SPLIT_CELLS 1024u        /* cells of a tile */
+struct SplitView {
+  int on;                                  // this frame's scan listed the heavy tiles
+  unsigned int* tile_slot;                 // [T] first slot of the bin's tiles, SPLIT_NONE: not split
+  unsigned int* extra;                     // [SPLIT_MAX_EXTRA] (bin << 8) | part of the extra workgroups' work
+  unsigned int* n_extra;
+  int cap;                                 // extra workgroups (x sub) in front of this frame's tile grids = parts the scan may list; a multiple of 8
+  unsigned int* need_host;                 // host-mapped: the parts this frame would have listed with unlimited room
+  unsigned int* tick;                      // [SPLIT_MAX_SLOTS] arrivals of k_tile_fuse's parts (zero between frames)
+  unsigned int* pts; unsigned int* inl;    // [slot][cell] whole-tile counts, written by k_tile_count's parts     } all zero between
+  unsigned long long* h; unsigned long long* v; unsigned long long* latest; unsigned int* cnt; unsigned int* out;   // } frames
+};
+__host__ __device__ __forceinline__ unsigned int split_parts(unsigned int n) {
+  const unsigned int np = (n + SPLIT_CAP - 1u) / SPLIT_CAP;
+  return np > SPLIT_MAX_PARTS ? SPLIT_MAX_PARTS : (np < 1u ? 1u : np);
+}
+
 // ---- gfx950 LDS-DMA: 64 lanes x 16 bytes from global memory straight into LDS (global_load_lds_dwordx4) -------------------------
 // lane i's 16 bytes land at lds_base + 16 i (lds_base must be wave-uniform); the copy is ordered for readers by the vmcnt(0) the
 // compiler places in front of the next __syncthreads().  For PURE copies of 16-byte records: no VGPR round trip, no ds_write.

@@ -812,6 +812,40 @@ __device__ __forceinline__ float exp_neg(float a) {
   } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
+// SPARSE tiles of the fused stencils.  A hole (mask < 0.5) searches its (2d + 1)^2 neighbourhood for the first source in the
+// reference's scan order and gives up after all 49 reads when there is none -- on a white-noise map a source is two or three reads
+// away, but a real map is mostly UNKNOWN beyond the sensor's dense zone (scan rings further apart than the dilation reach, the shadow
+// of a wall): 86 % holes at 1024^2 on the ray-cast terrain of tests/_fixtures.py, and the stencil launch took 69 us instead of 19.5.
+// When three cells of four of a tile's region are holes (on white noise nearly every hole still has a source in reach then, but such
+// maps are the first frames of a sparse cloud; with the limit at one hole in two the masks cost the 8192^2 stencil launch 22 %), the tile
+// first builds a REACH mask -- bit (r, c) set iff any source lies within
+// the square of radius d around (r, c): per region row the ballot of the source test, smeared d columns to both sides in scalar
+// registers (128 bits per row), then OR-ed over the 2d + 1 rows -- and a hole whose bit is clear skips the search (its value stays,
+// exactly what the search would have left).  Dense tiles pay one uniform branch.  src(r, c): the cell MAY be a source (a superset is fine).
+template <int PT_THREADS, class SrcFn>
+__device__ __forceinline__ void post_reach_masks(unsigned int* __restrict__ hs, unsigned int* __restrict__ reach, int RH, int RW, int d, SrcFn src) {
+  constexpr int PT_WAVES = PT_THREADS / 64;
+  const int tc = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int r = wv; r < RH; r += PT_WAVES) {
+    unsigned long long lo = __builtin_amdgcn_ballot_w64(src(r, tc));
+    unsigned long long hi = __builtin_amdgcn_ballot_w64(64 + tc < RW && src(r, 64 + tc));
+    unsigned long long slo = lo, shi = hi;
+    for (int k = 1; k <= d; ++k) {                                   // (uniform: scalar shifts)
+      slo |= (lo << k) | (lo >> k) | (hi << (64 - k));
+      shi |= (hi << k) | (hi >> k) | (lo >> (64 - k));
+    }
+    if (tc == 0) { hs[4 * r] = (unsigned int)slo; hs[4 * r + 1] = (unsigned int)(slo >> 32); hs[4 * r + 2] = (unsigned int)shi; hs[4 * r + 3] = (unsigned int)(shi >> 32); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * (RH - 2 * d); i += PT_THREADS) {  // rows d .. RH - d - 1: the only ones that hold holes
+    const int j = i + 4 * d;
+    unsigned int v = 0u;
+    for (int dy = -d; dy <= d; ++dy) v |= hs[j + 4 * dy];
+    reach[j] = v;
+  }
+  __syncthreads();
+}
+
 // k_post_dma: the same fused stencils with the region staged by gfx950's LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes
 // straight from HBM into LDS, no VGPR round trip, no ds_write).  The region is a pure copy of 16-byte cold halves (time, upper,
 // is_upper, valid'), so a wave moves one region row per instruction: lane = column, the LDS destination is wave-uniform base +
@@ -846,7 +880,9 @@ __global__ __launch_bounds__(512) void k_post_dma(KP P, TravW Wt, Cells cells, f
   float4* raw = reinterpret_cast<float4*>(lds);                             // [RH][RW] cold halves as they lie in HBM
   float* val = lds + 4 * RH * RW;                                           // [RH][vp] upper_bound, holes of the DW x DH region overwritten by their dilated value
   int* rtab = reinterpret_cast<int*>(val + RH * vp);                        // RH + 2 row terms (hole search, epilogue)
-  unsigned short* holes = reinterpret_cast<unsigned short*>(rtab + ((RH + 3) & ~1));
+  unsigned int* hs = reinterpret_cast<unsigned int*>(rtab + ((RH + 3) & ~1));      // sparse tiles: smeared source rows, reach mask (4 words per region row each)
+  unsigned int* reach = hs + 4 * RH;
+  unsigned short* holes = reinterpret_cast<unsigned short*>(reach + 4 * RH);
   __shared__ unsigned int n_holes;
   if (threadIdx.x == 0) n_holes = 0u;
   const int C = P.C;
@@ -898,8 +934,11 @@ __global__ __launch_bounds__(512) void k_post_dma(KP P, TravW Wt, Cells cells, f
   // criterion (:429-436).  Sources are cells with mask > 0.5 that exist and are is_inside (custom_kernels.py:34-44); a source is
   // never a hole, so the in-place writes cannot feed another search (Jacobi semantics of the reference kernel).
   const unsigned int nh = n_holes;
+  const bool sparse = 4 * (int)nh > 3 * DW * DH && RW <= 128;       // (uniform) three cells of four are holes
+  if (sparse) post_reach_masks<PT_THREADS>(hs, reach, RH, RW, d, [&](int r, int cc) { const float4 q = raw[r * RW + min(cc, RW - 1)]; return q.z + q.w > 0.5f; });
   for (unsigned int hi = threadIdx.x; hi < nh; hi += PT_THREADS) {
     const int pos = holes[hi], r = pos / DW + d, cc = pos - (pos / DW) * DW + d;
+    if (sparse && !((reach[4 * r + (cc >> 5)] >> (cc & 31)) & 1u)) continue;     // no source within reach
     bool found = false;
     for (int s2 = -2 * d; s2 <= 2 * d && !found; ++s2) {
       const int dy0 = max(-d, s2 - d), dy1 = min(d, s2 + d);
@@ -948,7 +987,9 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   // is_valid (normal filter).  One 12-byte LDS write per staged cell; a stride of three dwords across the lanes is conflict free.
   float* reg = lds;
   int* rtab = reinterpret_cast<int*>(reg + 3 * RH * rp);       // RH + 2 row terms
-  unsigned short* holes = reinterpret_cast<unsigned short*>(rtab + ((RH + 3) & ~1));      // compacted list of the holes of the DW x DH region
+  unsigned int* hs = reinterpret_cast<unsigned int*>(rtab + ((RH + 3) & ~1));      // sparse tiles: smeared source rows, reach mask (post_reach_masks)
+  unsigned int* reach = hs + 4 * RH;
+  unsigned short* holes = reinterpret_cast<unsigned short*>(reach + 4 * RH);      // compacted list of the holes of the DW x DH region
   __shared__ unsigned int n_holes, s_special;
   if (threadIdx.x == 0) { n_holes = 0u; s_special = 0u; }
   __syncthreads();
@@ -1066,8 +1107,11 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   // filled hole cannot feed another hole (Jacobi semantics of the reference kernel), and the stencils below read one array.
   __syncthreads();
   const unsigned int nh = n_holes;
+  const bool sparse = 4 * (int)nh > 3 * DW * DH && RW <= 128;       // (uniform) three cells of four are holes
+  if (sparse) post_reach_masks<PT_THREADS>(hs, reach, RH, RW, d, [&](int r, int cc) { return reg[(r * rp + min(cc, RW - 1)) * 3 + 1] > 0.5f; });
   for (unsigned int hi = threadIdx.x; hi < nh; hi += PT_THREADS) {
     const int pos = holes[hi], r = pos / DW, cc = pos - r * DW;
+    if (sparse && !((reach[4 * (r + d) + ((cc + d) >> 5)] >> ((cc + d) & 31)) & 1u)) continue;     // no source within reach: the raw value stays
     const int o0 = (r + d) * rp + (cc + d);
     // first hit on ascending anti-diagonals == the reference's scan order with its signed dx+dy criterion (:429-436)
     bool found = false;
@@ -1331,11 +1375,11 @@ void launch_overlap(hipStream_t s, const KP& P, Cells cells, int cmin, int cmax,
   hipLaunchKernelGGL(k_overlap, dim3(nblk(w * w)), dim3(EM_BLOCK), 0, s, P, cells, cmin, cmax, hmin, hmax);
 }
 static size_t post_lds_bytes(int R, int d) {      // k_post: (value, mask, valid) region, row table, hole list
-  return sizeof(float) * ((size_t)3 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)(R + 6 + 2 * d + 4)) + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;
+  return sizeof(float) * ((size_t)3 * (R + 6 + 2 * d) * (PT_C + 6 + 2 * d + 1) + (size_t)(R + 6 + 2 * d + 4)) + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 32 * (size_t)(R + 6 + 2 * d) + 16;
 }
 static size_t post_dma_lds_bytes(int R, int d) {  // k_post_dma: 16-byte region cells + value plane, row table, hole list
   const size_t RH = R + 6 + 2 * d, RW = PT_C + 6 + 2 * d;
-  return 16 * RH * RW + 4 * RH * (RW + 1) + 4 * (RH + 4) + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;
+  return 16 * RH * RW + 4 * RH * (RW + 1) + 4 * (RH + 4) + 32 * RH + sizeof(unsigned short) * (size_t)(R + 6) * (PT_C + 6) + 16;
 }
 // true: the LDS-DMA kernel handles this (tile height, radius) -- one lane per region row for the row terms, three workgroups per CU
 static bool post_use_dma(int R, int d) {

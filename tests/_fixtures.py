@@ -163,3 +163,58 @@ def semantic_kernel_run(K, c):
     cm = np.zeros((4, 4, 4), np.uint32); K.sem_add_color(col, R, t, cpc, cml, cch, cm, n); out["color_map"] = cm.copy()
     cs = c["prev"].copy(); K.sem_color_average(cm, cpc, cml, cch, cs, 16); out["color_average_map"] = cs
     return out
+
+
+def terrain_height(x, y, boxes):
+    """the scene of terrain_cloud: rolling ground (+-0.4 m) with box-shaped obstacles (walls) on it; world frame"""
+    h = 0.3 * np.sin(0.35 * x) * np.cos(0.27 * y) + 0.1 * np.sin(1.3 * x + 0.5 * y)
+    for (x0, x1, y0, y1, top) in boxes:
+        h = np.where((x >= x0) & (x <= x1) & (y >= y0) & (y <= y1), np.maximum(h, top), h)
+    return h
+
+
+def terrain_boxes(C, res, shift=0.0):
+    """a handful of walls and blocks, scaled with the map; `shift` moves every second one diagonally (a scene that changed between frames)"""
+    L = C * res / 2
+    u = L / 20.0
+    raw = [(3, 3.4, -6, 6, 1.6), (-9, -5, 4, 4.3, 1.2), (-4, -2.5, -8, -6.5, 0.7), (8, 12, -12, -11.6, 1.5), (-14, -13.6, -10, 2, 0.9), (6, 7, 7, 8, 0.5)]
+    out = []
+    for k, (x0, x1, y0, y1, top) in enumerate(raw):
+        d = shift if k % 2 else 0.0                                  # along x AND y: a wall leaves the cells it stood on
+        out.append(((x0 + d) * u, (x1 + d) * u, (y0 + d) * u, (y1 + d) * u, top))
+    return out
+
+
+def terrain_cloud(C, n_az, n_el, seed, res=0.04, sensor_h=1.0, shift=0.0, noise=0.01):
+    """A spatially coherent, SCAN-ORDERED cloud: a sensor `sensor_h` above the origin casts n_az x n_el beams (azimuth-major, elevation
+    -60 .. -2.9 degrees) at terrain_height(); every beam is marched to its first intersection (coarse steps + bisection) and gets range
+    noise.  Sensor frame (the map frame is R p + t with R = I, t = (0, 0, sensor_h)); float32 (n_az * n_el, 3).  Beams without a hit
+    inside 1.3 x the half width end there (outside the map).  Unlike cloud() -- white noise of +-0.5 m in z -- neighbouring beams end in
+    neighbouring cells, rays do not dive under the ground they measured, and walls cast shadows."""
+    rng = np.random.default_rng(seed)
+    L = C * res / 2
+    boxes = terrain_boxes(C, res, shift)
+    az = np.repeat(np.linspace(-np.pi, np.pi, n_az, endpoint=False), n_el)
+    el = np.tile(np.deg2rad(np.linspace(-60.0, -2.9, n_el)), n_az)
+    dx, dy, dz = np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)
+    r_max = 1.3 * L
+    step = max(res * 4, r_max / 160)
+    lo = np.full_like(az, r_max)
+    hi = np.full_like(az, r_max)
+    live = np.arange(az.shape[0])                                  # beams still above the ground
+    r = 0.0
+    for _ in range(int(np.ceil(r_max / step))):
+        r_next = r + step
+        below = (sensor_h + dz[live] * r_next) <= terrain_height(dx[live] * r_next, dy[live] * r_next, boxes)
+        hit = live[below]
+        lo[hit] = r; hi[hit] = r_next
+        live = live[~below]
+        r = r_next
+        if live.size == 0:
+            break
+    for _ in range(10):
+        mid = 0.5 * (lo + hi)
+        below = (sensor_h + dz * mid) <= terrain_height(dx * mid, dy * mid, boxes)
+        hi = np.where(below, mid, hi); lo = np.where(below, lo, mid)
+    rr = hi + rng.normal(0.0, noise, az.shape)
+    return np.stack([dx * rr, dy * rr, dz * rr], axis=1).astype(np.float32)
