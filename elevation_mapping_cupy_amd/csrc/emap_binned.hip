@@ -325,6 +325,12 @@ __device__ __forceinline__ bool drift_inlier(const KP& P, const float4 m, float 
 }
 
 #define TF_BLOCK 1024   /* threads per tile of the tile kernels */
+#ifndef SPLIT_U
+#define SPLIT_U 4         /* records per thread and trip in k_tile_count<true> (k_tile_fuse<.., true>: one -- four were slower, 76 -> 92 us on the terrain) */
+#endif
+#ifndef SPLIT_U_FUSE
+#define SPLIT_U_FUSE 1
+#endif
 // The hot halves (h, v, valid, trav) of one 16 x 64 tile -> LDS, one wave per tile row.  Without pending map moves this is a pure
 // copy of 1 KB per row: gfx950's LDS-DMA (no VGPR round trip, no ds_write); cells beyond the map / strip read as zero.  With pending
 // moves the cells pass through cell_now() in registers.  The caller's next __syncthreads() publishes the tile.
@@ -360,21 +366,31 @@ __device__ __forceinline__ void tile_count_body(const KP& P, const BinGeo& G, co
   if (split) { s_pts[threadIdx.x] = 0u; s_inl[threadIdx.x] = 0u; }
   __syncthreads();
   const unsigned int sel = (unsigned int)sb;
-  for (unsigned int kb = r0; kb < r1; kb += TF_BLOCK) {     // uniform trip count: the wave reductions need all lanes
-    const unsigned int k = kb + threadIdx.x;
-    long long e_fix = 0; unsigned int inl = 0;
-    if (k < r1) {
-      const BinRec r = recs[k];
-      const unsigned int lcb = r.lc_inl & 0x7fffffffu;
-      if ((lcb >> 10) == sel) {
-        const float4 m = s_cell[lcb & 1023u];
-        if (drift_inlier(P, m, r.z)) { inl = 1; e_fix = __double2ll_rn((double)(r.z - m.x) * EM_SCALE_E); }
-        if (split) { atomicAdd(&s_pts[lcb & 1023u], 1u); if (inl) atomicAdd(&s_inl[lcb & 1023u], 1u); }
+  // the split kernels (frames with heavy tiles) keep SPLIT_U records per thread in flight: a part is up to SPLIT_CAP / 1024 dependent
+  // trips of load -> LDS, each a full memory round trip when only one load per thread is outstanding
+  constexpr int U = SPLIT ? SPLIT_U : 1;
+  for (unsigned int kb = r0; kb < r1; kb += TF_BLOCK * U) {     // uniform trip count: the wave reductions need all lanes
+    BinRec rr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const unsigned int k = kb + u * TF_BLOCK + threadIdx.x; if (k < r1) rr[u] = recs[k]; }
+    long long e_fix = 0; unsigned long long cnt = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned int k = kb + u * TF_BLOCK + threadIdx.x;
+      bool inl = false;
+      if (k < r1) {
+        const BinRec& r = rr[u];
+        const unsigned int lcb = r.lc_inl & 0x7fffffffu;
+        if ((lcb >> 10) == sel) {
+          const float4 m = s_cell[lcb & 1023u];
+          if (drift_inlier(P, m, r.z)) { inl = true; e_fix += __double2ll_rn((double)(r.z - m.x) * EM_SCALE_E); }
+          if (split) { atomicAdd(&s_pts[lcb & 1023u], 1u); if (inl) atomicAdd(&s_inl[lcb & 1023u], 1u); }
+        }
       }
+      cnt += __popcll(__ballot(inl));
     }
-    if (__any(inl)) {
+    if (cnt) {                                                 // (wave-uniform)
       const long long s = wave_sum_ll(e_fix);
-      const unsigned long long cnt = __popcll(__ballot(inl));
       if ((threadIdx.x & 63) == 0) {
         const unsigned int slot = (unsigned int)(((unsigned int)t * (TF_BLOCK / 64) + (threadIdx.x >> 6) + kb) & (EM_ERR_SLOTS - 1));
         atomicAdd(reinterpret_cast<unsigned long long*>(&slots[slot].sum), (unsigned long long)s);
@@ -445,8 +461,15 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
     }
     __syncthreads();
     const float shift = s_shift;
-    for (unsigned int k = r0 + threadIdx.x; k < r1; k += TF_BLOCK) {          // pass 2: custom_kernels.py:160-197
-      const BinRec r = recs[k];
+    constexpr int U = SPLIT ? SPLIT_U_FUSE : 1;                               // (records per thread in flight: see tile_count_body)
+    for (unsigned int kb = r0 + threadIdx.x; kb < r1; kb += TF_BLOCK * U) {   // pass 2: custom_kernels.py:160-197
+     BinRec rr[U];
+#pragma unroll
+     for (int u = 0; u < U; ++u) if (kb + u * TF_BLOCK < r1) rr[u] = recs[kb + u * TF_BLOCK];
+#pragma unroll
+     for (int u = 0; u < U; ++u) {
+      if (kb + u * TF_BLOCK >= r1) continue;
+      const BinRec& r = rr[u];
       const unsigned int lcb = r.lc_inl & 0x7fffffffu;
       if ((lcb >> 10) != sel) continue;
       const unsigned int lc = lcb & 1023u;
@@ -461,6 +484,7 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
       atomicAdd(&s_v[lc], (unsigned long long)__double2ll_rn((double)new_v * EM_SCALE_V));
       atomicAdd(&s_cnt[lc], 1u);
       atomicMax(&s_latest[lc], ((unsigned long long)(r.i + 1u) << 32) | (unsigned long long)__float_as_uint(new_h));
+     }
     }
     __syncthreads();
     if (split) {
@@ -475,16 +499,25 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
         }
         if (s_out[threadIdx.x]) atomicAdd(&SV.out[i], s_out[threadIdx.x]);
       }
-      __threadfence();                                       // release: the sums are performed before the ticket is taken
+      // Order: the atomics above are performed at the memory side (device scope); s_waitcnt 0 waits for their acknowledgements, the
+      // barrier collects the workgroup, then the ticket -- the hand-off k_bin_scan uses (last_block_ticket).  A release FENCE here
+      // writes back the XCD's whole L2 for every part: 1.6 us per part, measured (fuse 76 -> 163 us going from 19 to 73 parts).
+#ifdef SPLIT_FENCE
+      __threadfence();
+#else
+      __builtin_amdgcn_s_waitcnt(0);
+#endif
       __syncthreads();
       if (threadIdx.x == 0) {
-        const unsigned int arrived = __hip_atomic_fetch_add(&SV.tick[w.slot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int arrived = __hip_atomic_fetch_add(&SV.tick[w.slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_final = arrived == w.np - 1u;
         if (s_final) __hip_atomic_store(&SV.tick[w.slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
       if (!s_final) return;                                  // (uniform)
-      __threadfence();                                       // acquire
+#ifdef SPLIT_FENCE
+      __threadfence();
+#endif
       s_h[threadIdx.x] = __hip_atomic_load(&SV.h[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_v[threadIdx.x] = __hip_atomic_load(&SV.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_latest[threadIdx.x] = __hip_atomic_load(&SV.latest[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -410,7 +410,7 @@ struct BinStg;                                                                  
 // sensor delivers the opposite: the ground next to it is sampled hundreds of times per cell, and ONE tile of a scan-ordered,
 // ray-cast cloud (tests/_fixtures.py: terrain_cloud) holds 300 k of its 1 M points -- that workgroup then issues ~80 instructions
 // per record on one CU's four SIMDs while 255 CUs idle (k_tile_count 58 us, k_tile_fuse 148 us against 14 / 16 on the uniform
-// cloud).  So a tile with more than SPLIT_CAP records is cut into parts of <= SPLIT_CAP consecutive records; part 0 runs in the
+// cloud).  So a tile with more than SPLIT_CAP records is cut into parts of ~SPLIT_CAP consecutive records; part 0 runs in the
 // tile's own workgroup, parts 1.. in EXTRA workgroups in front of the grid (k_bin_scan's tail lists them: the first place that
 // knows the tile totals; emap_binned.hip: tile_work for how many the host launches).  Everything the parts accumulate is an integer sum or an ordered maximum, so the parts of a tile
 // merge through device atomics into the tile's SLOT of a small scratch array, in any order, bit for bit:
@@ -423,8 +423,12 @@ struct BinStg;                                                                  
 // Tiles of <= SPLIT_CAP records (every tile of a uniform cloud) take the old path; what they pay is one word of k_bin_scan's
 // tail per tile and one scalar load per workgroup.  Needs k_tile_count in the frame (the
 // drift gate's statistics: on unless the caller rules the gate out) -- otherwise nothing is split.
-#define SPLIT_CAP 16384u         /* records per part: 16 trips of the 1024 threads */
-#define SPLIT_MAX_PARTS 64u
+#ifndef SPLIT_CAP
+#define SPLIT_CAP 4096u          /* records per part: 4 trips of the 1024 threads.  Terrain scene, k_tile_count / k_tile_fuse: 28 / 39 us with 16384, 24 / 30 with 8192, 20 / 26 with 4096 (one workgroup per tile: 58 / 148) */
+#endif
+#ifndef SPLIT_MAX_PARTS
+#define SPLIT_MAX_PARTS 128u      /* < 256: the part index is 8 bits of a list entry */
+#endif
 #define SPLIT_MAX_SLOTS 1024u    /* tiles (x stacked tiles of a bin) split in one frame */
 #define SPLIT_MAX_EXTRA 4096u
 #define SPLIT_NONE 0xffffffffu

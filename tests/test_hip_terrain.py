@@ -79,7 +79,8 @@ def test_terrain_scene_row_strips_reproduce_the_single_context(world, C, n_az, n
 # ---- heavy tiles: most of the cloud in a handful of cells (the ground under a sensor), the tile kernels' split path --------------------
 def _heavy_cloud(C, N, seed, dz=0.0, frac=0.7, patch=0.03):
     """cloud() with `frac` of its points squeezed into the central patch x patch of the map: ONE sort tile holds more than SPLIT_CAP
-    (16384) records and is reduced by several workgroups (emap_device.h: SplitView)"""
+    (4096) records and is reduced by several workgroups (emap_device.h: SplitView).  The first frame of a context runs unsplit (the host has
+    not heard of a heavy tile yet), the following ones split: same bits either way"""
     p = fx.cloud(C, N, seed, dz=dz)
     k = int(N * frac)
     p[:k, :2] *= np.float32(patch)
