@@ -130,3 +130,30 @@ def test_heavy_tiles_row_strips_reproduce_the_single_context(world, C, N, ray_mo
     R, t = fx.POSES["rotated"]
     frames = [(_heavy_cloud(C, N, f, dz=-0.05 * f, frac=0.6, patch=0.05 + 0.1 * f), R, t.copy(), 1.0, 1.0, 6 if f == 0 else 2, None) for f in range(3)]
     _strips_vs_single(world, cfg, C, frames, "binned", weights, stand_in="stream", ray_mode=ray_mode)
+
+
+def test_heavy_tiles_soak_two_contexts_and_the_oracle(weights):
+    """40 frames whose heavy tiles change from frame to frame (so does the number of extra workgroups the host launches: it follows
+    the need the device reported last): two HIP contexts must agree byte for byte after every frame -- the parts of a tile merge
+    through device atomics with no fence between them and the ticket, a lost or late partial sum would show here -- and with the
+    oracle at the end."""
+    C, N = 400, 220000
+    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML)
+    a, orc = make_pair(cfg, C, "reference_fp16", weights)
+    b, _ = make_pair(cfg, C, "reference_fp16", weights)
+    a.set_scatter_mode("binned"); b.set_scatter_mode("binned")
+    rng = np.random.default_rng(5)
+    R, t = fx.POSES["rotated"]
+    for f in range(40):
+        p = _heavy_cloud(C, N, 100 + f, dz=float(rng.uniform(-0.1, 0.05)), frac=float(rng.uniform(0.1, 0.9)), patch=float(rng.uniform(0.01, 0.3)))
+        if f % 7 == 3:
+            p = fx.cloud(C, N, 100 + f)                       # a frame without heavy tiles in between
+        for m in (a, b):
+            m.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0)
+        orc.update_map_with_kernel(p, R, t, 1.0, 1.0)
+        assert a.elevation_map.tobytes() == b.elevation_map.tobytes(), "frame %d: two contexts differ" % f
+        for k in range(int(rng.integers(0, 4))):
+            a.update_time(); b.update_time(); orc.update_time()
+    assert a.normal_map.tobytes() == b.normal_map.tobytes()
+    assert_planes_close(a.elevation_map, orc.elevation_map, what="40 heavy frames")
+    assert_planes_close(a.normal_map, orc.normal_map, names=["nx", "ny", "nz"])
