@@ -216,7 +216,22 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
                                                  const unsigned int* __restrict__ order, const unsigned int* __restrict__ n_sorted) {
   // walking sorted records: workgroups behind the last record leave before the prologue (a frame that marches its rays by ray sorts
   // only the points of the strip's rows: most of a grid sized for the whole cloud is empty then)
-  if (order && (long)blockIdx.x * BLOCK / LPR >= (long)*n_sorted) return;
+  // The workgroups take the chunks of the sorted records OUTSIDE IN (first, last, second, second to last, ...).  The records are sorted
+  // by end-point tile, row-major over the map, and the map rides with the robot: the first and the last chunks are the far field --
+  // rays at the clip length, 350 steps, ~40 us per 1024-ray workgroup -- and the middle ones end next to the sensor (20-60 steps).
+  // Dispatched in tile order, a scan-ordered cloud finished with a round of far-field workgroups on a fifth of the CUs (terrain scene:
+  // 4.3x fewer wave cycles than the uniform cloud, 1.28x less time); now the long ones start first and the short ones fill the gaps:
+  // 221 -> 217 us there, 310 -> 301 us on four alternating uniform clouds (same box).  What remains of that gap is latency: a far-field
+  // wave works off a batch of queued visits (unknown cells between the scan rings) every other step, each a dependent trip to the
+  // threshold table; with the bitmap in global memory and two workgroups per CU the terrain pass takes 187 us, the uniform one more.  (The valid points outside the owned cells sit in the last bin: long rays, first.)
+  unsigned int chunk = blockIdx.x;
+  if (order) {
+    const unsigned int nbs = (unsigned int)(((long)*n_sorted * LPR + BLOCK - 1) / BLOCK);
+    if (blockIdx.x >= nbs) return;
+#ifndef RAY_TILE_ORDER
+    chunk = (blockIdx.x & 1u) ? nbs - 1u - (blockIdx.x >> 1) : (blockIdx.x >> 1);
+#endif
+  }
   const unsigned int* __restrict__ inert = reinterpret_cast<const unsigned int*>(inert64);   // 32-bit words: cheaper shifts
   const unsigned int wpr32 = (unsigned int)((P.pitch + 63) / 64) * 2u;                       // 32-bit words per bitmap row (pitch = C; a ray window: its width)
   // LDS words: [table (span)] [s_k (nS)] [queues (BLOCK/64 * 384)]
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
   // LPR lanes per ray (small clouds): lane `sub` of a ray marches the samples K = LPR * k + sub -- the march is a chain of ~350
   // dependent steps per wave, which is pure latency when the cloud cannot fill the chip; four lanes per ray cut the chain to a quarter
   // (each lane computes the cell of sample K - 1 itself for the new-cell test).
-  const long gi = (long)blockIdx.x * BLOCK + threadIdx.x;
+  const long gi = (long)chunk * BLOCK + threadIdx.x;
   const int sub = LPR > 1 ? (int)(gi % LPR) : 0;
   long i = gi / LPR;
   bool have = i < n;
@@ -394,7 +409,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
         atomicAdd(reinterpret_cast<unsigned long long*>(accr_dec(AR, cc)), (unsigned long long)d_sum);
         atomicAdd(accr_hits(AR, cc), hits);
       }
-      if (key) { unsigned int* kp = accr_key(AR, cc); if (ray_key_load(kp) < key) atomicMax(kp, key); }
+      if (key) { unsigned int* kp = accr_key(AR, cc); if (ray_key_load(kp) < key) atomicMax(kp, key); }     // (loading the key WITH the cell, ahead of the tests, measured no gain: 219 vs 221 us on the terrain)
     };
     if (!__builtin_amdgcn_ballot_w64(c_hit != 0u) || __popcll(cm) < 4) {
       // upper bounds only (the frames after clear(), a band a shift brought in) or next to nothing to combine: the visits of one step
