@@ -1,14 +1,13 @@
 #!/bin/bash
-# final run of the round on the GPU box: priority parity tests, the round's profiles (tools/profile_round.sh without its bench lines),
-# two bench lines, then the remaining tests as far as the time allows
+# closing run of a round on the GPU box: the round's profiles (tools/profile_round.sh without its bench lines; the terrain
+# sub-measurement is skipped under the profiler), then the parity tests.  Afterwards, locally: tools/profiles_from_gpurun.sh <tag>,
+# then tools/bench_lines.sh <tag> on the GPU box (the lines then quote the stamped kernel statistics) and the import once more.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=r04
+TAG=${1:-r04}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O $R/gpurun_out/final
 cd $R
-PRIO="tests/test_hip_terrain.py tests/test_hip_parity.py tests/test_hip_fuzz.py tests/test_hip_randomized.py tests/test_hip_semantic.py tests/test_hip_strips.py tests/test_hip_comm.py tests/test_hip_large_maps.py tests/test_hip_shift.py tests/test_hip_fullsize.py"
-timeout 400 python -m pytest $PRIO -m gpu -q -x 2>&1 | grep -vE "^RCCL|^HIP ver|^ROCm|^Hostname|^Librccl" | tail -5 > gpurun_out/final/tests_priority.txt
 python -c "import bench; print(bench.source_stamp())" > $O/source_stamp.txt
 cd /tmp && export TMPDIR=/tmp
 for wl in cfg2 cfg3; do
@@ -21,8 +20,5 @@ for wl in cfg2 cfg3; do
   done
 done
 cd $R
-python bench.py > $O/bench_cfg2.json 2>> $O/bench_err.log
-python bench.py --workload cfg3 --steps 20 > $O/bench_cfg3.json 2>> $O/bench_err.log
-IGN=""; for f in $PRIO; do IGN="$IGN --ignore=$f"; done
-timeout ${REST_TIMEOUT:-400} python -m pytest tests -m gpu -q -x $IGN 2>&1 | grep -vE "^RCCL|^HIP ver|^ROCm|^Hostname|^Librccl" | tail -5 > gpurun_out/final/tests_rest.txt
-cat gpurun_out/final/tests_priority.txt gpurun_out/final/tests_rest.txt; head -c 400 $O/bench_cfg2.json
+timeout ${TEST_TIMEOUT:-900} python -m pytest tests -m gpu -q -x 2>&1 | grep -vE "^RCCL|^HIP ver|^ROCm|^Hostname|^Librccl" | tail -6 > gpurun_out/final/tests.txt
+cat gpurun_out/final/tests.txt
