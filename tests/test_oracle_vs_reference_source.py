@@ -41,6 +41,30 @@ def test_count_outputs_on_warm_map(name, cfg, weights):
     assert abs(es - float(err[0])) <= 1e-4 * max(1.0, ec) * 1e-1 + 1e-5      # reference accumulates in float32, order dependent
 
 
+@pytest.mark.parametrize("name,cfg", [("yaml202", eo.YAML), ("default202", eo.DEFAULTS)])
+def test_count_outputs_on_the_terrain_scene(name, cfg, weights):
+    """the same comparison on a spatially coherent, scan-ordered cloud (tests/_fixtures.py: terrain_cloud): hundreds of points per cell
+    next to the sensor, most of the map never seen -- the inputs of tests/test_hip_terrain.py, so the oracle those GPU tests compare
+    with is tied to the reference's kernel on this kind of cloud too."""
+    rk = _ref(name)
+    C = 202
+    om = eo.OracleMap(eo.make_params(cfg, cell_n=C, weights=weights))
+    R, t = np.eye(3, dtype=np.float32), np.array([0, 0, 1], np.float32)
+    om.update_map_with_kernel(fx.terrain_cloud(C, 300, 160, 0), R, t)
+    for _ in range(10):
+        om.update_time()
+    om.update_variance()
+    p = fx.terrain_cloud(C, 300, 160, 1, shift=1.5)
+    Rf = R.ravel().copy()
+    nm = np.zeros((7, C, C), np.float32); err = np.zeros(1, np.float32); cnt = np.zeros(1, np.float32)
+    rk.error_counting(om.elevation_map.copy(), p.copy(), Rf, t.copy(), nm, err, cnt)
+    n_pts, n_inl, es, ec = om.count(p, R, t)
+    assert int(n_pts.max()) > 100 and int((n_pts > 0).sum()) < C * C // 2          # piled up, and most cells untouched
+    assert np.array_equal(n_pts, nm[4].astype(np.uint32)) and np.array_equal(n_inl, nm[3].astype(np.uint32))
+    assert ec == int(cnt[0]) and ec > 100
+    assert abs(es - float(err[0])) <= 1e-4 * max(1.0, ec) * 1e-1 + 1e-5      # reference accumulates in float32, order dependent
+
+
 def test_fuse_sums_without_outliers_rays_off(weights):
     """F2 fixture: rays disabled, fresh cells only => sequential == contract for every plane."""
     rk = _ref("yaml202_norays")
