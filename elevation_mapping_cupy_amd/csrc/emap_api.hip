@@ -69,7 +69,10 @@ void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, u
 void launch_bin_scatter(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, const unsigned int*, const unsigned int*, BinRec*, const BinStg*, const unsigned int*);
 void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, ErrSlot*, const SplitView&, long);
 void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const ChanView&, long,
-                          const unsigned int*, float*, float*, long);
+                          const unsigned int*, float*, float*, long, const SplitView&, void*, int);
+size_t sem_split_bytes(int);
+bool sem_split_possible(const SemSpec&);
+#define SEM_SPLIT_SLOTS 128      /* heavy tiles whose semantic sums several workgroups may share (19 MB of scratch) */
 void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, AccF*, FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&, const GateFold&, const SplitView&, long);
 #define BIN_MAX_T 16384
 #define BIN_MAX_B 2048
@@ -143,6 +146,7 @@ struct emap_ctx {
   unsigned int* bin_sync;          // ticket counters of k_bin_scan (last_block_ticket), zero between launches
   SplitView split;                 // heavy tiles reduced by several workgroups (emap_device.h); split.on: this frame's scan listed them
   void* split_mem;                 // one allocation behind split's arrays
+  void* sem_split_mem;             // scratch of the split semantic tile kernel (SemSplit), zero between launches
   volatile unsigned int* split_need;   // host-mapped word: the parts the last scan the device has finished would have listed
   bool split_dirty;                // k_tile_count has filled slots that no k_tile_fuse has cleared yet
   GateFold gate_fold;              // multi-GPU frames: gate decision on the all-reduced totals folded into the tile kernel (mode 0: k_gate ran)
@@ -393,7 +397,7 @@ int emap_destroy(emap_ctx* ctx) {
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   delete ctx->workers;
   hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert); hipFree(ctx->inl_plane); hipFree(ctx->ray_thr);
-  hipFree(ctx->bin_recs); hipFree(ctx->bin_own); hipFree(ctx->bin_own_cnt); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start); hipFree(ctx->bin_sync); hipFree(ctx->split_mem); if (ctx->split_need) hipHostFree((void*)ctx->split_need);
+  hipFree(ctx->bin_recs); hipFree(ctx->bin_own); hipFree(ctx->bin_own_cnt); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start); hipFree(ctx->bin_sync); hipFree(ctx->split_mem); hipFree(ctx->sem_split_mem); if (ctx->split_need) hipHostFree((void*)ctx->split_need);
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   emap_comm_destroy(ctx);
@@ -1164,8 +1168,14 @@ int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], cons
   S.any_bayes = nk[2] > 0;
   if (S.any_bayes) { int rc = ensure_alpha(ctx); if (rc) return rc; }
   if (ctx->frame_binned) {   // the frame's tile-sorted records are still valid: reduce in LDS, no global atomics
+    if (ctx->split.on && ctx->split.cap > 0 && !ctx->sem_split_mem && sem_split_possible(S)) {      // the frame listed heavy tiles: their semantic sums are shared too
+      void* m = nullptr;
+      CK(hipMalloc(&m, sem_split_bytes(SEM_SPLIT_SLOTS)));
+      if (hipMemsetAsync(m, 0, sem_split_bytes(SEM_SPLIT_SLOTS), ctx->stream) != hipSuccess) { hipFree(m); ctx->err = "hipMemsetAsync(semantic split scratch)"; return EMAP_ERR_HIP; }
+      ctx->sem_split_mem = m;
+    }
     launch_tile_semantic(ctx->stream, ctx->kp, ctx->bg, S, ctx->bin_recs, ctx->bin_tile_start, ctx->chan, ctx->n_pts,
-                         ctx->cnt_plane, ctx->sem, ctx->sem_alpha, ctx->ncells_alloc);
+                         ctx->cnt_plane, ctx->sem, ctx->sem_alpha, ctx->ncells_alloc, ctx->split, ctx->sem_split_mem, SEM_SPLIT_SLOTS);
     CK(hipGetLastError());
     return EMAP_OK;
   }

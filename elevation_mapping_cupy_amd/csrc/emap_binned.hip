@@ -728,20 +728,35 @@ void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* 
 typedef SemSpec SemSpecB;
 #define SEM_GROUP 4
 #define SEM_BLK 1024     /* one wave per tile row: 32 waves per CU with two workgroups (256 threads left the CU at 12 waves: the kernel is a chain of short, latency-bound phases) */
+// SPLIT (launches with extra workgroups in front, see tile_work): a heavy tile's parts each accumulate a channel group over their own
+// records, add the partial sums (doubles -- sums of floats of one magnitude, exact in any grouping just as the LDS accumulation is -- and
+// the colour sums) to the (tile, group) scratch of SemSplit and take that group's ticket; the part that arrives last reads the totals
+// back and writes the group's planes.  Only for specs whose groups are independent of each other (no class_bayesian renormalisation
+// over several layers, colour riding along or absent) and tiles whose slot lies below SemSplit::slots; everything else is reduced by
+// the tile's own workgroup as before.
+struct SemSplit { double* sum; unsigned int* col; unsigned int* tick; int slots, phases; };      // [slot][phase][4][cell], [slot][4][cell], [slot][phase]
+template <bool SPLIT>
 __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSpecB S, const BinRec* __restrict__ recs,
                                                              const unsigned int* __restrict__ tile_start, ChanView V,
                                                              long n, const unsigned int* __restrict__ cnt_plane,
-                                                             float* __restrict__ sem, float* __restrict__ alpha_planes, long plane) {
+                                                             float* __restrict__ sem, float* __restrict__ alpha_planes, long plane,
+                                                             SplitView SV, SemSplit X) {
   constexpr int NC = BIN_TR * BIN_TC;
   const float* __restrict__ chp = V.p - V.col0;          // (a local restrict pointer: the gathers below must stay free to run ahead of the plane stores)
   const long chs = V.stride;
   __shared__ double s_sum[SEM_GROUP][NC];
   __shared__ unsigned int s_col[4][NC];                 // r, g, b, count of ONE colour layer at a time
-  int t, sb;
-  bin_of_block(G, t, sb);                              // sb = which 16 x 64 tile of the bin
-  if (t >= G.T) return;
+  __shared__ bool s_fin;
+  TileWork w;                                          // sb = which 16 x 64 tile of the bin
+  if (!tile_work<SPLIT>(G, SV, tile_start, w)) return;
+  if (SPLIT && w.np > 1u && w.slot >= (unsigned int)X.slots) {      // no scratch for this tile: its own workgroup takes all of its records
+    if (w.part) return;
+    w.np = 1u; w.r0 = tile_start[w.t]; w.r1 = tile_start[w.t + 1];
+  }
+  const bool split = SPLIT && w.np > 1u;               // (uniform)
+  const int t = w.t, sb = w.sb;
   const int ty = t / G.tiles_x, tx = t - ty * G.tiles_x;
-  const unsigned int r0 = tile_start[t], r1 = tile_start[t + 1];
+  const unsigned int r0 = w.r0, r1 = w.r1;
   const int tc = threadIdx.x & 63, wv = threadIdx.x >> 6, col = tx * BIN_TC + tc;
   const int row_base = (ty * G.sub + sb) * BIN_TR;
   if (row_base >= P.nrows) return;
@@ -789,7 +804,40 @@ __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSp
       }
     }
     __syncthreads();
-    if (col < P.C) {
+    bool fin = true;                                          // this workgroup writes the group's planes
+    if (split) {
+      static_assert(SEM_BLK == NC && NC == (int)SPLIT_CELLS, "one thread per cell of a slot");
+      const int ph = g0 / SEM_GROUP;
+      double* xs = X.sum + ((size_t)w.slot * X.phases + ph) * SEM_GROUP * NC;
+      unsigned int* xc = X.col + (size_t)w.slot * 4 * NC;
+      for (int q = 0; q < ng; ++q) { const double v = s_sum[q][threadIdx.x]; if (v != 0.0) unsafeAtomicAdd(&xs[q * NC + threadIdx.x], v); }
+      if (ride && g0 == 0 && s_col[3][threadIdx.x])
+        for (int q = 0; q < 4; ++q) atomicAdd(&xc[q * NC + threadIdx.x], s_col[q][threadIdx.x]);
+      __builtin_amdgcn_s_waitcnt(0);                          // (the hand-off of k_tile_fuse's parts: acknowledgements, barrier, ticket)
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned int* tk = X.tick + (size_t)w.slot * X.phases + ph;
+        s_fin = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == w.np - 1u;
+        if (s_fin) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      fin = s_fin;
+      if (fin) {                                              // totals back into LDS, scratch left zeroed for the next frame
+        for (int q = 0; q < ng; ++q) {
+          const double v = __hip_atomic_load(&xs[q * NC + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_sum[q][threadIdx.x] = v;
+          if (v != 0.0) __hip_atomic_store(&xs[q * NC + threadIdx.x], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (ride && g0 == 0)
+          for (int q = 0; q < 4; ++q) {
+            const unsigned int v = __hip_atomic_load(&xc[q * NC + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_col[q][threadIdx.x] = v;
+            if (v) __hip_atomic_store(&xc[q * NC + threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+      }
+      __syncthreads();
+    }
+    if (fin && col < P.C) {
       for (int k = 0; k < BIN_TR / (SEM_BLK / 64); ++k) {
         const int tr = wv + (SEM_BLK / 64) * k, lrow = row_base + tr;
         if (lrow >= P.nrows) break;
@@ -876,7 +924,19 @@ __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSp
     }
   }
 }
+// scratch of the split semantic kernel: bytes for `slots` tiles (0: cannot split this spec)
+size_t sem_split_bytes(int slots) { return (size_t)slots * ((size_t)(SEM_MAX_CH / SEM_GROUP) * SEM_GROUP * SPLIT_CELLS * 8 + 4 * SPLIT_CELLS * 4 + (SEM_MAX_CH / SEM_GROUP) * 4); }
+bool sem_split_possible(const SemSpec& S) { return S.n_sum > 0 && !S.any_bayes && (S.n_col == 0 || S.n_col == 1); }     // independent groups; colour riding along or absent
 void launch_tile_semantic(hipStream_t s, const KP& P, const BinGeo& G, const SemSpec& S, const BinRec* recs, const unsigned int* tile_start,
-                          const ChanView& V, long n, const unsigned int* cnt_plane, float* sem, float* alpha_planes, long plane) {
-  hipLaunchKernelGGL(k_tile_semantic, dim3(tile_grid(G)), dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, V, n, cnt_plane, sem, alpha_planes, plane);
+                          const ChanView& V, long n, const unsigned int* cnt_plane, float* sem, float* alpha_planes, long plane,
+                          const SplitView& SV, void* split_mem, int split_slots) {
+  SemSplit X = {nullptr, nullptr, nullptr, 0, SEM_MAX_CH / SEM_GROUP};
+  const bool split = SV.on && SV.cap > 0 && split_mem && split_slots > 0 && sem_split_possible(S);
+  if (split) {
+    X.slots = split_slots;
+    X.sum = reinterpret_cast<double*>(split_mem);
+    X.col = reinterpret_cast<unsigned int*>(X.sum + (size_t)split_slots * X.phases * SEM_GROUP * SPLIT_CELLS);
+    X.tick = X.col + (size_t)split_slots * 4 * SPLIT_CELLS;
+    hipLaunchKernelGGL(k_tile_semantic<true>, dim3((unsigned int)SV.cap * G.sub + tile_grid(G)), dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, V, n, cnt_plane, sem, alpha_planes, plane, SV, X);
+  } else hipLaunchKernelGGL(k_tile_semantic<false>, dim3(tile_grid(G)), dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, V, n, cnt_plane, sem, alpha_planes, plane, SV, X);
 }

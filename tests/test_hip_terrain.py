@@ -157,3 +157,29 @@ def test_heavy_tiles_soak_two_contexts_and_the_oracle(weights):
     assert a.normal_map.tobytes() == b.normal_map.tobytes()
     assert_planes_close(a.elevation_map, orc.elevation_map, what="40 heavy frames")
     assert_planes_close(a.normal_map, orc.normal_map, names=["nx", "ny", "nz"])
+
+
+@pytest.mark.parametrize("mode", ["reference_fp16", "fp32"])
+@pytest.mark.parametrize("stack", [0, 2])
+def test_heavy_tiles_multi_modal_against_the_oracle(mode, stack):
+    """RGB + two averaged channels + a class_average channel on clouds whose points pile up in one sort tile: the semantic tile kernel
+    shares a heavy tile's sums between several workgroups too (k_tile_semantic<true>); the first frame runs unsplit."""
+    CH = ["x", "y", "z", "s0", "s1", "c0", "rgb"]
+    C, N = 300, 200000
+    hip, orc = make_pair(eo.YAML, C, mode)
+    hip.param.pointcloud_channel_fusions = {"rgb": "color", "c0": "class_average", "default": "average"}
+    hip.set_scatter_mode("binned", stack)
+    R, t = fx.POSES["identity"]
+    for f in range(4):
+        p = fx.semantic_cloud(C, N, f)
+        k = int(N * (0.5 + 0.1 * f))
+        p[:k, :2] *= np.float32(0.04 + 0.02 * f)                 # the central patch holds most of the cloud
+        hip.input_pointcloud(p, CH, R, t.copy(), 0.0, 0.0)
+        orc.update_map_with_kernel(p, R, t, 0.0, 0.0)
+        orc.semantic_update(p, R, t, average=[(3, 0), (4, 1)], class_average=[(5, 2)], color=[(6, 3)], alpha=0.5)
+        hip.update_time(); orc.update_time()
+    assert_planes_close(hip.elevation_map, orc.elevation_map, what="heavy multi-modal frames")
+    sm = hip.semantic_map.semantic_map
+    assert np.allclose(sm[:3], orc.semantic_map[:3], atol=1e-6, rtol=1e-5)
+    assert np.array_equal(sm[3].view(np.uint32), orc.semantic_map[3].view(np.uint32))
+    assert int((sm[3].view(np.uint32) != 0).sum()) > 1000

@@ -20,5 +20,5 @@ for wl in cfg2 cfg3; do
   done
 done
 cd $R
-timeout ${TEST_TIMEOUT:-900} python -m pytest tests -m gpu -q -x 2>&1 | grep -vE "^RCCL|^HIP ver|^ROCm|^Hostname|^Librccl" | tail -6 > gpurun_out/final/tests.txt
+timeout ${TEST_TIMEOUT:-900} python -m pytest ${TESTS:-tests} -m gpu -q -x 2>&1 | grep -vE "^RCCL|^HIP ver|^ROCm|^Hostname|^Librccl" | tail -6 > gpurun_out/final/tests.txt
 cat gpurun_out/final/tests.txt
