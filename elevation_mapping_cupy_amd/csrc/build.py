@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(os.path.dirname(HERE), "libemap_hip.so")
 OBJ = os.path.join(HERE, "_obj")
-SOURCES = ["emap_kernels.hip", "emap_binned.hip", "emap_semantic.hip", "emap_api.hip", "emap_inpaint_host.hip"]
+SOURCES = ["emap_kernels.hip", "emap_binned.hip", "emap_semantic.hip", "emap_api.hip", "emap_inpaint_host.hip", "emap_inpaint_ns.cpp"]      # (.cpp: host-only C++)
 HEADERS = ["emap_device.h", os.path.join("..", "..", "include", "emap_hip.h")]
 DEPS = SOURCES + HEADERS
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-gpu-rdc",
@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
 
     def compile_one(pair):
         src, obj = pair

@@ -11,11 +11,12 @@ Same semantics around the fill as the reference: mask = ``is_valid < 0.5``, the 
   line-by-line restatement and checks the properties every implementation must have).
 * ``method="front"``: the round-1/2 device-side substitute (``emap_inpaint_u8``: front-by-front distance-weighted mean of the known
   8-neighbours on the MI355X) for maps where a host pass per publish is too slow; needs the owning ElevationMap.
-* ``method="ns"`` (Navier-Stokes, ``cv2.INPAINT_NS``): not built; selects "telea" with a one-time note."""
+* ``method="ns"`` (``cv2.INPAINT_NS``, reference plugins/inpainting.py:33-38): the Navier-Stokes based method in its fast-marching form,
+  HOST code as well (``emap_inpaint_ns_u8``): the same march as Telea's, a pixel = the mean of the known pixels within the radius
+  weighted along the isophote direction.  Parity with OpenCV's values unpinned like "telea" (tests/test_inpaint_ns.py)."""
 from __future__ import annotations
 
 import ctypes as ct
-import sys
 from typing import List
 
 import numpy as np
@@ -28,10 +29,7 @@ from .plugin_manager import PluginBase
 class Inpainting(PluginBase):
     def __init__(self, cell_n: int = 100, method: str = "telea", emap=None, **kwargs):
         super().__init__()
-        if method == "ns":
-            print("[Inpainting] method 'ns' (Navier-Stokes) is not available in this build: using 'telea'", file=sys.stderr)
-            method = "telea"
-        self.method = method if method in ("telea", "front") else "telea"
+        self.method = method if method in ("telea", "ns", "front") else "telea"      # (the reference falls back to telea for unknown names, :37-38)
         self.cell_n = cell_n
         self.emap = emap
         self.sweeps_run = 0
@@ -45,14 +43,15 @@ class Inpainting(PluginBase):
         h_max, h_min = float(h[known].max()), float(h[known].min())
         span = (h_max - h_min) if h_max > h_min else 1.0
         q8 = np.clip((h - h_min) * 255 / span, 0, 255).astype(np.uint8)            # 8-bit image, truncation like astype("uint8")
-        if self.method == "telea":
+        if self.method in ("telea", "ns"):
             lib = _lib.load()
             mask = np.ascontiguousarray(~known, np.uint8)
             out8 = np.empty_like(q8)
             p = lambda a: a.ctypes.data_as(ct.POINTER(ct.c_uint8))               # noqa: E731
-            rc = lib.emap_inpaint_telea_u8(p(np.ascontiguousarray(q8)), p(mask), q8.shape[0], q8.shape[1], 1, p(out8))
+            fill = lib.emap_inpaint_telea_u8 if self.method == "telea" else lib.emap_inpaint_ns_u8
+            rc = fill(p(np.ascontiguousarray(q8)), p(mask), q8.shape[0], q8.shape[1], 1, p(out8))
             if rc != 0:
-                raise _lib.EmapError("emap_inpaint_telea_u8 failed (%d)" % rc)
+                raise _lib.EmapError("emap_inpaint_%s_u8 failed (%d)" % (self.method, rc))
             out = out8.astype(np.float32)
         else:
             if self.emap is None:

@@ -224,6 +224,11 @@ int emap_inpaint_u8(emap_ctx* ctx, const float* host_image, const float* host_kn
  * priority-queue algorithm that the reference also runs on the CPU.  A restatement of the published algorithm (OpenCV is absent
  * offline: parity with its values is not pinned). */
 int emap_inpaint_telea_u8(const uint8_t* image, const uint8_t* mask, int32_t rows, int32_t cols, int32_t radius, uint8_t* out);
+/* Inpainting plugin, method "ns" (EM/plugins/inpainting.py:33-38,59: cv2.inpaint(h, mask, 1, cv2.INPAINT_NS) on the host): the
+   Navier-Stokes based fill in its fast-marching form -- same march as above, a pixel = mean of the known pixels within `radius`
+   weighted along the isophote direction (csrc/emap_inpaint_ns.cpp).  HOST code, no context, same arguments and errors as
+   emap_inpaint_telea_u8.  Parity with OpenCV's values is NOT pinned (OpenCV absent offline); pinned against oracle/ns_inpaint.py. */
+int emap_inpaint_ns_u8(const uint8_t* image, const uint8_t* mask, int32_t rows, int32_t cols, int32_t radius, uint8_t* out);
 
 /* ---- camera path: ElevationMap.input_image (EM/elevation_mapping.py:468-562).
  * emap_image_correspondence = image_to_map_correspondence_kernel (EM/kernels/custom_image_kernels.py:9-157): x1, y1 = camera
