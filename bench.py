@@ -702,8 +702,10 @@ def run_strips_native(a, rank, world, local_rank, rdv):
     par = parameter_from(cfg, C, a.mode, weights, device=dev)
     halo = sharded.halo_rows_needed(par.dilation_size, world)
     row_w = None
-    # (from 2048^2 cells on the sharded frame marches its rays BY RAY -- emap_set_ray_mode -- and equal heights are right again)
-    if cfg["enable_visibility_cleanup"] and world > 1 and C < 2048 and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
+    # (a frame that marches its rays BY RAY wants equal heights: the library's predicate, not the map size alone)
+    ray_mode = {"auto": 0, "by_row": 1, "by_ray": 2}.get(os.environ.get("EMAP_RAY_MODE", "auto"), 0)
+    by_ray = sharded.frame_marches_by_ray(C, N, world, "native", ray_mode, a.scatter)
+    if cfg["enable_visibility_cleanup"] and world > 1 and not by_ray and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
         row_w = sharded.ray_balanced_weights(C, float(cfg["resolution"]), float(cfg["max_ray_length"]), halo, world)
     r0, r1 = sharded.strip_rows(C, world, rank, row_w)
     ok, emap, err = True, None, ""
@@ -712,6 +714,8 @@ def run_strips_native(a, rank, world, local_rank, rdv):
             raise ValueError("strip of %d rows is thinner than the %d-row halo" % (r1 - r0, halo))
         emap = ElevationMap(par, strip=(r0, r1 - r0, halo))
         emap.set_scatter_mode(a.scatter)
+        if ray_mode:
+            emap.set_ray_mode(os.environ["EMAP_RAY_MODE"])       # (A/B knob: "by_row" / "by_ray" on every rank)
     except Exception as ex:  # noqa: BLE001
         ok, err = False, str(ex)
     if not rdv.agree("create", ok):

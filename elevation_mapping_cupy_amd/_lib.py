@@ -67,6 +67,7 @@ SYMBOLS = [
 ]
 
 _lib = None
+ABI_VERSION = 2      # include/emap_hip.h: EMAP_ABI_VERSION (checked by load(), and across ranks by emap_comm_init)
 
 
 class EmapError(RuntimeError):
@@ -95,6 +96,10 @@ def load():
             except AttributeError:
                 if not os.environ.get("EMAP_HIP_LIB"):      # an older build handed in for an A/B run may lack newer entry points
                     raise
+    got = int(lib.emap_abi_version())
+    if got != ABI_VERSION and not os.environ.get("EMAP_HIP_LIB"):
+        raise EmapError("%s speaks ABI version %d, this binding expects %d (include/emap_hip.h: EMAP_ABI_VERSION) -- rebuild with "
+                        "`python -m elevation_mapping_cupy_amd.csrc.build`" % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

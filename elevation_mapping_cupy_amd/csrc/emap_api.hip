@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes only: the library itself is dlopen()ed by emap_comm_init
 #include "../../include/emap_hip.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -749,9 +750,14 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
       if (cap > (long)SPLIT_MAX_EXTRA) cap = SPLIT_MAX_EXTRA;
       ctx->split.cap = (int)((cap + 7) & ~7L);
     }
-    if (ctx->split.on && ctx->split_dirty)            // a count stage whose fuse stage never came (staged API): its slots are still filled
+    // a count stage whose fuse stage never came (staged API, an error in between): its slots are still filled.  The flag is only
+    // cleared by what really empties them -- this memset or a fuse stage (fuse_impl) -- never by a frame that splits nothing: such a
+    // frame in between must not make the NEXT split frame add its counts on top of stale ones.
+    if (ctx->split.on && ctx->split_dirty) {
       CK(hipMemsetAsync(ctx->split_mem, 0, (size_t)SPLIT_MAX_SLOTS * SPLIT_CELLS * 40 + 4 * SPLIT_MAX_SLOTS, ctx->stream));
-    ctx->split_dirty = ctx->split.on != 0;
+      ctx->split_dirty = false;
+    }
+    ctx->split_dirty = ctx->split_dirty || (ctx->split.on != 0 && ctx->split.cap > 0);      // (slots are only used by the SPLIT instantiations: extra workgroups in the launch)
     launch_bin_scan(ctx->stream, ctx->bg, ctx->bin_hist, ctx->bin_tile_total, ctx->bin_tile_start, ctx->bin_sync, ctx->split);
     if (tm) CK(hipEventRecord(ctx->ev[ST_SCATTER], ctx->stream));
     launch_bin_scatter(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, ctx->bin_tile_start, ctx->bin_recs, own, ctx->bin_own_cnt);
@@ -826,7 +832,7 @@ static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool fus
     if (fuse_average && rays) ctx->inert_zero = false;
     launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame, fuse_average, rays,
                     ctx->cnt_plane, ctx->inert, ctx->inl_plane, ctx->ray_thr, ctx->ov_args, ctx->gate_fold, ctx->split, ctx->n_pts);
-    ctx->split_dirty = false;
+    if (ctx->split.on) ctx->split_dirty = false;        // k_tile_fuse's parts cleared their slots (a frame that splits nothing leaves an older count stage's slots as they are)
     ctx->gate_fold.mode = 0;
     if (fuse_average) ctx->kp.mv.n = 0;   // every owned cell rewritten: pending map shifts are in memory now
     CK(hipGetLastError());
@@ -1714,6 +1720,8 @@ int emap_comm_unique_id(const char* rccl_path, uint8_t id_out[128]) {
   return EMAP_OK;
 }
 
+static long window_cap(const emap_ctx* ctx);
+static int alloc_window(emap_ctx* ctx, long cap);
 int emap_comm_init(emap_ctx* ctx, const char* rccl_path, const uint8_t id[128], int32_t rank, int32_t world) {
   CKARG(ctx && id && world >= 1 && rank >= 0 && rank < world, "bad rank / world");
   CKARG(!ctx->rccl, "communicator already initialised");
@@ -1732,6 +1740,24 @@ int emap_comm_init(emap_ctx* ctx, const char* rccl_path, const uint8_t id[128], 
   CK(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
   CK(hipMalloc((void**)&ctx->comm_sums, sizeof(double) * 36));
   CK(hipMemsetAsync(ctx->comm_sums, 0, sizeof(double) * 36, ctx->stream));
+  // Every rank must speak the same ABI: the halo rows are raw 16-byte cold half cells and the ray window raw 48-byte records, so a
+  // peer built against another layout would exchange misaligned bytes silently.  max(v) and max(-v) over the ranks: equal and
+  // opposite iff all ranks agree.
+  if (world > 1 && ctx->prm.enable_visibility_cleanup && ctx->win_cap < window_cap(ctx)) {      // rays by ray: see ensure_window
+    int rc = alloc_window(ctx, window_cap(ctx)); if (rc) return rc;
+  }
+  if (world > 1) {
+    const double mine[2] = {(double)EMAP_ABI_VERSION, -(double)EMAP_ABI_VERSION};
+    double got[2] = {0.0, 0.0};
+    CK(hipMemcpyAsync(ctx->comm_sums + 16, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+    CKN(a->AllReduce(ctx->comm_sums + 16, ctx->comm_sums + 18, 2, ncclFloat64, ncclMax, ctx->comm, ctx->stream));
+    CK(hipMemcpyAsync(got, ctx->comm_sums + 18, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (got[0] != mine[0] || got[1] != mine[1]) {
+      ctx->err = "emap_comm_init: the ranks were built against different EMAP_ABI_VERSIONs (" + std::to_string((int)-got[1]) + " .. " + std::to_string((int)got[0]) + ", this rank: " + std::to_string(EMAP_ABI_VERSION) + ")";
+      return EMAP_ERR_COMM;
+    }
+  }
   return EMAP_OK;
 }
 
@@ -1815,20 +1841,33 @@ static bool ray_window(const emap_ctx* ctx, const float t[3], Win* w) {
   w->c0 = c_lo & ~63; w->nc = ((c_hi - w->c0) + 63) & ~63;
   return true;
 }
+// The largest window ray_window can return for the context's parameters (reach on both sides + its alignment slack, clipped to the map).
+static long window_cap(const emap_ctx* ctx) {
+  const emap_params& p = ctx->prm;
+  const long C = p.cell_n;
+  const double reach = p.max_ray_length * 1.01 + 4.0 * p.resolution;
+  const long W = 2 * (long)std::ceil(reach / p.resolution) + 8;
+  const long nr = std::min<long>(((W + 7) & ~7L) + 8, (C + 7) & ~7L), nc = std::min<long>(((W + 63) & ~63L) + 64, (C + 63) & ~63L);
+  return nr * nc;
+}
+static int alloc_window(emap_ctx* ctx, long cap) {
+  CK(hipStreamSynchronize(ctx->stream));
+  hipFree(ctx->win_state); hipFree(ctx->win_bits); hipFree(ctx->win_thr); hipFree(ctx->win_dh); hipFree(ctx->win_key);
+  ctx->win_state = nullptr; ctx->win_bits = nullptr; ctx->win_thr = nullptr; ctx->win_dh = nullptr; ctx->win_key = nullptr; ctx->win_cap = 0;
+  CK(hipMalloc((void**)&ctx->win_state, sizeof(unsigned int) * 12 * (size_t)cap));      // hot 4 + cold 4 + normals 3 + inlier count 1 words per cell
+  CK(hipMalloc((void**)&ctx->win_bits, sizeof(unsigned long long) * ((size_t)cap / 64 + 2)));
+  CK(hipMalloc((void**)&ctx->win_thr, sizeof(float) * ((size_t)cap / 64 + 1)));
+  CK(hipMalloc((void**)&ctx->win_dh, sizeof(long long) * 2 * (size_t)cap));
+  CK(hipMalloc((void**)&ctx->win_key, sizeof(unsigned int) * (size_t)cap));
+  ctx->win_cap = cap;
+  return EMAP_OK;
+}
+// The window buffers are allocated COLLECTIVELY, in emap_comm_init (every rank, for the largest window its parameters allow; the
+// caller's agreement step follows): an allocation that fails on one rank in the middle of a frame would leave the other ranks alone
+// in the three all-reduces below.  The growth path here only runs when the parameters changed after emap_comm_init.
 static int ensure_window(emap_ctx* ctx, Win* w) {
   const long n = (long)w->nr * w->nc;
-  if (n > ctx->win_cap) {
-    CK(hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->win_state); hipFree(ctx->win_bits); hipFree(ctx->win_thr); hipFree(ctx->win_dh); hipFree(ctx->win_key);
-    ctx->win_state = nullptr; ctx->win_bits = nullptr; ctx->win_thr = nullptr; ctx->win_dh = nullptr; ctx->win_key = nullptr; ctx->win_cap = 0;
-    const long cap = n + n / 8;                                   // (the window grows a little when the sensor leaves a map edge)
-    CK(hipMalloc((void**)&ctx->win_state, sizeof(unsigned int) * 12 * (size_t)cap));      // hot 4 + cold 4 + normals 3 + inlier count 1 words per cell
-    CK(hipMalloc((void**)&ctx->win_bits, sizeof(unsigned long long) * ((size_t)cap / 64 + 2)));
-    CK(hipMalloc((void**)&ctx->win_thr, sizeof(float) * ((size_t)cap / 64 + 1)));
-    CK(hipMalloc((void**)&ctx->win_dh, sizeof(long long) * 2 * (size_t)cap));
-    CK(hipMalloc((void**)&ctx->win_key, sizeof(unsigned int) * (size_t)cap));
-    ctx->win_cap = cap;
-  }
+  if (n > ctx->win_cap) { int rc = alloc_window(ctx, std::max(n + n / 8, window_cap(ctx))); if (rc) return rc; }
   w->hot = reinterpret_cast<float4*>(ctx->win_state); w->cold = w->hot + n;
   w->normal = reinterpret_cast<float*>(w->cold + n); w->inl = ctx->win_state + 11 * n;
   w->bits = ctx->win_bits; w->thr = ctx->win_thr; w->dh = ctx->win_dh; w->key = ctx->win_key;

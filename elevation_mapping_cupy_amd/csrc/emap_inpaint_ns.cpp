@@ -53,7 +53,7 @@ struct Front {                                  // framed (rows + 2) x (cols + 2
 }  // namespace
 
 extern "C" int emap_inpaint_ns_u8(const uint8_t* image, const uint8_t* mask, int32_t rows, int32_t cols, int32_t radius, uint8_t* out) {
-  if (!image || !mask || !out || rows < 1 || cols < 1 || (int64_t)rows * cols > (int64_t)1 << 30) return EMAP_ERR_INVALID;
+  if (!image || !mask || !out || rows < 2 || cols < 2 || (int64_t)rows * cols > (int64_t)1 << 30) return EMAP_ERR_INVALID;
   const int range = radius < 1 ? 1 : (radius > 100 ? 100 : radius);
   Front M; M.R = rows + 2; M.C = cols + 2;
   const size_t n = (size_t)M.R * M.C;

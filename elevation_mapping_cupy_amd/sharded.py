@@ -59,6 +59,15 @@ def ray_balanced_weights(cell_n: int, resolution: float, max_ray_length: float, 
     return w
 
 
+def frame_marches_by_ray(cell_n: int, n_points: int, world: int, comm_kind: str = "native", ray_mode: int = 0, scatter: str = "auto") -> bool:
+    """Will a sharded frame WITH the visibility pass march its rays by ray (csrc/emap_api.hip: rays_by_ray -- the same predicate, from
+    the values every rank shares)?  Only the library's own frame (``emap_update_sharded`` over the native RCCL communicator) can; the
+    torch-driven fallback and the staged strip engine always march by row.  Strips of equal RAY work (ray_balanced_weights) are for
+    frames that march by row; a by-ray frame wants equal heights (the decision must not hang on cell_n alone)."""
+    binned = scatter == "binned" or (scatter == "auto" and n_points >= 131072)
+    return world > 1 and comm_kind == "native" and ray_mode != 1 and binned and (ray_mode == 2 or cell_n >= 2048)
+
+
 def halo_rows_needed(dilation_size: int, world: int) -> int:
     """dilation radius d, +3 rows for the traversability stencil computed from the dilated plane, +1 for the
     reference's flat-index wrap into the adjacent row (custom_kernels.py:403-407)."""
@@ -478,8 +487,9 @@ def bench_main(a, rank, world, local_rank):
     par = parameter_from(cfg, C, a.mode, weights, device=local_rank)
     # frames with the visibility pass: strips of equal ray work (thin around the sensor) instead of equal height
     row_w = None
-    # (from 2048^2 cells on the sharded frame marches its rays BY RAY -- emap_set_ray_mode -- and equal heights are right again)
-    if cfg["enable_visibility_cleanup"] and world > 1 and C < 2048 and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
+    # (a frame that marches its rays BY RAY -- emap_set_ray_mode -- wants equal heights; this engine drives the frame stage by stage
+    # from Python, i.e. always by row: frame_marches_by_ray(..., comm_kind="torch") is False whatever the map size)
+    if cfg["enable_visibility_cleanup"] and world > 1 and not frame_marches_by_ray(C, N, world, "torch") and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
         row_w = ray_balanced_weights(C, float(cfg["resolution"]), float(cfg["max_ray_length"]), halo_rows_needed(cfg["dilation_size"], world), world)
     eng = HipStripEngine(par, rank, world, local_rank, dev, row_w)
     comm, comm_kind = None, ("torch" if oversubscribed else os.environ.get("EMAP_COMM", "native"))

@@ -17,7 +17,9 @@
 extern "C" {
 #endif
 
-#define EMAP_ABI_VERSION 1
+/* 2 (round 4/5): emap_halo_pack / emap_halo_unpack / emap_halo_bytes move 16-byte COLD half cells (halo * cell_n * 4 floats) instead of
+ * 32-byte cells; emap_upload_points de-interleaves the extra channels; emap_comm_init makes the ranks agree on this number. */
+#define EMAP_ABI_VERSION 2
 
 typedef enum {
   EMAP_OK = 0,
@@ -64,7 +66,9 @@ typedef struct emap_stats {
   float additive_mean_error; /* elevation_mapping.py:356 / get_additive_mean_error :412 */
   float shift;             /* amount added to the elevation plane (:357), 0 if none */
   uint32_t n_points;       /* points bound for the frame */
-  uint64_t ray_visits;     /* inside-map cells visited by the visibility pass (0 unless stats requested) */
+  uint64_t ray_visits;     /* inside-map cells visited by the visibility pass (0 unless stats requested).  Row strips marching BY ROW: the
+                              visits inside this strip's rows; marching BY RAY (emap_set_ray_mode): the visits of THIS rank's rays over the
+                              whole ray window -- either way the sum over the ranks is the single context's count */
 } emap_stats;
 
 typedef struct emap_ctx emap_ctx;
@@ -227,7 +231,8 @@ int emap_inpaint_telea_u8(const uint8_t* image, const uint8_t* mask, int32_t row
 /* Inpainting plugin, method "ns" (EM/plugins/inpainting.py:33-38,59: cv2.inpaint(h, mask, 1, cv2.INPAINT_NS) on the host): the
    Navier-Stokes based fill in its fast-marching form -- same march as above, a pixel = mean of the known pixels within `radius`
    weighted along the isophote direction (csrc/emap_inpaint_ns.cpp).  HOST code, no context, same arguments and errors as
-   emap_inpaint_telea_u8.  Parity with OpenCV's values is NOT pinned (OpenCV absent offline); pinned against oracle/ns_inpaint.py. */
+   emap_inpaint_telea_u8; images of fewer than 2 x 2 pixels are rejected (EMAP_ERR_INVALID).  Parity with OpenCV's values is NOT pinned
+   (OpenCV absent offline); pinned against oracle/ns_inpaint.py. */
 int emap_inpaint_ns_u8(const uint8_t* image, const uint8_t* mask, int32_t rows, int32_t cols, int32_t radius, uint8_t* out);
 
 /* ---- camera path: ElevationMap.input_image (EM/elevation_mapping.py:468-562).

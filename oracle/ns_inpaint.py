@@ -36,6 +36,8 @@ def inpaint_ns(image, mask, radius=1):
     """image, mask: (rows, cols) uint8; returns the inpainted uint8 image"""
     img = np.asarray(image, np.uint8).copy(); mask = np.asarray(mask) != 0
     rows, cols = img.shape
+    if rows < 2 or cols < 2:                   # (the clamped neighbour indices need two rows / columns; emap_inpaint_ns_u8 rejects such shapes too)
+        raise ValueError("inpaint_ns needs at least 2 x 2 pixels")
     R, C = rows + 2, cols + 2
     rng = max(1, min(100, int(radius)))
     f = np.zeros((R, C), np.uint8); t = np.full((R, C), 1.0e6, F32)

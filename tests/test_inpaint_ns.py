@@ -47,6 +47,9 @@ def test_properties():
     assert np.abs(inside[8:12] - inside[9:13]).max() <= 2
     assert np.array_equal(_c(img, np.zeros_like(mask)), img)                # nothing to fill
     assert _lib.load().emap_inpaint_ns_u8(None, None, 4, 4, 1, None) != 0
+    one = np.zeros((1, 5), np.uint8)            # a single row / column: the neighbour stencil would leave the image
+    assert _lib.load().emap_inpaint_ns_u8(one.ctypes.data_as(ct.c_void_p), one.ctypes.data_as(ct.c_void_p), 1, 5, 1, one.ctypes.data_as(ct.c_void_p)) != 0
+    assert _lib.load().emap_inpaint_ns_u8(one.ctypes.data_as(ct.c_void_p), one.ctypes.data_as(ct.c_void_p), 5, 1, 1, one.ctypes.data_as(ct.c_void_p)) != 0
 
 
 def test_differs_from_telea_where_it_should():
