@@ -30,7 +30,7 @@ void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float
 void launch_win_pack(hipStream_t, const KP&, const Win&, Cells, const float*, long, const unsigned int*, const unsigned long long*);
 void launch_win_prepare(hipStream_t, const Win&, int);
 void launch_win_unpack(hipStream_t, const KP&, const Win&, AccR*);
-void launch_ray_apply(hipStream_t, const KP&, Cells, AccR*, unsigned long long*, const OverlapArgs&);
+void launch_ray_apply(hipStream_t, const KP&, Cells, AccR*, unsigned long long*, const OverlapArgs&, FrameDev*);
 void launch_average(hipStream_t, const KP&, Cells, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*, const OverlapArgs&);
 static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, const ChanView&, double*, unsigned int*, long);
@@ -1019,7 +1019,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
   if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane, ov); ctx->kp.mv.n = 0; }
-  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov); ctx->inert_zero = true; }
+  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   STAGE(ST_OVERLAP);
@@ -1956,7 +1956,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
   if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane, ov); ctx->kp.mv.n = 0; }
-  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov); ctx->inert_zero = true; }
+  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   STAGE(ST_OVERLAP);

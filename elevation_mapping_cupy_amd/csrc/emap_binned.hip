@@ -621,7 +621,10 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
           const int br = (row_base >> 3) + (threadIdx.x >> 3), bc = tx * 8 + (threadIdx.x & 7);
           float bt = ord_float(s_thr[threadIdx.x]);
           if (bt == INFINITY && s_thr[16 + threadIdx.x]) bt = 3.4028234664e38f;
-          if (br * 8 < P.nrows && bc * 8 < P.C) thr[(long)br * ((P.C + 7) >> 3) + bc] = bt;
+          if (br * 8 < P.nrows && bc * 8 < P.C) {
+            thr[(long)br * ((P.C + 7) >> 3) + bc] = bt;
+            if (bt != INFINITY) F->thr_finite = 1u;               // (racing writers store the same value; see FrameDev)
+          }
         }
       }
     }

@@ -66,7 +66,11 @@ struct FrameDev {                  // per-frame scalars that stay on the device 
   float shift, mean_error, additive_mean_error;
   int gate_fired;
   unsigned long long ray_visits;
-  unsigned int n_points, pad;
+  unsigned int n_points;
+  // set by the tile kernel in front of a visibility pass when ANY 8 x 8 block got a finite visit threshold, cleared again by
+  // k_ray_apply: 0 in front of k_rays = every block is virgin (the first frame after clear()) -- the queue worker then skips the
+  // threshold fetch, one dependent trip per batch of queued visits.  A stale 1 only costs that trip.
+  unsigned int thr_finite;
 };
 
 #define EM_SCALE_H 4294967296.0          /* 2^32 */

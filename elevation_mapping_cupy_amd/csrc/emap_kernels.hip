@@ -233,6 +233,8 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     chunk = (blockIdx.x & 1u) ? nbs - 1u - (blockIdx.x >> 1) : (blockIdx.x >> 1);
 #endif
   }
+  // every block virgin (the first frame after clear(): FrameDev::thr_finite): no threshold can filter anything -- skip the fetch
+  const bool all_virgin = thr != nullptr && P.wmode == 0 && F->thr_finite == 0u;              // (uniform; a ray window derives its own thresholds: k_win_prepare)
   const unsigned int* __restrict__ inert = reinterpret_cast<const unsigned int*>(inert64);   // 32-bit words: cheaper shifts
   const unsigned int wpr32 = (unsigned int)((P.pitch + 63) / 64) * 2u;                       // 32-bit words per bitmap row (pitch = C; a ray window: its width)
   // LDS words: [table (span)] [s_k (nS)] [queues (BLOCK/64 * 384)]
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     // exchanges, the distance test) is fetched only when some visit of the batch survives.
     const float erz = __shfl(rz, src, 64);
     const float nz = T.t[2] + erz * s;                                                   // the sample height, recomputed bit for bit
-    const float bthr = (has && thr) ? thr[(lrow >> 3) * (unsigned int)((P.pitch + 7) >> 3) + (col >> 3)] : 3.4028234664e38f;
+    const float bthr = (has && thr) ? (all_virgin ? INFINITY : thr[(lrow >> 3) * (unsigned int)((P.pitch + 7) >> 3) + (col >> 3)]) : 3.4028234664e38f;
     const bool live = has && !(nz >= bthr);
     if (!__builtin_amdgcn_ballot_w64(live)) return;                                      // wave-uniform
     const float erx = __shfl(rx, src, 64), ery = __shfl(ry, src, 64), edec = __shfl(dec, src, 64);
@@ -604,9 +606,10 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cells cells, AccF* _
 // inflation (custom_kernels.py:251-252), upper bound (:230-233, :254-255), then average_map_kernel's reset of cells whose
 // validity fell below 0.5 (:380-384); re-arms the accumulators.
 __global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cells cells, AccR* __restrict__ accr,
-                                                        unsigned long long* __restrict__ inert, OverlapArgs O) {
+                                                        unsigned long long* __restrict__ inert, OverlapArgs O, FrameDev* __restrict__ F) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
+  if (li == 0) F->thr_finite = 0u;                                   // the rays are done with the thresholds too (FrameDev)
   if (li < (long)P.nrows * ((P.C + 63) / 64)) inert[li] = 0ull;      // the rays are done with the bitmap: leave it zeroed for the tile kernel's ORs
   long c = li + (long)P.halo * P.C;
   const AccR r = accr[c];
@@ -1484,8 +1487,8 @@ void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, lo
 void launch_commit(hipStream_t s, const KP& P, Cells cells, const AccF* acc, const FrameDev* F, unsigned long long* inert) {
   hipLaunchKernelGGL(k_commit, dim3((P.C + 63) / 64, P.nrows), dim3(64), 0, s, P, cells, acc, F, inert);
 }
-void launch_ray_apply(hipStream_t s, const KP& P, Cells cells, AccR* accr, unsigned long long* inert, const OverlapArgs& O) {
-  hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr, inert, O);
+void launch_ray_apply(hipStream_t s, const KP& P, Cells cells, AccR* accr, unsigned long long* inert, const OverlapArgs& O, FrameDev* F) {
+  hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr, inert, O, F);
 }
 #ifndef RAY_BLOCK
 #define RAY_BLOCK 1024
