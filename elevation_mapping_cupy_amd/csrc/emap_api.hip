@@ -183,6 +183,11 @@ struct emap_ctx {
   bool byray_frame;             // the current sharded frame marches its rays by ray
   unsigned int* win_state; unsigned long long* win_bits; float* win_thr; long long* win_dh; unsigned int* win_key; long win_cap;
   hipStream_t comm_stream; hipEvent_t ev_ready, ev_done; double* comm_sums;   // [0..1] local err_sum / err_cnt, [2..3] totals, [4..36) emap_comm_allreduce_host
+  // the un-shifted normal planes after a row shift (normal_exchange): a row-aligned copy of the rows this strip's cells belong to
+  std::vector<int> cut_begin, cut_count;   // every rank's owned PHYSICAL rows (gathered by emap_comm_init)
+  float* nlag_buf; long nlag_cap;          // 3 planes of row_count x cell_n
+  bool nlag_ready;                         // filled for the current frame's visibility pass
+  bool cuts_ok;                            // the gathered strips tile the map
   std::string err;
 };
 
@@ -877,8 +882,11 @@ int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
   const bool sorted = ctx->frame_binned && ctx->bg.raybin;      // the sorted records hold EVERY valid point only with the ray-only bin
   char* const ab = reinterpret_cast<char*>(ctx->accr);
   const AccRView av = {ab + offsetof(AccR, dec), ab + offsetof(AccR, hits), ab + offsetof(AccR, upper_key), (int)sizeof(AccR), (int)sizeof(AccR), (int)sizeof(AccR), 0};
-  launch_rays(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->rt, ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, av,
-              ctx->normal, ctx->ncells_alloc, ctx->frame, ctx->want_ray_stats, ctx->inert, inl, ctx->rays_fused ? 1 : (int)(sizeof(AccF) / 4),
+  KP kr = ctx->kp;
+  kr.nlag = ctx->nlag_ready ? 1 : 0;                     // sharded frame after a row shift: the row-aligned copy of the normal planes (normal_exchange)
+  launch_rays(ctx->stream, kr, make_pose(ctx, R, t), ctx->rt, ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, av,
+              ctx->nlag_ready ? ctx->nlag_buf : ctx->normal, ctx->nlag_ready ? (long)ctx->strip.row_count * ctx->prm.cell_n : ctx->ncells_alloc,
+              ctx->frame, ctx->want_ray_stats, ctx->inert, inl, ctx->rays_fused ? 1 : (int)(sizeof(AccF) / 4),
               ctx->rays_fused ? ctx->ray_thr : nullptr,
               sorted ? reinterpret_cast<const unsigned int*>(ctx->bin_recs) : nullptr,        // march in tile-sorted order
               sorted ? ctx->bin_tile_start + ctx->bg.TB : nullptr);
@@ -1746,6 +1754,22 @@ int emap_comm_init(emap_ctx* ctx, const char* rccl_path, const uint8_t id[128], 
   if (world > 1 && ctx->prm.enable_visibility_cleanup && ctx->win_cap < window_cap(ctx)) {      // rays by ray: see ensure_window
     int rc = alloc_window(ctx, window_cap(ctx)); if (rc) return rc;
   }
+  // every rank's owned physical rows (the strips need not be equally high): who holds which normal rows after a row shift
+  ctx->cut_begin.assign(world, 0); ctx->cut_count.assign(world, 0);
+  ctx->cut_begin[rank] = ctx->strip.row_begin; ctx->cut_count[rank] = ctx->strip.row_count;
+  if (world > 1) {
+    CKARG(world <= 16, "at most 16 ranks");
+    double mine[32], got[32];
+    for (int k = 0; k < 32; ++k) mine[k] = 0.0;
+    mine[2 * rank] = ctx->strip.row_begin; mine[2 * rank + 1] = ctx->strip.row_count;
+    CK(hipMemcpyAsync(ctx->comm_sums + 4, mine, sizeof(double) * 2 * 16, hipMemcpyHostToDevice, ctx->stream));      // ([4..36): the host all-reduce's slots)
+    CKN(a->AllReduce(ctx->comm_sums + 4, ctx->comm_sums + 4, 2 * (size_t)world, ncclFloat64, ncclSum, ctx->comm, ctx->stream));
+    CK(hipMemcpyAsync(got, ctx->comm_sums + 4, sizeof(double) * 2 * world, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    long total = 0;
+    for (int r = 0; r < world; ++r) { ctx->cut_begin[r] = (int)got[2 * r]; ctx->cut_count[r] = (int)got[2 * r + 1]; total += ctx->cut_count[r]; }
+    ctx->cuts_ok = total == ctx->prm.cell_n;               // (checked where the boundaries are needed: normal_exchange)
+  }
   if (world > 1) {
     const double mine[2] = {(double)EMAP_ABI_VERSION, -(double)EMAP_ABI_VERSION};
     double got[2] = {0.0, 0.0};
@@ -1771,6 +1795,7 @@ int emap_comm_destroy(emap_ctx* ctx) {
   if (ctx->ev_ready) hipEventDestroy(ctx->ev_ready);
   if (ctx->ev_done) hipEventDestroy(ctx->ev_done);
   hipFree(ctx->comm_sums); hipFree(ctx->gather_buf); ctx->gather_buf = nullptr;
+  hipFree(ctx->nlag_buf); ctx->nlag_buf = nullptr; ctx->nlag_cap = 0; ctx->nlag_ready = false;
   delete ctx->rccl;
   ctx->rccl = nullptr; ctx->comm = nullptr; ctx->comm_stream = nullptr; ctx->ev_ready = ctx->ev_done = nullptr; ctx->comm_sums = nullptr;
   return EMAP_OK;
@@ -1805,14 +1830,72 @@ static int halo_exchange_start(emap_ctx* ctx) {
   CK(hipEventRecord(ctx->ev_done, ctx->comm_stream));
   return EMAP_OK;
 }
-// After a row shift the un-shifted normal planes (the reference does not roll normal_map) sit `lag` rows away from the cells they
-// belong to: up to halo_rows of them are with a neighbour.  One ring exchange of the planes' boundary rows into their halo rows
-// before the visibility pass restores them (k_rays: local_row of the normal's physical row); beyond halo_rows they read as 0.
-static int normal_exchange(emap_ctx* ctx) {
-  for (int k = 0; k < 3; ++k) {
-    int rc = ring_exchange(ctx, reinterpret_cast<char*>(ctx->normal + (size_t)k * ctx->ncells_alloc), sizeof(float) * (size_t)ctx->prm.cell_n, ctx->stream);
-    if (rc) return rc;
+// After a row shift the un-shifted normal planes (the reference does not roll normal_map, elevation_mapping.py:200-214) sit `lag`
+// rows away from the cells they belong to: the normal of the cell in PHYSICAL row p lives in physical row (p + lag) mod C of the
+// planes -- in this strip, with a neighbour, or (a robot that moved further than a strip is high) with a rank further away.  Before
+// the visibility pass every rank therefore fetches the rows [(row_begin + lag) mod C, + row_count) into a ROW-ALIGNED copy (row j =
+// the normals of owned row j; columns stay at the planes' own origin: normal_index in emap_device.h) from whoever owns them: local
+// pieces by device copies, the others by ONE grouped send / receive.  Every rank derives the same list of pieces from the strips'
+// boundaries (gathered by emap_comm_init) and the lag (a property of the shared origin), walks it in the same order, and so posts its
+// sends and receives in matching order.  Any lag, any strip heights: a strip never reads zeros where the single context reads stale
+// normals (until round 4 only lags up to halo_rows were served, from the planes' halo rows).
+struct LagPiece { int q, r, src, dst, rows; };      // rank q needs physical rows [src, src + rows), owned by rank r, as rows [dst, dst + rows) of its copy
+static void lag_pieces(int C, int W, const int* cut_begin, const int* cut_count, int lag, std::vector<LagPiece>& out) {
+  lag = ((lag % C) + C) % C;
+  for (int q = 0; q < W; ++q) {                               // rank q needs the physical rows [(b_q + lag) mod C, + n_q): <= 2 linear pieces
+    const int b = (cut_begin[q] + lag) % C, nq = cut_count[q];
+    for (int piece = 0; piece < 2; ++piece) {
+      const int p0 = piece == 0 ? b : 0, p1 = piece == 0 ? std::min(C, b + nq) : b + nq - C;      // physical rows [p0, p1)
+      const int d0 = piece == 0 ? 0 : C - b;                                                       // row of q's copy where the piece starts
+      if (p1 <= p0) continue;
+      for (int r = 0; r < W; ++r) {                           // ... cut by the owners of those rows
+        const int o0 = std::max(p0, cut_begin[r]), o1 = std::min(p1, cut_begin[r] + cut_count[r]);
+        if (o1 > o0) out.push_back(LagPiece{q, r, o0, d0 + o0 - p0, o1 - o0});
+      }
+    }
   }
+}
+// the plan as data (CPU property tests: every row of every rank's copy is written exactly once, from the row it belongs to)
+int emap_normal_lag_plan(int32_t cell_n, int32_t world, const int32_t* cut_begin, const int32_t* cut_count, int32_t lag, int32_t* pieces5, int32_t max_pieces, int32_t* n_pieces) {
+  if (!cut_begin || !cut_count || !pieces5 || !n_pieces || cell_n < 1 || world < 1 || max_pieces < 0) return EMAP_ERR_INVALID;
+  std::vector<LagPiece> v;
+  lag_pieces(cell_n, world, cut_begin, cut_count, lag, v);
+  *n_pieces = (int32_t)v.size();
+  if ((long)v.size() > max_pieces) return EMAP_ERR_INVALID;
+  for (size_t k = 0; k < v.size(); ++k) { pieces5[5 * k] = v[k].q; pieces5[5 * k + 1] = v[k].r; pieces5[5 * k + 2] = v[k].src; pieces5[5 * k + 3] = v[k].dst; pieces5[5 * k + 4] = v[k].rows; }
+  return EMAP_OK;
+}
+static int normal_exchange(emap_ctx* ctx) {
+  const int C = ctx->prm.cell_n, W = ctx->comm_world, me = ctx->comm_rank;
+  const long n = ctx->strip.row_count, H = ctx->strip.halo_rows;
+  if (!ctx->cuts_ok) { ctx->err = "normal_exchange: the strips the ranks reported to emap_comm_init do not tile the map"; return EMAP_ERR_COMM; }
+  if ((long)n * C > ctx->nlag_cap) {
+    CK(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->nlag_buf); ctx->nlag_buf = nullptr; ctx->nlag_cap = 0;
+    CK(hipMalloc((void**)&ctx->nlag_buf, sizeof(float) * 3 * (size_t)n * C));
+    ctx->nlag_cap = n * C;
+  }
+  std::vector<LagPiece> plan;
+  lag_pieces(C, W, ctx->cut_begin.data(), ctx->cut_count.data(), normal_row_lag(ctx), plan);
+  const RcclApi* a = ctx->rccl;
+  const size_t rowb = sizeof(float) * (size_t)C;
+  bool grouped = false;
+  for (const LagPiece& pc : plan) {
+    if (pc.q != me && pc.r != me) continue;
+    const size_t bytes = rowb * (size_t)pc.rows;
+    for (int k = 0; k < 3; ++k) {
+      float* dst = ctx->nlag_buf + (size_t)k * n * C + (size_t)pc.dst * C;                                                  // (q == me)
+      const float* src = ctx->normal + (size_t)k * ctx->ncells_alloc + (size_t)(H + pc.src - ctx->strip.row_begin) * C;     // (r == me)
+      if (pc.q == me && pc.r == me) CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      else {
+        if (!grouped) { CKN(a->GroupStart()); grouped = true; }
+        if (pc.q == me) CKN(a->Recv(dst, bytes, ncclChar, pc.r, ctx->comm, ctx->stream));
+        else CKN(a->Send(src, bytes, ncclChar, pc.q, ctx->comm, ctx->stream));
+      }
+    }
+  }
+  if (grouped) CKN(a->GroupEnd());
+  ctx->nlag_ready = true;
   return EMAP_OK;
 }
 
@@ -1883,7 +1966,10 @@ static int rays_by_ray_pass(emap_ctx* ctx, const float R[9], const float t[3]) {
   hipStream_t st = ctx->stream;
   // (1) the window's cells, normals and inlier counts: owners fill their rows, an exact integer all-reduce replicates them
   CK(hipMemsetAsync(ctx->win_state, 0, sizeof(unsigned int) * 12 * (size_t)n, st));
-  launch_win_pack(st, ctx->kp, w, ctx->cells, ctx->normal, ctx->ncells_alloc, ctx->inl_plane, ctx->inert);
+  KP kpk = ctx->kp;
+  kpk.nlag = ctx->nlag_ready ? 1 : 0;
+  launch_win_pack(st, kpk, w, ctx->cells, ctx->nlag_ready ? ctx->nlag_buf : ctx->normal, ctx->nlag_ready ? (long)ctx->strip.row_count * ctx->prm.cell_n : ctx->ncells_alloc,
+                  ctx->inl_plane, ctx->inert);
   CK(hipGetLastError());
   CKN(a->AllReduce(ctx->win_state, ctx->win_state, 12 * (size_t)n, ncclUint32, ncclSum, ctx->comm, st));
   // (2) bitmap + block thresholds of the window, accumulators re-armed
@@ -1949,9 +2035,9 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   if (rays_on) {
     if (!fused_avg && (rc = emap_commit(ctx))) return rc;
     STAGE(ST_RAYS);
-    if (ctx->comm_world > 1 && normal_row_lag(ctx) != 0 && (rc = normal_exchange(ctx))) { ctx->rays_fused = false; ctx->byray_frame = false; return rc; }
+    if (ctx->comm_world > 1 && normal_row_lag(ctx) != 0 && (rc = normal_exchange(ctx))) { ctx->rays_fused = false; ctx->byray_frame = false; ctx->nlag_ready = false; return rc; }
     rc = ctx->byray_frame ? rays_by_ray_pass(ctx, R, t) : emap_rays(ctx, R, t);
-    ctx->byray_frame = false;
+    ctx->byray_frame = false; ctx->nlag_ready = false;
     if (rc) { ctx->rays_fused = false; return rc; }
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);

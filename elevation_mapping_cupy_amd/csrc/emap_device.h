@@ -91,6 +91,9 @@ struct KP {
   // every map / strip context; the RAY WINDOW of a multi-GPU frame (rays marched by ray owner, emap_api.hip: rays_by_ray) is a small
   // rectangle of the map in logical coordinates with its own pitch (wmode = 1: normals are addressed like the cells)
   int col0, ncols, pitch, wmode;
+  // row strips after a ROW shift: the normal planes handed to k_rays / k_win_pack are a row-aligned copy (emap_api.hip:
+  // normal_exchange) -- row j holds the normals that belong to the cells of owned row j, columns still at the planes' own origin
+  int nlag, pad_nl_;
   // circular origin: logical cell (r, c) lives at physical row (r + org_r) mod C, column (c + org_c) mod C; row0 / nrows / halo
   // describe PHYSICAL rows (a strip keeps its rows when the map shifts).  norg_*: origin the stencil outputs (normal planes,
   // traversability_input) were written with -- the reference does not shift those (elevation_mapping.py:200-214).
@@ -218,6 +221,15 @@ __device__ __forceinline__ long owned_cell(const KP& P, int ix, int iy) {
   int rel = phys_row(P, ix) - P.row0;
   if (rel < 0 || rel >= P.nrows) return -1;
   return (long)(rel + P.halo) * P.C + phys_col(P, iy);
+}
+
+// Index of the normal of LOGICAL cell (lix, liy) in the normal planes, or -1 if this context does not hold it.  The planes keep the
+// origin they were written with (the reference does not shift normal_map, elevation_mapping.py:200-214): logical -> THEIR rows and
+// columns.  lrow = the cell's owned row (physical row - row0), only used for the row-aligned copy of a strip (KP::nlag).
+__device__ __forceinline__ long normal_index(const KP& P, int lrow, int lix, int liy) {
+  if (P.nlag) return (long)lrow * P.C + wrap_up(liy + P.norg_c, P.C);
+  const int nlr = local_row(P, wrap_up(lix + P.norg_r, P.C));
+  return nlr < 0 ? -1 : (long)nlr * P.C + wrap_up(liy + P.norg_c, P.C);
 }
 
 // row of the inert bitmap for physical row prow: the logical row on single-strip contexts, else the local (physical) row

@@ -389,8 +389,8 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
             float n0 = 0.f, n1 = 0.f, n2 = 0.f;
             if (P.wmode) { n0 = normal[c]; n1 = normal[plane_stride + c]; n2 = normal[2 * plane_stride + c]; }      // (uniform) ray window: the planes were gathered cell by cell
             else {
-              const int nlr = local_row(P, wrap_up(lix + P.norg_r, C));
-              if (nlr >= 0) { const long cn = (long)nlr * C + wrap_up(liy + P.norg_c, C); n0 = normal[cn]; n1 = normal[plane_stride + cn]; n2 = normal[2 * plane_stride + cn]; }
+              const long cn = normal_index(P, (int)lrow, lix, liy);
+              if (cn >= 0) { n0 = normal[cn]; n1 = normal[plane_stride + cn]; n2 = normal[2 * plane_stride + cn]; }
             }
             const float ip = erx * Qf<MODE>(n0) + ery * Qf<MODE>(n1) + erz * Qf<MODE>(n2);
             if (!(fabsf(ip) < Rt.f_cos_thresh)) {
@@ -659,8 +659,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_win_pack(KP P, Win W, Cells cells,
   W.hot[k] = h;
   W.cold[k] = make_float4(cd.x, cd.y, cd.z, quiet);
   float n0 = 0.f, n1 = 0.f, n2 = 0.f;                                       // the normal planes keep the origin they were written with (k_rays)
-  const int nlr = local_row(P, wrap_up(lr + P.norg_r, P.C));
-  if (nlr >= 0) { const long cn = (long)nlr * P.C + wrap_up(lc + P.norg_c, P.C); n0 = normal[cn]; n1 = normal[plane_stride + cn]; n2 = normal[2 * plane_stride + cn]; }
+  const long cn = normal_index(P, rel, lr, lc);
+  if (cn >= 0) { n0 = normal[cn]; n1 = normal[plane_stride + cn]; n2 = normal[2 * plane_stride + cn]; }
   const long wn = (long)W.nr * W.nc;
   W.normal[k] = n0; W.normal[wn + k] = n1; W.normal[2 * wn + k] = n2;
   W.inl[k] = inl_plane[c];
@@ -1179,8 +1179,11 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
 // LDS contents, hole search and epilogue are k_post's: bit-identical planes.  d <= 5 (RH <= 48 = 8 waves x 6 rows, <= 1024 extra cells).
 // ---------------------------------------------------------------------------------------------------------
 struct PostTile { int tile_r, tile_c, seg_e, rowT, interior; };
+#ifndef POST_PIPE_OCC
+#define POST_PIPE_OCC 4     /* waves per SIMD the register budget is set for: 4 = two workgroups per CU, 6 = three (A/B knob) */
+#endif
 template <int STAGE>
-__global__ __launch_bounds__(512, 4) void k_post_pipe(KP P, TravW Wt, Cells cells, float* __restrict__ trav_in,
+__global__ __launch_bounds__(512, POST_PIPE_OCC) void k_post_pipe(KP P, TravW Wt, Cells cells, float* __restrict__ trav_in,
                                                    float* __restrict__ normal, long plane_stride, int d, PostSegs S, int tiles_x, int n_tiles) {
   constexpr int PT_R = 32, PT_THREADS = 512, PT_WAVES = PT_THREADS / 64, U = 6, EU = 2;
   extern __shared__ float lds[];
@@ -1233,8 +1236,13 @@ __global__ __launch_bounds__(512, 4) void k_post_pipe(KP P, TravW Wt, Cells cell
   };
   int t = blockIdx.x;
   PostTile cur = make_tile(t);
+#ifndef POST_PIPE_NOPREFETCH
   issue(cur);
+#endif
   for (int it = 0;; ++it) {
+#ifdef POST_PIPE_NOPREFETCH
+    issue(cur);                                                       // (A/B: persistent workgroups WITHOUT the loads in flight under the epilogue)
+#endif
     unsigned int* n_holes = &n_holes2[it & 1];
     const int tile_r = cur.tile_r, tile_c = cur.tile_c;
     const int c0 = tile_c - 3 - d;
@@ -1318,7 +1326,9 @@ __global__ __launch_bounds__(512, 4) void k_post_pipe(KP P, TravW Wt, Cells cell
     const int tn = t + (int)gridDim.x;
     const bool has_next = tn < n_tiles;                               // (uniform)
     const PostTile nxt = make_tile(has_next ? tn : t);               // (the last tile re-requests itself: no branch around the loads)
+#ifndef POST_PIPE_NOPREFETCH
     issue(nxt);
+#endif
     const int col = tile_c + tc;
     if (col < C) {
       const int pcol = phys_col(P, col);
@@ -1607,7 +1617,7 @@ static int device_cus() {
 static int post_pipe_grid() {
   const char* e = getenv("EMAP_POST_PIPE_GRID");
   const int v = e ? atoi(e) : 0;
-  return v >= 1 && v <= 65535 ? v : 2 * device_cus();
+  return v >= 1 && v <= 65535 ? v : (POST_PIPE_OCC / 2) * device_cus();
 }
 static bool post_use_pipe(const KP& P, int d, long tiles) {
   const char* e = getenv("EMAP_POST_PIPE");

@@ -418,7 +418,14 @@ class ShardedElevationMap:
             e.fuse(R, t)
             e.commit()
             if c.world > 1 and hasattr(e, "normal_row_lag") and e.normal_row_lag() != 0:
-                # a row shift since the last frame: the un-shifted normal planes sit `lag` rows off -- fetch the neighbours' rows
+                # a row shift since the last frame: the un-shifted normal planes sit `lag` rows off -- fetch the neighbours' rows.
+                # This Python-driven fallback only moves the planes' halo rows; a larger shift needs rows from beyond them, which the
+                # library's own frame fetches from whoever owns them (emap_update_sharded: normal_exchange).  Refuse instead of
+                # marching the rays over zeros.
+                if abs(e.normal_row_lag()) > getattr(e, "halo", 0):
+                    from ._lib import EmapError
+                    raise EmapError("the map moved %d rows since the normals were written, more than the %d halo rows this fallback exchanges: "
+                                    "use the native communicator (emap_comm_init + emap_update_sharded)" % (abs(e.normal_row_lag()), getattr(e, "halo", 0)))
                 n_lo, n_hi, q_lo, q_hi = e.normal_halo_pack()
                 c.exchange_wait(c.exchange_start(n_lo, n_hi, q_lo, q_hi))
                 e.normal_halo_unpack()

@@ -276,6 +276,12 @@ int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf);
 int emap_normal_row_lag(emap_ctx* ctx, int32_t* lag);
 int emap_normal_halo_pack(emap_ctx* ctx, int side, float* dev_buf);
 int emap_normal_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf);
+/* Row strips after a ROW shift of more than halo_rows: which rank's normal rows each rank's cells belong to (emap_update_sharded
+ * fetches them itself, emap_api.hip: normal_exchange; EM/elevation_mapping.py:200-214 -- normal_map is not shifted with the map).  Pure
+ * host arithmetic, exposed for tests and for callers that drive the exchange themselves: rank q needs physical rows [src, src + rows),
+ * owned by rank r, as rows [dst, dst + rows) of its row-aligned copy; pieces5 = {q, r, src, dst, rows} per piece, in posting order. */
+int emap_normal_lag_plan(int32_t cell_n, int32_t world, const int32_t* cut_begin, const int32_t* cut_count, int32_t lag,
+                         int32_t* pieces5, int32_t max_pieces, int32_t* n_pieces);
 
 /* ---- row-strip communicator: one process per GPU, RCCL over xGMI issued from the library itself -------------
  * Nothing like it exists in the reference (single GPU).  `rccl_path` names the RCCL shared object to dlopen (NULL =

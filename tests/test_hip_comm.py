@@ -209,3 +209,23 @@ def test_rays_by_ray_reproduce_the_single_context(world, cfg_name, C, N, moves, 
     MV = [(0.13, -0.3, 0.05), (-0.10, 0.17, -0.02), None] if moves else [None] * 3
     frames = [(fx.cloud(C, N, f, dz=dz), R, t + np.array([0.4 * f, -0.3 * f, 0], np.float32), 1.0, 1.0, 6, mv) for (f, dz), mv in zip(enumerate((0.0, -0.02, -0.1)), MV)]
     _strips_vs_single(world, cfg, C, frames, "binned", weights, mode=mode, stand_in=stand_in, ray_mode="by_ray")
+
+
+@pytest.mark.parametrize("world,ray_mode,stand_in", [(2, "by_row", "blocking"), (2, "by_ray", "stream"), (4, "by_row", "stream"), (4, "by_ray", "blocking"),
+                                                      (8, "by_row", "blocking"), (8, "by_ray", "stream"), (3, "by_ray", "blocking"), (5, "by_row", "stream")])
+def test_strips_after_large_map_moves(world, ray_mode, stand_in, weights):
+    """A robot that moves FAST: move_to of 20-45 rows between the frames (0.8-1.8 m at 10 Hz), more than halo_rows (7) and -- on 8
+    ranks of a 300-row map -- more than a strip is high (37 rows).  The normal planes are not shifted with the map (reference
+    elevation_mapping.py:200-214: normal_map stays), so after the move the visibility pass of the next frame reads, for every cell, the
+    STALE normal at the cell's old index (custom_kernels.py:243-246) -- rows that a strip does not hold any more.  Until round 4 a
+    strip read zeros there (a documented deviation); now every rank fetches the rows its cells belong to from whoever owns them
+    (emap_api.hip: normal_exchange): strips == single context, bit for bit, by row and by ray."""
+    from oracle import emap_oracle as eo
+    cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML)
+    cfg["enable_visibility_cleanup"] = True
+    C, N = 300, 60000
+    R, t = fx.POSES["rotated"]
+    MV = [(1.2, -0.5, 0.0), (-0.6, 0.3, 0.02), (0.8, 1.1, 0.0), None]           # cumulative targets: +30, -45, +35 rows (and column shifts)
+    frames = [(fx.cloud(C, N, 30 + f, dz=dz), R, t + np.array([0.2 * f, -0.1 * f, 0], np.float32), 1.0, 1.0, 6, mv)
+              for (f, dz), mv in zip(enumerate((0.0, -0.02, -0.06, -0.1)), MV)]
+    _strips_vs_single(world, cfg, C, frames, "binned", weights, stand_in=stand_in, ray_mode=ray_mode)
