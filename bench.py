@@ -612,6 +612,17 @@ def run_single(a, local_rank=0):
             wallb, msb, loopsb = timed(emb, frb, kb, loops=3)
             latb = latencies(emb, frb, 10)
             stb, visb = stage_profile(lb, cb, frb, 6, with_stats=not mm)
+            if mm:       # the 11th stage: the RGB / semantic fusion (k_tile_semantic) -- a call of its own behind emap_update, timed by an event pair
+                acc_s, e_ms = 0.0, ct.c_float(0)
+                for i_ in range(6):
+                    rc = bind_cloud(lb, cb, devb[i_ % len(devb)], Nb) or lb.emap_update(cb, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), None)
+                    lb.emap_timer_begin(cb)
+                    rc = rc or lb.emap_semantic_update(cb, Rp, tp, ct.byref(specb))
+                    lb.emap_timer_end(cb, ct.byref(e_ms))
+                    if rc:
+                        raise RuntimeError(lb.emap_last_error(cb).decode())
+                    acc_s += e_ms.value
+                sem_stage_ms = acc_s / 6
             Lb = Cb * Cb
             fbytes = 12 * Nb + 56 * Lb + (16 * Nb + 32 * Lb if mm else 0)
             rb = roofline(stb, ev_overhead, Nb, Lb, name, fbytes, msb / kb, visb, False)
@@ -619,9 +630,9 @@ def run_single(a, local_rank=0):
                            "value": round(Nb * kb / wallb / 1e6, 2), "unit": "Mpoints/s", "ms_per_step": round(wallb * 1e3 / kb, 5),
                            "timed_loops_ms_per_step": loopsb, "latency_ms": {"p10": round(latb[0], 4), "p50": round(latb[1], 4), "p90": round(latb[2], 4)},
                            "dominant_kernel": rb["kernel"], "kernel_ms": rb["kernel_ms"], "frac": rb["frac"], "frame_frac": rb["frame_frac"],
-                           "ray_visits_per_s": rb["ray_visits_per_s"], "stage_ms": rb["stage_ms"],
-                           "note": ("stage_ms does not hold the RGB / semantic fusion (k_tile_semantic runs behind the frame's stages; "
-                                    "ms_per_step does); cloud bound de-interleaved: (N, 3) xyz + (N, 4) channels, as emap_upload_points leaves an uploaded cloud" if mm else None)}
+                           "ray_visits_per_s": rb["ray_visits_per_s"], "stage_ms": (dict(rb["stage_ms"], semantic=round(sem_stage_ms, 5)) if mm else rb["stage_ms"]),
+                           "note": ("stage_ms.semantic = the RGB / semantic fusion (k_tile_semantic: a call of its own behind the frame's ten stages, inside "
+                                    "ms_per_step); cloud bound de-interleaved: (N, 3) xyz + (N, 4) channels, as emap_upload_points leaves an uploaded cloud" if mm else None)}
             emb.close()
             free_clouds(hip, devb)
 
@@ -645,9 +656,10 @@ def run_single(a, local_rank=0):
             dt_ms = (time.perf_counter() - t0) * 1e3 / k_in
             bound_ms = bpp * N / (gbs * 1e9) * 1e3
             h2d[name] = {"ms_per_frame": round(dt_ms, 4), "Mpoints_s": round(N / dt_ms / 1e3, 1), "pcie_bound_ms": round(bound_ms, 4),
-                         "frac_of_pcie_bound_rate": round(bound_ms / dt_ms, 3)}
+                         "rate_vs_plain_pinned_copy": round(bound_ms / dt_ms, 3)}
         h2d["note"] = ("input_pointcloud(host cloud): frames per second through the reference's entry point; pcie_bound_ms = the time a plain "
-                       "pinned hipMemcpy of the caller's bytes (24 / 12 per point) takes at pinned_h2d_GBs")
+                       "pinned hipMemcpy of the caller's bytes (24 / 12 per point) takes at pinned_h2d_GBs; rate_vs_plain_pinned_copy = "
+                       "pcie_bound_ms / ms_per_frame (> 1 for float64 clouds: the upload casts on the host and moves 12 bytes per point, not 24)")
 
     if a.workload in ("cfg3", "cfg4"):
         config_cold = cold_start(emap, frame)
@@ -681,31 +693,89 @@ def run_single(a, local_rank=0):
 
 
 # -------------------------------------------------------------------------------------------------------------------------------
-def run_strips_native(a, rank, world, local_rank, rdv):
-    """one row strip per rank, both exchange steps issued by the C library over RCCL; no torch in the process.
-    Returns (False, None) -- on every rank alike -- when the native communicator cannot be used, so that the caller can fall
-    back, else (True, the JSON object on rank 0)."""
-    from elevation_mapping_cupy_amd import _lib, launch, sharded
+def _sem_spec():
+    """RGB (packed 24 bit, colour fusion) + three averaged semantic channels: the multi-modal layers of BASELINE configs[4]"""
+    from elevation_mapping_cupy_amd import _lib
+    spec = _lib.EmapSemSpec()
+    spec.n_col, spec.col_chan[0], spec.col_layer[0] = 1, 3, 0
+    spec.n_sum = 3
+    for k_ in range(3):
+        spec.sum_chan[k_], spec.sum_layer[k_], spec.sum_kind[k_] = 4 + k_, 1 + k_, 0
+    spec.alpha = 0.5
+    return spec
+
+
+def single_frame_ms(a, wl, hip, dev, C, N, frames=6, loops=3):
+    """the SAME-BOX N = 1 denominator of a sharded sub-measurement: workload `wl` on one whole-map context of this device, median of
+    `loops` timed loops of `frames` frames (ms per frame) -- run by rank 0 while the other ranks wait at a file barrier"""
+    import copy
+    from elevation_mapping_cupy_amd import _lib
     from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
     from elevation_mapping_cupy_amd.configs import parameter_from
+    b = copy.copy(a); b.workload = wl
+    mode = "fp32" if C > 2049 else a.mode
+    mm = wl == "cfg5"
+    par = parameter_from(workload_cfg(wl), C, mode, load_weights()); par.device = dev
+    em = ElevationMap(par); em.set_scatter_mode(a.scatter)
+    lib, ctx = em._lib, em._ctx
+    host = host_clouds(b, C, N, mm)[:2]
+    devc = device_clouds(hip, host, True)
+    del host
+    spec = None
+    if mm:
+        spec = _sem_spec()
+        if lib.emap_semantic_configure(ctx, 4):
+            raise RuntimeError(lib.emap_last_error(ctx).decode())
+    R = np.eye(3, dtype=np.float32).ravel().copy(); t = np.array([0, 0, 1], np.float32)
+    Rp, tp = _lib.f32p(R), _lib.f32p(t)
 
-    ndev = launch.device_count()
-    if not rdv.agree("devices", ndev >= world or os.environ.get("EMAP_RCCL_LIB")):     # RCCL refuses two ranks on one device
-        return False, None
-    dev = local_rank % max(1, ndev)
-    cfg = workload_cfg(a.workload)
-    C, N = a.cell_n, a.points
-    multimodal = a.workload == "cfg5"
-    if multimodal and C > 2049:
-        a.mode = "fp32"
+    def fr(i):
+        rc = bind_cloud(lib, ctx, devc[i % len(devc)], N)
+        rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), None)
+        if mm:
+            rc = rc or lib.emap_semantic_update(ctx, Rp, tp, ct.byref(spec))
+        if rc:
+            raise RuntimeError(lib.emap_last_error(ctx).decode())
+    for i in range(3):
+        fr(i)
+        for _ in range(4):
+            em.update_time()
+    em.update_variance()
+    for i in range(2):
+        fr(i)
+    res = []
+    for _ in range(loops):
+        em.sync(); t0 = time.perf_counter()
+        for i in range(frames):
+            fr(i)
+        em.sync(); res.append((time.perf_counter() - t0) * 1e3 / frames)
+    em.close(); free_clouds(hip, devc)
+    return round(sorted(res)[len(res) // 2], 5)
+
+
+def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag, hip):
+    """Workload `wl` on `world` row strips, one per rank: a strip context, its own RCCL communicator (both exchange steps issued by the
+    C library, emap_update_sharded), warm-up, a timed region of exactly `steps` frames (barrier + device sync on both sides, MAX over
+    the ranks), per-frame latency and the per-stage device times of every rank -- the RGB / semantic fusion of a multi-modal frame
+    INSIDE the timed frame and as an 11th stage ("semantic").  Returns None -- on every rank alike -- when the native communicator
+    cannot be used, else a record (complete on rank 0)."""
+    from elevation_mapping_cupy_amd import _lib, sharded
+    from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
+    from elevation_mapping_cupy_amd.configs import parameter_from
+    import copy
+    b = copy.copy(a); b.workload = wl
+    cfg = workload_cfg(wl)
+    multimodal = wl == "cfg5"
+    mode = "fp32" if C > 2049 else a.mode
     weights = load_weights()
-    par = parameter_from(cfg, C, a.mode, weights, device=dev)
+    par = parameter_from(cfg, C, mode, weights, device=dev)
     halo = sharded.halo_rows_needed(par.dilation_size, world)
+    rays = bool(cfg["enable_visibility_cleanup"])
     row_w = None
     # (a frame that marches its rays BY RAY wants equal heights: the library's predicate, not the map size alone)
     ray_mode = {"auto": 0, "by_row": 1, "by_ray": 2}.get(os.environ.get("EMAP_RAY_MODE", "auto"), 0)
-    by_ray = sharded.frame_marches_by_ray(C, N, world, "native", ray_mode, a.scatter)
-    if cfg["enable_visibility_cleanup"] and world > 1 and not by_ray and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
+    by_ray = rays and sharded.frame_marches_by_ray(C, N, world, "native", ray_mode, a.scatter)
+    if rays and world > 1 and not by_ray and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
         row_w = sharded.ray_balanced_weights(C, float(cfg["resolution"]), float(cfg["max_ray_length"]), halo, world)
     r0, r1 = sharded.strip_rows(C, world, rank, row_w)
     ok, emap, err = True, None, ""
@@ -718,30 +788,33 @@ def run_strips_native(a, rank, world, local_rank, rdv):
             emap.set_ray_mode(os.environ["EMAP_RAY_MODE"])       # (A/B knob: "by_row" / "by_ray" on every rank)
     except Exception as ex:  # noqa: BLE001
         ok, err = False, str(ex)
-    if not rdv.agree("create", ok):
+    if not rdv.agree(tag + "create", ok):
         if err:
             print("[rank %d] strip context failed: %s" % (rank, err), file=sys.stderr)
-        return False, None
+        if emap is not None:
+            emap.close()
+        return None
     lib, ctx = emap._lib, emap._ctx
     path = sharded.rccl_library_path().encode()
     uid = (ct.c_uint8 * 128)()
-    ok = True
     if rank == 0:
         ok = lib.emap_comm_unique_id(path, uid) == 0
-        rdv.publish("uid", bytes(uid) if ok else b"")
-    blob = rdv.fetch("uid", 0)
-    if not rdv.agree("uid", len(blob) == 128):
-        return False, None
+        rdv.publish(tag + "uid", bytes(uid) if ok else b"")
+    blob = rdv.fetch(tag + "uid", 0)
+    if not rdv.agree(tag + "uid", len(blob) == 128):
+        emap.close()
+        return None
     uid = (ct.c_uint8 * 128).from_buffer_copy(blob)
     ok = lib.emap_comm_init(ctx, path, uid, rank, world) == 0
     if not ok:
         print("[rank %d] emap_comm_init: %s" % (rank, lib.emap_last_error(ctx).decode()), file=sys.stderr)
-    if not rdv.agree("init", ok):
-        return False, None
+    if not rdv.agree(tag + "init", ok):
+        emap.close()
+        return None
     ok = lib.emap_comm_selftest(ctx) == 0
-    if not rdv.agree("selftest", ok):
-        lib.emap_comm_destroy(ctx)
-        return False, None
+    if not rdv.agree(tag + "selftest", ok):
+        lib.emap_comm_destroy(ctx); emap.close()
+        return None
 
     nr = ct.c_int32(0)
     rccl_ranks = int(nr.value) if lib.emap_comm_count(ctx, ct.byref(nr)) == 0 and nr.value else None    # ncclCommCount of the live communicator
@@ -755,8 +828,7 @@ def run_strips_native(a, rank, world, local_rank, rdv):
     def barrier():
         reduce([0.0], 0)
 
-    hip = Hip(); hip.set_device(dev)
-    clouds_host = host_clouds(a, C, N, multimodal)
+    clouds_host = host_clouds(b, C, N, multimodal)
     NCLOUD = len(clouds_host)
     channels = None
     if multimodal:
@@ -767,26 +839,31 @@ def run_strips_native(a, rank, world, local_rank, rdv):
     R = np.eye(3, dtype=np.float32).ravel().copy()
     t = np.array([0, 0, 1], np.float32)
     Rp, tp = _lib.f32p(R), _lib.f32p(t)
+    sem_ms = ct.c_float(0)
 
-    def frame(i, stats=None):
+    def frame(i, stats=None, time_sem=False):
         rc = bind_cloud(lib, ctx, clouds_dev[i % NCLOUD], N)
         rc = rc or lib.emap_update_sharded(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
         if rc:
             raise RuntimeError(lib.emap_last_error(ctx).decode())
-        if multimodal:
+        if multimodal:                  # per strip, no exchange step: part of the frame (and of the timed region)
+            if time_sem:
+                lib.emap_timer_begin(ctx)
             emap.semantic_map.update_layers_pointcloud(emap, channels, R, t)
+            if time_sem:
+                lib.emap_timer_end(ctx, ct.byref(sem_ms))
 
     for i in range(3):
         frame(i)
         for _ in range(4):
             emap.update_time()
     emap.update_variance()
-    for i in range(a.warmup):
+    for i in range(warmup):
         frame(i)
     emap.sync(); barrier()
     # ---- timed region: barrier + device sync on both sides, MAX over ranks ------------------------------------------------
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    for i in range(steps):
         frame(i)
     emap.sync()
     wall_local = time.perf_counter() - t0
@@ -794,49 +871,121 @@ def run_strips_native(a, rank, world, local_rank, rdv):
     wall = reduce([wall_local], 1)[0]
     # ---- per-frame latency: every frame synchronised on every rank (the collectives keep the ranks in step); max over ranks --------
     lat = []
-    for i in range(min(a.steps, 40)):
+    for i in range(min(steps, 40)):
         emap.sync()
         t1 = time.perf_counter(); frame(i); emap.sync(); lat.append((time.perf_counter() - t1) * 1e3)
     pct = reduce([float(x) for x in np.percentile(lat, [10, 50, 90])], 1)
     # ---- per-stage device time of every rank's strip ------------------------------------------------------------------------------
-    stage_ms, _ = stage_profile(lib, ctx, frame, min(a.steps, 20), with_stats=False)
+    reps = min(steps, 20)
+    stage_ms, _ = stage_profile(lib, ctx, frame, reps, with_stats=False)
+    if multimodal:                      # the 11th stage: the RGB / semantic fusion of the strip (event pair around the call)
+        acc = 0.0
+        for i in range(reps):
+            frame(i, None, True); acc += sem_ms.value
+        stage_ms["semantic"] = acc / reps
     ev_overhead = event_overhead(lib, ctx)
     emap.sync(); barrier()
-    all_stage = rdv.gather_json("stage_ms", {k: round(v, 5) for k, v in stage_ms.items()})
-    rows = rdv.gather_json("rows", [int(r0), int(r1)])
-    out = None
+    all_stage = rdv.gather_json(tag + "stage_ms", {k: round(v, 5) for k, v in stage_ms.items()})
+    rows = rdv.gather_json(tag + "rows", [int(r0), int(r1)])
+    rec = {"ok": True, "wall": wall, "stage_ms": stage_ms, "clouds_host": clouds_host, "cfg": cfg, "weights": weights, "R": R, "t": t}
     if rank == 0:
-        # algorithmic bytes of a strip: every rank reads the whole replicated cloud, but sorts / fuses only the points of its
-        # rows (N / world for uniform clouds) and streams only its L / world cells
-        Nw, Lw = N / world, C * C / world
-        sb = {"hist": 28 * N, "scan": 0, "scatter": 16 * N + 32 * Nw, "gate": 0, "fuse": 24 * Nw + 64 * Lw, "commit": 104 * Lw,
-              "rays": 12 * N + 48 * Lw, "average": 120 * Lw, "overlap": 0, "post": 40 * Lw}
         L = C * C
+        sb = sharded.strip_stage_bytes(N, L, world, full_sort=rays and not by_ray)
+        if multimodal:
+            sb["semantic"] = (16 * N + 32 * L) / world        # 4 channels x 4 B per point, 4 layers x (read + write) per cell of the strip
         frame_bytes = 12 * N + 56 * L + (16 * N + 32 * L if multimodal else 0)
-        roof = roofline(stage_ms, ev_overhead, N, L, a.workload, frame_bytes, wall * 1e3 / a.steps, 0, False, stage_bytes=sb)
+        roof = roofline({k: v for k, v in stage_ms.items() if k != "semantic"}, ev_overhead, N, L, wl, frame_bytes, wall * 1e3 / steps, 0, False,
+                        stage_bytes={k: v for k, v in sb.items() if k != "semantic"})
         roof["rank"] = 0
         roof["per_rank_stage_ms"] = all_stage
-        roof["note"] = "rank 0's strip; 'gate' includes the all-reduce, 'post' the halo exchange overlapped with the interior stencils"
-        cpu = None
-        if not a.no_cpu_baseline and not multimodal:
-            cpu = cpu_baseline(a, cfg, C, N, clouds_host, weights, R, t)
-        out = {
-            "metric": "Mpoints/s fused (map-update p50 latency in config)", "value": round(N * a.steps / wall / 1e6, 2),
-            "unit": "Mpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(wall * 1e3 / a.steps, 5), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_text(a, C, N, multimodal) + "; %d row strips, cloud replicated to every rank" % world,
-                       "index_mode": a.mode, "latency_ms": {"p10": round(pct[0], 4), "p50": round(pct[1], 4), "p90": round(pct[2], 4)},
+        roof["note"] = ("rank 0's strip; 'gate' includes the all-reduce, 'post' the halo exchange overlapped with the interior stencils" +
+                        ("; 'semantic' = the strip's RGB / semantic fusion (inside the timed frame)" if multimodal else ""))
+        rec.update({
+            "value": round(N * steps / wall / 1e6, 2), "ms_per_step": round(wall * 1e3 / steps, 5), "roofline": roof,
+            "config": {"workload": workload_text(b, C, N, multimodal) + "; %d row strips, cloud replicated to every rank" % world,
+                       "index_mode": mode, "latency_ms": {"p10": round(pct[0], 4), "p50": round(pct[1], 4), "p90": round(pct[2], 4)},
                        "halo_rows": halo, "parallelism": "row-strips x%d" % world, "ranks": world, "rccl_ranks": rccl_ranks,
                        "physical_devices": min(ndev, world),
                        "strip_rows": rows, "strip_heights": "equal ray work (thin around the sensor)" if row_w is not None else "equal",
+                       "rays": ("by ray over an all-reduced window" if by_ray else "by row") if rays else "off",
                        "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame, RCCL issued by the C library "
                                       "(halo exchange in place on a second stream); bootstrap: file rendezvous, no torch",
-                       "cloud": "device resident (H2D excluded)"},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "cloud": "device resident (H2D excluded)"}})
+    rdv.barrier(tag + "measured")
+    lib.emap_comm_destroy(ctx)
+    emap.close()
+    free_clouds(hip, clouds_dev)
+    return rec
+
+
+def strips_plan(a):
+    """what `bench.py --gpus N` measures, in order: the workload asked for (the line's `value`: default cfg2 = BASELINE configs[1], the
+    metric's configuration) and -- on the default line -- the two configurations north_star's scaling target names, as sharded
+    sub-measurements with a same-box N = 1 run beside each.  EMAP_BENCH_SUB_SIZES="cfg5:1024:300000,cfg4:1024:300000" (test hook)
+    shrinks the sub-measurements."""
+    plan = [{"key": None, "tag": "main_", "workload": a.workload, "cell_n": a.cell_n, "points": a.points, "steps": a.steps, "warmup": a.warmup, "n1": False}]
+    if a.workload == "cfg2" and not a.no_large and a.cell_n == 1024 and a.points == 1_000_000:
+        sizes = {"cfg5": (8192, 16_000_000), "cfg4": (4096, 4_000_000)}
+        for item in filter(None, os.environ.get("EMAP_BENCH_SUB_SIZES", "").split(",")):
+            k_, c_, n_ = item.split(":"); sizes[k_] = (int(c_), int(n_))
+        for wl in ("cfg5", "cfg4"):
+            plan.append({"key": wl, "tag": wl + "_", "workload": wl, "cell_n": sizes[wl][0], "points": sizes[wl][1], "steps": min(a.steps, 10), "warmup": 2, "n1": True})
+    return plan
+
+
+def run_strips_native(a, rank, world, local_rank, rdv):
+    """one row strip per rank, both exchange steps issued by the C library over RCCL; no torch in the process.
+    Returns (False, None) -- on every rank alike -- when the native communicator cannot be used, so that the caller can fall
+    back, else (True, the JSON object on rank 0).
+    `value` / `ms_per_step` = the workload asked for (default cfg2 = BASELINE configs[1]: the metric's configuration).  The default
+    line additionally carries what north_star's scaling target names -- `config.cfg5` (configs[4]: 8192^2 multi-modal map, 16 M points,
+    semantic fusion inside the timed frame) and `config.cfg4` (configs[3]: 4096^2, 4 M points, rays + overlap) on the SAME N strips,
+    each with the same-box N = 1 time beside it (`n1_ms_per_step`, `speedup_vs_n1`): the 1024^2 frame is seven launches of 5-20 us
+    and does not strong-scale, the large maps are where the strips are for."""
+    from elevation_mapping_cupy_amd import launch
+    ndev = launch.device_count()
+    if not rdv.agree("devices", ndev >= world or os.environ.get("EMAP_RCCL_LIB")):     # RCCL refuses two ranks on one device
+        return False, None
+    dev = local_rank % max(1, ndev)
+    hip = Hip(); hip.set_device(dev)
+    C, N = a.cell_n, a.points
+    plan = strips_plan(a)
+    main = strips_workload(a, a.workload, C, N, a.steps, a.warmup, rank, world, dev, ndev, rdv, plan[0]["tag"], hip)
+    if main is None:
+        return False, None
+    subs = {}
+    for item in plan[1:]:
+            wl = item["key"]
+            rec = strips_workload(a, wl, item["cell_n"], item["points"], item["steps"], item["warmup"], rank, world, dev, ndev, rdv, item["tag"], hip)
+            n1 = None
+            if rec is not None and rank == 0:
+                try:
+                    n1 = single_frame_ms(a, wl, hip, dev, item["cell_n"], item["points"])      # the same-box denominator (the other ranks wait below, off the GPU)
+                except Exception as ex:  # noqa: BLE001
+                    print("[rank 0] N = 1 run of %s failed: %s" % (wl, ex), file=sys.stderr)
+            rdv.barrier(wl + "_n1")
+            if rec is not None and rank == 0:
+                sub = dict(rec["config"])
+                sub.update({"value": rec["value"], "unit": "Mpoints/s", "ms_per_step": rec["ms_per_step"], "n_gpus": world,
+                            "n1_ms_per_step": n1, "speedup_vs_n1": (round(n1 / rec["ms_per_step"], 3) if n1 else None),
+                            "stage_ms_rank0": rec["roofline"]["stage_ms"], "per_rank_stage_ms": rec["roofline"]["per_rank_stage_ms"],
+                            "dominant_kernel": rec["roofline"]["kernel"], "frac": rec["roofline"]["frac"]})
+                subs[wl] = sub
+    out = None
+    if rank == 0:
+        cpu = None
+        if not a.no_cpu_baseline and a.workload != "cfg5":
+            cpu = cpu_baseline(a, main["cfg"], C, N, main["clouds_host"], main["weights"], main["R"], main["t"])
+        config = main["config"]
+        config.update(subs)
+        out = {
+            "metric": "Mpoints/s fused (map-update p50 latency in config)", "value": main["value"],
+            "unit": "Mpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": main["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": config, "roofline": main["roofline"], "cpu_baseline": cpu,
         }
     rdv.barrier("done")             # file barrier: the other ranks do not spin on the GPU while rank 0 runs the CPU baseline
-    lib.emap_comm_destroy(ctx)
     return True, out
 
 
@@ -846,9 +995,18 @@ def run_strips(a, rank, world, local_rank):
     if a.dry_run:                       # launcher / rendezvous plumbing only (CPU test hook)
         got = rdv.gather_json("dry", {"rank": rank, "pid": os.getpid()})
         ok = rdv.agree("dry", len(got) == world)
+        plan = strips_plan(a)
+        for item in plan:               # the rendezvous steps of every planned measurement, under the tags the real run uses
+            for step in ("create", "uid", "init", "selftest"):
+                ok = rdv.agree(item["tag"] + step, True) and ok
+            rdv.barrier(item["tag"] + "measured")
+            if item["n1"]:
+                rdv.barrier(item["key"] + "_n1")
         rdv.barrier("dry_done")
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": got, "agreed": ok}), flush=True)
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": got, "agreed": ok,
+                              "plan": {"value": {k: plan[0][k] for k in ("workload", "cell_n", "points", "steps")},
+                                       "config": {it["key"]: {k: it[k] for k in ("workload", "cell_n", "points", "steps", "n1")} for it in plan[1:]}}}), flush=True)
         rdv.finish()
         return
     # RCCL prints its version banner on stdout through C stdio: keep fd 1 pointed at stderr until the JSON line is due

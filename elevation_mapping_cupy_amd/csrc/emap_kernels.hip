@@ -4,7 +4,6 @@
 // write integer/fixed-point accumulators, per-cell passes commit) -- not a translation of the CuPy kernels.
 // Compiled with -ffp-contract=off: decisions (indices, gates) must be bit-identical to the oracle.
 #include "emap_device.h"
-#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -1165,199 +1164,6 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// k_post_pipe: the fused stencils of k_post<32, .> as PERSISTENT workgroups with the next tile's loads in flight (round 5).
-// At 8192^2 k_post runs 64 rounds of 512 workgroups, each a chain load -> barrier -> hole search -> 4 x 285-instruction epilogue ->
-// store; the ablation of round 4 put 0.485 ms of issue + LDS work next to ~0.39 ms of memory phases that two workgroups
-// per CU do not hide behind each other.  Here a workgroup walks the tiles t = blockIdx.x + k * gridDim.x and issues the 16-byte
-// cold-half loads of tile k + 1 into REGISTERS (eight float4 per thread: six region rows of the wave's column + two cells of the
-// 6 + 2d extra columns) right before the epilogue of tile k -- the loads' round trip runs under ~1200 instructions of filter
-// arithmetic per wave -- and commits them to the (single) LDS region after the barrier that ends tile k.  No second LDS buffer: two
-// workgroups per CU as before.  The row terms (circular origin, strip ownership, border) live in one register per lane (lane j =
-// region row j - 1, computed by every wave: no table, no barrier in front of the loads) and reach the address arithmetic through
-// v_readlane / ds_bpermute.  Tiles along the map's edges (2 % at 8192^2) are staged synchronously by the general walk of k_post.
-// LDS contents, hole search and epilogue are k_post's: bit-identical planes.  d <= 5 (RH <= 48 = 8 waves x 6 rows, <= 1024 extra cells).
-// ---------------------------------------------------------------------------------------------------------
-struct PostTile { int tile_r, tile_c, seg_e, rowT, interior; };
-#ifndef POST_PIPE_OCC
-#define POST_PIPE_OCC 4     /* waves per SIMD the register budget is set for: 4 = two workgroups per CU, 6 = three (A/B knob) */
-#endif
-template <int STAGE>
-__global__ __launch_bounds__(512, POST_PIPE_OCC) void k_post_pipe(KP P, TravW Wt, Cells cells, float* __restrict__ trav_in,
-                                                   float* __restrict__ normal, long plane_stride, int d, PostSegs S, int tiles_x, int n_tiles) {
-  constexpr int PT_R = 32, PT_THREADS = 512, PT_WAVES = PT_THREADS / 64, U = 6, EU = 2;
-  extern __shared__ float lds[];
-  const int RW = PT_C + 6 + 2 * d, rp = RW + 1, RH = PT_R + 6 + 2 * d;
-  const int DW = PT_C + 6, DH = PT_R + 6;
-  float* reg = lds;
-  int* rtab = reinterpret_cast<int*>(reg + 3 * RH * rp);
-  unsigned int* hs = reinterpret_cast<unsigned int*>(rtab + ((RH + 3) & ~1));
-  unsigned int* reach = hs + 4 * RH;
-  unsigned short* holes = reinterpret_cast<unsigned short*>(reach + 4 * RH);
-  __shared__ unsigned int n_holes2[2];
-  if (threadIdx.x == 0) { n_holes2[0] = 0u; n_holes2[1] = 0u; }
-  __syncthreads();
-  const int C = P.C, EC = RW - 64, etotal = RH * EC;
-  const int tc = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  auto make_tile = [&](int t) {
-    PostTile T;
-    const int tyy = t / tiles_x, tx = t - tyy * tiles_x;
-    int seg_b = S.b[0], ty = tyy; T.seg_e = S.e[0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) if (k < S.n && tyy >= S.t0[k]) { seg_b = S.b[k]; T.seg_e = S.e[k]; ty = tyy - S.t0[k]; }
-    T.tile_r = seg_b + ty * PT_R; T.tile_c = tx * PT_C;
-    const int r0 = T.tile_r - 3 - d, c0 = T.tile_c - 3 - d, g = r0 - 1 + tc;
-    const bool in_map = g >= 0 && g <= C - 1;
-    const int lr = in_map ? local_row(P, phys_row(P, g)) : -1;
-    T.rowT = lr < 0 ? (int)0x80000000 : lr | ((g >= 1 && g <= C - 2) ? 0 : 0x40000000);
-    const bool special = (T.rowT & (int)0xC0000000) && tc >= 1 && tc <= RH;
-    T.interior = (__builtin_amdgcn_ballot_w64(special) == 0ull && c0 >= 1 && c0 + RW - 1 <= C - 2) ? 1 : 0;      // (uniform)
-    return T;
-  };
-  float4 q[U], qe[EU];
-  auto issue = [&](const PostTile& T) {                               // interior tiles: the loads of the whole region, nothing waits for them here
-    // NO branch around a load or around this function: a conditional load is merged with the registers' old contents on the spot,
-    // i.e. waited for.  So the loads go out for EVERY tile with clamped coordinates -- exact for interior tiles; an edge tile loads
-    // some cells it then ignores (it is staged by the general walk).
-    const int c0 = T.tile_c - 3 - d;
-    const unsigned int pc0 = (unsigned int)phys_col(P, min(max(c0 + tc, 0), C - 1));
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int r = min(wv + u * PT_WAVES, RH - 1);                     // scalar
-      q[u] = cells.cold[(long)(__umul24((unsigned int)__builtin_amdgcn_readlane(T.rowT, r + 1) & 0xffffffu, (unsigned int)C) + pc0)];
-    }
-#pragma unroll
-    for (int e = 0; e < EU; ++e) {
-      const int eb = min((int)threadIdx.x + e * PT_THREADS, etotal - 1);
-      const int r = (int)__umulhi((unsigned int)eb, S.emagic), cc = 64 + eb - r * EC;
-      const int rt = __shfl(T.rowT, r + 1, 64);
-      qe[e] = cells.cold[(long)(__umul24((unsigned int)rt & 0xffffffu, (unsigned int)C) + (unsigned int)phys_col(P, min(max(c0 + cc, 0), C - 1)))];
-    }
-  };
-  int t = blockIdx.x;
-  PostTile cur = make_tile(t);
-#ifndef POST_PIPE_NOPREFETCH
-  issue(cur);
-#endif
-  for (int it = 0;; ++it) {
-#ifdef POST_PIPE_NOPREFETCH
-    issue(cur);                                                       // (A/B: persistent workgroups WITHOUT the loads in flight under the epilogue)
-#endif
-    unsigned int* n_holes = &n_holes2[it & 1];
-    const int tile_r = cur.tile_r, tile_c = cur.tile_c;
-    const int c0 = tile_c - 3 - d;
-    if (cur.interior) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int r = wv + u * PT_WAVES;
-        if (r >= RH) continue;
-        const float m = q[u].w + q[u].z;
-        float3 o; o.x = q[u].y; o.y = m; o.z = q[u].w;
-        *reinterpret_cast<float3*>(reg + (r * rp + tc) * 3) = o;
-        if (m < 0.5f && (unsigned int)(r - d) < (unsigned int)DH && (unsigned int)(tc - d) < (unsigned int)DW) holes[atomicAdd(n_holes, 1u)] = (unsigned short)((r - d) * DW + (tc - d));
-      }
-#pragma unroll
-      for (int e = 0; e < EU; ++e) {
-        const int eb = threadIdx.x + e * PT_THREADS;
-        if (eb >= etotal) continue;
-        const int r = (int)__umulhi((unsigned int)eb, S.emagic), cc = 64 + eb - r * EC;
-        const float m = qe[e].w + qe[e].z;
-        float3 o; o.x = qe[e].y; o.y = m; o.z = qe[e].w;
-        *reinterpret_cast<float3*>(reg + (r * rp + cc) * 3) = o;
-        if (m < 0.5f && (unsigned int)(r - d) < (unsigned int)DH && (unsigned int)(cc - d) < (unsigned int)DW) holes[atomicAdd(n_holes, 1u)] = (unsigned short)((r - d) * DW + (cc - d));
-      }
-    } else {
-      // edge tiles: k_post's general walk (flag bits of the row table and of the column, flat-index row carry), staged synchronously
-      if (wv == 0 && tc < RH + 2) rtab[tc] = cur.rowT;
-      __syncthreads();
-      auto col_terms = [&](int cc, int& dr, int& pc, int& flags) {
-        int cl = c0 + cc; dr = 0;
-        if (cl < 0) { cl += C; dr = -1; } else if (cl >= C) { cl -= C; dr = 1; }
-        flags = ((cl >= 1 && cl <= C - 2) ? 0 : 0x40000000) | (cl < C ? 0 : (int)0x80000000);
-        pc = cl < C ? phys_col(P, cl) : 0;
-      };
-      auto put = [&](int r, int cc, int tqv, const float4& q1) {
-        const bool ok = tqv >= 0, inside = (tqv & 0x40000000) == 0;
-        const float m = q1.w + q1.z;
-        float3 o;
-        o.x = ok ? q1.y : 0.f;
-        o.y = ok ? (inside ? m : -m - 1.f) : -1.f;
-        o.z = ok ? q1.w : 0.f;
-        *reinterpret_cast<float3*>(reg + (r * rp + cc) * 3) = o;
-        if (ok && m < 0.5f && (unsigned int)(r - d) < (unsigned int)DH && (unsigned int)(cc - d) < (unsigned int)DW) holes[atomicAdd(n_holes, 1u)] = (unsigned short)((r - d) * DW + (cc - d));
-      };
-      int ldr, lpc, lfl;
-      col_terms(tc, ldr, lpc, lfl);
-      const int* ltab = rtab + 1 + ldr;
-#pragma unroll 1
-      for (int r = wv; r < RH; r += PT_WAVES) {                       // (2 % of the tiles at 8192^2: one load at a time, no registers held)
-        const int T = ltab[r];
-        put(r, tc, T | lfl, cells.cold[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)lpc)]);
-      }
-#pragma unroll 1
-      for (int eb = threadIdx.x; eb < etotal; eb += PT_THREADS) {
-        const int r = (int)__umulhi((unsigned int)eb, S.emagic), cc = 64 + eb - r * EC;
-        int dr, pc, fl;
-        col_terms(cc, dr, pc, fl);
-        const int T = rtab[r + 1 + dr];
-        put(r, cc, T | fl, cells.cold[(long)(__umul24((unsigned int)T & 0xffffffu, (unsigned int)C) + (unsigned int)pc)]);
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) n_holes2[(it & 1) ^ 1] = 0u;              // the other counter: last read before the barrier that ended the previous tile
-    const unsigned int nh = *n_holes;
-    const bool sparse = 4 * (int)nh > 3 * DW * DH && RW <= 128;
-    if (sparse) post_reach_masks<PT_THREADS>(hs, reach, RH, RW, d, [&](int r, int cc) { return reg[(r * rp + min(cc, RW - 1)) * 3 + 1] > 0.5f; });
-    for (unsigned int hi = threadIdx.x; hi < nh; hi += PT_THREADS) {
-      const int pos = holes[hi], r = pos / DW, cc = pos - r * DW;
-      if (sparse && !((reach[4 * (r + d) + ((cc + d) >> 5)] >> ((cc + d) & 31)) & 1u)) continue;
-      const int o0 = (r + d) * rp + (cc + d);
-      bool found = false;
-      for (int s2 = -2 * d; s2 <= 2 * d && !found; ++s2) {
-        const int dy0 = max(-d, s2 - d), dy1 = min(d, s2 + d);
-        for (int dy = dy0; dy <= dy1; ++dy) {
-          const int o = o0 + dy * rp + (s2 - dy);
-          if (reg[o * 3 + 1] > 0.5f) { reg[o0 * 3] = reg[o * 3]; found = true; break; }
-        }
-      }
-    }
-    if (nh) __syncthreads();
-    // the next tile's loads go out now and come back under the epilogue
-    const int tn = t + (int)gridDim.x;
-    const bool has_next = tn < n_tiles;                               // (uniform)
-    const PostTile nxt = make_tile(has_next ? tn : t);               // (the last tile re-requests itself: no branch around the loads)
-#ifndef POST_PIPE_NOPREFETCH
-    issue(nxt);
-#endif
-    const int col = tile_c + tc;
-    if (col < C) {
-      const int pcol = phys_col(P, col);
-      const float* dil = reg + (d * rp + d) * 3;
-      const int dp = rp;
-      constexpr int RPW = PT_R / PT_WAVES;
-      const bool col_in = STAGE == 0 && col >= 3 && col <= C - 4;
-      const bool col_n = col >= 1 && col <= C - 3;
-      // the filter weights are read through a kernarg pointer the compiler cannot see through: as loop invariants all 132 would be
-      // hoisted in front of the tile loop and spilled through v_writelane (294 SGPR spills, 161 VGPRs: one workgroup per CU)
-      typedef const __attribute__((address_space(4))) TravW* wt_ptr;
-      const __attribute__((address_space(4))) char* ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
-#pragma unroll
-      for (int k = 0; k < RPW; ++k) {
-        const int tr = wv * RPW + k, gr = tile_r + tr;               // scalar
-        if (gr >= cur.seg_e) break;
-        asm volatile("" : "+s"(ka));
-        wt_ptr wtp = (wt_ptr)(ka + ((sizeof(KP) + alignof(TravW) - 1) & ~(alignof(TravW) - 1)));
-        const float* t0 = &dil[((tr + 3) * dp + (tc + 3)) * 3];
-        const long c = (long)(__builtin_amdgcn_readlane(cur.rowT, tr + 4 + d) & 0xffffff) * C + pcol;
-        POST_CELL(*wtp, 3, t0, dp, t0[2], col_in && gr >= 3 && gr <= C - 4, col_n && gr >= 1 && gr <= C - 3, c);
-      }
-    }
-    if (!has_next) break;
-    __syncthreads();                                                 // every read of the region is done: the next tile may land
-    t = tn; cur = nxt;
-  }
-}
-
 // update_variance + update_time (elevation_mapping.py:420-426)
 __global__ __launch_bounds__(EM_BLOCK) void k_var_time(KP P, Cells cells, int do_var, int do_time) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
@@ -1599,33 +1405,6 @@ static bool post_use_dma(int R, int d) {
   static const long lds_kb = []() { const char* e = getenv("EMAP_POST_DMA_LDS_KB"); long v = e ? atol(e) : 0; return v >= 16 && v <= 150 ? v : 52; }();   // tuning knob
   return !dma_off && R >= 16 && R + 8 + 2 * d <= 64 && (long)post_dma_lds_bytes(R, d) <= lds_kb * 1024;     // (4-row tiles of robot-scale maps: 12.0 vs 9.7 us, measured)
 }
-// CUs of the current device (persistent grids), cached per device
-static int device_cus() {
-  static int cus[EM_MAX_DEV];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EM_MAX_DEV) dev = 0;
-  if (!cus[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; cus[dev] = n; }
-  return cus[dev];
-}
-// k_post_pipe (persistent workgroups, the next tile's loads in flight): 32-row tiles, d <= 5, and enough tiles per workgroup for the
-// pipeline to matter.  EMAP_POST_PIPE = 0: never, 1: whenever the shape allows, unset: from POST_PIPE_MIN_ROUNDS tiles per workgroup
-// on.  EMAP_POST_PIPE_GRID = n: that many workgroups instead of two per CU (tests: many tiles per workgroup on a small map).  Both are
-// read at every launch (a getenv costs less than the launch's argument marshalling), so a test can switch them inside one process.
-#ifndef POST_PIPE_MIN_ROUNDS
-#define POST_PIPE_MIN_ROUNDS 6
-#endif
-static int post_pipe_grid() {
-  const char* e = getenv("EMAP_POST_PIPE_GRID");
-  const int v = e ? atoi(e) : 0;
-  return v >= 1 && v <= 65535 ? v : (POST_PIPE_OCC / 2) * device_cus();
-}
-static bool post_use_pipe(const KP& P, int d, long tiles) {
-  const char* e = getenv("EMAP_POST_PIPE");
-  const int mode = e ? atoi(e) : -1;
-  if (mode == 0 || d > 5 || d != P.dil || post_lds_bytes(32, d) > 60 * 1024) return false;
-  const long grid = post_pipe_grid();
-  return mode == 1 ? tiles > grid : tiles >= (long)POST_PIPE_MIN_ROUNDS * grid;
-}
 int post_tile_rows(const KP& P) {
   static const int force_r = []() { const char* e = getenv("EMAP_POST_R"); int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32) ? v : 0; }();
   int R;
@@ -1643,7 +1422,6 @@ int post_tile_rows(const KP& P) {
   static const bool win_env = []() { const char* e = getenv("EMAP_POST_DMA_WINDOW"); long a = 0, b = 0; if (e && sscanf(e, "%ld %ld", &a, &b) == 2 && a >= 1 && b > a) { win_lo = a; win_hi = b; } return true; }();
   (void)win_env;
   const long cells = (long)P.nrows * P.C;
-  if (!force_r && R == 32 && post_use_pipe(P, P.dil, (long)((P.C + PT_C - 1) / PT_C) * ((P.nrows + 31) / 32))) return R;      // persistent, pipelined 32-row tiles (k_post_pipe)
   if (!force_r && R == 32 && !post_use_dma(32, P.dil) && post_use_dma(16, P.dil) && cells >= win_lo * win_lo && cells < win_hi * win_hi && P.C < win_hi) R = 16;      // (the row pitch counts: strips of wider maps keep k_post)
   while (R > 4 && !post_use_dma(R, P.dil) && post_lds_bytes(R, P.dil) > 150 * 1024) R /= 2;      // dilation radii up to 32: the staged region must fit the 160 KB LDS
   return R;
@@ -1675,15 +1453,6 @@ void launch_post(hipStream_t s, const KP& P, const float* w1, const float* w2, c
   const bool dma = post_use_dma(R, d) && (win_forced || (R == 16 && cells_ >= 3072L * 3072L && cells_ < 5120L * 5120L && P.C < 5120));
   dim3 g((P.C + PT_C - 1) / PT_C, tiles), b(dma ? 512 : (R >= 32 ? POST_T32 : 512));
   const size_t lds = dma ? post_dma_lds_bytes(R, d) : post_lds_bytes(R, d);
-  if (!dma && R == 32 && post_use_pipe(P, d, (long)g.x * g.y)) {
-    const int tiles_x = (int)g.x, n_tiles = (int)(g.x * g.y);
-    const dim3 gp((unsigned int)std::min<long>(n_tiles, post_pipe_grid()));
-#define POST_PIPE_GO(ST) do { auto kern = k_post_pipe<ST>; static LdsRaised raised; raise_lds(kern, raised, 158 * 1024); \
-      hipLaunchKernelGGL(kern, gp, dim3(512), lds, s, P, W, cells, trav_in, normal, plane_stride, d, S, tiles_x, n_tiles); } while (0)
-    if (stage == 1) POST_PIPE_GO(1); else POST_PIPE_GO(0);
-#undef POST_PIPE_GO
-    return;
-  }
 #define POST_GO(KERN, RR, ST) do { auto kern = KERN<RR, ST>; static LdsRaised raised; \
     raise_lds(kern, raised, 158 * 1024); \
     hipLaunchKernelGGL(kern, g, b, lds, s, P, W, cells, trav_in, normal, plane_stride, d, S); } while (0)

@@ -68,6 +68,22 @@ def frame_marches_by_ray(cell_n: int, n_points: int, world: int, comm_kind: str 
     return world > 1 and comm_kind == "native" and ray_mode != 1 and binned and (ray_mode == 2 or cell_n >= 2048)
 
 
+def strip_stage_bytes(n_points: int, n_cells: int, world: int, full_sort: bool = False, bucketed: bool = False):
+    """Algorithmic bytes of the timed stages of ONE strip's frame (the kernels as they are; bench.py: STAGE_BYTES holds the
+    single-context table): N points in the frame's cloud, L cells in the whole map.  The point passes of a strip stream the
+    replicated cloud once (12 B of xyz per point; `bucketed`: only the strip's share was uploaded) and keep a 16-byte staging record
+    per OWNED point, which the scatter pass permutes; a frame whose rays march by row sorts every valid point (`full_sort`: the
+    single-context point passes).  The tile and stencil kernels only see the strip's points and cells."""
+    N, L = float(n_points), float(n_cells)
+    Nw, Lw = N / world, L / world
+    if full_sort:
+        hist, scatter = 12 * N, 12 * N + 16 * N
+    else:
+        hist, scatter = 12 * (Nw if bucketed else N) + 16 * Nw, 16 * Nw + 16 * Nw
+    return {"hist": hist, "scan": 0, "scatter": scatter, "gate": 16 * Nw + 16 * Lw, "fuse": 16 * Nw + 32 * Lw, "commit": 104 * Lw,
+            "rays": 12 * N + 48 * Lw, "average": 120 * Lw, "overlap": 0, "post": 40 * Lw}
+
+
 def halo_rows_needed(dilation_size: int, world: int) -> int:
     """dilation radius d, +3 rows for the traversability stencil computed from the dilated plane, +1 for the
     reference's flat-index wrap into the adjacent row (custom_kernels.py:403-407)."""
@@ -586,9 +602,7 @@ def bench_main(a, rank, world, local_rank):
         eng.lib.emap_enable_stage_timing(eng.ctx, 0)
         torch.cuda.synchronize(); comm.barrier()
         stage_ms = dict(zip(STAGES, (acc / reps).tolist()))
-        Nw, Lw = N / world, C * C / world
-        strip_bytes = {"hist": 28 * N, "scan": 0, "scatter": 16 * N + 32 * Nw, "gate": 0, "fuse": 24 * Nw + 64 * Lw, "commit": 104 * Lw,
-                       "rays": 12 * N + 48 * Lw, "average": 120 * Lw, "overlap": 0, "post": 52 * Lw}
+        strip_bytes = strip_stage_bytes(N, C * C, world, full_sort=bool(cfg["enable_visibility_cleanup"]))
         empty = []                       # spacing of an event pair with nothing in between (bench.py does the same calibration)
         for _ in range(50):
             e_ms = ct.c_float(0)

@@ -44,3 +44,26 @@ def test_bench_gpus_2_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["value"] > 0 and d["steps"] == 4
     assert d["config"]["physical_devices"] in (1, 2)
+
+
+def test_sharded_default_line_carries_cfg5_and_cfg4_next_to_their_n1_times():
+    """The N > 1 line (here: the row-strip path forced onto ONE rank, real RCCL communicator) keeps BASELINE configs[1] as `value` and
+    adds what north_star's scaling target names as sharded sub-measurements -- config.cfg5 (multi-modal map, semantic fusion inside
+    the timed frame, an 11th stage "semantic") and config.cfg4 (rays + overlap) -- each with the same-box N = 1 time beside it.
+    Sub-measurement sizes shrunk through the test hook; the code path is the one `bench.py --gpus 8` runs."""
+    env = dict(os.environ, EMAP_BENCH_SUB_SIZES="cfg5:1024:300000,cfg4:1024:300000")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["rccl_ranks"] == 1 and "cfg2" in d["config"]["workload"]
+    for k in ("cfg5", "cfg4"):
+        c = d["config"][k]
+        assert c["ms_per_step"] > 0 and c["n1_ms_per_step"] > 0 and c["speedup_vs_n1"] > 0 and c["rccl_ranks"] == 1 and c["n_gpus"] == 1
+        assert len(c["per_rank_stage_ms"]) == 1 and c["dominant_kernel"] in c["stage_ms_rank0"]
+    assert d["config"]["cfg5"]["per_rank_stage_ms"][0]["semantic"] > 0           # the fusion of the extra channels is inside the frame and visible
+    assert d["config"]["cfg4"]["rays"] in ("by row", "by ray over an all-reduced window")
+    assert d["config"]["cfg4"]["stage_ms_rank0"]["rays"] > 0

@@ -27,6 +27,19 @@ def test_self_launch_prints_one_json_line_with_the_ranks_that_ran():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 3 and d["agreed"] is True and [r["rank"] for r in d["ranks"]] == [0, 1, 2]
     assert len({r["pid"] for r in d["ranks"]}) == 3                      # three OS processes
+    # what the N > 1 line measures: `value` on BASELINE configs[1], and -- what north_star's scaling target names -- configs[4] (8192^2
+    # multi-modal, 16 M points) and configs[3] (4096^2, rays) as sharded sub-measurements, each with a same-box N = 1 run beside it
+    plan = d["plan"]
+    assert plan["value"] == {"workload": "cfg2", "cell_n": 1024, "points": 1000000, "steps": 50}
+    assert plan["config"]["cfg5"] == {"workload": "cfg5", "cell_n": 8192, "points": 16000000, "steps": 10, "n1": True}
+    assert plan["config"]["cfg4"] == {"workload": "cfg4", "cell_n": 4096, "points": 4000000, "steps": 10, "n1": True}
+
+
+def test_a_single_workload_line_plans_no_sub_measurements():
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--dry-run", "--workload", "cfg5"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    assert d["plan"]["value"]["workload"] == "cfg5" and d["plan"]["value"]["cell_n"] == 8192 and d["plan"]["config"] == {}
 
 
 def test_ranks_started_by_an_external_launcher_find_each_other():
