@@ -835,14 +835,32 @@ def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag
         channels = ["rgb", "sem0", "sem1", "sem2"]
         par.pointcloud_channel_fusions = {"rgb": "color", "default": "average"}
         emap.semantic_map.prepare(channels)
-    clouds_dev = device_clouds(hip, clouds_host, not a.interleaved_cloud)
     R = np.eye(3, dtype=np.float32).ravel().copy()
     t = np.array([0, 0, 1], np.float32)
     Rp, tp = _lib.f32p(R), _lib.f32p(t)
+    # Every rank is handed the same clouds; where the frame allows it (no visibility pass that marches by row) a rank keeps only the
+    # points that can land in its rows -- the product's own predicate (emap_strip_point_mask = what emap_upload_points_strip /
+    # ShardedElevationMap.input_pointcloud upload), applied once because the timed clouds are device resident.
+    bucket = world > 1 and (not rays or by_ray) and os.environ.get("EMAP_BENCH_BUCKET", "1") != "0"
+    n_local = [N] * NCLOUD
+    if bucket:
+        local = []
+        for p_ in clouds_host:
+            q_ = np.ascontiguousarray(p_[emap.strip_point_mask(p_, R, t)])
+            if q_.shape[0] == 0:                       # (no point of the cloud in this strip: one NaN row, as the upload path binds)
+                q_ = np.full((1, p_.shape[1]), np.nan, np.float32)
+            local.append(q_)
+        n_local = [q_.shape[0] for q_ in local]
+        clouds_dev = device_clouds(hip, local, not a.interleaved_cloud)
+        del local
+    else:
+        clouds_dev = device_clouds(hip, clouds_host, not a.interleaved_cloud)
     sem_ms = ct.c_float(0)
 
     def frame(i, stats=None, time_sem=False):
-        rc = bind_cloud(lib, ctx, clouds_dev[i % NCLOUD], N)
+        rc = bind_cloud(lib, ctx, clouds_dev[i % NCLOUD], n_local[i % NCLOUD])
+        if bucket:
+            rc = rc or lib.emap_declare_points_bucketed(ctx, Rp, tp, ct.c_int64(N))
         rc = rc or lib.emap_update_sharded(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
         if rc:
             raise RuntimeError(lib.emap_last_error(ctx).decode())
@@ -887,10 +905,11 @@ def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag
     emap.sync(); barrier()
     all_stage = rdv.gather_json(tag + "stage_ms", {k: round(v, 5) for k, v in stage_ms.items()})
     rows = rdv.gather_json(tag + "rows", [int(r0), int(r1)])
+    shares = rdv.gather_json(tag + "share", round(max(n_local) / float(N), 4))
     rec = {"ok": True, "wall": wall, "stage_ms": stage_ms, "clouds_host": clouds_host, "cfg": cfg, "weights": weights, "R": R, "t": t}
     if rank == 0:
         L = C * C
-        sb = sharded.strip_stage_bytes(N, L, world, full_sort=rays and not by_ray)
+        sb = sharded.strip_stage_bytes(N, L, world, full_sort=rays and not by_ray, bucketed=bucket)
         if multimodal:
             sb["semantic"] = (16 * N + 32 * L) / world        # 4 channels x 4 B per point, 4 layers x (read + write) per cell of the strip
         frame_bytes = 12 * N + 56 * L + (16 * N + 32 * L if multimodal else 0)
@@ -902,7 +921,8 @@ def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag
                         ("; 'semantic' = the strip's RGB / semantic fusion (inside the timed frame)" if multimodal else ""))
         rec.update({
             "value": round(N * steps / wall / 1e6, 2), "ms_per_step": round(wall * 1e3 / steps, 5), "roofline": roof,
-            "config": {"workload": workload_text(b, C, N, multimodal) + "; %d row strips, cloud replicated to every rank" % world,
+            "config": {"workload": workload_text(b, C, N, multimodal) + "; %d row strips, %s" % (world, "every rank binds only the points of its rows (bucketed with the library's predicate)" if bucket else "cloud replicated to every rank"),
+                       "cloud_share_per_rank": shares,
                        "index_mode": mode, "latency_ms": {"p10": round(pct[0], 4), "p50": round(pct[1], 4), "p90": round(pct[2], 4)},
                        "halo_rows": halo, "parallelism": "row-strips x%d" % world, "ranks": world, "rccl_ranks": rccl_ranks,
                        "physical_devices": min(ndev, world),

@@ -55,7 +55,7 @@ STAGES = ["hist", "scan", "scatter", "gate", "fuse", "commit", "rays", "average"
 # every symbol include/emap_hip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [
     "emap_abi_version", "emap_create", "emap_destroy", "emap_set_params", "emap_last_error", "emap_sync", "emap_clear",
-    "emap_upload_points", "emap_set_points_device", "emap_set_points_device_split", "emap_point_index", "emap_update", "emap_count",
+    "emap_upload_points", "emap_upload_points_strip", "emap_strip_point_mask", "emap_declare_points_bucketed", "emap_set_points_device", "emap_set_points_device_split", "emap_point_index", "emap_update", "emap_count",
     "emap_set_drift_inputs", "emap_drift_sums_to_device", "emap_set_drift_inputs_device",
     "emap_local_drift_sums", "emap_set_scatter_mode", "emap_fuse", "emap_fuse_average", "emap_commit", "emap_rays", "emap_average", "emap_overlap_clear",
     "emap_dilate", "emap_traversability_normals", "emap_post", "emap_post_part", "emap_update_variance", "emap_update_time", "emap_get_stats",

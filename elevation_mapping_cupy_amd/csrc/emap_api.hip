@@ -167,6 +167,8 @@ struct emap_ctx {
   hipEvent_t ev_copied[2], ev_used[2];     // DMA of slot done (copy stream) / the frame that read the slot's device buffer done (main stream)
   int up_slot; bool up_used[2]; hipStream_t copy_stream; Workers* workers;
   const float* pts; long n_pts; int stride;         // xyz of the bound cloud: rows of `stride` floats (3 for a de-interleaved cloud)
+  long n_pts_all;                                   // size of the cloud the caller handed over (> n_pts for a bucketed one): what every rank of a sharded map shares
+  bool pts_bucketed; float bucket_R[9], bucket_t[3];   // the bound cloud only holds the points that can land in this strip's rows under this pose (emap_upload_points_strip)
   ChanView chan; int n_cols;                        // its extra channels (emap_device.h: ChanView); n_cols = columns of the caller's matrix (3 + K)
   int* tail_idx; unsigned char* tail_flags; long tail_cap;
   // frame state
@@ -492,10 +494,37 @@ int emap_set_params(emap_ctx* ctx, const emap_params* params) {
 int emap_sync(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); CK(hipStreamSynchronize(ctx->stream)); return EMAP_OK; }
 
 // ---- point cloud --------------------------------------------------------------------------------------
-int emap_upload_points(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype) {
-  CKARG(ctx, "null ctx");
-  CKARG(n >= 0 && stride >= 3 && stride < 4096 && (dtype == 0 || dtype == 1), "bad point buffer description");
-  CKARG(n == 0 || host, "null host buffer");
+// Which points of a cloud can land in THIS strip's rows under the pose (R, t map-centre relative)?  A conservative host-side test in
+// double arithmetic: the kernels decide the row with the index mode's own rounding (emap_device.h: geometry / axis_idx -- in
+// reference_fp16 mode coordinates, R and t pass through binary16), so the row estimate gets a margin that bounds every rounding on
+// that path (2^-10 relative on every term in reference_fp16 mode, 2^-20 in fp32 mode) plus two cells; points outside the map clamp to
+// its first / last row like the kernels' index does.  A point with a NaN coordinate is skipped by every kernel: never kept; one the
+// test cannot place (non-finite row estimate, magnitudes beyond binary16) is kept everywhere.  The kept set is a SUPERSET of the
+// points the strip's kernels act on, in the cloud's order -- so the strip's maps stay bit-identical (the kernels repeat the exact test).
+struct StripKeep {
+  double R0, R1, R2, t0, res, eps, half_c; int C, ls, nrows; bool half_mode;
+  StripKeep(const emap_ctx* ctx, const float R[9], const float t[3]) {
+    const emap_params& p = ctx->prm;
+    R0 = R[0]; R1 = R[1]; R2 = R[2]; t0 = t[0]; res = p.resolution; C = p.cell_n; half_c = 0.5 * C;
+    half_mode = p.mode == EMAP_MODE_REFERENCE_FP16;
+    eps = half_mode ? 1.0 / 1024.0 : 1.0 / 1048576.0;
+    ls = ((ctx->strip.row_begin - ctx->kp.org_r) % C + C) % C;      // logical row of the strip's first physical row
+    nrows = ctx->strip.row_count;
+  }
+  bool operator()(double x, double y, double z) const {
+    if (x != x || y != y || z != z) return false;
+    const double a = R0 * x, b = R1 * y, c = R2 * z, xf = a + b + c + t0;
+    if (!(std::fabs(xf) <= 1.0e30) || (half_mode && (std::fabs(x) > 60000.0 || std::fabs(y) > 60000.0 || std::fabs(z) > 60000.0 || std::fabs(xf) > 60000.0))) return true;
+    const double m = eps * (2.0 * (std::fabs(a) + std::fabs(b) + std::fabs(c)) + std::fabs(t0) + std::fabs(xf)) + 2.0 * res;
+    auto row = [&](double v) { const double r = std::floor(v / res + half_c); return r < 0.0 ? 0 : (r > C - 1 ? C - 1 : (int)r); };
+    const int lo = row(xf - m), hi = row(xf + m);
+    const int d = ((lo - ls) % C + C) % C;
+    return d < nrows || d + (hi - lo) >= C;
+  }
+};
+
+// conversion + (optional) order-preserving compaction of a host cloud into the pinned slot and out to the device, chunk by chunk
+static int upload_impl(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype, const StripKeep* keep, int64_t* n_kept) {
   CK(hipSetDevice(ctx->device));
   const long tot = (long)n * stride + (stride > 3 ? 64 : 0);      // (+ the padding in front of the channel matrix)
   if (!ctx->copy_stream) {
@@ -525,16 +554,43 @@ int emap_upload_points(emap_ctx* ctx, const void* host, int64_t n, int64_t strid
   // A cloud with extra channels is DE-INTERLEAVED on the way: the workers write xyz as an (n, 3) matrix and the K channels as an
   // (n, K) matrix behind it (at a 256-byte boundary) -- the conversion touches every element anyway -- so that the frame's point
   // passes stream 12 bytes per point instead of 12 + 4 K and the semantic fusion reads one K-float record per point.
+  // With `keep` (row strips, emap_upload_points_strip) only the points that pass it are written, in order: every worker counts the
+  // survivors of its share of the chunk, the shares' offsets follow, a second pass over the (cache-resident) share writes them.
   const long K = stride - 3, chan_off = K ? ((3 * (long)n + 63) & ~63L) : 0;
+  long kept = 0;
   if (tot > 0) {
     float* pin = ctx->pts_pin[sl];
     const long cp = (1L << 19) / stride > 0 ? (1L << 19) / stride : 1;      // points per chunk: about 2 MB of float32 per DMA
+    std::vector<long> cnt, off;
     for (long p0 = 0; p0 < (long)n; p0 += cp) {
       const long p1 = p0 + cp < (long)n ? p0 + cp : (long)n;
+      long out0 = p0, out1 = p1;                                    // rows [out0, out1) of the device matrices this chunk fills
+      auto coord = [&](long i, int k) -> double { return dtype == 0 ? (double)static_cast<const float*>(host)[i * stride + k] : static_cast<const double*>(host)[i * stride + k]; };
+      if (keep) {
+        cnt.assign(ctx->workers->th.size(), 0); off.assign(ctx->workers->th.size(), 0);
+        ctx->workers->run([&](int w, int nw) {
+          const long per = (p1 - p0 + nw - 1) / nw, a = p0 + (long)w * per, b = a + per < p1 ? a + per : p1;
+          long c = 0;
+          for (long i = a; i < b; ++i) c += (*keep)(coord(i, 0), coord(i, 1), coord(i, 2)) ? 1 : 0;
+          cnt[w] = c;
+        });
+        long run = kept;
+        for (size_t w = 0; w < cnt.size(); ++w) { off[w] = run; run += cnt[w]; }
+        out0 = kept; out1 = run;
+      }
       ctx->workers->run([&](int w, int nw) {
         const long per = (p1 - p0 + nw - 1) / nw, a = p0 + (long)w * per, b = a + per < p1 ? a + per : p1;
         if (b <= a) return;
-        if (K == 0) {
+        if (keep) {
+          long o = off[w];
+          for (long i = a; i < b; ++i) {
+            const double x = coord(i, 0), y = coord(i, 1), z = coord(i, 2);
+            if (!(*keep)(x, y, z)) continue;
+            pin[3 * o] = (float)x; pin[3 * o + 1] = (float)y; pin[3 * o + 2] = (float)z;      // fp32 cast (:456)
+            for (long k = 0; k < K; ++k) pin[chan_off + K * o + k] = (float)coord(i, 3 + (int)k);
+            ++o;
+          }
+        } else if (K == 0) {
           if (dtype == 0) memcpy(pin + 3 * a, static_cast<const float*>(host) + 3 * a, sizeof(float) * 3 * (size_t)(b - a));
           else { const double* src = static_cast<const double*>(host); for (long i = 3 * a; i < 3 * b; ++i) pin[i] = (float)src[i]; }   // fp32 cast (:456)
         } else if (dtype == 0) {
@@ -553,22 +609,88 @@ int emap_upload_points(emap_ctx* ctx, const void* host, int64_t n, int64_t strid
           }
         }
       });
-      CK(hipMemcpyAsync(ctx->pts_dev[sl] + 3 * p0, pin + 3 * p0, sizeof(float) * 3 * (size_t)(p1 - p0), hipMemcpyHostToDevice, ctx->copy_stream));
-      if (K) CK(hipMemcpyAsync(ctx->pts_dev[sl] + chan_off + K * p0, pin + chan_off + K * p0, sizeof(float) * (size_t)K * (size_t)(p1 - p0), hipMemcpyHostToDevice, ctx->copy_stream));
+      kept = keep ? out1 : p1;
+      if (out1 > out0) {
+        CK(hipMemcpyAsync(ctx->pts_dev[sl] + 3 * out0, pin + 3 * out0, sizeof(float) * 3 * (size_t)(out1 - out0), hipMemcpyHostToDevice, ctx->copy_stream));
+        if (K) CK(hipMemcpyAsync(ctx->pts_dev[sl] + chan_off + K * out0, pin + chan_off + K * out0, sizeof(float) * (size_t)K * (size_t)(out1 - out0), hipMemcpyHostToDevice, ctx->copy_stream));
+      }
+    }
+    if (keep && kept == 0 && n > 0) {
+      // none of the cloud's points can land in this strip's rows: bind ONE row of NaNs (skipped by every kernel, like any NaN row of a
+      // cloud) so that the frame takes the same path -- launches, collectives -- as on the ranks that did get points
+      pin[0] = pin[1] = pin[2] = NAN;
+      for (long k = 0; k < K; ++k) pin[chan_off + k] = 0.f;
+      CK(hipMemcpyAsync(ctx->pts_dev[sl], pin, sizeof(float) * 3, hipMemcpyHostToDevice, ctx->copy_stream));
+      if (K) CK(hipMemcpyAsync(ctx->pts_dev[sl] + chan_off, pin + chan_off, sizeof(float) * (size_t)K, hipMemcpyHostToDevice, ctx->copy_stream));
+      kept = 1;
     }
     CK(hipEventRecord(ctx->ev_copied[sl], ctx->copy_stream));
     CK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[sl], 0));     // kernels enqueued from now on see the cloud; nothing waits on the host
     ctx->up_used[sl] = true;
   }
-  ctx->pts = ctx->pts_dev[sl]; ctx->n_pts = (long)n; ctx->stride = 3; ctx->n_cols = (int)stride;
+  ctx->pts = ctx->pts_dev[sl]; ctx->n_pts = keep ? kept : (long)n; ctx->n_pts_all = (long)n; ctx->stride = 3; ctx->n_cols = (int)stride;
   ctx->chan.p = K ? ctx->pts_dev[sl] + chan_off : ctx->pts_dev[sl]; ctx->chan.stride = K ? (int)K : 3; ctx->chan.col0 = K ? 3 : 0;
+  ctx->pts_bucketed = false;
+  if (n_kept) *n_kept = ctx->n_pts;
+  return EMAP_OK;
+}
+
+int emap_upload_points(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype) {
+  CKARG(ctx, "null ctx");
+  CKARG(n >= 0 && stride >= 3 && stride < 4096 && (dtype == 0 || dtype == 1), "bad point buffer description");
+  CKARG(n == 0 || host, "null host buffer");
+  return upload_impl(ctx, host, n, stride, dtype, nullptr, nullptr);
+}
+
+// Row strips: every rank of a multi-GPU map is handed the SAME cloud (one sensor message), but only the points of its rows ever reach
+// its tile kernels.  This entry point converts, uploads and binds only those (StripKeep: a conservative superset, order preserved), so a
+// rank moves and streams 1 / G of the cloud: 8 x 192 MB over PCIe per 16 M-point frame on 8 GPUs become 192 MB.  The frame that follows
+// must use the SAME pose (checked) and must not march its rays by row (every valid point marches a ray through every strip then:
+// emap_update_sharded refuses); a cloud of a whole-map context is uploaded as by emap_upload_points.
+int emap_upload_points_strip(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype, const float R[9], const float t[3], int64_t* n_kept) {
+  CKARG(ctx && R && t, "null argument");
+  CKARG(n >= 0 && stride >= 3 && stride < 4096 && (dtype == 0 || dtype == 1), "bad point buffer description");
+  CKARG(n == 0 || host, "null host buffer");
+  if (ctx->strip.row_count >= ctx->prm.cell_n) return upload_impl(ctx, host, n, stride, dtype, nullptr, n_kept);
+  const StripKeep keep(ctx, R, t);
+  int rc = upload_impl(ctx, host, n, stride, dtype, &keep, n_kept);
+  if (rc) return rc;
+  ctx->pts_bucketed = true;
+  memcpy(ctx->bucket_R, R, sizeof ctx->bucket_R); memcpy(ctx->bucket_t, t, sizeof ctx->bucket_t);
+  return EMAP_OK;
+}
+
+// the same predicate as data: keep[i] = 1 iff point i would be uploaded by emap_upload_points_strip (callers that keep their clouds
+// on the device -- bench.py -- bucket them once with it; tests check the superset property against the exact cell indices)
+int emap_strip_point_mask(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype, const float R[9], const float t[3], uint8_t* keep_out) {
+  CKARG(ctx && R && t && keep_out, "null argument");
+  CKARG(n >= 0 && stride >= 3 && stride < 4096 && (dtype == 0 || dtype == 1), "bad point buffer description");
+  CKARG(n == 0 || host, "null host buffer");
+  const bool whole = ctx->strip.row_count >= ctx->prm.cell_n;
+  const StripKeep keep(ctx, R, t);
+  for (int64_t i = 0; i < n; ++i) {
+    const double x = dtype == 0 ? (double)static_cast<const float*>(host)[i * stride] : static_cast<const double*>(host)[i * stride];
+    const double y = dtype == 0 ? (double)static_cast<const float*>(host)[i * stride + 1] : static_cast<const double*>(host)[i * stride + 1];
+    const double z = dtype == 0 ? (double)static_cast<const float*>(host)[i * stride + 2] : static_cast<const double*>(host)[i * stride + 2];
+    keep_out[i] = (whole || keep(x, y, z)) ? 1 : 0;
+  }
+  return EMAP_OK;
+}
+
+// A device-resident cloud the caller bucketed itself (with emap_strip_point_mask's predicate, for THIS pose): declares it, so that the
+// frame checks pose and ray mode as for an uploaded one.
+int emap_declare_points_bucketed(emap_ctx* ctx, const float R[9], const float t[3], int64_t n_all) {
+  CKARG(ctx && R && t && n_all >= ctx->n_pts, "bad argument");
+  if (ctx->strip.row_count >= ctx->prm.cell_n) return EMAP_OK;
+  ctx->pts_bucketed = true; ctx->n_pts_all = (long)n_all;
+  memcpy(ctx->bucket_R, R, sizeof ctx->bucket_R); memcpy(ctx->bucket_t, t, sizeof ctx->bucket_t);
   return EMAP_OK;
 }
 
 int emap_set_points_device_split(emap_ctx* ctx, const float* xyz_dev, const float* chan_dev, int64_t n, int64_t n_chan) {
   CKARG(ctx, "null ctx");
   CKARG(n >= 0 && n_chan >= 0 && n_chan < 4093 && (n == 0 || (xyz_dev && (n_chan == 0 || chan_dev))), "bad device point buffers");
-  ctx->pts = xyz_dev; ctx->n_pts = (long)n; ctx->stride = 3; ctx->n_cols = 3 + (int)n_chan;
+  ctx->pts = xyz_dev; ctx->n_pts = (long)n; ctx->stride = 3; ctx->n_cols = 3 + (int)n_chan; ctx->pts_bucketed = false; ctx->n_pts_all = (long)n;
   ctx->chan.p = n_chan ? chan_dev : xyz_dev; ctx->chan.stride = n_chan ? (int)n_chan : 3; ctx->chan.col0 = n_chan ? 3 : 0;
   return EMAP_OK;
 }
@@ -576,7 +698,7 @@ int emap_set_points_device_split(emap_ctx* ctx, const float* xyz_dev, const floa
 int emap_set_points_device(emap_ctx* ctx, const float* dev, int64_t n, int64_t stride) {
   CKARG(ctx, "null ctx");
   CKARG(n >= 0 && stride >= 3 && stride < 4096 && (n == 0 || dev), "bad device point buffer");
-  ctx->pts = dev; ctx->n_pts = (long)n; ctx->stride = (int)stride; ctx->n_cols = (int)stride;
+  ctx->pts = dev; ctx->n_pts = (long)n; ctx->stride = (int)stride; ctx->n_cols = (int)stride; ctx->pts_bucketed = false; ctx->n_pts_all = (long)n;
   ctx->chan.p = dev; ctx->chan.stride = (int)stride; ctx->chan.col0 = 0;            // interleaved rows: the channels sit behind xyz
   return EMAP_OK;
 }
@@ -731,7 +853,8 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
   if (!ctx->in_update) ctx->gate_possible = true;          // the staged API always gathers the statistics
   CK(hipSetDevice(ctx->device));
   // small clouds: two launches with global atomics win; large clouds: counting sort by tile + LDS reduction
-  const bool binned = ctx->n_pts > 0 && (ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts >= 131072));   // measured crossover on MI355X: 60-135 k points for 202^2 .. 1024^2 maps
+  // (a cloud bucketed for a strip decides by the size of the WHOLE cloud: every rank of a sharded frame then takes the same path)
+  const bool binned = ctx->n_pts > 0 && (ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts_all >= 131072));   // measured crossover on MI355X: 60-135 k points for 202^2 .. 1024^2 maps
   ctx->frame_binned = binned;
   if (binned) {
     // the ray-only sort bin exists when the parameters enable the visibility pass (a staged emap_rays call on a context without it
@@ -877,6 +1000,7 @@ int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
   CKARG(ctx && R && t, "null argument"); NEED_POINTS();
   CK(hipSetDevice(ctx->device));
   CKARG(ctx->committed || ctx->rays_fused, "emap_rays needs emap_commit first (rays read snapshot S1)");
+  CKARG(!ctx->pts_bucketed, "a bucketed cloud (emap_upload_points_strip) cannot march its rays by row: every valid point marches a ray through every strip");
   // newmap[3]: the tile kernel's dense plane, or the high halves of AccF::pts_inl (5 x u64 records) on the staged / atomic path
   const unsigned int* inl = ctx->rays_fused ? ctx->inl_plane : reinterpret_cast<const unsigned int*>(ctx->acc) + 1;
   const bool sorted = ctx->frame_binned && ctx->bg.raybin;      // the sorted records hold EVERY valid point only with the ray-only bin
@@ -1180,6 +1304,9 @@ int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], cons
     S.sum_q[k] = kind >= 2 ? seen[kind]++ : 0;
   }
   S.any_bayes = nk[2] > 0;
+  // class_bayesian / bayesian_inference reproduce the reference's launch decode (element exists while id * K + q < N): the GLOBAL point
+  // index and cloud size -- a cloud bucketed for a strip renumbers its points
+  CKARG(!(ctx->pts_bucketed && (nk[2] + nk[3]) > 0), "a bucketed cloud (emap_upload_points_strip) cannot feed class_bayesian / bayesian_inference fusions: they decode the global point index");
   if (S.any_bayes) { int rc = ensure_alpha(ctx); if (rc) return rc; }
   if (ctx->frame_binned) {   // the frame's tile-sorted records are still valid: reduce in LDS, no global atomics
     if (ctx->split.on && ctx->split.cap > 0 && !ctx->sem_split_mem && sem_split_possible(S)) {      // the frame listed heavy tiles: their semantic sums are shared too
@@ -1902,7 +2029,7 @@ static int normal_exchange(emap_ctx* ctx) {
 // ---- rays by ray (emap_kernels.hip: k_win_pack / k_win_prepare / k_win_unpack) ---------------------------------------------------
 // Decided from values every rank shares (parameters, world size, cloud size): all ranks take the same branch of the collective code.
 static bool frame_binned_everywhere(const emap_ctx* ctx) {      // emap_count's choice, for a cloud of this size
-  return ctx->n_pts > 0 && (ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts >= 131072));
+  return ctx->n_pts_all > 0 && (ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts_all >= 131072));
 }
 static bool rays_by_ray(const emap_ctx* ctx) {
   if (!ctx->rccl || ctx->comm_world <= 1 || !ctx->prm.enable_visibility_cleanup || ctx->ray_mode == 1) return false;
@@ -2009,6 +2136,12 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   ctx->in_update = true;
   ctx->gate_possible = p.enable_drift_compensation && (position_noise > p.position_noise_thresh || orientation_noise > p.orientation_noise_thresh);
   ctx->byray_frame = rays_by_ray(ctx);        // (before the sort: a by-ray frame sorts only the points of the strip's rows)
+  if (ctx->pts_bucketed) {                    // emap_upload_points_strip: the cloud only holds the points of this strip's rows, for ONE pose
+    if (memcmp(ctx->bucket_R, R, sizeof ctx->bucket_R) != 0 || memcmp(ctx->bucket_t, t, sizeof ctx->bucket_t) != 0) {
+      ctx->in_update = false; ctx->byray_frame = false; ctx->err = "the bound cloud was bucketed for another pose (emap_upload_points_strip)"; return EMAP_ERR_INVALID; }
+    if (p.enable_visibility_cleanup && !ctx->byray_frame) {
+      ctx->in_update = false; ctx->err = "a bucketed cloud cannot feed a visibility pass that marches BY ROW (every valid point marches a ray through every strip): upload the whole cloud, or march by ray (emap_set_ray_mode)"; return EMAP_ERR_INVALID; }
+  }
   rc = emap_count(ctx, R, t);                 // records ST_HIST / ST_SCAN / ST_SCATTER itself
   ctx->in_update = false;
   if (rc) { ctx->byray_frame = false; return rc; }          // "gate" (recorded by emap_count) = per-tile error sums + local sums + all-reduce + gate

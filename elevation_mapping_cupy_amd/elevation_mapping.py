@@ -194,11 +194,13 @@ class ElevationMap:
         """"auto" | "atomic" | "binned": how count/fuse scatter into the map (bit-identical results).
         ``bin_stack`` (test hook) forces bins of that many stacked 16x64 tiles, as maps beyond 16384 tiles use."""
         self._chk(self._lib.emap_set_scatter_mode(self._ctx, {"auto": 0, "atomic": 1, "binned": 2}[mode] | (int(bin_stack) << 8)))
+        self._scatter_mode = mode
 
     def set_ray_mode(self, mode):
         """"auto" | "by_row" | "by_ray": how a SHARDED frame (emap_update_sharded) runs the visibility pass (include/emap_hip.h:
         emap_set_ray_mode; bit-identical results, every rank the same setting)"""
         self._chk(self._lib.emap_set_ray_mode(self._ctx, {"auto": 0, "by_row": 1, "by_ray": 2}[mode]))
+        self._ray_mode = {"auto": 0, "by_row": 1, "by_ray": 2}[mode]
 
     def reload_params(self):
         """Push changed ``self.param`` scalars to the device (kernargs, no recompilation)."""
@@ -301,8 +303,11 @@ class ElevationMap:
     def shift_translation_to_map_center(self, t):
         t -= self.center
 
-    def bind_points(self, points_all):
-        """Upload a host cloud ``(N, 3+K)`` (float32 or float64) and bind it for the next stage calls."""
+    def bind_points(self, points_all, strip_pose=None):
+        """Upload a host cloud ``(N, 3+K)`` (float32 or float64) and bind it for the next stage calls.  ``strip_pose = (R, t)`` (t
+        map-centre relative) on a row-strip context: only the points that can land in this strip's rows under that pose are converted
+        and uploaded (include/emap_hip.h: emap_upload_points_strip -- the frame must then use the same pose and must not march its
+        rays by row); returns the number of points bound."""
         pts = np.asarray(points_all)
         if pts.dtype == np.float64:
             pts = np.ascontiguousarray(pts)
@@ -311,10 +316,30 @@ class ElevationMap:
             pts = np.ascontiguousarray(pts, np.float32)
             dtype = 0
         assert pts.ndim == 2 and pts.shape[1] >= 3
+        if strip_pose is not None:
+            R, t = self._rt(*strip_pose)
+            kept = ct.c_int64(0)
+            self._chk(self._lib.emap_upload_points_strip(self._ctx, ct.c_void_p(pts.ctypes.data), ct.c_int64(pts.shape[0]),
+                                                         ct.c_int64(pts.shape[1]), dtype, f32p(R), f32p(t), ct.byref(kept)))
+            self._n_bound = int(kept.value)
+            self._bound_host = None                 # (the bound cloud is a subset: nothing indexes the host copy by point)
+            return self._n_bound
         self._chk(self._lib.emap_upload_points(self._ctx, ct.c_void_p(pts.ctypes.data), ct.c_int64(pts.shape[0]),
                                                ct.c_int64(pts.shape[1]), dtype))
         self._n_bound = pts.shape[0]
         self._bound_host = pts
+        return self._n_bound
+
+    def strip_point_mask(self, points_all, R, t):
+        """which points ``bind_points(points_all, strip_pose=(R, t))`` would upload (bool array; all True on a whole-map context)"""
+        pts = np.asarray(points_all)
+        dtype = 1 if pts.dtype == np.float64 else 0
+        pts = np.ascontiguousarray(pts) if dtype else np.ascontiguousarray(pts, np.float32)
+        R, t = self._rt(R, t)
+        keep = np.zeros(pts.shape[0], np.uint8)
+        self._chk(self._lib.emap_strip_point_mask(self._ctx, ct.c_void_p(pts.ctypes.data), ct.c_int64(pts.shape[0]), ct.c_int64(pts.shape[1]), dtype,
+                                                  f32p(R), f32p(t), keep.ctypes.data_as(ct.POINTER(ct.c_uint8))))
+        return keep.astype(bool)
 
     def bind_points_device(self, dev_ptr, n, stride):
         """Bind a device-resident float32 cloud (raw pointer) without copying."""

@@ -409,8 +409,37 @@ class ShardedElevationMap:
     def move(self, delta_position):
         self.e.move(delta_position)
 
+    def buckets_clouds(self, n_points, channels=None):
+        """Can this map's frames run on a cloud BUCKETED per rank (every rank uploads only the points of its rows,
+        emap_upload_points_strip)?  Needs the library's own frame (native communicator), no visibility pass that marches by row
+        (every valid point marches a ray through every strip then), and no fusion that decodes the global point index."""
+        if not isinstance(self.comm, NativeComm) or self.comm.world <= 1:
+            return False
+        m = self.e.map
+        C = int(m.param.cell_n) if hasattr(m, "param") else self.e.C
+        by_ray = frame_marches_by_ray(C, int(n_points), self.comm.world, "native", getattr(m, "_ray_mode", 0), getattr(m, "_scatter_mode", "auto"))
+        if self.rays_on and not by_ray:
+            return False
+        if channels is not None and len(channels) > 3 and m.semantic_map is not None:
+            _, fusions = m.semantic_map.prepare(list(channels[3:]))
+            if any(f in ("pointcloud_class_bayesian", "pointcloud_bayesian_inference", "pointcloud_class_max", "class_bayesian", "bayesian_inference", "class_max") for f in fusions):
+                return False
+        return True
+
+    def input_pointcloud(self, points, channels, R, t, position_noise, orientation_noise):
+        """ElevationMap.input_pointcloud (EM/elevation_mapping.py:434-466) on a sharded map: EVERY rank is handed the same sensor cloud
+        (``points``: host (N, 3 + K)); ``t`` is map-centre relative.  Where the frame allows it (buckets_clouds) a rank converts,
+        uploads and streams only the points of its rows -- 1 / world of the cloud per rank instead of all of it."""
+        pts = np.asarray(points)
+        names = list(channels) if channels is not None else None
+        if self.buckets_clouds(pts.shape[0], names):
+            self.e.map.bind_points(pts, strip_pose=(R, t))
+        else:
+            self.e.map.bind_points(pts)
+        self.update(R, t, position_noise, orientation_noise, names if (names is not None and len(names) > 3) else None)
+
     def update(self, R, t, position_noise, orientation_noise, channels=None):
-        """One frame on the bound (replicated) cloud; ``t`` is map-centre relative.  ``channels`` (names of ALL cloud columns,
+        """One frame on the bound cloud (replicated, or bucketed by input_pointcloud); ``t`` is map-centre relative.  ``channels`` (names of ALL cloud columns,
         x, y, z first) additionally fuses the extra columns into the strip's RGB / semantic layers (BASELINE config 5)."""
         e, c = self.e, self.comm
         extra = list(channels[3:]) if channels is not None else None      # x, y, z are not layers (input_pointcloud forwards channels[3:])

@@ -98,6 +98,18 @@ int emap_clear(emap_ctx* ctx);
  * A cloud with extra channels (stride > 3) is de-interleaved while it is converted: on the device it is an (n, 3) xyz matrix
  * and an (n, stride - 3) channel matrix (the reference keeps the interleaved rows and strides over them in every kernel). */
 int emap_upload_points(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype);
+/* Row strips (multi-GPU): every rank is handed the SAME sensor cloud, but only the points of its rows reach its tile kernels.  Converts,
+ * uploads and binds only the points that can land in this strip's rows under the pose (R, t map-centre relative, as emap_update takes
+ * them) -- a conservative superset decided on the host, order preserved, so the strip's maps stay bit-identical -- i.e. 1 / G of the
+ * cloud crosses PCIe and is streamed per rank (reference side: input_pointcloud uploads the whole cloud, EM/elevation_mapping.py:434-466;
+ * SURVEY 8(e) "host bucket by strip").  The frame that follows must use the same pose and must not march its rays BY ROW
+ * (emap_update_sharded checks both); class_bayesian / bayesian_inference fusions need the whole cloud (global point index).  On a
+ * whole-map context it is emap_upload_points.  n_kept (may be NULL): points bound. */
+int emap_upload_points_strip(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype, const float R[9], const float t[3], int64_t* n_kept);
+/* the same predicate as data: keep[i] = 1 iff emap_upload_points_strip would upload point i (for callers that keep their clouds on
+ * the device and bucket them themselves; they then declare the bound cloud with emap_declare_points_bucketed) */
+int emap_strip_point_mask(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype, const float R[9], const float t[3], uint8_t* keep);
+int emap_declare_points_bucketed(emap_ctx* ctx, const float R[9], const float t[3], int64_t n_all);   /* n_all: size of the whole cloud */
 /* bind a device-resident float32 cloud without copying (update_map_with_kernel takes device arrays, :316) */
 int emap_set_points_device(emap_ctx* ctx, const float* dev, int64_t n, int64_t stride);
 /* the same for a cloud that is already de-interleaved on the device (what emap_upload_points produces): xyz (n, 3) and the

@@ -46,6 +46,10 @@ def main():
     ap.add_argument("--no-lockstep", action="store_true")
     ap.add_argument("--skip-single", action="store_true", help="profiling aid: run the single context only briefly (its kernels would mix into a rocprofv3 --stats summary of the strips)")
     ap.add_argument("--interleaved-cloud", action="store_true", help="cfg5: interleaved (N, 7) device rows instead of the de-interleaved layout of an uploaded cloud")
+    ap.add_argument("--replicated-cloud", action="store_true", help="every rank binds the WHOLE cloud (rounds 1-4); default: a rank binds only the points "
+                    "that can land in its rows wherever the frame allows it (emap_strip_point_mask = what emap_upload_points_strip uploads)")
+    ap.add_argument("--scene", default="uniform", choices=["uniform", "terrain"], help="terrain (1024^2 only): the scan-ordered, ray-cast scene of "
+                    "tests/_fixtures.py: terrain_cloud -- one heavy tile under the sensor, 86 %% of the cells never seen")
     ap.add_argument("--ray-mode", default="auto", choices=["auto", "by_row", "by_ray"], help="with --rays: how the sharded frame runs the visibility "
                     "pass (emap_set_ray_mode; auto = by ray from 2048^2 cells on)")
     a = ap.parse_args()
@@ -63,9 +67,14 @@ def main():
     cfg = bench.workload_cfg("cfg3" if a.rays else "cfg2")
     weights = bench.load_weights()
     hip = bench.Hip(); hip.set_device(0)
-    clouds_host = bench.host_clouds(ba, C, N, multimodal)
+    if a.scene == "terrain":
+        import _fixtures as fx
+        assert C == 1024 and not multimodal, "the terrain scene is built for the 1024^2 map"
+        clouds_host = [fx.terrain_cloud(C, 2000, 500, s_, shift=sh) for s_, sh in enumerate((0.0, 0.4, -0.3, 0.2))]
+        N = clouds_host[0].shape[0]
+    else:
+        clouds_host = bench.host_clouds(ba, C, N, multimodal)
     clouds_dev = bench.device_clouds(hip, clouds_host, not a.interleaved_cloud)
-    del clouds_host
     R = np.eye(3, dtype=np.float32).ravel().copy(); t = np.array([0, 0, 1], np.float32)
     Rp, tp = _lib.f32p(R), _lib.f32p(t)
     channels = ["rgb", "sem0", "sem1", "sem2"] if multimodal else None
@@ -88,14 +97,32 @@ def main():
             em.semantic_map.prepare(channels)
         em._rows01 = [int(r0), int(r1)]
         em.set_ray_mode(a.ray_mode)
+        # the rank's clouds: the whole ones, or -- where the frame allows it -- only the points that can land in its rows
+        em._clouds, em._n_local, em._bucketed = clouds_dev, [N] * len(clouds_dev), False
+        if G > 1 and not a.replicated_cloud and (not a.rays or by_ray):
+            local = []
+            for p_ in clouds_host:
+                q_ = np.ascontiguousarray(p_[em.strip_point_mask(p_, R, t)])
+                local.append(q_ if q_.shape[0] else np.full((1, p_.shape[1]), np.nan, np.float32))
+            em._n_local = [q_.shape[0] for q_ in local]
+            em._clouds = bench.device_clouds(hip, local, not a.interleaved_cloud)
+            em._bucketed = True
         return em
+
+    def drop_rank(em):
+        if em._bucketed:
+            bench.free_clouds(hip, em._clouds)
+        em.close()
 
     def frame_fn(em, sharded_frame):
         lib, ctx = em._lib, em._ctx
         call = lib.emap_update_sharded if sharded_frame else lib.emap_update
 
         def frame(i, stats=None):
-            rc = bench.bind_cloud(lib, ctx, clouds_dev[i % len(clouds_dev)], N)
+            k = i % len(em._clouds)
+            rc = bench.bind_cloud(lib, ctx, em._clouds[k], em._n_local[k])
+            if em._bucketed:
+                rc = rc or lib.emap_declare_points_bucketed(ctx, Rp, tp, ct.c_int64(N))
             rc = rc or call(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
             if rc:
                 raise RuntimeError(lib.emap_last_error(ctx).decode())
@@ -170,12 +197,14 @@ def main():
            "splits": {}}
 
     out["ray_mode"] = ("by ray" if by_ray else "by row") if a.rays else None
+    out["scene"] = a.scene
+    out["cloud"] = "replicated to every rank" if (a.replicated_cloud or (a.rays and not by_ray)) else "bucketed per rank (emap_strip_point_mask: the points that can land in the rank's rows)"
     for G in [g for g in a.gs if g > 1]:
         # ---- solo: every rank alone, loop-back collectives ----------------------------------------------------------------------------
         # (not with rays by ray: a rank alone sees only its own rows in the all-reduced ray window -- every other cell reads as unknown,
         #  and the march would queue a visit for each of them; the lockstep run below has the real window)
         os.environ["STREAM_RCCL_LOOPBACK"] = "1"
-        solo, stages, rows = [], [], []
+        solo, stages, rows, shares = [], [], [], []
         for rank in range(G if not by_ray else 0):
             em = make_rank(G, rank, True)
             comm_init(em, new_uid(em._lib), rank, G)
@@ -185,13 +214,14 @@ def main():
             stg, _ = bench.stage_profile(em._lib, em._ctx, lambda i, s: fr(i), min(a.steps, 10), with_stats=False)
             stages.append({k: round(max(v - ev, 0.0), 5) for k, v in stg.items()})
             rows.append(em._rows01)
+            shares.append(round(max(em._n_local) / float(N), 4))
             em._lib.emap_comm_destroy(em._ctx)
-            em.close()
+            drop_rank(em)
         os.environ["STREAM_RCCL_LOOPBACK"] = "0"
         sp = {}
         if solo:
             slow = int(np.argmax(solo))
-            sp = {"rows": rows, "solo_frame_ms_per_rank": [round(v, 5) for v in solo], "solo_frame_ms_max": round(max(solo), 5),
+            sp = {"rows": rows, "cloud_share_per_rank": shares, "stage_ms_net_per_rank": stages, "solo_frame_ms_per_rank": [round(v, 5) for v in solo], "solo_frame_ms_max": round(max(solo), 5),
                   "solo_frame_ms_sum": round(sum(solo), 5), "stage_ms_net_slowest_rank": stages[slow], "stage_ms_net_rank0": stages[0],
                   "hist_plus_scatter_ms_max": round(max(s["hist"] + s["scatter"] for s in stages), 5),
                   "speedup_solo_no_wire": round(single_ms / max(solo), 3)}
@@ -228,7 +258,7 @@ def main():
             if errs:
                 raise errs[0]
             for em in ems:
-                em.close()
+                drop_rank(em)
             lock = float(np.median(walls))
             sp.update({"lockstep_frame_ms_all_ranks_one_gpu": round(lock, 5), "work_inflation_vs_single": round(lock / single_ms, 3),
                        "lockstep_ms_per_rank_average": round(lock / G, 5), "speedup_bound_from_lockstep": round(G * single_ms / lock, 3)})
