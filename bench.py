@@ -906,6 +906,8 @@ def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag
     all_stage = rdv.gather_json(tag + "stage_ms", {k: round(v, 5) for k, v in stage_ms.items()})
     rows = rdv.gather_json(tag + "rows", [int(r0), int(r1)])
     shares = rdv.gather_json(tag + "share", round(max(n_local) / float(N), 4))
+    wb = ct.c_uint64(0)
+    wire_bytes = int(wb.value) if lib.emap_comm_wire_bytes(ctx, ct.byref(wb)) == 0 else None
     rec = {"ok": True, "wall": wall, "stage_ms": stage_ms, "clouds_host": clouds_host, "cfg": cfg, "weights": weights, "R": R, "t": t}
     if rank == 0:
         L = C * C
@@ -928,6 +930,7 @@ def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag
                        "physical_devices": min(ndev, world),
                        "strip_rows": rows, "strip_heights": "equal ray work (thin around the sensor)" if row_w is not None else "equal",
                        "rays": ("by ray over an all-reduced window" if by_ray else "by row") if rays else "off",
+                       "by_ray_wire_bytes_per_frame": wire_bytes if by_ray else None,
                        "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame, RCCL issued by the C library "
                                       "(halo exchange in place on a second stream); bootstrap: file rendezvous, no torch",
                        "cloud": "device resident (H2D excluded)"}})

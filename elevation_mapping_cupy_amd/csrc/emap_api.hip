@@ -27,7 +27,7 @@ void launch_gate(hipStream_t, const GateArgs&, ErrSlot*, FrameDev*, int, double*
 void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, Cells, AccF*, const FrameDev*);
 void launch_commit(hipStream_t, const KP&, Cells, const AccF*, const FrameDev*, unsigned long long*);
 void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, Cells, const AccRView&, const float*, long, FrameDev*, bool, const unsigned long long*, const unsigned int*, int, const float*, const unsigned int*, const unsigned int*);
-void launch_win_pack(hipStream_t, const KP&, const Win&, Cells, const float*, long, const unsigned int*, const unsigned long long*);
+void launch_win_pack(hipStream_t, const KP&, const Win&, Cells, const float*, long, const unsigned int*, const unsigned long long*, float);
 void launch_win_prepare(hipStream_t, const Win&, int);
 void launch_win_unpack(hipStream_t, const KP&, const Win&, AccR*);
 void launch_ray_apply(hipStream_t, const KP&, Cells, AccR*, unsigned long long*, const OverlapArgs&, FrameDev*);
@@ -183,7 +183,8 @@ struct emap_ctx {
   // rays by ray (multi-GPU frames with a visibility pass): the replicated ray window around the sensor (emap_device.h: Win)
   int ray_mode;                 // 0 auto (by ray from 2048^2 cells on), 1 always by row, 2 by ray whenever the frame allows it
   bool byray_frame;             // the current sharded frame marches its rays by ray
-  unsigned int* win_state; unsigned long long* win_bits; float* win_thr; long long* win_dh; unsigned int* win_key; long win_cap;
+  size_t wire_bytes;            // payload of the last by-ray frame's three all-reduces (bytes per rank)
+  unsigned int* win_state; unsigned int* win_rec; unsigned long long* win_bits; float* win_thr; long long* win_dh; unsigned int* win_key; long win_cap;
   hipStream_t comm_stream; hipEvent_t ev_ready, ev_done; double* comm_sums;   // [0..1] local err_sum / err_cnt, [2..3] totals, [4..36) emap_comm_allreduce_host
   // the un-shifted normal planes after a row shift (normal_exchange): a row-aligned copy of the rows this strip's cells belong to
   std::vector<int> cut_begin, cut_count;   // every rank's owned PHYSICAL rows (gathered by emap_comm_init)
@@ -409,7 +410,7 @@ int emap_destroy(emap_ctx* ctx) {
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   emap_comm_destroy(ctx);
-  hipFree(ctx->win_state); hipFree(ctx->win_bits); hipFree(ctx->win_thr); hipFree(ctx->win_dh); hipFree(ctx->win_key);
+  hipFree(ctx->win_state); hipFree(ctx->win_rec); hipFree(ctx->win_bits); hipFree(ctx->win_thr); hipFree(ctx->win_dh); hipFree(ctx->win_key);
   for (int i = 0; i <= ST_N; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   if (ctx->t0) hipEventDestroy(ctx->t0);
   if (ctx->t1) hipEventDestroy(ctx->t1);
@@ -2062,9 +2063,10 @@ static long window_cap(const emap_ctx* ctx) {
 }
 static int alloc_window(emap_ctx* ctx, long cap) {
   CK(hipStreamSynchronize(ctx->stream));
-  hipFree(ctx->win_state); hipFree(ctx->win_bits); hipFree(ctx->win_thr); hipFree(ctx->win_dh); hipFree(ctx->win_key);
-  ctx->win_state = nullptr; ctx->win_bits = nullptr; ctx->win_thr = nullptr; ctx->win_dh = nullptr; ctx->win_key = nullptr; ctx->win_cap = 0;
-  CK(hipMalloc((void**)&ctx->win_state, sizeof(unsigned int) * 12 * (size_t)cap));      // hot 4 + cold 4 + normals 3 + inlier count 1 words per cell
+  hipFree(ctx->win_state); hipFree(ctx->win_rec); hipFree(ctx->win_bits); hipFree(ctx->win_thr); hipFree(ctx->win_dh); hipFree(ctx->win_key);
+  ctx->win_state = nullptr; ctx->win_rec = nullptr; ctx->win_bits = nullptr; ctx->win_thr = nullptr; ctx->win_dh = nullptr; ctx->win_key = nullptr; ctx->win_cap = 0;
+  CK(hipMalloc((void**)&ctx->win_state, sizeof(unsigned int) * 12 * (size_t)cap));      // hot 4 + cold 4 + normals 3 + wall flag 1 words per cell (local expansion)
+  CK(hipMalloc((void**)&ctx->win_rec, sizeof(unsigned int) * 8 * (size_t)cap));         // the 32-byte records that travel
   CK(hipMalloc((void**)&ctx->win_bits, sizeof(unsigned long long) * ((size_t)cap / 64 + 2)));
   CK(hipMalloc((void**)&ctx->win_thr, sizeof(float) * ((size_t)cap / 64 + 1)));
   CK(hipMalloc((void**)&ctx->win_dh, sizeof(long long) * 2 * (size_t)cap));
@@ -2080,7 +2082,7 @@ static int ensure_window(emap_ctx* ctx, Win* w) {
   if (n > ctx->win_cap) { int rc = alloc_window(ctx, std::max(n + n / 8, window_cap(ctx))); if (rc) return rc; }
   w->hot = reinterpret_cast<float4*>(ctx->win_state); w->cold = w->hot + n;
   w->normal = reinterpret_cast<float*>(w->cold + n); w->inl = ctx->win_state + 11 * n;
-  w->bits = ctx->win_bits; w->thr = ctx->win_thr; w->dh = ctx->win_dh; w->key = ctx->win_key;
+  w->bits = ctx->win_bits; w->thr = ctx->win_thr; w->dh = ctx->win_dh; w->key = ctx->win_key; w->rec = ctx->win_rec;
   return EMAP_OK;
 }
 // The visibility pass of a sharded frame, by ray: called where emap_rays would be, between the tile kernel and k_ray_apply.
@@ -2091,14 +2093,15 @@ static int rays_by_ray_pass(emap_ctx* ctx, const float R[9], const float t[3]) {
   const RcclApi* a = ctx->rccl;
   const long n = (long)w.nr * w.nc;
   hipStream_t st = ctx->stream;
-  // (1) the window's cells, normals and inlier counts: owners fill their rows, an exact integer all-reduce replicates them
-  CK(hipMemsetAsync(ctx->win_state, 0, sizeof(unsigned int) * 12 * (size_t)n, st));
+  // (1) the window's cells, normals and wall flags as 32-byte records: owners fill their rows, an exact integer all-reduce replicates them
+  CK(hipMemsetAsync(ctx->win_rec, 0, sizeof(unsigned int) * 8 * (size_t)n, st));
   KP kpk = ctx->kp;
   kpk.nlag = ctx->nlag_ready ? 1 : 0;
   launch_win_pack(st, kpk, w, ctx->cells, ctx->nlag_ready ? ctx->nlag_buf : ctx->normal, ctx->nlag_ready ? (long)ctx->strip.row_count * ctx->prm.cell_n : ctx->ncells_alloc,
-                  ctx->inl_plane, ctx->inert);
+                  ctx->inl_plane, ctx->inert, ctx->rt.f_wall);
   CK(hipGetLastError());
-  CKN(a->AllReduce(ctx->win_state, ctx->win_state, 12 * (size_t)n, ncclUint32, ncclSum, ctx->comm, st));
+  CKN(a->AllReduce(ctx->win_rec, ctx->win_rec, 8 * (size_t)n, ncclUint32, ncclSum, ctx->comm, st));
+  ctx->wire_bytes = 32 * (size_t)n + 16 * (size_t)n + 4 * (size_t)n;      // per rank and frame: the window records + the effects ({dec, hits} sums, key maxima) that come back
   // (2) bitmap + block thresholds of the window, accumulators re-armed
   launch_win_prepare(st, w, ctx->prm.cell_n);
   CK(hipMemsetAsync(w.bits + n / 64, 0xff, sizeof(unsigned long long), st));          // the all-ones word behind the last row (k_rays' passive lanes)
@@ -2136,6 +2139,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   ctx->in_update = true;
   ctx->gate_possible = p.enable_drift_compensation && (position_noise > p.position_noise_thresh || orientation_noise > p.orientation_noise_thresh);
   ctx->byray_frame = rays_by_ray(ctx);        // (before the sort: a by-ray frame sorts only the points of the strip's rows)
+  ctx->wire_bytes = 0;
   if (ctx->pts_bucketed) {                    // emap_upload_points_strip: the cloud only holds the points of this strip's rows, for ONE pose
     if (memcmp(ctx->bucket_R, R, sizeof ctx->bucket_R) != 0 || memcmp(ctx->bucket_t, t, sizeof ctx->bucket_t) != 0) {
       ctx->in_update = false; ctx->byray_frame = false; ctx->err = "the bound cloud was bucketed for another pose (emap_upload_points_strip)"; return EMAP_ERR_INVALID; }
@@ -2194,6 +2198,12 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
     for (int i = 0; i < ST_N; ++i) CK(hipEventElapsedTime(&ctx->stage_ms[i], ctx->ev[i], ctx->ev[i + 1]));
   }
   if (stats) return emap_get_stats(ctx, stats);
+  return EMAP_OK;
+}
+
+int emap_comm_wire_bytes(emap_ctx* ctx, uint64_t* bytes) {
+  CKARG(ctx && bytes, "null argument");
+  *bytes = (uint64_t)ctx->wire_bytes;
   return EMAP_OK;
 }
 

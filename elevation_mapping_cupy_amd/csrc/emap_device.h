@@ -128,7 +128,11 @@ __device__ __forceinline__ unsigned int* accr_key(const AccRView& A, unsigned in
 // max) and the owners take their rows back (k_win_unpack).
 struct Win {
   int r0, c0, nr, nc;
-  float4* hot; float4* cold; float* normal; unsigned int* inl;      // nr * nc elements each (normal: 3 planes)
+  // what travels: ONE 32-byte record per cell {h, v, time, upper, n0, n1, n2, flags} -- flags bit 0: valid >= 0.5, 1: is_upper >= 0.5,
+  // 2: quiet (snapshot S1), 3: this frame's drift inliers exceed wall_num_thresh -- everything the march and the window's bitmap /
+  // thresholds read of a cell (round 5; until round 4 the 48 bytes of the two half cells, float normals and the inlier COUNT)
+  unsigned int* rec;                                                 // 8 words per cell
+  float4* hot; float4* cold; float* normal; unsigned int* inl;      // nr * nc elements each (normal: 3 planes), expanded from rec by k_win_prepare on every rank; inl = the flag
   unsigned long long* bits; float* thr;                              // nr * nc / 64 words (+ an all-ones word); (nr / 8) * (nc / 8) thresholds
   long long* dh; unsigned int* key;                                  // {dec, hits} pairs and keys of the window's cells
 };

@@ -393,8 +393,9 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
             }
             const float ip = erx * Qf<MODE>(n0) + ery * Qf<MODE>(n1) + erz * Qf<MODE>(n2);
             if (!(fabsf(ip) < Rt.f_cos_thresh)) {
-              const float n_inl = (float)inl[(long)c * inl_stride];      // newmap[3]: drift inliers of this frame in the cell
-              if (!(n_inl > Rt.f_wall && m1.x < 1.0f)) {
+              // newmap[3]: drift inliers of this frame in the cell; a ray window carries the comparison's result, evaluated by the cell's owner (k_win_pack)
+              const bool wall = P.wmode ? inl[(long)c * inl_stride] != 0u : (float)inl[(long)c * inl_stride] > Rt.f_wall;
+              if (!(wall && m1.x < 1.0f)) {
                 contrib = true; c_hit = 1u;
                 c_dec = __double2ll_rn((double)edec * EM_SCALE_V);
                 if (nz < m1.y || m1.z < 0.5f) c_key = ~float_ord(nz);
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cells cells, AccR*
 //   k_win_unpack   after the all-reduce of the effects: the owners move their rows into their AccR records (k_ray_apply follows)
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(EM_BLOCK) void k_win_pack(KP P, Win W, Cells cells, const float* __restrict__ normal, long plane_stride,
-                                                       const unsigned int* __restrict__ inl_plane, const unsigned long long* __restrict__ inert) {
+                                                       const unsigned int* __restrict__ inl_plane, const unsigned long long* __restrict__ inert, float f_wall) {
   const long k = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (k >= (long)W.nr * W.nc) return;
   const int wr = (int)(k / W.nc), wc = (int)(k - (long)wr * W.nc), lr = W.r0 + wr, lc = W.c0 + wc;
@@ -654,15 +655,16 @@ __global__ __launch_bounds__(EM_BLOCK) void k_win_pack(KP P, Win W, Cells cells,
   const long c = (long)(rel + P.halo) * P.C + pcol;
   const float4 h = cells.hot[c], cd = cells.cold[c];
   const unsigned long long word = inert[(long)bitmap_row(P, prow) * ((P.C + 63) / 64) + (lc >> 6)];   // bitmap: LOGICAL column, local row
-  const float quiet = ((word >> (lc & 63)) & 1ull) ? 1.0f : 0.0f;
-  W.hot[k] = h;
-  W.cold[k] = make_float4(cd.x, cd.y, cd.z, quiet);
+  const bool quiet = (word >> (lc & 63)) & 1ull;
   float n0 = 0.f, n1 = 0.f, n2 = 0.f;                                       // the normal planes keep the origin they were written with (k_rays)
   const long cn = normal_index(P, rel, lr, lc);
   if (cn >= 0) { n0 = normal[cn]; n1 = normal[plane_stride + cn]; n2 = normal[2 * plane_stride + cn]; }
-  const long wn = (long)W.nr * W.nc;
-  W.normal[k] = n0; W.normal[wn + k] = n1; W.normal[2 * wn + k] = n2;
-  W.inl[k] = inl_plane[c];
+  // the tests the march makes on (valid, is_upper, inlier count) travel as bits: !(x < 0.5) keeps what `x < 0.5f` decides (NaN included),
+  // and the wall test n_inl > wall_num_thresh (custom_kernels.py:248) is evaluated here, by the owner
+  const unsigned int flags = (!(h.z < 0.5f) ? 1u : 0u) | (!(cd.z < 0.5f) ? 2u : 0u) | (quiet ? 4u : 0u) | ((float)inl_plane[c] > f_wall ? 8u : 0u);
+  uint4* rec = reinterpret_cast<uint4*>(W.rec) + 2 * k;
+  rec[0] = make_uint4(__float_as_uint(h.x), __float_as_uint(h.y), __float_as_uint(cd.x), __float_as_uint(cd.y));
+  rec[1] = make_uint4(__float_as_uint(n0), __float_as_uint(n1), __float_as_uint(n2), flags);
 }
 // One workgroup = 8 window rows x 64 columns.  quiet = the bit the owner's tile kernel derived from snapshot S1.  The visit threshold
 // of a cell that is NOT quiet is a function of (valid, h, upper, is_upper), and for such a cell the averaged state the window holds
@@ -677,6 +679,14 @@ __global__ __launch_bounds__(512) void k_win_prepare(Win W, int C) {
   const long k = (long)wr * W.nc + wc;
   bool quiet = true, other = false;
   float visit_thr = -INFINITY;
+  {   // expand the travelled record into the arrays k_rays addresses (hot / cold half cells, normal planes, the wall flag)
+    const uint4 a = reinterpret_cast<const uint4*>(W.rec)[2 * k], b = reinterpret_cast<const uint4*>(W.rec)[2 * k + 1];
+    const long wn = (long)W.nr * W.nc;
+    W.hot[k] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), (b.w & 1u) ? 1.0f : 0.0f, 0.0f);
+    W.cold[k] = make_float4(__uint_as_float(a.z), __uint_as_float(a.w), (b.w & 2u) ? 1.0f : 0.0f, (b.w & 4u) ? 1.0f : 0.0f);
+    W.normal[k] = __uint_as_float(b.x); W.normal[wn + k] = __uint_as_float(b.y); W.normal[2 * wn + k] = __uint_as_float(b.z);
+    W.inl[k] = (b.w >> 3) & 1u;
+  }
   if (W.r0 + wr < C && W.c0 + wc < C) {
     const float4 h = W.hot[k], cd = W.cold[k];
     quiet = cd.w != 0.0f;
@@ -862,6 +872,41 @@ __device__ __forceinline__ void post_reach_masks(unsigned int* __restrict__ hs, 
     reach[j] = v;
   }
   __syncthreads();
+}
+
+// Round 5: the search itself on those masks.  On a mostly unknown map a hole between two scan rings probed 10-40 cells in LDS before
+// it found a source (terrain scene: the stencil launch 56 us against 20 on white noise).  With the raw SOURCE bits of every region row
+// in LDS (one ballot per row: no smearing, no OR pass) a hole takes the (2d + 1)-bit window of each of its 2d + 1 rows, shifts row dy's
+// window left by dy + d -- after that every anti-diagonal dx + dy = const is ONE bit position in all rows -- and ORs them: the first
+// set bit is the reference's first anti-diagonal with a source (:429-436), the first row that has that bit its first dy; nothing set =
+// no source in reach.  ~60 instructions per hole whatever the distance, the same cell as the probing loop picks (same order).
+template <int PT_THREADS, class SrcFn>
+__device__ __forceinline__ void post_source_masks(unsigned int* __restrict__ sm, int RH, int RW, SrcFn src) {      // 5 words per region row: columns 0 .. 127 + a zero word
+  constexpr int PT_WAVES = PT_THREADS / 64;
+  const int tc = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int r = wv; r < RH; r += PT_WAVES) {
+    const unsigned long long lo = __builtin_amdgcn_ballot_w64(src(r, tc));
+    const unsigned long long hi = __builtin_amdgcn_ballot_w64(64 + tc < RW && src(r, 64 + tc));
+    if (tc == 0) { sm[5 * r] = (unsigned int)lo; sm[5 * r + 1] = (unsigned int)(lo >> 32); sm[5 * r + 2] = (unsigned int)hi; sm[5 * r + 3] = (unsigned int)(hi >> 32); sm[5 * r + 4] = 0u; }
+  }
+  __syncthreads();
+}
+// first source of the hole at region (R0, C0) in the reference's scan order: true + its offsets, false: none within reach
+__device__ __forceinline__ bool post_first_source(const unsigned int* __restrict__ sm, int R0, int C0, int d, int& dy_out, int& dx_out) {
+  const int cs = C0 - d, k = cs >> 5, sh = cs & 31;
+  const unsigned int wmask = (2u << (2 * d)) - 1u;                  // 2d + 1 bits
+  unsigned long long any = 0ull;
+  for (int dy = -d; dy <= d; ++dy) {
+    const unsigned int* m = sm + 5 * (R0 + dy) + k;
+    any |= (unsigned long long)(__builtin_amdgcn_alignbit(m[1], m[0], sh) & wmask) << (dy + d);
+  }
+  if (!any) return false;
+  const int s2 = (int)__builtin_ctzll(any) - 2 * d;                 // the first anti-diagonal dx + dy with a source
+  for (int dy = max(-d, s2 - d); dy <= min(d, s2 + d); ++dy) {
+    const unsigned int* m = sm + 5 * (R0 + dy) + k;
+    if ((__builtin_amdgcn_alignbit(m[1], m[0], sh) >> (s2 - dy + d)) & 1u) { dy_out = dy; dx_out = s2 - dy; return true; }
+  }
+  return false;                                                     // (not reached: the bit came from one of these rows)
 }
 
 // k_post_dma: the same fused stencils with the region staged by gfx950's LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes
@@ -1125,11 +1170,19 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   // filled hole cannot feed another hole (Jacobi semantics of the reference kernel), and the stencils below read one array.
   __syncthreads();
   const unsigned int nh = n_holes;
-  const bool sparse = 4 * (int)nh > 3 * DW * DH && RW <= 128;       // (uniform) three cells of four are holes
-  if (sparse) post_reach_masks<PT_THREADS>(hs, reach, RH, RW, d, [&](int r, int cc) { return reg[(r * rp + min(cc, RW - 1)) * 3 + 1] > 0.5f; });
+  const bool sparse = 4 * (int)nh > 3 * DW * DH && RW <= 128 && d <= 15;       // (uniform) three cells of four are holes
+  if (sparse) {                                                     // mostly unknown tile: the search on bit masks (post_first_source)
+    post_source_masks<PT_THREADS>(hs, RH, RW, [&](int r, int cc) { return reg[(r * rp + min(cc, RW - 1)) * 3 + 1] > 0.5f; });
+    for (unsigned int hi = threadIdx.x; hi < nh; hi += PT_THREADS) {
+      const int pos = holes[hi], r = pos / DW, cc = pos - r * DW;
+      int dy, dx;
+      if (!post_first_source(hs, r + d, cc + d, d, dy, dx)) continue;      // no source within reach: the raw value stays
+      const int o0 = (r + d) * rp + (cc + d);
+      reg[o0 * 3] = reg[(o0 + dy * rp + dx) * 3];                    // a hole's slot is never read by another search (its mask is < 0.5)
+    }
+  } else
   for (unsigned int hi = threadIdx.x; hi < nh; hi += PT_THREADS) {
     const int pos = holes[hi], r = pos / DW, cc = pos - r * DW;
-    if (sparse && !((reach[4 * (r + d) + ((cc + d) >> 5)] >> ((cc + d) & 31)) & 1u)) continue;     // no source within reach: the raw value stays
     const int o0 = (r + d) * rp + (cc + d);
     // first hit on ascending anti-diagonals == the reference's scan order with its signed dx+dy criterion (:429-436)
     bool found = false;
@@ -1367,8 +1420,8 @@ void launch_rays(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, co
     else launch_rays_t<1, false>(s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
   }
 }
-void launch_win_pack(hipStream_t s, const KP& P, const Win& W, Cells cells, const float* normal, long plane_stride, const unsigned int* inl_plane, const unsigned long long* inert) {
-  hipLaunchKernelGGL(k_win_pack, dim3(nblk((long)W.nr * W.nc)), dim3(EM_BLOCK), 0, s, P, W, cells, normal, plane_stride, inl_plane, inert);
+void launch_win_pack(hipStream_t s, const KP& P, const Win& W, Cells cells, const float* normal, long plane_stride, const unsigned int* inl_plane, const unsigned long long* inert, float f_wall) {
+  hipLaunchKernelGGL(k_win_pack, dim3(nblk((long)W.nr * W.nc)), dim3(EM_BLOCK), 0, s, P, W, cells, normal, plane_stride, inl_plane, inert, f_wall);
 }
 void launch_win_prepare(hipStream_t s, const Win& W, int C) {
   hipLaunchKernelGGL(k_win_prepare, dim3(W.nc / 64, W.nr / 8), dim3(512), 0, s, W, C);

@@ -309,6 +309,9 @@ int emap_comm_selftest(emap_ctx* ctx);
 /* number of ranks RCCL itself reports for the communicator (ncclCommCount): what a launcher prints as evidence that the
  * strips really talk through one RCCL communicator of that size */
 int emap_comm_count(emap_ctx* ctx, int32_t* ranks);
+/* payload (bytes per rank) of the collectives the last frame's visibility pass issued when it marched BY RAY: the all-reduced window
+ * records (32 B per window cell) and the effects coming back (20 B per cell); 0 for a frame that marched by row */
+int emap_comm_wire_bytes(emap_ctx* ctx, uint64_t* bytes);
 /* out-of-band reductions over the ranks through the communicator itself (barriers and timing reductions of a launcher:
  * no second bootstrap channel needed once RCCL is up): all-reduce of n <= 16 host doubles, op 0 = sum, 1 = max, in place;
  * blocks until the result is back on the host, i.e. it is also a barrier behind all work enqueued on the strip's stream. */
