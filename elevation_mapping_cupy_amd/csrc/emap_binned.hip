@@ -551,13 +551,15 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
           // map move (the pending moves are written out with this rewrite: the whole cell then takes the slow way).
           const bool inwin = !RAYS && overlap_window(O, logi_row(P, P.row0 + lrow), logi_col(P, col));
           Cell m;
-          bool wcold;
+          bool wcold, whot = true;
+          float4 hq0 = make_float4(0.f, 0.f, 0.f, 0.f);      // the hot half as it lies in memory (no pending moves)
           if (P.mv.n) {                                        // (uniform)
             m = cells[c];
             cell_now(P, m, P.row0 + lrow, col);
             wcold = true;
           } else {
             const float4 hq = s_cell[lc];
+            hq0 = hq;
             const bool fused = s_cnt[lc] != 0u;
             const float4 cq = ((RAYS && !fused) || inwin) ? cells.cold[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             m.h = hq.x; m.v = hq.y; m.valid = hq.z; m.trav = hq.w; m.time = cq.x; m.upper = cq.y; m.is_upper = cq.z; m.pad = 0.f;
@@ -575,7 +577,12 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
           average_cell(P, m, a);
           // clear_overlap_map (:372-375) of a frame WITHOUT a visibility pass rides on this rewrite (with rays: k_ray_apply)
           if (inwin) wcold = overlap_cell(P, O, m) || wcold;
-          cells.hot[c] = make_float4(m.h, m.v, m.valid, m.trav);
+          // A cell that comes out of the frame with the bits it went in with is not stored again: an unknown cell without points
+          // stays (0, initial_variance, 0) whatever the drift shift -- 86 % of the cells of a robot's map, 60 % at 8192^2 / 16 M
+          // points -- and its 16 bytes of write traffic stay away (round 5; the staged copy in LDS is what memory holds).
+          if (P.mv.n == 0) whot = (__float_as_uint(m.h) ^ __float_as_uint(hq0.x)) | (__float_as_uint(m.v) ^ __float_as_uint(hq0.y)) |
+                                  (__float_as_uint(m.valid) ^ __float_as_uint(hq0.z)) | (__float_as_uint(m.trav) ^ __float_as_uint(hq0.w));
+          if (whot) cells.hot[c] = make_float4(m.h, m.v, m.valid, m.trav);
           if (wcold) cells.cold[c] = make_float4(m.time, m.upper, m.is_upper, m.valid);
           if (cnt_plane) cnt_plane[c] = s_cnt[lc];
           if (RAYS) inl_plane[c] = s_inl[lc];

@@ -841,45 +841,18 @@ __device__ __forceinline__ float exp_neg(float a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // SPARSE tiles of the fused stencils.  A hole (mask < 0.5) searches its (2d + 1)^2 neighbourhood for the first source in the
-// reference's scan order and gives up after all 49 reads when there is none -- on a white-noise map a source is two or three reads
-// away, but a real map is mostly UNKNOWN beyond the sensor's dense zone (scan rings further apart than the dilation reach, the shadow
-// of a wall): 86 % holes at 1024^2 on the ray-cast terrain of tests/_fixtures.py, and the stencil launch took 69 us instead of 19.5.
-// When three cells of four of a tile's region are holes (on white noise nearly every hole still has a source in reach then, but such
-// maps are the first frames of a sparse cloud; with the limit at one hole in two the masks cost the 8192^2 stencil launch 22 %), the tile
-// first builds a REACH mask -- bit (r, c) set iff any source lies within
-// the square of radius d around (r, c): per region row the ballot of the source test, smeared d columns to both sides in scalar
-// registers (128 bits per row), then OR-ed over the 2d + 1 rows -- and a hole whose bit is clear skips the search (its value stays,
-// exactly what the search would have left).  Dense tiles pay one uniform branch.  src(r, c): the cell MAY be a source (a superset is fine).
-template <int PT_THREADS, class SrcFn>
-__device__ __forceinline__ void post_reach_masks(unsigned int* __restrict__ hs, unsigned int* __restrict__ reach, int RH, int RW, int d, SrcFn src) {
-  constexpr int PT_WAVES = PT_THREADS / 64;
-  const int tc = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int r = wv; r < RH; r += PT_WAVES) {
-    unsigned long long lo = __builtin_amdgcn_ballot_w64(src(r, tc));
-    unsigned long long hi = __builtin_amdgcn_ballot_w64(64 + tc < RW && src(r, 64 + tc));
-    unsigned long long slo = lo, shi = hi;
-    for (int k = 1; k <= d; ++k) {                                   // (uniform: scalar shifts)
-      slo |= (lo << k) | (lo >> k) | (hi << (64 - k));
-      shi |= (hi << k) | (hi >> k) | (lo >> (64 - k));
-    }
-    if (tc == 0) { hs[4 * r] = (unsigned int)slo; hs[4 * r + 1] = (unsigned int)(slo >> 32); hs[4 * r + 2] = (unsigned int)shi; hs[4 * r + 3] = (unsigned int)(shi >> 32); }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 4 * (RH - 2 * d); i += PT_THREADS) {  // rows d .. RH - d - 1: the only ones that hold holes
-    const int j = i + 4 * d;
-    unsigned int v = 0u;
-    for (int dy = -d; dy <= d; ++dy) v |= hs[j + 4 * dy];
-    reach[j] = v;
-  }
-  __syncthreads();
-}
-
-// Round 5: the search itself on those masks.  On a mostly unknown map a hole between two scan rings probed 10-40 cells in LDS before
-// it found a source (terrain scene: the stencil launch 56 us against 20 on white noise).  With the raw SOURCE bits of every region row
-// in LDS (one ballot per row: no smearing, no OR pass) a hole takes the (2d + 1)-bit window of each of its 2d + 1 rows, shifts row dy's
-// window left by dy + d -- after that every anti-diagonal dx + dy = const is ONE bit position in all rows -- and ORs them: the first
-// set bit is the reference's first anti-diagonal with a source (:429-436), the first row that has that bit its first dy; nothing set =
-// no source in reach.  ~60 instructions per hole whatever the distance, the same cell as the probing loop picks (same order).
+// reference's scan order (ascending anti-diagonals dx + dy, :429-436) and gives up after all 49 reads when there is none -- on a
+// white-noise map a source is two or three reads away, but a real map is mostly UNKNOWN beyond the sensor's dense zone (scan rings
+// further apart than the dilation reach, the shadow of a wall): 86 % holes at 1024^2 on the ray-cast terrain of tests/_fixtures.py, a
+// hole between two scan rings probed 10-40 cells in LDS before it found one, and the stencil launch took 69 us instead of 19.5.
+// Round 4 put a reach mask in front of the search (source ballots smeared by d, OR-ed over 2d + 1 rows: 69 -> 56 us).  Round 5 runs
+// the search itself on bits, in tiles where three cells of four are holes (dense tiles keep the probing loop: one or two probes beat
+// seven window reads): the raw SOURCE bits of every region row go to LDS (one ballot per row, no smearing); a hole takes the
+// (2d + 1)-bit window of each of its 2d + 1 rows and shifts row dy's window left by dy + d -- after that every anti-diagonal
+// dx + dy = const is ONE bit position in all rows -- and ORs them: the first set bit is the first anti-diagonal with a source, the
+// first row that has that bit the first dy of the reference's order; nothing set = no source in reach, the raw value stays.  ~60
+// instructions per hole whatever the distance, the same cell as the probing loop picks: terrain 56 -> 40 us, 8192^2 / 16 M points
+// (79 % holes) 0.947 -> 0.910 ms.
 template <int PT_THREADS, class SrcFn>
 __device__ __forceinline__ void post_source_masks(unsigned int* __restrict__ sm, int RH, int RW, SrcFn src) {      // 5 words per region row: columns 0 .. 127 + a zero word
   constexpr int PT_WAVES = PT_THREADS / 64;
@@ -943,9 +916,8 @@ __global__ __launch_bounds__(512) void k_post_dma(KP P, TravW Wt, Cells cells, f
   float4* raw = reinterpret_cast<float4*>(lds);                             // [RH][RW] cold halves as they lie in HBM
   float* val = lds + 4 * RH * RW;                                           // [RH][vp] upper_bound, holes of the DW x DH region overwritten by their dilated value
   int* rtab = reinterpret_cast<int*>(val + RH * vp);                        // RH + 2 row terms (hole search, epilogue)
-  unsigned int* hs = reinterpret_cast<unsigned int*>(rtab + ((RH + 3) & ~1));      // sparse tiles: smeared source rows, reach mask (4 words per region row each)
-  unsigned int* reach = hs + 4 * RH;
-  unsigned short* holes = reinterpret_cast<unsigned short*>(reach + 4 * RH);
+  unsigned int* hs = reinterpret_cast<unsigned int*>(rtab + ((RH + 3) & ~1));      // sparse tiles: source bits of the region rows, 5 words each (post_source_masks); 8 words per row reserved
+  unsigned short* holes = reinterpret_cast<unsigned short*>(hs + 8 * RH);
   __shared__ unsigned int n_holes;
   if (threadIdx.x == 0) n_holes = 0u;
   const int C = P.C;
@@ -997,11 +969,23 @@ __global__ __launch_bounds__(512) void k_post_dma(KP P, TravW Wt, Cells cells, f
   // criterion (:429-436).  Sources are cells with mask > 0.5 that exist and are is_inside (custom_kernels.py:34-44); a source is
   // never a hole, so the in-place writes cannot feed another search (Jacobi semantics of the reference kernel).
   const unsigned int nh = n_holes;
-  const bool sparse = 4 * (int)nh > 3 * DW * DH && RW <= 128;       // (uniform) three cells of four are holes
-  if (sparse) post_reach_masks<PT_THREADS>(hs, reach, RH, RW, d, [&](int r, int cc) { const float4 q = raw[r * RW + min(cc, RW - 1)]; return q.z + q.w > 0.5f; });
+  const bool sparse = 4 * (int)nh > 3 * DW * DH && RW <= 128 && d <= 15;       // (uniform) three cells of four are holes
+  if (sparse) {                                                     // mostly unknown tile: the search on bit masks (post_first_source)
+    post_source_masks<PT_THREADS>(hs, RH, RW, [&](int r, int cc) {
+      const int c1 = min(cc, RW - 1);
+      const float4 q = raw[r * RW + c1];
+      int dr, pc, fl;
+      col_terms(c1, dr, pc, fl);
+      return q.z + q.w > 0.5f && ((rtab[r + 1 + dr] | fl) & (int)0xC0000000) == 0;      // a source: mask > 0.5, exists, is_inside
+    });
+    for (unsigned int hi = threadIdx.x; hi < nh; hi += PT_THREADS) {
+      const int pos = holes[hi], r = pos / DW + d, cc = pos - (pos / DW) * DW + d;
+      int dy, dx;
+      if (post_first_source(hs, r, cc, d, dy, dx)) val[r * vp + cc] = raw[(r + dy) * RW + cc + dx].y;
+    }
+  } else
   for (unsigned int hi = threadIdx.x; hi < nh; hi += PT_THREADS) {
     const int pos = holes[hi], r = pos / DW + d, cc = pos - (pos / DW) * DW + d;
-    if (sparse && !((reach[4 * r + (cc >> 5)] >> (cc & 31)) & 1u)) continue;     // no source within reach
     bool found = false;
     for (int s2 = -2 * d; s2 <= 2 * d && !found; ++s2) {
       const int dy0 = max(-d, s2 - d), dy1 = min(d, s2 + d);
@@ -1050,9 +1034,8 @@ __global__ __launch_bounds__(PT_R >= 32 ? POST_T32 : 512) void k_post(KP P, Trav
   // is_valid (normal filter).  One 12-byte LDS write per staged cell; a stride of three dwords across the lanes is conflict free.
   float* reg = lds;
   int* rtab = reinterpret_cast<int*>(reg + 3 * RH * rp);       // RH + 2 row terms
-  unsigned int* hs = reinterpret_cast<unsigned int*>(rtab + ((RH + 3) & ~1));      // sparse tiles: smeared source rows, reach mask (post_reach_masks)
-  unsigned int* reach = hs + 4 * RH;
-  unsigned short* holes = reinterpret_cast<unsigned short*>(reach + 4 * RH);      // compacted list of the holes of the DW x DH region
+  unsigned int* hs = reinterpret_cast<unsigned int*>(rtab + ((RH + 3) & ~1));      // sparse tiles: source bits of the region rows, 5 words each (post_source_masks)
+  unsigned short* holes = reinterpret_cast<unsigned short*>(hs + 8 * RH);         // compacted list of the holes of the DW x DH region
   __shared__ unsigned int n_holes, s_special;
   if (threadIdx.x == 0) { n_holes = 0u; s_special = 0u; }
   __syncthreads();
