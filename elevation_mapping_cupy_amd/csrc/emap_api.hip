@@ -30,7 +30,7 @@ void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float
 void launch_win_pack(hipStream_t, const KP&, const Win&, Cells, const float*, long, const unsigned int*, const unsigned long long*, float);
 void launch_win_prepare(hipStream_t, const Win&, int);
 void launch_win_unpack(hipStream_t, const KP&, const Win&, AccR*);
-void launch_ray_apply(hipStream_t, const KP&, Cells, AccR*, unsigned long long*, const OverlapArgs&, FrameDev*);
+void launch_ray_apply(hipStream_t, const KP&, Cells, AccR*, unsigned long long*, const OverlapArgs&, FrameDev*, unsigned int*);
 void launch_average(hipStream_t, const KP&, Cells, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*, const OverlapArgs&);
 static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, const ChanView&, double*, unsigned int*, long);
@@ -430,6 +430,10 @@ int emap_clear(emap_ctx* ctx) {
   CK(hipMemsetAsync(ctx->accr, 0, sizeof(AccR) * ctx->ncells_alloc, ctx->stream));
   CK(hipMemsetAsync(ctx->slots, 0, sizeof(ErrSlot) * EM_ERR_SLOTS, ctx->stream));
   CK(hipMemsetAsync(ctx->frame, 0, sizeof(FrameDev), ctx->stream));
+  if (ctx->split_need) {              // FrameDev::ray_class and its host-mapped mirror restart together (no frame is in flight after the wait)
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->split_need[1] = 0u;
+  }
   ctx->committed = false;
   CK(hipGetLastError());
   return EMAP_OK;
@@ -754,7 +758,10 @@ static int ensure_bins(emap_ctx* ctx, bool raybin) {
   // strip contexts without a visibility pass: cheap ownership test + lane compaction in the point passes (emap_binned.hip)
   // ... and strips whose frame marches its rays BY RAY: a rank then needs exactly the points of its rows (the valid ones that are not
   // is_inside ride in the ray-only bin) -- the other ranks march the rest
-  ctx->bin_strip = ctx->strip.row_count < ctx->prm.cell_n && (!raybin || ctx->byray_frame);
+  // ... but not for a cloud that was BUCKETED for this strip on the host (emap_upload_points_strip): nearly every point is an owned one
+  // then, the ownership pre-test and the staging record (16 B written + read per point) buy nothing -- the plain kernels sort 2 M
+  // points in 42 us where the strip variants take 52
+  ctx->bin_strip = ctx->strip.row_count < ctx->prm.cell_n && (!raybin || ctx->byray_frame) && !ctx->pts_bucketed;
   if (const char* e = getenv("EMAP_BIN_STRIP")) { if (atoi(e) == 0) ctx->bin_strip = false; }      // test / tuning hook
   // Blocks: ~4096 points each, but every block carries a row of the (block, tile) matrix through three passes (written, scanned,
   // read): keep the matrix (4 B x TB x B, x4) below the cloud's own traffic (12 B x n, x2) -- B <= n / (3 TB) -- without dropping
@@ -800,7 +807,7 @@ static int ensure_bins(emap_ctx* ctx, bool raybin) {
     ctx->split.extra = u; u += SPLIT_MAX_EXTRA;
     ctx->split.n_extra = u;
     CK(hipHostMalloc((void**)&ctx->split_need, 64, hipHostMallocMapped));
-    *ctx->split_need = 0u;
+    ctx->split_need[0] = 0u; ctx->split_need[1] = 0u;      // [0]: heavy-tile parts (k_bin_scan), [1]: the ray kernel the map's state asks for (k_ray_apply)
     CK(hipHostGetDevicePointer((void**)&ctx->split.need_host, const_cast<unsigned int*>(ctx->split_need), 0));
     ctx->split.on = 0;
   }
@@ -1009,6 +1016,7 @@ int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
   const AccRView av = {ab + offsetof(AccR, dec), ab + offsetof(AccR, hits), ab + offsetof(AccR, upper_key), (int)sizeof(AccR), (int)sizeof(AccR), (int)sizeof(AccR), 0};
   KP kr = ctx->kp;
   kr.nlag = ctx->nlag_ready ? 1 : 0;                     // sharded frame after a row shift: the row-aligned copy of the normal planes (normal_exchange)
+  kr.ray_pref = ctx->split_need ? (int)ctx->split_need[1] : 0;      // (host-mapped word written by k_ray_apply: FrameDev::ray_class)
   launch_rays(ctx->stream, kr, make_pose(ctx, R, t), ctx->rt, ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, av,
               ctx->nlag_ready ? ctx->nlag_buf : ctx->normal, ctx->nlag_ready ? (long)ctx->strip.row_count * ctx->prm.cell_n : ctx->ncells_alloc,
               ctx->frame, ctx->want_ray_stats, ctx->inert, inl, ctx->rays_fused ? 1 : (int)(sizeof(AccF) / 4),
@@ -1152,7 +1160,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
   if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane, ov); ctx->kp.mv.n = 0; }
-  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame); ctx->inert_zero = true; }
+  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame, ctx->split.need_host ? ctx->split.need_host + 1 : nullptr); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   STAGE(ST_OVERLAP);
@@ -2109,6 +2117,7 @@ static int rays_by_ray_pass(emap_ctx* ctx, const float R[9], const float t[3]) {
   CK(hipMemsetAsync(w.key, 0, sizeof(unsigned int) * (size_t)n, st));
   // (3) the march: this rank's sorted records = the valid points of its rows, over the window
   KP kw = ctx->kp;
+  kw.ray_pref = ctx->split_need ? (int)ctx->split_need[1] : 0;
   kw.org_r = kw.org_c = kw.norg_r = kw.norg_c = 0; kw.mv.n = 0;
   kw.row0 = w.r0; kw.nrows = w.nr; kw.halo = 0; kw.col0 = w.c0; kw.ncols = w.nc; kw.pitch = w.nc; kw.wmode = 1;
   Cells wc; wc.hot = w.hot; wc.cold = w.cold;
@@ -2179,7 +2188,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
   if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane, ov); ctx->kp.mv.n = 0; }
-  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame); ctx->inert_zero = true; }
+  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame, ctx->split.need_host ? ctx->split.need_host + 1 : nullptr); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   STAGE(ST_OVERLAP);

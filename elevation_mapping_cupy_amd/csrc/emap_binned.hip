@@ -589,10 +589,12 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
         } else acc[c] = a;
       }
       if (AVG && RAYS) {                                       // every wave of the workgroup gets here (no early exit above)
+        unsigned int n_quiet = 0u;
         if (lrow < P.nrows) {                                  // wave-uniform condition: the ballot sees the whole row segment
           // the bitmap is indexed by LOGICAL column (k_commit): the 64 physical columns of this wave are one or two runs of logical
           // columns that straddle word boundaries -> OR the shifted pieces into the (pre-zeroed) words
           const unsigned long long bits = __ballot(quiet);
+          n_quiet = (unsigned int)__popcll(bits);
           if (tc == 0 && ((P.org_c | P.C) & 63) == 0) inert[(long)bitmap_row(P, P.row0 + lrow) * (P.C / 64) + logi_col(P, tx * BIN_TC) / 64] = bits;   // aligned: one whole word
           else if (tc == 0) {
             unsigned long long* row = inert + (long)bitmap_row(P, P.row0 + lrow) * ((P.C + 63) / 64);
@@ -614,8 +616,9 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
         // other cells gets the largest finite float instead (filters nothing either)
         unsigned int* s_thr = s_pts;                           // the counters are dead by now: 2 block rows x 8 block columns (+ 16 "other" flags)
         __syncthreads();
-        if (threadIdx.x < 32) s_thr[threadIdx.x] = 0u;         // float_ord(x) > 0 for every x
+        if (threadIdx.x < 33) s_thr[threadIdx.x] = 0u;         // float_ord(x) > 0 for every x; [32]: quiet cells of the tile
         __syncthreads();
+        if (tc == 0 && n_quiet) atomicAdd(&s_thr[32], n_quiet);
         unsigned int o = float_ord(visit_thr);
         o = max(o, (unsigned int)__shfl_xor((int)o, 1, 64)); o = max(o, (unsigned int)__shfl_xor((int)o, 2, 64)); o = max(o, (unsigned int)__shfl_xor((int)o, 4, 64));
         const unsigned long long ob = __ballot(other);
@@ -630,8 +633,8 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
           if (bt == INFINITY && s_thr[16 + threadIdx.x]) bt = 3.4028234664e38f;
           if (br * 8 < P.nrows && bc * 8 < P.C) {
             thr[(long)br * ((P.C + 7) >> 3) + bc] = bt;
-            if (bt != INFINITY) F->thr_finite = 1u;               // (racing writers store the same value; see FrameDev)
           }
+          if (threadIdx.x == 0 && s_thr[32]) atomicAdd(&F->quiet_cells[blockIdx.x & 7u], s_thr[32]);      // (FrameDev: which ray kernel the next frames use)
         }
       }
     }

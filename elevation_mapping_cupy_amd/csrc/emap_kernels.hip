@@ -232,8 +232,6 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     chunk = (blockIdx.x & 1u) ? nbs - 1u - (blockIdx.x >> 1) : (blockIdx.x >> 1);
 #endif
   }
-  // every block virgin (the first frame after clear(): FrameDev::thr_finite): no threshold can filter anything -- skip the fetch
-  const bool all_virgin = thr != nullptr && P.wmode == 0 && F->thr_finite == 0u;              // (uniform; a ray window derives its own thresholds: k_win_prepare)
   const unsigned int* __restrict__ inert = reinterpret_cast<const unsigned int*>(inert64);   // 32-bit words: cheaper shifts
   const unsigned int wpr32 = (unsigned int)((P.pitch + 63) / 64) * 2u;                       // 32-bit words per bitmap row (pitch = C; a ray window: its width)
   // LDS words: [table (span)] [s_k (nS)] [queues (BLOCK/64 * 384)]
@@ -358,7 +356,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     // exchanges, the distance test) is fetched only when some visit of the batch survives.
     const float erz = __shfl(rz, src, 64);
     const float nz = T.t[2] + erz * s;                                                   // the sample height, recomputed bit for bit
-    const float bthr = (has && thr) ? (all_virgin ? INFINITY : thr[(lrow >> 3) * (unsigned int)((P.pitch + 7) >> 3) + (col >> 3)]) : 3.4028234664e38f;
+    const float bthr = (has && thr) ? thr[(lrow >> 3) * (unsigned int)((P.pitch + 7) >> 3) + (col >> 3)] : 3.4028234664e38f;
     const bool live = has && !(nz >= bthr);
     if (!__builtin_amdgcn_ballot_w64(live)) return;                                      // wave-uniform
     const float erx = __shfl(rx, src, 64), ery = __shfl(ry, src, 64), edec = __shfl(dec, src, 64);
@@ -606,10 +604,16 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cells cells, AccF* _
 // inflation (custom_kernels.py:251-252), upper bound (:230-233, :254-255), then average_map_kernel's reset of cells whose
 // validity fell below 0.5 (:380-384); re-arms the accumulators.
 __global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cells cells, AccR* __restrict__ accr,
-                                                        unsigned long long* __restrict__ inert, OverlapArgs O, FrameDev* __restrict__ F) {
+                                                        unsigned long long* __restrict__ inert, OverlapArgs O, FrameDev* __restrict__ F,
+                                                        unsigned int* __restrict__ ray_pref_host) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   if (li >= (long)P.nrows * P.C) return;
-  if (li == 0) F->thr_finite = 0u;                                   // the rays are done with the thresholds too (FrameDev)
+  if (li == 0) {                                                     // share of quiet cells -> which ray kernel the next frames use (FrameDev)
+    unsigned int q = 0u;
+    for (int k = 0; k < 8; ++k) { q += F->quiet_cells[k]; F->quiet_cells[k] = 0u; }
+    const unsigned int cls = (unsigned long long)q * 10ull < (unsigned long long)P.nrows * (unsigned long long)P.C * 3ull ? 1u : 0u;      // fewer than 30 % quiet
+    if (ray_pref_host && cls != F->ray_class) { F->ray_class = cls; __hip_atomic_store(ray_pref_host, cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+  }
   if (li < (long)P.nrows * ((P.C + 63) / 64)) inert[li] = 0ull;      // the rays are done with the bitmap: leave it zeroed for the tile kernel's ORs
   long c = li + (long)P.halo * P.C;
   const AccR r = accr[c];
@@ -1339,8 +1343,8 @@ void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, lo
 void launch_commit(hipStream_t s, const KP& P, Cells cells, const AccF* acc, const FrameDev* F, unsigned long long* inert) {
   hipLaunchKernelGGL(k_commit, dim3((P.C + 63) / 64, P.nrows), dim3(64), 0, s, P, cells, acc, F, inert);
 }
-void launch_ray_apply(hipStream_t s, const KP& P, Cells cells, AccR* accr, unsigned long long* inert, const OverlapArgs& O, FrameDev* F) {
-  hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr, inert, O, F);
+void launch_ray_apply(hipStream_t s, const KP& P, Cells cells, AccR* accr, unsigned long long* inert, const OverlapArgs& O, FrameDev* F, unsigned int* ray_pref_host) {
+  hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr, inert, O, F, ray_pref_host);
 }
 #ifndef RAY_BLOCK
 #define RAY_BLOCK 1024
@@ -1358,8 +1362,11 @@ template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(h
   const size_t lds = (IDX == 1 ? (((size_t)(Rt.hi - Rt.lo) + 2 + 3) & ~(size_t)3) * 4 : 0) + (size_t)(((Rt.nS + 3) & ~3) + 8 * lpr) * 4 + (size_t)(block / 64) * 3 * 128 * 4;
   size_t map_bytes = ((size_t)P.nrows * ((P.pitch + 63) / 64) * 2 + 2) * 4;       // bitmap + the all-ones word ...
   { size_t al = 4; while (al < (size_t)((P.pitch + 63) / 64) * 8) al <<= 1; map_bytes += al; }      // ... + alignment to the row pitch
-  static const bool lmap_off = getenv("EMAP_RAY_LMAP") && atoi(getenv("EMAP_RAY_LMAP")) == 0;     // tuning / test hook
-  const bool lmap = !lmap_off && !small && lds + map_bytes <= 158 * 1024;             // (small clouds: staging the bitmap per workgroup would dominate)
+  // EMAP_RAY_LMAP = 0 / 1: never / whenever it fits (tuning and test hook); unset: whenever it fits unless the map is mostly unknown or
+  // stale (KP::ray_pref, from the previous frames' share of quiet cells): there the march queues cell work at almost every step and
+  // is latency bound -- the global-bitmap variant runs two workgroups per CU (terrain scene: 187 vs 217 us; uniform benchmark: LDS 10 % ahead)
+  static const int lmap_env = getenv("EMAP_RAY_LMAP") ? atoi(getenv("EMAP_RAY_LMAP")) : -1;
+  const bool lmap = !small && lds + map_bytes <= 158 * 1024 && (lmap_env == 1 || (lmap_env != 0 && !P.ray_pref));      // (small clouds: staging the bitmap per workgroup would dominate)
   dim3 g((unsigned int)((n * lpr + block - 1) / block)), b(block);
   auto go = [&](auto kern, LdsRaised& raised, size_t bytes) {    // per instantiation and device: the half -> index table + queues [+ bitmap] can exceed the default 64 KB window
     if (!raise_lds(kern, raised, 158 * 1024) && bytes > 64 * 1024) return;      // (the launch below would fail: hipGetLastError reports it to the caller)
