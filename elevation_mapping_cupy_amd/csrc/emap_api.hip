@@ -30,7 +30,7 @@ void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float
 void launch_win_pack(hipStream_t, const KP&, const Win&, Cells, const float*, long, const unsigned int*, const unsigned long long*, float);
 void launch_win_prepare(hipStream_t, const Win&, int);
 void launch_win_unpack(hipStream_t, const KP&, const Win&, AccR*);
-void launch_ray_apply(hipStream_t, const KP&, Cells, AccR*, unsigned long long*, const OverlapArgs&, FrameDev*, unsigned int*);
+void launch_ray_apply(hipStream_t, const KP&, Cells, AccR*, unsigned long long*, const OverlapArgs&, FrameDev*, unsigned int*, int);
 void launch_average(hipStream_t, const KP&, Cells, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*, const OverlapArgs&);
 static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
 void launch_sem_points(hipStream_t, const KP&, const Pose&, const SemSpec&, const float*, long, int, const ChanView&, double*, unsigned int*, long);
@@ -184,6 +184,7 @@ struct emap_ctx {
   int ray_mode;                 // 0 auto (by ray from 2048^2 cells on), 1 always by row, 2 by ray whenever the frame allows it
   bool byray_frame;             // the current sharded frame marches its rays by ray
   size_t wire_bytes;            // payload of the last by-ray frame's three all-reduces (bytes per rank)
+  int ray_par;                  // parity of the k_ray_apply launches (FrameDev::quiet_sum)
   unsigned int* win_state; unsigned int* win_rec; unsigned long long* win_bits; float* win_thr; long long* win_dh; unsigned int* win_key; long win_cap;
   hipStream_t comm_stream; hipEvent_t ev_ready, ev_done; double* comm_sums;   // [0..1] local err_sum / err_cnt, [2..3] totals, [4..36) emap_comm_allreduce_host
   // the un-shifted normal planes after a row shift (normal_exchange): a row-aligned copy of the rows this strip's cells belong to
@@ -761,7 +762,9 @@ static int ensure_bins(emap_ctx* ctx, bool raybin) {
   // ... but not for a cloud that was BUCKETED for this strip on the host (emap_upload_points_strip): nearly every point is an owned one
   // then, the ownership pre-test and the staging record (16 B written + read per point) buy nothing -- the plain kernels sort 2 M
   // points in 42 us where the strip variants take 52
-  ctx->bin_strip = ctx->strip.row_count < ctx->prm.cell_n && (!raybin || ctx->byray_frame) && !ctx->pts_bucketed;
+  // (a by-ray frame keeps the strip variants: there the EXACT ownership test decides which rank marches a point's ray -- a point the
+  // host-side superset kept for two neighbouring strips must not ride in both ranks' ray-only bins)
+  ctx->bin_strip = ctx->strip.row_count < ctx->prm.cell_n && (!raybin || ctx->byray_frame) && !(ctx->pts_bucketed && !raybin);
   if (const char* e = getenv("EMAP_BIN_STRIP")) { if (atoi(e) == 0) ctx->bin_strip = false; }      // test / tuning hook
   // Blocks: ~4096 points each, but every block carries a row of the (block, tile) matrix through three passes (written, scanned,
   // read): keep the matrix (4 B x TB x B, x4) below the cloud's own traffic (12 B x n, x2) -- B <= n / (3 TB) -- without dropping
@@ -1160,7 +1163,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
   if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane, ov); ctx->kp.mv.n = 0; }
-  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame, ctx->split.need_host ? ctx->split.need_host + 1 : nullptr); ctx->inert_zero = true; }
+  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame, ctx->split.need_host ? ctx->split.need_host + 1 : nullptr, ctx->ray_par ^= 1); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   STAGE(ST_OVERLAP);
@@ -2188,7 +2191,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
   if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane, ov); ctx->kp.mv.n = 0; }
-  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame, ctx->split.need_host ? ctx->split.need_host + 1 : nullptr); ctx->inert_zero = true; }
+  else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame, ctx->split.need_host ? ctx->split.need_host + 1 : nullptr, ctx->ray_par ^= 1); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   STAGE(ST_OVERLAP);

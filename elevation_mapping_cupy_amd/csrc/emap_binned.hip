@@ -229,6 +229,9 @@ __global__ __launch_bounds__(SCAN_BLK) void k_bin_scan(BinGeo G, unsigned int* _
   }
 }
 
+#ifndef SCATTER_U
+#define SCATTER_U 4
+#endif
 template <int MODE, int BLK, bool STRIP>
 __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
                                                      const unsigned int* __restrict__ hist, const unsigned int* __restrict__ tile_start,
@@ -239,27 +242,44 @@ __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, Pose T, BinGeo G, con
   for (int t = threadIdx.x; t < G.TB; t += BLK) cur[t] = tile_start[t] + row[t];
   __syncthreads();
   const long base = (long)blockIdx.x * G.chunk;
+  // SCATTER_U loads in flight per thread (round 5): a block is ONE workgroup of eight waves on its CU (245 blocks of 4096 points at
+  // 1 M points; 253 blocks and a 64-KB cursor array at 16 M), and a thread that walks its eight points one dependent load at a time
+  // spends the pass waiting -- 8 round trips of ~1.5 us were the 13 us the pass took.
+  constexpr int U = SCATTER_U;
   if (!STRIP) {
-    for (long k = threadIdx.x; k < G.chunk; k += BLK) {      // geometry once more, LDS cursor -> sorted position; no map access
-      const long i = base + k;
-      if (i >= n) break;
-      float rx, ry, rz;
-      load_point(pts, i, stride, rx, ry, rz);
-      const Geo g = geometry<MODE>(P, T, rx, ry, rz);
-      unsigned int lc;
-      const int bin = bin_of(P, G, g, lc);
-      if (bin < 0) continue;
-      const unsigned int pos = atomicAdd(&cur[bin], 1u);
-      BinRec o; o.lc_inl = lc; o.z = g.z; o.v = g.v; o.i = (unsigned int)i;
-      recs[pos] = o;
+    for (long k0 = threadIdx.x; k0 < G.chunk; k0 += (long)U * BLK) {      // geometry once more, LDS cursor -> sorted position; no map access
+      float rx[U], ry[U], rz[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long i = base + k0 + (long)u * BLK;
+        rx[u] = ry[u] = rz[u] = NAN;                          // (a NaN row: no bin)
+        if (k0 + (long)u * BLK < G.chunk && i < n) load_point(pts, i, stride, rx[u], ry[u], rz[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long i = base + k0 + (long)u * BLK;
+        const Geo g = geometry<MODE>(P, T, rx[u], ry[u], rz[u]);
+        unsigned int lc;
+        const int bin = bin_of(P, G, g, lc);
+        if (bin < 0) continue;
+        const unsigned int pos = atomicAdd(&cur[bin], 1u);
+        BinRec o; o.lc_inl = lc; o.z = g.z; o.v = g.v; o.i = (unsigned int)i;
+        recs[pos] = o;
+      }
     }
   } else {
     const unsigned int m = stg_cnt[blockIdx.x];              // a pure permutation of the block's staged records
-    for (unsigned int j = threadIdx.x; j < m; j += BLK) {
-      const BinStg r = stg[base + j];
-      const unsigned int pos = atomicAdd(&cur[r.key >> 16], 1u);
-      BinRec o; o.lc_inl = r.key & 0xffffu; o.z = r.z; o.v = r.v; o.i = r.i;
-      recs[pos] = o;
+    for (unsigned int j0 = threadIdx.x; j0 < m; j0 += U * BLK) {
+      BinStg r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (j0 + u * BLK < m) r[u] = stg[base + j0 + u * BLK];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (j0 + u * BLK >= m) continue;
+        const unsigned int pos = atomicAdd(&cur[r[u].key >> 16], 1u);
+        BinRec o; o.lc_inl = r[u].key & 0xffffu; o.z = r[u].z; o.v = r[u].v; o.i = r[u].i;
+        recs[pos] = o;
+      }
     }
   }
 }
@@ -589,12 +609,10 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
         } else acc[c] = a;
       }
       if (AVG && RAYS) {                                       // every wave of the workgroup gets here (no early exit above)
-        unsigned int n_quiet = 0u;
         if (lrow < P.nrows) {                                  // wave-uniform condition: the ballot sees the whole row segment
           // the bitmap is indexed by LOGICAL column (k_commit): the 64 physical columns of this wave are one or two runs of logical
           // columns that straddle word boundaries -> OR the shifted pieces into the (pre-zeroed) words
           const unsigned long long bits = __ballot(quiet);
-          n_quiet = (unsigned int)__popcll(bits);
           if (tc == 0 && ((P.org_c | P.C) & 63) == 0) inert[(long)bitmap_row(P, P.row0 + lrow) * (P.C / 64) + logi_col(P, tx * BIN_TC) / 64] = bits;   // aligned: one whole word
           else if (tc == 0) {
             unsigned long long* row = inert + (long)bitmap_row(P, P.row0 + lrow) * ((P.C + 63) / 64);
@@ -616,9 +634,8 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
         // other cells gets the largest finite float instead (filters nothing either)
         unsigned int* s_thr = s_pts;                           // the counters are dead by now: 2 block rows x 8 block columns (+ 16 "other" flags)
         __syncthreads();
-        if (threadIdx.x < 33) s_thr[threadIdx.x] = 0u;         // float_ord(x) > 0 for every x; [32]: quiet cells of the tile
+        if (threadIdx.x < 32) s_thr[threadIdx.x] = 0u;         // float_ord(x) > 0 for every x
         __syncthreads();
-        if (tc == 0 && n_quiet) atomicAdd(&s_thr[32], n_quiet);
         unsigned int o = float_ord(visit_thr);
         o = max(o, (unsigned int)__shfl_xor((int)o, 1, 64)); o = max(o, (unsigned int)__shfl_xor((int)o, 2, 64)); o = max(o, (unsigned int)__shfl_xor((int)o, 4, 64));
         const unsigned long long ob = __ballot(other);
@@ -634,7 +651,6 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
           if (br * 8 < P.nrows && bc * 8 < P.C) {
             thr[(long)br * ((P.C + 7) >> 3) + bc] = bt;
           }
-          if (threadIdx.x == 0 && s_thr[32]) atomicAdd(&F->quiet_cells[blockIdx.x & 7u], s_thr[32]);      // (FrameDev: which ray kernel the next frames use)
         }
       }
     }

@@ -67,12 +67,14 @@ struct FrameDev {                  // per-frame scalars that stay on the device 
   int gate_fired;
   unsigned long long ray_visits;
   unsigned int n_points;
-  // Cells the frame's tile kernel marked QUIET (known + fresh, or border) in front of a visibility pass, summed by its workgroups into
-  // eight slots (one device atomic per workgroup); k_ray_apply totals and clears them and tells the host -- through a host-mapped word,
-  // only when it changes -- which ray kernel the NEXT frames should use (ray_class: 1 = a mostly unknown / stale map, where the march
-  // queues cell work at almost every step and is latency bound: the bitmap stays in global memory and two workgroups share a CU;
-  // 0 = the bitmap staged in LDS).  Measured on the terrain scene: 187 vs 217 us; on the uniform benchmark the LDS variant is 10 % ahead.
-  unsigned int quiet_cells[8];
+  // Which ray kernel the map's state asks for.  k_ray_apply zeroes the frame's inert bitmap (quiet = known + fresh, or border) anyway: on
+  // the way it counts the set bits (one device atomic per workgroup that holds bitmap words -- 64 at 1024^2; counting in the tile
+  // kernel, one atomic per tile workgroup on one line, cost that kernel 9 us: device atomics on a line serialise at ~10 ns) into
+  // quiet_sum[parity of the launch]; thread 0 of the NEXT launch reads the finished sum, derives the class -- fewer than 30 % quiet:
+  // a mostly unknown / stale map, where the march queues cell work at almost every step and is latency bound -- and tells the host
+  // through a host-mapped word when it changes: such a map keeps the ray kernel's bitmap in global memory and runs two workgroups per
+  // CU (terrain scene: 193 vs 219 us; on the uniform benchmark the LDS variant is 10 % ahead).
+  unsigned int quiet_sum[2];
   unsigned int ray_class, pad_;
 };
 

@@ -605,16 +605,28 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cells cells, AccF* _
 // validity fell below 0.5 (:380-384); re-arms the accumulators.
 __global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cells cells, AccR* __restrict__ accr,
                                                         unsigned long long* __restrict__ inert, OverlapArgs O, FrameDev* __restrict__ F,
-                                                        unsigned int* __restrict__ ray_pref_host) {
+                                                        unsigned int* __restrict__ ray_pref_host, int par) {
   long li = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
-  if (li >= (long)P.nrows * P.C) return;
-  if (li == 0) {                                                     // share of quiet cells -> which ray kernel the next frames use (FrameDev)
+  const long words = (long)P.nrows * ((P.C + 63) / 64);
+  if ((long)blockIdx.x * EM_BLOCK < words) {                         // (uniform per workgroup) the rays are done with the bitmap: count its bits, leave it zeroed for the tile kernel's ORs
+    __shared__ unsigned int s_q;
+    if (threadIdx.x == 0) s_q = 0u;
+    __syncthreads();
     unsigned int q = 0u;
-    for (int k = 0; k < 8; ++k) { q += F->quiet_cells[k]; F->quiet_cells[k] = 0u; }
-    const unsigned int cls = (unsigned long long)q * 10ull < (unsigned long long)P.nrows * (unsigned long long)P.C * 3ull ? 1u : 0u;      // fewer than 30 % quiet
-    if (ray_pref_host && cls != F->ray_class) { F->ray_class = cls; __hip_atomic_store(ray_pref_host, cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    if (li < words) { q = (unsigned int)__popcll(inert[li]); inert[li] = 0ull; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += (unsigned int)__shfl_xor((int)q, o, 64);
+    if ((threadIdx.x & 63) == 0 && q) atomicAdd(&s_q, q);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_q) atomicAdd(&F->quiet_sum[par & 1], s_q);
   }
-  if (li < (long)P.nrows * ((P.C + 63) / 64)) inert[li] = 0ull;      // the rays are done with the bitmap: leave it zeroed for the tile kernel's ORs
+  if (li == 0) {                                                     // the PREVIOUS launch's finished count -> which ray kernel the next frames use (FrameDev)
+    const unsigned int q = F->quiet_sum[(par & 1) ^ 1];
+    F->quiet_sum[(par & 1) ^ 1] = 0u;
+    const unsigned int cls = (unsigned long long)q * 10ull < (unsigned long long)P.nrows * (unsigned long long)P.C * 3ull ? 1u : 0u;      // fewer than 30 % quiet
+    if (q && ray_pref_host && cls != F->ray_class) {                 // (q = 0: no finished count yet -- a real one holds at least the border cells) F->ray_class = cls; __hip_atomic_store(ray_pref_host, cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+  }
+  if (li >= (long)P.nrows * P.C) return;
   long c = li + (long)P.halo * P.C;
   const AccR r = accr[c];
   bool win = false;                                                  // clear_overlap_map follows the averaging (:372-375): centred window
@@ -1343,8 +1355,8 @@ void launch_fuse(hipStream_t s, const KP& P, const Pose& T, const float* pts, lo
 void launch_commit(hipStream_t s, const KP& P, Cells cells, const AccF* acc, const FrameDev* F, unsigned long long* inert) {
   hipLaunchKernelGGL(k_commit, dim3((P.C + 63) / 64, P.nrows), dim3(64), 0, s, P, cells, acc, F, inert);
 }
-void launch_ray_apply(hipStream_t s, const KP& P, Cells cells, AccR* accr, unsigned long long* inert, const OverlapArgs& O, FrameDev* F, unsigned int* ray_pref_host) {
-  hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr, inert, O, F, ray_pref_host);
+void launch_ray_apply(hipStream_t s, const KP& P, Cells cells, AccR* accr, unsigned long long* inert, const OverlapArgs& O, FrameDev* F, unsigned int* ray_pref_host, int par) {
+  hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr, inert, O, F, ray_pref_host, par);
 }
 #ifndef RAY_BLOCK
 #define RAY_BLOCK 1024

@@ -128,7 +128,7 @@ def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_f
     assert not any(x.is_alive() for x in th), "a rank is stuck in the exchange"
     assert not errs, errs
     for b, rows, m, nm, add, gathered in out:
-        if gathered is not None and check_gather == "all":        # (after a move a strip's un-shifted normals have holes until the next frame)
+        if gathered is not None and check_gather == "all":        # (after a move the gathered normal planes are compared only once a frame has rewritten them)
             assert np.array_equal(gathered[0], want[0]) and np.array_equal(gathered[1], want_n[2]), "gathered planes differ"
         elif gathered is not None:
             assert np.array_equal(gathered[0], want[0]), "gathered elevation differs"
@@ -157,7 +157,7 @@ def test_native_multi_rank_frame_with_in_process_rccl_stand_in(world, cfg_name, 
     if cfg_name.endswith("norays"):
         cfg["enable_visibility_cleanup"] = False
     R, t = fx.POSES["rotated"]
-    # move_to between the frames: ring halo, normal rows (after a move a strip's view of the un-shifted normals has holes until the next frame)
+    # move_to between the frames: ring halo, normal rows fetched from their owners
     MV = [(0.13, -0.3, 0.05), (-0.10, 0.17, -0.02), None] if moves else [None] * 3
     frames = [(fx.cloud(C, N, f, dz=dz), R, t, 1.0, 1.0, 6, mv) for (f, dz), mv in zip(enumerate((0.0, -0.02, -0.1)), MV)]
     _strips_vs_single(world, cfg, C, frames, scatter, weights, check_gather=None if scatter != "binned" else ("elevation" if moves else "all"), stand_in=stand_in)
@@ -186,7 +186,7 @@ def test_fuzz_strips_bitwise(k, weights):
         if rng.random() < 0.5:
             p[::211, int(rng.integers(0, 3))] = np.nan
         noise = 1.0 if rng.random() < 0.6 else 0.0
-        mv = (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.3, 0.3)), 0.0) if (f < 2 and rng.random() < 0.5) else None     # <= 7 rows: the halo ring hands the seam rows round
+        mv = (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.3, 0.3)), 0.0) if (f < 2 and rng.random() < 0.5) else None     # (small moves here; tens of rows: test_strips_after_large_map_moves)
         frames.append((p, R, t, noise, noise, int(rng.integers(0, 9)), mv))
     _strips_vs_single(world, cfg, C, frames, scatter, weights, mode=mode, stand_in="stream" if k % 2 else "blocking",
                       ray_mode=["auto", "by_ray", "by_ray"][int(rng.integers(0, 3))])          # (by ray takes effect on the tile-binned frames with a visibility pass)

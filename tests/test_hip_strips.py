@@ -163,8 +163,9 @@ def _rows_of(full_planes, begin, rows):
     return np.take(full_planes, (begin + np.arange(rows)) % C, axis=1)
 
 
-# row shifts of at most halo_rows (= 7) per move: after a larger one the visibility pass of the next frame finds the un-shifted normals
-# of the seam rows on no rank and reads them as 0 (documented deviation of strips; DESIGN.md "Map shift")
+# row shifts of at most halo_rows (= 7) per move: this test drives the stages from Python (ShardedElevationMap over a thread "communicator"),
+# which exchanges the normal planes' halo rows only and REFUSES a larger lag; the library's own frame (emap_update_sharded) fetches the
+# rows from whoever owns them for any shift -- tests/test_hip_comm.py::test_strips_after_large_map_moves (DESIGN.md "Map shift")
 MOVES = [(0.13, -0.3, 0.05), (-0.10, 0.49, -0.02), (0.17, 0.5, 0.0), (-0.05, -0.9, 0.11)]
 
 
