@@ -624,7 +624,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_ray_apply(KP P, Cells cells, AccR*
     const unsigned int q = F->quiet_sum[(par & 1) ^ 1];
     F->quiet_sum[(par & 1) ^ 1] = 0u;
     const unsigned int cls = (unsigned long long)q * 10ull < (unsigned long long)P.nrows * (unsigned long long)P.C * 3ull ? 1u : 0u;      // fewer than 30 % quiet
-    if (q && ray_pref_host && cls != F->ray_class) {                 // (q = 0: no finished count yet -- a real one holds at least the border cells) F->ray_class = cls; __hip_atomic_store(ray_pref_host, cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    // (q = 0: no finished count yet -- a real one holds at least the border cells)
+    if (q && ray_pref_host && cls != F->ray_class) { F->ray_class = cls; __hip_atomic_store(ray_pref_host, cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
   }
   if (li >= (long)P.nrows * P.C) return;
   long c = li + (long)P.halo * P.C;
