@@ -32,7 +32,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r04"  # tag of the committed rocprofv3 summaries under profiles/ that this round's numbers refer to
+PROFILE_ROUND = "r05"  # tag of the committed rocprofv3 summaries under profiles/ that this round's numbers refer to
 
 
 def source_stamp():

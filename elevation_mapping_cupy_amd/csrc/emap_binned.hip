@@ -351,6 +351,9 @@ __device__ __forceinline__ bool drift_inlier(const KP& P, const float4 m, float 
 #ifndef SPLIT_U_FUSE
 #define SPLIT_U_FUSE 1
 #endif
+#ifndef TILE_PREFETCH
+#define TILE_PREFETCH 1   /* tile kernels: first records requested before the staging barrier (A/B knob) */
+#endif
 // The hot halves (h, v, valid, trav) of one 16 x 64 tile -> LDS, one wave per tile row.  Without pending map moves this is a pure
 // copy of 1 KB per row: gfx950's LDS-DMA (no VGPR round trip, no ds_write); cells beyond the map / strip read as zero.  With pending
 // moves the cells pass through cell_now() in registers.  The caller's next __syncthreads() publishes the tile.
@@ -382,15 +385,24 @@ __device__ __forceinline__ void tile_count_body(const KP& P, const BinGeo& G, co
   const int row_base = (ty * G.sub + sb) * BIN_TR;
   if (row_base >= P.nrows || r0 == r1) return;
   const bool split = SPLIT && w.np > 1u;                             // (uniform)
+  // the split kernels (frames with heavy tiles) keep SPLIT_U records per thread in flight: a part is up to SPLIT_CAP / 1024 dependent
+  // trips of load -> LDS, each a full memory round trip when only one load per thread is outstanding
+  constexpr int U = SPLIT ? SPLIT_U : 1;
+  // (round 5) the first batch of records is requested BEFORE the tile's cells are staged: the two round trips overlap instead of
+  // following each other behind the barrier -- the tile kernels are chains of dependent trips, 128 rounds of them at 8192^2
+  BinRec rr[U];
+#if TILE_PREFETCH
+#pragma unroll
+  for (int u = 0; u < U; ++u) { const unsigned int k = r0 + u * TF_BLOCK + threadIdx.x; if (k < r1) rr[u] = recs[k]; }
+#endif
   stage_hot_tile(P, cells, s_cell, row_base, tx);
   if (split) { s_pts[threadIdx.x] = 0u; s_inl[threadIdx.x] = 0u; }
   __syncthreads();
   const unsigned int sel = (unsigned int)sb;
-  // the split kernels (frames with heavy tiles) keep SPLIT_U records per thread in flight: a part is up to SPLIT_CAP / 1024 dependent
-  // trips of load -> LDS, each a full memory round trip when only one load per thread is outstanding
-  constexpr int U = SPLIT ? SPLIT_U : 1;
   for (unsigned int kb = r0; kb < r1; kb += TF_BLOCK * U) {     // uniform trip count: the wave reductions need all lanes
-    BinRec rr[U];
+#if TILE_PREFETCH
+    if (kb != r0)
+#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) { const unsigned int k = kb + u * TF_BLOCK + threadIdx.x; if (k < r1) rr[u] = recs[k]; }
     long long e_fix = 0; unsigned long long cnt = 0;
@@ -464,6 +476,13 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
     if (row_base >= P.nrows) return;              // uniform
     const unsigned int sel = (unsigned int)sb;
     if (threadIdx.x == 0) s_shift = GF.mode ? gate_fold(GF, F, w.first) : F->shift;      // only pass 2 needs it (the first workgroup of the tile grid = bin 0, tile 0: always present)
+    // (round 5) the thread's FIRST record is requested before the cells are staged and the accumulators zeroed, and serves both
+    // passes: a tile of a uniform cloud holds about as many records as the workgroup has threads, so the second pass's trip to L2
+    // disappears and the first one overlaps the staging
+    const unsigned int k_first = r0 + threadIdx.x;
+    BinRec first; first.lc_inl = 0u; first.z = 0.f; first.v = 0.f; first.i = 0u;
+    const bool have_first = TILE_PREFETCH && !SPLIT && k_first < r1;
+    if (have_first) first = recs[k_first];
     stage_hot_tile(P, cells, s_cell, row_base, tx);
     for (int k = threadIdx.x; k < NC; k += TF_BLOCK) { s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull; }
     __syncthreads();
@@ -473,7 +492,7 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
       if (!AVG || RAYS) s_inl[threadIdx.x] = SV.inl[w.slot * SPLIT_CELLS + threadIdx.x];     // (as below: only the ray pass reads newmap[3])
     } else
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += TF_BLOCK) {          // pass 1: newmap[4] / newmap[3]
-      const BinRec r = recs[k];
+      const BinRec r = (have_first && k == k_first) ? first : recs[k];
       const unsigned int lcb = r.lc_inl & 0x7fffffffu;
       if ((lcb >> 10) != sel) continue;
       atomicAdd(&s_pts[lcb & 1023u], 1u);
@@ -485,7 +504,7 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
     for (unsigned int kb = r0 + threadIdx.x; kb < r1; kb += TF_BLOCK * U) {   // pass 2: custom_kernels.py:160-197
      BinRec rr[U];
 #pragma unroll
-     for (int u = 0; u < U; ++u) if (kb + u * TF_BLOCK < r1) rr[u] = recs[kb + u * TF_BLOCK];
+     for (int u = 0; u < U; ++u) if (kb + u * TF_BLOCK < r1) rr[u] = (have_first && u == 0 && kb == k_first) ? first : recs[kb + u * TF_BLOCK];
 #pragma unroll
      for (int u = 0; u < U; ++u) {
       if (kb + u * TF_BLOCK >= r1) continue;
