@@ -22,7 +22,7 @@
 #include <vector>
 
 // launchers (emap_kernels.hip)
-void launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, Cells, AccF*, ErrSlot*);
+bool launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, Cells, AccF*, ErrSlot*, const GateArgs*, FrameDev*, unsigned int*);
 void launch_gate(hipStream_t, const GateArgs&, ErrSlot*, FrameDev*, int, double*, const double*);
 void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, Cells, AccF*, const FrameDev*);
 void launch_commit(hipStream_t, const KP&, Cells, const AccF*, const FrameDev*, unsigned long long*);
@@ -152,6 +152,8 @@ struct emap_ctx {
   bool split_dirty;                // k_tile_count has filled slots that no k_tile_fuse has cleared yet
   GateFold gate_fold;              // multi-GPU frames: gate decision on the all-reduced totals folded into the tile kernel (mode 0: k_gate ran)
   OverlapArgs ov_args;             // clear_overlap_map folded into the frame's rewriting kernels (on = 0: separate k_overlap launch)
+  bool fold_gate, gate_folded;     // emap_update on the atomic path: the gate rides in k_count's last workgroup (cnt_sync: its ticket words)
+  unsigned int* cnt_sync;
   bool gate_possible;              // false inside emap_update when the host already knows that the drift gate cannot fire: the per-tile
                                    // error statistics are then skipped (they could not have any effect; err_sum / err_cnt report 0)
   BinGeo bg; BinRec* bin_recs; BinStg* bin_own; unsigned int* bin_own_cnt; long bin_own_cap; bool bin_strip;   // bin_own*: staged records of the owned points per block (strip contexts without a visibility pass)
@@ -402,7 +404,7 @@ int emap_destroy(emap_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   hipFree(ctx->cells.hot); hipFree(ctx->cells.cold); hipFree(ctx->acc); hipFree(ctx->accr); hipFree(ctx->trav_in);
-  hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->plug_buf); hipFree(ctx->plug_cnt); hipFree(ctx->slots); hipFree(ctx->frame);
+  hipFree(ctx->normal); hipFree(ctx->scratch); hipFree(ctx->plug_buf); hipFree(ctx->plug_cnt); hipFree(ctx->slots); hipFree(ctx->frame); hipFree(ctx->cnt_sync);
   for (int k = 0; k < 2; ++k) { hipFree(ctx->pts_dev[k]); if (ctx->pts_pin[k]) hipHostFree(ctx->pts_pin[k]); if (ctx->ev_copied[k]) hipEventDestroy(ctx->ev_copied[k]); if (ctx->ev_used[k]) hipEventDestroy(ctx->ev_used[k]); }
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   delete ctx->workers;
@@ -465,11 +467,13 @@ int emap_create(const emap_params* params, const emap_strip* strip, int device, 
   alloc((void**)&ctx->trav_in, sizeof(float) * n); alloc((void**)&ctx->normal, sizeof(float) * 3 * n);
   alloc((void**)&ctx->scratch, sizeof(float) * n); alloc((void**)&ctx->slots, sizeof(ErrSlot) * EM_ERR_SLOTS);
   alloc((void**)&ctx->frame, sizeof(FrameDev));
+  alloc((void**)&ctx->cnt_sync, sizeof(unsigned int) * EM_TICKET_WORDS);      // tickets of k_count's folded gate (zero between launches)
   alloc((void**)&ctx->inert, sizeof(unsigned long long) * ((size_t)ctx->strip.row_count * ((C + 63) / 64) + 2));      // + an all-ones word behind the last row (k_rays)
   if (rc == EMAP_OK) {
     hipEventCreate(&ctx->t0); hipEventCreate(&ctx->t1);
     for (int i = 0; i <= ST_N; ++i) hipEventCreate(&ctx->ev[i]);
     hipMemsetAsync(ctx->trav_in, 0, sizeof(float) * n, ctx->stream);
+    hipMemsetAsync(ctx->cnt_sync, 0, sizeof(unsigned int) * EM_TICKET_WORDS, ctx->stream);
     hipMemsetAsync(ctx->inert + (size_t)ctx->strip.row_count * ((C + 63) / 64), 0xff, 2 * sizeof(unsigned long long), ctx->stream);
     hipMemsetAsync(ctx->normal, 0, sizeof(float) * 3 * n, ctx->stream);
     rc = emap_clear(ctx);
@@ -905,7 +909,13 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
   } else {
     if (ctx->stage_timing && ctx->in_update)
       for (int e = ST_HIST; e <= ST_SCATTER; ++e) CK(hipEventRecord(ctx->ev[e], ctx->stream));
-    launch_count(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->slots);
+    // whole frames (emap_update) on this path: the drift gate rides in k_count's last workgroup, one launch less in a chain of six
+    static const bool fold_off = getenv("EMAP_GATE_FOLD") && atoi(getenv("EMAP_GATE_FOLD")) == 0;      // A/B and test hook
+    GateArgs ga;
+    const bool fold = ctx->fold_gate && !fold_off && ctx->cnt_sync;
+    if (fold) { ctx->use_override = false; ga = gate_args(ctx, ctx->pos_noise, ctx->ori_noise); }
+    ctx->gate_folded = launch_count(ctx->stream, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc, ctx->slots,
+                                    fold ? &ga : nullptr, ctx->frame, ctx->cnt_sync);
     if (ctx->stage_timing && ctx->in_update) CK(hipEventRecord(ctx->ev[ST_GATE], ctx->stream));
   }
   CK(hipGetLastError());
@@ -1138,10 +1148,13 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   ctx->in_update = true;
   // drift gate of elevation_mapping.py:346-349: with compensation off or both noises below their thresholds it cannot fire
   ctx->gate_possible = p.enable_drift_compensation && (position_noise > p.position_noise_thresh || orientation_noise > p.orientation_noise_thresh);
+  ctx->pos_noise = position_noise; ctx->ori_noise = orientation_noise;
+  ctx->fold_gate = true; ctx->gate_folded = false;
   rc = emap_count(ctx, R, t);                 // records ST_HIST / ST_SCAN / ST_SCATTER itself
-  ctx->in_update = false;
+  ctx->in_update = false; ctx->fold_gate = false;
   if (rc) return rc;            // (emap_count also recorded ST_GATE: the stage starts with the per-tile error sums)
-  if ((rc = emap_set_drift_inputs(ctx, position_noise, orientation_noise, nullptr, nullptr))) return rc;
+  if (ctx->gate_folded) { ctx->committed = false; ctx->gate_folded = false; }      // (small clouds: k_count's last workgroup was the gate)
+  else if ((rc = emap_set_drift_inputs(ctx, position_noise, orientation_noise, nullptr, nullptr))) return rc;
   STAGE(ST_FUSE);
   // binned scatter: fusion, commit and averaging happen in ONE tile kernel; with the visibility pass it also writes the inert
   // bitmap and the inlier plane, and the ray effects are applied by k_ray_apply ("average" stage) afterwards

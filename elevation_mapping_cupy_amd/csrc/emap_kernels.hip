@@ -12,10 +12,15 @@
 // One point per lane, coalesced 12-B xyz loads; one 16-B gather of (h, v, valid, trav); ONE 64-bit atomic per
 // point (points and inliers packed); the two global sums are wave-reduced and spread over 256 slots.
 // ---------------------------------------------------------------------------------------------------------
+// GATE (round 5): whole frames on this path (small clouds: the robot-scale configuration the reference ships is a chain of six
+// launches of ~4.5 us each) evaluate the drift gate in the LAST workgroup to finish -- the two-level ticket k_bin_scan uses: a
+// workgroup's slot atomics are performed at the memory side, s_waitcnt waits for their acknowledgements, then the ticket -- instead of
+// in a launch of their own (k_gate); the staged API and the multi-GPU frame keep k_gate.
+struct CountGate { int on, pad_; GateArgs A; FrameDev* F; unsigned int* sync; };
 template <int MODE>
 __global__ __launch_bounds__(EM_BLOCK) void k_count(KP P, Pose T, const float* __restrict__ pts, long n, int stride,
                                                      Cells cells, AccF* __restrict__ acc,
-                                                     ErrSlot* __restrict__ slots) {
+                                                     ErrSlot* __restrict__ slots, CountGate CG) {
   long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
   long long e_fix = 0;
   unsigned int inl = 0;
@@ -42,6 +47,14 @@ __global__ __launch_bounds__(EM_BLOCK) void k_count(KP P, Pose T, const float* _
       atomicAdd(reinterpret_cast<unsigned long long*>(&slots[slot].sum), (unsigned long long)s);
       atomicAdd(&slots[slot].cnt, k);
     }
+  }
+  if (CG.on) {                                                 // (uniform)
+    __shared__ bool s_last;
+    __builtin_amdgcn_s_waitcnt(0);                             // this wave's slot atomics are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = last_block_ticket(CG.sync, blockIdx.x, gridDim.x);
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) gate_eval(CG.A, slots, CG.F, (int)threadIdx.x, 0, nullptr, nullptr);
   }
 }
 
@@ -1337,11 +1350,15 @@ __global__ __launch_bounds__(EM_BLOCK) void k_point_index(KP P, Pose T, const fl
 // ---- launch wrappers used by emap_api.hip -------------------------------------------------------------
 static inline unsigned int nblk(long n) { return (unsigned int)((n + EM_BLOCK - 1) / EM_BLOCK); }
 
-void launch_count(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, Cells cells,
-                  AccF* acc, ErrSlot* slots) {
-  if (n <= 0) return;
-  if (P.mode == 0) hipLaunchKernelGGL(k_count<0>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, slots);
-  else hipLaunchKernelGGL(k_count<1>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, slots);
+// gate != nullptr: the drift gate rides in the last workgroup (whole frames: emap_update); false is returned when nothing was launched
+bool launch_count(hipStream_t s, const KP& P, const Pose& T, const float* pts, long n, int stride, Cells cells,
+                  AccF* acc, ErrSlot* slots, const GateArgs* gate, FrameDev* F, unsigned int* sync) {
+  if (n <= 0) return false;
+  CountGate CG; memset(&CG, 0, sizeof CG);
+  if (gate && F && sync) { CG.on = 1; CG.A = *gate; CG.F = F; CG.sync = sync; }
+  if (P.mode == 0) hipLaunchKernelGGL(k_count<0>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, slots, CG);
+  else hipLaunchKernelGGL(k_count<1>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, slots, CG);
+  return CG.on != 0;
 }
 void launch_gate(hipStream_t s, const GateArgs& A, ErrSlot* slots, FrameDev* F, int reduce_only, double* dev_out, const double* dev_totals) {
   hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, A, slots, F, reduce_only, dev_out, dev_totals);

@@ -301,7 +301,10 @@ int emap_normal_lag_plan(int32_t cell_n, int32_t world, const int32_t* cut_begin
  * bootstrap channel) and every rank calls emap_comm_init -- a collective call.  emap_update_sharded is emap_update for a
  * strip: count -> all-reduce(2 x f64 drift sums) -> gate -> fuse [-> commit -> rays] -> average -> overlap clearance ->
  * halo exchange of the boundary rows (in place, on a second stream) overlapped with the interior stencil tiles ->
- * boundary stencil tiles.  emap_comm_selftest checks an all-reduce and a send/recv round trip on the hardware. */
+ * boundary stencil tiles.  emap_comm_selftest checks an all-reduce and a send/recv round trip on the hardware.
+ * emap_comm_init (world <= 16) also gathers every rank's rows (who holds which normal rows after a map shift), allocates the ray window
+ * of a frame that marches its rays by ray -- so that no rank can fail alone in the middle of a frame's collectives -- and makes the
+ * ranks agree on EMAP_ABI_VERSION. */
 int emap_comm_unique_id(const char* rccl_path, uint8_t id_out[128]);
 int emap_comm_init(emap_ctx* ctx, const char* rccl_path, const uint8_t id[128], int32_t rank, int32_t world);
 int emap_comm_destroy(emap_ctx* ctx);
