@@ -69,6 +69,9 @@ struct __attribute__((aligned(16))) BinStg { unsigned int key; float z, v; unsig
 
 // STRIP: the context owns a row strip and no visibility pass follows (see the header).  The staged records of block b are
 // stg[b * chunk ...], their number stg_cnt[b].
+#ifndef HIST_U
+#define HIST_U 4
+#endif
 template <int MODE, int BLK, bool STRIP>
 __global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
                                                   unsigned int* __restrict__ hist, BinStg* __restrict__ stg,
@@ -78,14 +81,21 @@ __global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const 
   const long base = (long)blockIdx.x * G.chunk;
   if (!STRIP) {
     __syncthreads();
-    for (long k = threadIdx.x; k < G.chunk; k += BLK) {
-      const long i = base + k;
-      if (i >= n) break;
-      float rx, ry, rz;
-      load_point(pts, i, stride, rx, ry, rz);
-      unsigned int lc;
-      const int bin = bin_of(P, G, geometry<MODE>(P, T, rx, ry, rz), lc);
-      if (bin >= 0) atomicAdd(&h[bin], 1u);
+    constexpr int U = HIST_U;                                  // loads in flight per thread (as in k_bin_scatter)
+    for (long k0 = threadIdx.x; k0 < G.chunk; k0 += (long)U * BLK) {
+      float rx[U], ry[U], rz[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long k = k0 + (long)u * BLK, i = base + k;
+        rx[u] = ry[u] = rz[u] = NAN;                           // (a NaN row: no bin)
+        if (k < G.chunk && i < n) load_point(pts, i, stride, rx[u], ry[u], rz[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        unsigned int lc;
+        const int bin = bin_of(P, G, geometry<MODE>(P, T, rx[u], ry[u], rz[u]), lc);
+        if (bin >= 0) atomicAdd(&h[bin], 1u);
+      }
     }
   } else {
     float4* q = reinterpret_cast<float4*>(h + G.pitch) + (threadIdx.x >> 6) * BIN_QCAP;      // this wave's queue: (x, y, z, index)
