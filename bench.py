@@ -283,6 +283,31 @@ def cold_start(em, frame, n=10):
             "max_over_median": round(max(rays) / max(float(np.median(rays[-5:])), 1e-9), 2)}
 
 
+def scene_change(em, frame_a, frame_b, reps=3):
+    """the first frames of scene B after frames of scene A (device time per frame = sum of the stage spacings): a cloud with heavy
+    sort tiles right after clouds without -- the host sizes the extra workgroups of the tile kernels by the last frame it has heard
+    of, so the first frame of the new scene only finds the standing pool (emap_api.hip: emap_count)"""
+    lib, ctx = em._lib, em._ctx
+    lib.emap_enable_stage_timing(ctx, 1)
+    ms10 = (ct.c_float * 10)()
+    rows = []
+    for rep in range(reps):
+        for i in range(3):
+            frame_a(i, None)
+        em.sync()
+        row = []
+        for i in range(4):
+            frame_b(rep + i, None)
+            lib.emap_get_stage_times(ctx, ms10)
+            row.append((float(sum(ms10)), float(ms10[3]), float(ms10[4])))
+        rows.append(row)
+    lib.emap_enable_stage_timing(ctx, 0)
+    med = lambda k, j: round(float(np.median([r[k][j] for r in rows])), 4)
+    return {"first_frame_ms": med(0, 0), "second_frame_ms": med(1, 0), "fourth_frame_ms": med(3, 0),
+            "first_over_fourth": round(med(0, 0) / max(med(3, 0), 1e-9), 3),
+            "first_frame_gate_fuse_ms": [med(0, 1), med(0, 2)], "fourth_frame_gate_fuse_ms": [med(3, 1), med(3, 2)]}
+
+
 def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step, visits, pmc_ok, stage_bytes=None):
     sb = stage_bytes or {k: f(N, L) for k, f in STAGE_BYTES.items()}
     cand = {k: v for k, v in stage_ms.items() if sb[k] > 0}
@@ -536,11 +561,13 @@ def run_single(a, local_rank=0):
             wallt, mst, _ = timed(emt, frt, k3, loops=3)
             stt, vist = stage_profile(emt._lib, emt._ctx, frt, min(k3, 8))
             valid_t = float((emt.get_layer_raw(2) > 0.5).mean())
+            chg = scene_change(emt, make_frame(emt._lib, emt._ctx), frt)      # uniform clouds (no heavy tiles), then this scene
             coldt = cold_start(emt, frt)
             cfg3["terrain"] = {"workload": "cfg3 on a coherent scene: 2000 x 500 scan-ordered beams ray-cast at rolling ground with moving walls, 1 cm range noise",
                                "ms_per_step": round(wallt * 1e3 / k3, 5), "value": round(th[0].shape[0] * k3 / wallt / 1e6, 2), "unit": "Mpoints/s",
                                "valid_cell_fraction": round(valid_t, 4), "ray_visits_per_frame": int(vist),
-                               "stage_ms": {k_: round(v_, 5) for k_, v_ in stt.items() if v_ > 0}, "cold_start_ms": coldt}
+                               "stage_ms": {k_: round(v_, 5) for k_, v_ in stt.items() if v_ > 0}, "cold_start_ms": coldt,
+                               "after_uniform_frames": chg}
             emt.close()
             free_clouds(hip, td)
 
@@ -569,7 +596,8 @@ def run_single(a, local_rank=0):
             wall1, _, _ = timed(em1, fr1, k1, loops=3)
             lat1 = latencies(em1, fr1, 40)
             cfg1[tag] = {"ms_per_step": round(wall1 * 1e3 / k1, 5), "Mpoints_s": round(N1 * k1 / wall1 / 1e6, 1), "steps": k1,
-                         "latency_ms": {"p10": round(lat1[0], 4), "p50": round(lat1[1], 4), "p90": round(lat1[2], 4)}}
+                         "latency_ms": {"p10": round(lat1[0], 4), "p50": round(lat1[1], 4), "p90": round(lat1[2], 4)},
+                         "path": em1.last_update_path() if hasattr(l1, "emap_last_update_path") else "atomic"}
             em1.close()
 
     # ---- config.cfg4 / config.cfg5: BASELINE configs[3] / configs[4] on ONE GPU, timed in this process by the same code: the

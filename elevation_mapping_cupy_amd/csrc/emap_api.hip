@@ -24,6 +24,9 @@
 // launchers (emap_kernels.hip)
 bool launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, Cells, AccF*, ErrSlot*, const GateArgs*, FrameDev*, unsigned int*);
 void launch_gate(hipStream_t, const GateArgs&, ErrSlot*, FrameDev*, int, double*, const double*);
+int small_frame_grid(const KP&, long);
+void launch_small_frame(hipStream_t, int, const KP&, const Pose&, const float*, long, int, Cells, AccF*, unsigned int*, unsigned long long*, const OverlapArgs&,
+                        const GateArgs&, FrameDev*, ErrSlot*, unsigned int*, unsigned int*, unsigned int*, unsigned int, bool);
 void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, Cells, AccF*, const FrameDev*);
 void launch_commit(hipStream_t, const KP&, Cells, const AccF*, const FrameDev*, unsigned long long*);
 void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, Cells, const AccRView&, const float*, long, FrameDev*, bool, const unsigned long long*, const unsigned int*, int, const float*, const unsigned int*, const unsigned int*);
@@ -76,6 +79,9 @@ bool sem_split_possible(const SemSpec&);
 #define SEM_SPLIT_SLOTS 128      /* heavy tiles whose semantic sums several workgroups may share (19 MB of scratch) */
 void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, AccF*, FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&, const GateFold&, const SplitView&, long);
 #define BIN_MAX_T 16384
+#ifndef EMAP_SPLIT_POOL_DEFAULT
+#define EMAP_SPLIT_POOL_DEFAULT 16      /* standing pool of extra tile workgroups (emap_count) */
+#endif
 #define BIN_MAX_B 2048
 
 // timed stages of emap_update (emap_get_stage_times): hist+scan are 0 on the atomic path, where "scatter" is k_count
@@ -154,6 +160,10 @@ struct emap_ctx {
   OverlapArgs ov_args;             // clear_overlap_map folded into the frame's rewriting kernels (on = 0: separate k_overlap launch)
   bool fold_gate, gate_folded;     // emap_update on the atomic path: the gate rides in k_count's last workgroup (cnt_sync: its ticket words)
   unsigned int* cnt_sync;
+  // robot scale: count -> gate -> fuse -> commit / average in one launch (k_small_frame): its barriers' release words live behind the
+  // ticket words of cnt_sync; sf_err = host-mapped word a barrier that gave up sets (the next call fails loudly, the path stays off)
+  unsigned int sf_epoch; volatile unsigned int* sf_err; unsigned int* sf_err_dev; bool sf_off;
+  int update_path;                 // emap_last_update_path
   bool gate_possible;              // false inside emap_update when the host already knows that the drift gate cannot fire: the per-tile
                                    // error statistics are then skipped (they could not have any effect; err_sum / err_cnt report 0)
   BinGeo bg; BinRec* bin_recs; BinStg* bin_own; unsigned int* bin_own_cnt; long bin_own_cap; bool bin_strip;   // bin_own*: staged records of the owned points per block (strip contexts without a visibility pass)
@@ -409,7 +419,7 @@ int emap_destroy(emap_ctx* ctx) {
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   delete ctx->workers;
   hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert); hipFree(ctx->inl_plane); hipFree(ctx->ray_thr);
-  hipFree(ctx->bin_recs); hipFree(ctx->bin_own); hipFree(ctx->bin_own_cnt); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start); hipFree(ctx->bin_sync); hipFree(ctx->split_mem); hipFree(ctx->sem_split_mem); if (ctx->split_need) hipHostFree((void*)ctx->split_need);
+  hipFree(ctx->bin_recs); hipFree(ctx->bin_own); hipFree(ctx->bin_own_cnt); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start); hipFree(ctx->bin_sync); hipFree(ctx->split_mem); hipFree(ctx->sem_split_mem); if (ctx->split_need) hipHostFree((void*)ctx->split_need); if (ctx->sf_err) hipHostFree((void*)ctx->sf_err);
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   emap_comm_destroy(ctx);
@@ -884,11 +894,15 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
     // heavy tiles are split only when k_tile_count runs in this frame (it leaves the per-cell counts k_tile_fuse's parts need)
     static const bool split_off = getenv("EMAP_SPLIT") && atoi(getenv("EMAP_SPLIT")) == 0;      // A/B and test hook
     ctx->split.on = ctx->gate_possible && !split_off ? 1 : 0;
-    {   // extra workgroups of this frame's tile kernels: what the most recent finished scan asked for, + 25 % (a heavy tile that finds
-        // no room is reduced by its own workgroup alone); the first frame of a cloud with heavy tiles therefore runs unsplit
+    {   // extra workgroups of this frame's tile kernels: what the most recent finished scan asked for, + 25 %, and never fewer than a
+        // small STANDING POOL: a heavy tile takes as many parts as it finds room for (k_bin_scan's tail), so the first frame of a
+        // scene with heavy tiles -- the host has not heard of them yet -- is already reduced by pool + 1 workgroups per tile instead
+        // of one (round 5; before, that frame ran unsplit: 148 instead of 26 us in k_tile_fuse on the terrain scene)
       static const int cap_forced = getenv("EMAP_SPLIT_CAP") ? atoi(getenv("EMAP_SPLIT_CAP")) : -1;      // test hook
+      static const int pool = getenv("EMAP_SPLIT_POOL") ? atoi(getenv("EMAP_SPLIT_POOL")) : EMAP_SPLIT_POOL_DEFAULT;      // A/B knob
       const unsigned int need = *ctx->split_need;
       long cap = need ? (long)need + need / 4 + 8 : 0;
+      if (ctx->split.on && cap < pool) cap = pool;
       if (cap_forced >= 0) cap = cap_forced;
       if (cap > (long)SPLIT_MAX_EXTRA) cap = SPLIT_MAX_EXTRA;
       ctx->split.cap = (int)((cap + 7) & ~7L);
@@ -1145,37 +1159,67 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   const bool tm = ctx->stage_timing;
   int rc;
 #define STAGE(i) do { if (tm) CK(hipEventRecord(ctx->ev[i], ctx->stream)); } while (0)
-  ctx->in_update = true;
+  if (ctx->sf_err && *ctx->sf_err) {          // a grid barrier of an earlier k_small_frame gave up: that frame's result is undefined
+    ctx->sf_off = true; *ctx->sf_err = 0u;
+    ctx->err = "k_small_frame: a grid barrier was not released (the device did not hold the whole grid); the map is undefined from that frame on";
+    return EMAP_ERR_HIP;
+  }
+  const bool rays_on = p.enable_visibility_cleanup != 0;
+  // clear_overlap_map rides on the kernel that rewrites the cells last (tile kernel / k_average, or k_ray_apply after a visibility pass)
+  ctx->ov_args = overlap_args(ctx, t[2], p.enable_overlap_clearance != 0);
+  const bool ov_folded = ctx->ov_args.on != 0;
   // drift gate of elevation_mapping.py:346-349: with compensation off or both noises below their thresholds it cannot fire
   ctx->gate_possible = p.enable_drift_compensation && (position_noise > p.position_noise_thresh || orientation_noise > p.orientation_noise_thresh);
   ctx->pos_noise = position_noise; ctx->ori_noise = orientation_noise;
-  ctx->fold_gate = true; ctx->gate_folded = false;
-  rc = emap_count(ctx, R, t);                 // records ST_HIST / ST_SCAN / ST_SCATTER itself
-  ctx->in_update = false; ctx->fold_gate = false;
-  if (rc) return rc;            // (emap_count also recorded ST_GATE: the stage starts with the per-tile error sums)
-  if (ctx->gate_folded) { ctx->committed = false; ctx->gate_folded = false; }      // (small clouds: k_count's last workgroup was the gate)
-  else if ((rc = emap_set_drift_inputs(ctx, position_noise, orientation_noise, nullptr, nullptr))) return rc;
+  // robot scale (small clouds on small maps: the atomic path): count, gate, fuse and commit / average in ONE launch
+  static const bool sf_env_off = getenv("EMAP_SMALL_FRAME") && atoi(getenv("EMAP_SMALL_FRAME")) == 0;      // A/B and test hook
+  const bool atomic_path = !(ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts_all >= 131072));      // (emap_count's choice)
+  const int sf_grid = (!sf_env_off && !ctx->sf_off && atomic_path && ctx->cnt_sync && !ctx->pts_bucketed) ? small_frame_grid(ctx->kp, ctx->n_pts) : 0;
+  bool fused_small = false;
+  if (sf_grid > 0) {
+    if (!ctx->sf_err) {
+      CK(hipHostMalloc((void**)&ctx->sf_err, 64, hipHostMallocMapped));
+      *ctx->sf_err = 0u;
+      CK(hipHostGetDevicePointer((void**)&ctx->sf_err_dev, const_cast<unsigned int*>(ctx->sf_err), 0));
+    }
+    for (int e = ST_HIST; e <= ST_SCATTER; ++e) STAGE(e);
+    ctx->frame_binned = false; ctx->use_override = false;
+    if (++ctx->sf_epoch == 0u) ctx->sf_epoch = 1u;
+    launch_small_frame(ctx->stream, sf_grid, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc,
+                       ctx->cnt_plane, ctx->inert, ctx->ov_args, gate_args(ctx, position_noise, orientation_noise), ctx->frame, ctx->slots,
+                       ctx->cnt_sync, ctx->cnt_sync + 2048, ctx->sf_err_dev, ctx->sf_epoch, rays_on);
+    CK(hipGetLastError());
+    fused_small = true;
+    STAGE(ST_GATE);
+  } else {
+    ctx->in_update = true;
+    ctx->fold_gate = true; ctx->gate_folded = false;
+    rc = emap_count(ctx, R, t);                 // records ST_HIST / ST_SCAN / ST_SCATTER itself
+    ctx->in_update = false; ctx->fold_gate = false;
+    if (rc) { ctx->ov_args.on = 0; return rc; }            // (emap_count also recorded ST_GATE: the stage starts with the per-tile error sums)
+    if (ctx->gate_folded) { ctx->committed = false; ctx->gate_folded = false; }      // (small clouds: k_count's last workgroup was the gate)
+    else if ((rc = emap_set_drift_inputs(ctx, position_noise, orientation_noise, nullptr, nullptr))) { ctx->ov_args.on = 0; return rc; }
+  }
+  ctx->update_path = fused_small ? 2 : (ctx->frame_binned ? 1 : 0);
   STAGE(ST_FUSE);
   // binned scatter: fusion, commit and averaging happen in ONE tile kernel; with the visibility pass it also writes the inert
   // bitmap and the inlier plane, and the ray effects are applied by k_ray_apply ("average" stage) afterwards
   const bool fused_avg = ctx->frame_binned;
-  const bool rays_on = p.enable_visibility_cleanup != 0;
-  // clear_overlap_map rides on the kernel that rewrites the cells last (tile kernel, or k_ray_apply after a visibility pass)
-  ctx->ov_args = overlap_args(ctx, t[2], p.enable_overlap_clearance != 0);
-  const bool ov_folded = ctx->ov_args.on != 0;
-  rc = fuse_impl(ctx, R, t, fused_avg, rays_on);
+  rc = fused_small ? EMAP_OK : fuse_impl(ctx, R, t, fused_avg, rays_on);
   const OverlapArgs ov = ctx->ov_args; ctx->ov_args.on = 0;
   if (rc) return rc;
   STAGE(ST_COMMIT);
   ctx->rays_fused = fused_avg && rays_on;
   if (rays_on) {
-    if (!fused_avg && (rc = emap_commit(ctx))) return rc;
+    if (fused_small) { ctx->committed = true; ctx->inert_zero = false; ctx->kp.mv.n = 0; }      // (what emap_commit leaves: k_small_frame wrote S1 and the bitmap)
+    else if (!fused_avg && (rc = emap_commit(ctx))) return rc;
     STAGE(ST_RAYS);
     rc = emap_rays(ctx, R, t);
     if (rc) { ctx->rays_fused = false; return rc; }
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
-  if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane, ov); ctx->kp.mv.n = 0; }
+  if (fused_small && !rays_on) ctx->kp.mv.n = 0;            // (k_small_frame committed and averaged: every cell rewritten)
+  else if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane, ov); ctx->kp.mv.n = 0; }
   else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame, ctx->split.need_host ? ctx->split.need_host + 1 : nullptr, ctx->ray_par ^= 1); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
@@ -2327,6 +2371,7 @@ int emap_timer_end(emap_ctx* ctx, float* ms) {
   return EMAP_OK;
 }
 int emap_enable_stage_timing(emap_ctx* ctx, int enable) { CKARG(ctx, "null ctx"); ctx->stage_timing = enable != 0; ctx->want_ray_stats = enable > 1; return EMAP_OK; }
+int emap_last_update_path(emap_ctx* ctx, int32_t* path) { CKARG(ctx && path, "null argument"); *path = ctx->update_path; return EMAP_OK; }
 int emap_get_stage_times(emap_ctx* ctx, float ms_out[10]) { CKARG(ctx && ms_out, "null argument"); for (int i = 0; i < ST_N; ++i) ms_out[i] = ctx->stage_ms[i]; return EMAP_OK; }
 
 }  // extern "C"

@@ -218,11 +218,15 @@ __global__ __launch_bounds__(SCAN_BLK) void k_bin_scan(BinGeo G, unsigned int* _
     tile_start[tt] = run; run += n_t;
     if (SV.on && tt < G.T) {                                  // heavy tile: a slot per stacked tile of the bin, an extra workgroup per further part
       if (n_t > SPLIT_CAP) {                                  // (tile_slot is read for such tiles only)
-        const unsigned int np = split_parts(n_t);
-        const unsigned int s0 = atomicAdd(&s_nslot, (unsigned int)G.sub), e0 = atomicAdd(&s_nextra, np - 1u);
-        const bool fits = s0 + (unsigned int)G.sub <= SPLIT_MAX_SLOTS && e0 + np - 1u <= (unsigned int)SV.cap;     // (cap: the extra workgroups of this frame's launches)
-        for (unsigned int q = 1u; q < np; ++q) if (e0 + q - 1u < (unsigned int)SV.cap) SV.extra[e0 + q - 1u] = fits ? (((unsigned int)tt << 8) | q) : SPLIT_NONE;
-        SV.tile_slot[tt] = fits ? s0 : SPLIT_NONE;
+        // the tile WANTS split_parts(n_t) parts; it GETS as many as the extra workgroups of this frame's launches leave room for (cap:
+        // sized by the last finished frame's need, never below the standing pool -- emap_api.hip) -- at least two, or it is reduced
+        // by its own workgroup alone.  The number of parts travels in the high half of the tile's slot word.
+        const unsigned int want = split_parts(n_t) - 1u;
+        const unsigned int s0 = atomicAdd(&s_nslot, (unsigned int)G.sub), e0 = atomicAdd(&s_nextra, want);
+        const unsigned int room = e0 < (unsigned int)SV.cap ? (unsigned int)SV.cap - e0 : 0u, take = min(want, room);
+        const bool fits = s0 + (unsigned int)G.sub <= SPLIT_MAX_SLOTS && take > 0u;
+        for (unsigned int q = 1u; q <= take; ++q) SV.extra[e0 + q - 1u] = fits ? (((unsigned int)tt << 8) | q) : SPLIT_NONE;
+        SV.tile_slot[tt] = fits ? (s0 | ((take + 1u) << 16)) : SPLIT_NONE;
       }
     }
   }
@@ -339,9 +343,9 @@ __device__ __forceinline__ bool tile_work(const BinGeo& G, const SplitView& SV, 
   const unsigned int R0 = tile_start[w.t], R1 = tile_start[w.t + 1], n = R1 - R0;
   w.np = 1u; w.slot = SPLIT_NONE; w.r0 = R0; w.r1 = R1;
   if (SPLIT && n > SPLIT_CAP) {                                  // a heavy tile (uniform); the scan's tail listed it -- or found no room
-    const unsigned int s0 = SV.tile_slot[w.t];
-    if (s0 != SPLIT_NONE) {
-      w.np = split_parts(n); w.slot = s0 + (unsigned int)w.sb;
+    const unsigned int sw = SV.tile_slot[w.t];                   // first slot | parts << 16 (k_bin_scan's tail: as many parts as there was room for)
+    if (sw != SPLIT_NONE) {
+      w.np = sw >> 16; w.slot = (sw & 0xffffu) + (unsigned int)w.sb;
       const unsigned int len = (n + w.np - 1u) / w.np;
       w.r0 = min(R1, R0 + w.part * len); w.r1 = min(R1, w.r0 + len);
     }

@@ -611,6 +611,176 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cells cells, AccF* _
   if (a.pts_inl | a.cnt_out) { AccF z = {0ull, 0ull, 0ll, 0ll, 0ull}; acc[c] = z; }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Robot scale (round 5): phases A, A', B and B' / D of a small frame in ONE launch.
+// The configuration the reference ships (202^2 cells, ~50 k points per cloud: parameter.py:137,165) is neither bandwidth nor
+// issue bound here: its frame is a chain of dependent launches of 2-4 us of work each, and every launch costs ~4.5 us of dispatch +
+// drain on this stack.  k_small_frame runs count -> gate -> fuse -> commit+average (or, in front of a visibility pass, commit + inert
+// bitmap) as ONE grid with two grid-wide barriers in between: every workgroup is resident (launch_small_frame bounds the grid by a
+// quarter of what the device holds), a barrier is k_bin_scan's two-level ticket + one release word the waiting workgroups poll.
+//   * a thread keeps ITS point (geometry, cell, the cell's hot half) in registers from the count to the fuse phase: the cloud is read
+//     and transformed once per frame instead of twice;
+//   * what one phase writes and the next reads on ANOTHER XCD (per-cell counts, the accumulators, the shift) only ever moves through
+//     device-scope atomics and device-coherent (sc1) loads / stores -- the XCDs' L2s are not coherent with each other inside a launch.
+//     Same hand-off as last_block_ticket: stores acknowledged (s_waitcnt), workgroup barrier, ticket; see the note there;
+//   * the arithmetic is k_count's, k_fuse's and k_commit's / k_average's, statement for statement: the accumulators are integers,
+//     so the frame is bit-identical to the chain of launches (tests/test_hip_small_frame.py), which stays as the staged API, as the
+//     path of larger maps / clouds and as the fallback when the device cannot hold the grid.
+// A barrier that is not released within ~2 s (another grid holding the device: cannot happen to a grid this size on an MI355X that
+// is not partitioned, but a hang would take the whole box down) gives up, the frame's result is then undefined and the host-mapped
+// word makes the next call fail loudly (emap_api.hip).
+// ---------------------------------------------------------------------------------------------------------
+struct SmallFrame {
+  GateArgs A; FrameDev* F; ErrSlot* slots;
+  unsigned int* sync;        // two sets of ticket words (1024 apart), zero between launches
+  unsigned int* flag;        // [0], [32]: release words of the two barriers (= epoch of the last launch that passed); [64]: the frame's shift
+  unsigned int* err_host;    // host-mapped: a barrier gave up
+  unsigned int epoch;        // distinct per launch, never 0
+  int rays;                  // 1: a visibility pass follows (phase B' = k_commit: S1 + inert bitmap); 0: commit + average (k_average<false, false>)
+};
+#define SF_SPIN_LIMIT (1u << 21)
+__device__ __forceinline__ unsigned long long ld_dev(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ AccF acc_load_dev(const AccF* a) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(a);
+  AccF r; r.pts_inl = ld_dev(q); r.cnt_out = ld_dev(q + 1); r.sum_h = (long long)ld_dev(q + 2); r.sum_v = (long long)ld_dev(q + 3); r.latest = ld_dev(q + 4);
+  return r;
+}
+// every thread of the grid calls this; true in all threads of the LAST workgroup to arrive (which runs its serial section and then sf_release)
+__device__ __forceinline__ bool sf_arrive(unsigned int* sync, bool* s_last) {
+  __builtin_amdgcn_s_waitcnt(0);                               // this wave's atomics / device-coherent stores are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) *s_last = last_block_ticket(sync, blockIdx.x, gridDim.x);
+  __syncthreads();
+  return *s_last;
+}
+__device__ __forceinline__ void sf_release(unsigned int* flag, unsigned int epoch) {
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sf_wait(const unsigned int* flag, unsigned int epoch, unsigned int* err_host) {
+  if (threadIdx.x == 0) {
+    unsigned int it = 0u;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++it > SF_SPIN_LIMIT) { __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+  }
+  __syncthreads();
+}
+template <int MODE>
+__global__ __launch_bounds__(EM_BLOCK) void k_small_frame(KP P, Pose T, const float* __restrict__ pts, long n, int stride, Cells cells,
+                                                           AccF* __restrict__ acc, unsigned int* __restrict__ cnt_out,
+                                                           unsigned long long* __restrict__ inert, OverlapArgs O, SmallFrame S) {
+  __shared__ bool s_last;
+  const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;          // one point per thread (the host launches at least n threads)
+  // ---- phase A: k_count ------------------------------------------------------------------------------------------------------
+  long c = -1;
+  float gz = 0.f, gv = 0.f;
+  float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+  long long e_fix = 0;
+  unsigned int inl = 0;
+  if (i < n) {
+    float rx, ry, rz;
+    load_point(pts, i, stride, rx, ry, rz);
+    const Geo g = geometry<MODE>(P, T, rx, ry, rz);
+    const Owned oc = owned(P, g.ix, g.iy);
+    c = (g.finite && g.valid && g.inside) ? oc.c : -1;
+    gz = g.z; gv = g.v;
+    if (c >= 0) {
+      m = cells.hot[c];   // h, v, valid, trav
+      cell_now(P, m, oc.prow, oc.pcol);
+      const bool inlier = m.z > 0.5f && (double)fabsf(m.x - gz) < (double)m.y * P.mt && (double)m.y < P.dcvi_half &&
+                          (double)m.w > P.trav_inlier;
+      if (inlier) { inl = 1; e_fix = __double2ll_rn((double)(gz - m.x) * EM_SCALE_E); }
+      atomicAdd(&acc[c].pts_inl, 1ull | ((unsigned long long)inl << 32));
+    }
+  }
+  if (__any(inl)) {
+    const long long s = wave_sum_ll(e_fix);
+    const unsigned long long k = __popcll(__ballot(inl));
+    if ((threadIdx.x & 63) == 0) {
+      const unsigned int slot = (blockIdx.x * (EM_BLOCK / 64) + (threadIdx.x >> 6)) & (EM_ERR_SLOTS - 1);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&S.slots[slot].sum), (unsigned long long)s);
+      atomicAdd(&S.slots[slot].cnt, k);
+    }
+  }
+  // ---- barrier 1; the last workgroup is the drift gate (k_gate) and publishes the shift ----------------------------------------
+  if (sf_arrive(S.sync, &s_last)) {
+    if (threadIdx.x < 64) {
+      gate_eval(S.A, S.slots, S.F, (int)threadIdx.x, 0, nullptr, nullptr);
+      if (threadIdx.x == 0) __hip_atomic_store(S.flag + 64, __float_as_uint(S.F->shift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    sf_release(S.flag, S.epoch);
+  } else sf_wait(S.flag, S.epoch, S.err_host);
+  const float shift = __uint_as_float(__hip_atomic_load(S.flag + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  // ---- phase B: k_fuse against snapshot S0 ---------------------------------------------------------------------------------------
+  if (c >= 0) {
+    unsigned long long* const a = reinterpret_cast<unsigned long long*>(acc + c);      // pts_inl, cnt_out, sum_h, sum_v, latest
+    const float map_h = m.x + shift, map_v = m.y;
+    const unsigned int n_pts = (unsigned int)(ld_dev(a) & 0xffffffffull);
+    const float num_points = (float)n_pts;
+    const bool single = n_pts == 1u;                                 // a single writer: stores instead of atomics
+    if ((double)fabsf(map_h - gz) > (double)map_v * P.mt) {          // outlier :173-175
+      if (single) st_dev(a + 1, 1ull << 32); else atomicAdd(a + 1, 1ull << 32);
+    } else if (!(P.edge && (double)num_points > P.wall &&
+                 (double)gz < (double)map_h - (double)map_v * P.mt / (double)num_points)) {   // edge sharpening :177-179
+      const float new_h = (map_h * gv + gz * map_v) / (map_v + gv);          // :181-182
+      const float new_v = (map_v * gv) / (map_v + gv);
+      const long long fh = __double2ll_rn((double)new_h * EM_SCALE_H), fv = __double2ll_rn((double)new_v * EM_SCALE_V);
+      const unsigned long long lt = ((unsigned long long)(i + 1) << 32) | (unsigned long long)__float_as_uint(new_h);
+      if (single) { st_dev(a + 1, 1ull); st_dev(a + 2, (unsigned long long)fh); st_dev(a + 3, (unsigned long long)fv); st_dev(a + 4, lt); }
+      else {
+        atomicAdd(a + 2, (unsigned long long)fh);
+        atomicAdd(a + 3, (unsigned long long)fv);
+        atomicAdd(a + 1, 1ull);
+        atomicMax(a + 4, lt);
+      }
+    }
+  }
+  // ---- barrier 2 -------------------------------------------------------------------------------------------------------------------
+  if (sf_arrive(S.sync + 1024, &s_last)) sf_release(S.flag + 32, S.epoch);
+  else sf_wait(S.flag + 32, S.epoch, S.err_host);
+  // ---- per cell --------------------------------------------------------------------------------------------------------------------
+  if (!S.rays) {                                                    // k_average<false, false>: commit + average + overlap clearing + re-arm
+    const long ncell = (long)P.nrows * P.C, gstride = (long)gridDim.x * EM_BLOCK;
+    for (long li = i; li < ncell; li += gstride) {
+      const long cc = li + (long)P.halo * P.C;
+      Cell q = cells[cc];
+      const AccF a = acc_load_dev(acc + cc);
+      const int lrow = (int)(li / P.C), pcol = (int)(li - (long)lrow * P.C);
+      if (P.mv.n) cell_now(P, q, P.row0 + lrow, pcol);               // pending map shifts
+      q.h += shift; commit_cell(P, q, a);
+      if (cnt_out) cnt_out[cc] = (unsigned int)(a.cnt_out & 0xffffffffull);
+      average_cell(P, q, a);
+      if (O.on && overlap_window(O, logi_row(P, P.row0 + lrow), logi_col(P, pcol))) overlap_cell(P, O, q);
+      cells[cc] = q;
+      if (a.pts_inl | a.cnt_out) { AccF z = {0ull, 0ull, 0ll, 0ll, 0ull}; acc[cc] = z; }
+    }
+  } else {                                                          // k_commit: S1 + the inert bitmap, one wave per word
+    const int wpr = (P.C + 63) / 64, lane = threadIdx.x & 63;
+    const long nw = (long)P.nrows * wpr, wstride = (long)gridDim.x * (EM_BLOCK / 64);
+    for (long w = (long)blockIdx.x * (EM_BLOCK / 64) + (threadIdx.x >> 6); w < nw; w += wstride) {
+      const int lrow = (int)(w / wpr), cg = (int)(w - (long)lrow * wpr), lcol = cg * 64 + lane, prow = P.row0 + lrow;
+      bool quiet = false;
+      if (lcol < P.C) {
+        const int pcol = phys_col(P, lcol);
+        const long cc = (long)(lrow + P.halo) * P.C + pcol;
+        Cell q = cells[cc];
+        cell_now(P, q, prow, pcol);
+        const AccF a = acc_load_dev(acc + cc);
+        q.h += shift;
+        commit_cell(P, q, a);
+        cells[cc] = q;
+        quiet = (!(q.valid < 0.5f) && q.time < 0.5f) || border_cell(P, logi_row(P, prow), lcol);
+      }
+      const unsigned long long bits = __ballot(quiet);
+      if (lane == 0) inert[(long)bitmap_row(P, prow) * wpr + cg] = bits;
+    }
+  }
+}
+
 // Applies the effects of the visibility pass when the tile kernel has already committed AND averaged the frame (binned path):
 // only cells that are not fused this frame can carry ray effects (a fused cell is known and fresh: every ray skips it), so this is
 // a 16-byte stream over the ray accumulators with a read-modify-write of the few touched cells: validity decrement + variance
@@ -1359,6 +1529,42 @@ bool launch_count(hipStream_t s, const KP& P, const Pose& T, const float* pts, l
   if (P.mode == 0) hipLaunchKernelGGL(k_count<0>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, slots, CG);
   else hipLaunchKernelGGL(k_count<1>, dim3(nblk(n)), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, slots, CG);
   return CG.on != 0;
+}
+// Workgroups k_small_frame may use on the current device: a QUARTER of what the device holds at once (all of them must be resident;
+// the margin leaves room for the grids of other contexts / streams on the same device).  0: do not use it.
+static int small_frame_limit() {
+  static int limit[EM_MAX_DEV]; static bool known[EM_MAX_DEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EM_MAX_DEV) return 0;
+  if (!known[dev]) {
+    int cus = 0, nb0 = 0, nb1 = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, reinterpret_cast<const void*>(k_small_frame<0>), EM_BLOCK, 0) != hipSuccess) nb0 = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void*>(k_small_frame<1>), EM_BLOCK, 0) != hipSuccess) nb1 = 0;
+    (void)hipGetLastError();
+    const long all = (long)cus * (nb0 < nb1 ? nb0 : nb1);
+    limit[dev] = (int)(all / 4 > 512 ? 512 : all / 4);             // (512 x 256 threads = the largest cloud of the atomic path)
+    known[dev] = true;
+  }
+  return limit[dev];
+}
+// the grid of k_small_frame for n points on P's map, 0: the frame keeps the chain of launches
+int small_frame_grid(const KP& P, long n) {
+  if (n <= 0 || P.nrows != P.C || P.halo != 0 || P.C > 512) return 0;
+  const long cells = (long)P.nrows * P.C;
+  long g = nblk(n);
+  const long gc = nblk(cells) < 256 ? nblk(cells) : 256;           // small clouds: enough workgroups for the per-cell phase
+  if (g < gc) g = gc;
+  const int limit = small_frame_limit();
+  return g <= limit ? (int)g : 0;
+}
+void launch_small_frame(hipStream_t s, int grid, const KP& P, const Pose& T, const float* pts, long n, int stride, Cells cells, AccF* acc,
+                        unsigned int* cnt_out, unsigned long long* inert, const OverlapArgs& O, const GateArgs& gate, FrameDev* F,
+                        ErrSlot* slots, unsigned int* sync, unsigned int* flag, unsigned int* err_host, unsigned int epoch, bool rays) {
+  SmallFrame S; memset(&S, 0, sizeof S);
+  S.A = gate; S.F = F; S.slots = slots; S.sync = sync; S.flag = flag; S.err_host = err_host; S.epoch = epoch; S.rays = rays ? 1 : 0;
+  if (P.mode == 0) hipLaunchKernelGGL(k_small_frame<0>, dim3(grid), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, cnt_out, inert, O, S);
+  else hipLaunchKernelGGL(k_small_frame<1>, dim3(grid), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, cnt_out, inert, O, S);
 }
 void launch_gate(hipStream_t s, const GateArgs& A, ErrSlot* slots, FrameDev* F, int reduce_only, double* dev_out, const double* dev_totals) {
   hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, A, slots, F, reduce_only, dev_out, dev_totals);

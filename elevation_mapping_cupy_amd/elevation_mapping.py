@@ -196,6 +196,13 @@ class ElevationMap:
         self._chk(self._lib.emap_set_scatter_mode(self._ctx, {"auto": 0, "atomic": 1, "binned": 2}[mode] | (int(bin_stack) << 8)))
         self._scatter_mode = mode
 
+    def last_update_path(self):
+        """which kernels the last whole frame ran: "atomic" (chain of launches), "binned" (tile kernels) or "small_frame" (one launch,
+        robot scale) -- include/emap_hip.h: emap_last_update_path; the results are bit-identical"""
+        v = ct.c_int32(-1)
+        self._chk(self._lib.emap_last_update_path(self._ctx, ct.byref(v)))
+        return {0: "atomic", 1: "binned", 2: "small_frame"}[v.value]
+
     def set_ray_mode(self, mode):
         """"auto" | "by_row" | "by_ray": how a SHARDED frame (emap_update_sharded) runs the visibility pass (include/emap_hip.h:
         emap_set_ray_mode; bit-identical results, every rank the same setting)"""

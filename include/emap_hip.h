@@ -342,6 +342,12 @@ int emap_timer_end(emap_ctx* ctx, float* elapsed_ms); /* records, synchronises, 
  * enabling inserts hipEvents between the stages (each costs a few microseconds of its own) */
 int emap_enable_stage_timing(emap_ctx* ctx, int enable);
 int emap_get_stage_times(emap_ctx* ctx, float ms_out[10]);
+/* which kernels the last emap_update ran for phases count .. commit / average (results are bit-identical on all three):
+ * 0 = chain of launches with global atomics (k_count, k_fuse, k_commit / k_average), 1 = tile-binned (sort front-end + tile kernels),
+ * 2 = ONE launch, k_small_frame: small clouds on maps of up to 512^2 cells -- the robot-scale configuration the reference ships
+ * (EM/parameter.py:137,165 -> 202^2 cells; EM/elevation_mapping.py:316-391 is a chain of ~12 dependent launches there).
+ * EMAP_SMALL_FRAME=0 in the environment keeps such frames on path 0. */
+int emap_last_update_path(emap_ctx* ctx, int32_t* path);
 
 #ifdef __cplusplus
 }

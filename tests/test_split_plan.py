@@ -2,9 +2,11 @@
 in Python from the constants of the header and checked for the invariants the kernels rely on -- for ANY tile totals, any capacity the
 host launched and any order in which the scan's threads reserve list entries:
   * a tile is either reduced whole by its own workgroup, or by exactly np workgroups (its own + np - 1 listed parts) whose record
-    ranges tile [R0, R1) without gap or overlap -- np is what the last-arriving part compares its ticket with;
-  * no more parts are listed than extra workgroups were launched; a tile that finds no room falls back to its own workgroup alone;
-  * list entries past the reservation of a tile without room are marked empty, never stale.
+    ranges tile [R0, R1) without gap or overlap -- np is what the last-arriving part compares its ticket with, and it travels in the
+    high half of the tile's slot word: a tile takes as many parts as the launch has room for (round 5: a standing pool of extra
+    workgroups splits the heavy tiles of a scene the host has not heard of yet), 2 <= np <= split_parts(n);
+  * no more parts are listed than extra workgroups were launched; a tile that finds no room at all falls back to its own workgroup;
+  * every list entry below the listed count is written in this frame (a part, or the empty marker), never stale.
 The GPU tests (tests/test_hip_terrain.py) check the kernels' results bit for bit; this pins the arithmetic they share with the host."""
 import os
 import re
@@ -40,14 +42,14 @@ def scan_tail(totals, cap, sub, order):
         n = int(totals[tt])
         if n <= CAP:
             continue
-        nparts = split_parts(n)
+        want = split_parts(n) - 1
         s0, e0 = n_slot, n_extra
-        n_slot += sub; n_extra += nparts - 1
-        fits = s0 + sub <= MAX_SLOTS and e0 + nparts - 1 <= cap
-        for q in range(1, nparts):
-            if e0 + q - 1 < cap:
-                extra[e0 + q - 1] = ((tt << 8) | q) if fits else NONE
-        slot_of[tt] = s0 if fits else NONE
+        n_slot += sub; n_extra += want
+        take = min(want, max(cap - e0, 0))
+        fits = s0 + sub <= MAX_SLOTS and take > 0
+        for q in range(1, take + 1):
+            extra[e0 + q - 1] = ((tt << 8) | q) if fits else NONE
+        slot_of[tt] = (s0 | ((take + 1) << 16)) if fits else NONE
     return start, extra, slot_of, min(n_extra, cap), n_extra
 
 
@@ -73,8 +75,9 @@ def tile_work(block, cap, sub, n_tiles, start, extra, slot_of, n_listed):
     n = R1 - R0
     nparts, r0, r1, slot = 1, R0, R1, NONE
     if n > CAP and slot_of.get(t, NONE) != NONE:
-        nparts = split_parts(n)
-        slot = slot_of[t] + sb
+        nparts = slot_of[t] >> 16
+        assert 2 <= nparts <= split_parts(n)
+        slot = (slot_of[t] & 0xFFFF) + sb
         ln = (n + nparts - 1) // nparts
         r0 = min(R1, R0 + part * ln); r1 = min(R1, r0 + ln)
     return t, sb, part, nparts, r0, r1, slot
@@ -82,6 +85,7 @@ def tile_work(block, cap, sub, n_tiles, start, extra, slot_of, n_listed):
 
 def test_constants_fit_their_encodings():
     assert MAX_PARTS < 256                                     # the part index is 8 bits of a list entry
+    assert MAX_SLOTS + 4 < 1 << 16 and MAX_PARTS < 1 << 15    # slot | parts << 16 in one word, never the empty marker
     assert 16384 << 8 < NONE                                   # (bin << 8) | part never looks like the empty marker
     assert 16 * 1024 * 1024 // CAP <= MAX_EXTRA                # the parts a 16 M-point frame can need fit the list
 
@@ -124,6 +128,6 @@ def test_every_record_is_reduced_exactly_once(data):
             assert spans[0][0] == start[t] and spans[-1][1] == start[t + 1]
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])), "gap or overlap between the parts"
             if nparts > 1:
-                s = slot_of[t] + sb
+                s = (slot_of[t] & 0xFFFF) + sb
                 assert s not in slots_seen, "two tiles share a slot"
                 slots_seen[s] = key
