@@ -349,6 +349,38 @@ __device__ __forceinline__ bool last_block_ticket(unsigned int* __restrict__ syn
   return true;
 }
 
+// ---- grid-wide barrier of the single-launch kernels (k_small_frame, k_bin_sort) -------------------------------------------------
+// Every workgroup of the grid is RESIDENT (the host bounds the grid by what the device holds: small_frame_grid / sort_grid).  A barrier
+// is the two-level ticket above + one release word the waiting workgroups poll with device-coherent loads.  What a phase publishes for
+// the next one goes out as device-scope atomics / device-coherent (sc1) stores BEFORE the arrival (s_waitcnt: acknowledged) and is read
+// back with device-coherent loads after the release -- the hand-off of last_block_ticket, see the note there.  The release word holds
+// the epoch of the last launch that passed (distinct per launch, never 0).  A wait that is not released within ~2 s gives up (the
+// frame's result is then undefined) and sets a host-mapped word: the next call on the context fails loudly instead of the box hanging.
+#define SF_SPIN_LIMIT (1u << 21)
+// every thread of the grid calls this; true in all threads of the LAST workgroup to arrive (which runs its serial section and then sf_release)
+__device__ __forceinline__ bool sf_arrive(unsigned int* sync, bool* s_last) {
+  __builtin_amdgcn_s_waitcnt(0);                               // this wave's atomics / device-coherent stores are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) *s_last = last_block_ticket(sync, blockIdx.x, gridDim.x);
+  __syncthreads();
+  return *s_last;
+}
+__device__ __forceinline__ void sf_release(unsigned int* flag, unsigned int epoch) {
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sf_wait(const unsigned int* flag, unsigned int epoch, unsigned int* err_host) {
+  if (threadIdx.x == 0) {
+    unsigned int it = 0u;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++it > SF_SPIN_LIMIT) { __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+  }
+  __syncthreads();
+}
+
 // ---- drift gate (elevation_mapping.py:346-352) --------------------------------------------------------------------------
 // One wave: sums the error slots (integer => order independent), decides the shift, keeps additive_mean_error, re-arms the slots.
 // (Folding it into the last workgroup of k_tile_count was measured: no gain -- a small dependent launch costs ~1 us in the frame.)

@@ -638,36 +638,12 @@ struct SmallFrame {
   unsigned int epoch;        // distinct per launch, never 0
   int rays;                  // 1: a visibility pass follows (phase B' = k_commit: S1 + inert bitmap); 0: commit + average (k_average<false, false>)
 };
-#define SF_SPIN_LIMIT (1u << 21)
 __device__ __forceinline__ unsigned long long ld_dev(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ AccF acc_load_dev(const AccF* a) {
   const unsigned long long* q = reinterpret_cast<const unsigned long long*>(a);
   AccF r; r.pts_inl = ld_dev(q); r.cnt_out = ld_dev(q + 1); r.sum_h = (long long)ld_dev(q + 2); r.sum_v = (long long)ld_dev(q + 3); r.latest = ld_dev(q + 4);
   return r;
-}
-// every thread of the grid calls this; true in all threads of the LAST workgroup to arrive (which runs its serial section and then sf_release)
-__device__ __forceinline__ bool sf_arrive(unsigned int* sync, bool* s_last) {
-  __builtin_amdgcn_s_waitcnt(0);                               // this wave's atomics / device-coherent stores are acknowledged
-  __syncthreads();
-  if (threadIdx.x == 0) *s_last = last_block_ticket(sync, blockIdx.x, gridDim.x);
-  __syncthreads();
-  return *s_last;
-}
-__device__ __forceinline__ void sf_release(unsigned int* flag, unsigned int epoch) {
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void sf_wait(const unsigned int* flag, unsigned int epoch, unsigned int* err_host) {
-  if (threadIdx.x == 0) {
-    unsigned int it = 0u;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++it > SF_SPIN_LIMIT) { __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-    }
-  }
-  __syncthreads();
 }
 template <int MODE>
 __global__ __launch_bounds__(EM_BLOCK) void k_small_frame(KP P, Pose T, const float* __restrict__ pts, long n, int stride, Cells cells,
