@@ -309,12 +309,7 @@ def scene_change(em, frame_a, frame_b, reps=3):
 
 
 def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step, visits, pmc_ok, stage_bytes=None):
-    sb = dict(stage_bytes or {k: f(N, L) for k, f in STAGE_BYTES.items()})
-    stage_kernel = dict(STAGE_KERNEL)
-    if stage_ms.get("hist", 0) > 0 and stage_ms.get("scan", 0) <= 1e-4 and stage_ms.get("scatter", 0) <= 1e-4 and stage_bytes is None:
-        # the sort front-end ran as ONE launch (k_bin_sort: the "hist" spacing is the whole sort): the cloud in once, the records out
-        sb["hist"] = 12 * N + 16 * N
-        stage_kernel["hist"] = "k_bin_sort"
+    sb = stage_bytes or {k: f(N, L) for k, f in STAGE_BYTES.items()}
     cand = {k: v for k, v in stage_ms.items() if sb[k] > 0}
     dom = max(cand, key=cand.get)
     dom_bytes = sb[dom]
@@ -328,7 +323,7 @@ def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step
     traffic, traffic_src = None, None
     pmc_file = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (PROFILE_ROUND, workload))
     if pmc_ok and os.path.exists(pmc_file):
-        kern = stage_kernel[dom]
+        kern = STAGE_KERNEL[dom]
         pj = json.load(open(pmc_file))
         if pj.get("source_stamp") == source_stamp():
             most = -1.0
@@ -338,7 +333,7 @@ def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step
                     traffic, traffic_src = rec["hbm_bytes"], "profiles/%s (%s, median of %d launches)" % (os.path.basename(pmc_file), name, rec.get("launches", 0))
     # `frac` is LIVE: the dominant kernel's algorithmic bytes over its event spacing in THIS run.  Beside it, when profiles/ holds a
     # rocprofv3 summary of this command taken with THESE kernel sources, the same bytes over that summary's median duration
-    kus, ksrc = rocprof_kernel_us(workload, stage_kernel[dom]) if pmc_ok else (None, None)
+    kus, ksrc = rocprof_kernel_us(workload, STAGE_KERNEL[dom]) if pmc_ok else (None, None)
     frac_rocprof = round(dom_bytes / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if kus else None
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_source": "live: hipEvent spacing of the kernel on its stream in this run (kernel_ms)",

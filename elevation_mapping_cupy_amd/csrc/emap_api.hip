@@ -70,9 +70,6 @@ void launch_band_clear(hipStream_t, const KP&, float*, int, long, int, int);
 // tile-binned scatter (emap_binned.hip)
 void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, unsigned int*, BinStg*, unsigned int*);
 void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*, unsigned int*, const SplitView&);
-bool bin_sort_plan(const KP&, const BinGeo&, long, int*, long*);
-void launch_bin_sort(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, unsigned int*, unsigned int*, unsigned int*, BinRec*, const SplitView&,
-                     unsigned int*, unsigned int*, unsigned int);
 void launch_bin_scatter(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, const unsigned int*, const unsigned int*, BinRec*, const BinStg*, const unsigned int*);
 void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, ErrSlot*, const SplitView&, long);
 void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const ChanView&, long,
@@ -167,8 +164,6 @@ struct emap_ctx {
   // ticket words of cnt_sync; sf_err = host-mapped word a barrier that gave up sets (the next call fails loudly, the path stays off)
   unsigned int sf_epoch; volatile unsigned int* sf_err; unsigned int* sf_err_dev; bool sf_off;
   int update_path;                 // emap_last_update_path
-  bool sort_one_launch;            // this frame's sort front-end was k_bin_sort
-  bool sort_three;                 // test hook (emap_set_scatter_mode bit 16): never k_bin_sort
   bool gate_possible;              // false inside emap_update when the host already knows that the drift gate cannot fire: the per-tile
                                    // error statistics are then skipped (they could not have any effect; err_sum / err_cnt report 0)
   BinGeo bg; BinRec* bin_recs; BinStg* bin_own; unsigned int* bin_own_cnt; long bin_own_cap; bool bin_strip;   // bin_own*: staged records of the owned points per block (strip contexts without a visibility pass)
@@ -799,14 +794,6 @@ static int ensure_bins(emap_ctx* ctx, bool raybin) {
   long chunk = (n + B - 1) / B; chunk = ((chunk + unit - 1) / unit) * unit;
   g.B = (int)((n + chunk - 1) / chunk); if (g.B < 1) g.B = 1;
   g.chunk = chunk;
-  // small enough clouds on whole-map contexts sort in ONE launch (k_bin_sort: histogram, scan and scatter behind grid barriers, the
-  // points' geometry kept in registers in between) with blocks sized for a resident grid; everything else in three launches
-  static const bool sort_off = getenv("EMAP_BIN_SORT") && atoi(getenv("EMAP_BIN_SORT")) == 0;      // A/B and test hook
-  ctx->sort_one_launch = false;
-  if (!sort_off && !ctx->sort_three && !ctx->sf_off && !ctx->bin_strip && ctx->strip.row_count == ctx->prm.cell_n) {
-    int b1 = 0; long c1 = 0;
-    if (bin_sort_plan(ctx->kp, g, n, &b1, &c1)) { g.B = b1; g.chunk = c1; chunk = c1; ctx->sort_one_launch = true; }
-  }
   const size_t hist_need = (size_t)g.pitch * (size_t)g.B;
   if (hist_need > ctx->bin_hist_cap) {
     CK(hipStreamSynchronize(ctx->stream));
@@ -862,10 +849,9 @@ static int ensure_bins(emap_ctx* ctx, bool raybin) {
 
 int emap_set_scatter_mode(emap_ctx* ctx, int32_t mode) {
   const int m = mode & 0xff, sub = (mode >> 8) & 0xff;
-  CKARG(ctx && m >= 0 && m <= 2 && (mode >> 17) == 0, "scatter mode: 0 auto, 1 atomic, 2 binned");
+  CKARG(ctx && m >= 0 && m <= 2 && (mode >> 16) == 0, "scatter mode: 0 auto, 1 atomic, 2 binned");
   CKARG(sub == 0 || (sub <= 64 && (sub & (sub - 1)) == 0), "bin height factor must be a power of two <= 64");
   ctx->force_sub = sub;
-  ctx->sort_three = ((mode >> 16) & 1) != 0;      // test hook: the sort front-end keeps its three launches (k_bin_hist / k_bin_scan / k_bin_scatter)
   CKARG(m != 2 || bins_possible(ctx), "binned scatter: too many bins for the LDS histogram");
   ctx->scatter_mode = m;
   return EMAP_OK;
@@ -877,7 +863,7 @@ int emap_set_ray_mode(emap_ctx* ctx, int32_t mode) {
   return EMAP_OK;
 }
 
-// the host-mapped word a grid barrier that gave up sets (k_small_frame, k_bin_sort: emap_device.h)
+// the host-mapped word a grid barrier that gave up sets (k_small_frame: emap_device.h)
 static int ensure_barrier_word(emap_ctx* ctx) {
   if (ctx->sf_err) return EMAP_OK;
   CK(hipHostMalloc((void**)&ctx->sf_err, 64, hipHostMallocMapped));
@@ -911,11 +897,9 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
     const bool tm = ctx->stage_timing && ctx->in_update;
     const Pose pose = make_pose(ctx, R, t);
     BinStg* own = ctx->bin_strip ? ctx->bin_own : nullptr;
-    const bool one_launch = ctx->sort_one_launch && !own;      // (ensure_bins sized the blocks for k_bin_sort)
-    if (one_launch && (rc = ensure_barrier_word(ctx))) return rc;
     if (tm) CK(hipEventRecord(ctx->ev[ST_HIST], ctx->stream));
-    if (!one_launch) launch_bin_hist(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, own, ctx->bin_own_cnt);
-    if (tm && !one_launch) CK(hipEventRecord(ctx->ev[ST_SCAN], ctx->stream));
+    launch_bin_hist(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, own, ctx->bin_own_cnt);
+    if (tm) CK(hipEventRecord(ctx->ev[ST_SCAN], ctx->stream));
     // heavy tiles are split only when k_tile_count runs in this frame (it leaves the per-cell counts k_tile_fuse's parts need)
     static const bool split_off = getenv("EMAP_SPLIT") && atoi(getenv("EMAP_SPLIT")) == 0;      // A/B and test hook
     ctx->split.on = ctx->gate_possible && !split_off ? 1 : 0;
@@ -944,16 +928,9 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
       ctx->split_dirty = false;
     }
     ctx->split_dirty = ctx->split_dirty || (ctx->split.on != 0 && ctx->split.cap > 0);      // (slots are only used by the SPLIT instantiations: extra workgroups in the launch)
-    if (one_launch) {
-      if (++ctx->sf_epoch == 0u) ctx->sf_epoch = 1u;
-      launch_bin_sort(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, ctx->bin_tile_total, ctx->bin_tile_start,
-                      ctx->bin_recs, ctx->split, ctx->bin_sync, ctx->sf_err_dev, ctx->sf_epoch);
-      if (tm) { CK(hipEventRecord(ctx->ev[ST_SCAN], ctx->stream)); CK(hipEventRecord(ctx->ev[ST_SCATTER], ctx->stream)); }      // ("hist" = the whole sort)
-    } else {
-      launch_bin_scan(ctx->stream, ctx->bg, ctx->bin_hist, ctx->bin_tile_total, ctx->bin_tile_start, ctx->bin_sync, ctx->split);
-      if (tm) CK(hipEventRecord(ctx->ev[ST_SCATTER], ctx->stream));
-      launch_bin_scatter(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, ctx->bin_tile_start, ctx->bin_recs, own, ctx->bin_own_cnt);
-    }
+    launch_bin_scan(ctx->stream, ctx->bg, ctx->bin_hist, ctx->bin_tile_total, ctx->bin_tile_start, ctx->bin_sync, ctx->split);
+    if (tm) CK(hipEventRecord(ctx->ev[ST_SCATTER], ctx->stream));
+    launch_bin_scatter(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, ctx->bin_tile_start, ctx->bin_recs, own, ctx->bin_own_cnt);
     if (tm) CK(hipEventRecord(ctx->ev[ST_GATE], ctx->stream));        // the "gate" stage = per-tile error sums + k_gate
     if (ctx->gate_possible) launch_tile_count(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->slots, ctx->split, ctx->n_pts);
   } else {
@@ -1197,7 +1174,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
 #define STAGE(i) do { if (tm) CK(hipEventRecord(ctx->ev[i], ctx->stream)); } while (0)
   if (ctx->sf_err && *ctx->sf_err) {          // a grid barrier of an earlier k_small_frame gave up: that frame's result is undefined
     ctx->sf_off = true; *ctx->sf_err = 0u;
-    ctx->err = "k_small_frame / k_bin_sort: a grid barrier was not released (the device did not hold the whole grid); the map is undefined from that frame on";
+    ctx->err = "k_small_frame: a grid barrier was not released (the device did not hold the whole grid); the map is undefined from that frame on";
     return EMAP_ERR_HIP;
   }
   const bool rays_on = p.enable_visibility_cleanup != 0;
@@ -1232,7 +1209,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
     if (ctx->gate_folded) { ctx->committed = false; ctx->gate_folded = false; }      // (small clouds: k_count's last workgroup was the gate)
     else if ((rc = emap_set_drift_inputs(ctx, position_noise, orientation_noise, nullptr, nullptr))) { ctx->ov_args.on = 0; return rc; }
   }
-  ctx->update_path = fused_small ? 2 : (ctx->frame_binned ? (ctx->sort_one_launch ? 3 : 1) : 0);
+  ctx->update_path = fused_small ? 2 : (ctx->frame_binned ? 1 : 0);
   STAGE(ST_FUSE);
   // binned scatter: fusion, commit and averaging happen in ONE tile kernel; with the visibility pass it also writes the inert
   // bitmap and the inlier plane, and the ray effects are applied by k_ray_apply ("average" stage) afterwards

@@ -159,98 +159,34 @@ __global__ __launch_bounds__(BLK) void k_bin_hist(KP P, Pose T, BinGeo G, const 
 #define SCAN_TT 64
 #define SCAN_BLK 1024
 #define SCAN_RPW 16      /* rows per wave and slab */
-// COH: the matrix rows were written by OTHER workgroups of this same launch (k_bin_sort): device-coherent loads / stores -- the XCDs'
-// L2s are not coherent with each other inside a launch; false (k_bin_scan, the previous launch wrote them): plain accesses.
-template <bool COH> __device__ __forceinline__ unsigned int ldw(const unsigned int* p) {
-  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
-}
-template <bool COH> __device__ __forceinline__ void stw(unsigned int* p, unsigned int v) {
-  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
-}
-struct ScanShared { unsigned int part[SCAN_BLK / 64][SCAN_TT]; unsigned int nslot, nextra; };
-// column scan of the columns [64 cg, 64 cg + 64) by one workgroup of SCAN_BLK threads; returns the column total in every wave's lane
-template <bool COH>
-__device__ __forceinline__ unsigned int scan_columns(const BinGeo& G, unsigned int* hist, int cg, ScanShared& S) {
+__global__ __launch_bounds__(SCAN_BLK) void k_bin_scan(BinGeo G, unsigned int* __restrict__ hist, unsigned int* __restrict__ tile_total,
+                                                        unsigned int* __restrict__ tile_start, unsigned int* __restrict__ sync, SplitView SV) {
   constexpr int NW = SCAN_BLK / 64;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = cg * SCAN_TT + lane;
+  __shared__ unsigned int part[NW][SCAN_TT];
+  __shared__ unsigned int s_nslot, s_nextra;                // heavy tiles of this frame (SplitView, emap_device.h)
+  __shared__ bool s_last;
+  if (threadIdx.x == 0) { s_nslot = 0u; s_nextra = 0u; }   // (published by the barriers of the slab loop / the ticket hand-off below)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = blockIdx.x * SCAN_TT + lane;
   const bool col_ok = t < G.pitch;
   unsigned int carry = 0u;                                 // per column (lane), identical in all waves
   for (int sl = 0; sl < G.B; sl += NW * SCAN_RPW) {
     const int r0 = sl + w * SCAN_RPW;
     unsigned int v[SCAN_RPW];
 #pragma unroll
-    for (int j = 0; j < SCAN_RPW; ++j) v[j] = (col_ok && r0 + j < G.B) ? ldw<COH>(&hist[(long)(r0 + j) * G.pitch + t]) : 0u;
+    for (int j = 0; j < SCAN_RPW; ++j) v[j] = (col_ok && r0 + j < G.B) ? hist[(long)(r0 + j) * G.pitch + t] : 0u;
     unsigned int sum = 0u;
 #pragma unroll
     for (int j = 0; j < SCAN_RPW; ++j) sum += v[j];
-    S.part[w][lane] = sum;
+    part[w][lane] = sum;
     __syncthreads();
     unsigned int run = carry, tot = 0u;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) { const unsigned int x = S.part[k][lane]; if (k < w) run += x; tot += x; }
+    for (int k = 0; k < NW; ++k) { const unsigned int x = part[k][lane]; if (k < w) run += x; tot += x; }
 #pragma unroll
-    for (int j = 0; j < SCAN_RPW; ++j) { if (col_ok && r0 + j < G.B) stw<COH>(&hist[(long)(r0 + j) * G.pitch + t], run); run += v[j]; }
+    for (int j = 0; j < SCAN_RPW; ++j) { if (col_ok && r0 + j < G.B) hist[(long)(r0 + j) * G.pitch + t] = run; run += v[j]; }
     carry += tot;
     __syncthreads();
   }
-  return carry;
-}
-// the tail: exclusive scan of the TB tile totals by all 1024 threads -- every thread a run of consecutive tiles (two passes over
-// its run around ONE block-wide scan of the run sums; the 64 rounds of a 256-thread scan cost 30 us at 16385 bins)
-template <bool COH>
-__device__ __forceinline__ void scan_tail(const BinGeo& G, unsigned int* __restrict__ tile_total, unsigned int* __restrict__ tile_start,
-                                          const SplitView& SV, ScanShared& S) {
-  constexpr int NW = SCAN_BLK / 64;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int per = (G.TB + SCAN_BLK - 1) / SCAN_BLK, t_lo = min(G.TB, (int)threadIdx.x * per), t_hi = min(G.TB, t_lo + per);
-  unsigned int mine = 0u;
-  for (int tt = t_lo; tt < t_hi; ++tt) mine += __hip_atomic_load(&tile_total[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned int inc = mine;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
-  __syncthreads();                                            // part[][] is free again (every wave has left the slab loop)
-  if (lane == 63) S.part[0][w] = inc;
-  __syncthreads();
-  unsigned int base = 0u, total = 0u;
-#pragma unroll
-  for (int k = 0; k < NW; ++k) { const unsigned int x = S.part[0][k]; if (k < w) base += x; total += x; }
-  unsigned int run = base + inc - mine;
-  for (int tt = t_lo; tt < t_hi; ++tt) {
-    const unsigned int n_t = __hip_atomic_load(&tile_total[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    stw<COH>(&tile_start[tt], run); run += n_t;
-    if (SV.on && tt < G.T) {                                  // heavy tile: a slot per stacked tile of the bin, an extra workgroup per further part
-      if (n_t > SPLIT_CAP) {                                  // (tile_slot is read for such tiles only)
-        // the tile WANTS split_parts(n_t) parts; it GETS as many as the extra workgroups of this frame's launches leave room for (cap:
-        // sized by the last finished frame's need -- emap_api.hip) -- at least two, or it is reduced by its own workgroup alone.
-        // The number of parts travels in the high half of the tile's slot word.
-        const unsigned int want = split_parts(n_t) - 1u;
-        const unsigned int s0 = atomicAdd(&S.nslot, (unsigned int)G.sub), e0 = atomicAdd(&S.nextra, want);
-        const unsigned int room = e0 < (unsigned int)SV.cap ? (unsigned int)SV.cap - e0 : 0u, take = min(want, room);
-        const bool fits = s0 + (unsigned int)G.sub <= SPLIT_MAX_SLOTS && take > 0u;
-        for (unsigned int q = 1u; q <= take; ++q) SV.extra[e0 + q - 1u] = fits ? (((unsigned int)tt << 8) | q) : SPLIT_NONE;
-        SV.tile_slot[tt] = fits ? (s0 | ((take + 1u) << 16)) : SPLIT_NONE;
-      }
-    }
-  }
-  if (threadIdx.x == 0) stw<COH>(&tile_start[G.TB], total);   // = number of sorted records
-  if (SV.on) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      *SV.n_extra = min(S.nextra, (unsigned int)SV.cap);
-      if (S.nextra != SV.n_extra[1]) {                       // what the NEXT frames' launches should provide (host-mapped: a store across PCIe, only when it changes)
-        SV.n_extra[1] = S.nextra;
-        __hip_atomic_store(SV.need_host, S.nextra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
-}
-__global__ __launch_bounds__(SCAN_BLK) void k_bin_scan(BinGeo G, unsigned int* __restrict__ hist, unsigned int* __restrict__ tile_total,
-                                                        unsigned int* __restrict__ tile_start, unsigned int* __restrict__ sync, SplitView SV) {
-  __shared__ ScanShared S;
-  __shared__ bool s_last;
-  if (threadIdx.x == 0) { S.nslot = 0u; S.nextra = 0u; }   // heavy tiles of this frame (SplitView, emap_device.h); published by the barriers of the slab loop / the ticket hand-off below
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = blockIdx.x * SCAN_TT + lane;
-  const unsigned int carry = scan_columns<false>(G, hist, (int)blockIdx.x, S);
   // the totals go out as device-coherent stores and are read back with device-coherent loads; only their ORDER against the
   // ticket matters (wait for the stores' acknowledgement).  An agent-scope fence would write back / invalidate the XCD's whole L2
   // per workgroup (measured: 10 -> 30 us for this kernel).
@@ -262,7 +198,49 @@ __global__ __launch_bounds__(SCAN_BLK) void k_bin_scan(BinGeo G, unsigned int* _
   }
   __syncthreads();
   if (!s_last) return;
-  scan_tail<false>(G, tile_total, tile_start, SV, S);
+  // the tail: exclusive scan of the TB tile totals by all 1024 threads -- every thread a run of consecutive tiles (two passes over
+  // its run around ONE block-wide scan of the run sums; the 64 rounds of a 256-thread scan cost 30 us at 16385 bins)
+  const int per = (G.TB + SCAN_BLK - 1) / SCAN_BLK, t_lo = min(G.TB, (int)threadIdx.x * per), t_hi = min(G.TB, t_lo + per);
+  unsigned int mine = 0u;
+  for (int tt = t_lo; tt < t_hi; ++tt) mine += __hip_atomic_load(&tile_total[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned int inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+  __syncthreads();                                            // part[][] is free again (every wave has left the slab loop)
+  if (lane == 63) part[0][w] = inc;
+  __syncthreads();
+  unsigned int base = 0u, total = 0u;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) { const unsigned int x = part[0][k]; if (k < w) base += x; total += x; }
+  unsigned int run = base + inc - mine;
+  for (int tt = t_lo; tt < t_hi; ++tt) {
+    const unsigned int n_t = __hip_atomic_load(&tile_total[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tile_start[tt] = run; run += n_t;
+    if (SV.on && tt < G.T) {                                  // heavy tile: a slot per stacked tile of the bin, an extra workgroup per further part
+      if (n_t > SPLIT_CAP) {                                  // (tile_slot is read for such tiles only)
+        // the tile WANTS split_parts(n_t) parts; it GETS as many as the extra workgroups of this frame's launches leave room for (cap:
+        // sized by the last finished frame's need, never below the standing pool -- emap_api.hip) -- at least two, or it is reduced
+        // by its own workgroup alone.  The number of parts travels in the high half of the tile's slot word.
+        const unsigned int want = split_parts(n_t) - 1u;
+        const unsigned int s0 = atomicAdd(&s_nslot, (unsigned int)G.sub), e0 = atomicAdd(&s_nextra, want);
+        const unsigned int room = e0 < (unsigned int)SV.cap ? (unsigned int)SV.cap - e0 : 0u, take = min(want, room);
+        const bool fits = s0 + (unsigned int)G.sub <= SPLIT_MAX_SLOTS && take > 0u;
+        for (unsigned int q = 1u; q <= take; ++q) SV.extra[e0 + q - 1u] = fits ? (((unsigned int)tt << 8) | q) : SPLIT_NONE;
+        SV.tile_slot[tt] = fits ? (s0 | ((take + 1u) << 16)) : SPLIT_NONE;
+      }
+    }
+  }
+  if (threadIdx.x == 0) tile_start[G.TB] = total;             // = number of sorted records
+  if (SV.on) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      *SV.n_extra = min(s_nextra, (unsigned int)SV.cap);
+      if (s_nextra != SV.n_extra[1]) {                       // what the NEXT frames' launches should provide (host-mapped: a store across PCIe, only when it changes)
+        SV.n_extra[1] = s_nextra;
+        __hip_atomic_store(SV.need_host, s_nextra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 #ifndef SCATTER_U
@@ -317,94 +295,6 @@ __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, Pose T, BinGeo G, con
         recs[pos] = o;
       }
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// k_bin_sort (round 5): histogram, scan and scatter of a cloud of up to SORT_PPT points per thread in ONE launch.
-// The three launches of the sort front-end were 38 % of the 1024^2 / 1 M-point frame, each a single round of ~245 workgroups that is
-// over after two or three memory round trips; the scatter pass read the cloud and ran the geometry a second time because nothing
-// survives a launch boundary.  Here every workgroup of the grid is resident (launch_bin_sort bounds it), keeps the (bin, cell, z,
-// noise) of its points in REGISTERS from the histogram phase to the scatter phase, and the phases are separated by the grid barrier
-// of emap_device.h:
-//   phase 1  per point: geometry, LDS histogram; the block's row of the (block, tile) matrix goes out device-coherent
-//   arrive   (ticket 1; the last workgroup to arrive releases the scan workgroups)
-//   phase 2  the first ceil(TB / 64) workgroups scan 64 matrix columns each (scan_columns<true>), take ticket 2; the last of THEM runs
-//            the tail (tile starts, heavy-tile lists) and releases everybody
-//   phase 3  cursors = tile start + the block's exclusive prefix (device-coherent loads) in the LDS array the histogram used; records
-//            to their sorted positions
-// Same records at the same positions as the three launches leave them, up to the order INSIDE a (block, tile) run, which is not
-// defined there either (LDS cursors) and which nothing depends on.  Whole-map contexts only (a strip context shares its device with
-// other ranks' grids in the one-GPU emulations; the strip variants stage records anyway); larger clouds (more than SORT_PPT points
-// per thread) keep the three launches -- they are bandwidth, not launch, bound.
-// ---------------------------------------------------------------------------------------------------------------------------------
-#define SORT_BLK 1024
-#define SORT_PPT 8
-struct SortSync { unsigned int* sync; unsigned int* flag; unsigned int* err_host; unsigned int epoch; int pad_; };      // sync: two ticket sets 4096 words apart; flag[0], flag[32]
-template <int MODE>
-__global__ __launch_bounds__(SORT_BLK) void k_bin_sort(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
-                                                        unsigned int* hist, unsigned int* tile_total, unsigned int* tile_start,
-                                                        BinRec* __restrict__ recs, SplitView SV, SortSync Y) {
-  extern __shared__ __attribute__((aligned(16))) unsigned int h[];          // histogram row, later the cursors
-  __shared__ ScanShared S;
-  __shared__ bool s_last, s_last2;
-  for (int t = threadIdx.x; t < G.TB; t += SORT_BLK) h[t] = 0u;
-  if (threadIdx.x == 0) { S.nslot = 0u; S.nextra = 0u; }
-  const long base = (long)blockIdx.x * G.chunk;
-  __syncthreads();
-  // ---- phase 1 -------------------------------------------------------------------------------------------------------------------
-  unsigned int key[SORT_PPT]; float z[SORT_PPT], v[SORT_PPT];      // key = (bin << 10) | cell of the tile; ~0: no bin (sub == 1: 1024 cells per bin)
-  {
-    float rx[SORT_PPT], ry[SORT_PPT], rz[SORT_PPT];
-#pragma unroll
-    for (int u = 0; u < SORT_PPT; ++u) {
-      const long k = threadIdx.x + (long)u * SORT_BLK, i = base + k;
-      rx[u] = ry[u] = rz[u] = NAN;                             // (a NaN row: no bin)
-      if (k < G.chunk && i < n) load_point(pts, i, stride, rx[u], ry[u], rz[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < SORT_PPT; ++u) {
-      const Geo g = geometry<MODE>(P, T, rx[u], ry[u], rz[u]);
-      unsigned int lc;
-      const int bin = bin_of(P, G, g, lc);
-      z[u] = g.z; v[u] = g.v;
-      key[u] = bin >= 0 ? ((unsigned int)bin << 10) | lc : 0xffffffffu;
-      if (bin >= 0) atomicAdd(&h[bin], 1u);
-    }
-  }
-  __syncthreads();
-  unsigned int* row = hist + (long)blockIdx.x * G.pitch;
-  for (int t = threadIdx.x; t < G.pitch; t += SORT_BLK) stw<true>(&row[t], t < G.TB ? h[t] : 0u);
-  const bool last1 = sf_arrive(Y.sync, &s_last);               // (rows acknowledged, then the ticket)
-  if (last1) sf_release(Y.flag, Y.epoch);
-  // ---- phase 2 -------------------------------------------------------------------------------------------------------------------
-  const int ns = (G.TB + SCAN_TT - 1) / SCAN_TT;                // scan workgroups (the host checked ns <= gridDim.x)
-  bool released = false;
-  if ((int)blockIdx.x < ns) {
-    if (!last1) sf_wait(Y.flag, Y.epoch, Y.err_host);
-    const unsigned int carry = scan_columns<true>(G, hist, (int)blockIdx.x, S);
-    const int lane = threadIdx.x & 63, t = blockIdx.x * SCAN_TT + lane;
-    if (threadIdx.x < 64 && t < G.TB) __hip_atomic_store(&tile_total[t], carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);                             // prefixes and totals acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) s_last2 = last_block_ticket(Y.sync + 4096, blockIdx.x, (unsigned int)ns);
-    __syncthreads();
-    if (s_last2) {
-      scan_tail<true>(G, tile_total, tile_start, SV, S);
-      sf_release(Y.flag + 32, Y.epoch);
-      released = true;
-    }
-  }
-  if (!released) sf_wait(Y.flag + 32, Y.epoch, Y.err_host);
-  // ---- phase 3 -------------------------------------------------------------------------------------------------------------------
-  for (int t = threadIdx.x; t < G.TB; t += SORT_BLK) h[t] = ldw<true>(&tile_start[t]) + ldw<true>(&row[t]);
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < SORT_PPT; ++u) {
-    if (key[u] == 0xffffffffu) continue;
-    const unsigned int pos = atomicAdd(&h[key[u] >> 10], 1u);
-    BinRec o; o.lc_inl = key[u] & 1023u; o.z = z[u]; o.v = v[u]; o.i = (unsigned int)(base + threadIdx.x + (long)u * SORT_BLK);
-    recs[pos] = o;
   }
 }
 
@@ -867,50 +757,6 @@ void launch_bin_scatter(hipStream_t s, const KP& P, const Pose& T, const BinGeo&
     case 512: launch_bin_scatter_t<512>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); break;
     default: launch_bin_scatter_t<256>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt);
   }
-}
-// The single-launch sort front-end.  Its grid must be RESIDENT: at most HALF of what the device holds, so that the grids of two
-// contexts whose frames overlap in time (two streams) both fit -- 128 workgroups of 1024 threads on an MI355X (109 VGPRs: one per CU).
-int bin_sort_limit(int pitch) {
-  static int limit[EM_MAX_DEV]; static int pitch_known[EM_MAX_DEV];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EM_MAX_DEV) return 0;
-  if (pitch_known[dev] != pitch) {
-    const size_t lds = sizeof(unsigned int) * (size_t)pitch;
-    int cus = 0, nb0 = 0, nb1 = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, reinterpret_cast<const void*>(k_bin_sort<0>), SORT_BLK, lds) != hipSuccess) nb0 = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void*>(k_bin_sort<1>), SORT_BLK, lds) != hipSuccess) nb1 = 0;
-    (void)hipGetLastError();
-    limit[dev] = (int)((long)cus * (nb0 < nb1 ? nb0 : nb1) / 2);
-    if (limit[dev] > 512) limit[dev] = 512;                      // (the ticket words of the barriers)
-    pitch_known[dev] = pitch;
-  }
-  return limit[dev];
-}
-// Blocks / points per block of the one-launch sort for n points, or false: the frame keeps the three launches.  G: tiles_x/y, T, TB,
-// pitch, sub already set (emap_api.hip: ensure_bins).
-bool bin_sort_plan(const KP& P, const BinGeo& G, long n, int* B_out, long* chunk_out) {
-  if (P.nrows != P.C || G.sub != 1 || n <= 0) return false;
-  if (sizeof(unsigned int) * (size_t)G.pitch > 48 * 1024) return false;      // (larger histograms belong to maps whose clouds are not launch bound)
-  const long limit = bin_sort_limit(G.pitch), ns = (G.TB + SCAN_TT - 1) / SCAN_TT;
-  if (ns > limit) return false;
-  long b = (n + 4095) / 4096;                                   // ~4 points per thread ...
-  if (b > limit) b = limit;                                     // ... more when the grid would not be resident
-  if (b < ns) b = ns;
-  long chunk = (n + b - 1) / b; chunk = ((chunk + 1023) / 1024) * 1024;
-  if (chunk > (long)SORT_PPT * SORT_BLK) return false;
-  const long B = (n + chunk - 1) / chunk;
-  if (B < ns) return false;                                     // (a cloud this small belongs to the atomic path anyway)
-  *B_out = (int)B; *chunk_out = chunk;
-  return true;
-}
-void launch_bin_sort(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride, unsigned int* hist,
-                     unsigned int* tile_total, unsigned int* tile_start, BinRec* recs, const SplitView& SV, unsigned int* sync,
-                     unsigned int* err_host, unsigned int epoch) {
-  SortSync Y = {sync, sync + 8192, err_host, epoch, 0};
-  const size_t lds = sizeof(unsigned int) * G.pitch;
-  if (P.mode == 0) hipLaunchKernelGGL(k_bin_sort<0>, dim3(G.B), dim3(SORT_BLK), lds, s, P, T, G, pts, n, stride, hist, tile_total, tile_start, recs, SV, Y);
-  else hipLaunchKernelGGL(k_bin_sort<1>, dim3(G.B), dim3(SORT_BLK), lds, s, P, T, G, pts, n, stride, hist, tile_total, tile_start, recs, SV, Y);
 }
 void launch_tile_count(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cells cells,
                        ErrSlot* slots, const SplitView& SV, long n) {

@@ -349,13 +349,22 @@ __device__ __forceinline__ bool last_block_ticket(unsigned int* __restrict__ syn
   return true;
 }
 
-// ---- grid-wide barrier of the single-launch kernels (k_small_frame, k_bin_sort) -------------------------------------------------
-// Every workgroup of the grid is RESIDENT (the host bounds the grid by what the device holds: small_frame_grid / sort_grid).  A barrier
-// is the two-level ticket above + one release word the waiting workgroups poll with device-coherent loads.  What a phase publishes for
-// the next one goes out as device-scope atomics / device-coherent (sc1) stores BEFORE the arrival (s_waitcnt: acknowledged) and is read
+// ---- grid-wide barrier of the single-launch kernel (k_small_frame) --------------------------------------------------------------
+// Every workgroup of the grid is RESIDENT (the host bounds the grid by what the device holds: small_frame_grid).  A barrier is the
+// two-level ticket above + one release word the waiting workgroups poll with device-coherent loads.  What a phase publishes for the
+// next one goes out as device-scope atomics / device-coherent (sc1) stores BEFORE the arrival (s_waitcnt: acknowledged) and is read
 // back with device-coherent loads after the release -- the hand-off of last_block_ticket, see the note there.  The release word holds
 // the epoch of the last launch that passed (distinct per launch, never 0).  A wait that is not released within ~2 s gives up (the
 // frame's result is then undefined) and sets a host-mapped word: the next call on the context fails loudly instead of the box hanging.
+// What such a barrier costs on MI355X (measured, round 5): it is a chain of four to five DEPENDENT trips to the memory side
+// (acknowledgements, group ticket, root ticket, release store, poll), 1.5-2 us each, i.e. 6-8 us -- more than the ~4.5 us a launch
+// boundary occupies the stream, of which only ~1 us is not hidden behind the previous kernel's tail.  A barrier therefore only pays
+// where it saves work: k_small_frame (the cloud read and transformed once instead of twice) 27.1 -> 25.3 us per frame; a sort
+// front-end built the same way (histogram, scan and scatter in one launch, geometry kept in LDS: k_bin_sort) took 30 us against the
+// 35 us event spacing of its three launches and left the 1024^2 / 1 M-point frame at 71.0 vs 70.3 us -- removed.  Variants measured on
+// k_small_frame: a release word per ticket group instead of one (25.4 us: the polls are not what costs); one ever-growing counter that
+// every workgroup adds to WITHOUT waiting and then polls, the gate evaluated redundantly by every workgroup (29.2 us: 196 atomics and
+// 196 pollers on ONE address serialise at ~10 ns each, the late arrivals queue behind the early ones' polls).
 #define SF_SPIN_LIMIT (1u << 21)
 // every thread of the grid calls this; true in all threads of the LAST workgroup to arrive (which runs its serial section and then sf_release)
 __device__ __forceinline__ bool sf_arrive(unsigned int* sync, bool* s_last) {

@@ -190,20 +190,18 @@ class ElevationMap:
     def close(self):
         self.__del__()
 
-    def set_scatter_mode(self, mode, bin_stack=0, sort_three=False):
+    def set_scatter_mode(self, mode, bin_stack=0):
         """"auto" | "atomic" | "binned": how count/fuse scatter into the map (bit-identical results).
-        ``bin_stack`` (test hook) forces bins of that many stacked 16x64 tiles, as maps beyond 16384 tiles use; ``sort_three`` (test
-        hook) keeps the sort front-end in three launches where it would run as one."""
-        self._chk(self._lib.emap_set_scatter_mode(self._ctx, {"auto": 0, "atomic": 1, "binned": 2}[mode] | (int(bin_stack) << 8) | (int(bool(sort_three)) << 16)))
+        ``bin_stack`` (test hook) forces bins of that many stacked 16x64 tiles, as maps beyond 16384 tiles use."""
+        self._chk(self._lib.emap_set_scatter_mode(self._ctx, {"auto": 0, "atomic": 1, "binned": 2}[mode] | (int(bin_stack) << 8)))
         self._scatter_mode = mode
 
     def last_update_path(self):
-        """which kernels the last whole frame ran: "atomic" (chain of launches), "binned" (three sort launches + tile kernels),
-        "binned_sort1" (the sort front-end in one launch) or "small_frame" (one launch for count .. average, robot scale) --
-        include/emap_hip.h: emap_last_update_path; the results are bit-identical"""
+        """which kernels the last whole frame ran: "atomic" (chain of launches), "binned" (tile kernels) or "small_frame" (one launch,
+        robot scale) -- include/emap_hip.h: emap_last_update_path; the results are bit-identical"""
         v = ct.c_int32(-1)
         self._chk(self._lib.emap_last_update_path(self._ctx, ct.byref(v)))
-        return {0: "atomic", 1: "binned", 2: "small_frame", 3: "binned_sort1"}[v.value]
+        return {0: "atomic", 1: "binned", 2: "small_frame"}[v.value]
 
     def set_ray_mode(self, mode):
         """"auto" | "by_row" | "by_ray": how a SHARDED frame (emap_update_sharded) runs the visibility pass (include/emap_hip.h:

@@ -134,8 +134,7 @@ int emap_set_drift_inputs_device(emap_ctx* ctx, double position_noise, double or
 int emap_local_drift_sums(emap_ctx* ctx, double* err_sum, uint32_t* err_cnt);
 /* how the count/fuse passes scatter into the map: 0 = auto (tile-binned LDS reduction for clouds >= 131072 points, else global
  * atomics), 1 = global atomics, 2 = tile-binned. Results are bit-identical. Bins are 16x64-cell tiles; maps with more than
- * 16384 tiles stack 2, 4, ... tiles per bin. Test hooks: bits 8..15 of `mode` force a minimum stacking factor (power of two); bit 16
- * keeps the sort front-end in three launches where it would run as one (k_bin_sort, see emap_last_update_path). */
+ * 16384 tiles stack 2, 4, ... tiles per bin. Test hook: bits 8..15 of `mode` force a minimum stacking factor (power of two). */
 int emap_set_scatter_mode(emap_ctx* ctx, int32_t mode);
 int emap_fuse(emap_ctx* ctx, const float R[9], const float t[3]);           /* add_points_kernel fusion part */
 int emap_fuse_average(emap_ctx* ctx, const float R[9], const float t[3]);   /* fuse+commit+average when no ray pass follows */
@@ -344,12 +343,10 @@ int emap_timer_end(emap_ctx* ctx, float* elapsed_ms); /* records, synchronises, 
 int emap_enable_stage_timing(emap_ctx* ctx, int enable);
 int emap_get_stage_times(emap_ctx* ctx, float ms_out[10]);
 /* which kernels the last emap_update ran for phases count .. commit / average (results are bit-identical on all three):
- * 0 = chain of launches with global atomics (k_count, k_fuse, k_commit / k_average), 1 = tile-binned (sort front-end of three
- * launches + tile kernels), 3 = tile-binned with the sort front-end in ONE launch (k_bin_sort: whole-map contexts, clouds of up to
- * 4096 points per sort block, i.e. ~1 M points), 2 = ONE launch for count .. commit / average, k_small_frame: small clouds on maps of
- * up to 512^2 cells -- the robot-scale configuration the reference ships (EM/parameter.py:137,165 -> 202^2 cells;
- * EM/elevation_mapping.py:316-391 is a chain of ~12 dependent launches there).
- * EMAP_SMALL_FRAME=0 / EMAP_BIN_SORT=0 in the environment keep such frames on paths 0 / 1. */
+ * 0 = chain of launches with global atomics (k_count, k_fuse, k_commit / k_average), 1 = tile-binned (sort front-end + tile kernels),
+ * 2 = ONE launch, k_small_frame: small clouds on maps of up to 512^2 cells -- the robot-scale configuration the reference ships
+ * (EM/parameter.py:137,165 -> 202^2 cells; EM/elevation_mapping.py:316-391 is a chain of ~12 dependent launches there).
+ * EMAP_SMALL_FRAME=0 in the environment keeps such frames on path 0. */
 int emap_last_update_path(emap_ctx* ctx, int32_t* path);
 
 #ifdef __cplusplus

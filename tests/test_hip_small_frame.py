@@ -122,10 +122,10 @@ def test_larger_maps_and_clouds_keep_their_paths(weights):
     hip.update_map_with_kernel(fx.cloud(C, 20000, 0), [], R, t.copy(), 1.0, 1.0)
     assert hip.last_update_path() == "atomic"            # beyond 512^2 cells: the chain of launches
     hip.update_map_with_kernel(fx.cloud(C, 200000, 1), [], R, t.copy(), 1.0, 1.0)
-    assert hip.last_update_path() in ("binned", "binned_sort1")
+    assert hip.last_update_path() == "binned"
     small, _ = make_pair(dict(eo.YAML, enable_visibility_cleanup=False), 202, "reference_fp16", weights)
     small.update_map_with_kernel(fx.cloud(202, 200000, 1), [], R, t.copy(), 1.0, 1.0)
-    assert small.last_update_path() in ("binned", "binned_sort1")
+    assert small.last_update_path() == "binned"
 
 
 def test_run_to_run_and_two_contexts_bit_identical(weights):
@@ -143,61 +143,3 @@ def test_run_to_run_and_two_contexts_bit_identical(weights):
     assert a.last_update_path() == "small_frame"
     assert a.elevation_map.tobytes() == b.elevation_map.tobytes() and a.normal_map.tobytes() == b.normal_map.tobytes()
 
-
-# ---- k_bin_sort: the sort front-end of the tile-binned path (histogram, scan, scatter) in ONE launch --------------------------------------
-def _whole_frames(C, idx_mode, cfg, clouds, weights, **scatter):
-    hip, _ = make_pair(cfg, C, idx_mode, weights)
-    hip.set_scatter_mode(**scatter)
-    R, t = fx.POSES["identity"]
-    paths = []
-    for f, p in enumerate(clouds):
-        hip.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0)
-        paths.append(hip.last_update_path())
-        for k in range(5):
-            hip.update_time()
-    return hip, paths
-
-
-@pytest.mark.parametrize("rays", [False, True])
-@pytest.mark.parametrize("C,N,mode", [(1024, 1_000_000, "reference_fp16"), (1024, 200_000, "reference_fp16"), (202, 200_000, "reference_fp16"),
-                                      (2048, 500_000, "fp32"), (1024, 139_000, "fp32")])
-def test_sort_in_one_launch_equals_three_launches_and_the_atomic_path(C, N, mode, rays, weights):
-    """same records per tile whatever sorted them: the frames agree bit for bit (8 or 4 points per thread, with and without the
-    ray-only bin); the last frame also against global atomics"""
-    cfg = dict(eo.YAML, enable_visibility_cleanup=rays)
-    clouds = [fx.cloud(C, N, f, dz=-0.03 * f) for f in range(3)]
-    clouds[1][5::7] = np.nan                                   # NaN rows: no bin
-    one, paths = _whole_frames(C, mode, cfg, clouds, weights, mode="binned")
-    assert paths == ["binned_sort1"] * 3, paths
-    three, paths3 = _whole_frames(C, mode, cfg, clouds, weights, mode="binned", sort_three=True)
-    assert paths3 == ["binned"] * 3, paths3
-    _same(one, three, "one launch vs three")
-    atomic, _ = _whole_frames(C, mode, cfg, clouds, weights, mode="atomic")
-    _same(one, atomic, "one launch vs global atomics")
-
-
-def test_sort_in_one_launch_lists_heavy_tiles(weights):
-    """a scan-ordered, ray-cast cloud: one tile holds a third of the points -- the tail of the scan (inside k_bin_sort here) cuts it
-    into parts for the tile kernels; second and third frame run split"""
-    C = 1024
-    cfg = dict(eo.YAML)
-    clouds = [fx.terrain_cloud(C, 900, 300, s, shift=sh) for s, sh in enumerate((0.0, 0.4, -0.3))]
-    one, paths = _whole_frames(C, "reference_fp16", cfg, clouds, weights, mode="binned")
-    assert paths == ["binned_sort1"] * 3, paths
-    three, _ = _whole_frames(C, "reference_fp16", cfg, clouds, weights, mode="binned", sort_three=True)
-    _same(one, three, "terrain: one launch vs three")
-
-
-def test_sort_in_one_launch_against_the_oracle(weights):
-    C, N = 1024, 400_000
-    hip, orc = make_pair(eo.YAML, C, "reference_fp16", weights)
-    R, t = fx.POSES["rotated"]
-    for f, dz in enumerate((0.0, -0.02, -0.2)):
-        p = fx.cloud(C, N, f, dz=dz)
-        hip.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0)
-        assert hip.last_update_path() == "binned_sort1"
-        orc.update_map_with_kernel(p, R, t, 1.0, 1.0)
-        for k in range(7):
-            hip.update_time(); orc.update_time()
-    assert_planes_equal(hip.elevation_map, orc.elevation_map, what="oracle")
-    assert_planes_equal(hip.normal_map, orc.normal_map, names=NORMALS, what="oracle normals")
