@@ -428,6 +428,26 @@ __device__ __forceinline__ void gate_eval(const GateArgs& A, ErrSlot* __restrict
   F->shift = shift; F->gate_fired = fired;
 }
 
+// The shift gate_eval decides, computed from the slots WITHOUT touching them or the frame record (k_small_frame: the last workgroup to
+// arrive releases the others with the shift before it does the gate's bookkeeping).  Integer slot sums: the same value gate_eval derives
+// afterwards.  Whole frames only (no overrides, no all-reduced totals).  One wave; every lane returns the shift.
+__device__ __forceinline__ float gate_shift_only(const GateArgs& A, const ErrSlot* __restrict__ slots, int lane) {
+  long long s = 0; unsigned long long k = 0;
+  for (int j = lane; j < EM_ERR_SLOTS; j += 64) {
+    s += __hip_atomic_load(&slots[j].sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    k += __hip_atomic_load(&slots[j].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  s = wave_sum_ll(s); k = (unsigned long long)wave_sum_ll((long long)k);
+  const double sum = (double)s / EM_SCALE_E;
+  const float cnt = (float)k;
+  float shift = 0.0f;
+  if (A.enable && (double)cnt > A.min_cnt && A.noise_ok) {
+    const float mean = (float)sum / cnt;
+    if ((double)fabsf(mean) < A.max_drift) shift = mean * A.alpha;
+  }
+  return shift;
+}
+
 // Multi-GPU frames: the gate decision on the ALL-REDUCED drift totals rides in the head of the tile kernel (every workgroup reads
 // the two doubles and decides for itself -- the same value everywhere; workgroup (0, 0) also keeps the frame record): one dependent
 // launch less between the all-reduce and the fusion.  mode 0: not folded (the shift comes from FrameDev, written by k_gate).

@@ -633,7 +633,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cells cells, AccF* _
 struct SmallFrame {
   GateArgs A; FrameDev* F; ErrSlot* slots;
   unsigned int* sync;        // two sets of ticket words (1024 apart), zero between launches
-  unsigned int* flag;        // [0], [32]: release words of the two barriers (= epoch of the last launch that passed); [64]: the frame's shift
+  unsigned int* flag;        // [0..1]: release word of barrier 1, 8 bytes {epoch of the last launch that passed, that frame's shift}; [32]: release word of barrier 2
   unsigned int* err_host;    // host-mapped: a barrier gave up
   unsigned int epoch;        // distinct per launch, never 0
   int rays;                  // 1: a visibility pass follows (phase B' = k_commit: S1 + inert bitmap); 0: commit + average (k_average<false, false>)
@@ -682,15 +682,32 @@ __global__ __launch_bounds__(EM_BLOCK) void k_small_frame(KP P, Pose T, const fl
       atomicAdd(&S.slots[slot].cnt, k);
     }
   }
-  // ---- barrier 1; the last workgroup is the drift gate (k_gate) and publishes the shift ----------------------------------------
-  if (sf_arrive(S.sync, &s_last)) {
+  // ---- barrier 1; the last workgroup to arrive is the drift gate (k_gate) ------------------------------------------------------------
+  // It releases the others WITH the shift -- one 8-byte word {epoch, shift} -- as soon as it has the slot sums, and does the gate's
+  // bookkeeping (frame record, additive_mean_error, slots re-armed: nothing anybody reads in this launch) afterwards: a separate shift
+  // word cost two more dependent trips to the memory side per frame (its acknowledgement before the release, its load after the wait).
+  __shared__ float s_shift;
+  unsigned long long* const rel = reinterpret_cast<unsigned long long*>(S.flag);
+  if (sf_arrive(S.sync, &s_last)) {                                  // (this workgroup's own phase-A results were acknowledged before it took its ticket)
     if (threadIdx.x < 64) {
+      const float sh = gate_shift_only(S.A, S.slots, (int)threadIdx.x);
+      if (threadIdx.x == 0) {
+        st_dev(rel, (unsigned long long)S.epoch | ((unsigned long long)__float_as_uint(sh) << 32));
+        s_shift = sh;
+      }
       gate_eval(S.A, S.slots, S.F, (int)threadIdx.x, 0, nullptr, nullptr);
-      if (threadIdx.x == 0) __hip_atomic_store(S.flag + 64, __float_as_uint(S.F->shift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    sf_release(S.flag, S.epoch);
-  } else sf_wait(S.flag, S.epoch, S.err_host);
-  const float shift = __uint_as_float(__hip_atomic_load(S.flag + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  } else if (threadIdx.x == 0) {
+    unsigned int it = 0u;
+    unsigned long long w;
+    while ((unsigned int)(w = ld_dev(rel)) != S.epoch) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++it > SF_SPIN_LIMIT) { __hip_atomic_store(S.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+    s_shift = __uint_as_float((unsigned int)(w >> 32));
+  }
+  __syncthreads();
+  const float shift = s_shift;
   // ---- phase B: k_fuse against snapshot S0 ---------------------------------------------------------------------------------------
   if (c >= 0) {
     unsigned long long* const a = reinterpret_cast<unsigned long long*>(acc + c);      // pts_inl, cnt_out, sum_h, sum_v, latest
