@@ -491,7 +491,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
   const v2f txy = {T.t[0], T.t[1]};
   // loop constants that feed a second scalar operand slot live in vector registers (one scalar source per VALU instruction on
   // gfx9: the compiler would otherwise re-materialise them with a v_mov in every step)
-  unsigned int ones_off = (unsigned int)P.nrows * wpr32 * 4u + smap_base, base_v = smap_base, mask_v = 0x1ffffffcu;
+  unsigned int ones_off = (unsigned int)P.nrows * wpr32 * 4u + smap_base, base_v = smap_base, mask_v = (IDX == 2 && !STRIP) ? 0x1ffcu : 0x1ffffffcu;      // (PK: the shifted key still carries the row above bit 12)
   asm volatile("" : "+v"(ones_off), "+v"(base_v), "+v"(mask_v));
   auto cell_xy = [&](v2f n, int& ix, int& iy) -> unsigned int {                   // sample position -> cell, key (ix << 16) | iy   (cell_n <= 46340: 16 bits each)
     if constexpr (IDX == 2) {
@@ -507,11 +507,40 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     } else { ix = aidx(P, n.x); iy = aidx(P, n.y); }
     return ((unsigned int)ix << 16) | (unsigned int)iy;
   };
+  // PK (round 5): the float formula on whole-map contexts finishes BOTH axes in packed 16-bit integer arithmetic -- floor + conversion in one
+  // instruction per axis (v_cvt_flr_i32_f32), one saturating pack (v_cvt_pk_i16_i32), then + half width / max 0 / min C - 1 on the pair
+  // (v_pk_add_i16 clamp, v_pk_max_i16, v_pk_min_i16): six instructions where floor x 2, packed add, v_med3_f32 x 2, conversion x 2 and
+  // the shift-or that builds the key were eight, and the bitmap row is taken from the key's high half by v_mad_u32_u16 (op_sel).  Same
+  // index for every finite coordinate: clamp(floor(v) + hw, 0, C - 1) with hw <= 16383 is unchanged by saturating floor(v) to int16 first
+  // (a saturated value stays on its side of the clamp).  NaN samples do not occur (the rays of NaN points are never marched).
+  constexpr bool PK = IDX == 2 && !STRIP;
+  unsigned int hwhw_v = 0u, zero_v = 0u, cm1cm1_v = 0u;
+  if constexpr (PK) {
+    const unsigned int hw = (unsigned int)(int)P.hw_int_f, cm1 = (unsigned int)(C - 1);
+    hwhw_v = (hw << 16) | hw; cm1cm1_v = (cm1 << 16) | cm1;
+    asm volatile("" : "+v"(hwhw_v), "+v"(zero_v), "+v"(cm1cm1_v));
+  }
+  auto cell_key = [&](v2f n) -> unsigned int {                                    // PK only: sample position -> key (ix << 16) | iy
+    const v2h h = __builtin_convertvector(n, v2h);
+    const unsigned int hb = __builtin_bit_cast(unsigned int, h);
+    float fx, fy;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(fx) : "v"(hb), "s"(P.inv_res_f), "v"(frac_v));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(fy) : "v"(hb), "s"(P.inv_res_f), "v"(frac_v));
+    int fxi, fyi;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(fxi) : "v"(fx));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(fyi) : "v"(fy));
+    unsigned int k;
+    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(k) : "v"(fyi), "v"(fxi));            // low half: y, high half: x (signed saturation)
+    asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(k) : "v"(k), "v"(hwhw_v));
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(k) : "v"(k), "v"(zero_v));
+    asm("v_pk_min_i16 %0, %1, %2" : "=v"(k) : "v"(k), "v"(cm1cm1_v));
+    return k;
+  };
   unsigned int last_xy = 0xffffffffu;                           // the cell of the lane's previous sample (no cell: the first sample always acts)
   float s_end = 0.f;                                            // the lane's last sample (0: none -- the lane then never leaves the sensor's cell)
   if (!STRIP) {
     if (ke > 0) s_end = sS[ke - 1];
-    if (ke <= 0) { int ix0, iy0; rx = 0.f; ry = 0.f; last_xy = cell_xy(txy, ix0, iy0); }
+    if (ke <= 0) { int ix0, iy0; rx = 0.f; ry = 0.f; if constexpr (PK) last_xy = cell_key(txy); else last_xy = cell_xy(txy, ix0, iy0); }
   }
   const v2f rxy_m = {rx, ry};
   int kg = STRIP ? ((wb / LPR) & ~(2 * GU - 1)) : 0;            // first (lane) step of the current group (multiple of 8: the step table is read as float4)
@@ -526,13 +555,16 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
       s = sS[Kc];
       float sp = sS[max(Kc - 1, 0)];
       if (!STRIP) { asm("v_min_f32 %0, %1, %2" : "=v"(s) : "v"(s), "v"(s_end)); asm("v_min_f32 %0, %1, %2" : "=v"(sp) : "v"(sp), "v"(s_end)); }
-      int ixp, iyp;
-      const unsigned int xyp = cell_xy(txy + rxy_m * sp, ixp, iyp);
+      int ixp = 0, iyp = 0;
+      unsigned int xyp;
+      if constexpr (PK) xyp = cell_key(txy + rxy_m * sp); else xyp = cell_xy(txy + rxy_m * sp, ixp, iyp);
       if (!STRIP) prev_xy = K == 0 ? last_xy : xyp;             // (last_xy keeps its initial value here: none, or the sensor's cell for a lane without a ray)
       else prev_xy = ((unsigned int)(K - 1 - kb) < (unsigned int)(ke - kb)) ? xyp : 0xffffffffu;
     } else if (!STRIP) asm("v_min_f32 %0, %1, %2" : "=v"(s) : "v"(sk), "v"(s_end));
-    int ixs, iys;
-    const unsigned int xy = cell_xy(txy + rxy_m * s, ixs, iys);           // x, y of the sample (its height is only needed for queued visits)
+    int ixs = 0, iys = 0;
+    unsigned int xy;                                                      // x, y of the sample (its height is only needed for queued visits)
+    if constexpr (PK) { xy = cell_key(txy + rxy_m * s); if (STATS) { ixs = (int)(xy >> 16); iys = (int)(xy & 0xffffu); } }
+    else xy = cell_xy(txy + rxy_m * s, ixs, iys);
     const unsigned int ix = (unsigned int)ixs, iy = (unsigned int)iys;
     // own sample & new cell (:209-210) [& owned by this strip]; border cells (:211) read as inert in the bitmap
     bool act;
@@ -548,9 +580,14 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
       if (LPR == 1) last_xy = xy;
     }
     if (STATS) visits += (act && max(ix - 1u, iy - 1u) < (unsigned int)(C - 2)) ? 1u : 0u;
-    unsigned int colpart;                                       // ((iy >> 3) & ~3) | LDS base: byte offset of the word within its row
-    asm("v_and_or_b32 %0, %1, %3, %2" : "=v"(colpart) : "v"(bcol >> 3), "v"(base_v), "v"(mask_v));      // (no VOP3 literals on gfx9: the mask is a register)
-    const unsigned int off_a = mad24(brow, wpr32 * 4u, colpart);
+    unsigned int colpart, off_a;                                // ((iy >> 3) & ~3) | LDS base: byte offset of the word within its row
+    if constexpr (PK) {                                         // the key's low half is iy (the mask drops the ix bits), its high half the bitmap row
+      asm("v_and_or_b32 %0, %1, %3, %2" : "=v"(colpart) : "v"(xy >> 3), "v"(base_v), "v"(mask_v));
+      asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(off_a) : "v"(xy), "s"(wpr32 * 4u), "v"(colpart));
+    } else {
+      asm("v_and_or_b32 %0, %1, %3, %2" : "=v"(colpart) : "v"(bcol >> 3), "v"(base_v), "v"(mask_v));      // (no VOP3 literals on gfx9: the mask is a register)
+      off_a = mad24(brow, wpr32 * 4u, colpart);
+    }
     const unsigned int off = act ? off_a : ones_off;
     if (LMAP) w = *(const lds_u32*)(size_t)off;
     else w = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(inert) + off);
