@@ -63,3 +63,27 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "emap_oracle" not in txt, f
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md section D lists every entry point of the header next to the reference interface it replaces: a symbol added to
+    the ABI without its row there fails here"""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in _declared() if "`%s`" % n not in txt]
+    assert not missing, "INTEGRATION.md does not name: %s" % ", ".join(missing)
+
+
+def test_product_opens_nothing_under_oracle_or_the_reference_tree():
+    """the product may MENTION the oracle in comments; it must not open, execute or load anything under oracle/ or /root/reference:
+    no such path may appear in a string literal of the package, the compat layer or the header"""
+    lit = re.compile(r"\"([^\"\n]*)\"|'([^'\n]*)'")
+    for top in ("elevation_mapping_cupy_amd", "compat", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if not f.endswith((".py", ".hip", ".h", ".cpp")):
+                    continue
+                for ln in open(os.path.join(dirpath, f)).read().splitlines():
+                    code = ln.split("//")[0] if f.endswith((".hip", ".h", ".cpp")) else ln.split("#")[0]
+                    for m in lit.finditer(code):
+                        s = m.group(1) or m.group(2) or ""
+                        assert "/root/reference" not in s and "oracle/" not in s and "oracle." not in s, "%s: %r" % (f, s)
