@@ -9,8 +9,11 @@ Per frame (same stage order as reference update_map_with_kernel, EM/elevation_ma
     -> average -> overlap clearance -> HALO EXCHANGE of `halo` rows of cells with the strip neighbours
     -> dilation (owned rows +-3) -> traversability + normals
 
-* the cloud is replicated: every rank reads all points and keeps those whose row it owns (no exchange for fusion);
-* rays need no communication: every rank marches every ray and acts only on its own rows;
+* every rank is handed the same cloud and there is no exchange for fusion: a rank either binds all of it and keeps the points whose
+  row it owns (in-kernel), or -- round 5, wherever the frame allows it -- converts / uploads only the points that can land in its
+  rows (``ShardedElevationMap.input_pointcloud`` -> ``emap_upload_points_strip``: 1 / G of the cloud per rank);
+* rays marched BY ROW need no communication: every rank marches every ray and acts only on its own rows; the library's own frame
+  (``emap_update_sharded``) marches them BY RAY over an all-reduced window from 2048^2 cells on (DESIGN.md section 7c);
 * the two exchange steps go through ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on the GPU box,
   ``gloo`` in the CPU tests); buffers are plain device pointers on the C-ABI side (``emap_halo_pack/unpack``,
   ``emap_drift_sums_to_device``), so nothing syncs with the host inside a frame.
