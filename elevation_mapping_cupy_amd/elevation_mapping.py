@@ -711,6 +711,12 @@ class ElevationMap:
 
     compile_image_kernels = compile_kernels
 
+    def pad_value(self, x, shift_value, idx=None, value=0.0):
+        """host helper of the reference's shift (:172-198): fill the band a shift vacated in a (planes, rows, columns) stack.  The map
+        itself is shifted on the device (``emap_shift``: circular origin, no copy); this is for callers that shift their own arrays."""
+        from .semantic_map import SemanticMap
+        SemanticMap.pad_value(None, x, shift_value, idx=idx, value=value)
+
     def get_normal_ref(self, normal_x_data, normal_y_data, normal_z_data):
         n = self.get_normal_maps()
         normal_x_data[...] = n[0]

@@ -193,3 +193,32 @@ class SemanticMap:
 
     get_rgb = get_map_with_name
     get_semantic = get_map_with_name
+
+    # ---- the reference's small host helpers, kept for callers that use them directly ------------------------------------------
+    def process_map_for_publish(self, input_map):
+        """border-stripped copy of one layer (reference :376-386)"""
+        return np.array(input_map, copy=True)[1:-1, 1:-1]
+
+    def get_layer_indices(self, fusion_alg, layer_specs):
+        """positions in ``layer_specs`` of the layers fused by ``fusion_alg`` (reference :184-197, its chained comparison
+        ``key in val == fusion_alg`` included: a layer counts when its NAME is a substring of its fusion's name and that is the one asked for)"""
+        return np.array([it for it, (key, val) in enumerate(layer_specs.items()) if key in val and val == fusion_alg], dtype=np.int32)
+
+    def decode_max(self, mer):
+        """float32 values that carry (half probability | class id << 16) -> (probability as float32, class id) (reference :311-327)"""
+        bits = np.ascontiguousarray(mer, np.float32).view(np.uint32)
+        prob = (bits & np.uint32(0xFFFF)).astype(np.uint16).view(np.float16).astype(np.float32)
+        return prob, bits >> np.uint32(16)
+
+    def pad_value(self, x, shift_value, idx=None, value=0.0):
+        """fill the band a shift by ``shift_value`` (rows, columns) vacated in a (layers, rows, columns) stack (reference :99-125);
+        host arrays only -- the device layers are padded by ``emap_shift`` itself"""
+        sel = slice(None) if idx is None else idx
+        if shift_value[0] > 0:
+            x[sel, : shift_value[0], :] = value
+        elif shift_value[0] < 0:
+            x[sel, shift_value[0]:, :] = value
+        if shift_value[1] > 0:
+            x[sel, :, : shift_value[1]] = value
+        elif shift_value[1] < 0:
+            x[sel, :, shift_value[1]:] = value
