@@ -51,9 +51,16 @@ def kernels_of(src):
     for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?); Occupancy: (\d+)", txt, flags=re.S):
         name, body, occ = m.group(1), m.group(2), int(m.group(3))
         g = lambda pat, d=0: int((re.search(pat, body) or [None, d])[1])      # noqa: E731
+        # the kernel's instruction stream: from its label to the descriptor directive (static counts, every path once)
+        i0 = txt.find("\n%s:" % name)
+        code = txt[i0:m.start()] if i0 >= 0 else ""
+        mn = re.findall(r"^\t([a-z][a-z0-9_]+)(?:\s|$)", code, flags=re.M)
+        mix = {"valu": sum(x.startswith("v_") for x in mn), "salu": sum(x.startswith("s_") and x != "s_nop" and not x.startswith("s_waitcnt") for x in mn),
+               "ldsi": sum(x.startswith("ds_") for x in mn), "vmem": sum(x.startswith(("global_", "buffer_", "flat_", "scratch_")) for x in mn),
+               "nop": sum(x == "s_nop" for x in mn), "wait": sum(x.startswith("s_waitcnt") for x in mn)}
         recs.append({"mangled": name, "vgpr": g(r"; NumVgprs: (\d+)"), "agpr": g(r"; NumAgprs: (\d+)"), "sgpr": g(r"; TotalNumSgprs: (\d+)"),
                      "scratch": g(r"; ScratchSize: (\d+)"), "lds": g(r"; LDSByteSize: (\d+)"), "code": g(r"; codeLenInByte = (\d+)"),
-                     "occupancy": occ})
+                     "occupancy": occ, **mix})
     return recs
 
 
@@ -63,16 +70,19 @@ def main():
     print("# source_stamp: %s" % bench.source_stamp())
     print("# vgpr / agpr / sgpr: registers allocated; scratch: bytes per lane (spills -- 0 = none); lds: STATIC bytes per workgroup (dynamic LDS")
     print("# sized by the host launch is not included); code: bytes of ISA; occ: waves per SIMD the register / static-LDS budget allows (max 8)")
+    print("# right of the bar: STATIC instruction counts of the kernel's code (every path once, not what a wave executes): VALU, SALU (without s_nop /")
+    print("# s_waitcnt), LDS, vector memory, s_nop (hazard wait states the compiler inserted), s_waitcnt")
     print("# (the vgpr column of profiles/*_kernel_stats.txt is rocprofv3's VGPR_Count, which reads half of NumVgprs on this stack: k_post<32, 0> 24 there, 48 here)")
     total, spilled = 0, []
     for src in ("emap_kernels.hip", "emap_binned.hip", "emap_semantic.hip"):
         recs = kernels_of(src)
         names = demangle([r["mangled"] for r in recs])
         print("\n## %s: %d kernel instantiations" % (src, len(recs)))
-        print("%-78s %5s %5s %5s %8s %7s %7s %4s" % ("kernel", "vgpr", "agpr", "sgpr", "scratch", "lds", "code", "occ"))
+        print("%-78s %5s %5s %5s %8s %7s %7s %4s | %5s %5s %5s %5s %5s %5s" % ("kernel", "vgpr", "agpr", "sgpr", "scratch", "lds", "code", "occ", "valu", "salu", "lds", "vmem", "nop", "wait"))
         for r in sorted(recs, key=lambda r: short(names[r["mangled"]])):
             n = short(names[r["mangled"]])
-            print("%-78s %5d %5d %5d %8d %7d %7d %4d" % (n[:78], r["vgpr"], r["agpr"], r["sgpr"], r["scratch"], r["lds"], r["code"], r["occupancy"]))
+            print("%-78s %5d %5d %5d %8d %7d %7d %4d | %5d %5d %5d %5d %5d %5d" % (n[:78], r["vgpr"], r["agpr"], r["sgpr"], r["scratch"], r["lds"], r["code"], r["occupancy"],
+                                                                                      r["valu"], r["salu"], r["ldsi"], r["vmem"], r["nop"], r["wait"]))
             total += 1
             if r["scratch"]:
                 spilled.append((n, r["scratch"]))
