@@ -87,3 +87,17 @@ def test_product_opens_nothing_under_oracle_or_the_reference_tree():
                     for m in lit.finditer(code):
                         s = m.group(1) or m.group(2) or ""
                         assert "/root/reference" not in s and "oracle/" not in s and "oracle." not in s, "%s: %r" % (f, s)
+
+
+def test_the_ctypes_stub_of_integration_md_matches_the_header_and_the_binding():
+    """INTEGRATION.md (B) shows a maintainer the ctypes Structure for emap_params: its field list must be the header's, in order, and the
+    one the shipped binding uses"""
+    from elevation_mapping_cupy_amd import _lib
+    h = open(os.path.join(ROOT, "include", "emap_hip.h")).read()
+    body = re.search(r"typedef struct emap_params \{(.*?)\} emap_params;", h, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    header = [re.sub(r"\[.*\]", "", f.strip()) for decl in body.split(";") if decl.strip() for f in decl.strip().split(None, 1)[1].split(",")]
+    t = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = re.findall(r'"(\w+)"', t[t.index("class emap_params(ct.Structure)"):t.index("ctx = ct.c_void_p()")])
+    assert stub == header
+    assert [f[0] for f in _lib.EmapParams._fields_] == header
