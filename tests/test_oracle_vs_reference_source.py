@@ -211,3 +211,57 @@ def test_max_filter_sweeps_vs_reference_kernel(d):
         assert sweeps == ran
         assert np.array_equal(np.isnan(got), np.isnan(want))
         assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+
+
+def _random_pose(rng):
+    a = rng.uniform(-np.pi, np.pi, 3) * np.array([0.35, 0.35, 1.0])
+    R = fx.rot(a[0], a[1], a[2])
+    t = np.array([rng.uniform(-2.5, 2.5), rng.uniform(-2.5, 2.5), rng.uniform(0.3, 2.0)], np.float32)
+    return np.ascontiguousarray(R, np.float32), t
+
+
+@pytest.mark.parametrize("name,cfg", [("yaml202", eo.YAML), ("default202", eo.DEFAULTS)])
+def test_fuzz_count_outputs_and_point_index_vs_reference_source(name, cfg, weights):
+    """Seeded sweep over what the fixed fixtures do not vary: random sensor poses (any yaw, +-60 degrees of roll / pitch, sensor up to
+    2.5 m off the map centre), clouds with points far outside the map (clamped to its border by the half-precision index arithmetic),
+    points at the sensor (min_valid_distance), large magnitudes (beyond the float16 range: +-inf after the parameter rounding) and
+    exact cell-boundary coordinates.  Order-independent outputs only: per-cell point / inlier counts and the drift count of
+    error_counting_kernel (custom_kernels.py:280-345) on a warm map, and the (cell index, is_valid, is_inside) triple add_points_kernel
+    leaves in the point's first three columns (:260-262) -- all exact."""
+    rk = _ref(name)
+    C, N = 202, 20000
+    om, _, _ = _warm(cfg, C, 50000, weights)
+    res = float(eo.DEFAULTS["resolution"] if "resolution" not in cfg else cfg["resolution"])
+    rng = np.random.default_rng(2025)
+    for case in range(10):
+        R, t = _random_pose(rng)
+        Rf = R.ravel().copy()
+        p = fx.cloud(C, N, 100 + case, dz=float(rng.uniform(-0.3, 0.3)))
+        k = rng.integers(0, N, 600)
+        p[k[:150], :2] *= np.float32(3.0)                                            # far outside the map
+        p[k[150:250]] = rng.normal(0, 0.05, (100, 3)).astype(np.float32)             # at the sensor
+        p[k[250:300], int(rng.integers(0, 3))] = np.float32(7.0e4) * rng.choice([-1, 1])      # beyond the largest half (65504)
+        p[k[300:450], 0] = (np.round(p[k[300:450], 0] / res) * res).astype(np.float32)        # on cell boundaries
+        p[k[450:600], 1] = (np.round(p[k[450:600], 1] / res) * res + np.float32(res / 2)).astype(np.float32)
+        nm = np.zeros((7, C, C), np.float32); err = np.zeros(1, np.float32); cnt = np.zeros(1, np.float32)
+        rk.error_counting(om.elevation_map.copy(), p.copy(), Rf, t.copy(), nm, err, cnt)
+        n_pts, n_inl, es, ec = om.count(p, R, t)
+        assert np.array_equal(n_pts, nm[4].astype(np.uint32)), "case %d: points per cell" % case
+        assert np.array_equal(n_inl, nm[3].astype(np.uint32)), "case %d: drift inliers per cell" % case
+        assert ec == int(cnt[0]), "case %d" % case
+        assert abs(es - float(err[0])) <= 1e-5 * max(1.0, ec) + 1e-5
+        # the index tail of add_points_kernel on a FRESH map (so that nothing else of the kernel depends on the map's state)
+        pr = p.copy()
+        m = np.zeros((7, C, C), np.float32); m[1] = cfg.get("initial_variance", eo.DEFAULTS["initial_variance"]); m[3] = 1
+        rk.add_points(Rf, t.copy(), np.zeros((3, C, C), np.float32), pr, m, np.zeros((7, C, C), np.float32))
+        idx, valid, inside = om.point_index(p, R, t)
+        # (points beyond the half range become +-inf / NaN: their int cast is undefined in C++ -- the host-compiled reference gets
+        # INT_MIN from x86, the GPU saturates (NaN -> 0) and so do oracle and kernels.  Their is_valid flag is still compared -- a point
+        # infinitely far BELOW the sensor passes every height gate on both sides -- and none of them may land inside the map: the
+        # counts above are exact with them in the cloud.  Only their meaningless index / border flag is left out.)
+        fin = np.abs(p).max(axis=1) < 6.0e4
+        assert (~fin).sum() >= 40 and not inside[~fin].any()
+        assert np.array_equal(idx[fin], pr[fin, 0].astype(np.int32)), "case %d: cell index" % case
+        assert np.array_equal(valid.astype(bool), pr[:, 1] > 0.5), "case %d: is_valid" % case
+        assert np.array_equal(inside[fin].astype(bool), pr[fin, 2] > 0.5), "case %d: is_inside" % case
+        assert 0.05 < valid.mean() < 1.0
