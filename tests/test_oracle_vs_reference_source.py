@@ -265,3 +265,94 @@ def test_fuzz_count_outputs_and_point_index_vs_reference_source(name, cfg, weigh
         assert np.array_equal(valid.astype(bool), pr[:, 1] > 0.5), "case %d: is_valid" % case
         assert np.array_equal(inside[fin].astype(bool), pr[fin, 2] > 0.5), "case %d: is_inside" % case
         assert 0.05 < valid.mean() < 1.0
+
+
+@pytest.mark.parametrize("setname,C,sizes", [("default34", 34, (None, 1, 3, 10)), ("yaml66", 66, (None, 1, 2, 10))])
+def test_fuzz_stencils_vs_reference_source(setname, C, sizes):
+    """dilation_filter_kernel (custom_kernels.py:392-449) and normal_filter_kernel (:452-506) on random planes whose masks run from
+    empty to full (a hole next to nothing, a hole whose only source sits d cells away on the last anti-diagonal the kernel scans,
+    no hole at all), with huge, tiny, negative and signed-zero values: the dilated plane and its mask EXACT for every compiled radius
+    (None = the parameter set's own dilation_size), the normals within the 1e-6 the golden fixture uses (the reference normalises with
+    a reciprocal square root)."""
+    rk = _ref(setname)
+    rng = np.random.default_rng(C)
+    own = int(build_ref.PREBUILD[setname]["dilation_size"])
+    for case, density in enumerate((0.0, 0.002, 0.02, 0.1, 0.35, 0.8, 1.0, 0.05)):
+        plane = rng.uniform(-3, 3, (C, C)).astype(np.float32)
+        plane[rng.uniform(0, 1, (C, C)) < 0.05] *= np.float32(1.0e6)
+        plane[rng.uniform(0, 1, (C, C)) < 0.05] *= np.float32(1.0e-12)
+        plane[rng.uniform(0, 1, (C, C)) < 0.02] = np.float32(-0.0)
+        mask = (rng.uniform(0, 1, (C, C)) < density).astype(np.float32)
+        if case == 7:
+            mask *= rng.choice([0.3, 0.5, 0.51, 1.0, 2.0], (C, C)).astype(np.float32)      # the kernels test `> 0.5`, not `!= 0`
+        for d in sizes:
+            out = np.zeros((C, C), np.float32); om = np.zeros((C, C), np.float32)
+            rk.dilation_filter(plane.copy(), mask.copy(), out, om, size=d)
+            o2, m2 = eo.dilate_plane(C, own if d is None else d, plane, mask)
+            assert out.tobytes() == o2.tobytes(), "%s case %d d=%s: dilated plane" % (setname, case, d)
+            assert np.array_equal(om, m2), "%s case %d d=%s: dilated mask" % (setname, case, d)
+        nrm = np.zeros((3, C, C), np.float32)
+        rk.normal_filter(plane.copy(), mask.copy(), nrm)
+        o = eo.OracleMap(eo.make_params(eo.DEFAULTS, cell_n=C))
+        o.traversability_input[...] = plane
+        o.elevation_map[2] = mask
+        o.normals()
+        ok = np.isfinite(nrm) & np.isfinite(o.normal_map)
+        assert np.array_equal(np.isfinite(nrm), np.isfinite(o.normal_map)), "%s case %d: finiteness of the normals" % (setname, case)
+        assert np.allclose(o.normal_map[ok], nrm[ok], atol=1e-6), "%s case %d: normals" % (setname, case)
+
+
+def test_fuzz_fresh_frames_rays_off_vs_reference_source(weights):
+    """the race-free fixture of test_fuse_sums_without_outliers_rays_off under six random sensor poses and cloud heights: on a fresh
+    map with the visibility pass off the sequential reference run and the two-phase contract must agree in every plane -- flags, time,
+    upper bound and traversability exactly, fused height and variance within the 1e-5 north_star asks for (the reference sums floats in
+    point order) -- through count, fusion and average_map_kernel (custom_kernels.py:160-197, 280-389)."""
+    rk = _ref("yaml202_norays")
+    C, N = 202, 30000
+    cfg = dict(eo.YAML, enable_visibility_cleanup=False, enable_overlap_clearance=False)
+    rng = np.random.default_rng(77)
+    for case in range(6):
+        R, t = _random_pose(rng)
+        Rf = R.ravel().copy()
+        om = eo.OracleMap(eo.make_params(cfg, cell_n=C, weights=weights))
+        p = fx.cloud(C, N, 200 + case, dz=float(rng.uniform(-0.4, 0.2)))
+        p[rng.integers(0, N, 300), :2] *= np.float32(2.5)
+        m = om.elevation_map.copy(); nm = np.zeros((7, C, C), np.float32); nrm = np.zeros((3, C, C), np.float32)
+        err = np.zeros(1, np.float32); cnt = np.zeros(1, np.float32); pr = p.copy()
+        rk.error_counting(m, pr, Rf, t.copy(), nm, err, cnt); rk.add_points(Rf, t.copy(), nrm, pr, m, nm); rk.average_map(nm, m)
+        om.count(p, R, t); om.gate(0, 0); om.fuse(p, R, t); om.commit(); om.average()
+        assert int((m[2] > 0.5).sum()) > 500, "case %d: the pose must leave points on the map" % case
+        for pl in (2, 3, 4, 5, 6):
+            assert np.array_equal(om.elevation_map[pl], m[pl]), "case %d plane %d" % (case, pl)
+        assert np.allclose(om.elevation_map[0], m[0], atol=1e-5, rtol=1e-5), "case %d: height" % case
+        assert np.allclose(om.elevation_map[1], m[1], atol=1e-5, rtol=1e-5), "case %d: variance" % case
+
+
+def test_fuzz_warm_frames_with_rays_differ_only_where_the_reference_races(weights):
+    """test_warm_frame_race_exposed_planes_differ_only_where_the_reference_races under four random sensor poses: a warm, aged map,
+    visibility pass ON -- wherever the sequential run of the reference's kernels and the two-phase contract disagree, the cell is in
+    one of the reference's race classes (multi-point cell, outlier, stale cell fused this frame, cell written by the ray pass)."""
+    rk = _ref("yaml202")
+    C, N = 202, 30000
+    rng = np.random.default_rng(99)
+    for case in range(4):
+        R, t = _random_pose(rng)
+        Rf = R.ravel().copy()
+        om = eo.OracleMap(eo.make_params(eo.YAML, cell_n=C, weights=weights))
+        om.update_map_with_kernel(fx.cloud(C, 50000, 300 + case), R, t)
+        for _ in range(10):
+            om.update_time()
+        om.update_variance()
+        p = fx.cloud(C, N, 400 + case, dz=float(rng.uniform(-0.15, 0.0)))
+        pre = om.elevation_map.copy()
+        m = pre.copy(); nm = np.zeros((7, C, C), np.float32); nrm = om.normal_map.copy()
+        err = np.zeros(1, np.float32); cnt = np.zeros(1, np.float32); pr = p.copy()
+        rk.error_counting(m, pr, Rf, t.copy(), nm, err, cnt); rk.add_points(Rf, t.copy(), nrm, pr, m, nm); rk.average_map(nm, m)
+        om.count(p, R, t); om.gate(0, 0); om.fuse(p, R, t); om.commit(); om.rays(p, R, t)
+        racy = (om.last["n_pts"] > 1) | (om.last["n_out"] > 0) | (om.last["ray_hits"] > 0) | np.isfinite(om.last["ray_upper"])
+        racy |= (pre[2] > 0.5) & (pre[4] >= 0.5) & (om.last["n_pts"] > 0)
+        assert 0.0 < racy.mean() < 0.95, "case %d" % case
+        om.average()
+        for pl in range(7):
+            diff = ~np.isclose(om.elevation_map[pl], m[pl], atol=1e-5, rtol=1e-5)
+            assert not (diff & ~racy).any(), "case %d: plane %d differs on %d race-free cells" % (case, pl, int((diff & ~racy).sum()))
