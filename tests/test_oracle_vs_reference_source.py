@@ -356,3 +356,117 @@ def test_fuzz_warm_frames_with_rays_differ_only_where_the_reference_races(weight
         for pl in range(7):
             diff = ~np.isclose(om.elevation_map[pl], m[pl], atol=1e-5, rtol=1e-5)
             assert not (diff & ~racy).any(), "case %d: plane %d differs on %d race-free cells" % (case, pl, int((diff & ~racy).sum()))
+
+
+def test_fuzz_camera_path_vs_reference_source(weights):
+    """image_to_map_correspondence_kernel + the three samplers (custom_image_kernels.py:9-271) under eight random cameras: position
+    over / beside / outside the map, tilt up to grazing, narrow and wide lenses, with and without radtan distortion, rough relief
+    (occlusions), map centres off the origin -- uv, validity and the sampled layers exact."""
+    rk = _ref("image98")
+    C = 98
+    cfg = dict(eo.YAML, enable_visibility_cleanup=False)
+    rng = np.random.default_rng(4242)
+    R0, t0 = fx.POSES["identity"]
+    seen = 0
+    for case in range(8):
+        om = eo.OracleMap(eo.make_params(cfg, cell_n=C, weights=weights))
+        p = fx.cloud(C, 20000, 500 + case)
+        p[:, 2] += np.float32(rng.uniform(0.1, 0.5)) * np.sin(p[:, 0] * np.float32(rng.uniform(1, 4))) * np.cos(p[:, 1] * np.float32(rng.uniform(1, 4)))
+        om.update_map_with_kernel(p, R0, t0)
+        H, W = int(rng.choice([32, 48, 96])), int(rng.choice([40, 64, 128]))
+        f = float(rng.uniform(15.0, 120.0))
+        K = np.array([[f, 0, W / 2 + rng.uniform(-3, 3)], [0, f * rng.uniform(0.9, 1.1), H / 2 + rng.uniform(-3, 3)], [0, 0, 1]], np.float32)
+        D = (rng.normal(0, 1, 5) * np.array([0.08, 0.02, 0.004, 0.004, 0.001])).astype(np.float32) if case % 2 else np.zeros(5, np.float32)
+        Rwc = fx.rot(np.pi + rng.uniform(-1.2, 1.2), rng.uniform(-0.8, 0.8), rng.uniform(-3, 3)).astype(np.float32)
+        cam = np.array([rng.uniform(-2.5, 2.5), rng.uniform(-2.5, 2.5), rng.uniform(0.6, 3.0)], np.float32)
+        t = (-Rwc @ cam).astype(np.float32)
+        center = rng.uniform(-0.4, 0.4, 3).astype(np.float32)
+        Pm, x1, y1, z1 = fx.camera_inputs(center, C, 0.04, K, Rwc, t)
+        uv_r = np.zeros((2, C, C), np.float32); va_r = np.zeros((C, C), np.bool_)
+        rk.image_correspondence(om.elevation_map.copy(), x1, y1, z1, Pm.ravel().copy(), K.ravel().copy(), D.copy(), H, W, center, uv_r, va_r)
+        uv, va = eo.image_correspondence(om.P, om.elevation_map, x1, y1, z1, Pm.ravel(), K.ravel(), D, H, W, center)
+        assert np.array_equal(va.astype(bool), va_r), "case %d: validity" % case
+        assert np.array_equal(uv, uv_r), "case %d: uv" % case
+        seen += int(va_r.sum())
+        img = rng.uniform(0, 1, (3, H, W)).astype(np.float32)
+        rgb = rng.integers(0, 256, (3, H, W)).astype(np.float32)
+        sem = rng.uniform(0, 1, (3, C, C)).astype(np.float32)
+        new_r = np.zeros_like(sem)
+        rk.image_fuse("exponential", sem.copy(), 0, img[1].copy(), uv_r, va_r, H, W, new_r)
+        rk.image_fuse("color", sem.copy(), 1, rgb.copy(), uv_r, va_r, H, W, new_r)
+        rk.image_fuse("average", sem.copy(), 2, img[2].copy(), uv_r, va_r, H, W, new_r)
+        mine = sem.copy()
+        eo.image_fuse(om.P, "exponential", mine[0], img[1], uv, va, H, W, 0.7)
+        eo.image_fuse(om.P, "color", mine[1], rgb, uv, va, H, W)
+        eo.image_fuse(om.P, "average", mine[2], img[2], uv, va, H, W)
+        assert np.array_equal(mine[0], new_r[0]) and np.array_equal(mine[1].view(np.uint32), new_r[1].view(np.uint32)) and np.array_equal(mine[2], new_r[2]), "case %d" % case
+    assert seen > 2000, "the sweep must see the map"
+
+
+def test_fuzz_polygon_mask_vs_reference_source():
+    """polygon_mask_kernel (custom_kernels.py:509-651) on 40 random polygons: 3 ... 9 vertices in random order (self-intersecting ones
+    included -- the kernel's crossing test does not care), sizes from sub-cell to beyond the map, random map centres: exact."""
+    params = build_ref.PREBUILD["polygon130"]
+    if not ref_kernels.available(params):
+        pytest.skip("compiled reference not built")
+    rk = ref_kernels.RefKernels(params, build=False)
+    C = 130
+    P = eo.make_params(eo.DEFAULTS, cell_n=C)
+    rng = np.random.default_rng(31)
+    covered = 0
+    for case in range(40):
+        n = int(rng.integers(3, 10))
+        scale = float(10.0 ** rng.uniform(-2.0, 0.6))
+        center = (float(rng.uniform(-0.6, 0.6)), float(rng.uniform(-0.6, 0.6)))
+        poly = (rng.uniform(-1, 1, (n, 2)) * scale + rng.uniform(-1.0, 1.0, 2) + np.array(center)).astype(np.float32)
+        # get_polygon_traversability clips the vertices to the map first (elevation_mapping.py:851-855)
+        half = (C - 2) * 0.04 / 2
+        poly = np.clip(poly, np.array(center, np.float32) - np.float32(half), np.array(center, np.float32) + np.float32(half)).astype(np.float32)
+        want = np.full((C, C), -1, np.float32)
+        bbox = np.concatenate([poly.min(axis=0), poly.max(axis=0)]).astype(np.float32)
+        rk.polygon_mask(poly, center[0], center[1], bbox, want)
+        got = eo.polygon_mask(P, poly, center[0], center[1])
+        assert np.array_equal(got, want), "case %d (%d vertices, scale %.3g)" % (case, n, scale)
+        covered += int((want > 0.5).sum())
+    assert covered > 5000
+
+
+def test_fuzz_semantic_point_fusions_vs_reference_source():
+    """sum / average, sum / class_average and add_color / color_average (custom_semantic_kernels.py:9-51,167-194,233-267,270-375) driven
+    as tests/golden/make_golden.py drives them, under five random poses, cloud seeds and previous layer contents: the averaged layers
+    within 1e-6 (the reference adds floats in point order), the packed colour layer bit for bit."""
+    rk = _ref("yaml66")
+    params = build_ref.PREBUILD["yaml66"]
+    C, N, K = 66, 6000, 4
+    rng = np.random.default_rng(606)
+    i32 = lambda *a: np.array(a, np.int32)      # noqa: E731
+    for case in range(5):
+        R, t = _random_pose(rng)
+        t[:2] *= np.float32(0.3)                 # (a 66-cell map is 2.6 m wide)
+        Rf = R.ravel().copy()
+        p = fx.semantic_cloud(C, N, 700 + case)
+        prev = (rng.uniform(0, 1, (C, C)) * (rng.uniform(0, 1, (C, C)) < rng.uniform(0.1, 0.9))).astype(np.float32)
+        m = np.zeros((7, C, C), np.float32); m[1] = params["initial_variance"]; m[3] = 1
+        nm = np.zeros((7, C, C), np.float32); nrm = np.zeros((3, C, C), np.float32)
+        err = np.zeros(1, np.float32); cnt = np.zeros(1, np.float32)
+        xyz = np.ascontiguousarray(p[:, :3])
+        rk.error_counting(m, xyz, Rf, t.copy(), nm, err, cnt); rk.add_points(Rf, t.copy(), nrm, xyz, m, nm)
+        pc = p.copy(); pc[:, :3] = xyz
+        sem = np.zeros((4, C, C), np.float32); sem[2] = prev
+        newmap = np.zeros((4, C, C), np.float32)
+        rk.sem_sum(pc, Rf, t.copy(), i32(3, 4), i32(0, 1), i32(3 + K, 2), sem, newmap, N * 2)
+        rk.sem_average(newmap, i32(3, 4), i32(0, 1), i32(3 + K, 2), nm, sem, C * C * 2)
+        newmap2 = np.zeros((4, C, C), np.float32)
+        rk.sem_sum(pc, Rf, t.copy(), i32(5), i32(2), i32(3 + K, 1), sem, newmap2, N)
+        rk.sem_class_average(newmap2, i32(5), i32(2), i32(3 + K, 1), nm, sem, C * C)
+        color_map = np.zeros((4, C, C), np.uint32)
+        rk.sem_add_color(pc, Rf, t.copy(), i32(6), i32(3), i32(3 + K, 1), color_map, N)
+        rk.sem_color_average(color_map, i32(6), i32(3), i32(3 + K, 1), sem, C * C)
+        om = eo.OracleMap(eo.make_params(eo.YAML, cell_n=C))
+        om.count(p, R, t); om.gate(0, 0); om.fuse(p, R, t)
+        assert np.array_equal(om.last["cnt"], nm[2].astype(np.uint32)), "case %d: accepted points per cell" % case
+        assert int((nm[2] > 1).sum()) > 100, "case %d: cells with several points" % case
+        om.semantic_map = np.zeros((4, C, C), np.float32); om.semantic_map[2] = prev
+        om.semantic_update(p, R, t, average=[(3, 0), (4, 1)], class_average=[(5, 2)], color=[(6, 3)], alpha=0.5)
+        assert np.allclose(om.semantic_map[:3], sem[:3], atol=1e-6, rtol=1e-6), "case %d: averaged layers" % case
+        assert np.array_equal(om.semantic_map[3].view(np.uint32), sem[3].view(np.uint32)), "case %d: packed colour" % case
