@@ -470,3 +470,45 @@ def test_fuzz_semantic_point_fusions_vs_reference_source():
         om.semantic_update(p, R, t, average=[(3, 0), (4, 1)], class_average=[(5, 2)], color=[(6, 3)], alpha=0.5)
         assert np.allclose(om.semantic_map[:3], sem[:3], atol=1e-6, rtol=1e-6), "case %d: averaged layers" % case
         assert np.array_equal(om.semantic_map[3].view(np.uint32), sem[3].view(np.uint32)), "case %d: packed colour" % case
+
+
+def test_fuzz_bayesian_point_fusions_vs_reference_source():
+    """class_bayesian (alpha_kernel + renormalisation, the K = 2 launch-size quirk, negative theta ignored, persistent pseudo-counts)
+    and bayesian_inference (sum_compact + bayesian_inference kernels) as the reference's fusions run them
+    (fusion/pointcloud_class_bayesian.py:56-75, fusion/pointcloud_bayesian_inference.py:101-122; recipe of tests/golden/make_golden.py),
+    under five random poses, clouds, priors and previous layers."""
+    rk = _ref("bayes66")
+    params = build_ref.PREBUILD["bayes66"]
+    C, N, K = 66, 6000, 4
+    rng = np.random.default_rng(808)
+    i32 = lambda *a: np.array(a, np.int32)      # noqa: E731
+    for case in range(5):
+        R, t = _random_pose(rng)
+        t[:2] *= np.float32(0.3)
+        Rf = R.ravel().copy()
+        p = fx.bayes_cloud(C, N, 900 + case)
+        prior = rng.uniform(0, 2, (2, C, C)).astype(np.float32); prior[:, rng.uniform(0, 1, (C, C)) < rng.uniform(0.1, 0.6)] = 0.0
+        prev = (rng.uniform(0, 1, (C, C)) * (rng.uniform(0, 1, (C, C)) < 0.5)).astype(np.float32)
+        m = np.zeros((7, C, C), np.float32); m[1] = params["initial_variance"]; m[3] = 1
+        nm = np.zeros((7, C, C), np.float32); nrm = np.zeros((3, C, C), np.float32)
+        err = np.zeros(1, np.float32); cnt = np.zeros(1, np.float32)
+        xyz = np.ascontiguousarray(p[:, :3])
+        rk.error_counting(m, xyz, Rf, t.copy(), nm, err, cnt); rk.add_points(Rf, t.copy(), nrm, xyz, m, nm)
+        pc = p.copy(); pc[:, :3] = xyz
+        sem = np.zeros((3, C, C), np.float32); sem[2] = prev
+        newmap = np.zeros((3, C, C), np.float32); newmap[:2] = prior
+        rk.alpha(pc, i32(3, 4), i32(0, 1), i32(3 + K, 2), newmap, N)
+        sum_alpha = np.sum(newmap[[0, 1]], axis=0); sum_alpha[sum_alpha == 0] = 1
+        sem[[0, 1]] = newmap[[0, 1]] / np.expand_dims(sum_alpha, axis=0)
+        sum_mean = np.zeros((1, C, C), np.float32)
+        rk.sum_compact(pc, Rf, t.copy(), i32(5), i32(2), i32(3 + K, 1), sum_mean, N)
+        rk.bayesian_inference(i32(5), i32(2), i32(3 + K, 1), nm, newmap, sum_mean, sem, C * C)
+        om = eo.OracleMap(eo.make_params(eo.YAML, cell_n=C))
+        om.count(p, R, t); om.gate(0, 0); om.fuse(p, R, t)
+        om.semantic_map = np.zeros((3, C, C), np.float32); om.semantic_map[2] = prev
+        om.semantic_alpha = np.zeros((3, C, C), np.float32); om.semantic_alpha[:2] = prior
+        om.semantic_update(p, R, t, class_bayesian=[(3, 0), (4, 1)], bayesian_inference=[(5, 2)])
+        assert np.allclose(om.semantic_alpha[:2], newmap[:2], atol=1e-5, rtol=1e-5), "case %d: pseudo-counts" % case
+        assert np.allclose(om.semantic_map[:2], sem[:2], atol=1e-6, rtol=1e-5), "case %d: class probabilities" % case
+        assert np.array_equal(om.semantic_map[2], sem[2]), "case %d: bayesian_inference layer" % case
+        assert (newmap[:2] != prior).any()
