@@ -192,3 +192,33 @@ def test_host_steps_live_against_reference_host_code():
         getattr(h, kind)(*((np.array(vec, np.float64), np.eye(3)) if kind == "move_to" else (np.array(vec, np.float64),)))
         getattr(om, kind)(np.array(vec, np.float64))
         assert np.array_equal(np.asarray(h.center, np.float32), om.center) and np.array_equal(h.elevation_map, om.elevation_map)
+
+
+@pytest.mark.parametrize("name,seed", [("yaml202", 2), ("default202", 3)])
+def test_fuzz_single_point_warm_frames_under_random_poses_vs_reference_source(name, seed):
+    """the race-free one-point frames once more -- another injected warm map, 300 frames whose sensor pose changes every ten frames
+    (any yaw, +-60 degrees of roll / pitch, up to 1.5 m off the map centre, sensor height 0.5 ... 2 m): oracle == compiled reference
+    after EVERY frame on all 7 planes, with the ray-penetration and outlier branches reached."""
+    rk = _ref(name)
+    cfg = getattr(eo, W.SETS[name])
+    C = 202
+    m0, nrm = fx.warm_map(C, seed, cfg["initial_variance"])
+    om = eo.OracleMap(eo.make_params(cfg, cell_n=C))
+    om.elevation_map[...] = m0; om.normal_map[...] = nrm
+    m = m0.copy()
+    rng = np.random.default_rng(50 + seed)
+    pts = fx.cloud(C, 300, 7100 + seed)
+    hits = outl = 0
+    R = t = None
+    for k in range(300):
+        if k % 10 == 0:
+            a = rng.uniform(-np.pi, np.pi, 3) * np.array([0.33, 0.33, 1.0])
+            R = np.ascontiguousarray(fx.rot(a[0], a[1], a[2]), np.float32)
+            t = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.5, 1.5), rng.uniform(0.5, 2.0)], np.float32)
+            m[4] += np.float32(cfg["time_interval"]); om.update_time()
+        p = pts[k:k + 1].copy()
+        W.ref_frame(rk, m, nrm, p, R, t)
+        h, o = W.oracle_frame(om, p, R, t)
+        hits += h; outl += o
+        _close(om.elevation_map, m, "%s frame %d" % (name, k))
+    assert hits >= 300 and outl >= 5, (hits, outl)
