@@ -176,16 +176,19 @@ def test_openmp_baseline_mode_equals_sequential_oracle(weights):
     C, N = 130, 20000
     R, t = fx.POSES["rotated"]
     maps = {}
-    for nt in (1, 4):
+    for nt in (1, 4, 7):
         eo.set_threads(nt)
         om = eo.OracleMap(eo.make_params(eo.YAML, cell_n=C, weights=weights))
         for f, dz in enumerate((0.0, -0.02, -0.2)):
             om.frame_c(fx.cloud(C, N, f, dz=dz), R, t, 1.0, 1.0)
             for _ in range(6):
                 om.update_time()
-        maps[nt] = (om.elevation_map.copy(), om.normal_map.copy())
+        maps[nt] = (om.elevation_map.copy(), om.normal_map.copy(), float(om.additive_mean_error))
     eo.set_threads(1)
-    assert np.allclose(maps[1][0], maps[4][0], atol=1e-6, rtol=1e-6) and np.allclose(maps[1][1], maps[4][1], atol=1e-6)
+    # the oracle accumulates the kernels' integers / fixed-point sums: no dependence on thread count or
+    # point order is left -- bit for bit, which is what lets the GPU tests compare whole planes exactly
+    for nt in (4, 7):
+        assert maps[1][0].tobytes() == maps[nt][0].tobytes() and maps[1][1].tobytes() == maps[nt][1].tobytes() and maps[1][2] == maps[nt][2], nt
 
 
 def test_semantic_toy_golden_matches_the_compiled_reference_kernels():
