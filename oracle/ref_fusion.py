@@ -43,7 +43,7 @@ def _cp_namespace():
     xp.unique = lambda a: np.unique(np.asarray(a)).view(CpArray)
     xp.array = lambda *a, **k: np.array(*a, **k).view(CpArray)
     xp.bitwise_and = lambda a, b, dtype=None: (np.bitwise_and(np.asarray(a), b).astype(dtype) if dtype is not None else np.bitwise_and(a, b))
-    return {"cp": xp, "np": np, "__builtins__": dict(ref_host._SAFE_BUILTINS, enumerate=enumerate)}
+    return {"cp": xp, "np": np, "__builtins__": ref_host.exec_builtins(enumerate=enumerate)}
 
 
 def load(ref_kernels):

@@ -15,7 +15,10 @@ this module) are the DEFAULT pin; executing the reference file live is opt-in:
   need: imports, nested function / class definitions, lambdas, ``global`` / ``nonlocal``, ``with`` (except ``with self.map_lock``) / ``try`` / ``raise`` / ``del``,
   awaits / yields, dunder names and dunder attributes, string formatting, and every call or attribute chain whose root is not one of
   ``self`` / ``cp`` / ``xp`` / ``np`` / a local variable / a whitelisted builtin (``int``, ``float``, ``abs``, ``min``, ``max``, ``len``, ``range``,
-  ``print``).  The namespace handed to ``exec`` carries no ``__builtins__`` beyond that list.
+  ``print``).  The namespace handed to ``exec`` carries no ``__builtins__`` beyond that list -- plus ``__import__``, which the vetted code
+  cannot name (dunder names are rejected above) but NumPy's C code looks up in the CALLING frame's builtins the first time it lazily
+  imports one of its own helper modules (``PyImport_Import``): without it the first array operation of a process that happens inside
+  the extracted code dies with ``KeyError: '__import__'`` (seen when a live test ran on its own, round 5).
 """
 from __future__ import annotations
 
@@ -31,6 +34,11 @@ _SAFE_BUILTINS = {"int": int, "float": float, "abs": abs, "min": min, "max": max
 _ROOTS = {"self", "cp", "xp", "np"}
 METHODS = ("clear_overlap_map", "update_variance", "update_time", "move", "move_to", "pad_value", "shift_map_xy", "shift_map_z",
            "shift_translation_to_map_center")
+
+
+def exec_builtins(**extra):
+    """builtins of the namespaces the vetted reference code runs in (see the module docstring for why ``__import__`` is there)"""
+    return dict(_SAFE_BUILTINS, __import__=__import__, **extra)
 
 
 def available():
@@ -89,7 +97,7 @@ def _namespace():
     xp = types.ModuleType("numpy_as_cupy")
     xp.__dict__.update(np.__dict__)
     xp.asnumpy = lambda a: np.asarray(a)          # cupy-only helper used by get_position
-    return {"cp": xp, "xp": xp, "np": np, "__builtins__": dict(_SAFE_BUILTINS)}
+    return {"cp": xp, "xp": xp, "np": np, "__builtins__": exec_builtins()}
 
 
 def load():

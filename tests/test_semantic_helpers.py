@@ -63,7 +63,7 @@ def test_helpers_against_the_reference_statements():
     names = ("pad_value", "get_layer_indices", "decode_max", "process_map_for_publish")
     fns = {n.name: n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in names}
     ns = ref_host._namespace()
-    ns["__builtins__"] = dict(ns["__builtins__"], enumerate=enumerate)
+    ns["__builtins__"] = ref_host.exec_builtins(enumerate=enumerate)
     for n in names:
         ref_host._vet(fns[n], n, extra_builtins=("enumerate",))
     exec(compile(ast.Module(body=[fns[n] for n in names], type_ignores=[]), path, "exec"), ns)
