@@ -101,3 +101,23 @@ def test_the_ctypes_stub_of_integration_md_matches_the_header_and_the_binding():
     stub = re.findall(r'"(\w+)"', t[t.index("class emap_params(ct.Structure)"):t.index("ctx = ct.c_void_p()")])
     assert stub == header
     assert [f[0] for f in _lib.EmapParams._fields_] == header
+
+
+def test_the_header_is_plain_c():
+    """the drop-in boundary is a C ABI: include/emap_hip.h must compile as C99 (and as C++11) on its own, warnings as errors, and a C
+    program that only includes it must link against the library"""
+    import subprocess
+    import tempfile
+    hdr = os.path.join(ROOT, "include", "emap_hip.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
+    from elevation_mapping_cupy_amd import _lib
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "t.c")
+        open(src, "w").write('#include "emap_hip.h"\n#include <stdio.h>\nint main(void) { printf("%d\\n", emap_abi_version()); return emap_destroy(0); }\n')
+        exe = os.path.join(td, "t")
+        libdir = os.path.dirname(_lib.LIB_PATH)
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH),
+                               "-Wl,-rpath," + libdir])
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0 and out.stdout.strip() == str(_lib.ABI_VERSION), (out.returncode, out.stdout, out.stderr[-500:])
