@@ -131,7 +131,7 @@ void telea(Img& I, int range, Heap& H) {
 }  // namespace
 
 extern "C" int emap_inpaint_telea_u8(const uint8_t* image, const uint8_t* mask, int32_t rows, int32_t cols, int32_t radius, uint8_t* out) {
-  if (!image || !mask || !out || rows < 1 || cols < 1 || (int64_t)rows * cols > (int64_t)1 << 30) return EMAP_ERR_INVALID;
+  if (!image || !mask || !out || rows < 2 || cols < 2 || (int64_t)rows * cols > (int64_t)1 << 30) return EMAP_ERR_INVALID;      // (one row / one column: the clamped neighbours of the gradient term would leave the image)
   int range = radius < 1 ? 1 : (radius > 100 ? 100 : radius);
   Img I; I.R = rows + 2; I.C = cols + 2;
   const size_t n = (size_t)I.R * I.C;

@@ -238,9 +238,8 @@ int emap_inpaint_u8(emap_ctx* ctx, const float* host_image, const float* host_kn
 /* Inpainting plugin, method "telea" (EM/plugins/inpainting.py:59: cv2.inpaint(h, mask, 1, cv2.INPAINT_TELEA) on the host): Telea's
  * fast-marching fill of the pixels with mask != 0 in an 8-bit image, HOST arrays in and out, no context needed -- a serial
  * priority-queue algorithm that the reference also runs on the CPU.  A restatement of the published algorithm (OpenCV is absent
- * offline: parity with its values is not pinned).  Precondition: rows >= 2 and cols >= 2 -- the clamped neighbour rows / columns of
- * the image-gradient term leave a one-row or one-column image (found by an AddressSanitizer sweep at the end of round 5, DESIGN.md
- * section 8; emap_inpaint_ns_u8 rejects such shapes, this entry point does not yet; a map has at least 3 x 3 cells). */
+ * offline: parity with its values is not pinned).  Images of fewer than 2 x 2 pixels are rejected (EMAP_ERR_INVALID), as by
+ * emap_inpaint_ns_u8: the clamped neighbour rows / columns of the image-gradient term need two of each. */
 int emap_inpaint_telea_u8(const uint8_t* image, const uint8_t* mask, int32_t rows, int32_t cols, int32_t radius, uint8_t* out);
 /* Inpainting plugin, method "ns" (EM/plugins/inpainting.py:33-38,59: cv2.inpaint(h, mask, 1, cv2.INPAINT_NS) on the host): the
    Navier-Stokes based fill in its fast-marching form -- same march as above, a pixel = mean of the known pixels within `radius`

@@ -52,6 +52,10 @@ def test_properties():
     assert err.max() <= 12 and err.mean() <= 5                               # radius 1 and a unit-length gradient term: a ramp of 32 levels across the hole comes back within a third
     assert np.array_equal(_c(img, np.zeros_like(mask)), img)                # nothing to fill
     assert _lib.load().emap_inpaint_telea_u8(None, None, 4, 4, 1, None) != 0
+    lib = _lib.load()                                                       # one row / one column: rejected (the gradient term's neighbours would leave the image)
+    for shape in ((1, 9), (9, 1), (1, 1)):
+        a, m1, o = np.full(shape, 7, np.uint8), np.ones(shape, np.uint8), np.zeros(shape, np.uint8)
+        assert lib.emap_inpaint_telea_u8(a.ctypes.data_as(ct.POINTER(ct.c_uint8)), m1.ctypes.data_as(ct.POINTER(ct.c_uint8)), shape[0], shape[1], 1, o.ctypes.data_as(ct.POINTER(ct.c_uint8))) != 0
 
 
 def test_plugin_routes_methods():
