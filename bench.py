@@ -47,6 +47,20 @@ def source_stamp():
     return h.hexdigest()[:16]
 
 
+def sem_in_frame(lib):
+    """True when the multi-modal frames of this run declare their RGB / semantic fusion for the frame (emap_frame_semantics, round 6:
+    fused inside emap_update's tile pass); False with an older library handed in for an A/B run (EMAP_HIP_LIB) or
+    EMAP_BENCH_SEM_SEPARATE=1: the separate emap_semantic_update call behind every frame, as until round 5"""
+    return hasattr(lib, "emap_frame_semantics") and os.environ.get("EMAP_BENCH_SEM_SEPARATE", "0") != "1"
+
+
+def mm_frame(lib, ctx, Rp, tp, spec, stats=None):
+    """one multi-modal frame on the bound cloud: heights + RGB / semantic layers (returns the first non-zero status)"""
+    if sem_in_frame(lib):
+        return lib.emap_frame_semantics(ctx, ct.byref(spec), 0) or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
+    return lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats) or lib.emap_semantic_update(ctx, Rp, tp, ct.byref(spec))
+
+
 def rocprof_kernel_us(workload, kernel_prefix):
     """median duration (us) of a kernel in profiles/<round>_<workload>_kernel_stats.txt -- None when the file is missing or was taken
     with other kernel sources (its '# source_stamp:' line)"""
@@ -466,9 +480,10 @@ def run_single(a, local_rank=0):
 
         def frame(i, stats=None):
             rc = bind_cloud(lib, ctx, cl_dev[i % len(cl_dev)], n_pts)
-            rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
             if multimodal:
-                rc = rc or lib.emap_semantic_update(ctx, Rp, tp, ct.byref(spec))
+                rc = rc or mm_frame(lib, ctx, Rp, tp, spec, stats)
+            else:
+                rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
             if rc:
                 raise RuntimeError(lib.emap_last_error(ctx).decode())
         return frame
@@ -630,9 +645,10 @@ def run_single(a, local_rank=0):
 
             def frb(i, stats=None, lb=lb, cb=cb, devb=devb, Nb=Nb, mm=mm, specb=specb):
                 rc = bind_cloud(lb, cb, devb[i % len(devb)], Nb)
-                rc = rc or lb.emap_update(cb, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
                 if mm:
-                    rc = rc or lb.emap_semantic_update(cb, Rp, tp, ct.byref(specb))
+                    rc = rc or mm_frame(lb, cb, Rp, tp, specb, stats)
+                else:
+                    rc = rc or lb.emap_update(cb, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
                 if rc:
                     raise RuntimeError(lb.emap_last_error(cb).decode())
             warm(emb, frb)
@@ -640,7 +656,8 @@ def run_single(a, local_rank=0):
             wallb, msb, loopsb = timed(emb, frb, kb, loops=3)
             latb = latencies(emb, frb, 10)
             stb, visb = stage_profile(lb, cb, frb, 6, with_stats=not mm)
-            if mm:       # the 11th stage: the RGB / semantic fusion (k_tile_semantic) -- a call of its own behind emap_update, timed by an event pair
+            sem_stage_ms = 0.0          # (fused inside the frame's tile pass: part of "fuse")
+            if mm and not sem_in_frame(lb):       # the 11th stage: the RGB / semantic fusion (k_tile_semantic) -- a call of its own behind emap_update, timed by an event pair
                 acc_s, e_ms = 0.0, ct.c_float(0)
                 for i_ in range(6):
                     rc = bind_cloud(lb, cb, devb[i_ % len(devb)], Nb) or lb.emap_update(cb, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), None)
@@ -759,9 +776,10 @@ def single_frame_ms(a, wl, hip, dev, C, N, frames=6, loops=3):
 
     def fr(i):
         rc = bind_cloud(lib, ctx, devc[i % len(devc)], N)
-        rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), None)
         if mm:
-            rc = rc or lib.emap_semantic_update(ctx, Rp, tp, ct.byref(spec))
+            rc = rc or mm_frame(lib, ctx, Rp, tp, spec)
+        else:
+            rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), None)
         if rc:
             raise RuntimeError(lib.emap_last_error(ctx).decode())
     for i in range(3):
@@ -889,10 +907,14 @@ def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag
         rc = bind_cloud(lib, ctx, clouds_dev[i % NCLOUD], n_local[i % NCLOUD])
         if bucket:
             rc = rc or lib.emap_declare_points_bucketed(ctx, Rp, tp, ct.c_int64(N))
+        in_frame = multimodal and sem_in_frame(lib)
+        if in_frame and not rc:         # the strip's RGB / semantic fusion rides inside the frame (emap_frame_semantics)
+            emap.semantic_map.declare_frame(emap, channels)
         rc = rc or lib.emap_update_sharded(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
         if rc:
             raise RuntimeError(lib.emap_last_error(ctx).decode())
-        if multimodal:                  # per strip, no exchange step: part of the frame (and of the timed region)
+        sem_ms.value = 0.0
+        if multimodal and not in_frame:  # per strip, no exchange step: part of the frame (and of the timed region)
             if time_sem:
                 lib.emap_timer_begin(ctx)
             emap.semantic_map.update_layers_pointcloud(emap, channels, R, t)

@@ -59,7 +59,7 @@ SYMBOLS = [
     "emap_set_drift_inputs", "emap_drift_sums_to_device", "emap_set_drift_inputs_device",
     "emap_local_drift_sums", "emap_set_scatter_mode", "emap_fuse", "emap_fuse_average", "emap_commit", "emap_rays", "emap_average", "emap_overlap_clear",
     "emap_dilate", "emap_traversability_normals", "emap_post", "emap_post_part", "emap_update_variance", "emap_update_time", "emap_get_stats",
-    "emap_get_layer", "emap_set_layer", "emap_publish_layer", "emap_shift", "emap_strip_logical_begin", "emap_semantic_configure", "emap_semantic_update",
+    "emap_get_layer", "emap_set_layer", "emap_publish_layer", "emap_shift", "emap_strip_logical_begin", "emap_semantic_configure", "emap_semantic_update", "emap_frame_semantics",
     "emap_semantic_get_layer", "emap_semantic_set_layer", "emap_semantic_clear", "emap_semantic_get_alpha", "emap_semantic_set_alpha", "emap_semantic_class_max", "emap_semantic_accumulate", "emap_semantic_finalize", "emap_min_filter", "emap_max_filter", "emap_smooth_filter", "emap_erode", "emap_inpaint_u8", "emap_inpaint_telea_u8", "emap_inpaint_ns_u8", "emap_image_correspondence", "emap_image_get_correspondence",
     "emap_image_fuse", "emap_image_set_tolerance", "emap_image_fuse_arrays", "emap_polygon_mask", "emap_dilate_planes", "emap_halo_bytes", "emap_halo_pack", "emap_halo_unpack", "emap_normal_row_lag", "emap_normal_halo_pack", "emap_normal_halo_unpack", "emap_normal_lag_plan",
     "emap_comm_unique_id", "emap_comm_init", "emap_comm_destroy", "emap_comm_selftest", "emap_comm_count", "emap_comm_wire_bytes", "emap_comm_allreduce_host", "emap_comm_gather_layer", "emap_update_sharded", "emap_set_ray_mode",
@@ -67,7 +67,7 @@ SYMBOLS = [
 ]
 
 _lib = None
-ABI_VERSION = 2      # include/emap_hip.h: EMAP_ABI_VERSION (checked by load(), and across ranks by emap_comm_init)
+ABI_VERSION = 3      # include/emap_hip.h: EMAP_ABI_VERSION (checked by load(), and across ranks by emap_comm_init)
 
 
 class EmapError(RuntimeError):

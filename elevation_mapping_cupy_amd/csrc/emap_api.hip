@@ -70,14 +70,15 @@ void launch_band_clear(hipStream_t, const KP&, float*, int, long, int, int);
 // tile-binned scatter (emap_binned.hip)
 void launch_bin_hist(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, unsigned int*, BinStg*, unsigned int*);
 void launch_bin_scan(hipStream_t, const BinGeo&, unsigned int*, unsigned int*, unsigned int*, unsigned int*, const SplitView&);
-void launch_bin_scatter(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, const unsigned int*, const unsigned int*, BinRec*, const BinStg*, const unsigned int*);
-void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, ErrSlot*, const SplitView&, long);
-void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, const unsigned int*, const ChanView&, long,
+void launch_bin_scatter(hipStream_t, const KP&, const Pose&, const BinGeo&, const float*, long, int, const unsigned int*, const unsigned int*, BinRec*, const BinStg*, const unsigned int*, const ChanView&, const SemCarry&);
+void launch_tile_count(hipStream_t, const KP&, const BinGeo&, const BinRec*, int, const unsigned int*, Cells, ErrSlot*, const SplitView&, long);
+void launch_tile_semantic(hipStream_t, const KP&, const BinGeo&, const SemSpec&, const BinRec*, int, int, const unsigned int*, const ChanView&, long,
                           const unsigned int*, float*, float*, long, const SplitView&, void*, int);
 size_t sem_split_bytes(int);
 bool sem_split_possible(const SemSpec&);
 #define SEM_SPLIT_SLOTS 128      /* heavy tiles whose semantic sums several workgroups may share (19 MB of scratch) */
-void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, const unsigned int*, Cells, AccF*, FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&, const GateFold&, const SplitView&, long);
+void launch_bin_fuse(hipStream_t, const KP&, const BinGeo&, const BinRec*, int, const unsigned int*, Cells, AccF*, FrameDev*, bool, bool, unsigned int*, unsigned long long*, unsigned int*, float*, const OverlapArgs&, const GateFold&, const SplitView&, long, const SemMini*);
+bool bin_fuse_takes_semantics(const SplitView&, bool, bool, int);
 #define BIN_MAX_T 16384
 #ifndef EMAP_SPLIT_POOL_DEFAULT
 #define EMAP_SPLIT_POOL_DEFAULT 0       /* standing pool of extra tile workgroups (emap_count): off -- measured, see there */
@@ -167,7 +168,13 @@ struct emap_ctx {
   bool gate_possible;              // false inside emap_update when the host already knows that the drift gate cannot fire: the per-tile
                                    // error statistics are then skipped (they could not have any effect; err_sum / err_cnt report 0)
   BinGeo bg; BinRec* bin_recs; BinStg* bin_own; unsigned int* bin_own_cnt; long bin_own_cap; bool bin_strip;   // bin_own*: staged records of the owned points per block (strip contexts without a visibility pass)
-  unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;
+  unsigned int* bin_hist; unsigned int* bin_tile_total; unsigned int* bin_tile_start; long bin_cap; size_t bin_hist_cap;      // bin_cap: 16-byte units
+  // The semantic fusion declared for the NEXT whole frame (emap_frame_semantics): run inside the frame.  A frame that can CARRIES the
+  // channels in 32-byte sorted records (bin_rs = 2, carry: which columns) and fuses them in the tile kernel itself (fsem_merged);
+  // every other frame runs the stand-alone semantic kernels before it returns -- the result is the same either way.
+  bool fsem_set, fsem_merged; int fsem_keep_counts; SemSpec fsem;
+  bool carry_want;                 // this frame's emap_count may sort 32-byte records (decided by frame_sem_begin)
+  int bin_rs; SemCarry carry;      // stride of the current frame's sorted records in 16-byte units; the carried columns (on = 0: none)
   // semantic layers (planar float planes + double / uint32 accumulators), allocated on demand
   float* img_uv; unsigned char* img_valid; float* img_buf; size_t img_cap;   // camera path
   double img_tol; bool img_tol_set;   // tolerance_z_collision of the occlusion walk (0.10 unless emap_image_set_tolerance was called)
@@ -213,6 +220,8 @@ struct emap_ctx {
 #define CKARG(cond, msg) do { if (!(cond)) { if (ctx) ctx->err = msg; return EMAP_ERR_INVALID; } } while (0)
 
 static float q16(float x) { return (float)(_Float16)x; }
+static int frame_sem_begin(emap_ctx* ctx, bool rays_on);                               // (the frame's semantic fusion: defined next to emap_semantic_update)
+static int frame_sem_finish(emap_ctx* ctx, const float R[9], const float t[3]);
 
 static void build_kp(emap_ctx* ctx) {
   const emap_params& p = ctx->prm;
@@ -462,6 +471,7 @@ int emap_create(const emap_params* params, const emap_strip* strip, int device, 
   ctx->prm = *params;
   if (strip) ctx->strip = *strip; else { ctx->strip.row_begin = 0; ctx->strip.row_count = params->cell_n; ctx->strip.halo_rows = 0; ctx->strip.pad_ = 0; }
   ctx->device = device;
+  ctx->bin_rs = 1;
   build_kp(ctx);
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) { fprintf(stderr, "emap_create: hipSetDevice(%d): %s\n", device, hipGetErrorString(e)); delete ctx; return EMAP_ERR_HIP; }
@@ -780,6 +790,10 @@ static int ensure_bins(emap_ctx* ctx, bool raybin) {
   // host-side superset kept for two neighbouring strips must not ride in both ranks' ray-only bins)
   ctx->bin_strip = ctx->strip.row_count < ctx->prm.cell_n && (!raybin || ctx->byray_frame) && !(ctx->pts_bucketed && !raybin);
   if (const char* e = getenv("EMAP_BIN_STRIP")) { if (atoi(e) == 0) ctx->bin_strip = false; }      // test / tuning hook
+  // 32-byte records that carry the frame's semantic channels (frame_sem_begin): plain point passes only (a strip's staging records
+  // hold no channels), never in front of a visibility pass (k_rays walks 16-byte records)
+  ctx->bin_rs = (ctx->carry_want && !ctx->bin_strip && !raybin) ? 2 : 1;
+  if (ctx->bin_rs == 1) ctx->carry.on = 0;
   // Blocks: ~4096 points each, but every block carries a row of the (block, tile) matrix through three passes (written, scanned,
   // read): keep the matrix (4 B x TB x B, x4) below the cloud's own traffic (12 B x n, x2) -- B <= n / (3 TB) -- without dropping
   // under one block per CU.  (8192^2 / 16 M points: 2048 blocks of 16385 bins were 537 MB of matrix traffic per frame.)
@@ -828,12 +842,12 @@ static int ensure_bins(emap_ctx* ctx, bool raybin) {
     CK(hipHostGetDevicePointer((void**)&ctx->split.need_host, const_cast<unsigned int*>(ctx->split_need), 0));
     ctx->split.on = 0;
   }
-  if (n > ctx->bin_cap) {
+  if (n * ctx->bin_rs > ctx->bin_cap) {
     CK(hipStreamSynchronize(ctx->stream));
     if (ctx->bin_recs) CK(hipFree(ctx->bin_recs));
     ctx->bin_recs = nullptr; ctx->bin_cap = 0;
-    CK(hipMalloc((void**)&ctx->bin_recs, sizeof(BinRec) * n));
-    ctx->bin_cap = n;
+    CK(hipMalloc((void**)&ctx->bin_recs, sizeof(BinRec) * n * ctx->bin_rs));
+    ctx->bin_cap = n * ctx->bin_rs;
   }
   if (ctx->bin_strip && (long)g.B * chunk > ctx->bin_own_cap) {
     CK(hipStreamSynchronize(ctx->stream));
@@ -884,7 +898,8 @@ static GateArgs gate_args(emap_ctx* ctx, double position_noise, double orientati
 
 int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
   CKARG(ctx && R && t, "null argument"); NEED_POINTS();
-  if (!ctx->in_update) ctx->gate_possible = true;          // the staged API always gathers the statistics
+  if (!ctx->in_update) { ctx->gate_possible = true; ctx->carry_want = false; }          // the staged API always gathers the statistics and sorts plain 16-byte records
+  ctx->bin_rs = 1;
   CK(hipSetDevice(ctx->device));
   // small clouds: two launches with global atomics win; large clouds: counting sort by tile + LDS reduction
   // (a cloud bucketed for a strip decides by the size of the WHOLE cloud: every rank of a sharded frame then takes the same path)
@@ -930,10 +945,12 @@ int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
     ctx->split_dirty = ctx->split_dirty || (ctx->split.on != 0 && ctx->split.cap > 0);      // (slots are only used by the SPLIT instantiations: extra workgroups in the launch)
     launch_bin_scan(ctx->stream, ctx->bg, ctx->bin_hist, ctx->bin_tile_total, ctx->bin_tile_start, ctx->bin_sync, ctx->split);
     if (tm) CK(hipEventRecord(ctx->ev[ST_SCATTER], ctx->stream));
-    launch_bin_scatter(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, ctx->bin_tile_start, ctx->bin_recs, own, ctx->bin_own_cnt);
+    launch_bin_scatter(ctx->stream, ctx->kp, pose, ctx->bg, ctx->pts, ctx->n_pts, ctx->stride, ctx->bin_hist, ctx->bin_tile_start, ctx->bin_recs, own, ctx->bin_own_cnt,
+                       ctx->chan, ctx->carry);
     if (tm) CK(hipEventRecord(ctx->ev[ST_GATE], ctx->stream));        // the "gate" stage = per-tile error sums + k_gate
-    if (ctx->gate_possible) launch_tile_count(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->slots, ctx->split, ctx->n_pts);
+    if (ctx->gate_possible) launch_tile_count(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_rs, ctx->bin_tile_start, ctx->cells, ctx->slots, ctx->split, ctx->n_pts);
   } else {
+    ctx->carry.on = 0;
     if (ctx->stage_timing && ctx->in_update)
       for (int e = ST_HIST; e <= ST_SCATTER; ++e) CK(hipEventRecord(ctx->ev[e], ctx->stream));
     // whole frames (emap_update) on this path: the drift gate rides in k_count's last workgroup, one launch less in a chain of six
@@ -1006,8 +1023,21 @@ static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool fus
     if (fuse_average && rays && ((ctx->kp.org_c | ctx->prm.cell_n) & 63) != 0 && !ctx->inert_zero)     // unaligned columns: the tile kernel ORs its ballots into the logical bitmap
       CK(hipMemsetAsync(ctx->inert, 0, sizeof(unsigned long long) * ((size_t)ctx->strip.row_count * ((ctx->prm.cell_n + 63) / 64)), ctx->stream));
     if (fuse_average && rays) ctx->inert_zero = false;
-    launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame, fuse_average, rays,
-                    ctx->cnt_plane, ctx->inert, ctx->inl_plane, ctx->ray_thr, ctx->ov_args, ctx->gate_fold, ctx->split, ctx->n_pts);
+    // a carrying frame fuses its semantic channels inside the tile kernel (emap_binned.hip: k_tile_fuse<.., SEM>) unless the launch
+    // holds heavy-tile parts: then the stand-alone kernel follows (frame_sem_finish), reading the channels from the records all the same
+    SemMini sm; memset(&sm, 0, sizeof sm);
+    const bool merged = ctx->fsem_set && ctx->carry.on && bin_fuse_takes_semantics(ctx->split, fuse_average, rays, ctx->bin_rs);
+    if (merged) {
+      const SemSpec& S = ctx->fsem;
+      sm.n_sum = S.n_sum; sm.n_col = S.n_col; sm.alpha = S.alpha; sm.sem = ctx->sem; sm.plane = ctx->ncells_alloc;
+      for (int q = 0; q < S.n_sum; ++q) { sm.slot[q] = S.sum_chan[q] - ctx->carry.c0; sm.layer[q] = S.sum_layer[q]; sm.kind[q] = S.sum_kind[q]; }
+      if (S.n_col) { sm.col_slot = S.col_chan[0] - ctx->carry.c0; sm.col_layer = S.col_layer[0]; }
+    }
+    ctx->fsem_merged = merged;
+    if (ctx->fsem_set) ctx->update_path |= merged ? 4 : (ctx->carry.on ? 8 : 0);      // (emap_last_update_path)
+    launch_bin_fuse(ctx->stream, ctx->kp, ctx->bg, ctx->bin_recs, ctx->bin_rs, ctx->bin_tile_start, ctx->cells, ctx->acc, ctx->frame, fuse_average, rays,
+                    (merged && !ctx->fsem_keep_counts) ? nullptr : ctx->cnt_plane, ctx->inert, ctx->inl_plane, ctx->ray_thr, ctx->ov_args, ctx->gate_fold, ctx->split, ctx->n_pts,
+                    merged ? &sm : nullptr);
     if (ctx->split.on) ctx->split_dirty = false;        // k_tile_fuse's parts cleared their slots (a frame that splits nothing leaves an older count stage's slots as they are)
     ctx->gate_fold.mode = 0;
     if (fuse_average) ctx->kp.mv.n = 0;   // every owned cell rewritten: pending map shifts are in memory now
@@ -1165,7 +1195,13 @@ int emap_get_stats(emap_ctx* ctx, emap_stats* out) {
   return EMAP_OK;
 }
 
+static int update_impl(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats);
 int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats) {
+  const int rc = update_impl(ctx, R, t, position_noise, orientation_noise, stats);
+  if (ctx) { ctx->fsem_set = false; ctx->carry_want = false; }      // the declared semantic fusion belongs to ONE frame, whatever became of it
+  return rc;
+}
+static int update_impl(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats) {
   CKARG(ctx && R && t, "null argument"); NEED_POINTS();
   CK(hipSetDevice(ctx->device));
   const emap_params& p = ctx->prm;
@@ -1178,6 +1214,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
     return EMAP_ERR_HIP;
   }
   const bool rays_on = p.enable_visibility_cleanup != 0;
+  if ((rc = frame_sem_begin(ctx, rays_on))) return rc;
   // clear_overlap_map rides on the kernel that rewrites the cells last (tile kernel / k_average, or k_ray_apply after a visibility pass)
   ctx->ov_args = overlap_args(ctx, t[2], p.enable_overlap_clearance != 0);
   const bool ov_folded = ctx->ov_args.on != 0;
@@ -1232,6 +1269,7 @@ int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double positi
   else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame, ctx->split.need_host ? ctx->split.need_host + 1 : nullptr, ctx->ray_par ^= 1); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
+  if ((rc = frame_sem_finish(ctx, R, t))) return rc;      // semantic_map.update_layers_pointcloud (elevation_mapping.py:368) -- unless the tile kernel fused the channels itself
   STAGE(ST_OVERLAP);
   if (p.enable_overlap_clearance && !ov_folded && (rc = emap_overlap_clear(ctx, t[2]))) return rc;
   STAGE(ST_POST);
@@ -1363,16 +1401,15 @@ static int ensure_alpha(emap_ctx* ctx) {
   return EMAP_OK;
 }
 
-int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], const emap_sem_spec* spec) {
-  CKARG(ctx && R && t && spec, "null argument"); NEED_POINTS();
+// emap_sem_spec -> SemSpec, checked against the bound cloud and the configured layers
+static int sem_spec_checked(emap_ctx* ctx, const emap_sem_spec* spec, SemSpec* out) {
   CKARG(spec->n_sum >= 0 && spec->n_sum <= SEM_MAX_CH && spec->n_col >= 0 && spec->n_col <= 4, "too many channels");
   CKARG(ctx->cnt_plane, "emap_semantic_configure must be called before the frame (the average pass records the counts)");
   for (int k = 0; k < spec->n_sum; ++k)
     CKARG(spec->sum_layer[k] >= 0 && spec->sum_layer[k] < ctx->sem_layers && spec->sum_chan[k] >= 3 && spec->sum_chan[k] < ctx->n_cols, "bad channel/layer index");
   for (int k = 0; k < spec->n_col; ++k)
     CKARG(spec->col_layer[k] >= 0 && spec->col_layer[k] < ctx->sem_layers && spec->col_chan[k] >= 3 && spec->col_chan[k] < ctx->n_cols, "bad colour channel/layer index");
-  CK(hipSetDevice(ctx->device));
-  SemSpec S; memset(&S, 0, sizeof S); memcpy(&S, spec, sizeof *spec);
+  SemSpec& S = *out; memset(&S, 0, sizeof S); memcpy(&S, spec, sizeof *spec);
   int nk[4] = {0, 0, 0, 0};
   for (int k = 0; k < S.n_sum; ++k) { CKARG(S.sum_kind[k] >= 0 && S.sum_kind[k] <= 3, "bad fusion kind"); nk[S.sum_kind[k]]++; }
   int seen[4] = {0, 0, 0, 0};
@@ -1385,6 +1422,61 @@ int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], cons
   // class_bayesian / bayesian_inference reproduce the reference's launch decode (element exists while id * K + q < N): the GLOBAL point
   // index and cloud size -- a cloud bucketed for a strip renumbers its points
   CKARG(!(ctx->pts_bucketed && (nk[2] + nk[3]) > 0), "a bucketed cloud (emap_upload_points_strip) cannot feed class_bayesian / bayesian_inference fusions: they decode the global point index");
+  return EMAP_OK;
+}
+static int semantic_update_impl(emap_ctx* ctx, const float R[9], const float t[3], const SemSpec& S);
+
+int emap_frame_semantics(emap_ctx* ctx, const emap_sem_spec* spec_or_null, int32_t keep_counts) {
+  CKARG(ctx, "null ctx");
+  ctx->fsem_set = false; ctx->fsem_keep_counts = keep_counts != 0;
+  if (!spec_or_null || spec_or_null->n_sum + spec_or_null->n_col == 0) return EMAP_OK;
+  CKARG(spec_or_null->n_sum >= 0 && spec_or_null->n_sum <= SEM_MAX_CH && spec_or_null->n_col >= 0 && spec_or_null->n_col <= 4, "too many channels");
+  memset(&ctx->fsem, 0, sizeof ctx->fsem); memcpy(&ctx->fsem, spec_or_null, sizeof *spec_or_null);      // (checked against the cloud bound when the frame starts)
+  ctx->fsem_set = true;
+  return EMAP_OK;
+}
+// Start of a whole frame: check the declared fusion against the bound cloud and decide whether the frame's sort may CARRY the channels
+// (32-byte records): kinds average / class_average and at most one colour channel, at most four channel columns, all within four
+// consecutive columns of the cloud; no visibility pass (k_rays walks 16-byte records).  emap_count then settles it (tile-binned
+// path, plain point passes: ensure_bins).  EMAP_SEM_CARRY=0: never (A/B and test hook).
+static int frame_sem_begin(emap_ctx* ctx, bool rays_on) {
+  ctx->carry_want = false; ctx->fsem_merged = false; memset(&ctx->carry, 0, sizeof ctx->carry);
+  if (!ctx->fsem_set) return EMAP_OK;
+  emap_sem_spec raw; memcpy(&raw, &ctx->fsem, sizeof raw);
+  SemSpec S;
+  int rc = sem_spec_checked(ctx, &raw, &S);
+  if (rc) { ctx->fsem_set = false; return rc; }
+  ctx->fsem = S;
+  if (S.any_bayes && (rc = ensure_alpha(ctx))) { ctx->fsem_set = false; return rc; }
+  static const bool off = getenv("EMAP_SEM_CARRY") && atoi(getenv("EMAP_SEM_CARRY")) == 0;
+  if (off || rays_on || S.n_sum > 4 || S.n_col > 1 || S.n_sum + S.n_col == 0) return EMAP_OK;
+  int cmin = 1 << 30, cmax = -1;
+  for (int k = 0; k < S.n_sum; ++k) { if (S.sum_kind[k] > 1) return EMAP_OK; cmin = std::min(cmin, S.sum_chan[k]); cmax = std::max(cmax, S.sum_chan[k]); }
+  for (int k = 0; k < S.n_col; ++k) { cmin = std::min(cmin, S.col_chan[k]); cmax = std::max(cmax, S.col_chan[k]); }
+  if (cmax - cmin >= 4) return EMAP_OK;
+  ctx->carry_want = true;
+  ctx->carry.c0 = cmin; ctx->carry.ncols = ctx->n_cols;
+  // the de-interleaved (N, 4) channel matrix of an uploaded cloud: one aligned 16-byte load per point
+  ctx->carry.on = (ctx->chan.stride == 4 && ctx->chan.col0 == cmin && ((uintptr_t)ctx->chan.p & 15) == 0) ? 2 : 1;
+  return EMAP_OK;
+}
+// End of the frame's fusion stages: whatever the tile kernel did not fuse itself runs now (the frame's counts are in cnt_plane)
+static int frame_sem_finish(emap_ctx* ctx, const float R[9], const float t[3]) {
+  if (!ctx->fsem_set) return EMAP_OK;
+  ctx->fsem_set = false; ctx->carry_want = false;
+  if (ctx->fsem_merged) { ctx->fsem_merged = false; return EMAP_OK; }
+  return semantic_update_impl(ctx, R, t, ctx->fsem);
+}
+
+int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], const emap_sem_spec* spec) {
+  CKARG(ctx && R && t && spec, "null argument"); NEED_POINTS();
+  SemSpec S;
+  int rc = sem_spec_checked(ctx, spec, &S);
+  if (rc) return rc;
+  return semantic_update_impl(ctx, R, t, S);
+}
+static int semantic_update_impl(emap_ctx* ctx, const float R[9], const float t[3], const SemSpec& S) {
+  CK(hipSetDevice(ctx->device));
   if (S.any_bayes) { int rc = ensure_alpha(ctx); if (rc) return rc; }
   if (ctx->frame_binned) {   // the frame's tile-sorted records are still valid: reduce in LDS, no global atomics
     if (ctx->split.on && ctx->split.cap > 0 && !ctx->sem_split_mem && sem_split_possible(S)) {      // the frame listed heavy tiles: their semantic sums are shared too
@@ -1393,7 +1485,7 @@ int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], cons
       if (hipMemsetAsync(m, 0, sem_split_bytes(SEM_SPLIT_SLOTS), ctx->stream) != hipSuccess) { hipFree(m); ctx->err = "hipMemsetAsync(semantic split scratch)"; return EMAP_ERR_HIP; }
       ctx->sem_split_mem = m;
     }
-    launch_tile_semantic(ctx->stream, ctx->kp, ctx->bg, S, ctx->bin_recs, ctx->bin_tile_start, ctx->chan, ctx->n_pts,
+    launch_tile_semantic(ctx->stream, ctx->kp, ctx->bg, S, ctx->bin_recs, ctx->bin_rs, ctx->carry.on ? ctx->carry.c0 : -1, ctx->bin_tile_start, ctx->chan, ctx->n_pts,
                          ctx->cnt_plane, ctx->sem, ctx->sem_alpha, ctx->ncells_alloc, ctx->split, ctx->sem_split_mem, SEM_SPLIT_SLOTS);
     CK(hipGetLastError());
     return EMAP_OK;
@@ -2205,7 +2297,13 @@ static int rays_by_ray_pass(emap_ctx* ctx, const float R[9], const float t[3]) {
 
 // One frame of the strip: the stage order of ShardedElevationMap.update (sharded.py) with both exchange steps issued from
 // here -- no Python, no host synchronisation between the stages.
+static int update_sharded_impl(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats);
 int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats) {
+  const int rc = update_sharded_impl(ctx, R, t, position_noise, orientation_noise, stats);
+  if (ctx) { ctx->fsem_set = false; ctx->carry_want = false; ctx->in_update = false; }
+  return rc;
+}
+static int update_sharded_impl(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats) {
   CKARG(ctx && R && t, "null argument"); NEED_POINTS();
   CKARG(ctx->rccl && ctx->comm, "emap_comm_init has not been called");
   CK(hipSetDevice(ctx->device));
@@ -2214,6 +2312,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   const bool tm = ctx->stage_timing;
   int rc;
 #define STAGE(i) do { if (tm) CK(hipEventRecord(ctx->ev[i], ctx->stream)); } while (0)
+  if ((rc = frame_sem_begin(ctx, p.enable_visibility_cleanup != 0))) return rc;
   ctx->in_update = true;
   ctx->gate_possible = p.enable_drift_compensation && (position_noise > p.position_noise_thresh || orientation_noise > p.orientation_noise_thresh);
   ctx->byray_frame = rays_by_ray(ctx);        // (before the sort: a by-ray frame sorts only the points of the strip's rows)
@@ -2228,6 +2327,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   ctx->in_update = false;
   if (rc) { ctx->byray_frame = false; return rc; }          // "gate" (recorded by emap_count) = per-tile error sums + local sums + all-reduce + gate
   if (ctx->byray_frame && !ctx->frame_binned) { ctx->byray_frame = false; ctx->err = "rays by ray: this rank could not take the tile-binned path the other ranks take"; return EMAP_ERR_INVALID; }
+  ctx->update_path = ctx->frame_binned ? 1 : 0;
   ctx->use_override = false;
   if ((rc = gate_impl(ctx, 0.0, 0.0, 1, ctx->comm_sums, nullptr))) return rc;                       // local sums -> device
   CKN(a->AllReduce(ctx->comm_sums, ctx->comm_sums + 2, 2, ncclFloat64, ncclSum, ctx->comm, ctx->stream));   // exchange step 1
@@ -2260,6 +2360,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame, ctx->split.need_host ? ctx->split.need_host + 1 : nullptr, ctx->ray_par ^= 1); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
+  if ((rc = frame_sem_finish(ctx, R, t))) return rc;      // (as in emap_update)
   STAGE(ST_OVERLAP);
   if (p.enable_overlap_clearance && !ov_folded && (rc = emap_overlap_clear(ctx, t[2]))) return rc;
   STAGE(ST_POST);                             // "post" = halo exchange + stencils

@@ -246,11 +246,23 @@ __global__ __launch_bounds__(SCAN_BLK) void k_bin_scan(BinGeo G, unsigned int* _
 #ifndef SCATTER_U
 #define SCATTER_U 4
 #endif
-template <int MODE, int BLK, bool STRIP>
+// the four carried channel columns of point i (SemCarry, emap_device.h): one aligned 16-byte load when the channel matrix is the
+// de-interleaved (N, 4) one (on == 2), else column by column (columns past the row read as 0)
+__device__ __forceinline__ float4 load_carry(const ChanView& V, const SemCarry& SC, long i) {
+  if (SC.on == 2) return reinterpret_cast<const float4*>(V.p)[i];
+  const float* __restrict__ row = chan_row(V, i);
+  float4 r;
+  r.x = SC.c0 < SC.ncols ? row[SC.c0] : 0.f; r.y = SC.c0 + 1 < SC.ncols ? row[SC.c0 + 1] : 0.f;
+  r.z = SC.c0 + 2 < SC.ncols ? row[SC.c0 + 2] : 0.f; r.w = SC.c0 + 3 < SC.ncols ? row[SC.c0 + 3] : 0.f;
+  return r;
+}
+// CH: the frame carries its semantic channels -- 32-byte records (BinRec32), the channel row read coalesced next to the point
+template <int MODE, int BLK, bool STRIP, bool CH>
 __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, Pose T, BinGeo G, const float* __restrict__ pts, long n, int stride,
                                                      const unsigned int* __restrict__ hist, const unsigned int* __restrict__ tile_start,
                                                      BinRec* __restrict__ recs, const BinStg* __restrict__ stg,
-                                                     const unsigned int* __restrict__ stg_cnt) {
+                                                     const unsigned int* __restrict__ stg_cnt, ChanView V, SemCarry SC) {
+  static_assert(!(STRIP && CH), "a strip's staged records carry no channels");
   extern __shared__ unsigned int cur[];
   const unsigned int* row = hist + (long)blockIdx.x * G.pitch;
   for (int t = threadIdx.x; t < G.TB; t += BLK) cur[t] = tile_start[t] + row[t];
@@ -263,11 +275,13 @@ __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, Pose T, BinGeo G, con
   if (!STRIP) {
     for (long k0 = threadIdx.x; k0 < G.chunk; k0 += (long)U * BLK) {      // geometry once more, LDS cursor -> sorted position; no map access
       float rx[U], ry[U], rz[U];
+      float4 ch[CH ? U : 1];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long i = base + k0 + (long)u * BLK;
         rx[u] = ry[u] = rz[u] = NAN;                          // (a NaN row: no bin)
-        if (k0 + (long)u * BLK < G.chunk && i < n) load_point(pts, i, stride, rx[u], ry[u], rz[u]);
+        if (CH) ch[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 + (long)u * BLK < G.chunk && i < n) { load_point(pts, i, stride, rx[u], ry[u], rz[u]); if (CH) ch[u] = load_carry(V, SC, i); }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -277,8 +291,16 @@ __global__ __launch_bounds__(BLK) void k_bin_scatter(KP P, Pose T, BinGeo G, con
         const int bin = bin_of(P, G, g, lc);
         if (bin < 0) continue;
         const unsigned int pos = atomicAdd(&cur[bin], 1u);
-        BinRec o; o.lc_inl = lc; o.z = g.z; o.v = g.v; o.i = (unsigned int)i;
-        recs[pos] = o;
+        if (CH) {
+          // both halves of one 32-byte sector.  (What a random store costs on this part is the 16-byte lane store, not the instruction or
+          // the line it lands in: a lane PAIR writing each record -- even lane the head, odd lane the channels, 32 sectors per store
+          // instruction instead of 64 -- left the pass at 466 us for 16 M points, round 6; the 16-byte records of a plain frame: 258.)
+          BinRec32 o; o.lc_inl = lc; o.z = g.z; o.v = g.v; o.i = (unsigned int)i; o.c[0] = ch[u].x; o.c[1] = ch[u].y; o.c[2] = ch[u].z; o.c[3] = ch[u].w;
+          reinterpret_cast<BinRec32*>(recs)[pos] = o;
+        } else {
+          BinRec o; o.lc_inl = lc; o.z = g.z; o.v = g.v; o.i = (unsigned int)i;
+          recs[pos] = o;
+        }
       }
     }
   } else {
@@ -387,7 +409,8 @@ __device__ __forceinline__ void stage_hot_tile(const KP& P, Cells cells, float4*
 // Error sums of the drift compensation, per tile: the tile's cells are staged ONCE, coalesced, in LDS and every sorted record of
 // the tile is tested against its cell there -- the per-point gather of a random 32-byte cell (a whole 128-byte line per point,
 // 144 MB fetched for 48 MB needed, profiles/r01f_pmc_cfg2.json) is gone.  Wave-reduced sums go to the 256 padded slots.
-template <bool SPLIT>
+// RS: stride of the sorted records in 16-byte units (2: BinRec32 of a frame that carries its channels; only the leading 16 bytes are read here)
+template <bool SPLIT, int RS>
 __device__ __forceinline__ void tile_count_body(const KP& P, const BinGeo& G, const BinRec* __restrict__ recs, Cells cells,
                                                 ErrSlot* __restrict__ slots, const SplitView& SV, const TileWork& w) {
   constexpr int NC = BIN_TR * BIN_TC;
@@ -407,7 +430,7 @@ __device__ __forceinline__ void tile_count_body(const KP& P, const BinGeo& G, co
   BinRec rr[U];
 #if TILE_PREFETCH
 #pragma unroll
-  for (int u = 0; u < U; ++u) { const unsigned int k = r0 + u * TF_BLOCK + threadIdx.x; if (k < r1) rr[u] = recs[k]; }
+  for (int u = 0; u < U; ++u) { const unsigned int k = r0 + u * TF_BLOCK + threadIdx.x; if (k < r1) rr[u] = recs[(size_t)k * RS]; }
 #endif
   stage_hot_tile(P, cells, s_cell, row_base, tx);
   if (split) { s_pts[threadIdx.x] = 0u; s_inl[threadIdx.x] = 0u; }
@@ -418,7 +441,7 @@ __device__ __forceinline__ void tile_count_body(const KP& P, const BinGeo& G, co
     if (kb != r0)
 #endif
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const unsigned int k = kb + u * TF_BLOCK + threadIdx.x; if (k < r1) rr[u] = recs[k]; }
+    for (int u = 0; u < U; ++u) { const unsigned int k = kb + u * TF_BLOCK + threadIdx.x; if (k < r1) rr[u] = recs[(size_t)k * RS]; }
     long long e_fix = 0; unsigned long long cnt = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -451,12 +474,12 @@ __device__ __forceinline__ void tile_count_body(const KP& P, const BinGeo& G, co
     if (s_inl[threadIdx.x]) atomicAdd(&SV.inl[i], s_inl[threadIdx.x]);
   }
 }
-template <bool SPLIT>
+template <bool SPLIT, int RS>
 __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const BinRec* __restrict__ recs,
                                                           const unsigned int* __restrict__ tile_start, Cells cells,
                                                           ErrSlot* __restrict__ slots, SplitView SV) {
   TileWork w;
-  if (tile_work<SPLIT>(G, SV, tile_start, w)) tile_count_body<SPLIT>(P, G, recs, cells, slots, SV, w);
+  if (tile_work<SPLIT>(G, SV, tile_start, w)) tile_count_body<SPLIT, RS>(P, G, recs, cells, slots, SV, w);
 }
 
 // AVG = true (whole frames, emap_update): the epilogue commits AND averages the tile in registers and writes the 32-byte cells
@@ -468,16 +491,28 @@ __global__ __launch_bounds__(TF_BLOCK) void k_tile_count(KP P, BinGeo G, const B
 // rays additionally need is written here too: the inert bitmap (one wave ballot = one 64-bit word per tile row) and newmap[3],
 // the per-cell drift-inlier counts (`inl_plane`, read only when a ray penetrates a cell).  The ray effects are applied afterwards
 // by k_ray_apply.  AVG = false keeps the staged contract: AccF records for k_commit / k_rays / k_average.
-template <bool AVG, bool RAYS, bool SPLIT>
+// RS: stride of the sorted records in 16-byte units (2: BinRec32, the frame carries its semantic channels).
+// SEM (round 6; AVG frames without a visibility pass and without heavy-tile parts, RS = 2): the RGB / semantic point fusion of the
+// frame (semantic_map.py:223-259; custom_semantic_kernels.py:9-51 sum, :167-194 average / class_average, :233-267 colour) runs HERE,
+// as a third pass over the tile's records after the cells have been written: the accumulators of the Kalman pass and the staged
+// cells are dead by then, their LDS holds the fp64 channel sums and the colour sums; the count the averages divide by (newmap[2],
+// accepted height points) and the colour's point count (= the points per cell of pass 1) are still in LDS -- no count plane, no
+// second kernel over the records, no gather of channel rows by point index (k_tile_semantic below stays for everything else).
+template <bool AVG, bool RAYS, bool SPLIT, int RS, bool SEM>
 __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, const BinRec* __restrict__ recs, Cells cells,
                                                AccF* __restrict__ acc, FrameDev* __restrict__ F,
                                                unsigned int* __restrict__ cnt_plane, unsigned long long* __restrict__ inert,
                                                unsigned int* __restrict__ inl_plane, float* __restrict__ thr, const OverlapArgs& O, const GateFold& GF,
-                                               const SplitView& SV, const TileWork& w) {
+                                               const SplitView& SV, const TileWork& w, const SemMini& SM) {
+  static_assert(!SEM || (AVG && !RAYS && !SPLIT && RS == 2), "the semantic pass rides on whole frames without rays / parts, on 32-byte records");
   constexpr int NC = BIN_TR * BIN_TC;
-  __shared__ unsigned int s_pts[NC], s_inl[NC], s_cnt[NC], s_out[NC];
-  __shared__ unsigned long long s_h[NC], s_v[NC], s_latest[NC];
-  __shared__ float4 s_cell[NC];            // (h, v, valid, trav) of the tile's cells, staged once (coalesced): no per-record gather
+  // one block of LDS: [pts | cnt] stay alive through the semantic pass, everything behind them is re-used by it
+  struct FuseLds { unsigned int pts[NC], cnt[NC], inl[NC], out[NC]; unsigned long long h[NC], v[NC], latest[NC]; float4 cell[NC]; };
+  static_assert(offsetof(FuseLds, cell) == offsetof(FuseLds, h) + 3 * NC * 8 && sizeof(FuseLds) == 56 * NC, "FuseLds is packed");
+  __shared__ __attribute__((aligned(16))) FuseLds L;
+  unsigned int (&s_pts)[NC] = L.pts; unsigned int (&s_inl)[NC] = L.inl; unsigned int (&s_cnt)[NC] = L.cnt; unsigned int (&s_out)[NC] = L.out;
+  unsigned long long (&s_h)[NC] = L.h; unsigned long long (&s_v)[NC] = L.v; unsigned long long (&s_latest)[NC] = L.latest;
+  float4 (&s_cell)[NC] = L.cell;            // (h, v, valid, trav) of the tile's cells, staged once (coalesced): no per-record gather
   __shared__ float s_shift;
   __shared__ bool s_final;
   const int t = w.t, sb = w.sb;
@@ -495,8 +530,9 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
     // disappears and the first one overlaps the staging
     const unsigned int k_first = r0 + threadIdx.x;
     BinRec first; first.lc_inl = 0u; first.z = 0.f; first.v = 0.f; first.i = 0u;
+    float4 first_ch = make_float4(0.f, 0.f, 0.f, 0.f);      // (SEM: the record's channels, for the third pass)
     const bool have_first = TILE_PREFETCH && !SPLIT && k_first < r1;
-    if (have_first) first = recs[k_first];
+    if (have_first) { first = recs[(size_t)k_first * RS]; if (SEM) first_ch = reinterpret_cast<const float4*>(recs)[(size_t)k_first * RS + 1]; }
     stage_hot_tile(P, cells, s_cell, row_base, tx);
     for (int k = threadIdx.x; k < NC; k += TF_BLOCK) { s_pts[k] = 0u; s_inl[k] = 0u; s_cnt[k] = 0u; s_out[k] = 0u; s_h[k] = 0ull; s_v[k] = 0ull; s_latest[k] = 0ull; }
     __syncthreads();
@@ -506,7 +542,7 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
       if (!AVG || RAYS) s_inl[threadIdx.x] = SV.inl[w.slot * SPLIT_CELLS + threadIdx.x];     // (as below: only the ray pass reads newmap[3])
     } else
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += TF_BLOCK) {          // pass 1: newmap[4] / newmap[3]
-      const BinRec r = (have_first && k == k_first) ? first : recs[k];
+      const BinRec r = (have_first && k == k_first) ? first : recs[(size_t)k * RS];
       const unsigned int lcb = r.lc_inl & 0x7fffffffu;
       if ((lcb >> 10) != sel) continue;
       atomicAdd(&s_pts[lcb & 1023u], 1u);
@@ -518,7 +554,7 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
     for (unsigned int kb = r0 + threadIdx.x; kb < r1; kb += TF_BLOCK * U) {   // pass 2: custom_kernels.py:160-197
      BinRec rr[U];
 #pragma unroll
-     for (int u = 0; u < U; ++u) if (kb + u * TF_BLOCK < r1) rr[u] = (have_first && u == 0 && kb == k_first) ? first : recs[kb + u * TF_BLOCK];
+     for (int u = 0; u < U; ++u) if (kb + u * TF_BLOCK < r1) rr[u] = (have_first && u == 0 && kb == k_first) ? first : recs[(size_t)(kb + u * TF_BLOCK) * RS];
 #pragma unroll
      for (int u = 0; u < U; ++u) {
       if (kb + u * TF_BLOCK >= r1) continue;
@@ -686,17 +722,65 @@ __device__ __forceinline__ void tile_fuse_body(const KP& P, const BinGeo& G, con
           }
         }
       }
+      if (SEM) {
+        if (r0 == r1) return;                                    // (uniform) a tile without records: no cell has a count, nothing is written
+        // the semantic view of the block behind [pts | cnt]: colour sums r, g over inl / out, four fp64 channel sums over h, v, latest
+        // and the first half of the staged cells, colour sum b over the third quarter of the staged cells
+        unsigned int* const s_cr = L.inl; unsigned int* const s_cg = L.out;
+        double* const s_sum = reinterpret_cast<double*>(L.h);                         // [4][NC]
+        unsigned int* const s_cb = reinterpret_cast<unsigned int*>(L.cell) + 2 * NC;
+        static_assert(4 * NC * sizeof(double) == 3 * NC * 8 + 2 * NC * 4, "s_sum ends where s_cb begins");
+        __syncthreads();                                          // every wave is through its epilogue: accumulators and staged cells are dead
+        const int ns = SM.n_sum;
+        for (int k = threadIdx.x; k < ns * NC; k += TF_BLOCK) s_sum[k] = 0.0;
+        if (SM.n_col) { s_cr[threadIdx.x] = 0u; s_cg[threadIdx.x] = 0u; s_cb[threadIdx.x] = 0u; }
+        __syncthreads();
+        auto pick = [](const float4& q, int j) { return j == 0 ? q.x : (j == 1 ? q.y : (j == 2 ? q.z : q.w)); };
+        for (unsigned int k = r0 + threadIdx.x; k < r1; k += TF_BLOCK) {          // pass 3: custom_semantic_kernels.py:9-51, :233-267
+          const bool pf = have_first && k == k_first;
+          const unsigned int lcb = (pf ? first.lc_inl : recs[(size_t)k * RS].lc_inl) & 0x7fffffffu;
+          if ((lcb >> 10) != sel) continue;
+          const float4 ch = pf ? first_ch : reinterpret_cast<const float4*>(recs)[(size_t)k * RS + 1];
+          const unsigned int lc = lcb & 1023u;
+          for (int q = 0; q < ns; ++q) unsafeAtomicAdd(&s_sum[q * NC + lc], (double)pick(ch, SM.slot[q]));
+          if (SM.n_col) {
+            const unsigned int color = __float_as_uint(pick(ch, SM.col_slot));
+            atomicAdd(&s_cr[lc], (color & 0xFF0000u) >> 16);
+            atomicAdd(&s_cg[lc], (color & 0xFF00u) >> 8);
+            atomicAdd(&s_cb[lc], color & 0xFFu);
+          }
+        }
+        __syncthreads();
+        if (live) {                                               // :167-194 (average / class_average), :254-267 (colour) on this thread's cell
+          const int lc = tr * BIN_TC + tc;
+          const long c = (long)(lrow + P.halo) * P.C + col;
+          const unsigned int cnt = s_cnt[lc], cn = s_pts[lc];     // accepted height points (newmap[2]); points of the cell (the colour's own count)
+          if (SM.n_col && cn) {
+            const unsigned int rr = s_cr[lc] / cn, gg = s_cg[lc] / cn, bb = s_cb[lc] / cn;
+            SM.sem[(long)SM.col_layer * SM.plane + c] = __uint_as_float((rr << 16) + (gg << 8) + bb);
+          }
+          if (cnt) for (int q = 0; q < ns; ++q) {
+            const long j = (long)SM.layer[q] * SM.plane + c;
+            const double sq = s_sum[q * NC + lc];
+            if (SM.kind[q] == 0) SM.sem[j] = (float)(sq / (double)cnt);
+            else {
+              const float prev = SM.sem[j];
+              SM.sem[j] = (prev == 0.0f) ? (float)(sq / (double)cnt) : (float)(SM.alpha * (double)prev + (1.0 - SM.alpha) * sq / (double)cnt);
+            }
+          }
+        }
+      }
     }
   }
 }
-template <bool AVG, bool RAYS, bool SPLIT>
+template <bool AVG, bool RAYS, bool SPLIT, int RS, bool SEM>
 __global__ __launch_bounds__(TF_BLOCK) void k_tile_fuse(KP P, BinGeo G, const BinRec* __restrict__ recs,
                                                          const unsigned int* __restrict__ tile_start, Cells cells,
                                                          AccF* __restrict__ acc, FrameDev* __restrict__ F,
                                                          unsigned int* __restrict__ cnt_plane, unsigned long long* __restrict__ inert,
-                                                         unsigned int* __restrict__ inl_plane, float* __restrict__ thr, OverlapArgs O, GateFold GF, SplitView SV) {
+                                                         unsigned int* __restrict__ inl_plane, float* __restrict__ thr, OverlapArgs O, GateFold GF, SplitView SV, SemMini SM) {
   TileWork w;                                     // sb = which 16 x 64 tile of the bin (sub == 1 up to 16384 tiles); for a heavy tile: a part of its records
-  if (tile_work<SPLIT>(G, SV, tile_start, w)) tile_fuse_body<AVG, RAYS, SPLIT>(P, G, recs, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF, SV, w);
+  if (tile_work<SPLIT>(G, SV, tile_start, w)) tile_fuse_body<AVG, RAYS, SPLIT, RS, SEM>(P, G, recs, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF, SV, w, SM);
 }
 
 static inline unsigned int nb(long n) { return (unsigned int)((n + EM_BLOCK - 1) / EM_BLOCK); }
@@ -736,48 +820,67 @@ void launch_bin_hist(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G,
 void launch_bin_scan(hipStream_t s, const BinGeo& G, unsigned int* hist, unsigned int* tile_total, unsigned int* tile_start, unsigned int* sync, const SplitView& SV) {
   hipLaunchKernelGGL(k_bin_scan, dim3((G.TB + SCAN_TT - 1) / SCAN_TT), dim3(SCAN_BLK), 0, s, G, hist, tile_total, tile_start, sync, SV);
 }
-template <int MODE, int BLK, bool STRIP>
+template <int MODE, int BLK, bool STRIP, bool CH>
 static void launch_bin_scatter_i(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
-                                 const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const BinStg* own, const unsigned int* own_cnt) {
+                                 const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const BinStg* own, const unsigned int* own_cnt,
+                                 const ChanView& V, const SemCarry& SC) {
   static LdsRaised raised;
-  raise_lds(k_bin_scatter<MODE, BLK, STRIP>, raised, 80 * 1024);
-  hipLaunchKernelGGL((k_bin_scatter<MODE, BLK, STRIP>), dim3(G.B), dim3(BLK), sizeof(unsigned int) * G.pitch, s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt);
+  raise_lds(k_bin_scatter<MODE, BLK, STRIP, CH>, raised, 80 * 1024);
+  hipLaunchKernelGGL((k_bin_scatter<MODE, BLK, STRIP, CH>), dim3(G.B), dim3(BLK), sizeof(unsigned int) * G.pitch, s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt, V, SC);
 }
 template <int BLK>
 static void launch_bin_scatter_t(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
-                                 const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const BinStg* own, const unsigned int* own_cnt) {
-  if (own) { if (P.mode == 0) launch_bin_scatter_i<0, BLK, true>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); else launch_bin_scatter_i<1, BLK, true>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); }
-  else { if (P.mode == 0) launch_bin_scatter_i<0, BLK, false>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); else launch_bin_scatter_i<1, BLK, false>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); }
+                                 const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const BinStg* own, const unsigned int* own_cnt,
+                                 const ChanView& V, const SemCarry& SC) {
+  if (own) { if (P.mode == 0) launch_bin_scatter_i<0, BLK, true, false>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt, V, SC); else launch_bin_scatter_i<1, BLK, true, false>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt, V, SC); }
+  else if (SC.on) { if (P.mode == 0) launch_bin_scatter_i<0, BLK, false, true>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt, V, SC); else launch_bin_scatter_i<1, BLK, false, true>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt, V, SC); }
+  else { if (P.mode == 0) launch_bin_scatter_i<0, BLK, false, false>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt, V, SC); else launch_bin_scatter_i<1, BLK, false, false>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt, V, SC); }
 }
+// SC.on: the records are 32-byte BinRec32 (never together with the strip variants: own == nullptr then)
 void launch_bin_scatter(hipStream_t s, const KP& P, const Pose& T, const BinGeo& G, const float* pts, long n, int stride,
-                        const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const BinStg* own, const unsigned int* own_cnt) {
+                        const unsigned int* hist, const unsigned int* tile_start, BinRec* recs, const BinStg* own, const unsigned int* own_cnt,
+                        const ChanView& V, const SemCarry& SC) {
   static const int blk = env_block("EMAP_SCATTER_BLOCK", 512);
   switch (blk) {
-    case 1024: launch_bin_scatter_t<1024>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); break;
-    case 512: launch_bin_scatter_t<512>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt); break;
-    default: launch_bin_scatter_t<256>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt);
+    case 1024: launch_bin_scatter_t<1024>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt, V, SC); break;
+    case 512: launch_bin_scatter_t<512>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt, V, SC); break;
+    default: launch_bin_scatter_t<256>(s, P, T, G, pts, n, stride, hist, tile_start, recs, own, own_cnt, V, SC);
   }
 }
-void launch_tile_count(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cells cells,
+void launch_tile_count(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, int rs, const unsigned int* tile_start, Cells cells,
                        ErrSlot* slots, const SplitView& SV, long n) {
   static_assert(TF_BLOCK == BIN_TR * BIN_TC, "one thread per cell of a tile");
   (void)n;
-  if (SV.on && SV.cap > 0) hipLaunchKernelGGL(k_tile_count<true>, dim3((unsigned int)SV.cap * G.sub + tile_grid(G)), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, slots, SV);
-  else hipLaunchKernelGGL(k_tile_count<false>, dim3(tile_grid(G)), dim3(TF_BLOCK), 0, s, P, G, recs, tile_start, cells, slots, SV);
+  const bool split = SV.on && SV.cap > 0;
+  const dim3 g((split ? (unsigned int)SV.cap * G.sub : 0u) + tile_grid(G)), b(TF_BLOCK);
+  if (split) { if (rs == 2) hipLaunchKernelGGL((k_tile_count<true, 2>), g, b, 0, s, P, G, recs, tile_start, cells, slots, SV); else hipLaunchKernelGGL((k_tile_count<true, 1>), g, b, 0, s, P, G, recs, tile_start, cells, slots, SV); }
+  else { if (rs == 2) hipLaunchKernelGGL((k_tile_count<false, 2>), g, b, 0, s, P, G, recs, tile_start, cells, slots, SV); else hipLaunchKernelGGL((k_tile_count<false, 1>), g, b, 0, s, P, G, recs, tile_start, cells, slots, SV); }
 }
 // fuse_average: commit + average in the tile kernel (whole frames); rays: the visibility pass follows (bitmap + inlier plane wanted)
-void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, const unsigned int* tile_start, Cells cells,
+// true when a launch with these arguments would run the semantic fusion inside the tile kernel (SEM): a carrying frame (rs == 2) that
+// commits + averages itself, without a visibility pass and without heavy-tile parts in the launch
+bool bin_fuse_takes_semantics(const SplitView& SV, bool fuse_average, bool rays, int rs) { return rs == 2 && fuse_average && !rays && !(SV.on && SV.cap > 0); }
+// rs: record stride in 16-byte units; sm (may be null): the frame's semantic fusion, run inside the kernel when bin_fuse_takes_semantics()
+void launch_bin_fuse(hipStream_t s, const KP& P, const BinGeo& G, const BinRec* recs, int rs, const unsigned int* tile_start, Cells cells,
                      AccF* acc, FrameDev* F, bool fuse_average, bool rays, unsigned int* cnt_plane, unsigned long long* inert,
-                     unsigned int* inl_plane, float* thr, const OverlapArgs& O, const GateFold& GF, const SplitView& SV, long n) {
+                     unsigned int* inl_plane, float* thr, const OverlapArgs& O, const GateFold& GF, const SplitView& SV, long n, const SemMini* sm) {
   (void)n;
   const bool split = SV.on && SV.cap > 0;
   const dim3 g((split ? (unsigned int)SV.cap * G.sub : 0u) + tile_grid(G)), b(TF_BLOCK);
-#define EM_FUSE(A, R) do { if (split) hipLaunchKernelGGL((k_tile_fuse<A, R, true>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF, SV); \
-                            else hipLaunchKernelGGL((k_tile_fuse<A, R, false>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF, SV); } while (0)
-  if (fuse_average && rays) EM_FUSE(true, true);
+  SemMini SM; memset(&SM, 0, sizeof SM);
+#define EM_FUSE_I(A, R, SP, RS_, SE) hipLaunchKernelGGL((k_tile_fuse<A, R, SP, RS_, SE>), g, b, 0, s, P, G, recs, tile_start, cells, acc, F, cnt_plane, inert, inl_plane, thr, O, GF, SV, SM)
+#define EM_FUSE(A, R) do { if (split) EM_FUSE_I(A, R, true, 1, false); else EM_FUSE_I(A, R, false, 1, false); } while (0)
+  if (rs == 2) {                                   // a carrying frame (emap_api.hip: only whole frames without a visibility pass carry)
+    if (sm && bin_fuse_takes_semantics(SV, fuse_average, rays, rs)) { SM = *sm; EM_FUSE_I(true, false, false, 2, true); }
+    else if (fuse_average && !rays) { if (split) EM_FUSE_I(true, false, true, 2, false); else EM_FUSE_I(true, false, false, 2, false); }
+    else if (!fuse_average) { if (split) EM_FUSE_I(false, false, true, 2, false); else EM_FUSE_I(false, false, false, 2, false); }
+    else abort();                                  // (32-byte records in front of a visibility pass: k_rays walks 16-byte records)
+  }
+  else if (fuse_average && rays) EM_FUSE(true, true);
   else if (fuse_average) EM_FUSE(true, false);
   else EM_FUSE(false, false);
 #undef EM_FUSE
+#undef EM_FUSE_I
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -797,12 +900,14 @@ typedef SemSpec SemSpecB;
 // over several layers, colour riding along or absent) and tiles whose slot lies below SemSplit::slots; everything else is reduced by
 // the tile's own workgroup as before.
 struct SemSplit { double* sum; unsigned int* col; unsigned int* tick; int slots, phases; };      // [slot][phase][4][cell], [slot][4][cell], [slot][phase]
-template <bool SPLIT>
+// RS: record stride in 16-byte units; RS == 2 (the frame carried columns [cc0, cc0 + 4) of the cloud in its 32-byte records, emap_device.h:
+// BinRec32): a group whose channels all lie in that window reads them from the record itself -- no gather
+template <bool SPLIT, int RS>
 __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSpecB S, const BinRec* __restrict__ recs,
                                                              const unsigned int* __restrict__ tile_start, ChanView V,
                                                              long n, const unsigned int* __restrict__ cnt_plane,
                                                              float* __restrict__ sem, float* __restrict__ alpha_planes, long plane,
-                                                             SplitView SV, SemSplit X) {
+                                                             SplitView SV, SemSplit X, int cc0) {
   constexpr int NC = BIN_TR * BIN_TC;
   const float* __restrict__ chp = V.p - V.col0;          // (a local restrict pointer: the gathers below must stay free to run ahead of the plane stores)
   const long chs = V.stride;
@@ -838,16 +943,19 @@ __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSp
     int cmin = SEM_MAX_CH + 4096, cmax = 0;
     for (int q = 0; q < ng; ++q) { cmin = min(cmin, S.sum_chan[g0 + q]); cmax = max(cmax, S.sum_chan[g0 + q]); }
     if (ride && g0 == 0) { cmin = min(cmin, S.col_chan[0]); cmax = max(cmax, S.col_chan[0]); }
-    const bool wide = cmax - cmin < 4 && cmin >= V.col0 && cmin - V.col0 + 4 <= V.stride;          // (uniform) the 16 bytes stay inside the point's row
+    const bool inrec = RS == 2 && cc0 >= 0 && cmin >= cc0 && cmax < cc0 + 4;                       // (uniform) the group's channels travelled in the record
+    if (inrec) cmin = cc0;
+    const bool wide = inrec || (cmax - cmin < 4 && cmin >= V.col0 && cmin - V.col0 + 4 <= V.stride);          // (uniform) the 16 bytes stay inside the point's row
     struct __attribute__((packed, aligned(4))) P4 { float a, b, c, d; };
     auto pick = [](const P4& w, int j) { return j == 0 ? w.a : (j == 1 ? w.b : (j == 2 ? w.c : w.d)); };
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += SEM_BLK) {
-      const BinRec r = recs[k];
+      const BinRec r = recs[(size_t)k * RS];
       if (((r.lc_inl & 0x7fffffffu) >> 10) != sel) continue;
       const unsigned int lc = r.lc_inl & 1023u;
       const float* __restrict__ p = chp + (long)r.i * chs;
       P4 w4 = {0.f, 0.f, 0.f, 0.f};
-      if (wide) w4 = *reinterpret_cast<const P4*>(p + cmin);
+      if (inrec) { const float4 q4 = reinterpret_cast<const float4*>(recs)[(size_t)k * RS + 1]; w4.a = q4.x; w4.b = q4.y; w4.c = q4.z; w4.d = q4.w; }
+      else if (wide) w4 = *reinterpret_cast<const P4*>(p + cmin);
       for (int q = 0; q < ng; ++q) {
         const float v = wide ? pick(w4, S.sum_chan[g0 + q] - cmin) : p[S.sum_chan[g0 + q]];
         const int kind = S.sum_kind[g0 + q];
@@ -953,7 +1061,7 @@ __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSp
     for (int k = threadIdx.x; k < NC; k += SEM_BLK) s_col[3][k] = 0u;
     __syncthreads();
     for (unsigned int k = r0 + threadIdx.x; k < r1; k += SEM_BLK) {
-      const BinRec r = recs[k];
+      const BinRec r = recs[(size_t)k * RS];
       if (((r.lc_inl & 0x7fffffffu) >> 10) != sel) continue;
       const unsigned int lc = r.lc_inl & 1023u;
       for (int l = 0; l < K; ++l) if ((long)r.i * K + l < n) atomicAdd(&s_col[3][lc], 1u);
@@ -963,7 +1071,7 @@ __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSp
       for (int k = threadIdx.x; k < 3 * NC; k += SEM_BLK) (&s_col[0][0])[k] = 0u;
       __syncthreads();
       for (unsigned int k = r0 + threadIdx.x; k < r1; k += SEM_BLK) {
-        const BinRec r = recs[k];
+        const BinRec r = recs[(size_t)k * RS];
         if ((long)r.i * K + l >= n || ((r.lc_inl & 0x7fffffffu) >> 10) != sel) continue;
         const unsigned int lc = r.lc_inl & 1023u;
         const unsigned int color = __float_as_uint(chp[(long)r.i * chs + S.col_chan[l]]);
@@ -989,7 +1097,7 @@ __global__ __launch_bounds__(SEM_BLK) void k_tile_semantic(KP P, BinGeo G, SemSp
 // scratch of the split semantic kernel: bytes for `slots` tiles (0: cannot split this spec)
 size_t sem_split_bytes(int slots) { return (size_t)slots * ((size_t)(SEM_MAX_CH / SEM_GROUP) * SEM_GROUP * SPLIT_CELLS * 8 + 4 * SPLIT_CELLS * 4 + (SEM_MAX_CH / SEM_GROUP) * 4); }
 bool sem_split_possible(const SemSpec& S) { return S.n_sum > 0 && !S.any_bayes && (S.n_col == 0 || S.n_col == 1); }     // independent groups; colour riding along or absent
-void launch_tile_semantic(hipStream_t s, const KP& P, const BinGeo& G, const SemSpec& S, const BinRec* recs, const unsigned int* tile_start,
+void launch_tile_semantic(hipStream_t s, const KP& P, const BinGeo& G, const SemSpec& S, const BinRec* recs, int rs, int cc0, const unsigned int* tile_start,
                           const ChanView& V, long n, const unsigned int* cnt_plane, float* sem, float* alpha_planes, long plane,
                           const SplitView& SV, void* split_mem, int split_slots) {
   SemSplit X = {nullptr, nullptr, nullptr, 0, SEM_MAX_CH / SEM_GROUP};
@@ -999,6 +1107,9 @@ void launch_tile_semantic(hipStream_t s, const KP& P, const BinGeo& G, const Sem
     X.sum = reinterpret_cast<double*>(split_mem);
     X.col = reinterpret_cast<unsigned int*>(X.sum + (size_t)split_slots * X.phases * SEM_GROUP * SPLIT_CELLS);
     X.tick = X.col + (size_t)split_slots * 4 * SPLIT_CELLS;
-    hipLaunchKernelGGL(k_tile_semantic<true>, dim3((unsigned int)SV.cap * G.sub + tile_grid(G)), dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, V, n, cnt_plane, sem, alpha_planes, plane, SV, X);
-  } else hipLaunchKernelGGL(k_tile_semantic<false>, dim3(tile_grid(G)), dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, V, n, cnt_plane, sem, alpha_planes, plane, SV, X);
+    const dim3 g((unsigned int)SV.cap * G.sub + tile_grid(G));
+    if (rs == 2) hipLaunchKernelGGL((k_tile_semantic<true, 2>), g, dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, V, n, cnt_plane, sem, alpha_planes, plane, SV, X, cc0);
+    else hipLaunchKernelGGL((k_tile_semantic<true, 1>), g, dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, V, n, cnt_plane, sem, alpha_planes, plane, SV, X, cc0);
+  } else if (rs == 2) hipLaunchKernelGGL((k_tile_semantic<false, 2>), dim3(tile_grid(G)), dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, V, n, cnt_plane, sem, alpha_planes, plane, SV, X, cc0);
+  else hipLaunchKernelGGL((k_tile_semantic<false, 1>), dim3(tile_grid(G)), dim3(SEM_BLK), 0, s, P, G, S, recs, tile_start, V, n, cnt_plane, sem, alpha_planes, plane, SV, X, cc0);
 }

@@ -491,6 +491,18 @@ __device__ __forceinline__ bool overlap_cell(const KP& P, const OverlapArgs& O, 
 struct BinGeo { int tiles_x, tiles_y, T, B; long chunk; int sub, TB, pitch, raybin; };
 struct __attribute__((aligned(16))) BinRec { unsigned int lc_inl; float z, v; unsigned int i; };  // sorted by tile
 struct BinStg;                                                                                     // staging record of the strip variants
+// Records of a frame that CARRIES its semantic channels (round 6): the sorted record is 32 bytes -- the 16 above + the point's four
+// carried channel columns -- so the semantic fusion reads a point's channels at the record's own position instead of gathering a
+// 128-byte line per 16-byte channel row by point index (8192^2 / 16 M points: 2.0 GB fetched for 0.26 GB), and the scatter pass
+// writes ONE full 32-byte sector per point (a 16-byte record already cost a whole sector on the way out; a SECOND stream of 16-byte
+// stores was measured at 3.5x the pass in round 5).  Tile kernels address records as 16-byte units with a stride RS of 1 or 2.
+struct __attribute__((aligned(32))) BinRec32 { unsigned int lc_inl; float z, v; unsigned int i; float c[4]; };
+static_assert(sizeof(BinRec32) == 32, "BinRec32");
+// what a carrying frame's scatter pass copies: columns [c0, c0 + 4) of the caller's (N, ncols) matrix (missing columns read as 0)
+struct SemCarry { int on, c0, ncols, pad_; };
+// the semantic fusion of a carrying frame inside the tile kernel (k_tile_fuse<.., SEM>): averaged channels (kind 0 average, 1
+// class_average) and at most one colour channel, each addressed by its slot 0..3 in the record
+struct SemMini { int n_sum, n_col; int slot[4], layer[4], kind[4]; int col_slot, col_layer; double alpha; float* sem; long plane; };
 
 // ---- HEAVY tiles: the records of one tile reduced by SEVERAL workgroups --------------------------------------------------------
 // One workgroup per tile is the right grain for a uniform cloud (1 M points / 1024 tiles: one trip of 1024 threads per tile).  A

@@ -201,7 +201,15 @@ class ElevationMap:
         robot scale) -- include/emap_hip.h: emap_last_update_path; the results are bit-identical"""
         v = ct.c_int32(-1)
         self._chk(self._lib.emap_last_update_path(self._ctx, ct.byref(v)))
-        return {0: "atomic", 1: "binned", 2: "small_frame"}[v.value]
+        return {0: "atomic", 1: "binned", 2: "small_frame"}[v.value & 3]
+
+    def last_frame_semantics(self):
+        """how the last whole frame fused the channels declared for it (emap_frame_semantics): "in_tile_pass" (32-byte records, fused by
+        the tile kernel that fused the heights), "carried" (32-byte records, the stand-alone semantic kernel read the channels from
+        them: a launch with heavy-tile parts) or "separate" (the stand-alone kernels on 16-byte records / the atomic path)"""
+        v = ct.c_int32(-1)
+        self._chk(self._lib.emap_last_update_path(self._ctx, ct.byref(v)))
+        return "in_tile_pass" if v.value & 4 else ("carried" if v.value & 8 else "separate")
 
     def set_ray_mode(self, mode):
         """"auto" | "by_row" | "by_ray": how a SHARDED frame (emap_update_sharded) runs the visibility pass (include/emap_hip.h:
@@ -373,9 +381,11 @@ class ElevationMap:
         if points_all is not None:
             self.bind_points(points_all)
         R, t32 = self._rt(R, t)
-        if self.semantic_map is not None and channels:
-            self.semantic_map.prepare(list(channels))     # layers + count plane must exist before the average pass
         with self.map_lock:
+            jobs = []
+            if self.semantic_map is not None and channels:
+                # layers + count plane must exist before the average pass; the sum / colour fusions ride inside the frame
+                jobs = self.semantic_map.declare_frame(self, list(channels))
             t32 = t32 - self.center
             try:
                 t -= self.center  # reference mutates the caller's array
@@ -386,8 +396,8 @@ class ElevationMap:
                                             ct.c_double(orientation_noise), ct.byref(st) if want_stats else None))
             if want_stats:
                 self._take_stats(st)
-            if self.semantic_map is not None and channels:
-                self.semantic_map.update_layers_pointcloud(self, list(channels), R, t32)
+            if jobs:
+                self.semantic_map.finish_frame(self, jobs, R, t32)
         return st if want_stats else None
 
     def _take_stats(self, st):

@@ -95,21 +95,24 @@ class SemanticMap:
                 self.add_layer(channel)
         return process_channels, fusions
 
-    def update_layers_pointcloud(self, emap, channels, R, t):
-        """fuse the extra channels of the bound cloud (reference semantic_map.py:223-259)."""
+    def frame_fusions(self, channels):
+        """what one frame's extra channels ask for: ``(spec, class_max_jobs)`` -- the ``emap_sem_spec`` of the sum / colour fusions (None
+        when there is none) and the ``class_max`` fusions as ``(plugin, cloud columns, layer indices)``, which run as a pass of their
+        own on the device (reference semantic_map.py:223-259: one ``plugin(...)`` call per fusion algorithm)."""
         process_channels, fusions = self.prepare(channels)
         if not process_channels:
-            return
+            return None, []
         spec = EmapSemSpec()
         spec.alpha = float(self.param.average_weight)
         ns = nc = 0
+        jobs = []
         for fusion in sorted(set(fusions)):
             plug = self.fusion_manager.get_plugin(fusion, "pointcloud")
             if plug is None:
                 continue
             pcl_ids, layer_ids = self.get_indices_fusion(process_channels, fusion, self.layer_specs_points)
             if plug.kind == "class_max":      # a frame of its own on the device (per-layer maxima over exact class sums)
-                plug.fuse(emap, pcl_ids, layer_ids, R, t)
+                jobs.append((plug, pcl_ids, layer_ids))
                 continue
             for ch, ly in zip(pcl_ids, layer_ids):
                 if plug.kind == "color":
@@ -121,7 +124,26 @@ class SemanticMap:
                         raise ValueError("at most 16 averaged channels per cloud")
                     spec.sum_chan[ns], spec.sum_layer[ns], spec.sum_kind[ns] = int(ch), int(ly), _KIND[plug.kind]; ns += 1
         spec.n_sum, spec.n_col = ns, nc
-        if ns == 0 and nc == 0:
+        return (spec if ns + nc else None), jobs
+
+    def declare_frame(self, emap, channels):
+        """before ``emap_update``: hand the frame its sum / colour fusions (``emap_frame_semantics``: they run INSIDE the frame, as
+        ``update_layers_pointcloud`` does inside the reference's ``update_map_with_kernel``, elevation_mapping.py:368); returns the
+        ``class_max`` jobs to run after it (``finish_frame``)."""
+        spec, jobs = self.frame_fusions(channels)
+        emap._chk(emap._lib.emap_frame_semantics(emap._ctx, ct.byref(spec) if spec is not None else None, 1 if jobs else 0))
+        return jobs
+
+    def finish_frame(self, emap, jobs, R, t):
+        for plug, pcl_ids, layer_ids in jobs:
+            plug.fuse(emap, pcl_ids, layer_ids, R, t)
+
+    def update_layers_pointcloud(self, emap, channels, R, t):
+        """fuse the extra channels of the bound cloud AFTER a frame that did not declare them (reference semantic_map.py:223-259;
+        ``update_map_with_kernel`` itself goes through ``declare_frame`` / ``finish_frame``)."""
+        spec, jobs = self.frame_fusions(channels)
+        self.finish_frame(emap, jobs, R, t)
+        if spec is None:
             return
         R = np.ascontiguousarray(np.asarray(R, np.float32).reshape(9))
         t = np.ascontiguousarray(np.asarray(t, np.float32).reshape(3))

@@ -19,7 +19,7 @@ extern "C" {
 
 /* 2 (round 4/5): emap_halo_pack / emap_halo_unpack / emap_halo_bytes move 16-byte COLD half cells (halo * cell_n * 4 floats) instead of
  * 32-byte cells; emap_upload_points de-interleaves the extra channels; emap_comm_init makes the ranks agree on this number. */
-#define EMAP_ABI_VERSION 2
+#define EMAP_ABI_VERSION 3
 
 typedef enum {
   EMAP_OK = 0,
@@ -180,6 +180,17 @@ typedef struct emap_sem_spec {
 } emap_sem_spec;
 int emap_semantic_configure(emap_ctx* ctx, int32_t n_layers);                 /* SemanticMap.add_layer */
 int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], const emap_sem_spec* spec); /* after emap_update */
+/* semantic_map.update_layers_pointcloud as the reference runs it -- INSIDE update_map_with_kernel, between average_map_kernel and
+ * clear_overlap_map (EM/elevation_mapping.py:366-368; EM/semantic_map.py:223-259): declares the fusion of the extra channels of
+ * the bound cloud for the NEXT emap_update / emap_update_sharded call, which then fuses them before it returns (the declaration is
+ * consumed by that one frame, also when the frame fails; spec_or_null == NULL or an empty spec withdraws it).  The layers hold what
+ * an emap_semantic_update call after the frame would have left.  What the frame gains: a tile-binned frame without a visibility pass
+ * whose fusions are average / class_average / at most one colour channel over at most four consecutive channel columns sorts 32-byte
+ * records that carry those columns and fuses them in the tile pass that fuses the heights (no second pass over the records, no gather
+ * of channel rows by point index, no count plane).  keep_counts != 0: the frame also leaves the per-cell accepted counts (new_map[2])
+ * for a later emap_semantic_update / emap_semantic_class_max call on the same frame.  The spec is checked against the cloud that is
+ * bound when the frame starts (EMAP_ERR_INVALID from that emap_update). */
+int emap_frame_semantics(emap_ctx* ctx, const emap_sem_spec* spec_or_null, int32_t keep_counts);
 int emap_semantic_get_layer(emap_ctx* ctx, int32_t layer, float* host_out);
 int emap_semantic_set_layer(emap_ctx* ctx, int32_t layer, const float* host_in);
 int emap_semantic_clear(emap_ctx* ctx);                                        /* SemanticMap.clear (layers only, :47-49) */
@@ -347,7 +358,10 @@ int emap_get_stage_times(emap_ctx* ctx, float ms_out[10]);
  * 0 = chain of launches with global atomics (k_count, k_fuse, k_commit / k_average), 1 = tile-binned (sort front-end + tile kernels),
  * 2 = ONE launch, k_small_frame: small clouds on maps of up to 512^2 cells -- the robot-scale configuration the reference ships
  * (EM/parameter.py:137,165 -> 202^2 cells; EM/elevation_mapping.py:316-391 is a chain of ~12 dependent launches there).
- * EMAP_SMALL_FRAME=0 in the environment keeps such frames on path 0. */
+ * EMAP_SMALL_FRAME=0 in the environment keeps such frames on path 0.
+ * Bits 2-3 (the value & 3 is the path above): how the frame fused the channels declared by emap_frame_semantics -- 4 = inside the tile
+ * kernel that fused the heights (32-byte sorted records), 8 = 32-byte records, stand-alone semantic kernel (a launch with heavy-tile
+ * parts), neither = stand-alone kernels on 16-byte records / the atomic path.  EMAP_SEM_CARRY=0 keeps every frame on the last form. */
 int emap_last_update_path(emap_ctx* ctx, int32_t* path);
 
 #ifdef __cplusplus

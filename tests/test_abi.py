@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libemap_hip.so does not export %s" % n
     assert sorted(_lib.SYMBOLS) == names, "python binding table and header disagree"
-    assert lib.emap_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.emap_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_struct_layouts_match_header():
