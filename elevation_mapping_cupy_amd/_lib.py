@@ -63,7 +63,7 @@ SYMBOLS = [
     "emap_semantic_get_layer", "emap_semantic_set_layer", "emap_semantic_clear", "emap_semantic_get_alpha", "emap_semantic_set_alpha", "emap_semantic_class_max", "emap_semantic_accumulate", "emap_semantic_finalize", "emap_min_filter", "emap_max_filter", "emap_smooth_filter", "emap_erode", "emap_inpaint_u8", "emap_inpaint_telea_u8", "emap_inpaint_ns_u8", "emap_image_correspondence", "emap_image_get_correspondence",
     "emap_image_fuse", "emap_image_set_tolerance", "emap_image_fuse_arrays", "emap_polygon_mask", "emap_dilate_planes", "emap_halo_bytes", "emap_halo_pack", "emap_halo_unpack", "emap_normal_row_lag", "emap_normal_halo_pack", "emap_normal_halo_unpack", "emap_normal_lag_plan",
     "emap_comm_unique_id", "emap_comm_init", "emap_comm_destroy", "emap_comm_selftest", "emap_comm_count", "emap_comm_wire_bytes", "emap_comm_allreduce_host", "emap_comm_gather_layer", "emap_update_sharded", "emap_set_ray_mode",
-    "emap_timer_begin", "emap_timer_end", "emap_enable_stage_timing", "emap_get_stage_times", "emap_last_update_path",
+    "emap_timer_begin", "emap_timer_end", "emap_enable_stage_timing", "emap_get_stage_times", "emap_last_update_path", "emap_small_frame_aborts",
 ]
 
 _lib = None

@@ -25,8 +25,8 @@
 bool launch_count(hipStream_t, const KP&, const Pose&, const float*, long, int, Cells, AccF*, ErrSlot*, const GateArgs*, FrameDev*, unsigned int*);
 void launch_gate(hipStream_t, const GateArgs&, ErrSlot*, FrameDev*, int, double*, const double*);
 int small_frame_grid(const KP&, long);
-void launch_small_frame(hipStream_t, int, const KP&, const Pose&, const float*, long, int, Cells, AccF*, unsigned int*, unsigned long long*, const OverlapArgs&,
-                        const GateArgs&, FrameDev*, ErrSlot*, unsigned int*, unsigned int*, unsigned int*, unsigned int, bool);
+void launch_small_frame(hipStream_t, int, const KP&, const Pose&, const float*, long, int, Cells, AccF*, unsigned int*, const OverlapArgs&,
+                        const GateArgs&, FrameDev*, FrameDev*, ErrSlot*, unsigned int*, unsigned int*, unsigned int*, unsigned int*, unsigned int, unsigned int, int);
 void launch_fuse(hipStream_t, const KP&, const Pose&, const float*, long, int, Cells, AccF*, const FrameDev*);
 void launch_commit(hipStream_t, const KP&, Cells, const AccF*, const FrameDev*, unsigned long long*);
 void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float*, long, int, Cells, const AccRView&, const float*, long, FrameDev*, bool, const unsigned long long*, const unsigned int*, int, const float*, const unsigned int*, const unsigned int*);
@@ -161,9 +161,19 @@ struct emap_ctx {
   OverlapArgs ov_args;             // clear_overlap_map folded into the frame's rewriting kernels (on = 0: separate k_overlap launch)
   bool fold_gate, gate_folded;     // emap_update on the atomic path: the gate rides in k_count's last workgroup (cnt_sync: its ticket words)
   unsigned int* cnt_sync;
-  // robot scale: count -> gate -> fuse -> commit / average in one launch (k_small_frame): its barriers' release words live behind the
-  // ticket words of cnt_sync; sf_err = host-mapped word a barrier that gave up sets (the next call fails loudly, the path stays off)
-  unsigned int sf_epoch; volatile unsigned int* sf_err; unsigned int* sf_err_dev; bool sf_off;
+  // robot scale: count -> gate -> fuse -> commit + average in one launch (k_small_frame): its barriers' release words live behind the
+  // ticket words of cnt_sync.  A launch whose grid barrier is ABORTED leaves map, accumulators and drift record exactly as it found
+  // them, and the launches queued behind it do nothing (device-side poison word).  sf_host = two host-mapped words: [0] epoch of the
+  // last launch that will be applied, [1] epoch of the first aborted launch.  The frames issued and not yet known to be applied wait
+  // in sf_ring with everything needed to run them again; sf_settle (every entry point but the ones that only bind a cloud) learns
+  // their fate and, after an abort, re-runs them in order on the chain of launches.
+  unsigned int sf_epoch; volatile unsigned int* sf_host; unsigned int* sf_host_dev; unsigned int* sf_poison; bool sf_off;
+  FrameDev* frame_save;            // the frame record as the gate of the last k_small_frame found it
+  struct SfFrame { unsigned int epoch; float R[9], t[3]; double pn, on; Moves mv; const float* pts; long n_pts, n_pts_all; int stride; ChanView chan; int n_cols; };
+  enum { SF_RING = 8 };
+  SfFrame sf_ring[SF_RING]; int sf_head, sf_count;
+  bool sf_redo;                    // inside sf_recover: frames take the chain of launches
+  unsigned int sf_aborts;          // frames re-run so far (emap_small_frame_aborts)
   int update_path;                 // emap_last_update_path
   bool gate_possible;              // false inside emap_update when the host already knows that the drift gate cannot fire: the per-tile
                                    // error statistics are then skipped (they could not have any effect; err_sum / err_cnt report 0)
@@ -220,6 +230,58 @@ struct emap_ctx {
 #define CKARG(cond, msg) do { if (!(cond)) { if (ctx) ctx->err = msg; return EMAP_ERR_INVALID; } } while (0)
 
 static float q16(float x) { return (float)(_Float16)x; }
+// The k_small_frame launches that are issued and not yet known to be applied (emap_ctx::sf_ring).  sf_settle waits until the device
+// has decided the fate of the last of them (a poll of a host-mapped word: the decision falls at the launch's second barrier, long
+// before the stream is idle), forgets those that will be applied, and after an ABORT (the launch left everything as it found it, the
+// launches behind it did nothing: emap_kernels.hip) drains the stream and re-runs the aborted frame and every one after it, in order,
+// on the chain of launches, each on the cloud that was bound when it was issued.  Every entry point that reads or changes the map, the
+// drift record or a cloud buffer passes through SF_CHECK first; binding another device cloud and emap_update's own small-frame path do
+// not (frames pipeline), they only make room in the ring.
+static int update_impl(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats);
+static void sf_forget_applied(emap_ctx* ctx) {
+  const unsigned int passed = ctx->sf_host[0];
+  while (ctx->sf_count > 0 && ctx->sf_ring[ctx->sf_head].epoch <= passed) { ctx->sf_head = (ctx->sf_head + 1) % emap_ctx::SF_RING; --ctx->sf_count; }
+}
+static int sf_recover(emap_ctx* ctx) {
+  CK(hipSetDevice(ctx->device));
+  CK(hipStreamSynchronize(ctx->stream));      // the aborted launch, the idle ones behind it and their stencil launches have drained
+  const unsigned int first = ctx->sf_host[1];
+  ctx->sf_host[1] = 0u;
+  CK(hipMemset(ctx->sf_poison, 0, 4));
+  // the binding of the moment (maybe a cloud for a frame that has not been issued yet) comes back afterwards
+  const float* pts = ctx->pts; const long n_pts = ctx->n_pts, n_all = ctx->n_pts_all; const int stride = ctx->stride, n_cols = ctx->n_cols; const ChanView chan = ctx->chan;
+  const bool fsem_set = ctx->fsem_set; ctx->fsem_set = false;      // (a fusion declared for the frame to come is not the re-run frames')
+  int rc = EMAP_OK;
+  ctx->sf_redo = true;
+  bool first_done = false;
+  while (ctx->sf_count > 0) {
+    const emap_ctx::SfFrame f = ctx->sf_ring[ctx->sf_head];
+    ctx->sf_head = (ctx->sf_head + 1) % emap_ctx::SF_RING; --ctx->sf_count;
+    if (f.epoch < first) continue;            // applied before the abort
+    if (!first_done) { ctx->kp.mv = f.mv; first_done = true; }      // the pending map shifts the aborted launch was to write out (later frames: none, no shift can lie between unsettled frames)
+    ctx->pts = f.pts; ctx->n_pts = f.n_pts; ctx->n_pts_all = f.n_pts_all; ctx->stride = f.stride; ctx->chan = f.chan; ctx->n_cols = f.n_cols;
+    ++ctx->sf_aborts;
+    if (rc == EMAP_OK) rc = update_impl(ctx, f.R, f.t, f.pn, f.on, nullptr);
+  }
+  ctx->sf_redo = false; ctx->fsem_set = fsem_set;
+  ctx->pts = pts; ctx->n_pts = n_pts; ctx->n_pts_all = n_all; ctx->stride = stride; ctx->chan = chan; ctx->n_cols = n_cols;
+  return rc;
+}
+static int sf_settle(emap_ctx* ctx) {
+  if (ctx->sf_redo || ctx->sf_count == 0) return EMAP_OK;
+  const unsigned int last = ctx->sf_ring[(ctx->sf_head + ctx->sf_count - 1) % emap_ctx::SF_RING].epoch;
+  for (long spins = 0; ctx->sf_host[1] == 0u && ctx->sf_host[0] < last; ++spins) {
+    if (spins > (1L << 22)) {                 // (something else is very slow on this stream: wait for it the ordinary way)
+      CK(hipSetDevice(ctx->device)); CK(hipStreamSynchronize(ctx->stream));
+      if (ctx->sf_host[1] == 0u && ctx->sf_host[0] < last) { ctx->err = "k_small_frame finished without reporting its outcome"; return EMAP_ERR_HIP; }
+      break;
+    }
+  }
+  if (ctx->sf_host[1] != 0u) return sf_recover(ctx);
+  sf_forget_applied(ctx);
+  return EMAP_OK;
+}
+#define SF_CHECK() do { if (ctx->sf_count > 0) { int rc_sf_ = sf_settle(ctx); if (rc_sf_) return rc_sf_; } } while (0)
 static int frame_sem_begin(emap_ctx* ctx, bool rays_on);                               // (the frame's semantic fusion: defined next to emap_semantic_update)
 static int frame_sem_finish(emap_ctx* ctx, const float R[9], const float t[3]);
 
@@ -428,7 +490,7 @@ int emap_destroy(emap_ctx* ctx) {
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   delete ctx->workers;
   hipFree(ctx->tail_idx); hipFree(ctx->tail_flags); hipFree(ctx->ray_S); hipFree(ctx->ray_lut); hipFree(ctx->inert); hipFree(ctx->inl_plane); hipFree(ctx->ray_thr);
-  hipFree(ctx->bin_recs); hipFree(ctx->bin_own); hipFree(ctx->bin_own_cnt); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start); hipFree(ctx->bin_sync); hipFree(ctx->split_mem); hipFree(ctx->sem_split_mem); if (ctx->split_need) hipHostFree((void*)ctx->split_need); if (ctx->sf_err) hipHostFree((void*)ctx->sf_err);
+  hipFree(ctx->bin_recs); hipFree(ctx->bin_own); hipFree(ctx->bin_own_cnt); hipFree(ctx->bin_hist); hipFree(ctx->bin_tile_total); hipFree(ctx->bin_tile_start); hipFree(ctx->bin_sync); hipFree(ctx->split_mem); hipFree(ctx->sem_split_mem); if (ctx->split_need) hipHostFree((void*)ctx->split_need); if (ctx->sf_host) hipHostFree((void*)ctx->sf_host); hipFree(ctx->frame_save); hipFree(ctx->sf_poison);
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   emap_comm_destroy(ctx);
@@ -442,7 +504,7 @@ int emap_destroy(emap_ctx* ctx) {
 }
 
 int emap_clear(emap_ctx* ctx) {
-  CKARG(ctx, "null ctx");
+  CKARG(ctx, "null ctx"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   // ElevationMap.clear (elevation_mapping.py:119-128): all planes 0, variance = initial_variance
   Cell z = {0.f, (float)ctx->prm.initial_variance, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -511,7 +573,7 @@ int emap_create(const emap_params* params, const emap_strip* strip, int device, 
 }
 
 int emap_set_params(emap_ctx* ctx, const emap_params* params) {
-  CKARG(ctx && params, "null argument");
+  CKARG(ctx && params, "null argument"); SF_CHECK();
   CKARG(params->cell_n == ctx->prm.cell_n, "cell_n cannot change");
   std::string why;
   if (!validate(params, &ctx->strip, &why)) { ctx->err = why; return EMAP_ERR_INVALID; }
@@ -521,7 +583,11 @@ int emap_set_params(emap_ctx* ctx, const emap_params* params) {
   return build_ray_tables(ctx);
 }
 
-int emap_sync(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); CK(hipStreamSynchronize(ctx->stream)); return EMAP_OK; }
+int emap_sync(emap_ctx* ctx) {
+  CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); CK(hipStreamSynchronize(ctx->stream));
+  if (ctx->sf_count > 0) { SF_CHECK(); CK(hipStreamSynchronize(ctx->stream)); }      // (an aborted small frame is re-run before the caller is told the stream is idle)
+  return EMAP_OK;
+}
 
 // ---- point cloud --------------------------------------------------------------------------------------
 // Which points of a cloud can land in THIS strip's rows under the pose (R, t map-centre relative)?  A conservative host-side test in
@@ -554,7 +620,7 @@ struct StripKeep {
 };
 
 // conversion + (optional) order-preserving compaction of a host cloud into the pinned slot and out to the device, chunk by chunk
-static int upload_impl(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype, const StripKeep* keep, int64_t* n_kept) {
+static int upload_impl(emap_ctx* ctx, const void* host, int64_t n, int64_t stride, int dtype, const StripKeep* keep, int64_t* n_kept) { SF_CHECK();
   CK(hipSetDevice(ctx->device));
   const long tot = (long)n * stride + (stride > 3 ? 64 : 0);      // (+ the padding in front of the channel matrix)
   if (!ctx->copy_stream) {
@@ -747,7 +813,7 @@ static int ensure_tail(emap_ctx* ctx) {
 }
 
 int emap_point_index(emap_ctx* ctx, const float R[9], const float t[3], int32_t* idx, uint8_t* valid, uint8_t* inside) {
-  CKARG(ctx && R && t && idx && valid && inside, "null argument");
+  CKARG(ctx && R && t && idx && valid && inside, "null argument"); SF_CHECK();
   if (!ctx->pts && ctx->n_pts) { ctx->err = "no point cloud bound"; return EMAP_ERR_NO_POINTS; }
   CK(hipSetDevice(ctx->device));
   if (ctx->n_pts == 0) return EMAP_OK;
@@ -863,7 +929,7 @@ static int ensure_bins(emap_ctx* ctx, bool raybin) {
 
 int emap_set_scatter_mode(emap_ctx* ctx, int32_t mode) {
   const int m = mode & 0xff, sub = (mode >> 8) & 0xff;
-  CKARG(ctx && m >= 0 && m <= 2 && (mode >> 16) == 0, "scatter mode: 0 auto, 1 atomic, 2 binned");
+  CKARG(ctx && m >= 0 && m <= 2 && (mode >> 16) == 0, "scatter mode: 0 auto, 1 atomic, 2 binned"); SF_CHECK();
   CKARG(sub == 0 || (sub <= 64 && (sub & (sub - 1)) == 0), "bin height factor must be a power of two <= 64");
   ctx->force_sub = sub;
   CKARG(m != 2 || bins_possible(ctx), "binned scatter: too many bins for the LDS histogram");
@@ -879,10 +945,14 @@ int emap_set_ray_mode(emap_ctx* ctx, int32_t mode) {
 
 // the host-mapped word a grid barrier that gave up sets (k_small_frame: emap_device.h)
 static int ensure_barrier_word(emap_ctx* ctx) {
-  if (ctx->sf_err) return EMAP_OK;
-  CK(hipHostMalloc((void**)&ctx->sf_err, 64, hipHostMallocMapped));
-  *ctx->sf_err = 0u;
-  CK(hipHostGetDevicePointer((void**)&ctx->sf_err_dev, const_cast<unsigned int*>(ctx->sf_err), 0));
+  if (ctx->sf_host) return EMAP_OK;
+  if (!ctx->frame_save) CK(hipMalloc((void**)&ctx->frame_save, sizeof(FrameDev)));
+  if (!ctx->sf_poison) { CK(hipMalloc((void**)&ctx->sf_poison, 64)); CK(hipMemsetAsync(ctx->sf_poison, 0, 64, ctx->stream)); }
+  volatile unsigned int* h = nullptr;
+  CK(hipHostMalloc((void**)&h, 64, hipHostMallocMapped));
+  h[0] = 0u; h[1] = 0u;
+  if (hipHostGetDevicePointer((void**)&ctx->sf_host_dev, const_cast<unsigned int*>(h), 0) != hipSuccess) { hipHostFree((void*)h); ctx->err = "hipHostGetDevicePointer"; return EMAP_ERR_HIP; }
+  ctx->sf_host = h;
   return EMAP_OK;
 }
 
@@ -897,7 +967,7 @@ static GateArgs gate_args(emap_ctx* ctx, double position_noise, double orientati
 }
 
 int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
-  CKARG(ctx && R && t, "null argument"); NEED_POINTS();
+  CKARG(ctx && R && t, "null argument"); SF_CHECK(); NEED_POINTS();
   if (!ctx->in_update) { ctx->gate_possible = true; ctx->carry_want = false; }          // the staged API always gathers the statistics and sorts plain 16-byte records
   ctx->bin_rs = 1;
   CK(hipSetDevice(ctx->device));
@@ -977,7 +1047,7 @@ static int gate_impl(emap_ctx* ctx, double position_noise, double orientation_no
 
 int emap_set_drift_inputs(emap_ctx* ctx, double position_noise, double orientation_noise, const double* err_sum_override,
                           const uint32_t* err_cnt_override) {
-  CKARG(ctx, "null ctx");
+  CKARG(ctx, "null ctx"); SF_CHECK();
   ctx->pos_noise = position_noise; ctx->ori_noise = orientation_noise;
   ctx->use_override = err_sum_override && err_cnt_override;
   if (ctx->use_override) { ctx->sum_override = *err_sum_override; ctx->cnt_override = *err_cnt_override; }
@@ -985,19 +1055,19 @@ int emap_set_drift_inputs(emap_ctx* ctx, double position_noise, double orientati
 }
 
 int emap_drift_sums_to_device(emap_ctx* ctx, double* dev_out2) {
-  CKARG(ctx && dev_out2, "null argument");
+  CKARG(ctx && dev_out2, "null argument"); SF_CHECK();
   ctx->use_override = false;
   return gate_impl(ctx, 0.0, 0.0, 1, dev_out2, nullptr);
 }
 
 int emap_set_drift_inputs_device(emap_ctx* ctx, double position_noise, double orientation_noise, const double* dev_totals2) {
-  CKARG(ctx && dev_totals2, "null argument");
+  CKARG(ctx && dev_totals2, "null argument"); SF_CHECK();
   ctx->use_override = false;
   return gate_impl(ctx, position_noise, orientation_noise, 0, nullptr, dev_totals2);
 }
 
 int emap_local_drift_sums(emap_ctx* ctx, double* err_sum, uint32_t* err_cnt) {
-  CKARG(ctx && err_sum && err_cnt, "null argument");
+  CKARG(ctx && err_sum && err_cnt, "null argument"); SF_CHECK();
   ctx->use_override = false;
   int rc = gate_impl(ctx, 0.0, 0.0, 1, nullptr, nullptr);
   if (rc) return rc;
@@ -1048,11 +1118,11 @@ static int fuse_impl(emap_ctx* ctx, const float R[9], const float t[3], bool fus
   CK(hipGetLastError());
   return EMAP_OK;
 }
-int emap_fuse(emap_ctx* ctx, const float R[9], const float t[3]) { CKARG(ctx && R && t, "null argument"); return fuse_impl(ctx, R, t); }
+int emap_fuse(emap_ctx* ctx, const float R[9], const float t[3]) { CKARG(ctx && R && t, "null argument"); SF_CHECK(); return fuse_impl(ctx, R, t); }
 
 // fuse + commit + average_map in one call for frames without a visibility pass (one tile kernel on the binned path)
 int emap_fuse_average(emap_ctx* ctx, const float R[9], const float t[3]) {
-  CKARG(ctx && R && t, "null argument");
+  CKARG(ctx && R && t, "null argument"); SF_CHECK();
   const bool fused = ctx->frame_binned;
   int rc = fuse_impl(ctx, R, t, fused);
   if (rc) return rc;
@@ -1063,7 +1133,7 @@ int emap_fuse_average(emap_ctx* ctx, const float R[9], const float t[3]) {
 }
 
 int emap_commit(emap_ctx* ctx) {
-  CKARG(ctx, "null ctx");
+  CKARG(ctx, "null ctx"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   if (!ctx->committed) {
     launch_commit(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->frame, ctx->inert);
@@ -1075,7 +1145,7 @@ int emap_commit(emap_ctx* ctx) {
 }
 
 int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
-  CKARG(ctx && R && t, "null argument"); NEED_POINTS();
+  CKARG(ctx && R && t, "null argument"); SF_CHECK(); NEED_POINTS();
   CK(hipSetDevice(ctx->device));
   CKARG(ctx->committed || ctx->rays_fused, "emap_rays needs emap_commit first (rays read snapshot S1)");
   CKARG(!ctx->pts_bucketed, "a bucketed cloud (emap_upload_points_strip) cannot march its rays by row: every valid point marches a ray through every strip");
@@ -1098,7 +1168,7 @@ int emap_rays(emap_ctx* ctx, const float R[9], const float t[3]) {
 }
 
 int emap_average(emap_ctx* ctx) {
-  CKARG(ctx, "null ctx");
+  CKARG(ctx, "null ctx"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, true, ctx->cnt_plane, OverlapArgs{});
   ctx->committed = false; ctx->kp.mv.n = 0;       // (uncommitted: k_average wrote the pending map shifts out itself)
@@ -1117,8 +1187,9 @@ static OverlapArgs overlap_args(const emap_ctx* ctx, float t_z, bool on) {
   return o;
 }
 
-int emap_overlap_clear(emap_ctx* ctx, float t_z) {
-  CKARG(ctx, "null ctx");
+static int overlap_clear_impl(emap_ctx* ctx, float t_z);
+int emap_overlap_clear(emap_ctx* ctx, float t_z) { CKARG(ctx, "null ctx"); SF_CHECK(); return overlap_clear_impl(ctx, t_z); }
+static int overlap_clear_impl(emap_ctx* ctx, float t_z) {      // (inside a frame: no SF_CHECK -- a small frame just issued must not be waited for)
   CK(hipSetDevice(ctx->device));
   FLUSH();
   const OverlapArgs o = overlap_args(ctx, t_z, true);
@@ -1148,7 +1219,7 @@ static void post_rows(emap_ctx* ctx, int nj, const int* j0, const int* j1, int s
 }
 
 int emap_dilate(emap_ctx* ctx) {          // dilation_filter_kernel alone: traversability_input (k_post, stage 1)
-  CKARG(ctx, "null ctx");
+  CKARG(ctx, "null ctx"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   FLUSH();
   { const int j0 = 0, j1 = ctx->strip.row_count; post_rows(ctx, 1, &j0, &j1, 1); }
@@ -1162,8 +1233,9 @@ int emap_traversability_normals(emap_ctx* ctx) { return emap_post_part(ctx, 0); 
 // dilation + traversability + normals in one launch.  part: 0 = whole strip,
 // 1 = only the rows that do not depend on halo rows (can run while the halo exchange is in flight),
 // 2 = the remaining (boundary) rows.
-int emap_post_part(emap_ctx* ctx, int32_t part) {
-  CKARG(ctx && part >= 0 && part <= 2, "bad argument");
+static int post_part_impl(emap_ctx* ctx, int32_t part);
+int emap_post_part(emap_ctx* ctx, int32_t part) { CKARG(ctx && part >= 0 && part <= 2, "bad argument"); SF_CHECK(); return post_part_impl(ctx, part); }
+static int post_part_impl(emap_ctx* ctx, int32_t part) {      // (inside a frame: no SF_CHECK, see overlap_clear_impl)
   CK(hipSetDevice(ctx->device));
   FLUSH();
   const int n = ctx->strip.row_count;
@@ -1180,11 +1252,11 @@ int emap_post_part(emap_ctx* ctx, int32_t part) {
 }
 int emap_post(emap_ctx* ctx) { return emap_post_part(ctx, 0); }
 
-int emap_update_variance(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 1, 0); ctx->kp.mv.n = 0; CK(hipGetLastError()); return EMAP_OK; }
-int emap_update_time(emap_ctx* ctx) { CKARG(ctx, "null ctx"); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 0, 1); ctx->kp.mv.n = 0; CK(hipGetLastError()); return EMAP_OK; }
+int emap_update_variance(emap_ctx* ctx) { CKARG(ctx, "null ctx"); SF_CHECK(); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 1, 0); ctx->kp.mv.n = 0; CK(hipGetLastError()); return EMAP_OK; }
+int emap_update_time(emap_ctx* ctx) { CKARG(ctx, "null ctx"); SF_CHECK(); CK(hipSetDevice(ctx->device)); launch_var_time(ctx->stream, ctx->kp, ctx->cells, 0, 1); ctx->kp.mv.n = 0; CK(hipGetLastError()); return EMAP_OK; }
 
 int emap_get_stats(emap_ctx* ctx, emap_stats* out) {
-  CKARG(ctx && out, "null argument");
+  CKARG(ctx && out, "null argument"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   FrameDev f;
   CK(hipMemcpyAsync(&f, ctx->frame, sizeof f, hipMemcpyDeviceToHost, ctx->stream));
@@ -1195,7 +1267,6 @@ int emap_get_stats(emap_ctx* ctx, emap_stats* out) {
   return EMAP_OK;
 }
 
-static int update_impl(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats);
 int emap_update(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats) {
   const int rc = update_impl(ctx, R, t, position_noise, orientation_noise, stats);
   if (ctx) { ctx->fsem_set = false; ctx->carry_want = false; }      // the declared semantic fusion belongs to ONE frame, whatever became of it
@@ -1208,12 +1279,14 @@ static int update_impl(emap_ctx* ctx, const float R[9], const float t[3], double
   const bool tm = ctx->stage_timing;
   int rc;
 #define STAGE(i) do { if (tm) CK(hipEventRecord(ctx->ev[i], ctx->stream)); } while (0)
-  if (ctx->sf_err && *ctx->sf_err) {          // a grid barrier of an earlier k_small_frame gave up: that frame's result is undefined
-    ctx->sf_off = true; *ctx->sf_err = 0u;
-    ctx->err = "k_small_frame: a grid barrier was not released (the device did not hold the whole grid); the map is undefined from that frame on";
-    return EMAP_ERR_HIP;
-  }
   const bool rays_on = p.enable_visibility_cleanup != 0;
+  // robot scale (small clouds on small maps: the atomic path): count, gate, fuse and commit / average in ONE launch
+  static const bool sf_env_off = getenv("EMAP_SMALL_FRAME") && atoi(getenv("EMAP_SMALL_FRAME")) == 0;      // A/B and test hook
+  const bool atomic_path = !(ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts_all >= 131072));      // (emap_count's choice)
+  // (not with a visibility pass or a declared semantic fusion behind it: an ABORTED launch must leave nothing for the rest of the frame to
+  // act on -- the stencil launch that follows is a pure function of the map -- until sf_recover has re-run the frame)
+  const int sf_grid = (!sf_env_off && !ctx->sf_off && !ctx->sf_redo && atomic_path && ctx->cnt_sync && !ctx->pts_bucketed && !rays_on && !ctx->fsem_set) ? small_frame_grid(ctx->kp, ctx->n_pts) : 0;
+  if (sf_grid == 0) SF_CHECK();                 // (a frame on any other path: the small frames in flight are settled first)
   if ((rc = frame_sem_begin(ctx, rays_on))) return rc;
   // clear_overlap_map rides on the kernel that rewrites the cells last (tile kernel / k_average, or k_ray_apply after a visibility pass)
   ctx->ov_args = overlap_args(ctx, t[2], p.enable_overlap_clearance != 0);
@@ -1221,19 +1294,29 @@ static int update_impl(emap_ctx* ctx, const float R[9], const float t[3], double
   // drift gate of elevation_mapping.py:346-349: with compensation off or both noises below their thresholds it cannot fire
   ctx->gate_possible = p.enable_drift_compensation && (position_noise > p.position_noise_thresh || orientation_noise > p.orientation_noise_thresh);
   ctx->pos_noise = position_noise; ctx->ori_noise = orientation_noise;
-  // robot scale (small clouds on small maps: the atomic path): count, gate, fuse and commit / average in ONE launch
-  static const bool sf_env_off = getenv("EMAP_SMALL_FRAME") && atoi(getenv("EMAP_SMALL_FRAME")) == 0;      // A/B and test hook
-  const bool atomic_path = !(ctx->scatter_mode == 2 || (ctx->scatter_mode == 0 && bins_possible(ctx) && ctx->n_pts_all >= 131072));      // (emap_count's choice)
-  const int sf_grid = (!sf_env_off && !ctx->sf_off && atomic_path && ctx->cnt_sync && !ctx->pts_bucketed) ? small_frame_grid(ctx->kp, ctx->n_pts) : 0;
   bool fused_small = false;
   if (sf_grid > 0) {
     if ((rc = ensure_barrier_word(ctx))) { ctx->ov_args.on = 0; return rc; }
+    sf_forget_applied(ctx);
+    if (ctx->sf_count == emap_ctx::SF_RING || ctx->sf_epoch >= 0x7ffffff0u) {      // no room to remember another frame (or the epochs wrap): settle the ones in flight
+      if ((rc = sf_settle(ctx))) { ctx->ov_args.on = 0; return rc; }
+      if (ctx->sf_epoch >= 0x7ffffff0u) { CK(hipStreamSynchronize(ctx->stream)); ctx->sf_epoch = 0u; ctx->sf_host[0] = 0u; }
+    }
     for (int e = ST_HIST; e <= ST_SCATTER; ++e) STAGE(e);
     ctx->frame_binned = false; ctx->use_override = false;
-    if (++ctx->sf_epoch == 0u) ctx->sf_epoch = 1u;
+    ++ctx->sf_epoch;
+    {   // what the launch stands for, should a barrier be aborted (sf_recover)
+      emap_ctx::SfFrame& f = ctx->sf_ring[(ctx->sf_head + ctx->sf_count) % emap_ctx::SF_RING];
+      f.epoch = ctx->sf_epoch; memcpy(f.R, R, sizeof f.R); memcpy(f.t, t, sizeof f.t); f.pn = position_noise; f.on = orientation_noise; f.mv = ctx->kp.mv;
+      f.pts = ctx->pts; f.n_pts = ctx->n_pts; f.n_pts_all = ctx->n_pts_all; f.stride = ctx->stride; f.chan = ctx->chan; f.n_cols = ctx->n_cols;
+      ++ctx->sf_count;
+    }
+    unsigned int spin = SF_SPIN_DEFAULT; int test_abort = 0;      // test hooks (read per frame: a test toggles them)
+    if (const char* e = getenv("EMAP_SF_SPIN_LIMIT")) { const long v = atol(e); if (v >= 1 && v <= (1L << 24)) spin = (unsigned int)v; }
+    if (const char* e = getenv("EMAP_SF_TEST_ABORT")) test_abort = atoi(e);
     launch_small_frame(ctx->stream, sf_grid, ctx->kp, make_pose(ctx, R, t), ctx->pts, ctx->n_pts, ctx->stride, ctx->cells, ctx->acc,
-                       ctx->cnt_plane, ctx->inert, ctx->ov_args, gate_args(ctx, position_noise, orientation_noise), ctx->frame, ctx->slots,
-                       ctx->cnt_sync, ctx->cnt_sync + 2048, ctx->sf_err_dev, ctx->sf_epoch, rays_on);
+                       ctx->cnt_plane, ctx->ov_args, gate_args(ctx, position_noise, orientation_noise), ctx->frame, ctx->frame_save, ctx->slots,
+                       ctx->cnt_sync, ctx->cnt_sync + 2048, ctx->sf_host_dev, ctx->sf_poison, ctx->sf_epoch, spin, test_abort);
     CK(hipGetLastError());
     fused_small = true;
     STAGE(ST_GATE);
@@ -1257,23 +1340,22 @@ static int update_impl(emap_ctx* ctx, const float R[9], const float t[3], double
   STAGE(ST_COMMIT);
   ctx->rays_fused = fused_avg && rays_on;
   if (rays_on) {
-    if (fused_small) { ctx->committed = true; ctx->inert_zero = false; ctx->kp.mv.n = 0; }      // (what emap_commit leaves: k_small_frame wrote S1 and the bitmap)
-    else if (!fused_avg && (rc = emap_commit(ctx))) return rc;
+    if (!fused_avg && (rc = emap_commit(ctx))) return rc;
     STAGE(ST_RAYS);
     rc = emap_rays(ctx, R, t);
     if (rc) { ctx->rays_fused = false; return rc; }
   } else STAGE(ST_RAYS);
   STAGE(ST_AVERAGE);
-  if (fused_small && !rays_on) ctx->kp.mv.n = 0;            // (k_small_frame committed and averaged: every cell rewritten)
+  if (fused_small) ctx->kp.mv.n = 0;                        // (k_small_frame committed and averaged: every cell rewritten)
   else if (!fused_avg) { launch_average(ctx->stream, ctx->kp, ctx->cells, ctx->acc, ctx->accr, ctx->frame, ctx->committed, rays_on, ctx->cnt_plane, ov); ctx->kp.mv.n = 0; }
   else if (rays_on) { launch_ray_apply(ctx->stream, ctx->kp, ctx->cells, ctx->accr, ctx->inert, ov, ctx->frame, ctx->split.need_host ? ctx->split.need_host + 1 : nullptr, ctx->ray_par ^= 1); ctx->inert_zero = true; }
   ctx->committed = false; ctx->rays_fused = false;
   CK(hipGetLastError());
   if ((rc = frame_sem_finish(ctx, R, t))) return rc;      // semantic_map.update_layers_pointcloud (elevation_mapping.py:368) -- unless the tile kernel fused the channels itself
   STAGE(ST_OVERLAP);
-  if (p.enable_overlap_clearance && !ov_folded && (rc = emap_overlap_clear(ctx, t[2]))) return rc;
+  if (p.enable_overlap_clearance && !ov_folded && (rc = overlap_clear_impl(ctx, t[2]))) return rc;
   STAGE(ST_POST);
-  if ((rc = emap_post(ctx))) return rc;
+  if ((rc = post_part_impl(ctx, 0))) return rc;
   STAGE(ST_N);
 #undef STAGE
   if (tm) {
@@ -1287,7 +1369,7 @@ static int update_impl(emap_ctx* ctx, const float R[9], const float t[3], double
 // ---- state access -------------------------------------------------------------------------------------------
 // Views are (row_count, cell_n) host arrays in LOGICAL order (k_plane_view / k_get_plane): row j = logical row j of a full map,
 // or the j-th logical row of a strip (emap_strip_logical_begin), columns logical.
-static int plane_view(emap_ctx* ctx, int plane, float* host, bool to_device) {
+static int plane_view(emap_ctx* ctx, int plane, float* host, bool to_device) { SF_CHECK();
   const size_t bytes = sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n;
   FLUSH();
   if (to_device) CK(hipMemcpyAsync(ctx->scratch, host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -1310,7 +1392,7 @@ int emap_get_layer(emap_ctx* ctx, int plane, float* host_out) {
 }
 
 int emap_publish_layer(emap_ctx* ctx, int32_t kind, float center_z, int32_t use_only_above_for_upper_bound, float* host_out) {
-  CKARG(ctx && host_out && kind >= 0 && kind <= 8, "bad argument");
+  CKARG(ctx && host_out && kind >= 0 && kind <= 8, "bad argument"); SF_CHECK();
   CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "emap_publish_layer: single-strip contexts only");
   CK(hipSetDevice(ctx->device));
   FLUSH();
@@ -1329,7 +1411,7 @@ int emap_set_layer(emap_ctx* ctx, int plane, const float* host_in) {
 }
 
 int emap_strip_logical_begin(emap_ctx* ctx, int32_t* logical_row) {
-  CKARG(ctx && logical_row, "null argument");
+  CKARG(ctx && logical_row, "null argument"); SF_CHECK();
   const int C = ctx->prm.cell_n;
   *logical_row = ctx->strip.row_count == C ? 0 : ((ctx->strip.row_begin - ctx->kp.org_r) % C + C) % C;
   return EMAP_OK;
@@ -1340,7 +1422,7 @@ int emap_strip_logical_begin(emap_ctx* ctx, int32_t* logical_row) {
 // and the next full rewrite of the cells writes out; only the semantic layers clear their entering band here (O(border) bytes).
 // The normal planes and traversability_input keep their own origin: the reference does not shift them.
 int emap_shift(emap_ctx* ctx, int32_t shift_rows, int32_t shift_cols, float dz) {
-  CKARG(ctx, "null ctx");
+  CKARG(ctx, "null ctx"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   const int C = ctx->prm.cell_n;
   CKARG(shift_rows > -(1 << 20) && shift_rows < (1 << 20) && shift_cols > -(1 << 20) && shift_cols < (1 << 20), "absurd shift");   // (a shift of cell_n or more resets every cell: the replay predicate covers it)
@@ -1362,7 +1444,7 @@ int emap_shift(emap_ctx* ctx, int32_t shift_rows, int32_t shift_cols, float dz) 
 
 // ---- RGB / semantic layers (EM/semantic_map.py, EM/fusion/pointcloud_{average,class_average,color}.py) -------------
 int emap_semantic_configure(emap_ctx* ctx, int32_t n_layers) {
-  CKARG(ctx && n_layers >= 0 && n_layers <= 64, "bad layer count");
+  CKARG(ctx && n_layers >= 0 && n_layers <= 64, "bad layer count"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   const long n = ctx->ncells_alloc;
   if (!ctx->cnt_plane) {
@@ -1469,7 +1551,7 @@ static int frame_sem_finish(emap_ctx* ctx, const float R[9], const float t[3]) {
 }
 
 int emap_semantic_update(emap_ctx* ctx, const float R[9], const float t[3], const emap_sem_spec* spec) {
-  CKARG(ctx && R && t && spec, "null argument"); NEED_POINTS();
+  CKARG(ctx && R && t && spec, "null argument"); SF_CHECK(); NEED_POINTS();
   SemSpec S;
   int rc = sem_spec_checked(ctx, spec, &S);
   if (rc) return rc;
@@ -1581,7 +1663,7 @@ int emap_semantic_finalize(emap_ctx* ctx, int32_t op, void* newmap_inout, int32_
 // pinned by the reference's own statements executed from its file (tests/golden/class_max_ref66.npz).
 int emap_semantic_class_max(emap_ctx* ctx, const float R[9], const float t[3], int32_t n_ch, const int32_t* chan, const int32_t* layer,
                             const uint32_t* prev_unique, int32_t n_prev, uint32_t* unique_out, int32_t unique_cap, int32_t* n_unique_out) {
-  CKARG(ctx && R && t && chan && layer && unique_out && n_unique_out && n_ch >= 1 && n_ch <= 8 && n_prev >= 0 && (n_prev == 0 || prev_unique), "bad argument");
+  CKARG(ctx && R && t && chan && layer && unique_out && n_unique_out && n_ch >= 1 && n_ch <= 8 && n_prev >= 0 && (n_prev == 0 || prev_unique), "bad argument"); SF_CHECK();
   // the id set and the planes zeroed between two layers are properties of the WHOLE map: a row strip would take them from its own rows
   CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "class_max: single-strip contexts only");
   NEED_POINTS();
@@ -1638,7 +1720,7 @@ int emap_semantic_class_max(emap_ctx* ctx, const float R[9], const float t[3], i
   return EMAP_OK;
 }
 
-static int sem_view(emap_ctx* ctx, float* planes, int32_t layer, float* host, bool to_device) {   // semantic layers share the map's origin
+static int sem_view(emap_ctx* ctx, float* planes, int32_t layer, float* host, bool to_device) { SF_CHECK();   // semantic layers share the map's origin
   const size_t bytes = sizeof(float) * (size_t)ctx->strip.row_count * ctx->prm.cell_n;
   if (to_device) CK(hipMemcpyAsync(ctx->scratch, host, bytes, hipMemcpyHostToDevice, ctx->stream));
   launch_plane_view(ctx->stream, ctx->kp, ctx->kp.org_r, ctx->kp.org_c, planes + (long)layer * ctx->ncells_alloc, ctx->scratch, to_device);
@@ -1671,7 +1753,7 @@ int emap_semantic_set_layer(emap_ctx* ctx, int32_t layer, const float* host_in) 
   return sem_view(ctx, ctx->sem, layer, const_cast<float*>(host_in), true);
 }
 int emap_semantic_clear(emap_ctx* ctx) {
-  CKARG(ctx, "null ctx");
+  CKARG(ctx, "null ctx"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   if (ctx->sem_layers > 0) CK(hipMemsetAsync(ctx->sem, 0, sizeof(float) * ctx->ncells_alloc * ctx->sem_layers, ctx->stream));
   return EMAP_OK;
@@ -1797,7 +1879,7 @@ int emap_inpaint_u8(emap_ctx* ctx, const float* host_image, const float* host_kn
 // ---- camera path (EM/elevation_mapping.py:468-562, EM/kernels/custom_image_kernels.py) -------------------------------
 int emap_image_correspondence(emap_ctx* ctx, float x1, float y1, float z1, const float P[12], const float K[9], const float D[5],
                               float image_height, float image_width, const float center[3]) {
-  CKARG(ctx && P && K && D && center, "null argument");
+  CKARG(ctx && P && K && D && center, "null argument"); SF_CHECK();
   CKARG(ctx->strip.halo_rows == 0 && ctx->strip.row_count == ctx->prm.cell_n, "camera path: single-strip contexts only");
   CK(hipSetDevice(ctx->device));
   FLUSH();
@@ -1811,7 +1893,7 @@ int emap_image_correspondence(emap_ctx* ctx, float x1, float y1, float z1, const
   return EMAP_OK;
 }
 int emap_image_get_correspondence(emap_ctx* ctx, float* uv_host, uint8_t* valid_host) {
-  CKARG(ctx && uv_host && valid_host && ctx->img_uv, "no correspondence computed yet");
+  CKARG(ctx && uv_host && valid_host && ctx->img_uv, "no correspondence computed yet"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   const size_t L = (size_t)ctx->prm.cell_n * ctx->prm.cell_n;
   CK(hipMemcpyAsync(uv_host, ctx->img_uv, sizeof(float) * 2 * L, hipMemcpyDeviceToHost, ctx->stream));
@@ -1821,7 +1903,7 @@ int emap_image_get_correspondence(emap_ctx* ctx, float* uv_host, uint8_t* valid_
 }
 int emap_image_fuse(emap_ctx* ctx, int32_t kind, int32_t layer, const float* host_image, int32_t n_planes, int32_t height, int32_t width,
                     double alpha) {
-  CKARG(ctx && host_image && kind >= 0 && kind <= 2 && layer >= 0 && layer < ctx->sem_layers, "bad argument");
+  CKARG(ctx && host_image && kind >= 0 && kind <= 2 && layer >= 0 && layer < ctx->sem_layers, "bad argument"); SF_CHECK();
   CKARG(ctx->img_uv, "emap_image_correspondence must run first");
   CKARG(n_planes >= (kind == 1 ? 3 : 1) && height > 0 && width > 0, "bad image shape");
   CK(hipSetDevice(ctx->device));
@@ -1850,7 +1932,7 @@ int emap_image_set_tolerance(emap_ctx* ctx, double tolerance_z_collision) {
 // one out; cells without a valid correspondence keep their value (the reference's else branch copies sem_map to new_sem_map)
 int emap_image_fuse_arrays(emap_ctx* ctx, int32_t kind, const float* sem_plane, const float* host_image, int32_t n_planes, int32_t height,
                            int32_t width, const float* uv, const uint8_t* valid, double alpha, float* out_plane) {
-  CKARG(ctx && sem_plane && host_image && uv && valid && out_plane && kind >= 0 && kind <= 2, "bad argument");
+  CKARG(ctx && sem_plane && host_image && uv && valid && out_plane && kind >= 0 && kind <= 2, "bad argument"); SF_CHECK();
   CKARG(n_planes >= (kind == 1 ? 3 : 1) && height > 0 && width > 0, "bad image shape");
   CK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -1946,7 +2028,7 @@ int emap_halo_bytes(emap_ctx* ctx, int64_t* bytes_per_side) {
   return EMAP_OK;
 }
 int emap_halo_pack(emap_ctx* ctx, int side, float* dev_buf) {
-  CKARG(ctx && dev_buf && (side == 0 || side == 1), "bad argument");
+  CKARG(ctx && dev_buf && (side == 0 || side == 1), "bad argument"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
   if (H == 0) return EMAP_OK;
@@ -1956,7 +2038,7 @@ int emap_halo_pack(emap_ctx* ctx, int side, float* dev_buf) {
   return EMAP_OK;
 }
 int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf) {
-  CKARG(ctx && dev_buf && (side == 0 || side == 1), "bad argument");
+  CKARG(ctx && dev_buf && (side == 0 || side == 1), "bad argument"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
   if (H == 0) return EMAP_OK;
@@ -1969,7 +2051,7 @@ int emap_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf) {
 // (see normal_exchange); emap_normal_row_lag tells the caller whether it is due
 int emap_normal_row_lag(emap_ctx* ctx, int32_t* lag) { CKARG(ctx && lag, "null argument"); *lag = normal_row_lag(ctx); return EMAP_OK; }
 int emap_normal_halo_pack(emap_ctx* ctx, int side, float* dev_buf) {
-  CKARG(ctx && dev_buf && (side == 0 || side == 1), "bad argument");
+  CKARG(ctx && dev_buf && (side == 0 || side == 1), "bad argument"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
   if (H == 0) return EMAP_OK;
@@ -1979,7 +2061,7 @@ int emap_normal_halo_pack(emap_ctx* ctx, int side, float* dev_buf) {
   return EMAP_OK;
 }
 int emap_normal_halo_unpack(emap_ctx* ctx, int side, const float* dev_buf) {
-  CKARG(ctx && dev_buf && (side == 0 || side == 1), "bad argument");
+  CKARG(ctx && dev_buf && (side == 0 || side == 1), "bad argument"); SF_CHECK();
   CK(hipSetDevice(ctx->device));
   const long H = ctx->strip.halo_rows, C = ctx->prm.cell_n, n = ctx->strip.row_count;
   if (H == 0) return EMAP_OK;
@@ -2304,7 +2386,7 @@ int emap_update_sharded(emap_ctx* ctx, const float R[9], const float t[3], doubl
   return rc;
 }
 static int update_sharded_impl(emap_ctx* ctx, const float R[9], const float t[3], double position_noise, double orientation_noise, emap_stats* stats) {
-  CKARG(ctx && R && t, "null argument"); NEED_POINTS();
+  CKARG(ctx && R && t, "null argument"); SF_CHECK(); NEED_POINTS();
   CKARG(ctx->rccl && ctx->comm, "emap_comm_init has not been called");
   CK(hipSetDevice(ctx->device));
   const emap_params& p = ctx->prm;
@@ -2398,7 +2480,7 @@ int emap_comm_count(emap_ctx* ctx, int32_t* ranks) {
 // cell_n x cell_n device plane and the planes are all-reduced (x + 0 + ... + 0 is exact for every x; only -0.0 comes back as +0.0).
 // Read-back for publishing on a sharded map; not on the per-frame path.
 int emap_comm_gather_layer(emap_ctx* ctx, int32_t plane, float* host_full_out) {
-  CKARG(ctx && ctx->rccl && ctx->comm, "emap_comm_init has not been called");
+  CKARG(ctx && ctx->rccl && ctx->comm, "emap_comm_init has not been called"); SF_CHECK();
   CKARG(host_full_out && plane >= 0 && plane < EMAP_PLANE_COUNT, "bad argument");
   CK(hipSetDevice(ctx->device));
   FLUSH();
@@ -2481,6 +2563,7 @@ int emap_timer_end(emap_ctx* ctx, float* ms) {
   return EMAP_OK;
 }
 int emap_enable_stage_timing(emap_ctx* ctx, int enable) { CKARG(ctx, "null ctx"); ctx->stage_timing = enable != 0; ctx->want_ray_stats = enable > 1; return EMAP_OK; }
+int emap_small_frame_aborts(emap_ctx* ctx, uint32_t* frames) { CKARG(ctx && frames, "null argument"); SF_CHECK(); *frames = ctx->sf_aborts; return EMAP_OK; }
 int emap_last_update_path(emap_ctx* ctx, int32_t* path) { CKARG(ctx && path, "null argument"); *path = ctx->update_path; return EMAP_OK; }
 int emap_get_stage_times(emap_ctx* ctx, float ms_out[10]) { CKARG(ctx && ms_out, "null argument"); for (int i = 0; i < ST_N; ++i) ms_out[i] = ctx->stage_ms[i]; return EMAP_OK; }
 

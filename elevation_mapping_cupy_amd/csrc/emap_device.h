@@ -78,6 +78,7 @@ struct FrameDev {                  // per-frame scalars that stay on the device 
   unsigned int ray_class, pad_;
 };
 
+static_assert(sizeof(FrameDev) % 8 == 0, "FrameDev is copied as 64-bit words (k_small_frame)");
 #define EM_SCALE_H 4294967296.0          /* 2^32 */
 #define EM_SCALE_V 1099511627776.0       /* 2^40 */
 #define EM_SCALE_E 68719476736.0         /* 2^36 */
@@ -350,12 +351,18 @@ __device__ __forceinline__ bool last_block_ticket(unsigned int* __restrict__ syn
 }
 
 // ---- grid-wide barrier of the single-launch kernel (k_small_frame) --------------------------------------------------------------
-// Every workgroup of the grid is RESIDENT (the host bounds the grid by what the device holds: small_frame_grid).  A barrier is the
-// two-level ticket above + one release word the waiting workgroups poll with device-coherent loads.  What a phase publishes for the
-// next one goes out as device-scope atomics / device-coherent (sc1) stores BEFORE the arrival (s_waitcnt: acknowledged) and is read
-// back with device-coherent loads after the release -- the hand-off of last_block_ticket, see the note there.  The release word holds
-// the epoch of the last launch that passed (distinct per launch, never 0).  A wait that is not released within ~2 s gives up (the
-// frame's result is then undefined) and sets a host-mapped word: the next call on the context fails loudly instead of the box hanging.
+// The host bounds the grid by a quarter of what the device holds (small_frame_grid), so every workgroup CAN be resident; whether it
+// IS depends on what else runs on the device.  A barrier is the two-level ticket above + one 64-bit release word the waiting
+// workgroups poll with device-coherent loads.  What a phase publishes for the next one goes out as device-scope atomics /
+// device-coherent (sc1) stores BEFORE the arrival (s_waitcnt: acknowledged) and is read back with device-coherent loads after the
+// release -- the hand-off of last_block_ticket, see the note there.
+// Outcome of a barrier (round 6): ONE decision for the whole grid, taken by a compare-and-swap on the release word.  Its low half holds
+// the epoch of the last launch that passed (distinct per launch, 1 .. 2^31 - 1), the high half that launch's payload (barrier 1: the
+// drift shift).  The last workgroup to arrive swaps {old -> epoch | payload}: released.  A waiter whose patience runs out (SF spin
+// limit, ~0.1 s: a foreign grid is holding the CUs the rest of this grid needs) swaps {old -> epoch | SF_ABORT}: aborted.  Whoever
+// loses the swap reads the winner's word.  Either EVERY workgroup passes or EVERY workgroup -- those that arrive later included --
+// takes the abort path: k_small_frame then puts its accumulators back and leaves the map as the launch found it; the host re-runs the frame on the chain of launches at its next call (emap_api.hip: sf_recover).  Nothing hangs, nothing is
+// left undefined.
 // What such a barrier costs on MI355X (measured, round 5): it is a chain of four to five DEPENDENT trips to the memory side
 // (acknowledgements, group ticket, root ticket, release store, poll), 1.5-2 us each, i.e. 6-8 us -- more than the ~4.5 us a launch
 // boundary occupies the stream, of which only ~1 us is not hidden behind the previous kernel's tail.  A barrier therefore only pays
@@ -365,8 +372,9 @@ __device__ __forceinline__ bool last_block_ticket(unsigned int* __restrict__ syn
 // k_small_frame: a release word per ticket group instead of one (25.4 us: the polls are not what costs); one ever-growing counter that
 // every workgroup adds to WITHOUT waiting and then polls, the gate evaluated redundantly by every workgroup (29.2 us: 196 atomics and
 // 196 pollers on ONE address serialise at ~10 ns each, the late arrivals queue behind the early ones' polls).
-#define SF_SPIN_LIMIT (1u << 21)
-// every thread of the grid calls this; true in all threads of the LAST workgroup to arrive (which runs its serial section and then sf_release)
+#define SF_ABORT 0x80000000u
+#define SF_SPIN_DEFAULT (1u << 15)      /* polls of ~4 us each under contention (measured: 2000 polls = 8.5 ms): ~0.13 s */
+// every thread of the grid calls this; true in all threads of the LAST workgroup to arrive (which then calls sf_decide_last)
 __device__ __forceinline__ bool sf_arrive(unsigned int* sync, bool* s_last) {
   __builtin_amdgcn_s_waitcnt(0);                               // this wave's atomics / device-coherent stores are acknowledged
   __syncthreads();
@@ -374,20 +382,33 @@ __device__ __forceinline__ bool sf_arrive(unsigned int* sync, bool* s_last) {
   __syncthreads();
   return *s_last;
 }
-__device__ __forceinline__ void sf_release(unsigned int* flag, unsigned int epoch) {
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ONE thread of the last workgroup to arrive: release the grid with `payload`; returns the word that stands (low half epoch: released,
+// epoch | SF_ABORT: a waiter gave up first)
+__device__ __forceinline__ unsigned long long sf_decide_last(unsigned long long* rel, unsigned int epoch, unsigned int payload) {
+  unsigned long long old = __hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long want = (unsigned long long)epoch | ((unsigned long long)payload << 32);
+  if ((unsigned int)old == (epoch | SF_ABORT)) return old;
+  if (__hip_atomic_compare_exchange_strong(rel, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return want;
+  return old;                                                  // (the only other writer of this launch: a waiter's abort)
 }
-__device__ __forceinline__ void sf_wait(const unsigned int* flag, unsigned int epoch, unsigned int* err_host) {
-  if (threadIdx.x == 0) {
-    unsigned int it = 0u;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++it > SF_SPIN_LIMIT) { __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+// ONE thread of every other workgroup: wait for the decision; `impatient`: give up at once (test hook).  err_host: host-mapped word
+// that learns of the abort (code: the launch's epoch).
+__device__ __forceinline__ unsigned long long sf_wait_decision(unsigned long long* rel, unsigned int epoch, unsigned int spin_limit, bool impatient,
+                                                               unsigned int* err_host, unsigned int code) {
+  unsigned int it = 0u;
+  for (;;) {
+    unsigned long long w = __hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (((unsigned int)w & ~SF_ABORT) == epoch) return w;      // released or aborted
+    if (impatient || ++it > spin_limit) {
+      const unsigned long long ab = (unsigned long long)(epoch | SF_ABORT);
+      if (__hip_atomic_compare_exchange_strong(rel, &w, ab, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return ab;
+      }
+      return w;                                                // lost the swap: w is the last arriver's release (the only other writer)
     }
+    __builtin_amdgcn_s_sleep(1);
   }
-  __syncthreads();
 }
 
 // ---- drift gate (elevation_mapping.py:346-352) --------------------------------------------------------------------------

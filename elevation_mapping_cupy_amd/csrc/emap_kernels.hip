@@ -649,31 +649,41 @@ __global__ __launch_bounds__(EM_BLOCK) void k_average(KP P, Cells cells, AccF* _
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Robot scale (round 5): phases A, A', B and B' / D of a small frame in ONE launch.
+// Robot scale (round 5): phases A, A', B and B' + D of a small frame in ONE launch.
 // The configuration the reference ships (202^2 cells, ~50 k points per cloud: parameter.py:137,165) is neither bandwidth nor
 // issue bound here: its frame is a chain of dependent launches of 2-4 us of work each, and every launch costs ~4.5 us of dispatch +
-// drain on this stack.  k_small_frame runs count -> gate -> fuse -> commit+average (or, in front of a visibility pass, commit + inert
-// bitmap) as ONE grid with two grid-wide barriers in between: every workgroup is resident (launch_small_frame bounds the grid by a
-// quarter of what the device holds), a barrier is k_bin_scan's two-level ticket + one release word the waiting workgroups poll.
+// drain on this stack.  k_small_frame runs count -> gate -> fuse -> commit + average as ONE grid with two grid-wide barriers in
+// between (emap_device.h: sf_arrive / sf_decide_last / sf_wait_decision):
 //   * a thread keeps ITS point (geometry, cell, the cell's hot half) in registers from the count to the fuse phase: the cloud is read
 //     and transformed once per frame instead of twice;
 //   * what one phase writes and the next reads on ANOTHER XCD (per-cell counts, the accumulators, the shift) only ever moves through
 //     device-scope atomics and device-coherent (sc1) loads / stores -- the XCDs' L2s are not coherent with each other inside a launch.
 //     Same hand-off as last_block_ticket: stores acknowledged (s_waitcnt), workgroup barrier, ticket; see the note there;
-//   * the arithmetic is k_count's, k_fuse's and k_commit's / k_average's, statement for statement: the accumulators are integers,
-//     so the frame is bit-identical to the chain of launches (tests/test_hip_small_frame.py), which stays as the staged API, as the
-//     path of larger maps / clouds and as the fallback when the device cannot hold the grid.
-// A barrier that is not released within ~2 s (another grid holding the device: cannot happen to a grid this size on an MI355X that
-// is not partitioned, but a hang would take the whole box down) gives up, the frame's result is then undefined and the host-mapped
-// word makes the next call fail loudly (emap_api.hip).
+//   * the arithmetic is k_count's, k_fuse's and k_average's, statement for statement: the accumulators are integers, so the frame is
+//     bit-identical to the chain of launches (tests/test_hip_small_frame.py), which stays as the staged API, as the path of larger
+//     maps / clouds, of frames with a visibility pass or a declared semantic fusion, and as the way a frame is RE-RUN after an abort.
+// Round 6 -- a barrier can no longer leave the map undefined.  The grid fits the device four times over, but it is not a cooperative
+// launch: while another process' kernels hold the CUs, part of this grid may wait at a barrier for workgroups that have not started.
+// A waiter that runs out of patience ABORTS the barrier for the whole grid, consistently (one compare-and-swap decides between
+// "released" and "aborted"): every workgroup -- those that only start afterwards included -- then leaves at that barrier, and the LAST
+// one to arrive there (every other workgroup's atomics are acknowledged by then, nobody writes any more) puts things back: the frame
+// accumulators and the error slots to zero (what every launch finds), the frame record to what the gate found.  No cell is written
+// before the second barrier has passed: after an abort the map, the accumulators and the drift record are bit for bit what the
+// launch found.  The aborting launch also raises a device-side POISON word: the k_small_frame launches already queued behind it
+// (frames may be pipelined) find it and leave at once, so no later frame is fused onto a map that lacks an earlier one.  Two
+// host-mapped words keep the host informed -- [0] the epoch of the last launch whose second barrier passed, [1] the epoch of the first
+// aborted launch -- and the host re-runs the aborted frame and every small frame issued after it, in order, on the chain of
+// launches, before anything else looks at the map (emap_api.hip: sf_settle / sf_recover).
 // ---------------------------------------------------------------------------------------------------------
 struct SmallFrame {
-  GateArgs A; FrameDev* F; ErrSlot* slots;
+  GateArgs A; FrameDev* F; FrameDev* F_save; ErrSlot* slots;
   unsigned int* sync;        // two sets of ticket words (1024 apart), zero between launches
-  unsigned int* flag;        // [0..1]: release word of barrier 1, 8 bytes {epoch of the last launch that passed, that frame's shift}; [32]: release word of barrier 2
-  unsigned int* err_host;    // host-mapped: a barrier gave up
-  unsigned int epoch;        // distinct per launch, never 0
-  int rays;                  // 1: a visibility pass follows (phase B' = k_commit: S1 + inert bitmap); 0: commit + average (k_average<false, false>)
+  unsigned int* flag;        // 64-bit release words: [0..1] barrier 1 {epoch [| SF_ABORT], that frame's shift}; [32..33] barrier 2
+  unsigned int* host;        // host-mapped: [0] epoch of the last launch whose second barrier passed, [1] epoch of the first aborted launch (0: none)
+  unsigned int* poison;      // device word, non-zero: an earlier launch was aborted and the host has not re-run it yet -- do nothing
+  unsigned int epoch;        // distinct per launch, 1 .. 2^31 - 1
+  unsigned int spin_limit;   // polls before a waiter gives up
+  int test_abort;            // test hook: workgroup 0 gives up at once at barrier 1 / 2 (0: never)
 };
 __device__ __forceinline__ unsigned long long ld_dev(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -685,8 +695,10 @@ __device__ __forceinline__ AccF acc_load_dev(const AccF* a) {
 template <int MODE>
 __global__ __launch_bounds__(EM_BLOCK) void k_small_frame(KP P, Pose T, const float* __restrict__ pts, long n, int stride, Cells cells,
                                                            AccF* __restrict__ acc, unsigned int* __restrict__ cnt_out,
-                                                           unsigned long long* __restrict__ inert, OverlapArgs O, SmallFrame S) {
+                                                           OverlapArgs O, SmallFrame S) {
   __shared__ bool s_last;
+  __shared__ unsigned long long s_word;
+  const unsigned int poisoned = __hip_atomic_load(S.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (written by an EARLIER launch: the same for every workgroup; needed in front of the first atomic)
   const long i = (long)blockIdx.x * EM_BLOCK + threadIdx.x;          // one point per thread (the host launches at least n threads)
   // ---- phase A: k_count ------------------------------------------------------------------------------------------------------
   long c = -1;
@@ -707,9 +719,11 @@ __global__ __launch_bounds__(EM_BLOCK) void k_small_frame(KP P, Pose T, const fl
       const bool inlier = m.z > 0.5f && (double)fabsf(m.x - gz) < (double)m.y * P.mt && (double)m.y < P.dcvi_half &&
                           (double)m.w > P.trav_inlier;
       if (inlier) { inl = 1; e_fix = __double2ll_rn((double)(gz - m.x) * EM_SCALE_E); }
+      if (poisoned) return;                                           // (uniform over the grid)
       atomicAdd(&acc[c].pts_inl, 1ull | ((unsigned long long)inl << 32));
     }
   }
+  if (poisoned) return;
   if (__any(inl)) {
     const long long s = wave_sum_ll(e_fix);
     const unsigned long long k = __popcll(__ballot(inl));
@@ -719,32 +733,38 @@ __global__ __launch_bounds__(EM_BLOCK) void k_small_frame(KP P, Pose T, const fl
       atomicAdd(&S.slots[slot].cnt, k);
     }
   }
+  // an aborted barrier, in the LAST workgroup to arrive at it: every accumulator word and every error slot back to zero, and the poison
+  // word raised for the launches queued behind this one
+  auto wipe = [&]() {
+    if (threadIdx.x == 0) __hip_atomic_store(S.poison, S.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long nall = (long)(P.nrows + 2 * P.halo) * P.C;
+    for (long k = threadIdx.x; k < nall * 5; k += EM_BLOCK) st_dev(reinterpret_cast<unsigned long long*>(acc) + k, 0ull);
+    for (int k = threadIdx.x; k < EM_ERR_SLOTS; k += EM_BLOCK) { st_dev(reinterpret_cast<unsigned long long*>(&S.slots[k].sum), 0ull); st_dev(&S.slots[k].cnt, 0ull); }
+  };
   // ---- barrier 1; the last workgroup to arrive is the drift gate (k_gate) ------------------------------------------------------------
   // It releases the others WITH the shift -- one 8-byte word {epoch, shift} -- as soon as it has the slot sums, and does the gate's
   // bookkeeping (frame record, additive_mean_error, slots re-armed: nothing anybody reads in this launch) afterwards: a separate shift
   // word cost two more dependent trips to the memory side per frame (its acknowledgement before the release, its load after the wait).
-  __shared__ float s_shift;
-  unsigned long long* const rel = reinterpret_cast<unsigned long long*>(S.flag);
-  if (sf_arrive(S.sync, &s_last)) {                                  // (this workgroup's own phase-A results were acknowledged before it took its ticket)
+  unsigned long long* const rel1 = reinterpret_cast<unsigned long long*>(S.flag);
+  unsigned long long* const rel2 = reinterpret_cast<unsigned long long*>(S.flag + 32);
+  const bool last1 = sf_arrive(S.sync, &s_last);                     // (this workgroup's own phase-A results were acknowledged before it took its ticket)
+  if (last1) {
     if (threadIdx.x < 64) {
       const float sh = gate_shift_only(S.A, S.slots, (int)threadIdx.x);
-      if (threadIdx.x == 0) {
-        st_dev(rel, (unsigned long long)S.epoch | ((unsigned long long)__float_as_uint(sh) << 32));
-        s_shift = sh;
+      unsigned long long w = 0ull;
+      if (threadIdx.x == 0) { w = sf_decide_last(rel1, S.epoch, __float_as_uint(sh)); s_word = w; }
+      w = __shfl(w, 0, 64);
+      if (!((unsigned int)w & SF_ABORT)) {
+        // the frame record as the gate finds it: what an abort of the SECOND barrier puts back (device-coherent: read by another workgroup)
+        if (threadIdx.x < (int)(sizeof(FrameDev) / 8)) st_dev(reinterpret_cast<unsigned long long*>(S.F_save) + threadIdx.x, reinterpret_cast<const unsigned long long*>(S.F)[threadIdx.x]);
+        gate_eval(S.A, S.slots, S.F, (int)threadIdx.x, 0, nullptr, nullptr);
       }
-      gate_eval(S.A, S.slots, S.F, (int)threadIdx.x, 0, nullptr, nullptr);
     }
-  } else if (threadIdx.x == 0) {
-    unsigned int it = 0u;
-    unsigned long long w;
-    while ((unsigned int)(w = ld_dev(rel)) != S.epoch) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++it > SF_SPIN_LIMIT) { __hip_atomic_store(S.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-    }
-    s_shift = __uint_as_float((unsigned int)(w >> 32));
-  }
+  } else if (threadIdx.x == 0) s_word = sf_wait_decision(rel1, S.epoch, S.spin_limit, S.test_abort == 1 && blockIdx.x == 0, S.host + 1, S.epoch);
   __syncthreads();
-  const float shift = s_shift;
+  const unsigned long long w1 = s_word;
+  if ((unsigned int)w1 & SF_ABORT) { if (last1) wipe(); return; }    // (uniform over the GRID: one compare-and-swap decided)
+  const float shift = __uint_as_float((unsigned int)(w1 >> 32));
   // ---- phase B: k_fuse against snapshot S0 ---------------------------------------------------------------------------------------
   if (c >= 0) {
     unsigned long long* const a = reinterpret_cast<unsigned long long*>(acc + c);      // pts_inl, cnt_out, sum_h, sum_v, latest
@@ -770,44 +790,33 @@ __global__ __launch_bounds__(EM_BLOCK) void k_small_frame(KP P, Pose T, const fl
     }
   }
   // ---- barrier 2 -------------------------------------------------------------------------------------------------------------------
-  if (sf_arrive(S.sync + 1024, &s_last)) sf_release(S.flag + 32, S.epoch);
-  else sf_wait(S.flag + 32, S.epoch, S.err_host);
-  // ---- per cell --------------------------------------------------------------------------------------------------------------------
-  if (!S.rays) {                                                    // k_average<false, false>: commit + average + overlap clearing + re-arm
-    const long ncell = (long)P.nrows * P.C, gstride = (long)gridDim.x * EM_BLOCK;
-    for (long li = i; li < ncell; li += gstride) {
-      const long cc = li + (long)P.halo * P.C;
-      Cell q = cells[cc];
-      const AccF a = acc_load_dev(acc + cc);
-      const int lrow = (int)(li / P.C), pcol = (int)(li - (long)lrow * P.C);
-      if (P.mv.n) cell_now(P, q, P.row0 + lrow, pcol);               // pending map shifts
-      q.h += shift; commit_cell(P, q, a);
-      if (cnt_out) cnt_out[cc] = (unsigned int)(a.cnt_out & 0xffffffffull);
-      average_cell(P, q, a);
-      if (O.on && overlap_window(O, logi_row(P, P.row0 + lrow), logi_col(P, pcol))) overlap_cell(P, O, q);
-      cells[cc] = q;
-      if (a.pts_inl | a.cnt_out) { AccF z = {0ull, 0ull, 0ll, 0ll, 0ull}; acc[cc] = z; }
+  const bool last2 = sf_arrive(S.sync + 1024, &s_last);
+  if (threadIdx.x == 0)
+    s_word = last2 ? sf_decide_last(rel2, S.epoch, 0u) : sf_wait_decision(rel2, S.epoch, S.spin_limit, S.test_abort == 2 && blockIdx.x == 0, S.host + 1, S.epoch);
+  __syncthreads();
+  if ((unsigned int)s_word & SF_ABORT) {                             // (uniform over the grid)
+    if (last2) {                                                      // every other workgroup is through its phase B -- and through the gate's bookkeeping
+      wipe();
+      if (threadIdx.x < (int)(sizeof(FrameDev) / 8))
+        reinterpret_cast<unsigned long long*>(S.F)[threadIdx.x] = ld_dev(reinterpret_cast<const unsigned long long*>(S.F_save) + threadIdx.x);
     }
-  } else {                                                          // k_commit: S1 + the inert bitmap, one wave per word
-    const int wpr = (P.C + 63) / 64, lane = threadIdx.x & 63;
-    const long nw = (long)P.nrows * wpr, wstride = (long)gridDim.x * (EM_BLOCK / 64);
-    for (long w = (long)blockIdx.x * (EM_BLOCK / 64) + (threadIdx.x >> 6); w < nw; w += wstride) {
-      const int lrow = (int)(w / wpr), cg = (int)(w - (long)lrow * wpr), lcol = cg * 64 + lane, prow = P.row0 + lrow;
-      bool quiet = false;
-      if (lcol < P.C) {
-        const int pcol = phys_col(P, lcol);
-        const long cc = (long)(lrow + P.halo) * P.C + pcol;
-        Cell q = cells[cc];
-        cell_now(P, q, prow, pcol);
-        const AccF a = acc_load_dev(acc + cc);
-        q.h += shift;
-        commit_cell(P, q, a);
-        cells[cc] = q;
-        quiet = (!(q.valid < 0.5f) && q.time < 0.5f) || border_cell(P, logi_row(P, prow), lcol);
-      }
-      const unsigned long long bits = __ballot(quiet);
-      if (lane == 0) inert[(long)bitmap_row(P, prow) * wpr + cg] = bits;
-    }
+    return;
+  }
+  if (last2 && threadIdx.x == 0) __hip_atomic_store(S.host, S.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // the frame WILL be applied: the host may forget it
+  // ---- per cell: k_average<false, false> -- commit + average + overlap clearing + re-arm ---------------------------------------------
+  const long ncell = (long)P.nrows * P.C, gstride = (long)gridDim.x * EM_BLOCK;
+  for (long li = i; li < ncell; li += gstride) {
+    const long cc = li + (long)P.halo * P.C;
+    Cell q = cells[cc];
+    const AccF a = acc_load_dev(acc + cc);
+    const int lrow = (int)(li / P.C), pcol = (int)(li - (long)lrow * P.C);
+    if (P.mv.n) cell_now(P, q, P.row0 + lrow, pcol);               // pending map shifts
+    q.h += shift; commit_cell(P, q, a);
+    if (cnt_out) cnt_out[cc] = (unsigned int)(a.cnt_out & 0xffffffffull);
+    average_cell(P, q, a);
+    if (O.on && overlap_window(O, logi_row(P, P.row0 + lrow), logi_col(P, pcol))) overlap_cell(P, O, q);
+    cells[cc] = q;
+    if (a.pts_inl | a.cnt_out) { AccF z = {0ull, 0ull, 0ll, 0ll, 0ull}; acc[cc] = z; }
   }
 }
 
@@ -1589,12 +1598,14 @@ int small_frame_grid(const KP& P, long n) {
   return g <= limit ? (int)g : 0;
 }
 void launch_small_frame(hipStream_t s, int grid, const KP& P, const Pose& T, const float* pts, long n, int stride, Cells cells, AccF* acc,
-                        unsigned int* cnt_out, unsigned long long* inert, const OverlapArgs& O, const GateArgs& gate, FrameDev* F,
-                        ErrSlot* slots, unsigned int* sync, unsigned int* flag, unsigned int* err_host, unsigned int epoch, bool rays) {
+                        unsigned int* cnt_out, const OverlapArgs& O, const GateArgs& gate, FrameDev* F, FrameDev* F_save,
+                        ErrSlot* slots, unsigned int* sync, unsigned int* flag, unsigned int* host2, unsigned int* poison, unsigned int epoch,
+                        unsigned int spin_limit, int test_abort) {
   SmallFrame S; memset(&S, 0, sizeof S);
-  S.A = gate; S.F = F; S.slots = slots; S.sync = sync; S.flag = flag; S.err_host = err_host; S.epoch = epoch; S.rays = rays ? 1 : 0;
-  if (P.mode == 0) hipLaunchKernelGGL(k_small_frame<0>, dim3(grid), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, cnt_out, inert, O, S);
-  else hipLaunchKernelGGL(k_small_frame<1>, dim3(grid), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, cnt_out, inert, O, S);
+  S.A = gate; S.F = F; S.F_save = F_save; S.slots = slots; S.sync = sync; S.flag = flag; S.host = host2; S.poison = poison; S.epoch = epoch;
+  S.spin_limit = spin_limit; S.test_abort = test_abort;
+  if (P.mode == 0) hipLaunchKernelGGL(k_small_frame<0>, dim3(grid), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, cnt_out, O, S);
+  else hipLaunchKernelGGL(k_small_frame<1>, dim3(grid), dim3(EM_BLOCK), 0, s, P, T, pts, n, stride, cells, acc, cnt_out, O, S);
 }
 void launch_gate(hipStream_t s, const GateArgs& A, ErrSlot* slots, FrameDev* F, int reduce_only, double* dev_out, const double* dev_totals) {
   hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, A, slots, F, reduce_only, dev_out, dev_totals);

@@ -203,6 +203,13 @@ class ElevationMap:
         self._chk(self._lib.emap_last_update_path(self._ctx, ct.byref(v)))
         return {0: "atomic", 1: "binned", 2: "small_frame"}[v.value & 3]
 
+    def small_frame_aborts(self):
+        """how many robot-scale frames were re-run on the chain of launches because their single launch aborted a grid barrier (foreign
+        work held the GPU) -- include/emap_hip.h: emap_small_frame_aborts; normally 0, the results are the same either way"""
+        v = ct.c_uint32(0)
+        self._chk(self._lib.emap_small_frame_aborts(self._ctx, ct.byref(v)))
+        return int(v.value)
+
     def last_frame_semantics(self):
         """how the last whole frame fused the channels declared for it (emap_frame_semantics): "in_tile_pass" (32-byte records, fused by
         the tile kernel that fused the heights), "carried" (32-byte records, the stand-alone semantic kernel read the channels from

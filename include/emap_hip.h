@@ -363,6 +363,15 @@ int emap_get_stage_times(emap_ctx* ctx, float ms_out[10]);
  * kernel that fused the heights (32-byte sorted records), 8 = 32-byte records, stand-alone semantic kernel (a launch with heavy-tile
  * parts), neither = stand-alone kernels on 16-byte records / the atomic path.  EMAP_SEM_CARRY=0 keeps every frame on the last form. */
 int emap_last_update_path(emap_ctx* ctx, int32_t* path);
+/* k_small_frame synchronises its own grid (two barriers inside ONE launch).  If foreign work on the device keeps part of that grid from
+ * starting for ~0.1 s, the launch aborts -- one compare-and-swap decides for the whole grid -- and leaves the map, the frame
+ * accumulators and the drift record bit for bit as it found them; small frames already queued behind it do nothing.  The library re-runs
+ * those frames, in order, on the chain of launches (path 0) before the next call on the context reads or changes anything: a frame
+ * always completes, as the reference's does (EM/elevation_mapping.py:316-391), only later.  Precondition inherited from
+ * emap_set_points_device: a device cloud stays valid until the frame that reads it has completed (emap_sync).  *frames = how many
+ * frames have been re-run this way since emap_create (normally 0).  Test hooks: EMAP_SF_TEST_ABORT=1|2 (workgroup 0 gives up at once
+ * at that barrier), EMAP_SF_SPIN_LIMIT=<polls> (a waiter's patience). */
+int emap_small_frame_aborts(emap_ctx* ctx, uint32_t* frames);
 
 #ifdef __cplusplus
 }

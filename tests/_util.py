@@ -69,3 +69,23 @@ def rccl_stand_in(kind="blocking"):
         subprocess.check_call(cmd)
         os.replace(tmp, out)
     return out
+
+
+def cu_hog():
+    """Builds tests/foreign/cu_hog.hip (a foreign kernel that holds compute units: test infrastructure for the grid barriers of
+    k_small_frame) and returns the loaded library.  Prebuilt by __graft_entry__.build() into tests/foreign/_build/."""
+    import ctypes as ct
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "foreign")
+    src = os.path.join(here, "cu_hog.hip")
+    out_dir = os.path.join(here, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libcu_hog.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        tmp = out + ".%d.tmp" % os.getpid()
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", src, "-o", tmp])
+        os.replace(tmp, out)
+    lib = ct.CDLL(out)
+    lib.hog_start.argtypes = [ct.c_int, ct.c_int, ct.c_double]
+    return lib

@@ -1,5 +1,8 @@
 """GPU: k_small_frame -- the robot-scale frame (small clouds on maps of up to 512^2 cells: what the reference ships, EM/parameter.py:137,165)
-runs count -> gate -> fuse -> commit / average as ONE launch with two grid-wide barriers (emap_kernels.hip).  The same frames through the
+without a visibility pass runs count -> gate -> fuse -> commit + average as ONE launch with two grid-wide barriers (emap_kernels.hip).
+A barrier that foreign work on the GPU keeps from completing ABORTS consistently, the launch leaves everything as it found it and the
+library re-runs the frame on the chain of launches (round 6): forced aborts at either barrier, pipelined frames behind an aborted one,
+and frames under a foreign kernel that holds most of the compute units -- the map is bit for bit the chain's, always.  The same frames through the
 staged API are a chain of launches of the older kernels (k_count, k_gate, k_fuse, k_commit, k_average): every plane must agree BIT FOR
 BIT between the two (integer / fixed-point accumulators, the same float statements), and with the oracle (reference:
 EM/elevation_mapping.py:316-391, EM/kernels/custom_kernels.py:160-197,280-389)."""
@@ -48,8 +51,9 @@ def test_one_launch_equals_the_chain_and_the_oracle(cfg_name, C, N, rays, mode, 
     for f, (dz, pn, on) in enumerate(frames):
         p = fx.cloud(C, N, f, dz=dz)
         st = one.update_map_with_kernel(p, [], R, t.copy(), pn, on)
-        # (512 workgroups -- the largest cloud of the atomic path -- need a device that holds 2048 of them: an unpartitioned MI355X)
-        assert one.last_update_path() == ("small_frame" if N <= 65536 else one.last_update_path())
+        # (512 workgroups -- the largest cloud of the atomic path -- need a device that holds 2048 of them: an unpartitioned MI355X; a frame
+        # with a visibility pass keeps the chain of launches: an aborted launch must leave nothing for the rest of the frame to act on)
+        assert one.last_update_path() == ("atomic" if rays else ("small_frame" if N <= 65536 else one.last_update_path()))
         _staged(chain, p, R, t, pn, on)
         orc.update_map_with_kernel(p, R, t, pn, on)
         sc = chain.stats()
@@ -82,7 +86,7 @@ def test_pending_map_moves_are_replayed_inside_the_one_launch(rays, weights):
                     m.shift_map_xy(np.array([-2, 4]))
         p = fx.cloud(C, N, f, dz=-0.03 * f)
         one.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0)
-        assert one.last_update_path() == "small_frame"
+        assert one.last_update_path() == ("atomic" if rays else "small_frame")
         _staged(chain, p, R, t, 1.0, 1.0)
         _same(one, chain, "frame %d" % f)
         for k in range(7):
@@ -93,7 +97,7 @@ def test_pending_map_moves_are_replayed_inside_the_one_launch(rays, weights):
 def test_tiny_and_ragged_clouds(N, weights):
     """a cloud smaller than the per-cell phase's grid; NaN rows; points outside the map and on its border"""
     C = 202
-    cfg = dict(eo.YAML)
+    cfg = dict(eo.YAML, enable_visibility_cleanup=False)
     one, orc = make_pair(cfg, C, "reference_fp16", weights)
     chain, _ = make_pair(cfg, C, "reference_fp16", weights)
     R, t = fx.POSES["rotated"]
@@ -131,8 +135,9 @@ def test_larger_maps_and_clouds_keep_their_paths(weights):
 def test_run_to_run_and_two_contexts_bit_identical(weights):
     """40 frames on two contexts that alternate on the device: the barriers' epochs / ticket words are per context"""
     C, N = 202, 50000
-    a, _ = make_pair(eo.YAML, C, "reference_fp16", weights)
-    b, _ = make_pair(eo.YAML, C, "reference_fp16", weights)
+    cfg = dict(eo.YAML, enable_visibility_cleanup=False)
+    a, _ = make_pair(cfg, C, "reference_fp16", weights)
+    b, _ = make_pair(cfg, C, "reference_fp16", weights)
     R, t = fx.POSES["rotated"]
     for f in range(40):
         p = fx.cloud(C, N, f % 5, dz=-0.01 * (f % 7))
@@ -143,3 +148,121 @@ def test_run_to_run_and_two_contexts_bit_identical(weights):
     assert a.last_update_path() == "small_frame"
     assert a.elevation_map.tobytes() == b.elevation_map.tobytes() and a.normal_map.tobytes() == b.normal_map.tobytes()
 
+
+
+# ---- round 6: a grid barrier that cannot complete aborts; the frame is re-run on the chain ----------------------------------------------
+NO_RAYS = dict(eo.YAML, enable_visibility_cleanup=False)
+
+
+class _env:
+    def __init__(self, **kv): self.kv = kv
+    def __enter__(self):
+        import os
+        for k, v in self.kv.items():
+            os.environ[k] = str(v)
+    def __exit__(self, *a):
+        import os
+        for k in self.kv:
+            os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("barrier", [1, 2])
+@pytest.mark.parametrize("mode", ["reference_fp16", "fp32"])
+def test_forced_abort_is_recovered_bit_for_bit(barrier, mode, weights):
+    """workgroup 0 gives up at once at the first / second barrier of every second frame (EMAP_SF_TEST_ABORT): the launch leaves map,
+    accumulators and drift record as it found them and the frame is re-run on the chain -- pending map moves included, statistics
+    (err_cnt, shift, additive_mean_error) included"""
+    C, N = 202, 50000
+    one, _ = make_pair(NO_RAYS, C, mode, weights)
+    chain, _ = make_pair(NO_RAYS, C, mode, weights)
+    R, t = fx.POSES["rotated"]
+    frames = [(0.0, 0.0, 0.0), (-0.02, 1.0, 1.0), (-0.2, 1.0, 1.0), (0.05, 1.0, 0.0), (-0.04, 1.0, 1.0), (0.0, 1.0, 1.0)]
+    for f, (dz, pn, on) in enumerate(frames):
+        if f in (2, 5):
+            for m in (one, chain):
+                m.shift_map_xy(np.array([3, -5])); m.shift_map_z(0.01 * f)
+        p = fx.cloud(C, N, f, dz=dz)
+        if f % 2 == 1:
+            with _env(EMAP_SF_TEST_ABORT=barrier):
+                st = one.update_map_with_kernel(p, [], R, t.copy(), pn, on)
+        else:
+            st = one.update_map_with_kernel(p, [], R, t.copy(), pn, on)
+        _staged(chain, p, R, t, pn, on)
+        sc = chain.stats()
+        assert (st.err_cnt, st.gate_fired, st.n_points) == (sc.err_cnt, sc.gate_fired, sc.n_points), "frame %d" % f
+        assert np.float32(st.shift).tobytes() == np.float32(sc.shift).tobytes() and st.err_sum == sc.err_sum, "frame %d" % f
+        assert np.float32(st.additive_mean_error).tobytes() == np.float32(sc.additive_mean_error).tobytes(), "frame %d" % f
+        _same(one, chain, "frame %d" % f)
+        for k in range(6):
+            one.update_time(); chain.update_time()
+    assert one.small_frame_aborts() == 3, one.small_frame_aborts()      # (the chain itself == the oracle: test_one_launch_equals_the_chain_and_the_oracle; the oracle has no map moves)
+
+
+@pytest.mark.parametrize("barrier", [1, 2])
+def test_frames_queued_behind_an_aborted_one_are_rerun_in_order(barrier, weights):
+    """device-resident clouds, no synchronisation between the frames: the launch of frame 2 aborts while frames 3 .. 6 are already
+    queued -- they find the poison word, do nothing, and all five are re-run in order at the next call that looks at the map"""
+    import bench
+    C, N = 202, 40000
+    one, _ = make_pair(NO_RAYS, C, "reference_fp16", weights)
+    chain, _ = make_pair(NO_RAYS, C, "reference_fp16", weights)
+    R, t = fx.POSES["rotated"]
+    rt = bench.Hip()
+    clouds = [fx.cloud(C, N, f, dz=-0.01 * f) for f in range(7)]
+    dev = []
+    for p in clouds:
+        d = rt.malloc(p.nbytes); rt.h2d(d, p); dev.append(d)
+    for f, p in enumerate(clouds):
+        one.bind_points_device(dev[f].value, N, 3)
+        if f == 2:
+            with _env(EMAP_SF_TEST_ABORT=barrier):
+                one.update_map_with_kernel(None, [], R, t.copy(), 1.0, 1.0, want_stats=False)
+        else:
+            one.update_map_with_kernel(None, [], R, t.copy(), 1.0, 1.0, want_stats=False)
+        _staged(chain, p, R, t, 1.0, 1.0)
+    _same(one, chain, "after the queue")           # (the first read settles the frames in flight)
+    assert one.small_frame_aborts() == 5, one.small_frame_aborts()
+    so, sc = one.stats(), chain.stats()
+    assert np.float32(so.additive_mean_error).tobytes() == np.float32(sc.additive_mean_error).tobytes() and so.err_cnt == sc.err_cnt
+    one.update_map_with_kernel(clouds[0], [], R, t.copy(), 1.0, 1.0)       # and the one-launch path goes on afterwards
+    assert one.last_update_path() == "small_frame" and one.small_frame_aborts() == 5
+    _staged(chain, clouds[0], R, t, 1.0, 1.0)
+    _same(one, chain, "the frame after")
+    one.sync()
+    for d in dev:
+        rt.free(d)
+
+
+def test_frames_under_a_foreign_kernel_that_holds_the_compute_units(weights):
+    """a foreign grid of 1024-thread workgroups (two fill a CU's wave slots) occupies all but a few CUs for 60 ms while frames are
+    issued with a short patience (EMAP_SF_SPIN_LIMIT): whichever launches manage to run all their workgroups pass, the others abort
+    and are re-run -- the map never differs from the chain's"""
+    from _util import cu_hog
+    hog = cu_hog()
+    C, N = 202, 50000
+    one, _ = make_pair(NO_RAYS, C, "reference_fp16", weights)
+    chain, _ = make_pair(NO_RAYS, C, "reference_fp16", weights)
+    R, t = fx.POSES["rotated"]
+    import time
+    assert hog.hog_start(0, 8, 1.0) == 0 and hog.hog_wait() == 0          # (loads the foreign code object: 0.2 s the first time)
+    aborted = 0
+    for rnd, groups in enumerate((500, 508, 480)):
+        p0 = fx.cloud(C, N, rnd)
+        one.update_map_with_kernel(p0, [], R, t.copy(), 1.0, 1.0); _staged(chain, p0, R, t, 1.0, 1.0)
+        one.sync()
+        assert hog.hog_start(0, groups, 60.0) == 0
+        time.sleep(0.003)                                                 # the foreign grid is resident before the frames are issued
+        with _env(EMAP_SF_SPIN_LIMIT=2000):
+            for f in range(3):
+                p = fx.cloud(C, N, 10 + 3 * rnd + f, dz=-0.02 * f)
+                one.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0, want_stats=False)
+                _staged(chain, p, R, t, 1.0, 1.0)
+            _same(one, chain, "round %d" % rnd)
+        assert hog.hog_wait() == 0
+        aborted = one.small_frame_aborts()
+    print("frames re-run under contention:", aborted)
+    assert aborted >= 1          # (with 480 .. 508 of the 512 half-CU slots taken, part of a 196-workgroup grid cannot start: measured, every round aborts)
+    p = fx.cloud(C, N, 99)
+    one.update_map_with_kernel(p, [], R, t.copy(), 1.0, 1.0); _staged(chain, p, R, t, 1.0, 1.0)
+    assert one.last_update_path() == "small_frame"
+    _same(one, chain, "afterwards")
