@@ -216,6 +216,12 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // range predicate, one bitmap bit; everything else happens only for the few cells that are neither known-and-fresh nor out.
 // (launch bounds: 8 waves per SIMD, i.e. two 1024-thread workgroups per CU -- measured: with 82 instead of 70 SGPRs the kernel
 // silently dropped to one workgroup per CU and ran 13 % slower)
+// Which part of the bitmap the LMAP variants of whole-map contexts keep in LDS (round 6): no ray reaches beyond max_ray_length from the
+// sensor, so only the rows [r0, r0 + nr) x 32-bit word columns [w0, w0 + wpr) around it are staged -- 520 x 576 cells = 37 KB at
+// 10 m / 0.04 m whatever the size of the map (before: the whole map's bitmap, 128 KB at 1024^2, and no LDS variant at all beyond
+// ~1100^2 cells: the 4096^2 frame marched at 661 G visits / s against 914 at 1024^2).  Computed by the host (ray_lds_window) with a
+// margin that bounds every rounding between the sensor position and a sample's cell; the whole map when it is no larger.
+struct LWin { int r0, nr, w0, wpr; };
 template <int MODE, bool STATS, int IDX, bool STRIP, int BLOCK, bool LMAP, int LPR>
 #ifndef RAY_OCC
 #define RAY_OCC 8
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
                                                  long plane_stride, FrameDev* __restrict__ F,
                                                  const unsigned long long* __restrict__ inert64,
                                                  const unsigned int* __restrict__ inl, int inl_stride, const float* __restrict__ thr,
-                                                 const unsigned int* __restrict__ order, const unsigned int* __restrict__ n_sorted) {
+                                                 const unsigned int* __restrict__ order, const unsigned int* __restrict__ n_sorted, LWin LW) {
   // walking sorted records: workgroups behind the last record leave before the prologue (a frame that marches its rays by ray sorts
   // only the points of the strip's rows: most of a grid sized for the whole cloud is empty then)
   // The workgroups take the chunks of the sorted records OUTSIDE IN (first, last, second, second to last, ...).  The records are sorted
@@ -265,17 +271,34 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
   // (the copy starts at an LDS offset aligned to the row pitch: the word address is then (row * pitch) + ((column part) | base), one
   // v_and_or instead of an and + an add per step)
   typedef __attribute__((address_space(3))) unsigned int lds_u32;
-  unsigned int map_align = 4u; while (map_align < wpr32 * 4u) map_align <<= 1;
+  constexpr bool WIN = LMAP && !STRIP;                          // whole-map contexts stage the sensor's reach window only (LWin)
+  const unsigned int lwpr32 = WIN ? (unsigned int)LW.wpr : wpr32, lrows = WIN ? (unsigned int)LW.nr : (unsigned int)P.nrows;      // the LDS copy: 32-bit words per row, rows
+  unsigned int map_align = 16u; if (!WIN) { map_align = 4u; while (map_align < wpr32 * 4u) map_align <<= 1; }      // (!WIN: aligned to the row pitch, see above; WIN adds its base)
+  // (A per-wave KEY CACHE for the first frame after clear() -- {cell, key} pairs the wave has already pushed, 256 direct-mapped 64-bit
+  // entries per wave, a visit whose key is not above the cached one skips the device-coherent key load and the atomic -- was built and
+  // measured in round 6: bit-identical, and SLOWER, same box: steady uniform pass 218.6 -> 228 us, first frame after clear() 0.90 -> 1.0 ms.
+  // The cold frame is not bound by its key traffic: with an all-zero bitmap EVERY step of every ray goes through the visit queue.)
   const unsigned int q_end = (unsigned int)(size_t)(lds_u32*)(qbase + (BLOCK / 64) * 384);       // byte offset in LDS
   const unsigned int smap_base = LMAP ? (q_end + map_align - 1u) & ~(map_align - 1u) : 0u;
-  if (LMAP) {     // a pure copy: LDS-DMA, one kilobyte per wave instruction (the row pitch is a multiple of 16 bytes); the two trailing all-ones words by hand
+  if (LMAP) {     // a pure copy: LDS-DMA, one kilobyte per wave instruction; the two trailing all-ones words by hand
     lds_u32* smap = (lds_u32*)(size_t)smap_base;
-    const unsigned int nb = (unsigned int)P.nrows * wpr32 * 4u;                 // bytes of the bitmap proper
+    const unsigned int nb = lrows * lwpr32 * 4u;                                // bytes of the staged bitmap
     const char* src = reinterpret_cast<const char*>(inert);
     const unsigned int wave0 = (unsigned int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 1024u, lane16 = (threadIdx.x & 63u) * 16u;
-    for (unsigned int off = wave0; off < nb; off += (BLOCK / 64) * 1024u)
-      if (off + lane16 < nb) lds_dma16_at(src + off + lane16, smap_base + off);
-    if (threadIdx.x < 2) smap[nb / 4u + threadIdx.x] = inert[nb / 4u + threadIdx.x];
+    if (WIN && (lwpr32 != wpr32 || LW.r0 != 0)) {
+      // a window: 16-byte pieces enumerated row-major over the window land contiguously in LDS (lane i of a wave at base + 16 i)
+      // whatever their global addresses (host: w0 and wpr are multiples of 4 words, the map's row pitch of 16 bytes)
+      const unsigned int ppr = lwpr32 / 4u;
+      for (unsigned int off = wave0; off < nb; off += (BLOCK / 64) * 1024u) {
+        const unsigned int pce = (off + lane16) / 16u, row = pce / ppr, j = pce - row * ppr;
+        if (off + lane16 < nb) lds_dma16_at(src + ((size_t)((unsigned int)LW.r0 + row) * wpr32 + (unsigned int)LW.w0) * 4u + j * 16u, smap_base + off);
+      }
+      if (threadIdx.x < 2) smap[nb / 4u + threadIdx.x] = 0xffffffffu;
+    } else {
+      for (unsigned int off = wave0; off < nb; off += (BLOCK / 64) * 1024u)
+        if (off + lane16 < nb) lds_dma16_at(src + off + lane16, smap_base + off);
+      if (threadIdx.x < 2) smap[nb / 4u + threadIdx.x] = inert[nb / 4u + threadIdx.x];
+    }
   }
   __syncthreads();
   float frac_v = P.hw_frac_f;
@@ -491,7 +514,10 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
   const v2f txy = {T.t[0], T.t[1]};
   // loop constants that feed a second scalar operand slot live in vector registers (one scalar source per VALU instruction on
   // gfx9: the compiler would otherwise re-materialise them with a v_mov in every step)
-  unsigned int ones_off = (unsigned int)P.nrows * wpr32 * 4u + smap_base, base_v = smap_base, mask_v = (IDX == 2 && !STRIP) ? 0x1ffcu : 0x1ffffffcu;      // (PK: the shifted key still carries the row above bit 12)
+  // (WIN: the word of cell (ix, iy) lies at ix * row bytes + (iy >> 5) * 4 + base_v with the window's origin folded into base_v -- an
+  // ADD, v_lshl_add_u32, where the whole-map copy ORs its pitch-aligned base in: the same instruction count per step)
+  unsigned int ones_off = lrows * lwpr32 * 4u + smap_base, base_v = WIN ? smap_base - ((unsigned int)LW.r0 * lwpr32 + (unsigned int)LW.w0) * 4u : smap_base,
+               mask_v = (IDX == 2 && !STRIP) ? 0x1ffcu : 0x1ffffffcu;      // (PK: the shifted key still carries the row above bit 12)
   asm volatile("" : "+v"(ones_off), "+v"(base_v), "+v"(mask_v));
   auto cell_xy = [&](v2f n, int& ix, int& iy) -> unsigned int {                   // sample position -> cell, key (ix << 16) | iy   (cell_n <= 46340: 16 bits each)
     if constexpr (IDX == 2) {
@@ -582,11 +608,16 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
     if (STATS) visits += (act && max(ix - 1u, iy - 1u) < (unsigned int)(C - 2)) ? 1u : 0u;
     unsigned int colpart, off_a;                                // ((iy >> 3) & ~3) | LDS base: byte offset of the word within its row
     if constexpr (PK) {                                         // the key's low half is iy (the mask drops the ix bits), its high half the bitmap row
-      asm("v_and_or_b32 %0, %1, %3, %2" : "=v"(colpart) : "v"(xy >> 3), "v"(base_v), "v"(mask_v));
-      asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(off_a) : "v"(xy), "s"(wpr32 * 4u), "v"(colpart));
+      if constexpr (WIN) {
+        unsigned int wi;
+        asm("v_bfe_u32 %0, %1, 5, 11" : "=v"(wi) : "v"(xy));                                     // iy >> 5: the word column
+        asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(colpart) : "v"(wi), "v"(base_v));
+      } else asm("v_and_or_b32 %0, %1, %3, %2" : "=v"(colpart) : "v"(xy >> 3), "v"(base_v), "v"(mask_v));
+      asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(off_a) : "v"(xy), "s"(lwpr32 * 4u), "v"(colpart));
     } else {
-      asm("v_and_or_b32 %0, %1, %3, %2" : "=v"(colpart) : "v"(bcol >> 3), "v"(base_v), "v"(mask_v));      // (no VOP3 literals on gfx9: the mask is a register)
-      off_a = mad24(brow, wpr32 * 4u, colpart);
+      if constexpr (WIN) asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(colpart) : "v"(bcol >> 5), "v"(base_v));
+      else asm("v_and_or_b32 %0, %1, %3, %2" : "=v"(colpart) : "v"(bcol >> 3), "v"(base_v), "v"(mask_v));      // (no VOP3 literals on gfx9: the mask is a register)
+      off_a = mad24(brow, lwpr32 * 4u, colpart);
     }
     const unsigned int off = act ? off_a : ones_off;
     if (LMAP) w = *(const lds_u32*)(size_t)off;
@@ -1623,9 +1654,38 @@ void launch_commit(hipStream_t s, const KP& P, Cells cells, const AccF* acc, con
 void launch_ray_apply(hipStream_t s, const KP& P, Cells cells, AccR* accr, unsigned long long* inert, const OverlapArgs& O, FrameDev* F, unsigned int* ray_pref_host, int par) {
   hipLaunchKernelGGL(k_ray_apply, dim3(nblk((long)P.nrows * P.C)), dim3(EM_BLOCK), 0, s, P, cells, accr, inert, O, F, ray_pref_host, par);
 }
+// 512 threads per workgroup (round 6; 1024 until round 5): with the reach window an LDS-bitmap workgroup needs ~60 KB, two fit a CU,
+// and one's prologue (table, window copy, barrier) overlaps the other's march -- same box, 1024 / 512 / 256: uniform 1024^2 pass 224 /
+// 217 / 224 us, terrain scene 184 / 164 / 153 us, 4096^2 / 4 M rays 1.65 / 1.48 / 1.67 ms.
 #ifndef RAY_BLOCK
-#define RAY_BLOCK 1024
+#define RAY_BLOCK 512
 #endif
+// The reach window of the rays of one frame on a whole-map context, in bitmap coordinates (logical rows, 32-bit word columns): a sample
+// lies at t + r * s with s <= Q(max_ray_length) and |r_x|, |r_y| <= 1 + 2^-10 (unit vector, components rounded to half in
+// reference_fp16 mode); its coordinate is then rounded to half (2^-11 relative; fp32 mode: 2^-24) and indexed by floor(x / res + C / 2),
+// clamped to the map.  D bounds all of that with room to spare, + 2 cells.  false: no window (non-finite pose, a row pitch the 2-D copy
+// cannot take, or nothing to gain: the window is the map).
+static bool ray_lds_window(const KP& P, const Pose& T, LWin* w) {
+  const int C = P.C, wpr32 = ((P.pitch + 63) / 64) * 2;
+  if ((wpr32 * 4) % 16 != 0 || P.pitch != P.C || P.nrows != P.C) return false;
+  int lo[2], hi[2];
+  for (int a = 0; a < 2; ++a) {
+    const double t = (double)T.t[a];
+    if (!(fabs(t) < 1.0e6)) return false;
+    const double D = (double)P.q_mrl * 1.004 + (fabs(t) + (double)P.q_mrl) * (P.mode == 0 ? 1.0 / 512.0 : 1.0e-5) + 2.0 * P.res;
+    const double l = floor((t - D) / P.res + P.half_w) - 2.0, h = floor((t + D) / P.res + P.half_w) + 2.0;
+    lo[a] = (int)fmin(fmax(l, 0.0), (double)(C - 1)); hi[a] = (int)fmin(fmax(h, 0.0), (double)(C - 1));
+  }
+  LWin v;
+  v.r0 = lo[0]; v.nr = hi[0] - lo[0] + 1;
+  v.w0 = (lo[1] / 128) * 4;                                    // 128 columns = four 32-bit words = one 16-byte piece
+  int w1 = (hi[1] / 128 + 1) * 4; if (w1 > wpr32) w1 = wpr32;
+  v.wpr = w1 - v.w0;
+  if (v.wpr % 4 != 0) return false;                            // (a pitch that is not a multiple of 128 columns cuts the last piece)
+  if ((long)v.nr * v.wpr >= (long)P.nrows * wpr32) return false;
+  *w = v;
+  return true;
+}
 template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(hipStream_t s, const KP& P, const Pose& T, const RayTab& Rt, const float* pts,
                                                                               long n, int stride, Cells cells, const AccRView& accr,
                                                                               const float* normal, long plane_stride, FrameDev* F, const unsigned long long* inert,
@@ -1633,12 +1693,17 @@ template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(h
   constexpr int SMALL_BLOCK = 256, SMALL_LPR = 4;
   // Small clouds (robot scale: 50 k rays = 49 workgroups of 1024) leave most of the 256 CUs idle while every wave walks its ~350
   // dependent steps: 256-thread workgroups spread the same waves over four times as many CUs, one wave per SIMD.
-  const bool small = n < (long)128 * RAY_BLOCK;
+  const bool small = n < 131072;
   const int block = small ? SMALL_BLOCK : RAY_BLOCK;
   const int lpr = small ? SMALL_LPR : 1;
-  const size_t lds = (IDX == 1 ? (((size_t)(Rt.hi - Rt.lo) + 2 + 3) & ~(size_t)3) * 4 : 0) + (size_t)(((Rt.nS + 3) & ~3) + 8 * lpr) * 4 + (size_t)(block / 64) * 3 * 128 * 4;
+  const size_t lds = (IDX == 1 ? (((size_t)(Rt.hi - Rt.lo) + 2 + 3) & ~(size_t)3) * 4 : 0) + (size_t)(((Rt.nS + 3) & ~3) + 8 * lpr) * 4 + (size_t)(block / 64) * 3 * 128 * 4;      // [index table] + step table + the waves' visit queues
   size_t map_bytes = ((size_t)P.nrows * ((P.pitch + 63) / 64) * 2 + 2) * 4;       // bitmap + the all-ones word ...
   { size_t al = 4; while (al < (size_t)((P.pitch + 63) / 64) * 8) al <<= 1; map_bytes += al; }      // ... + alignment to the row pitch
+  LWin lw = {0, P.nrows, 0, ((P.pitch + 63) / 64) * 2};
+  if (!STRIP) {                                    // whole-map contexts: only the sensor's reach window (EMAP_RAY_WINDOW=0: the whole bitmap, A/B and test hook)
+    static const bool win_off = getenv("EMAP_RAY_WINDOW") && atoi(getenv("EMAP_RAY_WINDOW")) == 0;
+    if (!win_off && ray_lds_window(P, T, &lw)) map_bytes = ((size_t)lw.nr * lw.wpr + 2) * 4 + 16;
+  }
   // EMAP_RAY_LMAP = 0 / 1: never / whenever it fits (tuning and test hook); unset: whenever it fits unless the map is mostly unknown or
   // stale (KP::ray_pref, from the previous frames' share of quiet cells): there the march queues cell work at almost every step and
   // is latency bound -- the global-bitmap variant runs two workgroups per CU (terrain scene: 187 vs 217 us; uniform benchmark: LDS 10 % ahead)
@@ -1647,7 +1712,7 @@ template <int MODE, bool STATS, int IDX, bool STRIP> static void launch_rays_i(h
   dim3 g((unsigned int)((n * lpr + block - 1) / block)), b(block);
   auto go = [&](auto kern, LdsRaised& raised, size_t bytes) {    // per instantiation and device: the half -> index table + queues [+ bitmap] can exceed the default 64 KB window
     if (!raise_lds(kern, raised, 158 * 1024) && bytes > 64 * 1024) return;      // (the launch below would fail: hipGetLastError reports it to the caller)
-    hipLaunchKernelGGL(kern, g, b, bytes, s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted);
+    hipLaunchKernelGGL(kern, g, b, bytes, s, P, T, Rt, pts, n, stride, cells, accr, normal, plane_stride, F, inert, inl, inl_stride, thr, order, n_sorted, lw);
   };
   static LdsRaised raised0, raised1, raised2;
   if (small) go(k_rays<MODE, STATS, IDX, STRIP, SMALL_BLOCK, false, SMALL_LPR>, raised2, lds);
