@@ -61,6 +61,33 @@ def mm_frame(lib, ctx, Rp, tp, spec, stats=None):
     return lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats) or lib.emap_semantic_update(ctx, Rp, tp, ct.byref(spec))
 
 
+# VALU issue peak of the chip: 256 CUs x 4 SIMDs, a wave64 vector instruction occupies its SIMD for 4 cycles at 2.4 GHz
+# (MI355X_MICROARCH.md) -> 0.6 G wave-instructions / s / SIMD
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
+
+
+def sq_valu_insts(workload, kernel_prefix):
+    """SQ_INSTS_VALU per launch (wave instructions, average over the dispatches) of a kernel from the committed rocprofv3 --pmc SQ_*
+    pass of this workload (profiles/<round>_<workload>_sq_counters.txt) -- (None, why) when the file is missing or was taken with
+    other kernel sources"""
+    f = os.path.join(ROOT, "profiles", "%s_%s_sq_counters.txt" % (PROFILE_ROUND, workload))
+    if not os.path.exists(f):
+        return None, "profiles/%s missing" % os.path.basename(f)
+    lines = open(f).read().splitlines()
+    stamp = next((ln.split(":", 1)[1].strip() for ln in lines if ln.startswith("# source_stamp:")), None)
+    if stamp != source_stamp():
+        return None, "profiles/%s: taken with other kernel sources (stamp %s, now %s)" % (os.path.basename(f), stamp, source_stamp())
+    best, best_w = None, -1.0
+    for ln in lines:
+        name = ln.replace("void ", "", 1).lstrip()
+        if name.startswith(kernel_prefix) and " SQ_INSTS_VALU " in ln:
+            tail = ln.split("SQ_INSTS_VALU", 1)[1].split()
+            v, n = float(tail[0]), float(tail[1].split("=")[1])
+            if v * n > best_w:
+                best, best_w = v, v * n
+    return best, "profiles/%s" % os.path.basename(f)
+
+
 def rocprof_kernel_us(workload, kernel_prefix):
     """median duration (us) of a kernel in profiles/<round>_<workload>_kernel_stats.txt -- None when the file is missing or was taken
     with other kernel sources (its '# source_stamp:' line)"""
@@ -322,7 +349,14 @@ def scene_change(em, frame_a, frame_b, reps=3):
             "first_frame_gate_fuse_ms": [med(0, 1), med(0, 2)], "fourth_frame_gate_fuse_ms": [med(3, 1), med(3, 2)]}
 
 
-def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step, visits, pmc_ok, stage_bytes=None):
+def ray_samples(cloud, cfg):
+    """~ samples one frame's rays take (custom_kernels.py:203-211: one every resolution / sqrt(2) up to min(|point - sensor|,
+    max_ray_length)) -- the synthetic clouds are given in the sensor frame; every row counted (invalid points are a small share)"""
+    r = np.minimum(np.linalg.norm(np.asarray(cloud[:, :3], np.float64), axis=1), float(cfg["max_ray_length"]))
+    return int(np.floor(r[np.isfinite(r)] / (float(cfg["resolution"]) / 2 ** 0.5)).sum())
+
+
+def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step, visits, pmc_ok, stage_bytes=None, samples=None):
     sb = stage_bytes or {k: f(N, L) for k, f in STAGE_BYTES.items()}
     cand = {k: v for k, v in stage_ms.items() if sb[k] > 0}
     dom = max(cand, key=cand.get)
@@ -349,6 +383,30 @@ def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step
     # rocprofv3 summary of this command taken with THESE kernel sources, the same bytes over that summary's median duration
     kus, ksrc = rocprof_kernel_us(workload, STAGE_KERNEL[dom]) if pmc_ok else (None, None)
     frac_rocprof = round(dom_bytes / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if kus else None
+    if dom == "rays":
+        # The visibility march is bound by vector-instruction ISSUE, not by HBM (12 N + 48 L bytes against ~20 instructions for each of
+        # ~3.5e8 samples): its roofline is SQ_INSTS_VALU per launch (committed SQ-counter pass of this command, same kernel sources) over
+        # the live kernel time, against the rate the chip's 1024 SIMDs can issue wave64 vector instructions at.  The HBM figure stays
+        # beside it as `hbm`.
+        insts, isrc = sq_valu_insts(workload, "k_rays<") if pmc_ok else (None, "no SQ-counter pass for this map / cloud size")
+        ginst = insts / (dom_ms * 1e-3) / 1e9 if insts else None
+        return {"bound": "valu", "kernel": dom, "achieved": round(ginst, 1) if ginst else None, "peak": round(VALU_PEAK_GINST, 1),
+                "unit": "G wave-instructions/s", "frac": round(ginst / VALU_PEAK_GINST, 4) if ginst else None,
+                "frac_source": "SQ_INSTS_VALU per launch (%s) / live hipEvent spacing of the kernel (kernel_ms) / (1024 SIMDs x 0.6 G wave-instructions/s)" % isrc,
+                "valu_insts_per_launch": insts,
+                "hbm": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "frac_rocprof": frac_rocprof, "algorithmic_bytes": int(dom_bytes)},
+                "kernel_us_rocprof": kus, "kernel_us_rocprof_source": ksrc,
+                "source_stamp": source_stamp(), "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes": int(dom_bytes), "kernel_ms": round(dom_ms, 5), "kernel_ms_net": round(max(dom_ms - ev_overhead, 0.0), 5),
+                "event_pair_overhead_ms": round(ev_overhead, 5),
+                "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+                "frame_algorithmic_bytes": int(frame_bytes),
+                "frame_frac": round(frame_bytes / (dev_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "ray_visits_per_frame": int(visits),
+                "ray_visits_per_s": (round(visits / (stage_ms["rays"] * 1e-3) / 1e9, 1) if visits else None), "visits_unit": "G cell visits/s",
+                "ray_samples_per_frame": samples, "ray_samples_per_s": (round(samples / (stage_ms["rays"] * 1e-3) / 1e9, 1) if samples else None),
+                "valu_insts_per_sample": (round(insts * 64.0 / samples, 1) if insts and samples else None), "samples_unit": "G samples/s (a sample = one step of one ray; ~, from the cloud)"}
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_source": "live: hipEvent spacing of the kernel on its stream in this run (kernel_ms)",
             "frac_rocprof": frac_rocprof, "kernel_us_rocprof": kus, "kernel_us_rocprof_source": ksrc,
@@ -539,7 +597,8 @@ def run_single(a, local_rank=0):
     L = C * C
     frame_bytes = 12 * N + 56 * L + (16 * N + 32 * L if multimodal else 0)   # B_frame of BASELINE.md §5 (K extra channels, L semantic layers)
     pmc_ok = C == 1024 and N == 1_000_000 and a.mode == "reference_fp16"
-    roof = roofline(stage_ms, ev_overhead, N, L, a.workload, frame_bytes, ms_dev / a.steps, visits, pmc_ok)
+    samples = ray_samples(clouds_host[0], cfg) if cfg.get("enable_visibility_cleanup") else None
+    roof = roofline(stage_ms, ev_overhead, N, L, a.workload, frame_bytes, ms_dev / a.steps, visits, pmc_ok, samples=samples)
 
     # ---- config.cfg3: the frame WITH the visibility pass + overlap clearance, same process, second map ------------------
     cfg3 = None
@@ -554,12 +613,14 @@ def run_single(a, local_rank=0):
         lat3 = latencies(em3, fr3, min(k3, 10))
         st3, vis3 = stage_profile(em3._lib, em3._ctx, fr3, min(k3, 8))
         cold = cold_start(em3, fr3)
-        r3 = roofline(st3, ev_overhead, N, L, "cfg3", frame_bytes, ms3 / k3, vis3, pmc_ok)
+        r3 = roofline(st3, ev_overhead, N, L, "cfg3", frame_bytes, ms3 / k3, vis3, pmc_ok, samples=ray_samples(clouds_host[0], cfgr))
         cfg3 = {"workload": "cfg3: same map and clouds with enable_visibility_cleanup + enable_overlap_clearance",
                 "value": round(N * k3 / wall3 / 1e6, 2), "unit": "Mpoints/s", "steps": k3, "ms_per_step": round(wall3 * 1e3 / k3, 5),
                 "latency_ms": {"p10": round(lat3[0], 4), "p50": round(lat3[1], 4), "p90": round(lat3[2], 4)},
-                "dominant_kernel": r3["kernel"], "kernel_ms": r3["kernel_ms"], "frac": r3["frac"], "traffic": r3["traffic"],
+                "dominant_kernel": r3["kernel"], "kernel_ms": r3["kernel_ms"], "bound": r3["bound"], "frac": r3["frac"], "unit": r3["unit"], "achieved": r3["achieved"],
+                "hbm": r3.get("hbm"), "traffic": r3["traffic"],
                 "ray_visits_per_frame": r3["ray_visits_per_frame"], "ray_visits_per_s": r3["ray_visits_per_s"],
+                "ray_samples_per_frame": r3.get("ray_samples_per_frame"), "ray_samples_per_s": r3.get("ray_samples_per_s"), "valu_insts_per_sample": r3.get("valu_insts_per_sample"),
                 "stage_ms": r3["stage_ms"], "cold_start_ms": cold}
         em3.close()
         # ---- the same frame on a spatially COHERENT scene: scan-ordered beams ray-cast at a terrain with walls (tests/_fixtures.py:
@@ -674,10 +735,11 @@ def run_single(a, local_rank=0):
             large[name] = {"workload": workload_text(b, Cb, Nb, mm), "index_mode": "fp32", "n_gpus": 1, "steps": kb,
                            "value": round(Nb * kb / wallb / 1e6, 2), "unit": "Mpoints/s", "ms_per_step": round(wallb * 1e3 / kb, 5),
                            "timed_loops_ms_per_step": loopsb, "latency_ms": {"p10": round(latb[0], 4), "p50": round(latb[1], 4), "p90": round(latb[2], 4)},
-                           "dominant_kernel": rb["kernel"], "kernel_ms": rb["kernel_ms"], "frac": rb["frac"], "frame_frac": rb["frame_frac"],
+                           "dominant_kernel": rb["kernel"], "kernel_ms": rb["kernel_ms"], "bound": rb["bound"], "frac": rb["frac"], "hbm": rb.get("hbm"), "frame_frac": rb["frame_frac"],
                            "ray_visits_per_s": rb["ray_visits_per_s"], "stage_ms": (dict(rb["stage_ms"], semantic=round(sem_stage_ms, 5)) if mm else rb["stage_ms"]),
-                           "note": ("stage_ms.semantic = the RGB / semantic fusion (k_tile_semantic: a call of its own behind the frame's ten stages, inside "
-                                    "ms_per_step); cloud bound de-interleaved: (N, 3) xyz + (N, 4) channels, as emap_upload_points leaves an uploaded cloud" if mm else None)}
+                           "note": (("the RGB / semantic fusion is declared for the frame (emap_frame_semantics) and runs inside the 'fuse' stage's tile kernel on 32-byte sorted records; "
+                                     if sem_in_frame(lb) else "stage_ms.semantic = the RGB / semantic fusion (k_tile_semantic: a call of its own behind the frame's ten stages, inside ms_per_step); ") +
+                                    "cloud bound de-interleaved: (N, 3) xyz + (N, 4) channels, as emap_upload_points leaves an uploaded cloud") if mm else None}
             emb.close()
             free_clouds(hip, devb)
 
@@ -1104,8 +1166,9 @@ def run_strips(a, rank, world, local_rank):
     else:
         if rank == 0:
             print("native RCCL strips unavailable here (fewer devices than ranks, or RCCL failed): torch.distributed fallback", file=sys.stderr)
-        from elevation_mapping_cupy_amd import sharded
-        sharded.bench_main(a, rank, world, local_rank)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))      # (test infrastructure: the product package holds no torch.distributed path)
+        import _torch_strips
+        _torch_strips.bench_main(a, rank, world, local_rank)
     rdv.finish()
 
 

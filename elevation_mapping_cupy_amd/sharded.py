@@ -14,12 +14,13 @@ Per frame (same stage order as reference update_map_with_kernel, EM/elevation_ma
   rows (``ShardedElevationMap.input_pointcloud`` -> ``emap_upload_points_strip``: 1 / G of the cloud per rank);
 * rays marched BY ROW need no communication: every rank marches every ray and acts only on its own rows; the library's own frame
   (``emap_update_sharded``) marches them BY RAY over an all-reduced window from 2048^2 cells on (DESIGN.md section 7c);
-* the two exchange steps go through ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on the GPU box,
-  ``gloo`` in the CPU tests); buffers are plain device pointers on the C-ABI side (``emap_halo_pack/unpack``,
-  ``emap_drift_sums_to_device``), so nothing syncs with the host inside a frame.
+* the two exchange steps are issued by the C library itself over RCCL (``NativeComm`` -> ``emap_comm_init`` /
+  ``emap_update_sharded``): nothing syncs with the host inside a frame, no second communication backend in the product.
 
-The orchestration is engine-agnostic (``StripEngine`` protocol) so that the world_size-2 gloo tests can drive it on
-CPU with a test engine; the product engine is ``HipStripEngine`` (libemap_hip.so).
+The stage ORDER of a sharded frame is also written out engine- and communicator-agnostically (``ShardedElevationMap._update``: what
+``emap_update_sharded`` does, as a protocol over ``count / local_sums / gate / fuse / ... / halo_pack / post``) so that the
+world_size-2 / 3 gloo tests can drive it on CPU with a test engine and a test communicator (tests/_torch_strips.py holds the
+torch.distributed communicator and the engine with exchange buffers; nothing in this package imports torch).
 """
 from __future__ import annotations
 
@@ -65,7 +66,7 @@ def ray_balanced_weights(cell_n: int, resolution: float, max_ray_length: float, 
 def frame_marches_by_ray(cell_n: int, n_points: int, world: int, comm_kind: str = "native", ray_mode: int = 0, scatter: str = "auto") -> bool:
     """Will a sharded frame WITH the visibility pass march its rays by ray (csrc/emap_api.hip: rays_by_ray -- the same predicate, from
     the values every rank shares)?  Only the library's own frame (``emap_update_sharded`` over the native RCCL communicator) can; the
-    torch-driven fallback and the staged strip engine always march by row.  Strips of equal RAY work (ray_balanced_weights) are for
+    stage-by-stage orchestration (ShardedElevationMap._update) always marches by row.  Strips of equal RAY work (ray_balanced_weights) are for
     frames that march by row; a by-ray frame wants equal heights (the decision must not hang on cell_n alone)."""
     binned = scatter == "binned" or (scatter == "auto" and n_points >= 131072)
     return world > 1 and comm_kind == "native" and ray_mode != 1 and binned and (ray_mode == 2 or cell_n >= 2048)
@@ -93,78 +94,16 @@ def halo_rows_needed(dilation_size: int, world: int) -> int:
     return 0 if world == 1 else int(dilation_size) + 4
 
 
-# ---------------------------------------------------------------------------------------------------------------
-class TorchComm:
-    """The two collectives of the path on top of torch.distributed (nccl=RCCL on GPU, gloo on CPU)."""
-
-    def __init__(self, device=None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.device = device  # torch.device or None (CPU)
-        # RCCL orders its work after the current HIP stream by itself; gloo with device tensors (test setups with
-        # several ranks on one GPU) copies through the host without looking at our stream: drain it first
-        self.host_sync = device is not None and "nccl" not in str(dist.get_backend())
-
-    def _drain(self):
-        if self.host_sync:
-            self.torch.cuda.current_stream(self.device).synchronize()
-
-    def all_reduce_sum_(self, tensor):
-        """in-place sum of a small float64 tensor (2 elements: err_sum, err_cnt)."""
-        if self.world > 1:
-            self._drain()
-            self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
-        return tensor
-
-    def exchange_start(self, send_lo, send_hi, recv_lo, recv_hi):
-        """neighbour exchange on the strip RING (strips are physical row ranges of a circular map): send_lo -> rank-1 (arrives in
-        its recv_hi), send_hi -> rank+1 (arrives in its recv_lo), modulo world.  The posting order (sends low, high; receives
-        upper, lower) keeps the pairs apart when both neighbours are the same rank.  Returns the in-flight requests."""
-        dist = self.dist
-        if self.world == 1:
-            return []
-        self._drain()
-        prev, nxt = (self.rank - 1) % self.world, (self.rank + 1) % self.world
-        ops = [dist.P2POp(dist.isend, send_lo, prev), dist.P2POp(dist.isend, send_hi, nxt),
-               dist.P2POp(dist.irecv, recv_hi, nxt), dist.P2POp(dist.irecv, recv_lo, prev)]
-        return dist.batch_isend_irecv(ops)
-
-    def exchange_wait(self, works):
-        for w in works:
-            w.wait()
-        if self.host_sync:
-            self.torch.cuda.synchronize(self.device)
-
-    def all_gather_object(self, obj):
-        if self.world == 1:
-            return [obj]
-        self._drain()
-        out = [None] * self.world
-        self.dist.all_gather_object(out, obj)
-        return out
-
-    def barrier(self):
-        if self.world > 1:
-            self.dist.barrier()
-
-    def max_float(self, x):
-        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
-        if self.world > 1:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-
 def rccl_library_path():
-    """RCCL build that matches the HIP runtime of this process: PyTorch wheels bundle their own ROCm libraries and export
-    them globally, so with torch imported its librccl.so is the consistent choice; otherwise the system ROCm's."""
+    """RCCL build that matches the HIP runtime of this process: a process that has PyTorch loaded (its wheels bundle their own ROCm
+    libraries and export them globally) must take that librccl.so; otherwise the system ROCm's.  (Looks at sys.modules only.)"""
     env = os.environ.get("EMAP_RCCL_LIB")
     if env:
         return env
     import sys
-    if "torch" in sys.modules:
-        cand = os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib", "librccl.so")
+    loaded = sys.modules.get("torch")
+    if loaded is not None and getattr(loaded, "__file__", None):
+        cand = os.path.join(os.path.dirname(loaded.__file__), "lib", "librccl.so")
         if os.path.exists(cand):
             return cand
     for cand in ("/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"):
@@ -175,37 +114,35 @@ def rccl_library_path():
 
 class NativeComm:
     """Both exchange steps issued by the C library itself (``emap_comm_init`` / ``emap_update_sharded``): RCCL resolved with
-    dlopen, all-reduce on the strip's stream, in-place halo send/recv on a second stream.  torch.distributed (any backend)
-    is only the bootstrap channel for the 128-byte ncclUniqueId and the out-of-band barrier / timing reductions."""
+    dlopen, all-reduce on the strip's stream, in-place halo send/recv on a second stream.  The one out-of-band step -- handing rank
+    0's 128-byte ncclUniqueId to every rank -- goes through ``uid`` (the caller distributed it) or a ``launch.FileRendezvous``
+    (``rdv``; default: the one the launcher's environment names); barriers and reductions afterwards go through RCCL itself."""
 
-    def __init__(self, engine, rank=None, world=None, bootstrap=True, uid=None, rccl_path=None):
+    def __init__(self, engine, rank=None, world=None, bootstrap=True, uid=None, rccl_path=None, rdv=None):
         from ._lib import EmapError
         self.e = engine
-        if bootstrap:
-            import torch
-            import torch.distributed as dist
-            self.torch, self.dist = torch, dist
-            self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        else:
-            self.torch = self.dist = None
-            self.rank, self.world = int(rank or 0), int(world or 1)
+        self.rank = int(os.environ.get("RANK", 0) if rank is None else rank)
+        self.world = int(os.environ.get("WORLD_SIZE", 1) if world is None else world)
         path = (rccl_path or rccl_library_path()).encode()
-        ok = 1
-        if uid is not None:              # the caller distributed the id itself (bootstrap=False with several ranks)
+        if uid is not None:              # the caller distributed the id itself
             uid = (ct.c_uint8 * 128).from_buffer_copy(bytes(uid))
         else:
             uid = (ct.c_uint8 * 128)()
+            ok = 1
             if self.rank == 0:
                 ok = 1 if engine.lib.emap_comm_unique_id(path, uid) == 0 else 0
-        if self.world > 1 and bootstrap:
-            # agree on success before the collective init (a rank that cannot load RCCL must not leave the others waiting)
-            payload = [bytes(uid) if ok else None]
-            self.dist.broadcast_object_list(payload, src=0)
-            if payload[0] is None:
-                raise EmapError("rank 0 could not create the RCCL unique id")
-            uid = (ct.c_uint8 * 128).from_buffer_copy(payload[0])
-        elif not ok:
-            raise EmapError("could not create the RCCL unique id (%s)" % path.decode())
+            if self.world > 1:
+                if not bootstrap and rdv is None:
+                    raise EmapError("several ranks need the unique id handed over (uid=) or a rendezvous (rdv=)")
+                from .launch import FileRendezvous
+                rdv = rdv or FileRendezvous.from_env(self.rank, self.world)
+                # agree on success before the collective init (a rank that cannot load RCCL must not leave the others waiting)
+                payload = rdv.broadcast("rccl_uid", (bytes(uid) if ok else b"") if self.rank == 0 else None)
+                if len(payload) != 128:
+                    raise EmapError("rank 0 could not create the RCCL unique id")
+                uid = (ct.c_uint8 * 128).from_buffer_copy(payload)
+            elif not ok:
+                raise EmapError("could not create the RCCL unique id (%s)" % path.decode())
         engine._chk(engine.lib.emap_comm_init(engine.ctx, path, uid, self.rank, self.world))
         self.path = path.decode()
 
@@ -225,52 +162,37 @@ class NativeComm:
         self.e._chk(self.e.lib.emap_comm_count(self.e.ctx, ct.byref(n)))
         return int(n.value)
 
-    def _oob(self, t):
-        """tensor for the out-of-band (bootstrap) channel: CPU when gloo is available, else on the strip's device"""
-        return t if "gloo" in str(self.dist.get_backend()) else t.to(self.e.torch_device)
+    def _reduce(self, x, op):
+        v = (ct.c_double * 1)(float(x))
+        self.e._chk(self.e.lib.emap_comm_allreduce_host(self.e.ctx, v, 1, int(op)))
+        return float(v[0])
 
     def barrier(self):
-        if self.world > 1:      # out-of-band (host) barrier on the bootstrap channel; callers synchronise the device themselves
-            self.dist.all_reduce(self._oob(self.torch.zeros(1, dtype=self.torch.int32)))
+        """behind all work enqueued on the strip's stream, on every rank (an all-reduce through the communicator itself)"""
+        if self.world > 1:
+            self._reduce(0.0, 0)
 
     def max_float(self, x):
-        if self.world == 1:
-            return float(x)
-        t = self._oob(self.torch.tensor([x], dtype=self.torch.float64))
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        return float(x) if self.world == 1 else self._reduce(x, 1)
 
 
 # ---------------------------------------------------------------------------------------------------------------
 class HipStripEngine:
-    """One strip on one MI355X: thin adapter from the sharding protocol to the C ABI."""
+    """One strip on one MI355X: thin adapter from the sharding protocol to the C ABI.  Whole frames run inside the library
+    (``update_native`` -> ``emap_update_sharded`` over a ``NativeComm``); the single stages are exposed for orchestrations that drive
+    a frame stage by stage (``ShardedElevationMap._update`` with an engine that also owns exchange buffers: the test engines)."""
 
-    def __init__(self, param, rank, world, device_index, torch_device, row_weights=None):
-        import torch
+    def __init__(self, param, rank, world, device_index, torch_device=None, row_weights=None, stream=None):
         from .elevation_mapping import ElevationMap
-        self.torch = torch
-        self.torch_device = torch_device
         C = int(param.cell_n)
         r0, r1 = strip_rows(C, world, rank, row_weights)
         self.halo = halo_rows_needed(param.dilation_size, world)
         if world > 1 and (r1 - r0) < self.halo:
             raise ValueError("strip of %d rows is thinner than the %d-row halo" % (r1 - r0, self.halo))
         param.device = device_index
-        # one dedicated torch stream per strip: the HIP kernels (C ABI) and the collectives are ordered on it
-        self.stream = torch.cuda.Stream(device=torch_device)
-        self.map = ElevationMap(param, strip=(r0, r1 - r0, self.halo), stream=self.stream.cuda_stream)
+        self.map = ElevationMap(param, strip=(r0, r1 - r0, self.halo), stream=stream)      # stream None: the context's own
         self.lib, self.ctx = self.map._lib, self.map._ctx
         self.C, self.rows = C, r1 - r0
-        n = max(1, self.halo * C * 4)          # emap_halo_pack: the 16-byte cold half cells of the boundary rows
-        with torch.cuda.stream(self.stream):
-            mk = lambda: torch.zeros(n, dtype=torch.float32, device=torch_device)  # noqa: E731
-            self.send = [mk(), mk()]
-            self.recv = [mk(), mk()]
-            self.sums = torch.zeros(2, dtype=torch.float64, device=torch_device)
-        self.stream.synchronize()
-
-    def stream_ctx(self):
-        return self.torch.cuda.stream(self.stream)
 
     def _chk(self, rc):
         self.map._chk(rc)
@@ -283,13 +205,6 @@ class HipStripEngine:
 
     def count(self, R, t):
         self.map.stage("count", R, t)
-
-    def local_sums(self):
-        self._chk(self.lib.emap_drift_sums_to_device(self.ctx, ct.c_void_p(self.sums.data_ptr())))
-        return self.sums
-
-    def gate(self, pn, on, totals):
-        self._chk(self.lib.emap_set_drift_inputs_device(self.ctx, ct.c_double(pn), ct.c_double(on), ct.c_void_p(totals.data_ptr())))
 
     def fuse(self, R, t):
         self.map.stage("fuse", R, t)
@@ -309,17 +224,6 @@ class HipStripEngine:
     def overlap(self, tz):
         self.map.stage("overlap", t=tz)
 
-    def halo_pack(self):
-        for side in (0, 1):
-            self._chk(self.lib.emap_halo_pack(self.ctx, side, ct.c_void_p(self.send[side].data_ptr())))
-        return self.send[0], self.send[1], self.recv[0], self.recv[1]
-
-    def halo_unpack(self, have_lo, have_hi):
-        if have_lo:
-            self._chk(self.lib.emap_halo_unpack(self.ctx, 0, ct.c_void_p(self.recv[0].data_ptr())))
-        if have_hi:
-            self._chk(self.lib.emap_halo_unpack(self.ctx, 1, ct.c_void_p(self.recv[1].data_ptr())))
-
     def post(self, part=0):
         """dilation + traversability + normals; part 1 = tiles independent of the halo, 2 = boundary tiles, 0 = all"""
         self._chk(self.lib.emap_post_part(self.ctx, int(part)))
@@ -329,20 +233,6 @@ class HipStripEngine:
         lag = ct.c_int32(0)
         self._chk(self.lib.emap_normal_row_lag(self.ctx, ct.byref(lag)))
         return lag.value
-
-    def normal_halo_pack(self):
-        if not hasattr(self, "nsend"):
-            n = max(1, 3 * self.halo * self.C)
-            with self.torch.cuda.stream(self.stream):
-                mk = lambda: self.torch.zeros(n, dtype=self.torch.float32, device=self.torch_device)  # noqa: E731
-                self.nsend, self.nrecv = [mk(), mk()], [mk(), mk()]
-        for side in (0, 1):
-            self._chk(self.lib.emap_normal_halo_pack(self.ctx, side, ct.c_void_p(self.nsend[side].data_ptr())))
-        return self.nsend[0], self.nsend[1], self.nrecv[0], self.nrecv[1]
-
-    def normal_halo_unpack(self):
-        for side in (0, 1):
-            self._chk(self.lib.emap_normal_halo_unpack(self.ctx, side, ct.c_void_p(self.nrecv[side].data_ptr())))
 
     def move_to(self, position, R):
         """every rank shifts its strip by the same amount: the strip keeps its PHYSICAL rows, the logical rows it holds change"""
@@ -362,8 +252,17 @@ class HipStripEngine:
         """create the layers / count plane of the extra cloud channels BEFORE the frame (SemanticMap.prepare)"""
         self.map.semantic_map.prepare(list(channels))
 
+    def semantic_declare(self, channels):
+        """the strip's RGB / semantic fusion rides inside the next frame (SemanticMap.declare_frame); returns the jobs to run after it"""
+        return self.map.semantic_map.declare_frame(self.map, list(channels))
+
+    def semantic_finish(self, jobs, R, t):
+        R = np.ascontiguousarray(np.asarray(R, np.float32).reshape(9))
+        t = np.ascontiguousarray(np.asarray(t, np.float32).reshape(3))
+        self.map.semantic_map.finish_frame(self.map, jobs, R, t)
+
     def semantic_update(self, channels, R, t):
-        """RGB / semantic fusion of the bound cloud's extra channels into this strip's layers: per cell, no exchange step"""
+        """RGB / semantic fusion of the bound cloud's extra channels into this strip's layers AFTER a frame: per cell, no exchange step"""
         R = np.ascontiguousarray(np.asarray(R, np.float32).reshape(9))
         t = np.ascontiguousarray(np.asarray(t, np.float32).reshape(3))
         self.map.semantic_map.update_layers_pointcloud(self.map, list(channels), R, t)
@@ -446,14 +345,17 @@ class ShardedElevationMap:
         x, y, z first) additionally fuses the extra columns into the strip's RGB / semantic layers (BASELINE config 5)."""
         e, c = self.e, self.comm
         extra = list(channels[3:]) if channels is not None else None      # x, y, z are not layers (input_pointcloud forwards channels[3:])
+        if isinstance(c, NativeComm):
+            jobs = e.semantic_declare(extra) if extra else []      # the fusion rides inside the library's frame (emap_frame_semantics)
+            e.update_native(R, t, position_noise, orientation_noise)
+            if jobs:
+                e.semantic_finish(jobs, R, t)
+            return
         if extra:
             e.semantic_prepare(extra)
-        if isinstance(c, NativeComm):
-            e.update_native(R, t, position_noise, orientation_noise)
-        else:
-            ctx = e.stream_ctx() if hasattr(e, "stream_ctx") else contextlib.nullcontext()
-            with ctx:
-                self._update(R, t, position_noise, orientation_noise)
+        ctx = e.stream_ctx() if hasattr(e, "stream_ctx") else contextlib.nullcontext()
+        with ctx:
+            self._update(R, t, position_noise, orientation_noise)
         if extra:
             e.semantic_update(extra, R, t)
 
@@ -494,186 +396,3 @@ class ShardedElevationMap:
             e.post(0)
 
 
-# ---------------------------------------------------------------------------------------------------------------
-def bench_main(a, rank, world, local_rank):
-    """``bench.py --gpus N`` under torch.distributed.run: row strips of the SAME workload as N=1 (strong scaling)."""
-    import torch
-    import torch.distributed as dist
-    from .configs import CORE_PARAM_YAML, parameter_from
-
-    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import _fixtures as fx
-
-    # RCCL prints its version banner on stdout through C stdio: keep fd 1 pointed at stderr until the JSON line is due
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
-    n_dev = max(1, torch.cuda.device_count())
-    oversubscribed = world > n_dev          # more ranks than GPUs (single-GPU boxes): ranks share devices, RCCL refuses that => gloo
-    local_rank = local_rank % n_dev
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        # CPU tensors (bootstrap, timing reductions) go through gloo; the nccl backend is only instantiated if the
-        # torch-driven fallback below has to move device tensors.  Single node: keep gloo on the loopback interface (the
-        # container hostname may not resolve); if gloo cannot come up at all, everything runs over nccl.
-        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")       # RCCL's bootstrap sockets too (data moves over xGMI / shared memory)
-        try:
-            dist.init_process_group(backend="gloo" if oversubscribed else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
-        except Exception as ex:  # noqa: BLE001
-            print("[rank %d] gloo bootstrap unavailable (%s); using nccl only" % (rank, ex), file=sys.stderr)
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    cpu_ok = "gloo" in str(dist.get_backend())
-    cfg = dict(CORE_PARAM_YAML)
-    multimodal = a.workload == "cfg5"
-    if a.workload in ("cfg2", "cfg5"):
-        cfg.update(enable_visibility_cleanup=False, enable_overlap_clearance=False)
-    C, N = a.cell_n, a.points
-    if multimodal and C > 2049:
-        a.mode = "fp32"
-    w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
-    weights = {k: w[k] for k in ("w1", "w2", "w3", "w_out")}
-    par = parameter_from(cfg, C, a.mode, weights, device=local_rank)
-    # frames with the visibility pass: strips of equal ray work (thin around the sensor) instead of equal height
-    row_w = None
-    # (a frame that marches its rays BY RAY -- emap_set_ray_mode -- wants equal heights; this engine drives the frame stage by stage
-    # from Python, i.e. always by row: frame_marches_by_ray(..., comm_kind="torch") is False whatever the map size)
-    if cfg["enable_visibility_cleanup"] and world > 1 and not frame_marches_by_ray(C, N, world, "torch") and os.environ.get("EMAP_STRIPS", "balanced") == "balanced":
-        row_w = ray_balanced_weights(C, float(cfg["resolution"]), float(cfg["max_ray_length"]), halo_rows_needed(cfg["dilation_size"], world), world)
-    eng = HipStripEngine(par, rank, world, local_rank, dev, row_w)
-    comm, comm_kind = None, ("torch" if oversubscribed else os.environ.get("EMAP_COMM", "native"))
-
-    def all_agree(ok):
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=None if cpu_ok else dev)
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # CPU tensor: gloo
-        return int(flag.item()) == 1
-
-    if comm_kind == "native":
-        # every step that can fail on one rank only is followed by an agreement, so that no rank is left alone in a collective
-        try:
-            comm = NativeComm(eng)
-        except Exception as ex:  # noqa: BLE001
-            print("[rank %d] native RCCL path unavailable (%s)" % (rank, ex), file=sys.stderr)
-            comm = None
-        if all_agree(comm is not None):
-            try:
-                comm.selftest()
-                ok = True
-            except Exception as ex:  # noqa: BLE001
-                print("[rank %d] RCCL self-test failed (%s)" % (rank, ex), file=sys.stderr)
-                ok = False
-            if not all_agree(ok):
-                comm = None
-        else:
-            comm = None
-        if comm is None and rank == 0:
-            print("falling back to torch.distributed collectives", file=sys.stderr)
-    if comm is None:
-        comm_kind = "torch"
-        comm = TorchComm(dev)
-    sm = ShardedElevationMap(eng, comm, cfg["enable_visibility_cleanup"], cfg["enable_overlap_clearance"])
-
-    NCLOUD = 2 if multimodal else 5
-    channels, stride = None, 3
-    if multimodal:                      # rgb (packed 24 bit) + 3 averaged semantic channels, as bench.py builds them at N = 1
-        channels, stride = ["x", "y", "z", "rgb", "sem0", "sem1", "sem2"], 7
-        par.pointcloud_channel_fusions = {"rgb": "color", "default": "average"}
-        host = []
-        for s_ in range(NCLOUD):
-            p_ = fx.cloud(C, N, s_, dz=-0.02 * s_, extra=4)
-            rng = np.random.default_rng(100 + s_)
-            p_[:, 3] = rng.integers(0, 1 << 24, N, dtype=np.uint32).view(np.float32)
-            p_[:, 4:7] = rng.uniform(0, 1, (N, 3)).astype(np.float32)
-            host.append(p_)
-        clouds = [torch.from_numpy(p_).to(dev) for p_ in host]
-    else:
-        clouds = [torch.from_numpy(fx.cloud(C, N, s, dz=(0.0 if s == 0 else -0.02 * s))).to(dev) for s in range(NCLOUD)]
-    R = np.eye(3, dtype=np.float32).ravel().copy()
-    t = np.array([0, 0, 1], np.float32)
-
-    def frame(i):
-        cl = clouds[i % NCLOUD]
-        eng.bind_points_device(cl.data_ptr(), N, stride)
-        sm.update(R, t, 1.0, 1.0, channels)
-
-    for i in range(3):
-        frame(i)
-        for _ in range(4):
-            eng.update_time()
-    eng.update_variance()
-    for i in range(a.warmup):
-        frame(i)
-    torch.cuda.synchronize(); comm.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        frame(i)
-    torch.cuda.synchronize()
-    wall_local = time.perf_counter() - t0
-    comm.barrier(); torch.cuda.synchronize()
-    wall = comm.max_float(max(wall_local, 0.0))
-    # per-stage device time of THIS rank's strip (hipEvents on the strip's stream) -> roofline of its dominant kernel.
-    # Algorithmic bytes of a strip: every rank reads the whole replicated cloud, but sorts / fuses only the points of its
-    # rows (N / world for uniform clouds) and streams only its L / world cells.
-    roof = None
-    if isinstance(comm, NativeComm):
-        from ._lib import STAGES
-        eng.lib.emap_enable_stage_timing(eng.ctx, 1)
-        reps, acc = min(a.steps, 20), np.zeros(10)
-        for i in range(reps):
-            frame(i)
-            ms10 = (ct.c_float * 10)()
-            eng.lib.emap_get_stage_times(eng.ctx, ms10)
-            acc += np.array(list(ms10))
-        eng.lib.emap_enable_stage_timing(eng.ctx, 0)
-        torch.cuda.synchronize(); comm.barrier()
-        stage_ms = dict(zip(STAGES, (acc / reps).tolist()))
-        strip_bytes = strip_stage_bytes(N, C * C, world, full_sort=bool(cfg["enable_visibility_cleanup"]))
-        empty = []                       # spacing of an event pair with nothing in between (bench.py does the same calibration)
-        for _ in range(50):
-            e_ms = ct.c_float(0)
-            eng.lib.emap_timer_begin(eng.ctx); eng.lib.emap_timer_end(eng.ctx, ct.byref(e_ms)); empty.append(e_ms.value)
-        ev_overhead = float(np.median(empty))
-        kernels = {k: v for k, v in stage_ms.items() if strip_bytes[k] > 0}
-        dom = max(kernels, key=kernels.get)
-        dom_ms = max(stage_ms[dom] - ev_overhead, 1e-6)
-        achieved = strip_bytes[dom] / (dom_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-                "traffic": None, "algorithmic_bytes": int(strip_bytes[dom]), "kernel_ms": round(dom_ms, 5), "event_pair_overhead_ms": round(ev_overhead, 5), "rank": 0,
-                "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
-                "note": "rank 0's strip; 'gate' includes the all-reduce, 'post' the halo exchange overlapped with the interior stencils"}
-    if rank == 0:
-        out = {
-            "metric": "Mpoints/s fused (map-update p50 latency in config)", "value": round(N * a.steps / wall / 1e6, 2),
-            "unit": "Mpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(wall * 1e3 / a.steps, 5), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d map in %d row strips, %d uniform-random points/frame replicated to every rank, "
-                                   "core_param.yaml values" % (a.workload, C, C, world, N),
-                       "index_mode": a.mode, "halo_rows": eng.halo, "parallelism": "row-strips x%d" % world, "ranks": world,
-                       "physical_devices": min(n_dev, world), "oversubscribed": bool(oversubscribed),
-                       "strip_heights": "equal ray work (thin around the sensor)" if row_w is not None else "equal",
-                       "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame (RCCL, %s)" %
-                                      ("issued by the C library, halo exchange in place on a second stream" if comm_kind == "native"
-                                       else "driven through torch.distributed")},
-            "roofline": roof, "cpu_baseline": None,
-        }
-    comm.barrier()
-    if isinstance(comm, NativeComm):
-        eng.lib.emap_comm_destroy(eng.ctx)
-    dist.destroy_process_group()
-    try:
-        ct.CDLL(None).fflush(None)
-    except OSError:
-        pass
-    sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    os.close(saved_stdout)
-    if rank == 0:
-        print(json.dumps(out), flush=True)

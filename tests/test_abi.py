@@ -65,6 +65,19 @@ def test_product_never_imports_the_oracle():
                 assert "emap_oracle" not in txt, f
 
 
+def test_product_imports_neither_torch_nor_test_code():
+    """north_star: "no PyTorch, no CuPy, no Triton" -- the package and the compat layer import none of them, and nothing from tests/
+    (the torch.distributed communicator of the strip tests lives in tests/_torch_strips.py)"""
+    for top in ("elevation_mapping_cupy_amd", "compat"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith(".py"):
+                    txt = open(os.path.join(dirpath, f)).read()
+                    assert not re.search(r"^\s*(from|import)\s+(torch|cupy|triton)\b", txt, flags=re.M), os.path.join(dirpath, f)
+                    assert not re.search(r"^\s*(from|import)\s+(_fixtures|_util|_torch_strips|conftest)\b", txt, flags=re.M), os.path.join(dirpath, f)
+                    assert "\"tests\"" not in txt and "'tests'" not in txt, os.path.join(dirpath, f)
+
+
 def test_integration_doc_names_every_entry_point():
     """INTEGRATION.md section D lists every entry point of the header next to the reference interface it replaces: a symbol added to
     the ABI without its row there fails here"""

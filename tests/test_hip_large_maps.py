@@ -74,7 +74,8 @@ def test_config4_four_strips_reproduce_the_single_context(weights):
     from test_hip_strips import ThreadComm
     from elevation_mapping_cupy_amd.configs import parameter_from
     from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
-    from elevation_mapping_cupy_amd.sharded import HipStripEngine, ShardedElevationMap
+    from elevation_mapping_cupy_amd.sharded import ShardedElevationMap
+    from _torch_strips import TorchStripEngine as HipStripEngine      # (the stage-by-stage orchestration needs exchange buffers: test infrastructure)
     C, N, world = 4096, 2_000_000, 4
     cfg = _cfg4()
     R, t = fx.POSES["rotated"]

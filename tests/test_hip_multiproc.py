@@ -1,6 +1,7 @@
-"""GPU, multi-process: two OS processes (torch.distributed, one rank each) drive two HipStripEngine strips on the SAME
-MI355X -- gloo carries the collectives here because RCCL refuses two ranks on one device; everything else (process
-model, TorchComm, device tensors handed to the C ABI, stream ordering) is the code path of the multi-GPU bench."""
+"""GPU, multi-process: two OS processes (one rank each) drive two strips on the SAME MI355X, the frame orchestrated stage by stage
+(ShardedElevationMap._update) -- gloo carries the collectives because RCCL refuses two ranks on one device and the in-process RCCL
+stand-ins cannot span processes; communicator and buffer-owning engine are test infrastructure (tests/_torch_strips.py).  The
+product's own multi-rank frame (emap_update_sharded over RCCL) is covered by test_hip_comm.py / test_hip_large_strips.py."""
 import os
 import socket
 import sys
@@ -23,7 +24,8 @@ def _worker(rank, world, port, outdir, C, N, rays):
     import torch.distributed as dist
     import _fixtures as fx
     from elevation_mapping_cupy_amd.configs import parameter_from
-    from elevation_mapping_cupy_amd.sharded import HipStripEngine, ShardedElevationMap, TorchComm
+    from elevation_mapping_cupy_amd.sharded import ShardedElevationMap
+    from _torch_strips import TorchComm, TorchStripEngine as HipStripEngine
     from oracle import emap_oracle as eo
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -1,7 +1,7 @@
 """GPU: the strip kernels (row0/nrows/halo addressing, owned-row filter of points and rays, device-side drift sums,
 halo pack/unpack) -- G strip contexts on ONE device driven in lock-step by threads must reproduce the single-context
 map bit for bit.  (The multi-process exchange itself is covered on CPU by tests/test_sharded_gloo.py; the driver's
-multi-GPU run uses the same ShardedElevationMap with TorchComm over RCCL.)"""
+multi-GPU run is emap_update_sharded over RCCL: test_hip_comm.py.)"""
 import threading
 
 import numpy as np
@@ -55,7 +55,8 @@ def test_strip_contexts_reproduce_single_context(world, cfg_name, C, weights):
     import torch
     from elevation_mapping_cupy_amd.configs import parameter_from
     from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
-    from elevation_mapping_cupy_amd.sharded import HipStripEngine, ShardedElevationMap
+    from elevation_mapping_cupy_amd.sharded import ShardedElevationMap
+    from _torch_strips import TorchStripEngine as HipStripEngine      # (the stage-by-stage orchestration needs exchange buffers: test infrastructure)
     from oracle import emap_oracle as eo
     from elevation_mapping_cupy_amd.sharded import ray_balanced_weights, strip_rows
     cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML if cfg_name.startswith("yaml") else {})
@@ -110,7 +111,8 @@ def test_strips_fuse_rgb_and_semantic_channels_like_the_single_context(world, sc
     import torch
     from elevation_mapping_cupy_amd.configs import parameter_from
     from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
-    from elevation_mapping_cupy_amd.sharded import HipStripEngine, ShardedElevationMap
+    from elevation_mapping_cupy_amd.sharded import ShardedElevationMap
+    from _torch_strips import TorchStripEngine as HipStripEngine      # (the stage-by-stage orchestration needs exchange buffers: test infrastructure)
     from oracle import emap_oracle as eo
     C, N = 202, 30000
     cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML, enable_visibility_cleanup=False)
@@ -177,7 +179,8 @@ def test_strips_follow_the_robot_like_the_single_context(world, cfg_name, weight
     import torch
     from elevation_mapping_cupy_amd.configs import parameter_from
     from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap
-    from elevation_mapping_cupy_amd.sharded import HipStripEngine, ShardedElevationMap
+    from elevation_mapping_cupy_amd.sharded import ShardedElevationMap
+    from _torch_strips import TorchStripEngine as HipStripEngine      # (the stage-by-stage orchestration needs exchange buffers: test infrastructure)
     from oracle import emap_oracle as eo
     C, N = 130, 30000
     cfg = dict(eo.DEFAULTS); cfg.update(eo.YAML)

@@ -82,7 +82,8 @@ def _worker(rank, world, port, outdir, cfg_name, C, N):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     import torch.distributed as dist
     import _fixtures as fx
-    from elevation_mapping_cupy_amd.sharded import ShardedElevationMap, TorchComm
+    from elevation_mapping_cupy_amd.sharded import ShardedElevationMap
+    from _torch_strips import TorchComm
     from oracle import emap_oracle as eo
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
