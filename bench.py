@@ -117,8 +117,9 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
-                    help="cfg2/cfg3: BASELINE configs[1]/[2] (1024^2, 1 M points); cfg4: configs[3] (4096^2, 4 M points, fp32 index mode, "
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "ref_main"],
+                    help="ref_main: the reference's own profiling loop (EM/elevation_mapping.py:925-967) through the drop-in package, per-call "
+                         "host latencies + one stage-timed line each for the MinFilter plugin, the layer read-back and the camera path; cfg2/cfg3: BASELINE configs[1]/[2] (1024^2, 1 M points); cfg4: configs[3] (4096^2, 4 M points, fp32 index mode, "
                          "rays + overlap on); cfg5: 8192^2 multi-modal map (height + RGB + 3 semantic layers), 16 M points, fp32 index "
                          "mode, rays/overlap off")
     ap.add_argument("--points", type=int, default=None, help="default 1 M (cfg2/cfg3), 4 M (cfg4) or 16 M (cfg5)")
@@ -1172,6 +1173,156 @@ def run_strips(a, rank, world, local_rank):
     rdv.finish()
 
 
+# -------------------------------------------------------------------------------------------------------------------------------
+SHIPPED_PLUGINS = """
+min_filter: {enable: True, fill_nan: False, is_height_layer: True, layer_name: "min_filter", extra_params: {dilation_size: 1, iteration_n: 30}}
+smooth_filter: {enable: True, fill_nan: False, is_height_layer: True, layer_name: "smooth", extra_params: {input_layer_name: "min_filter"}}
+inpainting: {enable: True, fill_nan: False, is_height_layer: True, layer_name: "inpaint", extra_params: {method: "telea"}}
+erosion: {enable: True, fill_nan: False, is_height_layer: False, layer_name: "erosion", extra_params: {input_layer_name: "traversability", dilation_size: 3, iteration_n: 20, reverse: True}}
+"""
+
+
+def _pct(xs):
+    return {"p10": round(float(np.percentile(xs, 10)) * 1e3, 4), "p50": round(float(np.percentile(xs, 50)) * 1e3, 4), "p90": round(float(np.percentile(xs, 90)) * 1e3, 4)}
+
+
+def run_ref_main(a, local_rank=0):
+    """The boundary, not just the ABI: the loop of the reference's own profiling script (EM/elevation_mapping.py:925-967 -- 50 x
+    {input_pointcloud of a 100 000 x 7 HOST float64 cloud, update_normal, move_to, seven get_map_with_name_ref, one
+    get_polygon_traversability}) through the drop-in package (compat/elevation_mapping_cupy), every call timed on the host; and one
+    stage-timed line each for the rows of SURVEY section 8 that had no number: the MinFilter plugin (a15, as shipped: 1 x 30 sweeps), the
+    layer read-back (f3: emap_publish_layer) and the camera path (f4: emap_image_correspondence + emap_image_fuse)."""
+    import pickle
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "compat"))
+    from elevation_mapping_cupy import elevation_mapping as em_mod
+    from elevation_mapping_cupy import parameter as par_mod
+    from elevation_mapping_cupy_amd import _lib
+    d = tempfile.mkdtemp(prefix="emap_refmain_")
+    w = load_weights()
+    with open(os.path.join(d, "weights.dat"), "wb") as f:
+        pickle.dump({"conv1.weight": w["w1"], "conv2.weight": w["w2"], "conv3.weight": w["w3"], "conv_final.weight": w["w_out"]}, f)
+    with open(os.path.join(d, "plugin_config.yaml"), "w") as f:
+        f.write(SHIPPED_PLUGINS)
+    param = par_mod.Parameter(use_chainer=False, weight_file=os.path.join(d, "weights.dat"), plugin_config_file=os.path.join(d, "plugin_config.yaml"))
+    param.additional_layers = ["rgb", "grass", "tree", "people"]
+    # (the script's `param.fusion_algorithms = ["color", "class_bayesian" x 3]` is the pre-plugin spelling: in the reference's current
+    # API that list names the fusion PLUGINS to register, so the intent -- rgb by colour, the classes by class_bayesian -- goes here)
+    param.pointcloud_channel_fusions = {"rgb": "color", "default": "class_bayesian"}
+    param.update()
+    param.device = local_rank
+    elevation = em_mod.ElevationMap(param)
+    lib, ctx = elevation._lib, elevation._ctx
+    layers = ["elevation", "variance", "traversability", "min_filter", "smooth", "inpaint", "rgb"]
+    rng = np.random.default_rng(123)
+    R, t = rng.random((3, 3)), rng.random(3)
+    points = rng.random((100000, len(layers)))                      # float64, as xp.random.rand gives it
+    channels = ["x", "y", "z"] + list(param.additional_layers)
+    data = np.zeros((elevation.cell_n - 2, elevation.cell_n - 2), dtype=np.float32)
+    calls = {k: [] for k in ["input_pointcloud", "update_normal", "move_to", "get_map_with_name_ref x7", "get_polygon_traversability", "iteration"]}
+    per_layer = {k: [] for k in layers}
+
+    def timed_call(key, fn):
+        t0 = time.perf_counter(); r = fn(); calls[key].append(time.perf_counter() - t0); return r
+
+    def get_all():
+        for layer in layers:
+            t0 = time.perf_counter(); elevation.get_map_with_name_ref(layer, data); per_layer[layer].append(time.perf_counter() - t0)
+    n_it = max(10, a.steps)
+    for i in range(a.warmup + n_it):
+        if i == a.warmup:
+            for v in list(calls.values()) + list(per_layer.values()):
+                del v[:]
+        t_it = time.perf_counter()
+        timed_call("input_pointcloud", lambda: elevation.input_pointcloud(points, channels, R, t.copy(), 0, 0))
+        timed_call("update_normal", lambda: elevation.update_normal(elevation.elevation_map[0]))
+        pos = np.array([i * 0.01, i * 0.02, i * 0.01])
+        timed_call("move_to", lambda: elevation.move_to(pos, R))
+        timed_call("get_map_with_name_ref x7", get_all)
+        polygon = np.array([[0, 0], [2, 0], [0, 2]], dtype=np.float64)
+        result = np.array([0, 0, 0], np.float64)
+        timed_call("get_polygon_traversability", lambda: elevation.get_polygon_traversability(polygon, result))
+        calls["iteration"].append(time.perf_counter() - t_it)
+    elevation.sync() if hasattr(elevation, "sync") else None
+    # device time of the frame inside input_pointcloud (the stage events of emap_update) next to the call's host time
+    lib.emap_enable_stage_timing(ctx, 1)
+    dev_ms = []
+    for i in range(10):
+        elevation.input_pointcloud(points, channels, R, t.copy(), 0, 0)
+        ms10 = (ct.c_float * 10)(); lib.emap_get_stage_times(ctx, ms10); dev_ms.append(float(sum(ms10)))
+    lib.emap_enable_stage_timing(ctx, 0)
+    frame_dev_ms = float(np.median(dev_ms))
+    wall = float(np.sum(calls["iteration"]))
+    it_ms = float(np.median(calls["iteration"])) * 1e3
+
+    # ---- stage-timed lines: device time by an event pair on the context's stream around the call, host time beside it ---------------
+    def staged(fn, reps=20):
+        host, dev = [], []
+        e_ms = ct.c_float(0)
+        for _ in range(reps + 2):
+            lib.emap_sync(ctx)
+            lib.emap_timer_begin(ctx); t0 = time.perf_counter(); rc = fn(); th = time.perf_counter() - t0; lib.emap_timer_end(ctx, ct.byref(e_ms))
+            if rc:
+                raise RuntimeError(lib.emap_last_error(ctx).decode())
+            host.append(th); dev.append(e_ms.value)
+        return round(float(np.median(host[2:])) * 1e3, 4), round(float(np.median(dev[2:])), 4)
+
+    stages = {}
+    from elevation_mapping_cupy_amd.elevation_mapping import ElevationMap as AmdMap
+    from elevation_mapping_cupy_amd.configs import parameter_from
+    for C in (202, 1024):
+        par = parameter_from(workload_cfg("cfg2"), C, "reference_fp16", w); par.device = local_rank
+        m = AmdMap(par)
+        ml, mc = m._lib, m._ctx
+        import _fixtures as fx
+        Rm, tm = fx.POSES["identity"]
+        for f_ in range(3):
+            m.update_map_with_kernel(fx.cloud(C, 50000 if C == 202 else 1_000_000, f_), [], Rm, tm.copy(), 1.0, 1.0)
+        L = C * C
+        out = np.empty((C, C), np.float32); sweeps = ct.c_int32(0)
+        lib_, ctx_ = lib, ctx
+        lib, ctx = ml, mc                       # (staged() times on the context it is given)
+        h_ms, d_ms = staged(lambda: ml.emap_min_filter(mc, None, None, 1, 30, _lib.f32p(out), ct.byref(sweeps)))
+        nsw = max(1, int(sweeps.value))
+        stages["min_filter_%d" % C] = {"what": "emap_min_filter (a15, MinFilter plugin as shipped: dilation 1, <= 30 Jacobi sweeps with a device-side early exit), the map's own planes, result read back",
+                                        "cells": L, "sweeps_run": nsw, "host_ms": h_ms, "device_ms": d_ms, "Gcells_per_s": round(L * nsw / (d_ms * 1e-3) / 1e9, 2),
+                                        "algorithmic_bytes": int(16 * L * nsw + 4 * L), "frac_hbm": round((16.0 * L * nsw + 4 * L) / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        pub = np.empty((C - 2, C - 2), np.float32)
+        h_ms, d_ms = staged(lambda: ml.emap_publish_layer(mc, 0, ct.c_float(0.0), 0, _lib.f32p(pub)))
+        stages["publish_layer_%d" % C] = {"what": "emap_publish_layer (f3: get_map_with_name_ref('elevation') -- strip, NaN fill, + center_z, double flip in one kernel + one D2H of (C-2)^2 floats)",
+                                           "cells": L, "host_ms": h_ms, "device_ms": d_ms, "Gcells_per_s": round(L / (d_ms * 1e-3) / 1e9, 2),
+                                           "algorithmic_bytes": int(8 * L + 4 * (C - 2) ** 2), "d2h_GBs": round(4.0 * (C - 2) ** 2 / (h_ms * 1e-3) / 1e9, 2),
+                                           "frac_hbm": round((8.0 * L + 4 * (C - 2) ** 2) / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # camera path: a 480 x 640 pinhole looking down at the map from 3 m, one feature plane (exponential fusion needs a layer)
+        if ml.emap_semantic_configure(mc, 1):
+            raise RuntimeError(ml.emap_last_error(mc).decode())
+        H, W = 480, 640
+        K = np.array([[400, 0, W / 2], [0, 400, H / 2], [0, 0, 1]], np.float32)
+        Rc = np.array([[1, 0, 0], [0, -1, 0], [0, 0, -1]], np.float32); tc = np.array([0, 0, 3], np.float32)
+        Pm = (K @ np.concatenate([Rc, tc[:, None]], 1)).astype(np.float32)
+        D = np.zeros(5, np.float32); cen = np.zeros(3, np.float32)
+        img = np.random.default_rng(3).random((1, H, W), dtype=np.float32)
+        h1, d1 = staged(lambda: ml.emap_image_correspondence(mc, ct.c_float(C / 2), ct.c_float(C / 2), ct.c_float(3.0), _lib.f32p(np.ascontiguousarray(Pm.reshape(-1))),
+                                                             _lib.f32p(np.ascontiguousarray(K.reshape(-1))), _lib.f32p(D), ct.c_float(H), ct.c_float(W), _lib.f32p(cen)))
+        h2, d2 = staged(lambda: ml.emap_image_fuse(mc, 0, 0, _lib.f32p(img), 1, H, W, ct.c_double(0.7)))
+        stages["image_%d" % C] = {"what": "f4 camera path: emap_image_correspondence (projection + Bresenham occlusion walk per cell) then emap_image_fuse (one 480 x 640 plane uploaded, exponential fusion)",
+                                   "cells": L, "correspondence": {"host_ms": h1, "device_ms": d1, "Gcells_per_s": round(L / (d1 * 1e-3) / 1e9, 2)},
+                                   "fuse": {"host_ms": h2, "device_ms": d2, "Gcells_per_s": round(L / (d2 * 1e-3) / 1e9, 2), "image_bytes": int(img.nbytes)}}
+        lib, ctx = lib_, ctx_
+        m.close()
+    out = {"metric": "reference profiling loop (EM/elevation_mapping.py:925-967) through the drop-in package, iterations/s", "value": round(n_it / wall, 2),
+           "unit": "iterations/s", "n_gpus": 1, "steps": n_it, "warmup": a.warmup, "ms_per_step": round(it_ms, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "ref_main: %dx%d map (Parameter defaults), 100000 x 7 host float64 cloud per iteration (rgb: color, grass / tree / people: class_bayesian), "
+                                  "shipped plugin configuration (min_filter 1 x 30, smooth, inpaint telea, erosion), seven layers read back per iteration" % (elevation.cell_n, elevation.cell_n),
+                      "host_ms_per_call": {k: _pct(v) for k, v in calls.items()},
+                      "get_map_with_name_ref_ms": {k: _pct(v) for k, v in per_layer.items()},
+                      "input_pointcloud": {"host_ms_p50": _pct(calls["input_pointcloud"])["p50"], "frame_device_ms": round(frame_dev_ms, 4),
+                                           "note": "device = sum of the frame's stage event spacings; the call returns without waiting for the device (no statistics read back)"},
+                      "stage_lines": stages}}
+    print(json.dumps(out), flush=True)
+
+
 def launch_ranks(a, argv):
     """bench.py was started without a launcher: become one (one process per GPU, WORLD_SIZE = --gpus)"""
     from elevation_mapping_cupy_amd import launch
@@ -1193,6 +1344,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or a.force_sharded or a.dry_run:
         return run_strips(a, rank, world, local_rank)
+    if a.workload == "ref_main":
+        return run_ref_main(a, local_rank)
     return run_single(a, local_rank)
 
 
