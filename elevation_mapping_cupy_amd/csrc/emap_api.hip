@@ -197,7 +197,7 @@ struct emap_ctx {
   int up_slot; bool up_used[2]; hipStream_t copy_stream; Workers* workers;
   const float* pts; long n_pts; int stride;         // xyz of the bound cloud: rows of `stride` floats (3 for a de-interleaved cloud)
   long n_pts_all;                                   // size of the cloud the caller handed over (> n_pts for a bucketed one): what every rank of a sharded map shares
-  bool pts_bucketed; float bucket_R[9], bucket_t[3];   // the bound cloud only holds the points that can land in this strip's rows under this pose (emap_upload_points_strip)
+  bool pts_bucketed; float bucket_R[9], bucket_t[3]; int bucket_org_r;   // the bound cloud only holds the points that can land in this strip's rows under this pose (emap_upload_points_strip)
   ChanView chan; int n_cols;                        // its extra channels (emap_device.h: ChanView); n_cols = columns of the caller's matrix (3 + K)
   int* tail_idx; unsigned char* tail_flags; long tail_cap;
   // frame state
@@ -751,7 +751,7 @@ int emap_upload_points_strip(emap_ctx* ctx, const void* host, int64_t n, int64_t
   const StripKeep keep(ctx, R, t);
   int rc = upload_impl(ctx, host, n, stride, dtype, &keep, n_kept);
   if (rc) return rc;
-  ctx->pts_bucketed = true;
+  ctx->pts_bucketed = true; ctx->bucket_org_r = ctx->kp.org_r;
   memcpy(ctx->bucket_R, R, sizeof ctx->bucket_R); memcpy(ctx->bucket_t, t, sizeof ctx->bucket_t);
   return EMAP_OK;
 }
@@ -778,7 +778,7 @@ int emap_strip_point_mask(emap_ctx* ctx, const void* host, int64_t n, int64_t st
 int emap_declare_points_bucketed(emap_ctx* ctx, const float R[9], const float t[3], int64_t n_all) {
   CKARG(ctx && R && t && n_all >= ctx->n_pts, "bad argument");
   if (ctx->strip.row_count >= ctx->prm.cell_n) return EMAP_OK;
-  ctx->pts_bucketed = true; ctx->n_pts_all = (long)n_all;
+  ctx->pts_bucketed = true; ctx->n_pts_all = (long)n_all; ctx->bucket_org_r = ctx->kp.org_r;
   memcpy(ctx->bucket_R, R, sizeof ctx->bucket_R); memcpy(ctx->bucket_t, t, sizeof ctx->bucket_t);
   return EMAP_OK;
 }
@@ -968,6 +968,12 @@ static GateArgs gate_args(emap_ctx* ctx, double position_noise, double orientati
 
 int emap_count(emap_ctx* ctx, const float R[9], const float t[3]) {
   CKARG(ctx && R && t, "null argument"); SF_CHECK(); NEED_POINTS();
+  // a cloud bucketed for this strip holds the points of its rows under ONE pose and ONE row origin: the common entry point of every
+  // frame (whole, sharded or staged) checks both -- a row shift in between moves the strip's logical rows under the kept points
+  if (ctx->pts_bucketed) {
+    CKARG(memcmp(ctx->bucket_R, R, sizeof ctx->bucket_R) == 0 && memcmp(ctx->bucket_t, t, sizeof ctx->bucket_t) == 0, "the bound cloud was bucketed for another pose (emap_upload_points_strip)");
+    CKARG(ctx->bucket_org_r == ctx->kp.org_r, "the map's rows shifted since the bound cloud was bucketed for this strip (emap_upload_points_strip): upload it again");
+  }
   if (!ctx->in_update) { ctx->gate_possible = true; ctx->carry_want = false; }          // the staged API always gathers the statistics and sorts plain 16-byte records
   ctx->bin_rs = 1;
   CK(hipSetDevice(ctx->device));
@@ -2111,6 +2117,7 @@ static long window_cap(const emap_ctx* ctx);
 static int alloc_window(emap_ctx* ctx, long cap);
 int emap_comm_init(emap_ctx* ctx, const char* rccl_path, const uint8_t id[128], int32_t rank, int32_t world) {
   CKARG(ctx && id && world >= 1 && rank >= 0 && rank < world, "bad rank / world");
+  CKARG(world <= 16, "at most 16 ranks");                    // (before anything collective: every rank sees the same `world`)
   CKARG(!ctx->rccl, "communicator already initialised");
   CKARG(world == 1 || ctx->strip.halo_rows > 0, "a strip of a multi-rank map needs halo rows");
   CK(hipSetDevice(ctx->device));
@@ -2122,45 +2129,52 @@ int emap_comm_init(emap_ctx* ctx, const char* rccl_path, const uint8_t id[128], 
   ncclResult_t r = a->CommInitRank(&ctx->comm, world, uid, rank);
   if (r != ncclSuccess) { ctx->err = std::string("ncclCommInitRank: ") + a->GetErrorString(r); delete a; ctx->rccl = nullptr; ctx->comm = nullptr; return EMAP_ERR_COMM; }
   ctx->comm_rank = rank; ctx->comm_world = world;
-  CK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
-  CK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
-  CK(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
-  CK(hipMalloc((void**)&ctx->comm_sums, sizeof(double) * 36));
-  CK(hipMemsetAsync(ctx->comm_sums, 0, sizeof(double) * 36, ctx->stream));
-  // Every rank must speak the same ABI: the halo rows are raw 16-byte cold half cells and the ray window raw 48-byte records, so a
-  // peer built against another layout would exchange misaligned bytes silently.  max(v) and max(-v) over the ranks: equal and
-  // opposite iff all ranks agree.
-  if (world > 1 && ctx->prm.enable_visibility_cleanup && ctx->win_cap < window_cap(ctx)) {      // rays by ray: see ensure_window
-    int rc = alloc_window(ctx, window_cap(ctx)); if (rc) return rc;
-  }
+  // From here on the call is COLLECTIVE: a rank that fails locally must not leave the others waiting in an all-reduce.  The local set-up
+  // therefore only collects a status; the first all-reduce carries it (max over the ranks) together with the ABI check, every rank
+  // returns the same verdict, and a failed init leaves no half-built communicator behind.
+  int local_rc = EMAP_OK;
+  auto step = [&](hipError_t e, const char* what) { if (local_rc == EMAP_OK && e != hipSuccess) { local_rc = EMAP_ERR_HIP; ctx->err = std::string(what) + ": " + hipGetErrorString(e); } };
+  step(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking), "hipStreamCreate(comm)");
+  step(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming), "hipEventCreate");
+  step(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming), "hipEventCreate");
+  step(hipMalloc((void**)&ctx->comm_sums, sizeof(double) * 36), "hipMalloc(comm_sums)");
+  if (local_rc == EMAP_OK) step(hipMemsetAsync(ctx->comm_sums, 0, sizeof(double) * 36, ctx->stream), "hipMemsetAsync(comm_sums)");
+  if (local_rc == EMAP_OK && world > 1 && ctx->prm.enable_visibility_cleanup && ctx->win_cap < window_cap(ctx))      // rays by ray: see ensure_window
+    local_rc = alloc_window(ctx, window_cap(ctx));
+  auto fail = [&](int rc) { const std::string keep = ctx->err; emap_comm_destroy(ctx); ctx->err = keep; return rc; };
+  if (world > 1 && !ctx->comm_sums) return fail(local_rc ? local_rc : EMAP_ERR_HIP);      // (nothing to reduce through: the peers time out in RCCL -- an out-of-memory device at start-up)
   // every rank's owned physical rows (the strips need not be equally high): who holds which normal rows after a row shift
   ctx->cut_begin.assign(world, 0); ctx->cut_count.assign(world, 0);
   ctx->cut_begin[rank] = ctx->strip.row_begin; ctx->cut_count[rank] = ctx->strip.row_count;
   if (world > 1) {
-    CKARG(world <= 16, "at most 16 ranks");
-    double mine[32], got[32];
-    for (int k = 0; k < 32; ++k) mine[k] = 0.0;
-    mine[2 * rank] = ctx->strip.row_begin; mine[2 * rank + 1] = ctx->strip.row_count;
-    CK(hipMemcpyAsync(ctx->comm_sums + 4, mine, sizeof(double) * 2 * 16, hipMemcpyHostToDevice, ctx->stream));      // ([4..36): the host all-reduce's slots)
-    CKN(a->AllReduce(ctx->comm_sums + 4, ctx->comm_sums + 4, 2 * (size_t)world, ncclFloat64, ncclSum, ctx->comm, ctx->stream));
-    CK(hipMemcpyAsync(got, ctx->comm_sums + 4, sizeof(double) * 2 * world, hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    long total = 0;
-    for (int r = 0; r < world; ++r) { ctx->cut_begin[r] = (int)got[2 * r]; ctx->cut_count[r] = (int)got[2 * r + 1]; total += ctx->cut_count[r]; }
-    ctx->cuts_ok = total == ctx->prm.cell_n;               // (checked where the boundaries are needed: normal_exchange)
-  }
-  if (world > 1) {
-    const double mine[2] = {(double)EMAP_ABI_VERSION, -(double)EMAP_ABI_VERSION};
-    double got[2] = {0.0, 0.0};
+    // Every rank must speak the same ABI: the halo rows are raw 16-byte cold half cells and the ray window raw 32-byte records, so a
+    // peer built against another layout would exchange misaligned bytes silently.  max(v) and max(-v) over the ranks: equal and
+    // opposite iff all ranks agree; the third word is the worst local status.
+    const double mine[3] = {(double)EMAP_ABI_VERSION, -(double)EMAP_ABI_VERSION, (double)(local_rc != EMAP_OK)};
+    double got[3] = {0.0, 0.0, 0.0};
     CK(hipMemcpyAsync(ctx->comm_sums + 16, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
-    CKN(a->AllReduce(ctx->comm_sums + 16, ctx->comm_sums + 18, 2, ncclFloat64, ncclMax, ctx->comm, ctx->stream));
-    CK(hipMemcpyAsync(got, ctx->comm_sums + 18, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
+    CKN(a->AllReduce(ctx->comm_sums + 16, ctx->comm_sums + 20, 3, ncclFloat64, ncclMax, ctx->comm, ctx->stream));
+    CK(hipMemcpyAsync(got, ctx->comm_sums + 20, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
+    if (got[2] != 0.0) {
+      if (local_rc == EMAP_OK) ctx->err = "emap_comm_init: another rank could not set up its communicator state";
+      return fail(local_rc ? local_rc : EMAP_ERR_COMM);
+    }
     if (got[0] != mine[0] || got[1] != mine[1]) {
       ctx->err = "emap_comm_init: the ranks were built against different EMAP_ABI_VERSIONs (" + std::to_string((int)-got[1]) + " .. " + std::to_string((int)got[0]) + ", this rank: " + std::to_string(EMAP_ABI_VERSION) + ")";
-      return EMAP_ERR_COMM;
+      return fail(EMAP_ERR_COMM);
     }
-  }
+    double cuts[32], all[32];
+    for (int k = 0; k < 32; ++k) cuts[k] = 0.0;
+    cuts[2 * rank] = ctx->strip.row_begin; cuts[2 * rank + 1] = ctx->strip.row_count;
+    CK(hipMemcpyAsync(ctx->comm_sums + 4, cuts, sizeof(double) * 2 * 16, hipMemcpyHostToDevice, ctx->stream));      // ([4..36): the host all-reduce's slots)
+    CKN(a->AllReduce(ctx->comm_sums + 4, ctx->comm_sums + 4, 2 * (size_t)world, ncclFloat64, ncclSum, ctx->comm, ctx->stream));
+    CK(hipMemcpyAsync(all, ctx->comm_sums + 4, sizeof(double) * 2 * world, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    long total = 0;
+    for (int q = 0; q < world; ++q) { ctx->cut_begin[q] = (int)all[2 * q]; ctx->cut_count[q] = (int)all[2 * q + 1]; total += ctx->cut_count[q]; }
+    ctx->cuts_ok = total == ctx->prm.cell_n;               // (checked where the boundaries are needed: normal_exchange)
+  } else if (local_rc != EMAP_OK) return fail(local_rc);
   return EMAP_OK;
 }
 

@@ -190,6 +190,16 @@ def test_a_bucketed_cloud_refuses_what_it_cannot_serve(weights):
                 sm.update(R, t + np.float32(0.25), 1.0, 1.0)
             sm.update(R, t, 1.0, 1.0)                                            # the pose it was bucketed for: fine (collective: both ranks get here)
             eng.sync()
+            # a ROW shift moves the strip's logical rows under the kept points: the same pose is refused too (every rank shifts alike),
+            # by the frame and by the staged entry point, until the cloud is bucketed again
+            eng.map.shift_map_xy(np.array([5, 0]))
+            with pytest.raises(EmapError, match="rows shifted"):
+                sm.update(R, t, 1.0, 1.0)
+            with pytest.raises(EmapError, match="rows shifted"):
+                eng.map.stage("count", R, t)
+            eng.map.bind_points(p, strip_pose=(R, t))
+            sm.update(R, t, 1.0, 1.0)
+            eng.sync()
             eng.lib.emap_comm_destroy(eng.ctx)
         except Exception as e:  # pragma: no cover
             errs.append(e)
