@@ -32,7 +32,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r05"  # tag of the committed rocprofv3 summaries under profiles/ that this round's numbers refer to
+PROFILE_ROUND = "r06"  # tag of the committed rocprofv3 summaries under profiles/ that this round's numbers refer to
 
 
 def source_stamp():
@@ -54,16 +54,19 @@ def sem_in_frame(lib):
     return hasattr(lib, "emap_frame_semantics") and os.environ.get("EMAP_BENCH_SEM_SEPARATE", "0") != "1"
 
 
-def mm_frame(lib, ctx, Rp, tp, spec, stats=None):
-    """one multi-modal frame on the bound cloud: heights + RGB / semantic layers (returns the first non-zero status)"""
+def mm_frame(lib, ctx, Rp, tp, spec, stats=None, noise=1.0):
+    """one multi-modal frame on the bound cloud: heights + RGB / semantic layers (returns the first non-zero status).  noise: position /
+    orientation noise of the frame -- 1.0: above the YAML thresholds, the drift gate is OPEN (the per-tile drift statistics run); 0.0:
+    the host can rule the gate out (elevation_mapping.py:346-349) and the frame skips them"""
     if sem_in_frame(lib):
-        return lib.emap_frame_semantics(ctx, ct.byref(spec), 0) or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
-    return lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats) or lib.emap_semantic_update(ctx, Rp, tp, ct.byref(spec))
+        return lib.emap_frame_semantics(ctx, ct.byref(spec), 0) or lib.emap_update(ctx, Rp, tp, ct.c_double(noise), ct.c_double(noise), stats)
+    return lib.emap_update(ctx, Rp, tp, ct.c_double(noise), ct.c_double(noise), stats) or lib.emap_semantic_update(ctx, Rp, tp, ct.byref(spec))
 
 
-# VALU issue peak of the chip: 256 CUs x 4 SIMDs, a wave64 vector instruction occupies its SIMD for 4 cycles at 2.4 GHz
-# (MI355X_MICROARCH.md) -> 0.6 G wave-instructions / s / SIMD
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
+# VALU issue peak of the chip: 256 CUs x 4 SIMD-32 units, a wave64 vector instruction issues over 2 cycles at 2.4 GHz
+# (MI355X_MICROARCH.md, "Wave scheduling") -> 1.2 G wave-instructions / s / SIMD.  (tools/clockbench.hip measured ~1 per ns and SIMD
+# on dependent mixed code, DESIGN section 5b.)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 
 
 def sq_valu_insts(workload, kernel_prefix):
@@ -83,6 +86,8 @@ def sq_valu_insts(workload, kernel_prefix):
         if name.startswith(kernel_prefix) and " SQ_INSTS_VALU " in ln:
             tail = ln.split("SQ_INSTS_VALU", 1)[1].split()
             v, n = float(tail[0]), float(tail[1].split("=")[1])
+            if len(tail) > 2 and tail[2].startswith("med="):      # the median over the dispatches = the steady-state frames (the average includes warm-up / cold-start frames)
+                v = float(tail[2].split("=")[1])
             if v * n > best_w:
                 best, best_w = v, v * n
     return best, "profiles/%s" % os.path.basename(f)
@@ -138,6 +143,9 @@ def parse(argv=None):
     ap.add_argument("--force-sharded", action="store_true", help="run the row-strip path even with one rank (self-test)")
     ap.add_argument("--pre-shift", type=int, nargs=2, default=None, metavar=("ROWS", "COLS"),
                     help="experiment: shift the map by this many cells before the frames (circular origin off the tile grid)")
+    ap.add_argument("--gate", default="open", choices=["open", "shut"],
+                    help="drift gate of the timed frames: open = position / orientation noise 1.0, above the YAML thresholds (BASELINE's frame: "
+                         "the drift statistics run and the gate fires); shut = noise 0.0, the host rules the gate out and the frame skips the statistics")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous plumbing only, no GPU work (CPU test hook)")
     a = ap.parse_args(argv)
     a.cell_n = a.cell_n or {"cfg5": 8192, "cfg4": 4096}.get(a.workload, 1024)
@@ -393,7 +401,7 @@ def roofline(stage_ms, ev_overhead, N, L, workload, frame_bytes, dev_ms_per_step
         ginst = insts / (dom_ms * 1e-3) / 1e9 if insts else None
         return {"bound": "valu", "kernel": dom, "achieved": round(ginst, 1) if ginst else None, "peak": round(VALU_PEAK_GINST, 1),
                 "unit": "G wave-instructions/s", "frac": round(ginst / VALU_PEAK_GINST, 4) if ginst else None,
-                "frac_source": "SQ_INSTS_VALU per launch (%s) / live hipEvent spacing of the kernel (kernel_ms) / (1024 SIMDs x 0.6 G wave-instructions/s)" % isrc,
+                "frac_source": "SQ_INSTS_VALU per launch (median over the dispatches, %s) / live hipEvent spacing of the kernel (kernel_ms) / (1024 SIMDs x 1.2 G wave-instructions/s)" % isrc,
                 "valu_insts_per_launch": insts,
                 "hbm": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "frac_rocprof": frac_rocprof, "algorithmic_bytes": int(dom_bytes)},
@@ -494,7 +502,8 @@ def cpu_baseline(a, cfg, C, N, clouds_host, weights, R, t):
 def workload_text(a, C, N, multimodal):
     return "%s: %dx%d map, %d uniform-random points/frame, core_param.yaml values, %s" % (
         a.workload, C, C, N, "rays+overlap on" if a.workload in ("cfg3", "cfg4") else
-        ("height + RGB + 3 semantic layers, fp32 index mode" if multimodal else "add_points + variance fusion, rays/overlap off"))
+        ("height + RGB + 3 semantic layers, fp32 index mode" if multimodal else "add_points + variance fusion, rays/overlap off")) + (
+        "; drift gate SHUT (noise 0.0: the host rules the gate out)" if getattr(a, "gate", "open") == "shut" else "")
 
 
 # -------------------------------------------------------------------------------------------------------------------------------
@@ -533,6 +542,8 @@ def run_single(a, local_rank=0):
     t = np.array([0, 0, 1], np.float32)
     Rp, tp = _lib.f32p(R), _lib.f32p(t)
 
+    noise = 0.0 if a.gate == "shut" else 1.0
+
     def make_frame(lib, ctx, cl_dev=None, n_pts=None):
         cl_dev = cl_dev or clouds_dev
         n_pts = n_pts or N
@@ -540,9 +551,9 @@ def run_single(a, local_rank=0):
         def frame(i, stats=None):
             rc = bind_cloud(lib, ctx, cl_dev[i % len(cl_dev)], n_pts)
             if multimodal:
-                rc = rc or mm_frame(lib, ctx, Rp, tp, spec, stats)
+                rc = rc or mm_frame(lib, ctx, Rp, tp, spec, stats, noise)
             else:
-                rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
+                rc = rc or lib.emap_update(ctx, Rp, tp, ct.c_double(noise), ct.c_double(noise), stats)
             if rc:
                 raise RuntimeError(lib.emap_last_error(ctx).decode())
         return frame
@@ -705,10 +716,10 @@ def run_single(a, local_rank=0):
                 if lb.emap_semantic_configure(cb, 4):
                     raise RuntimeError(lb.emap_last_error(cb).decode())
 
-            def frb(i, stats=None, lb=lb, cb=cb, devb=devb, Nb=Nb, mm=mm, specb=specb):
+            def frb(i, stats=None, lb=lb, cb=cb, devb=devb, Nb=Nb, mm=mm, specb=specb, nz=1.0):
                 rc = bind_cloud(lb, cb, devb[i % len(devb)], Nb)
                 if mm:
-                    rc = rc or mm_frame(lb, cb, Rp, tp, specb, stats)
+                    rc = rc or mm_frame(lb, cb, Rp, tp, specb, stats, nz)
                 else:
                     rc = rc or lb.emap_update(cb, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
                 if rc:
@@ -730,6 +741,11 @@ def run_single(a, local_rank=0):
                         raise RuntimeError(lb.emap_last_error(cb).decode())
                     acc_s += e_ms.value
                 sem_stage_ms = acc_s / 6
+            gate_shut = None
+            if mm:       # the same frames with the drift gate ruled out by the host (noise 0.0): no per-tile drift statistics
+                import functools
+                wall0, _, loops0 = timed(emb, functools.partial(frb, nz=0.0), kb, loops=3)
+                gate_shut = {"ms_per_step": round(wall0 * 1e3 / kb, 5), "timed_loops_ms_per_step": loops0}
             Lb = Cb * Cb
             fbytes = 12 * Nb + 56 * Lb + (16 * Nb + 32 * Lb if mm else 0)
             rb = roofline(stb, ev_overhead, Nb, Lb, name, fbytes, msb / kb, visb, False)
@@ -737,7 +753,7 @@ def run_single(a, local_rank=0):
                            "value": round(Nb * kb / wallb / 1e6, 2), "unit": "Mpoints/s", "ms_per_step": round(wallb * 1e3 / kb, 5),
                            "timed_loops_ms_per_step": loopsb, "latency_ms": {"p10": round(latb[0], 4), "p50": round(latb[1], 4), "p90": round(latb[2], 4)},
                            "dominant_kernel": rb["kernel"], "kernel_ms": rb["kernel_ms"], "bound": rb["bound"], "frac": rb["frac"], "hbm": rb.get("hbm"), "frame_frac": rb["frame_frac"],
-                           "ray_visits_per_s": rb["ray_visits_per_s"], "stage_ms": (dict(rb["stage_ms"], semantic=round(sem_stage_ms, 5)) if mm else rb["stage_ms"]),
+                           "ray_visits_per_s": rb["ray_visits_per_s"], "stage_ms": (dict(rb["stage_ms"], semantic=round(sem_stage_ms, 5)) if mm else rb["stage_ms"]), "gate_shut": gate_shut,
                            "note": (("the RGB / semantic fusion is declared for the frame (emap_frame_semantics) and runs inside the 'fuse' stage's tile kernel on 32-byte sorted records; "
                                      if sem_in_frame(lb) else "stage_ms.semantic = the RGB / semantic fusion (k_tile_semantic: a call of its own behind the frame's ten stages, inside ms_per_step); ") +
                                     "cloud bound de-interleaved: (N, 3) xyz + (N, 4) channels, as emap_upload_points leaves an uploaded cloud") if mm else None}
@@ -1321,7 +1337,7 @@ def run_ref_main(a, local_rank=0):
         m.close()
     out = {"metric": "reference profiling loop (EM/elevation_mapping.py:925-967) through the drop-in package, iterations/s", "value": round(n_it / wall, 2),
            "unit": "iterations/s", "n_gpus": 1, "steps": n_it, "warmup": a.warmup, "ms_per_step": round(it_ms, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "source_stamp": source_stamp(),
            "config": {"workload": "ref_main: %dx%d map (Parameter defaults), 100000 x 7 host float64 cloud per iteration (rgb: color, grass / tree / people: class_bayesian), "
                                   "shipped plugin configuration (min_filter 1 x 30, smooth, inpaint telea, erosion), seven layers read back per iteration" % (elevation.cell_n, elevation.cell_n),
                       "host_ms_per_call": {k: _pct(v) for k, v in calls.items()},

@@ -25,7 +25,7 @@ def test_bench_json_contract(workload):
     assert d["value"] > 0 and d["unit"] == "Mpoints/s" and d["data"] == "synthetic" and "workload" in d["config"]
     r = d["roofline"]
     if workload == "cfg3":          # the visibility march is bound by vector-instruction issue: reported against that bound, the HBM figure beside it
-        assert r["bound"] == "valu" and r["kernel"] == "rays" and r["unit"] == "G wave-instructions/s" and abs(r["peak"] - 614.4) < 0.1 and "traffic" in r
+        assert r["bound"] == "valu" and r["kernel"] == "rays" and r["unit"] == "G wave-instructions/s" and abs(r["peak"] - 1228.8) < 0.1 and "traffic" in r
         assert r["frac"] is None or abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3      # (None: no SQ-counter pass of THESE kernel sources at this map size)
         h = r["hbm"]
         assert h["peak"] == 8000.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-3 and r["ray_samples_per_frame"] > 0

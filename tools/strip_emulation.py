@@ -123,10 +123,13 @@ def main():
             rc = bench.bind_cloud(lib, ctx, em._clouds[k], em._n_local[k])
             if em._bucketed:
                 rc = rc or lib.emap_declare_points_bucketed(ctx, Rp, tp, ct.c_int64(N))
+            in_frame = multimodal and bench.sem_in_frame(lib)
+            if in_frame and not rc:          # the RGB / semantic fusion rides inside the frame's tile pass (emap_frame_semantics)
+                em.semantic_map.declare_frame(em, channels)
             rc = rc or call(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), stats)
             if rc:
                 raise RuntimeError(lib.emap_last_error(ctx).decode())
-            if multimodal:
+            if multimodal and not in_frame:
                 em.semantic_map.update_layers_pointcloud(em, channels, R, t)
         return frame
 
