@@ -1037,6 +1037,7 @@ def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag
     shares = rdv.gather_json(tag + "share", round(max(n_local) / float(N), 4))
     wb = ct.c_uint64(0)
     wire_bytes = int(wb.value) if lib.emap_comm_wire_bytes(ctx, ct.byref(wb)) == 0 else None
+    wire_all = rdv.gather_json(tag + "wire", wire_bytes)       # sent + received per rank: the owners of the ray window's rows move the most
     rec = {"ok": True, "wall": wall, "stage_ms": stage_ms, "clouds_host": clouds_host, "cfg": cfg, "weights": weights, "R": R, "t": t}
     if rank == 0:
         L = C * C
@@ -1059,7 +1060,7 @@ def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag
                        "physical_devices": min(ndev, world),
                        "strip_rows": rows, "strip_heights": "equal ray work (thin around the sensor)" if row_w is not None else "equal",
                        "rays": ("by ray over an all-reduced window" if by_ray else "by row") if rays else "off",
-                       "by_ray_wire_bytes_per_frame": wire_bytes if by_ray else None,
+                       "by_ray_wire_bytes_per_frame": (max(x or 0 for x in wire_all) if by_ray else None), "by_ray_wire_bytes_per_rank": (wire_all if by_ray else None),
                        "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame, RCCL issued by the C library "
                                       "(halo exchange in place on a second stream); bootstrap: file rendezvous, no torch",
                        "cloud": "device resident (H2D excluded)"}})

@@ -33,6 +33,7 @@ void launch_rays(hipStream_t, const KP&, const Pose&, const RayTab&, const float
 void launch_win_pack(hipStream_t, const KP&, const Win&, Cells, const float*, long, const unsigned int*, const unsigned long long*, float);
 void launch_win_prepare(hipStream_t, const Win&, int);
 void launch_win_unpack(hipStream_t, const KP&, const Win&, AccR*);
+void launch_win_reduce(hipStream_t, long long*, unsigned int*, const long long*, const unsigned int*, int, long, long, long);
 void launch_ray_apply(hipStream_t, const KP&, Cells, AccR*, unsigned long long*, const OverlapArgs&, FrameDev*, unsigned int*, int);
 void launch_average(hipStream_t, const KP&, Cells, AccF*, AccR*, const FrameDev*, bool, bool, unsigned int*, const OverlapArgs&);
 static_assert(offsetof(SemSpec, sum_K) == sizeof(emap_sem_spec), "emap_sem_spec is the leading part of SemSpec");
@@ -215,6 +216,7 @@ struct emap_ctx {
   size_t wire_bytes;            // payload of the last by-ray frame's three all-reduces (bytes per rank)
   int ray_par;                  // parity of the k_ray_apply launches (FrameDev::quiet_sum)
   unsigned int* win_state; unsigned int* win_rec; unsigned long long* win_bits; float* win_thr; long long* win_dh; unsigned int* win_key; long win_cap;
+  long long* win_red_dh; unsigned int* win_red_key;      // by-ray effects reduced to the owners: (world - 1) parts of win_cap cells each
   hipStream_t comm_stream; hipEvent_t ev_ready, ev_done; double* comm_sums;   // [0..1] local err_sum / err_cnt, [2..3] totals, [4..36) emap_comm_allreduce_host
   // the un-shifted normal planes after a row shift (normal_exchange): a row-aligned copy of the rows this strip's cells belong to
   std::vector<int> cut_begin, cut_count;   // every rank's owned PHYSICAL rows (gathered by emap_comm_init)
@@ -494,7 +496,7 @@ int emap_destroy(emap_ctx* ctx) {
   hipFree(ctx->img_uv); hipFree(ctx->img_valid); hipFree(ctx->img_buf);
   hipFree(ctx->sem_alpha); hipFree(ctx->sem); hipFree(ctx->sem_sums); hipFree(ctx->sem_col); hipFree(ctx->cnt_plane);
   emap_comm_destroy(ctx);
-  hipFree(ctx->win_state); hipFree(ctx->win_rec); hipFree(ctx->win_bits); hipFree(ctx->win_thr); hipFree(ctx->win_dh); hipFree(ctx->win_key);
+  hipFree(ctx->win_state); hipFree(ctx->win_rec); hipFree(ctx->win_bits); hipFree(ctx->win_thr); hipFree(ctx->win_dh); hipFree(ctx->win_key); hipFree(ctx->win_red_dh); hipFree(ctx->win_red_key);
   for (int i = 0; i <= ST_N; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   if (ctx->t0) hipEventDestroy(ctx->t0);
   if (ctx->t1) hipEventDestroy(ctx->t1);
@@ -2328,14 +2330,18 @@ static long window_cap(const emap_ctx* ctx) {
 }
 static int alloc_window(emap_ctx* ctx, long cap) {
   CK(hipStreamSynchronize(ctx->stream));
-  hipFree(ctx->win_state); hipFree(ctx->win_rec); hipFree(ctx->win_bits); hipFree(ctx->win_thr); hipFree(ctx->win_dh); hipFree(ctx->win_key);
-  ctx->win_state = nullptr; ctx->win_rec = nullptr; ctx->win_bits = nullptr; ctx->win_thr = nullptr; ctx->win_dh = nullptr; ctx->win_key = nullptr; ctx->win_cap = 0;
+  hipFree(ctx->win_state); hipFree(ctx->win_rec); hipFree(ctx->win_bits); hipFree(ctx->win_thr); hipFree(ctx->win_dh); hipFree(ctx->win_key); hipFree(ctx->win_red_dh); hipFree(ctx->win_red_key);
+  ctx->win_state = nullptr; ctx->win_rec = nullptr; ctx->win_bits = nullptr; ctx->win_thr = nullptr; ctx->win_dh = nullptr; ctx->win_key = nullptr; ctx->win_red_dh = nullptr; ctx->win_red_key = nullptr; ctx->win_cap = 0;
   CK(hipMalloc((void**)&ctx->win_state, sizeof(unsigned int) * 12 * (size_t)cap));      // hot 4 + cold 4 + normals 3 + wall flag 1 words per cell (local expansion)
   CK(hipMalloc((void**)&ctx->win_rec, sizeof(unsigned int) * 8 * (size_t)cap));         // the 32-byte records that travel
   CK(hipMalloc((void**)&ctx->win_bits, sizeof(unsigned long long) * ((size_t)cap / 64 + 2)));
   CK(hipMalloc((void**)&ctx->win_thr, sizeof(float) * ((size_t)cap / 64 + 1)));
   CK(hipMalloc((void**)&ctx->win_dh, sizeof(long long) * 2 * (size_t)cap));
   CK(hipMalloc((void**)&ctx->win_key, sizeof(unsigned int) * (size_t)cap));
+  if (ctx->comm_world > 1) {       // what the other ranks send an owner: their {dec, hits} pairs and keys for its rows (at most the whole window, from every other rank)
+    CK(hipMalloc((void**)&ctx->win_red_dh, sizeof(long long) * 2 * (size_t)cap * (size_t)(ctx->comm_world - 1)));
+    CK(hipMalloc((void**)&ctx->win_red_key, sizeof(unsigned int) * (size_t)cap * (size_t)(ctx->comm_world - 1)));
+  }
   ctx->win_cap = cap;
   return EMAP_OK;
 }
@@ -2365,8 +2371,41 @@ static int rays_by_ray_pass(emap_ctx* ctx, const float R[9], const float t[3]) {
   launch_win_pack(st, kpk, w, ctx->cells, ctx->nlag_ready ? ctx->nlag_buf : ctx->normal, ctx->nlag_ready ? (long)ctx->strip.row_count * ctx->prm.cell_n : ctx->ncells_alloc,
                   ctx->inl_plane, ctx->inert, ctx->rt.f_wall);
   CK(hipGetLastError());
-  CKN(a->AllReduce(ctx->win_rec, ctx->win_rec, 8 * (size_t)n, ncclUint32, ncclSum, ctx->comm, st));
-  ctx->wire_bytes = 32 * (size_t)n + 16 * (size_t)n + 4 * (size_t)n;      // per rank and frame: the window records + the effects ({dec, hits} sums, key maxima) that come back
+  // Who owns which rows of the window: runs of consecutive window rows per owner, from the strips' physical rows (gathered by
+  // emap_comm_init) and the map's row origin -- the same list on every rank.  With it the window is replicated by BROADCASTS from its
+  // two or three owners and the effects return by REDUCTIONS to them (round 6): grouped sends / receives, every rank receives each window
+  // byte once and only the owners receive effects -- a ring all-reduce moves 2 (W - 1) / W of the whole window through every rank, twice.
+  // EMAP_BYRAY_ALLREDUCE=1 (or strips that do not tile the map): the three all-reduces of round 4 / 5.
+  struct Run { int q, a, rows; };
+  std::vector<Run> runs;
+  static const bool force_allreduce = getenv("EMAP_BYRAY_ALLREDUCE") && atoi(getenv("EMAP_BYRAY_ALLREDUCE")) != 0;
+  bool owners = ctx->comm_world > 1 && ctx->cuts_ok && !force_allreduce && ctx->win_red_dh;
+  if (owners) {
+    const int C = ctx->prm.cell_n;
+    for (int wr = 0; wr < w.nr && w.r0 + wr < C && owners; ++wr) {
+      const int prow = (w.r0 + wr + ctx->kp.org_r) % C;
+      int q = -1;
+      for (int r = 0; r < ctx->comm_world; ++r) if (prow >= ctx->cut_begin[r] && prow < ctx->cut_begin[r] + ctx->cut_count[r]) { q = r; break; }
+      if (q < 0) { owners = false; break; }
+      if (!runs.empty() && runs.back().q == q && runs.back().a + runs.back().rows == wr) runs.back().rows++;
+      else runs.push_back(Run{q, wr, 1});
+    }
+  }
+  const int me = ctx->comm_rank, W = ctx->comm_world;
+  size_t moved = 0;                                          // bytes this rank sends + receives in the frame's three exchange steps
+  if (owners) {
+    CKN(a->GroupStart());
+    for (const Run& r : runs) {
+      char* slab = reinterpret_cast<char*>(ctx->win_rec) + (size_t)r.a * w.nc * 32;
+      const size_t bytes = (size_t)r.rows * w.nc * 32;
+      if (r.q == me) { for (int p = 0; p < W; ++p) if (p != me) { CKN(a->Send(slab, bytes, ncclChar, p, ctx->comm, st)); moved += bytes; } }
+      else { CKN(a->Recv(slab, bytes, ncclChar, r.q, ctx->comm, st)); moved += bytes; }
+    }
+    CKN(a->GroupEnd());
+  } else {
+    CKN(a->AllReduce(ctx->win_rec, ctx->win_rec, 8 * (size_t)n, ncclUint32, ncclSum, ctx->comm, st));
+    moved = 32 * (size_t)n + 16 * (size_t)n + 4 * (size_t)n;      // per rank and frame: the window records + the effects ({dec, hits} sums, key maxima) that come back
+  }
   // (2) bitmap + block thresholds of the window, accumulators re-armed
   launch_win_prepare(st, w, ctx->prm.cell_n);
   CK(hipMemsetAsync(w.bits + n / 64, 0xff, sizeof(unsigned long long), st));          // the all-ones word behind the last row (k_rays' passive lanes)
@@ -2384,8 +2423,38 @@ static int rays_by_ray_pass(emap_ctx* ctx, const float R[9], const float t[3]) {
               w.bits, w.inl, 1, w.thr, reinterpret_cast<const unsigned int*>(ctx->bin_recs), ctx->bin_tile_start + ctx->bg.TB);
   CK(hipGetLastError());
   // (4) effects back to the owners: sums of {dec, hits}, maxima of the upper-bound keys
-  CKN(a->AllReduce(w.dh, w.dh, 2 * (size_t)n, ncclInt64, ncclSum, ctx->comm, st));
-  CKN(a->AllReduce(w.key, w.key, (size_t)n, ncclUint32, ncclMax, ctx->comm, st));
+  if (owners) {
+    // every rank sends its pairs and keys for a run to the run's owner; an owner receives W - 1 parts per run, packed run after run
+    // (part j = the j-th other rank), and folds them into its own slab
+    CKN(a->GroupStart());
+    long off = 0;
+    for (const Run& r : runs) {
+      const size_t cells = (size_t)r.rows * w.nc;
+      if (r.q == me) {
+        for (int p = 0, j = 0; p < W; ++p) if (p != me) {
+          CKN(a->Recv(reinterpret_cast<char*>(ctx->win_red_dh + 2 * ((size_t)j * ctx->win_cap + off)), cells * 16, ncclChar, p, ctx->comm, st));
+          CKN(a->Recv(reinterpret_cast<char*>(ctx->win_red_key + ((size_t)j * ctx->win_cap + off)), cells * 4, ncclChar, p, ctx->comm, st));
+          moved += cells * 20; ++j;
+        }
+        off += (long)cells;
+      } else {
+        CKN(a->Send(reinterpret_cast<char*>(w.dh + 2 * (size_t)r.a * w.nc), cells * 16, ncclChar, r.q, ctx->comm, st));
+        CKN(a->Send(reinterpret_cast<char*>(w.key + (size_t)r.a * w.nc), cells * 4, ncclChar, r.q, ctx->comm, st));
+        moved += cells * 20;
+      }
+    }
+    CKN(a->GroupEnd());
+    off = 0;
+    for (const Run& r : runs) if (r.q == me) {
+      const long cells = (long)r.rows * w.nc;
+      launch_win_reduce(st, w.dh + 2 * (size_t)r.a * w.nc, w.key + (size_t)r.a * w.nc, ctx->win_red_dh, ctx->win_red_key, W - 1, ctx->win_cap, off, cells);
+      off += cells;
+    }
+  } else {
+    CKN(a->AllReduce(w.dh, w.dh, 2 * (size_t)n, ncclInt64, ncclSum, ctx->comm, st));
+    CKN(a->AllReduce(w.key, w.key, (size_t)n, ncclUint32, ncclMax, ctx->comm, st));
+  }
+  ctx->wire_bytes = moved;
   launch_win_unpack(st, ctx->kp, w, ctx->accr);
   CK(hipGetLastError());
   return EMAP_OK;

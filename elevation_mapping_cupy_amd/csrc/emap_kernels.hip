@@ -993,6 +993,23 @@ __global__ __launch_bounds__(EM_BLOCK) void k_win_unpack(KP P, Win W, AccR* __re
   accr[(long)(rel + P.halo) * P.C + phys_col(P, lc)] = r;
 }
 
+// Effects of a by-ray frame reduced TO THE OWNERS (round 6): `parts` slabs of {dec, hits} pairs and keys, received from the other
+// ranks for `cells` consecutive window cells this rank owns, are folded into the rank's own slab -- integer sums and a maximum, the
+// order of the parts does not matter.  Part j's pairs start at dh_parts + j * part_stride pairs, its keys at key_parts + j * part_stride.
+__global__ __launch_bounds__(EM_BLOCK) void k_win_reduce(long long* __restrict__ dh, unsigned int* __restrict__ key, const long long* __restrict__ dh_parts,
+                                                         const unsigned int* __restrict__ key_parts, int parts, long part_stride, long off, long cells) {
+  const long k = (long)blockIdx.x * EM_BLOCK + threadIdx.x;
+  if (k >= cells) return;
+  long long d = dh[2 * k], h = dh[2 * k + 1];
+  unsigned int ky = key[k];
+  for (int j = 0; j < parts; ++j) {
+    const long q = (long)j * part_stride + off + k;
+    d += dh_parts[2 * q]; h += dh_parts[2 * q + 1];
+    ky = max(ky, key_parts[q]);
+  }
+  dh[2 * k] = d; dh[2 * k + 1] = h; key[k] = ky;
+}
+
 // clear_overlap_map (elevation_mapping.py:393-410): centred window, one launch instead of ~12
 __global__ __launch_bounds__(EM_BLOCK) void k_overlap(KP P, Cells cells, int cmin, int cmax, float hmin, float hmax) {
   int w = cmax - cmin;
@@ -1757,6 +1774,9 @@ void launch_win_pack(hipStream_t s, const KP& P, const Win& W, Cells cells, cons
 }
 void launch_win_prepare(hipStream_t s, const Win& W, int C) {
   hipLaunchKernelGGL(k_win_prepare, dim3(W.nc / 64, W.nr / 8), dim3(512), 0, s, W, C);
+}
+void launch_win_reduce(hipStream_t s, long long* dh, unsigned int* key, const long long* dh_parts, const unsigned int* key_parts, int parts, long part_stride, long off, long cells) {
+  if (cells > 0 && parts > 0) hipLaunchKernelGGL(k_win_reduce, dim3(nblk(cells)), dim3(EM_BLOCK), 0, s, dh, key, dh_parts, key_parts, parts, part_stride, off, cells);
 }
 void launch_win_unpack(hipStream_t s, const KP& P, const Win& W, AccR* accr) {
   hipLaunchKernelGGL(k_win_unpack, dim3(nblk((long)W.nr * W.nc)), dim3(EM_BLOCK), 0, s, P, W, accr);

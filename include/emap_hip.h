@@ -324,8 +324,12 @@ int emap_comm_selftest(emap_ctx* ctx);
 /* number of ranks RCCL itself reports for the communicator (ncclCommCount): what a launcher prints as evidence that the
  * strips really talk through one RCCL communicator of that size */
 int emap_comm_count(emap_ctx* ctx, int32_t* ranks);
-/* payload (bytes per rank) of the collectives the last frame's visibility pass issued when it marched BY RAY: the all-reduced window
- * records (32 B per window cell) and the effects coming back (20 B per cell); 0 for a frame that marched by row */
+/* bytes THIS rank sent + received in the exchange steps of the last frame's visibility pass when it marched BY RAY; 0 for a frame that
+ * marched by row.  Round 6: the window records (32 B per window cell) are broadcast by the owners of its rows and the effects (20 B
+ * per cell) are reduced to them -- grouped ncclSend / ncclRecv, an owner then folds the parts it received (k_win_reduce); an owner of
+ * a share f of the window moves (W - 1) f (32 + 20) + (1 - f) (32 + 20) bytes per cell, a rank that owns none of it 52.  With
+ * EMAP_BYRAY_ALLREDUCE=1, or strips that do not tile the map: the three all-reduces of rounds 4 / 5 (52 B per cell of payload on
+ * every rank, moved 2 (W - 1) / W times by a ring). */
 int emap_comm_wire_bytes(emap_ctx* ctx, uint64_t* bytes);
 /* out-of-band reductions over the ranks through the communicator itself (barriers and timing reductions of a launcher:
  * no second bootstrap channel needed once RCCL is up): all-reduce of n <= 16 host doubles, op 0 = sum, 1 = max, in place;

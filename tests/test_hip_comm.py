@@ -97,7 +97,7 @@ def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_f
     uid = (ct.c_uint8 * 128)()
     assert full._lib.emap_comm_unique_id(lib_path.encode(), uid) == 0
     dev = torch.device("cuda", 0)
-    out, errs = [None] * world, []
+    out, errs, wires = [None] * world, [], [0] * world
 
     def run(rank):
         try:
@@ -116,6 +116,9 @@ def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_f
                 if mv is not None:
                     sm.move_to(np.array(mv, np.float64), np.eye(3))
             eng.sync()
+            wb = ct.c_uint64(0)
+            assert eng.lib.emap_comm_wire_bytes(eng.ctx, ct.byref(wb)) == 0
+            wires[rank] = int(wb.value)
             gathered = (sm.gather("elevation"), sm.gather("normal_z")) if check_gather else None      # collective read-back of whole planes
             out[rank] = (eng.map.logical_row_begin, eng.map.rows, eng.map.elevation_map, eng.map.normal_map, eng.map.get_additive_mean_error(), gathered)
             eng.lib.emap_comm_destroy(eng.ctx)
@@ -127,6 +130,14 @@ def _strips_vs_single(world, cfg, C, frames, scatter, weights, mode="reference_f
     [x.join(timeout=120) for x in th]
     assert not any(x.is_alive() for x in th), "a rank is stuck in the exchange"
     assert not errs, errs
+    import os
+    if ray_mode == "by_ray" and world >= 3 and cfg["enable_visibility_cleanup"] and any(wires) and os.environ.get("EMAP_BYRAY_ALLREDUCE", "0") == "0":
+        # rays by ray: the window is BROADCAST by the owners of its rows and the effects are REDUCED to them (32 + 20 bytes per window cell of
+        # the map, each moved W - 1 times, counted once by the sender and once by the receiver) -- not three all-reduces, where every rank
+        # would report the same payload
+        assert sum(wires) % (2 * (world - 1) * 52) == 0, wires
+        if float(cfg["max_ray_length"]) < 5.0:      # a real sub-window: two or three ranks own its rows and move more than the others
+            assert len(set(wires)) > 1, wires
     for b, rows, m, nm, add, gathered in out:
         if gathered is not None and check_gather == "all":        # (after a move the gathered normal planes are compared only once a frame has rewritten them)
             assert np.array_equal(gathered[0], want[0]) and np.array_equal(gathered[1], want_n[2]), "gathered planes differ"
