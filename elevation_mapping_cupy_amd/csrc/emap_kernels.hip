@@ -448,12 +448,22 @@ __global__ __launch_bounds__(BLOCK, LMAP ? 4 : RAY_OCC) void k_rays(KP P, Pose T
       }
       if (key) { unsigned int* kp = accr_key(AR, cc); if (ray_key_load(kp) < key) atomicMax(kp, key); }     // (loading the key WITH the cell, ahead of the tests, measured no gain: 219 vs 221 us on the terrain)
     };
-    if (!__builtin_amdgcn_ballot_w64(c_hit != 0u) || __popcll(cm) < 4) {
-      // upper bounds only (the frames after clear(), a band a shift brought in) or next to nothing to combine: the visits of one step
-      // sit in the queue in lane order, so the rays that share a cell are mostly NEIGHBOURS -- a visit is dropped when the next
-      // lane's lowers the same cell at least as far (the lowest of a run always goes out), the rest goes out directly
-      const unsigned int cn = (unsigned int)__shfl_down((int)c, 1, 64), kn = (unsigned int)__shfl_down((int)c_key, 1, 64);
-      const bool covered = !c_hit && lane < 63 && cn == c && c_key <= kn;
+    // How the contributions of a batch go out.  With penetrations in it (or at least a handful of contributions) the wave combines
+    // the visits of a cell in LDS first (below).  Upper bounds only -- the frames after clear(), a band a shift brought in: the visits
+    // of one step sit in the queue in lane order, so the rays that share a cell are mostly NEIGHBOURS: a visit is dropped when the next
+    // lane's lowers the same cell at least as far (the lowest of a run always goes out), the rest goes out directly.  Round 6: when
+    // MANY neighbours share cells (a scan-ordered cloud: the rays of a wave travel together) the batch takes the LDS combination too --
+    // the first frame of the terrain scene after clear() 0.89 -> 0.33 ms (5.4x -> 2.0x its steady pass); a uniform-random cloud, whose
+    // rays share next to nothing, keeps the direct path (combining every batch cost it 5 % there).
+#ifndef RAY_COMBINE_DUPS
+#define RAY_COMBINE_DUPS 24   /* same box, 4 .. 32: first frame after clear() uniform 1.01 / 0.96 / 0.94 / 0.91 / 0.855 / 0.85 ms (never combining: 0.92), terrain 0.33-0.35 for all (never: 0.78-0.89); steady passes within 1-3 % */
+#endif
+    const unsigned int cn = (unsigned int)__shfl_down((int)c, 1, 64), kn = (unsigned int)__shfl_down((int)c_key, 1, 64);
+    const bool same_next = contrib && lane < 63 && cn == c;
+    const bool hits_in_batch = __builtin_amdgcn_ballot_w64(c_hit != 0u) != 0ull;
+    const bool combine = __popcll(cm) >= 4 && (hits_in_batch || __popcll(__builtin_amdgcn_ballot_w64(same_next)) >= RAY_COMBINE_DUPS);      // (wave-uniform)
+    if (!combine) {
+      const bool covered = !c_hit && same_next && c_key <= kn;
       if (contrib && !covered) flush(c, c_dec, c_hit, c_key);
       return;
     }
