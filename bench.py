@@ -966,7 +966,7 @@ def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag
     # Every rank is handed the same clouds; where the frame allows it (no visibility pass that marches by row) a rank keeps only the
     # points that can land in its rows -- the product's own predicate (emap_strip_point_mask = what emap_upload_points_strip /
     # ShardedElevationMap.input_pointcloud upload), applied once because the timed clouds are device resident.
-    bucket = world > 1 and (not rays or by_ray) and os.environ.get("EMAP_BENCH_BUCKET", "1") != "0"
+    bucket = (world > 1 or os.environ.get("EMAP_BENCH_BUCKET") == "force") and (not rays or by_ray) and os.environ.get("EMAP_BENCH_BUCKET", "1") != "0"      # ("force": the bucketed code path on one rank, test hook)
     n_local = [N] * NCLOUD
     if bucket:
         local = []
@@ -1022,6 +1022,32 @@ def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag
         emap.sync()
         t1 = time.perf_counter(); frame(i); emap.sync(); lat.append((time.perf_counter() - t1) * 1e3)
     pct = reduce([float(x) for x in np.percentile(lat, [10, 50, 90])], 1)
+    # ---- the same frames from a HOST cloud (what a sensor driver hands every rank): each rank's share bucketed, cast and uploaded by
+    # emap_upload_points_strip inside the frame -- the per-rank host pass and PCIe that the device-resident timed region above leaves
+    # out; asynchronous upload, so consecutive frames overlap it with the kernels.  Never part of `value`.
+    host_frame_ms = None
+    if bucket:
+        def host_frame(i):
+            p_ = clouds_host[i % NCLOUD]
+            kept = ct.c_int64(0)
+            rc = lib.emap_upload_points_strip(ctx, ct.c_void_p(p_.ctypes.data), ct.c_int64(p_.shape[0]), ct.c_int64(p_.shape[1]), 0, Rp, tp, ct.byref(kept))
+            if multimodal and sem_in_frame(lib) and not rc:
+                emap.semantic_map.declare_frame(emap, channels)
+            rc = rc or lib.emap_update_sharded(ctx, Rp, tp, ct.c_double(1.0), ct.c_double(1.0), None)
+            if rc:
+                raise RuntimeError(lib.emap_last_error(ctx).decode())
+            if multimodal and not sem_in_frame(lib):
+                emap.semantic_map.update_layers_pointcloud(emap, channels, R, t)
+        for i in range(2):
+            host_frame(i)
+        emap.sync(); barrier()
+        kh = max(3, min(steps, 6))
+        t1 = time.perf_counter()
+        for i in range(kh):
+            host_frame(i)
+        emap.sync()
+        host_frame_ms = round(reduce([(time.perf_counter() - t1) * 1e3 / kh], 1)[0], 4)
+        barrier()
     # ---- per-stage device time of every rank's strip ------------------------------------------------------------------------------
     reps = min(steps, 20)
     stage_ms, _ = stage_profile(lib, ctx, frame, reps, with_stats=False)
@@ -1060,7 +1086,7 @@ def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag
                        "physical_devices": min(ndev, world),
                        "strip_rows": rows, "strip_heights": "equal ray work (thin around the sensor)" if row_w is not None else "equal",
                        "rays": ("by ray over an all-reduced window" if by_ray else "by row") if rays else "off",
-                       "by_ray_wire_bytes_per_frame": (max(x or 0 for x in wire_all) if by_ray else None), "by_ray_wire_bytes_per_rank": (wire_all if by_ray else None),
+                       "host_cloud_frame_ms": host_frame_ms, "by_ray_wire_bytes_per_frame": (max(x or 0 for x in wire_all) if by_ray else None), "by_ray_wire_bytes_per_rank": (wire_all if by_ray else None),
                        "collectives": "all-reduce(2 x f64) + neighbour halo send/recv per frame, RCCL issued by the C library "
                                       "(halo exchange in place on a second stream); bootstrap: file rendezvous, no torch",
                        "cloud": "device resident (H2D excluded)"}})

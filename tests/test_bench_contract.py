@@ -60,7 +60,7 @@ def test_sharded_default_line_carries_cfg5_and_cfg4_next_to_their_n1_times():
     adds what north_star's scaling target names as sharded sub-measurements -- config.cfg5 (multi-modal map, semantic fusion inside
     the timed frame's tile pass; repeated at top level as `scaling_value`) and config.cfg4 (rays + overlap) -- each with the same-box N = 1 time beside it.
     Sub-measurement sizes shrunk through the test hook; the code path is the one `bench.py --gpus 8` runs."""
-    env = dict(os.environ, EMAP_BENCH_SUB_SIZES="cfg5:1024:300000,cfg4:1024:300000")
+    env = dict(os.environ, EMAP_BENCH_SUB_SIZES="cfg5:1024:300000,cfg4:1024:300000", EMAP_BENCH_BUCKET="force")      # (the bucketed-cloud code path of N > 1, on one rank)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -75,6 +75,7 @@ def test_sharded_default_line_carries_cfg5_and_cfg4_next_to_their_n1_times():
         assert len(c["per_rank_stage_ms"]) == 1 and c["dominant_kernel"] in c["stage_ms_rank0"]
     # the fusion of the extra channels is declared for the frame (emap_frame_semantics) and runs inside its tile pass: no stage of its own
     assert d["config"]["cfg5"]["per_rank_stage_ms"][0]["semantic"] == 0 and d["config"]["cfg5"]["per_rank_stage_ms"][0]["fuse"] > 0
+    assert d["config"]["host_cloud_frame_ms"] > 0 and d["config"]["cfg5"]["host_cloud_frame_ms"] > 0      # the same frames from a host cloud (bucketing + PCIe inclusive)
     sv = d["scaling_value"]                                                       # the strong-scaling figure, top level
     assert sv["speedup_vs_n1"] == d["config"]["cfg5"]["speedup_vs_n1"] and sv["rccl_ranks"] == 1 and sv["n_gpus"] == 1
     assert d["config"]["cfg4"]["rays"] in ("by row", "by ray over an all-reduced window")
