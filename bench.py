@@ -1038,16 +1038,26 @@ def strips_workload(a, wl, C, N, steps, warmup, rank, world, dev, ndev, rdv, tag
                 raise RuntimeError(lib.emap_last_error(ctx).decode())
             if multimodal and not sem_in_frame(lib):
                 emap.semantic_map.update_layers_pointcloud(emap, channels, R, t)
-        for i in range(2):
-            host_frame(i)
-        emap.sync(); barrier()
-        kh = max(3, min(steps, 6))
-        t1 = time.perf_counter()
-        for i in range(kh):
-            host_frame(i)
-        emap.sync()
-        host_frame_ms = round(reduce([(time.perf_counter() - t1) * 1e3 / kh], 1)[0], 4)
-        barrier()
+        # (the upload alone first, no collective in it: a rank that cannot stage the cloud -- pinned-memory limits -- must not leave the
+        # others waiting in the frame's all-reduce; every rank then agrees through the rendezvous before the frames are issued)
+        p0_ = clouds_host[0]
+        try:
+            ok_up = lib.emap_upload_points_strip(ctx, ct.c_void_p(p0_.ctypes.data), ct.c_int64(p0_.shape[0]), ct.c_int64(p0_.shape[1]), 0, Rp, tp, ct.byref(ct.c_int64(0))) == 0
+        except Exception:  # noqa: BLE001
+            ok_up = False
+        if rdv.agree(tag + "hostcloud", ok_up):
+            for i in range(2):
+                host_frame(i)
+            emap.sync(); barrier()
+            kh = max(3, min(steps, 6))
+            t1 = time.perf_counter()
+            for i in range(kh):
+                host_frame(i)
+            emap.sync()
+            host_frame_ms = round(reduce([(time.perf_counter() - t1) * 1e3 / kh], 1)[0], 4)
+            barrier()
+        elif rank == 0:
+            print("[bench] host-cloud frames skipped: a rank could not upload the cloud (%s)" % lib.emap_last_error(ctx).decode(), file=sys.stderr)
     # ---- per-stage device time of every rank's strip ------------------------------------------------------------------------------
     reps = min(steps, 20)
     stage_ms, _ = stage_profile(lib, ctx, frame, reps, with_stats=False)
